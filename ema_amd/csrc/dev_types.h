@@ -1,0 +1,56 @@
+// ema_amd/csrc/dev_types.h -- plain structs shared by the host side and the HIP kernels.
+//
+// HBM layout of the index (one replica per GPU):
+//   occ     : 64-byte blocks, one per 128 BWT symbols.  A block is four 16-byte
+//             slots {u64 count_c, u64 bases_c}: count_c = occurrences of symbol c
+//             before the block, bases_c = symbols 32c..32c+31 of the block, 2 bits
+//             each, symbol t of the slot at bits 2t..2t+1.  Four adjacent lanes
+//             read one block with a single 16-byte load each (global_load_dwordx4)
+//             and between them hold all four counters -- one coalesced 64-byte
+//             transaction per occ4 query.
+//   sa      : the whole suffix array (seq_len+1 rows, 4 or 8 bytes each): locating
+//             an occurrence is one load.
+//   pac     : forward strand, bwa's byte layout (4 bases/byte, first base in the
+//             high bits); the reverse strand is read complemented from the far end.
+//   contigs : offsets[n+1] (offsets[n] = l_pac).
+#ifndef EMA_DEV_TYPES_H
+#define EMA_DEV_TYPES_H
+
+#include <stdint.h>
+
+struct OccSlot { uint64_t cnt, bases; };   // 16 bytes
+
+struct DevIndex {
+	const OccSlot *occ;       // 4 slots per block
+	const void *sa;           // uint32_t* or uint64_t* by sa_width
+	const uint8_t *pac;
+	const int64_t *ctg_off;   // n_seqs + 1
+	uint64_t primary, seq_len;
+	uint64_t L2[5];
+	int64_t l_pac;
+	int32_t n_seqs, sa_width;
+};
+
+// bwa's mem_opt_t subset used by the kernels (mem_opt_init(); max_occ=3000 at reference src/align.c:185)
+struct DevOpts {
+	int a, b, o_del, e_del, o_ins, e_ins;
+	int pen_clip5, pen_clip3, w, zdrop;
+	int min_seed_len, split_len, split_width, max_mem_intv, max_occ, max_chain_gap;
+	int min_chain_weight, max_chain_extend;
+	float mask_level, drop_ratio, mask_level_redun;
+	int8_t mat[25];
+};
+
+// SMEM / seed interval: bwa's bwtintv_t.  info = start<<32 | end.
+struct Intv { uint64_t x0, x1, x2, info; };
+
+// per-read capacities of the seeding stage
+#define EMA_INTV_CAP 512      // intervals kept per read
+#define EMA_LIST_CAP 256      // entries of a forward/backward working list (<= read length)
+#define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
+
+// read status bits
+#define EMA_ST_INTV_OVERFLOW 1
+#define EMA_ST_LIST_OVERFLOW 2
+
+#endif

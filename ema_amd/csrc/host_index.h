@@ -1,0 +1,32 @@
+// ema_amd/csrc/host_index.h -- reads the on-disk index and lays it out for HBM.
+// Replaces bwa_idx_load() as called by the reference's load_reference()
+// (reference src/bwabridge.c:77-96).  Pure host C++, no HIP calls.
+#ifndef EMA_HOST_INDEX_H
+#define EMA_HOST_INDEX_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "dev_types.h"
+
+struct HostContig { std::string name; int64_t offset; int32_t len; int32_t is_alt; };
+
+struct HostIndex {
+	std::vector<OccSlot> occ;        // device layout (see dev_types.h)
+	std::vector<uint8_t> sa_bytes;   // seq_len+1 rows of sa_width bytes
+	std::vector<uint8_t> pac;
+	std::vector<int64_t> ctg_off;    // n+1
+	std::vector<HostContig> contigs;
+	uint64_t primary = 0, seq_len = 0, L2[5] = {0, 0, 0, 0, 0};
+	int64_t l_pac = 0;
+	int sa_width = 0;
+	// Fills a DevIndex whose pointers refer to THIS object's host buffers
+	// (used by the host-side SIMT harness in tests/; the engine overwrites the
+	// pointers with device addresses after upload).
+	DevIndex view() const;
+};
+
+// Loads <prefix>.bwt/.pac/.ann and <prefix>.fsa.  Returns "" on success, else an error message.
+std::string host_index_load(const std::string &prefix, HostIndex &out);
+
+#endif

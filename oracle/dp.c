@@ -1,0 +1,300 @@
+/*
+ * oracle/dp.c -- the three dynamic programs of the path (bwa's ksw.c):
+ *   orc_ksw_extend2  banded affine-gap seed extension   (via mem_chain2aln)
+ *   orc_ksw_global2  banded global alignment + traceback (via mem_reg2aln,
+ *                    reference src/bwabridge.c:304)
+ *   orc_ksw_align2   local alignment for mate rescue     (via mem_matesw,
+ *                    reference src/bwabridge.c:267,281)
+ * TEST INFRASTRUCTURE; PARITY UNPINNED (see oracle.h).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <assert.h>
+#include "oracle.h"
+
+typedef struct { int32_t h, e; } eh_t;
+
+int orc_ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                    int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
+                    int *_qle, int *_tle, int *_gtle, int *_gscore, int *_max_off)
+{
+	eh_t *eh;
+	int8_t *qp;
+	int i, j, k, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	int beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
+	assert(h0 > 0);
+	qp = malloc((size_t)qlen * m + 1);
+	eh = calloc(qlen + 1, sizeof(eh_t));
+	for (k = i = 0; k < m; ++k) {
+		const int8_t *p = &mat[k * m];
+		for (j = 0; j < qlen; ++j) qp[i++] = p[query[j]];
+	}
+	/* row -1: only insertions from h0 */
+	eh[0].h = h0; eh[1].h = h0 > oe_ins ? h0 - oe_ins : 0;
+	for (j = 2; j <= qlen && eh[j - 1].h > e_ins; ++j)
+		eh[j].h = eh[j - 1].h - e_ins;
+	/* clamp the band to what the scores can pay for */
+	k = m * m;
+	for (i = 0, max = 0; i < k; ++i) max = max > mat[i] ? max : mat[i];
+	max_ins = (int)((double)(qlen * max + end_bonus - o_ins) / e_ins + 1.);
+	max_ins = max_ins > 1 ? max_ins : 1;
+	w = w < max_ins ? w : max_ins;
+	max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
+	max_del = max_del > 1 ? max_del : 1;
+	w = w < max_del ? w : max_del;
+	max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1;
+	max_off = 0;
+	beg = 0; end = qlen;
+	for (i = 0; i < tlen; ++i) {
+		int t, f = 0, h1, mx = 0, mj = -1;
+		const int8_t *q = &qp[target[i] * qlen];
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		if (beg == 0) {
+			h1 = h0 - (o_del + e_del * (i + 1));
+			if (h1 < 0) h1 = 0;
+		} else h1 = 0;
+		for (j = beg; j < end; ++j) {
+			/* eh[j] = { H(i-1,j-1), E(i,j) }, f = F(i,j), h1 = H(i,j-1) */
+			eh_t *p = &eh[j];
+			int h, M = p->h, e = p->e;
+			p->h = h1;
+			M = M ? M + q[j] : 0;      /* gaps may only open from a match state */
+			h = M > e ? M : e;
+			h = h > f ? h : f;
+			h1 = h;
+			mj = mx > h ? mj : j;      /* last column attaining the row max */
+			mx = mx > h ? mx : h;
+			t = M - oe_del; t = t > 0 ? t : 0;
+			e -= e_del; e = e > t ? e : t;
+			p->e = e;
+			t = M - oe_ins; t = t > 0 ? t : 0;
+			f -= e_ins; f = f > t ? f : t;
+		}
+		orc_stats.cells_ext += (uint64_t)(end > beg ? end - beg : 0);
+		eh[end].h = h1; eh[end].e = 0;
+		if (j == qlen) {
+			max_ie = gscore > h1 ? max_ie : i;
+			gscore = gscore > h1 ? gscore : h1;
+		}
+		if (mx == 0) break;
+		if (mx > max) {
+			max = mx; max_i = i; max_j = mj;
+			max_off = max_off > abs(mj - i) ? max_off : abs(mj - i);
+		} else if (zdrop > 0) {
+			if (i - max_i > mj - max_j) {
+				if (max - mx - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+			} else {
+				if (max - mx - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+			}
+		}
+		for (j = beg; j < end && eh[j].h == 0 && eh[j].e == 0; ++j) {}
+		beg = j;
+		for (j = end; j >= beg && eh[j].h == 0 && eh[j].e == 0; --j) {}
+		end = j + 2 < qlen ? j + 2 : qlen;
+	}
+	free(eh); free(qp);
+	if (_qle) *_qle = max_j + 1;
+	if (_tle) *_tle = max_i + 1;
+	if (_gtle) *_gtle = max_ie + 1;
+	if (_gscore) *_gscore = gscore;
+	if (_max_off) *_max_off = max_off;
+	return max;
+}
+
+/* ------------------------------------------------------------------ */
+
+#define MINUS_INF (-0x40000000)
+
+static inline uint32_t *push_cigar(int *n_cigar, int *m_cigar, uint32_t *cigar, int op, int len)
+{
+	if (*n_cigar == 0 || op != (int)(cigar[(*n_cigar) - 1] & 0xf)) {
+		if (*n_cigar == *m_cigar) {
+			*m_cigar = *m_cigar ? (*m_cigar) << 1 : 4;
+			cigar = realloc(cigar, (size_t)(*m_cigar) << 2);
+		}
+		cigar[(*n_cigar)++] = len << 4 | op;
+	} else cigar[(*n_cigar) - 1] += len << 4;
+	return cigar;
+}
+
+int orc_ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                    int o_del, int e_del, int o_ins, int e_ins, int w, int *n_cigar_, uint32_t **cigar_)
+{
+	eh_t *eh;
+	int8_t *qp;
+	int i, j, k, oe_del = o_del + e_del, oe_ins = o_ins + e_ins, score, n_col;
+	uint8_t *z;   /* per cell: f-ext<<4 | e-ext<<2 | h direction */
+	int want_tb = n_cigar_ && cigar_;
+	if (n_cigar_) *n_cigar_ = 0;
+	n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	z = want_tb ? malloc((size_t)n_col * tlen + 1) : 0;
+	qp = malloc((size_t)qlen * m + 1);
+	eh = calloc(qlen + 1, sizeof(eh_t));
+	for (k = i = 0; k < m; ++k) {
+		const int8_t *p = &mat[k * m];
+		for (j = 0; j < qlen; ++j) qp[i++] = p[query[j]];
+	}
+	eh[0].h = 0; eh[0].e = MINUS_INF;
+	for (j = 1; j <= qlen && j <= w; ++j)
+		eh[j].h = -(o_ins + e_ins * j), eh[j].e = MINUS_INF;
+	for (; j <= qlen; ++j) eh[j].h = eh[j].e = MINUS_INF;
+	for (i = 0; i < tlen; ++i) {
+		int32_t f = MINUS_INF, h1, beg, end, t;
+		const int8_t *q = &qp[target[i] * qlen];
+		uint8_t *zi = want_tb ? &z[(size_t)i * n_col] : 0;
+		beg = i > w ? i - w : 0;
+		end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
+		for (j = beg; j < end; ++j) {
+			eh_t *p = &eh[j];
+			int32_t h, mm = p->h, e = p->e;
+			uint8_t d;
+			p->h = h1;
+			mm += q[j];
+			d = mm >= e ? 0 : 1;
+			h = mm >= e ? mm : e;
+			d = h >= f ? d : 2;
+			h = h >= f ? h : f;
+			h1 = h;
+			t = mm - oe_del;
+			e -= e_del;
+			d |= e > t ? 1 << 2 : 0;
+			e = e > t ? e : t;
+			p->e = e;
+			t = mm - oe_ins;
+			f -= e_ins;
+			d |= f > t ? 2 << 4 : 0;
+			f = f > t ? f : t;
+			if (zi) zi[j - beg] = d;
+		}
+		orc_stats.cells_global += (uint64_t)(end > beg ? end - beg : 0);
+		eh[end].h = h1; eh[end].e = MINUS_INF;
+	}
+	score = eh[qlen].h;
+	if (want_tb) {
+		int n_cigar = 0, m_cigar = 0, which = 0;
+		uint32_t *cigar = 0, tmp;
+		i = tlen - 1; k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+		while (i >= 0 && k >= 0) {
+			which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+			if (which == 0) cigar = push_cigar(&n_cigar, &m_cigar, cigar, 0, 1), --i, --k;
+			else if (which == 1) cigar = push_cigar(&n_cigar, &m_cigar, cigar, 2, 1), --i;
+			else cigar = push_cigar(&n_cigar, &m_cigar, cigar, 1, 1), --k;
+		}
+		if (i >= 0) cigar = push_cigar(&n_cigar, &m_cigar, cigar, 2, i + 1);
+		if (k >= 0) cigar = push_cigar(&n_cigar, &m_cigar, cigar, 1, k + 1);
+		for (i = 0; i < n_cigar >> 1; ++i)
+			tmp = cigar[i], cigar[i] = cigar[n_cigar - 1 - i], cigar[n_cigar - 1 - i] = tmp;
+		*n_cigar_ = n_cigar; *cigar_ = cigar;
+	}
+	free(eh); free(qp); free(z);
+	return score;
+}
+
+/* ------------------------------------------------------------------ */
+/*
+ * Local alignment (ksw_align2 -> ksw_u8 / ksw_i16).  Upstream is a striped
+ * SSE2 kernel; its H matrix equals the plain Gotoh recurrence with a zero
+ * floor (gaps open from H; the lazy-F loop completes F across stripes, and
+ * E never needs the F-corrected H because an insertion-then-deletion path
+ * always has an equal-scoring deletion-then-insertion twin).  Two details of
+ * the vector layout are visible in the results and are kept:
+ *   - the query is padded to a multiple of p = 16 (8-bit) or 8 (16-bit)
+ *     columns scoring 0 against everything; padded cells take part in the
+ *     per-row maximum that feeds the sub-optimal-score bookkeeping;
+ *   - qe = smallest query index among the cells of row te holding the max.
+ * Saturation cannot occur: the 8-bit kernel is chosen only when
+ * qlen * a < 250 and it stops at score + shift >= 255.
+ */
+static orc_kswr_t sw_core(int size, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m,
+                          const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra)
+{
+	orc_kswr_t r = {0, -1, -1, -1, -1, -1, -1};
+	int p = 8 * (3 - size), slen = (qlen + p - 1) / p, qpad = slen * p;
+	int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	int minsc = (xtra & ORC_KSW_XSUBO) ? xtra & 0xffff : 0x10000;
+	int endsc = (xtra & ORC_KSW_XSTOP) ? xtra & 0xffff : 0x10000;
+	int i, j, k, gmax = 0, te = -1, shift = 0, mdiff = 0, maxsc = 0;
+	int *H0 = calloc(qpad + 1, sizeof(int)), *H1 = calloc(qpad + 1, sizeof(int));
+	int *E = calloc(qpad + 1, sizeof(int)), *Hmax = calloc(qpad + 1, sizeof(int));
+	uint64_t *b = 0; int n_b = 0, m_b = 0;
+
+	for (i = 0, k = m * m; i < k; ++i) {
+		if (mat[i] < shift) shift = mat[i];
+		if (mat[i] > mdiff) mdiff = mat[i];
+	}
+	maxsc = mdiff; shift = -shift; (void)shift;
+	for (i = 0; i < tlen; ++i) {
+		int f = 0, imax = 0, *tmp;
+		const int8_t *row = &mat[target[i] * m];
+		for (j = 0; j < qpad; ++j) {
+			int s = j < qlen ? row[query[j]] : 0;
+			int h = (j ? H0[j - 1] : 0) + s, e = E[j], t;
+			if (h < 0) h = 0;
+			h = h > e ? h : e;
+			h = h > f ? h : f;
+			H1[j] = h;
+			imax = imax > h ? imax : h;
+			e -= e_del; if (e < 0) e = 0;
+			t = h - oe_del; if (t < 0) t = 0;
+			E[j] = e > t ? e : t;
+			f -= e_ins; if (f < 0) f = 0;
+			t = h - oe_ins; if (t < 0) t = 0;
+			f = f > t ? f : t;
+		}
+		orc_stats.cells_local += (uint64_t)qpad;
+		if (imax >= minsc) {
+			if (n_b == 0 || (int32_t)b[n_b - 1] + 1 != i) {
+				if (n_b == m_b) { m_b = m_b ? m_b << 1 : 8; b = realloc(b, 8 * (size_t)m_b); }
+				b[n_b++] = (uint64_t)imax << 32 | (uint32_t)i;
+			} else if ((int)(b[n_b - 1] >> 32) < imax) b[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i;
+		}
+		if (imax > gmax) {
+			gmax = imax; te = i;
+			memcpy(Hmax, H1, qpad * sizeof(int));
+			if ((size == 1 && gmax + shift >= 255) || gmax >= endsc) break;
+		}
+		tmp = H0; H0 = H1; H1 = tmp;
+	}
+	r.score = (size == 1 && gmax + shift >= 255) ? 255 : gmax;
+	r.te = te;
+	if (!(size == 1 && r.score == 255)) {
+		int mx = -1, low, high;
+		for (j = 0; j < qpad; ++j)
+			if (Hmax[j] > mx) mx = Hmax[j], r.qe = j;   /* ascending scan: smallest index wins ties */
+		if (b) {
+			i = (r.score + maxsc - 1) / maxsc;
+			low = te - i; high = te + i;
+			for (i = 0; i < n_b; ++i) {
+				int e = (int32_t)b[i];
+				if ((e < low || e > high) && (int)(b[i] >> 32) > r.score2)
+					r.score2 = (int)(b[i] >> 32), r.te2 = e;
+			}
+		}
+	}
+	free(b); free(H0); free(H1); free(E); free(Hmax);
+	return r;
+}
+
+static void revseq(int l, uint8_t *s)
+{
+	int i;
+	for (i = 0; i < l >> 1; ++i) { uint8_t t = s[i]; s[i] = s[l - 1 - i]; s[l - 1 - i] = t; }
+}
+
+orc_kswr_t orc_ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
+                          int o_del, int e_del, int o_ins, int e_ins, int xtra)
+{
+	int size = (xtra & ORC_KSW_XBYTE) ? 1 : 2;
+	orc_kswr_t r, rr;
+	r = sw_core(size, qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, xtra);
+	if ((xtra & ORC_KSW_XSTART) == 0 || ((xtra & ORC_KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
+	revseq(r.qe + 1, query); revseq(r.te + 1, target);
+	rr = sw_core(size, r.qe + 1, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, ORC_KSW_XSTOP | r.score);
+	revseq(r.qe + 1, query); revseq(r.te + 1, target);
+	if (r.score == rr.score)
+		r.tb = r.te - rr.te, r.qb = r.qe - rr.qe;
+	return r;
+}

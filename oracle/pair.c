@@ -1,0 +1,331 @@
+/*
+ * oracle/pair.c -- mate rescue, final alignment and the reference's bridge.
+ * TEST INFRASTRUCTURE; PARITY UNPINNED (see oracle.h).
+ *
+ *   orc_matesw      bwa mem_matesw / mem_infer_dir   <- reference src/bwabridge.c:267,281
+ *   orc_gen_cigar2  bwa bwa_gen_cigar2
+ *   orc_reg2aln     bwa mem_reg2aln / infer_bw       <- reference src/bwabridge.c:304
+ *   orc_mate_sw     reference src/bwabridge.c:204-299 (bwa_mem_mate_sw), restated
+ *   orc_align_pair  candidate part of reference src/align.c:986-1061
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <assert.h>
+#include "oracle.h"
+
+static inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)
+{
+	int64_t p2;
+	int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
+	p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+int orc_matesw(const orc_opt_t *opt, const orc_idx_t *idx, const orc_pestat_t pes[4], const orc_reg_t *a,
+               int l_ms, const uint8_t *ms, orc_reg_v *ma)
+{
+	int64_t l_pac = idx->l_pac;
+	int i, r, skip[4], n = 0, rid = -1;
+	for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+	for (i = 0; (size_t)i < ma->n; ++i) {
+		int64_t dist;
+		r = infer_dir(l_pac, a->rb, ma->a[i].rb, &dist);
+		if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+	}
+	if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
+	for (r = 0; r < 4; ++r) {
+		int is_rev, is_larger;
+		uint8_t *seq, *rev = 0, *ref = 0;
+		int64_t rb, re;
+		if (skip[r]) continue;
+		is_rev = (r >> 1 != (r & 1));
+		is_larger = !(r >> 1);
+		if (is_rev) {
+			rev = malloc(l_ms);
+			for (i = 0; i < l_ms; ++i) rev[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
+			seq = rev;
+		} else {
+			rev = malloc(l_ms);
+			memcpy(rev, ms, l_ms);
+			seq = rev;
+		}
+		if (!is_rev) {
+			rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
+			re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
+		} else {
+			rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
+			re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
+		}
+		if (rb < 0) rb = 0;
+		if (re > l_pac << 1) re = l_pac << 1;
+		if (rb < re) ref = orc_fetch_seq(idx, &rb, (rb + re) >> 1, &re, &rid);
+		if (a->rid == rid && re - rb >= opt->min_seed_len) {
+			orc_kswr_t aln;
+			orc_reg_t b;
+			int tmp, xtra = ORC_KSW_XSUBO | ORC_KSW_XSTART | (l_ms * opt->a < 250 ? ORC_KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
+			aln = orc_ksw_align2(l_ms, seq, (int)(re - rb), ref, 5, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, xtra);
+			memset(&b, 0, sizeof(b));
+			if (aln.score >= opt->min_seed_len && aln.qb >= 0) {
+				b.rid = a->rid;
+				b.is_alt = a->is_alt;
+				b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+				b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+				b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+				b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+				b.score = aln.score;
+				b.csub = aln.score2;
+				b.secondary = -1;
+				b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+				if (ma->n == ma->m) { ma->m = ma->m ? ma->m << 1 : 8; ma->a = realloc(ma->a, ma->m * sizeof(orc_reg_t)); }
+				++ma->n;
+				for (i = 0; (size_t)i < ma->n - 1; ++i)
+					if (ma->a[i].score < b.score) break;
+				tmp = i;
+				for (i = (int)ma->n - 1; i > tmp; --i) ma->a[i] = ma->a[i - 1];
+				ma->a[i] = b;
+			}
+			++n;
+		}
+		if (n) ma->n = orc_sort_dedup_patch(opt, 0, 0, (int)ma->n, ma->a);
+		free(rev);
+		free(ref);
+	}
+	return n;
+}
+
+/* ------------------------------------------------------------------ */
+
+uint32_t *orc_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac,
+                         const uint8_t *pac, int l_query, uint8_t *query, int64_t rb, int64_t re,
+                         int *score, int *n_cigar, int *NM)
+{
+	uint32_t *cigar = 0;
+	uint8_t tmp, *rseq;
+	int i;
+	int64_t rlen;
+
+	if (n_cigar) *n_cigar = 0;
+	if (NM) *NM = -1;
+	if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return 0;
+	rseq = orc_get_seq(l_pac, pac, rb, re, &rlen);
+	if (re - rb != rlen) goto done;
+	if (rb >= l_pac) {   /* reverse both so that indels are left-aligned on the forward strand */
+		for (i = 0; i < l_query >> 1; ++i)
+			tmp = query[i], query[i] = query[l_query - 1 - i], query[l_query - 1 - i] = tmp;
+		for (i = 0; i < rlen >> 1; ++i)
+			tmp = rseq[i], rseq[i] = rseq[rlen - 1 - i], rseq[rlen - 1 - i] = tmp;
+	}
+	if (l_query == re - rb && w_ == 0) {   /* gap-free */
+		if (n_cigar) {
+			cigar = malloc(4);
+			cigar[0] = (uint32_t)l_query << 4 | 0;
+			*n_cigar = 1;
+		}
+		for (i = 0, *score = 0; i < l_query; ++i)
+			*score += mat[rseq[i] * 5 + query[i]];
+	} else {
+		int w, max_gap, max_ins, max_del, min_w;
+		max_ins = (int)((double)(((l_query + 1) >> 1) * mat[0] - o_ins) / e_ins + 1.);
+		max_del = (int)((double)(((l_query + 1) >> 1) * mat[0] - o_del) / e_del + 1.);
+		max_gap = max_ins > max_del ? max_ins : max_del;
+		max_gap = max_gap > 1 ? max_gap : 1;
+		w = (max_gap + abs((int)rlen - l_query) + 1) >> 1;
+		w = w < w_ ? w : w_;
+		min_w = abs((int)rlen - l_query) + 3;
+		w = w > min_w ? w : min_w;
+		*score = orc_ksw_global2(l_query, query, (int)rlen, rseq, 5, mat, o_del, e_del, o_ins, e_ins, w, n_cigar, &cigar);
+	}
+	if (NM && n_cigar) {
+		int k, x, y, n_mm = 0, n_gap = 0;
+		for (k = 0, x = y = 0; k < *n_cigar; ++k) {
+			int op = cigar[k] & 0xf, len = cigar[k] >> 4;
+			if (op == 0) {
+				for (i = 0; i < len; ++i)
+					if (query[x + i] != rseq[y + i]) ++n_mm;
+				x += len; y += len;
+			} else if (op == 2) {
+				if (k > 0 && k < *n_cigar - 1) n_gap += len;   /* a terminal D is not counted */
+				y += len;
+			} else if (op == 1) x += len, n_gap += len;
+		}
+		*NM = n_mm + n_gap;
+	}
+	if (rb >= l_pac)
+		for (i = 0; i < l_query >> 1; ++i)
+			tmp = query[i], query[i] = query[l_query - 1 - i], query[l_query - 1 - i] = tmp;
+done:
+	free(rseq);
+	return cigar;
+}
+
+static inline int infer_bw(int l1, int l2, int score, int a, int q, int r)
+{
+	int w;
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+	if (w < abs(l1 - l2)) w = abs(l1 - l2);
+	return w;
+}
+
+orc_aln_t orc_reg2aln(const orc_opt_t *opt, const orc_idx_t *idx, int l_query, const uint8_t *query_, const orc_reg_t *ar)
+{
+	orc_aln_t a;
+	int i, w2, tmp, qb, qe, NM = -1, score = 0, is_rev, last_sc = -(1 << 30);
+	int64_t pos, rb, re;
+	uint8_t *query;
+
+	memset(&a, 0, sizeof(a));
+	if (ar == 0 || ar->rb < 0 || ar->re < 0) {
+		a.rid = -1; a.pos = -1; a.flag |= 0x4;
+		return a;
+	}
+	qb = ar->qb; qe = ar->qe;
+	rb = ar->rb; re = ar->re;
+	query = malloc(l_query);
+	for (i = 0; i < l_query; ++i) query[i] = query_[i] < 5 ? query_[i] : orc_nt4_table[(int)query_[i]];
+	a.mapq = 0;   /* upstream: mem_approx_mapq_se; the reference overwrites it (src/align.c:1027,1052) */
+	if (ar->secondary >= 0) a.flag |= 0x100;
+	tmp = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_del, opt->e_del);
+	w2 = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_ins, opt->e_ins);
+	w2 = w2 > tmp ? w2 : tmp;
+	if (w2 > opt->w) w2 = w2 < ar->w ? w2 : ar->w;
+	i = 0; a.cigar = 0;
+	do {
+		free(a.cigar);
+		w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
+		a.cigar = orc_gen_cigar2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, idx->l_pac, idx->pac,
+		                         qe - qb, &query[qb], rb, re, &score, &a.n_cigar, &NM);
+		if (score == last_sc || w2 == opt->w << 2) break;
+		last_sc = score;
+		w2 <<= 1;
+	} while (++i < 3 && score < ar->truesc - opt->a);
+	a.NM = NM;
+	is_rev = (rb < idx->l_pac ? rb : re - 1) >= idx->l_pac;
+	pos = is_rev ? (idx->l_pac << 1) - 1 - (re - 1) : rb;
+	a.is_rev = is_rev;
+	if (a.n_cigar > 0) {   /* squeeze out a leading or trailing deletion */
+		if ((a.cigar[0] & 0xf) == 2) {
+			pos += a.cigar[0] >> 4;
+			--a.n_cigar;
+			memmove(a.cigar, a.cigar + 1, a.n_cigar * 4);
+		} else if ((a.cigar[a.n_cigar - 1] & 0xf) == 2) {
+			--a.n_cigar;
+		}
+	}
+	if (qb != 0 || qe != l_query) {
+		int clip5, clip3;
+		clip5 = is_rev ? l_query - qe : qb;
+		clip3 = is_rev ? qb : l_query - qe;
+		a.cigar = realloc(a.cigar, 4 * (a.n_cigar + 2));
+		if (clip5) {
+			memmove(a.cigar + 1, a.cigar, a.n_cigar * 4);
+			a.cigar[0] = (uint32_t)clip5 << 4 | 3;
+			++a.n_cigar;
+		}
+		if (clip3) a.cigar[a.n_cigar++] = (uint32_t)clip3 << 4 | 3;
+	}
+	a.rid = orc_pos2rid(idx, pos);
+	assert(a.rid == ar->rid);
+	a.pos = pos - idx->anns[a.rid].offset;
+	a.score = ar->score; a.sub = ar->sub > ar->csub ? ar->sub : ar->csub;
+	a.is_alt = ar->is_alt; a.alt_sc = ar->alt_sc;
+	free(query);
+	return a;
+}
+
+/* ------------------------------------------------------------------ */
+/* reference src/bwabridge.c:204-299 */
+
+void orc_mate_sw(const orc_opt_t *opt, const orc_idx_t *idx, const char *read1, int len1, const char *read2, int len2,
+                 int score_delta, orc_reg_v *r1, orc_reg_v *r2)
+{
+	orc_pestat_t pes[4];
+	uint8_t *s1 = malloc(len1 > 0 ? len1 : 1), *s2 = malloc(len2 > 0 ? len2 : 1);
+	int i, num, best1 = 0, best2 = 0;
+	size_t k;
+
+	/* src/bwabridge.c:216-227: only FR, insert in [-35, 500] */
+	for (i = 0; i < 4; ++i) { pes[i].low = -35; pes[i].high = 500; pes[i].avg = 200.0; pes[i].std = 100.0; pes[i].failed = 1; }
+	pes[1].failed = 0;
+	for (i = 0; i < len1; ++i) s1[i] = orc_nt4_table[(unsigned char)read1[i]];   /* seq_convert, :151-157 */
+	for (i = 0; i < len2; ++i) s2[i] = orc_nt4_table[(unsigned char)read2[i]];
+
+	*r1 = orc_align1_core(opt, idx, len1, s1);   /* :236 */
+	*r2 = orc_align1_core(opt, idx, len2, s2);   /* :237 */
+	for (k = 0; k < r1->n; ++k) if (r1->a[k].score > best1) best1 = r1->a[k].score;   /* :245-252 */
+	for (k = 0; k < r2->n; ++k) if (r2->a[k].score > best2) best2 = r2->a[k].score;   /* :254-261 */
+
+	/* :263-269: rescue mate 1 around good hits of mate 2.  The loop bound is
+	 * the pre-rescue count of mate 2; the scores compared are pre-rescue too. */
+	{
+		size_t n2 = r2->n;
+		int *sc2 = malloc(sizeof(int) * (n2 + 1));
+		orc_reg_t *hit2 = malloc(sizeof(orc_reg_t) * (n2 + 1));
+		for (k = 0; k < n2; ++k) sc2[k] = r2->a[k].score, hit2[k] = r2->a[k];
+		for (k = 0, num = 0; k < n2 && num < 50; ++k)
+			if (sc2[k] >= best2 - score_delta) {
+				++num;
+				orc_matesw(opt, idx, pes, &hit2[k], len1, s1, r1);
+			}
+		free(sc2); free(hit2);
+	}
+	/* :271-283: rescue mate 2 around hits of the UPDATED mate-1 list, threshold from the pre-rescue best1 */
+	{
+		size_t n1 = r1->n;
+		orc_reg_t *hit1 = malloc(sizeof(orc_reg_t) * (n1 + 1));
+		for (k = 0; k < n1; ++k) hit1[k] = r1->a[k];
+		for (k = 0, num = 0; k < n1 && num < 50; ++k)
+			if (hit1[k].score >= best1 - score_delta) {
+				++num;
+				orc_matesw(opt, idx, pes, &hit1[k], len2, s2, r2);
+			}
+		free(hit1);
+	}
+	free(s1); free(s2);
+}
+
+void orc_align_pair(const orc_opt_t *opt, const orc_idx_t *idx, const char *read1, int len1,
+                    const char *read2, int len2, orc_pair_out_t *out)
+{
+	orc_reg_v r[2];
+	const char *rd[2] = { read1, read2 };
+	int ln[2] = { len1, len2 };
+	size_t k, n = 0, pool_m = 0;
+	int m;
+
+	orc_mate_sw(opt, idx, read1, len1, read2, len2, 25, &r[0], &r[1]);   /* src/align.c:1005 */
+	out->n1 = r[0].n; out->n2 = r[1].n;
+	out->c = calloc(out->n1 + out->n2 + 1, sizeof(orc_cand_t));
+	out->pool = 0; out->n_pool = 0;
+	for (m = 0; m < 2; ++m) {
+		uint8_t *s = malloc(ln[m] > 0 ? ln[m] : 1);
+		int i;
+		for (i = 0; i < ln[m]; ++i) s[i] = orc_nt4_table[(unsigned char)rd[m][i]];
+		for (k = 0; k < r[m].n; ++k, ++n) {   /* src/align.c:1010-1013 / 1035-1038 */
+			orc_cand_t *c = &out->c[n];
+			orc_aln_t a = orc_reg2aln(opt, idx, ln[m], s, &r[m].a[k]);
+			c->reg = r[m].a[k];
+			c->pos = a.pos; c->is_rev = a.is_rev; c->NM = a.NM; c->n_cigar = a.n_cigar;
+			c->aln_score = a.score; c->aln_sub = a.sub;
+			c->cigar_off = (uint32_t)out->n_pool;
+			if (out->n_pool + a.n_cigar > pool_m) {
+				pool_m = (out->n_pool + a.n_cigar) * 2 + 16;
+				out->pool = realloc(out->pool, pool_m * 4);
+			}
+			if (a.n_cigar) memcpy(out->pool + out->n_pool, a.cigar, a.n_cigar * 4);
+			out->n_pool += a.n_cigar;
+			orc_stats.n_cigar += a.n_cigar;
+			free(a.cigar);
+		}
+		orc_stats.n_regs += r[m].n;
+		free(s);
+		free(r[m].a);
+	}
+}
+
+void orc_pair_out_free(orc_pair_out_t *out)
+{
+	free(out->c); free(out->pool);
+	out->c = 0; out->pool = 0;
+}

@@ -1,0 +1,151 @@
+"""ctypes binding of oracle/libemaoracle.so -- test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Opt(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_unpaired", "pen_clip5",
+                                       "pen_clip3", "w", "zdrop")] + [("max_mem_intv", C.c_uint64)] + \
+               [(n, C.c_int) for n in ("T", "flag", "min_seed_len", "min_chain_weight", "max_chain_extend")] + \
+               [("split_factor", C.c_float)] + \
+               [(n, C.c_int) for n in ("split_width", "max_occ", "max_chain_gap", "n_threads", "chunk_size")] + \
+               [(n, C.c_float) for n in ("mask_level", "drop_ratio", "XA_drop_ratio", "mask_level_redun",
+                                         "mapQ_coef_len")] + \
+               [(n, C.c_int) for n in ("mapQ_coef_fac", "max_ins", "max_matesw", "max_XA_hits", "max_XA_hits_alt")] + \
+               [("mat", C.c_int8 * 25)]
+
+
+class Intv(C.Structure):
+    _fields_ = [("x", C.c_uint64 * 3), ("info", C.c_uint64)]
+
+
+class IntvV(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(Intv))]
+
+
+class Reg(C.Structure):
+    _fields_ = [("rb", C.c_int64), ("re", C.c_int64)] + \
+               [(n, C.c_int) for n in ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w",
+                                       "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] + \
+               [("frac_rep", C.c_float), ("hash", C.c_uint64)]
+
+
+class RegV(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(Reg))]
+
+
+class Cand(C.Structure):
+    _fields_ = [("reg", Reg), ("pos", C.c_int64), ("is_rev", C.c_int), ("NM", C.c_int), ("n_cigar", C.c_int),
+                ("cigar_off", C.c_uint32), ("aln_score", C.c_int), ("aln_sub", C.c_int)]
+
+
+class PairOut(C.Structure):
+    _fields_ = [("n1", C.c_size_t), ("n2", C.c_size_t), ("c", C.POINTER(Cand)), ("n_pool", C.c_size_t),
+                ("pool", C.POINTER(C.c_uint32))]
+
+
+class Kswr(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_ext", "n_lf", "n_occ", "w_ref", "n_regs", "n_cigar", "l_read",
+                                          "cells_ext", "cells_local", "cells_global")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ROOT, "oracle", "libemaoracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle`")
+        L = C.CDLL(path)
+        L.orc_idx_load.restype = C.c_void_p
+        L.orc_idx_load.argtypes = [C.c_char_p]
+        L.orc_idx_destroy.argtypes = [C.c_void_p]
+        L.orc_opt_init.argtypes = [C.POINTER(Opt)]
+        L.orc_collect_intv.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int, C.c_char_p, C.POINTER(IntvV)]
+        L.orc_sa.restype = C.c_uint64
+        L.orc_sa.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_occ.restype = C.c_uint64
+        L.orc_occ.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.orc_align_pair.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
+                                     C.POINTER(PairOut)]
+        L.orc_pair_out_free.argtypes = [C.POINTER(PairOut)]
+        L.orc_ksw_extend2.restype = C.c_int
+        L.orc_ksw_extend2.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int8)] + \
+            [C.c_int] * 8 + [C.POINTER(C.c_int)] * 5
+        L.orc_ksw_global2.restype = C.c_int
+        L.orc_ksw_global2.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int8)] + \
+            [C.c_int] * 5 + [C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint32))]
+        L.orc_ksw_align2.restype = Kswr
+        L.orc_ksw_align2.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int8)] + \
+            [C.c_int] * 5
+        L.orc_introsort_u64.argtypes = [C.c_size_t, C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def default_opt():
+    o = Opt()
+    lib().orc_opt_init(C.byref(o))
+    return o
+
+
+NT4 = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    NT4[_c] = _i
+    NT4[_c + 32] = _i
+
+
+class Index:
+    def __init__(self, prefix):
+        self.h = lib().orc_idx_load(prefix.encode())
+        if not self.h:
+            raise RuntimeError(f"oracle could not load index {prefix}")
+
+    def close(self):
+        if self.h:
+            lib().orc_idx_destroy(self.h)
+            self.h = None
+
+    def sa(self, k):
+        return lib().orc_sa(self.h, k)
+
+
+def collect_intv(idx: Index, opt, read_ascii: bytes):
+    """SMEM/seed intervals of one read as a list of (start, end, x0, x1, x2)."""
+    q = NT4[np.frombuffer(read_ascii, dtype=np.uint8)].tobytes()
+    v = IntvV(0, 0, None)
+    lib().orc_collect_intv(C.byref(opt), idx.h, len(q), q, C.byref(v))
+    out = [(v.a[i].info >> 32, v.a[i].info & 0xffffffff, v.a[i].x[0], v.a[i].x[1], v.a[i].x[2]) for i in range(v.n)]
+    C.CDLL(None).free(v.a)
+    return out
+
+
+REG_FIELDS = ("rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "csub", "sub_n", "w", "seedcov", "secondary",
+              "seedlen0", "n_comp", "is_alt", "frac_rep")
+
+
+def align_pair(idx: Index, opt, r1: bytes, r2: bytes):
+    """Returns ([cand dicts of mate1], [cand dicts of mate2]); each has the region fields, pos, is_rev, NM, cigar."""
+    out = PairOut()
+    lib().orc_align_pair(C.byref(opt), idx.h, r1, len(r1), r2, len(r2), C.byref(out))
+    res = ([], [])
+    for k in range(out.n1 + out.n2):
+        c = out.c[k]
+        d = {f: getattr(c.reg, f) for f in REG_FIELDS}
+        d.update(pos=c.pos, is_rev=c.is_rev, NM=c.NM,
+                 cigar=[out.pool[c.cigar_off + j] for j in range(c.n_cigar)])
+        res[0 if k < out.n1 else 1].append(d)
+    lib().orc_pair_out_free(C.byref(out))
+    return res

@@ -1,0 +1,275 @@
+// ema_amd/csrc/engine.hip -- C ABI of the engine (include/ema_engine.h): index upload, batch
+// staging, kernel pipeline, result assembly.  Host side of the drop-in boundary that replaces
+// the reference's per-pair bridge calls (reference src/bwabridge.c:204-311).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ema_engine.h"
+#include "dev_types.h"
+#include "host_index.h"
+#include "opts.h"
+
+extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
+                                int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int n_blocks,
+                                hipStream_t stream);
+
+namespace {
+
+const unsigned char kNt4[256] = {
+	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+	4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+	4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
+
+template <typename T> struct DevBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	hipError_t alloc(size_t count)
+	{
+		release();
+		n = count;
+		return hipMalloc((void **)&p, count * sizeof(T) + 256);
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct ema_engine {
+	ema_engine_opts opts;
+	DevOpts dopts;
+	DevIndex dix;
+	std::vector<HostContig> contigs;
+	int64_t l_pac = 0;
+	int device = 0;
+	int n_cu = 256;
+	hipStream_t stream = nullptr;
+	std::string err;
+	// index in HBM
+	DevBuf<OccSlot> d_occ;
+	DevBuf<uint8_t> d_sa, d_pac;
+	DevBuf<int64_t> d_ctg;
+	// batch
+	size_t cap_pairs = 0, n_pairs = 0;
+	bool staged = false, ran = false;
+	std::vector<uint8_t> h_nt4;
+	std::vector<uint32_t> h_off;
+	DevBuf<uint8_t> d_bases;
+	DevBuf<uint32_t> d_off;
+	// K1
+	int seed_blocks = 0;
+	DevBuf<Intv> d_intv, d_lists;
+	DevBuf<int> d_n_intv, d_status;
+	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	ema_engine_timing timing;
+};
+
+#define HIPCHK(e, call)                                                                              \
+	do {                                                                                             \
+		hipError_t rc_ = (call);                                                                     \
+		if (rc_ != hipSuccess) {                                                                     \
+			(e)->err = std::string(#call) + ": " + hipGetErrorString(rc_);                           \
+			return EMA_EDEVICE;                                                                      \
+		}                                                                                            \
+	} while (0)
+
+extern "C" {
+
+void ema_engine_opts_default(ema_engine_opts *o) { ema_fill_default_opts(o); }
+
+static int engine_alloc_batch(ema_engine *e)
+{
+	const size_t n_reads = 2 * e->cap_pairs;
+	HIPCHK(e, e->d_bases.alloc(n_reads * (size_t)(EMA_MAX_READ + 1)));
+	HIPCHK(e, e->d_off.alloc(n_reads + 1));
+	HIPCHK(e, e->d_intv.alloc(n_reads * (size_t)EMA_INTV_CAP));
+	HIPCHK(e, e->d_n_intv.alloc(n_reads));
+	HIPCHK(e, e->d_status.alloc(n_reads));
+	e->seed_blocks = e->n_cu * 4;   // 4 blocks x 4 waves = 16 waves per CU (VGPR-limited occupancy of K1)
+	HIPCHK(e, e->d_lists.alloc((size_t)e->seed_blocks * 32 * 2 * EMA_LIST_CAP));
+	return EMA_OK;
+}
+
+int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts *opts, ema_engine_t **out)
+{
+	if (!index_prefix || !out) return EMA_EARG;
+	*out = nullptr;
+	ema_engine *e = new ema_engine();
+	*out = e;   // returned even on failure so that the caller can read the error text
+	if (opts) e->opts = *opts; else ema_fill_default_opts(&e->opts);
+	e->dopts = ema_make_dev_opts(e->opts);
+	e->device = device;
+	memset(&e->timing, 0, sizeof(e->timing));
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { e->err = "no HIP device available (the engine has no CPU fallback)"; return EMA_EDEVICE; }
+	if (device < 0 || device >= n_dev) { e->err = "device index out of range"; return EMA_EARG; }
+	HIPCHK(e, hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(e, hipGetDeviceProperties(&prop, device));
+	e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	HIPCHK(e, hipStreamCreate(&e->stream));
+	for (auto &ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
+
+	HostIndex hix;
+	std::string msg = host_index_load(index_prefix, hix);
+	if (!msg.empty()) { e->err = msg; return EMA_EINDEX; }
+	e->contigs = hix.contigs;
+	e->l_pac = hix.l_pac;
+	HIPCHK(e, e->d_occ.alloc(hix.occ.size()));
+	HIPCHK(e, hipMemcpy(e->d_occ.p, hix.occ.data(), hix.occ.size() * sizeof(OccSlot), hipMemcpyHostToDevice));
+	HIPCHK(e, e->d_sa.alloc(hix.sa_bytes.size()));
+	HIPCHK(e, hipMemcpy(e->d_sa.p, hix.sa_bytes.data(), hix.sa_bytes.size(), hipMemcpyHostToDevice));
+	HIPCHK(e, e->d_pac.alloc(hix.pac.size()));
+	HIPCHK(e, hipMemcpy(e->d_pac.p, hix.pac.data(), hix.pac.size(), hipMemcpyHostToDevice));
+	HIPCHK(e, e->d_ctg.alloc(hix.ctg_off.size()));
+	HIPCHK(e, hipMemcpy(e->d_ctg.p, hix.ctg_off.data(), hix.ctg_off.size() * 8, hipMemcpyHostToDevice));
+	e->dix = hix.view();
+	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
+
+	e->cap_pairs = e->opts.batch_pairs > 0 ? (size_t)e->opts.batch_pairs : (size_t)131072;
+	int rc = engine_alloc_batch(e);
+	if (rc != EMA_OK) return rc;
+	return EMA_OK;
+}
+
+void ema_engine_close(ema_engine_t *e)
+{
+	if (!e) return;
+	(void)hipSetDevice(e->device);
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release();
+	e->d_bases.release(); e->d_off.release(); e->d_intv.release(); e->d_lists.release();
+	e->d_n_intv.release(); e->d_status.release();
+	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+	if (e->stream) (void)hipStreamDestroy(e->stream);
+	delete e;
+}
+
+const char *ema_engine_strerror(const ema_engine_t *e) { return e ? e->err.c_str() : "null engine"; }
+int ema_engine_n_contigs(const ema_engine_t *e) { return e ? (int)e->contigs.size() : 0; }
+const char *ema_engine_contig_name(const ema_engine_t *e, int rid)
+{
+	return (e && rid >= 0 && rid < (int)e->contigs.size()) ? e->contigs[rid].name.c_str() : nullptr;
+}
+int64_t ema_engine_contig_len(const ema_engine_t *e, int rid)
+{
+	return (e && rid >= 0 && rid < (int)e->contigs.size()) ? e->contigs[rid].len : -1;
+}
+int64_t ema_engine_contig_offset(const ema_engine_t *e, int rid)
+{
+	return (e && rid >= 0 && rid < (int)e->contigs.size()) ? e->contigs[rid].offset : -1;
+}
+int64_t ema_engine_l_pac(const ema_engine_t *e) { return e ? e->l_pac : -1; }
+size_t ema_engine_batch_capacity(const ema_engine_t *e) { return e ? e->cap_pairs : 0; }
+
+int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs)
+{
+	if (!e || !bases || !off) return EMA_EARG;
+	if (n_pairs > e->cap_pairs) { e->err = "batch larger than ema_engine_batch_capacity()"; return EMA_EARG; }
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t n_reads = 2 * n_pairs;
+	e->h_off.resize(n_reads + 1);
+	const uint32_t base0 = off[0];
+	for (size_t r = 0; r <= n_reads; ++r) e->h_off[r] = off[r] - base0;
+	for (size_t r = 0; r < n_reads; ++r)
+		if (off[r + 1] < off[r] || off[r + 1] - off[r] > EMA_MAX_READ) { e->err = "read longer than EMA_MAX_READ"; return EMA_ELIMIT; }
+	const size_t total = e->h_off[n_reads];
+	e->h_nt4.resize(total + 1);
+	const unsigned char *src = (const unsigned char *)bases + base0;
+	for (size_t i = 0; i < total; ++i) e->h_nt4[i] = kNt4[src[i]];   // seq_convert, reference src/bwabridge.c:151-157
+	HIPCHK(e, hipMemcpyAsync(e->d_bases.p, e->h_nt4.data(), total, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipMemcpyAsync(e->d_off.p, e->h_off.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	e->n_pairs = n_pairs;
+	e->staged = true; e->ran = false;
+	return EMA_OK;
+}
+
+static int run_seed(ema_engine *e)
+{
+	const int n_reads = (int)(2 * e->n_pairs);
+	ema_launch_seed(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_status.p,
+	                e->d_lists.p, e->seed_blocks, e->stream);
+	HIPCHK(e, hipGetLastError());
+	return EMA_OK;
+}
+
+int ema_engine_run(ema_engine_t *e)
+{
+	if (!e) return EMA_EARG;
+	if (!e->staged) { e->err = "ema_engine_run before ema_engine_stage"; return EMA_ESTATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
+	int rc = run_seed(e);
+	if (rc) return rc;
+	HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
+	e->ran = true;
+	return EMA_OK;
+}
+
+int ema_engine_sync(ema_engine_t *e)
+{
+	if (!e) return EMA_EARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (e->ran) {
+		HIPCHK(e, hipEventElapsedTime(&e->timing.seed_ms, e->ev[0], e->ev[1]));
+		e->timing.total_ms = e->timing.seed_ms;
+	}
+	return EMA_OK;
+}
+
+int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
+{
+	if (!e || !t) return EMA_EARG;
+	*t = e->timing;
+	return EMA_OK;
+}
+
+int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read)
+{
+	if (!e || !intv || !n_intv || !cap_per_read) return EMA_EARG;
+	if (!e->staged) { e->err = "ema_engine_debug_seeds before ema_engine_stage"; return EMA_ESTATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	int rc = run_seed(e);
+	if (rc) return rc;
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	const size_t n_reads = 2 * e->n_pairs;
+	*intv = (uint64_t *)malloc(n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv) + 8);
+	*n_intv = (int32_t *)malloc(n_reads * 4 + 8);
+	HIPCHK(e, hipMemcpy(*intv, e->d_intv.p, n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(*n_intv, e->d_n_intv.p, n_reads * 4, hipMemcpyDeviceToHost));
+	*cap_per_read = EMA_INTV_CAP;
+	return EMA_OK;
+}
+
+int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
+{
+	if (!e || !out) return EMA_EARG;
+	e->err = "ema_engine_fetch: pipeline stages after seeding are not built yet";
+	return EMA_ESTATE;
+}
+
+int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs, ema_batch_out **out)
+{
+	int rc = ema_engine_stage(e, bases, off, n_pairs);
+	if (rc) return rc;
+	if ((rc = ema_engine_run(e))) return rc;
+	if ((rc = ema_engine_sync(e))) return rc;
+	return ema_engine_fetch(e, out);
+}
+
+void ema_batch_free(ema_batch_out *out)
+{
+	if (!out) return;
+	free(out->cand_off); free(out->cand); free(out->cigar); free(out->status);
+	free(out);
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+"""ctypes binding of the engine's C ABI (include/ema_engine.h) for the tests and bench.py.
+
+The product boundary is the C ABI itself; this module only marshals numpy arrays across it.
+It never computes alignments on the CPU: if `libema_engine.so` or a GPU is missing, it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libema_engine.so")
+
+SYMBOLS = [
+    "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
+    "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
+    "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing",
+]
+
+
+class Opts(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w",
+                                       "zdrop", "min_seed_len", "split_width", "max_mem_intv", "max_occ",
+                                       "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
+               [(n, C.c_float) for n in ("split_factor", "mask_level", "drop_ratio", "mask_level_redun")] + \
+               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs")]
+
+
+class Cand(C.Structure):
+    _fields_ = [("rb", C.c_int64), ("re", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w",
+                                         "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] + \
+               [("frac_rep", C.c_float), ("pos", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("is_rev", "NM", "n_cigar")] + [("cigar_off", C.c_uint32)] + \
+               [(n, C.c_int32) for n in ("aln_score", "aln_sub")]
+
+
+CAND_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
+                      [(n, "<i4") for n in ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w",
+                                            "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] +
+                      [("frac_rep", "<f4"), ("pos", "<i8")] +
+                      [(n, "<i4") for n in ("is_rev", "NM", "n_cigar")] + [("cigar_off", "<u4")] +
+                      [(n, "<i4") for n in ("aln_score", "aln_sub")], align=True)
+
+
+class BatchOut(C.Structure):
+    _fields_ = [("n_pairs", C.c_size_t), ("cand_off", C.POINTER(C.c_uint64)), ("cand", C.POINTER(Cand)),
+                ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_size_t), ("status", C.POINTER(C.c_int32))]
+
+
+class Timing(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("seed_ms", "chain_ms", "extend_ms", "rescue_ms", "final_ms", "total_ms")]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the in-tree HIP library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make` or __graft_entry__.build(); "
+                               "the engine has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.ema_engine_opts_default.argtypes = [C.POINTER(Opts)]
+        L.ema_engine_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(Opts), C.POINTER(C.c_void_p)]
+        L.ema_engine_close.argtypes = [C.c_void_p]
+        L.ema_engine_strerror.restype = C.c_char_p
+        L.ema_engine_strerror.argtypes = [C.c_void_p]
+        L.ema_engine_n_contigs.argtypes = [C.c_void_p]
+        L.ema_engine_contig_name.restype = C.c_char_p
+        L.ema_engine_contig_name.argtypes = [C.c_void_p, C.c_int]
+        L.ema_engine_contig_len.restype = C.c_int64
+        L.ema_engine_contig_len.argtypes = [C.c_void_p, C.c_int]
+        L.ema_engine_contig_offset.restype = C.c_int64
+        L.ema_engine_contig_offset.argtypes = [C.c_void_p, C.c_int]
+        L.ema_engine_l_pac.restype = C.c_int64
+        L.ema_engine_l_pac.argtypes = [C.c_void_p]
+        L.ema_engine_batch_capacity.restype = C.c_size_t
+        L.ema_engine_batch_capacity.argtypes = [C.c_void_p]
+        L.ema_engine_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ema_engine_run.argtypes = [C.c_void_p]
+        L.ema_engine_sync.argtypes = [C.c_void_p]
+        L.ema_engine_fetch.argtypes = [C.c_void_p, C.POINTER(C.POINTER(BatchOut))]
+        L.ema_engine_align_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.POINTER(C.POINTER(BatchOut))]
+        L.ema_batch_free.argtypes = [C.POINTER(BatchOut)]
+        L.ema_engine_debug_seeds.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)),
+                                             C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]
+        L.ema_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        _lib = L
+    return _lib
+
+
+def default_opts() -> Opts:
+    o = Opts()
+    load_library().ema_engine_opts_default(C.byref(o))
+    return o
+
+
+class Batch:
+    """Result of one batch, copied out of the engine's buffers."""
+
+    def __init__(self, cand_off, cand, cigar, status):
+        self.cand_off, self.cand, self.cigar, self.status = cand_off, cand, cigar, status
+
+    def mate(self, pair, m):
+        lo, hi = int(self.cand_off[2 * pair + m]), int(self.cand_off[2 * pair + m + 1])
+        return self.cand[lo:hi]
+
+    def cigar_of(self, c):
+        return self.cigar[int(c["cigar_off"]):int(c["cigar_off"]) + int(c["n_cigar"])]
+
+
+class Engine:
+    """Mirror of the reference's bridge for a batch of pairs (reference include/bwabridge.h:92-106):
+    `Engine(prefix)` ~ load_reference(); `align_pairs()` ~ bwa_mem_mate_sw + bwa_smith_waterman for every
+    candidate of every pair."""
+
+    def __init__(self, index_prefix: str, device: int = 0, opts: Opts | None = None):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        rc = self._L.ema_engine_open(index_prefix.encode(), device, C.byref(opts) if opts is not None else None,
+                                     C.byref(self._h))
+        if rc != 0:
+            msg = self._L.ema_engine_strerror(self._h).decode() if self._h else "allocation failure"
+            if self._h:
+                self._L.ema_engine_close(self._h)
+                self._h = C.c_void_p()
+            raise RuntimeError(f"ema_engine_open failed ({rc}): {msg}")
+
+    def close(self):
+        if self._h:
+            self._L.ema_engine_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._L.ema_engine_strerror(self._h).decode()}")
+
+    @property
+    def capacity(self):
+        return int(self._L.ema_engine_batch_capacity(self._h))
+
+    def contigs(self):
+        n = self._L.ema_engine_n_contigs(self._h)
+        return [(self._L.ema_engine_contig_name(self._h, i).decode(), int(self._L.ema_engine_contig_len(self._h, i)),
+                 int(self._L.ema_engine_contig_offset(self._h, i))) for i in range(n)]
+
+    def stage(self, bases: np.ndarray, off: np.ndarray):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        self._check(self._L.ema_engine_stage(self._h, bases.ctypes.data, off.ctypes.data, (len(off) - 1) // 2), "stage")
+        self._n_reads_staged = len(off) - 1
+
+    def run(self):
+        self._check(self._L.ema_engine_run(self._h), "run")
+
+    def sync(self):
+        self._check(self._L.ema_engine_sync(self._h), "sync")
+
+    def timing(self):
+        t = Timing()
+        self._check(self._L.ema_engine_last_timing(self._h, C.byref(t)), "timing")
+        return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+    def fetch(self) -> Batch:
+        p = C.POINTER(BatchOut)()
+        self._check(self._L.ema_engine_fetch(self._h, C.byref(p)), "fetch")
+        try:
+            o = p.contents
+            n = o.n_pairs
+            cand_off = np.ctypeslib.as_array(o.cand_off, shape=(2 * n + 1,)).copy()
+            n_cand = int(cand_off[-1])
+            cand = np.frombuffer(C.string_at(o.cand, n_cand * C.sizeof(Cand)), dtype=CAND_DTYPE).copy() \
+                if n_cand else np.zeros(0, dtype=CAND_DTYPE)
+            cigar = np.ctypeslib.as_array(o.cigar, shape=(max(o.n_cigar, 1),)).copy()[:o.n_cigar]
+            status = np.ctypeslib.as_array(o.status, shape=(2 * n,)).copy()
+        finally:
+            self._L.ema_batch_free(p)
+        return Batch(cand_off, cand, cigar, status)
+
+    def align_pairs(self, bases: np.ndarray, off: np.ndarray) -> Batch:
+        self.stage(bases, off)
+        self.run()
+        self.sync()
+        return self.fetch()
+
+    def debug_seeds(self):
+        """Seed intervals of the staged batch: (intv[n_reads, cap, 4] u64 = k, k', size, start<<32|end; n_intv)."""
+        pi, pn, cap = C.POINTER(C.c_uint64)(), C.POINTER(C.c_int32)(), C.c_int32()
+        self._check(self._L.ema_engine_debug_seeds(self._h, C.byref(pi), C.byref(pn), C.byref(cap)), "debug_seeds")
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        try:
+            n_reads = self._n_reads_staged
+            intv = np.ctypeslib.as_array(pi, shape=(n_reads, cap.value, 4)).copy()
+            n_intv = np.ctypeslib.as_array(pn, shape=(n_reads,)).copy()
+        finally:
+            libc.free(pi)
+            libc.free(pn)
+        return intv, n_intv
+
+    _n_reads_staged = 0
+
+    def stage_pairs(self, pairs):
+        self.stage(pairs.bases, pairs.off)

@@ -1,0 +1,125 @@
+/*
+ * include/ema_engine.h -- C ABI of the MI355X engine for EMA's seed-and-extend hot path.
+ *
+ * This is the drop-in boundary: a batched form of the reference's bridge API
+ * (reference include/bwabridge.h:92-106).  The reference calls, once per read pair,
+ *
+ *     EasyAlignmentPairs bwa_mem_mate_sw(ref, opts, r1, l1, r2, l2, 25);   src/align.c:1005  (src/bwabridge.c:204-299)
+ *     bwa_smith_waterman(ref, opts, read, len, a->chained_hit, &r);        src/align.c:1013,1038 (src/bwabridge.c:301-311)
+ *
+ * for every candidate region of both mates.  Here the same work is done for a whole batch of
+ * pairs by HIP kernels with the index resident in HBM; the host then walks the per-pair
+ * candidate lists in the order the reference would have produced them.  INTEGRATION.md shows
+ * the binding a reference maintainer would add to src/align.c.
+ *
+ * Plain C types only.  One engine per GPU; calls on one engine must be serialised by the
+ * caller; several engines (one per GPU) may be used from different threads/processes.
+ * Every function returns 0 on success or a negative EMA_E* code; ema_engine_strerror()
+ * describes the last error of an engine.  There is no CPU fallback: opening an engine
+ * without a usable GPU fails.
+ */
+#ifndef EMA_ENGINE_H
+#define EMA_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMA_OK 0
+#define EMA_EARG (-1)       /* bad argument */
+#define EMA_EINDEX (-2)     /* index files missing or inconsistent */
+#define EMA_EDEVICE (-3)    /* HIP error (no device, out of memory, launch failure) */
+#define EMA_ELIMIT (-4)     /* a read exceeded an engine capacity (see ema_engine_status_of) */
+#define EMA_ESTATE (-5)     /* call sequence error (e.g. fetch before run) */
+
+typedef struct ema_engine ema_engine_t;
+
+/* bwa's mem_opt_t fields used on this path: mem_opt_init() defaults, with max_occ = 3000 as the
+ * reference sets at src/align.c:185.  ema_engine_opts_default() fills them. */
+typedef struct {
+	int a, b, o_del, e_del, o_ins, e_ins;
+	int pen_clip5, pen_clip3, w, zdrop;
+	int min_seed_len, split_width, max_mem_intv, max_occ, max_chain_gap;
+	int min_chain_weight, max_chain_extend;
+	float split_factor, mask_level, drop_ratio, mask_level_redun;
+	int score_delta;            /* reference src/align.c:1005 passes 25 */
+	int max_rescue;             /* reference src/bwabridge.c:264,278: 50 */
+	int pes_low, pes_high;      /* reference src/bwabridge.c:222-223: -35, 500 (FR only) */
+	int batch_pairs;            /* pairs per device batch (0 = engine default) */
+} ema_engine_opts;
+
+void ema_engine_opts_default(ema_engine_opts *o);
+
+/* replaces load_reference()/bwa_init() (reference src/bwabridge.c:77-96, src/align.c:180-186):
+ * reads <index_prefix>.{bwt,fsa,pac,ann} and uploads the index to HBM of `device`. */
+int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts *opts, ema_engine_t **out);
+void ema_engine_close(ema_engine_t *e);
+const char *ema_engine_strerror(const ema_engine_t *e);
+
+/* contig table (bns->anns[i].name/len/offset; reference src/align.c:199-200, src/bwabridge.c:86-91) */
+int ema_engine_n_contigs(const ema_engine_t *e);
+const char *ema_engine_contig_name(const ema_engine_t *e, int rid);
+int64_t ema_engine_contig_len(const ema_engine_t *e, int rid);
+int64_t ema_engine_contig_offset(const ema_engine_t *e, int rid);
+int64_t ema_engine_l_pac(const ema_engine_t *e);
+
+/* One candidate = one element of the reference's results.a (mem_alnreg_t, read through
+ * interpret_align, src/bwabridge.c:313-339, and mem_approx_mapq_se_insist, src/align.c:959-984)
+ * together with its final alignment (mem_aln_t as unpacked by interpret_single_read_alignment,
+ * src/bwabridge.c:359-379). */
+typedef struct {
+	/* region (forward-reverse coordinates, as in mem_alnreg_t) */
+	int64_t rb, re;
+	int32_t qb, qe;
+	int32_t rid;
+	int32_t score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
+	float frac_rep;
+	/* final alignment */
+	int64_t pos;            /* 0-based leftmost position on contig rid */
+	int32_t is_rev, NM, n_cigar;
+	uint32_t cigar_off;     /* first op in ema_batch_out.cigar (BAM packing: len<<4 | op, MIDSH = 0..4) */
+	int32_t aln_score, aln_sub;
+} ema_cand_t;
+
+typedef struct {
+	size_t n_pairs;
+	uint64_t *cand_off;     /* 2*n_pairs + 1: candidates of mate m of pair i are cand[cand_off[2i+m] .. cand_off[2i+m+1]) */
+	ema_cand_t *cand;       /* in the reference's order (results.a after rescue) */
+	uint32_t *cigar;
+	size_t n_cigar;
+	int32_t *status;        /* per read (2*n_pairs): 0, or EMA_ST_* capacity bits */
+} ema_batch_out;
+
+/* Whole hot path for a batch: reads are ASCII, read r at bases[off[r] .. off[r+1]);
+ * mate 1 of pair i is read 2i, mate 2 is read 2i+1 (off has 2*n_pairs+1 entries).
+ * *out is allocated by the engine; free it with ema_batch_free(). */
+int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs, ema_batch_out **out);
+void ema_batch_free(ema_batch_out *out);
+
+/* The same in three steps, so that a caller (and bench.py) can keep inputs resident in HBM and
+ * time the kernels alone:  stage = nt4-convert + H2D;  run = all kernels, asynchronous on the
+ * engine's stream;  fetch = wait + D2H + assemble.  n_pairs must not exceed ema_engine_batch_capacity(). */
+size_t ema_engine_batch_capacity(const ema_engine_t *e);
+int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs);
+int ema_engine_run(ema_engine_t *e);
+int ema_engine_sync(ema_engine_t *e);
+int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out);
+
+/* Stage-level access used by the parity tests and the profiler: seed intervals of the staged
+ * batch (what bwa's mem_collect_intv leaves in aux->mem).  Runs K1 only.
+ * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free(). */
+int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read);
+
+/* per-kernel device time of the last ema_engine_run (HIP events on the engine's stream), ms */
+typedef struct {
+	float seed_ms, chain_ms, extend_ms, rescue_ms, final_ms, total_ms;
+} ema_engine_timing;
+int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,35 @@
+// tests/emu/harness.cpp -- runs the HIP kernels of ema_amd/csrc through the host SIMT
+// interpreter (simt_emu.h).  TEST INFRASTRUCTURE for machines without a GPU; never shipped.
+#include <hip/hip_runtime.h>   // resolves to tests/emu/hip/hip_runtime.h
+#include <string>
+#include <vector>
+#include "host_index.h"
+#include "opts.h"
+
+// kernels + launchers, compiled as plain C++
+#include "k_seed.hip"
+
+extern "C" {
+
+void *emu_index_load(const char *prefix, char *err, int errlen)
+{
+	HostIndex *ix = new HostIndex();
+	std::string e = host_index_load(prefix, *ix);
+	if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); delete ix; return nullptr; }
+	return ix;
+}
+void emu_index_free(void *h) { delete (HostIndex *)h; }
+
+// bases: nt4 codes.  intv: n_reads*EMA_INTV_CAP*4 u64.  Returns the interval capacity per read.
+int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, uint64_t *intv, int *n_intv, int *status,
+             int n_blocks)
+{
+	HostIndex *ix = (HostIndex *)h;
+	ema_engine_opts o; ema_fill_default_opts(&o);
+	DevOpts d = ema_make_dev_opts(o);
+	DevIndex di = ix->view();
+	std::vector<Intv> lists((size_t)n_blocks * 256 / 8 * 2 * EMA_LIST_CAP);
+	ema_launch_seed(&di, &d, bases, off, n_reads, (Intv *)intv, n_intv, status, lists.data(), n_blocks, nullptr);
+	return EMA_INTV_CAP;
+}
+}

@@ -1,0 +1,180 @@
+// tests/emu/simt_emu.h -- a tiny lock-step SIMT interpreter for debugging the HIP kernels on a
+// machine without a GPU.  TEST INFRASTRUCTURE: it compiles the unmodified kernel sources
+// (ema_amd/csrc/k_*.hip) as plain C++ and runs every 64-lane wavefront as 64 ucontext fibers
+// scheduled round-robin; each cross-lane primitive (__shfl*, __ballot, ...) is one scheduling
+// round.  It models a wavefront only: no __syncthreads, no LDS sharing between waves, no
+// memory model.  It also checks convergence: all live lanes of a wave must reach the same
+// cross-lane call site in the same round, otherwise it aborts (that is a kernel bug on the GPU too).
+//
+// The results produced through this harness are NOT parity evidence -- the `-m gpu` tests are.
+#pragma once
+#include <ucontext.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include <algorithm>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+typedef void *hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+
+namespace emu {
+struct Lane {
+	ucontext_t ctx;
+	std::vector<char> stack;
+	bool done = false;
+	const void *site = nullptr;
+	unsigned par = 0;
+};
+struct Wave {
+	Lane lane[64];
+	ucontext_t sched;
+	uint64_t slot[2][64];
+	int cur = 0;
+	unsigned wave_base = 0;
+	dim3 bid, bdim, gdim;
+	std::function<void()> body;
+};
+inline Wave *W = nullptr;
+inline dim3 tid() { return dim3(W->wave_base + (unsigned)W->cur); }
+inline void yield(const void *site) {
+	Lane &l = W->lane[W->cur];
+	l.site = site;
+	swapcontext(&l.ctx, &W->sched);
+}
+inline void trampoline() {
+	W->body();
+	W->lane[W->cur].done = true;
+	swapcontext(&W->lane[W->cur].ctx, &W->sched);
+}
+inline void run_wave_at(Wave &w, unsigned base, unsigned n_lanes) {
+	W = &w;
+	w.wave_base = base;
+	for (unsigned l = 0; l < 64; ++l) {
+		Lane &L = w.lane[l];
+		L.done = l >= n_lanes; L.par = 0; L.site = nullptr;
+		if (L.done) continue;
+		if (L.stack.empty()) L.stack.resize(256 * 1024);
+		getcontext(&L.ctx);
+		L.ctx.uc_stack.ss_sp = L.stack.data();
+		L.ctx.uc_stack.ss_size = L.stack.size();
+		L.ctx.uc_link = nullptr;
+		makecontext(&L.ctx, (void (*)())trampoline, 0);
+	}
+	for (;;) {
+		bool any = false;
+		const void *site = nullptr; bool have = false;
+		for (unsigned l = 0; l < 64; ++l) {
+			Lane &L = w.lane[l];
+			if (L.done) continue;
+			w.cur = (int)l;
+			swapcontext(&w.sched, &L.ctx);
+			if (!L.done) {
+				any = true;
+				if (!have) { site = L.site; have = true; }
+				else if (site != L.site) { fprintf(stderr, "simt_emu: divergent cross-lane call (lane %u)\n", l); abort(); }
+			}
+		}
+		if (!any) break;
+	}
+}
+inline unsigned lane_id() { return (unsigned)W->cur; }
+template <typename T> inline T exch(T v, int src, const void *site) {
+	static_assert(sizeof(T) <= 8, "shuffle width");
+	Lane &L = W->lane[W->cur];
+	unsigned p = L.par & 1; ++L.par;
+	uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+	W->slot[p][W->cur] = raw;
+	yield(site);
+	uint64_t r = W->slot[p][src & 63];
+	T out; memcpy(&out, &r, sizeof(T));
+	return out;
+}
+}  // namespace emu
+
+#define threadIdx (emu::tid())
+#define blockIdx (emu::W->bid)
+#define blockDim (emu::W->bdim)
+#define gridDim (emu::W->gdim)
+#define warpSize 64
+
+#define EMU_SITE __builtin_return_address(0)
+template <typename T> __attribute__((noinline)) T __shfl(T v, int src, int width = 64) {
+	int l = (int)emu::lane_id();
+	int s = (l & ~(width - 1)) | (src & (width - 1));
+	return emu::exch(v, s, EMU_SITE);
+}
+template <typename T> __attribute__((noinline)) T __shfl_xor(T v, int mask, int width = 64) {
+	int l = (int)emu::lane_id();
+	int s = l ^ mask;
+	if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l;
+	return emu::exch(v, s, EMU_SITE);
+}
+template <typename T> __attribute__((noinline)) T __shfl_up(T v, unsigned d, int width = 64) {
+	int l = (int)emu::lane_id();
+	int s = l - (int)d;
+	if (s < (l & ~(width - 1))) s = l;
+	return emu::exch(v, s, EMU_SITE);
+}
+template <typename T> __attribute__((noinline)) T __shfl_down(T v, unsigned d, int width = 64) {
+	int l = (int)emu::lane_id();
+	int s = l + (int)d;
+	if (s > (l | (width - 1))) s = l;
+	return emu::exch(v, s, EMU_SITE);
+}
+__attribute__((noinline)) inline unsigned long long __ballot(int pred) {
+	emu::Lane &L = emu::W->lane[emu::W->cur];
+	unsigned p = L.par & 1; ++L.par;
+	emu::W->slot[p][emu::W->cur] = pred ? 1 : 0;
+	emu::yield(EMU_SITE);
+	unsigned long long m = 0;
+	for (int i = 0; i < 64; ++i)
+		if (!emu::W->lane[i].done && emu::W->slot[p][i]) m |= 1ULL << i;
+	return m;
+}
+__attribute__((noinline)) inline int __any(int pred) { return __ballot(pred) != 0; }
+__attribute__((noinline)) inline int __all(int pred) {
+	unsigned long long live = __ballot(1);
+	return __ballot(pred) == live;
+}
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+inline void __syncthreads() { fprintf(stderr, "simt_emu: __syncthreads is not modelled\n"); abort(); }
+inline void __threadfence_block() {}
+inline void __threadfence() {}
+template <typename T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+using std::min;
+using std::max;
+
+struct uint4 { unsigned x, y, z, w; };
+struct ulong2 { unsigned long long x, y; };
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                            \
+	do {                                                                                     \
+		dim3 g_ = (grid); dim3 b_ = (block);                                                           \
+		static emu::Wave wave_;                                                              \
+		for (unsigned bx_ = 0; bx_ < g_.x; ++bx_)                                            \
+			for (unsigned w0_ = 0; w0_ < b_.x; w0_ += 64) {                                  \
+				wave_.bid = dim3(bx_); wave_.bdim = b_; wave_.gdim = g_;                     \
+				wave_.body = [&]() { kern(__VA_ARGS__); };                                   \
+				emu::run_wave_at(wave_, w0_, std::min(64u, b_.x - w0_));                     \
+			}                                                                                \
+	} while (0)

@@ -1,0 +1,50 @@
+"""ctypes binding of tests/emu/_build/libemu.so (host SIMT interpreter running the HIP kernel sources).
+Debugging aid for machines without a GPU; the parity evidence is the `-m gpu` suite."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib(rebuild=False):
+    global _lib
+    if _lib is None:
+        so = os.path.join(ROOT, "tests", "emu", "_build", "libemu.so")
+        srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("harness.cpp", "simt_emu.h")]
+        csrc = os.path.join(ROOT, "ema_amd", "csrc")
+        srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
+        if rebuild or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")])
+        L = C.CDLL(so)
+        L.emu_index_load.restype = C.c_void_p
+        L.emu_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.emu_index_free.argtypes = [C.c_void_p]
+        L.emu_seed.restype = C.c_int
+        L.emu_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def index_load(prefix):
+    err = C.create_string_buffer(512)
+    h = lib().emu_index_load(prefix.encode(), err, 512)
+    if not h:
+        raise RuntimeError(err.value.decode())
+    return h
+
+
+def seed(h, nt4_bases: np.ndarray, off: np.ndarray, n_blocks=1, cap=512):
+    n_reads = len(off) - 1
+    intv = np.zeros((n_reads, cap, 4), dtype=np.uint64)
+    n_intv = np.zeros(n_reads, dtype=np.int32)
+    status = np.zeros(n_reads, dtype=np.int32)
+    got = lib().emu_seed(h, nt4_bases.ctypes.data, off.ctypes.data, n_reads, intv.ctypes.data, n_intv.ctypes.data,
+                         status.ctypes.data, n_blocks)
+    assert got == cap
+    return intv, n_intv, status

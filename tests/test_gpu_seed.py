@@ -1,0 +1,43 @@
+"""GPU parity of K1 (SMEM / seed-interval collection) against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import small_ref
+from ema_amd import synth
+from ema_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(kind, n_pairs, seed, **kw):
+    prefix, ctg = small_ref(kind)
+    pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
+    eng = Engine(prefix)
+    eng.stage(pairs.bases, pairs.off)
+    intv, n_intv = eng.debug_seeds()
+    idx, opt = O.Index(prefix), O.default_opt()
+    bad = 0
+    for r in range(2 * pairs.n):
+        ref = O.collect_intv(idx, opt, pairs.read(r))
+        got = [(int(v[3]) >> 32, int(v[3]) & 0xffffffff, int(v[0]), int(v[1]), int(v[2])) for v in intv[r, :n_intv[r]]]
+        bad += ref != got
+    eng.close()
+    assert bad == 0, f"{bad} of {2 * pairs.n} reads have different seed intervals"
+
+
+def test_seed_parity_clean():
+    _check("two_contigs", 600, 21)
+
+
+def test_seed_parity_with_n_bases():
+    _check("two_contigs", 300, 22, n_rate=0.01)
+
+
+def test_seed_parity_repeats():
+    _check("repeats", 600, 23)
+
+
+def test_seed_parity_250bp():
+    # config 5 of BASELINE.json (2x250 bp): beyond the reference's MAX_READ_LEN (include/align.h:61), supported here
+    _check("repeats", 200, 24, len1=250, len2=250)

@@ -1,0 +1,425 @@
+// ema_amd/csrc/dev_dp.hpp -- the three dynamic programs of the path as one-wavefront-per-task
+// device functions (gfx950, wave64).
+//
+// All three walk the target row by row and compute one whole DP row per step across the 64 lanes:
+// lane t owns the query columns 4t..4t+3 (EMA_MAX_READ <= 255 columns + the boundary column), and
+// keeps their H and E values in registers from row to row.  Within a row, M and E depend only on the
+// previous row; the horizontal gap state F obeys F(j+1) = max(F(j) - e, T(j)), a max-plus prefix
+// scan, which the wave resolves with a 6-step shuffle scan.  This form is exact (integer max/plus),
+// so the adaptive band of the extension (per-row [beg,end) shrink, m == 0 break, z-drop, argmax with
+// "last column wins") is reproduced row for row -- an anti-diagonal sweep could not, because the band
+// of row i+1 is only known after row i.
+//
+// Replaces (un-vendored bwa, reached from reference src/bwabridge.c:236-237, 267, 281, 304):
+//   ema_wave_extend  : ksw_extend2   (seed extension, via mem_chain2aln)
+//   ema_wave_global  : ksw_global2   (final alignment + traceback via mem_reg2aln; score only for mem_patch_reg)
+//   ema_wave_local   : ksw_u8/ksw_i16 (mate rescue via mem_matesw -> ksw_align2)
+#ifndef EMA_DEV_DP_HPP
+#define EMA_DEV_DP_HPP
+
+#include "dev_common.hpp"
+
+#define EMA_NC 4                       // query columns per lane
+#define EMA_DP_MINUS_INF (-0x40000000)
+#define EMA_NEG_BIG (-0x7f000000)      // "no element" in max scans; never reached by real values
+
+__device__ __forceinline__ int ema_wave_max(int v)
+{
+	v = max(v, __shfl_xor(v, 1)); v = max(v, __shfl_xor(v, 2)); v = max(v, __shfl_xor(v, 4));
+	v = max(v, __shfl_xor(v, 8)); v = max(v, __shfl_xor(v, 16)); v = max(v, __shfl_xor(v, 32));
+	return v;
+}
+// exclusive prefix max over lanes (lane 0 gets EMA_NEG_BIG)
+__device__ __forceinline__ int ema_wave_exscan_max(int v)
+{
+	const unsigned l = ema_lane();
+	int t;
+	t = __shfl_up(v, 1); if (l >= 1) v = max(v, t);
+	t = __shfl_up(v, 2); if (l >= 2) v = max(v, t);
+	t = __shfl_up(v, 4); if (l >= 4) v = max(v, t);
+	t = __shfl_up(v, 8); if (l >= 8) v = max(v, t);
+	t = __shfl_up(v, 16); if (l >= 16) v = max(v, t);
+	t = __shfl_up(v, 32); if (l >= 32) v = max(v, t);
+	t = __shfl_up(v, 1);
+	return l == 0 ? EMA_NEG_BIG : t;
+}
+// value of column j's owner (j wave-uniform); vals[c] = this lane's column 4*lane+c
+__device__ __forceinline__ int ema_col_get(const int vals[EMA_NC], int j)
+{
+	const int c = j & (EMA_NC - 1);
+	const int mine = c == 0 ? vals[0] : c == 1 ? vals[1] : c == 2 ? vals[2] : vals[3];
+	return __shfl(mine, j >> 2);
+}
+
+struct EmaSeq {          // a byte sequence read forwards (step 1) or backwards (step -1)
+	const uint8_t *p;
+	int step;
+	__device__ __forceinline__ int at(int i) const { return p[(long)i * step]; }
+};
+
+struct EmaExtRes { int score, qle, tle, gtle, gscore, max_off; };
+
+// ksw_extend2: banded extension from a seed with score h0.  qlen <= 255.
+__device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w,
+                                            int end_bonus, int zdrop, int h0)
+{
+	const int lane = (int)ema_lane();
+	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
+	int hh[EMA_NC], ee[EMA_NC], qb[EMA_NC];
+	// row -1 of the H/E arrays (index j holds H(-1, j-1); index 0 is the boundary column)
+#pragma unroll
+	for (int c = 0; c < EMA_NC; ++c) {
+		const int j = lane * EMA_NC + c;
+		int v = 0;
+		if (j == 0) v = h0;
+		else if (j <= qlen) {
+			// H[1] = max(h0 - oe_ins, 0); H[j] = H[j-1] - e_ins while H[j-1] > e_ins
+			const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
+			if (j == 1) v = h1v;
+			else {
+				// closed form of the run: H[j] = h1v - (j-1)*e_ins as long as every predecessor exceeded e_ins
+				const int cand = h1v - (j - 1) * e_ins;
+				const int pred = h1v - (j - 2) * e_ins;        // H[j-1] if the run reached it
+				v = (pred > e_ins) ? cand : 0;
+			}
+		}
+		hh[c] = v; ee[c] = 0;
+		qb[c] = j < qlen ? query.at(j) : 4;
+	}
+	int max_ins, max_del;
+	{
+		int mx = 0;
+		for (int i = 0; i < 25; ++i) mx = mx > o.mat[i] ? mx : o.mat[i];
+		max_ins = (int)((double)(qlen * mx + end_bonus - o.o_ins) / e_ins + 1.);
+		max_ins = max_ins > 1 ? max_ins : 1;
+		w = w < max_ins ? w : max_ins;
+		max_del = (int)((double)(qlen * mx + end_bonus - o.o_del) / e_del + 1.);
+		max_del = max_del > 1 ? max_del : 1;
+		w = w < max_del ? w : max_del;
+	}
+	int mx_sc = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+	int beg = 0, end = qlen;
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = target.at(i);
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1_init = 0;
+		if (beg == 0) { h1_init = h0 - (o.o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+		// per cell: M, E from the previous row; T = what F(j+1) may open with
+		int M[EMA_NC], g[EMA_NC];
+		int run = EMA_NEG_BIG;
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j >= beg && j < end;
+			const int s = o.mat[tb * 5 + qb[c]];
+			int m = hh[c] ? hh[c] + s : 0;
+			M[c] = m;
+			int t = m - oe_ins; t = t > 0 ? t : 0;
+			g[c] = in ? t + j * e_ins : EMA_NEG_BIG;
+			run = max(run, g[c]);
+		}
+		int pre = ema_wave_exscan_max(run);     // max g over all columns of lower lanes
+		int h[EMA_NC];
+		int m_key = -1;                         // (h << 9 | j), max over in-range cells
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j >= beg && j < end;
+			int f = pre == EMA_NEG_BIG ? 0 : pre - (j - 1) * e_ins;   // F(i,j) = max(0, max_{k<j} g_k - (j-1) e)
+			f = f > 0 ? f : 0;
+			int hv = M[c] > ee[c] ? M[c] : ee[c];
+			hv = hv > f ? hv : f;
+			h[c] = in ? hv : 0;
+			if (in) m_key = max(m_key, (hv << 9) | j);
+			pre = max(pre, g[c]);
+		}
+		// new E for in-range cells; new H array: index j takes H(i, j-1)
+		const int up = __shfl_up(h[EMA_NC - 1], 1);      // H(i, 4*lane - 1)
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j >= beg && j < end;
+			if (in) {
+				int t = M[c] - oe_del; t = t > 0 ? t : 0;
+				int e = ee[c] - e_del;
+				ee[c] = e > t ? e : t;
+			}
+			const int left = c == 0 ? up : h[c - 1];      // H(i, j-1)
+			if (in) hh[c] = j == beg ? h1_init : left;
+			else if (j == end) { hh[c] = end > beg ? left : h1_init; ee[c] = 0; }
+		}
+		const int h1_fin = end > beg ? ema_col_get(h, end - 1) : h1_init;
+		const int jfin = end > beg ? end : beg;
+		if (jfin == qlen) {
+			max_ie = gscore > h1_fin ? max_ie : i;
+			gscore = gscore > h1_fin ? gscore : h1_fin;
+		}
+		m_key = ema_wave_max(m_key);
+		const int m = m_key < 0 ? 0 : m_key >> 9, mj = m_key < 0 ? -1 : m_key & 511;
+		if (m == 0) break;
+		if (m > mx_sc) {
+			mx_sc = m; max_i = i; max_j = mj;
+			const int off = mj - i < 0 ? i - mj : mj - i;
+			max_off = max_off > off ? max_off : off;
+		} else if (zdrop > 0) {
+			if (i - max_i > mj - max_j) {
+				if (mx_sc - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+			} else {
+				if (mx_sc - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+			}
+		}
+		// next row's range.  Sequentially: beg = first j in [beg,end) with H or E non-zero (else end);
+		// then j = last non-zero index in [beg,end] (else beg-1); end = min(j+2, qlen).
+		int first = 1 << 20, last = -1;
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool nz = (j >= beg && j <= end) && (hh[c] != 0 || ee[c] != 0);
+			const unsigned long long b = __ballot(nz);
+			if (b) {
+				const int f_ = (__ffsll((long long)b) - 1) * EMA_NC + c;
+				const int l_ = (63 - __clzll((long long)b)) * EMA_NC + c;
+				first = first < f_ ? first : f_;
+				last = last > l_ ? last : l_;
+			}
+		}
+		beg = first < end ? first : end;
+		{
+			const int jl = last >= beg ? last : beg - 1;
+			end = jl + 2 < qlen ? jl + 2 : qlen;
+		}
+	}
+	EmaExtRes r;
+	r.score = mx_sc; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+	return r;
+}
+
+// ksw_global2: banded global alignment of query (columns) against target (rows).
+// z != nullptr: the direction matrix (n_col x tlen bytes, n_col = min(qlen, 2w+1)) is written for traceback.
+__device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
+{
+	const int lane = (int)ema_lane();
+	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
+	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	int hh[EMA_NC], ee[EMA_NC], qb[EMA_NC];
+#pragma unroll
+	for (int c = 0; c < EMA_NC; ++c) {
+		const int j = lane * EMA_NC + c;
+		int v = EMA_DP_MINUS_INF;
+		if (j == 0) v = 0;
+		else if (j <= qlen && j <= w) v = -(o.o_ins + e_ins * j);
+		hh[c] = v; ee[c] = EMA_DP_MINUS_INF;
+		qb[c] = j < qlen ? query.at(j) : 4;
+	}
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = target.at(i);
+		const int beg = i > w ? i - w : 0;
+		const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const int h1_init = beg == 0 ? -(o.o_del + e_del * (i + 1)) : EMA_DP_MINUS_INF;
+		int M[EMA_NC], g[EMA_NC];
+		int run = EMA_NEG_BIG;
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j >= beg && j < end;
+			const int m = hh[c] + o.mat[tb * 5 + qb[c]];
+			M[c] = m;
+			g[c] = in ? (m - oe_ins) + j * e_ins : EMA_NEG_BIG;
+			run = max(run, g[c]);
+		}
+		int pre = ema_wave_exscan_max(run);
+		int h[EMA_NC];
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j >= beg && j < end;
+			// F(i,j) = max(MINUS_INF - (j-beg) e, max_{beg<=k<j} g_k - (j-1) e)
+			int f = EMA_DP_MINUS_INF - (j - beg) * e_ins;
+			if (pre != EMA_NEG_BIG) f = max(f, pre - (j - 1) * e_ins);
+			const int m = M[c], e = ee[c];
+			int d = m >= e ? 0 : 1;
+			int hv = m >= e ? m : e;
+			d = hv >= f ? d : 2;
+			hv = hv >= f ? hv : f;
+			h[c] = hv;
+			if (in) {
+				int t = m - oe_del, e2 = e - e_del;
+				d |= e2 > t ? 1 << 2 : 0;
+				ee[c] = e2 > t ? e2 : t;
+				t = m - oe_ins;
+				d |= (f - e_ins) > t ? 2 << 4 : 0;
+				if (z) z[(size_t)i * n_col + (j - beg)] = (uint8_t)d;
+			}
+			pre = max(pre, g[c]);
+		}
+		const int up = __shfl_up(h[EMA_NC - 1], 1);
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j >= beg && j < end;
+			const int left = c == 0 ? up : h[c - 1];
+			if (in) hh[c] = j == beg ? h1_init : left;
+			else if (j == end) { hh[c] = end > beg ? left : h1_init; ee[c] = EMA_DP_MINUS_INF; }
+		}
+	}
+	return ema_col_get(hh, qlen);
+}
+
+// Traceback of ema_wave_global's direction matrix (ksw_global2's backtrack): wave-uniform, sequential.
+// Ops are produced from the alignment's end towards its start and written backwards into cig[0..cap),
+// so cig[first..cap) is the CIGAR in forward order (BAM packing len<<4|op, M=0 I=1 D=2).  Returns `first`,
+// or -1 if cap is too small.
+__device__ inline int ema_traceback(const uint8_t *z, int qlen, int tlen, int w, uint32_t *cig, int cap)
+{
+	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0, pos = cap, last_op = -1;
+	uint32_t cur = 0;
+	while (i >= 0 && k >= 0) {
+		which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+		const int op = which == 0 ? 0 : which == 1 ? 2 : 1;
+		if (op == last_op) cur += 1u << 4;
+		else {
+			if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; }
+			cur = 1u << 4 | (uint32_t)op; last_op = op;
+		}
+		if (which == 0) { --i; --k; } else if (which == 1) --i; else --k;
+	}
+	if (i >= 0) {
+		if (last_op == 2) cur += (uint32_t)(i + 1) << 4;
+		else { if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; } cur = (uint32_t)(i + 1) << 4 | 2u; last_op = 2; }
+	}
+	if (k >= 0) {
+		if (last_op == 1) cur += (uint32_t)(k + 1) << 4;
+		else { if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; } cur = (uint32_t)(k + 1) << 4 | 1u; last_op = 1; }
+	}
+	if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; }
+	return pos;
+}
+
+struct EmaLocalRes { int score, te, qe, score2, te2; };
+
+// One pass of ksw_u8 / ksw_i16 (see oracle/dp.c for why the striped SSE2 kernel equals this):
+// Gotoh local alignment over qpad = ceil(qlen/p)*p columns (p = 16 for the 8-bit kernel, 8 for the 16-bit one),
+// padded columns scoring 0.  minsc / endsc as in ksw (0x10000 = off).  qpad <= 256.
+// bsc: scratch for ksw's b[] list (one u64 per target row at most).
+__device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, EmaSeq query, int tlen, EmaSeq target,
+                                             int minsc, int endsc, uint64_t *bsc)
+{
+	const int lane = (int)ema_lane();
+	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
+	const int qpad = (qlen + p - 1) / p * p;
+	int maxsc = 0;
+	for (int i = 0; i < 25; ++i) maxsc = maxsc > o.mat[i] ? maxsc : o.mat[i];
+	int hh[EMA_NC], ee[EMA_NC], qb[EMA_NC], hmax[EMA_NC];
+#pragma unroll
+	for (int c = 0; c < EMA_NC; ++c) {
+		const int j = lane * EMA_NC + c;
+		hh[c] = 0; ee[c] = 0; hmax[c] = 0;          // hh[c] = H(i-1, j)
+		qb[c] = j < qlen ? query.at(j) : 5;         // 5 = padding column
+	}
+	int gmax = 0, te = -1;
+	// sub-optimal bookkeeping: ksw's b[] list of (row maximum, row); the exclusion window needs te, so the
+	// list is kept (wave-uniform writes) and scanned at the end.
+	int n_b = 0;
+	int last_sc = 0, last_row = -2;                 // copy of b[n_b-1]
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = target.at(i);
+		const int up = __shfl_up(hh[EMA_NC - 1], 1);     // H(i-1, 4*lane-1)
+		int Hd[EMA_NC], g[EMA_NC];
+		int run = EMA_NEG_BIG;
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j < qpad;
+			const int diag = c == 0 ? (lane == 0 ? 0 : up) : hh[c - 1];
+			const int s = qb[c] == 5 ? 0 : o.mat[tb * 5 + qb[c]];
+			int hv = diag + s; hv = hv > 0 ? hv : 0;
+			hv = hv > ee[c] ? hv : ee[c];
+			Hd[c] = hv;                                  // before the F term
+			int t = hv - oe_ins;
+			g[c] = in ? t + j * e_ins : EMA_NEG_BIG;
+			run = max(run, g[c]);
+		}
+		int pre = ema_wave_exscan_max(run);
+		int rowmax = 0;
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			const bool in = j < qpad;
+			int f = pre == EMA_NEG_BIG ? 0 : pre - (j - 1) * e_ins;
+			f = f > 0 ? f : 0;
+			const int hv = Hd[c] > f ? Hd[c] : f;
+			if (in) {
+				hh[c] = hv;
+				rowmax = rowmax > hv ? rowmax : hv;
+				int e = ee[c] - e_del; e = e > 0 ? e : 0;
+				int t = hv - oe_del; t = t > 0 ? t : 0;
+				ee[c] = e > t ? e : t;
+			}
+			pre = max(pre, g[c]);
+		}
+		const int imax = ema_wave_max(rowmax);
+		if (imax >= minsc) {
+			if (n_b == 0 || last_row + 1 != i) {
+				bsc[n_b++] = (uint64_t)imax << 32 | (uint32_t)i;
+				last_sc = imax; last_row = i;
+			} else if (last_sc < imax) {
+				bsc[n_b - 1] = (uint64_t)imax << 32 | (uint32_t)i;
+				last_sc = imax; last_row = i;
+			}
+		}
+		if (imax > gmax) {
+			gmax = imax; te = i;
+#pragma unroll
+			for (int c = 0; c < EMA_NC; ++c) hmax[c] = hh[c];
+			if (gmax >= endsc) break;
+		}
+	}
+	EmaLocalRes r;
+	r.score = gmax; r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1;
+	// qe: smallest query index holding the maximum of row te
+	{
+		int best = -1;
+#pragma unroll
+		for (int c = 0; c < EMA_NC; ++c) {
+			const int j = lane * EMA_NC + c;
+			if (j < qpad && hmax[c] == gmax && best < 0) best = j;
+		}
+		const unsigned long long b = __ballot(best >= 0);
+		if (b) r.qe = __shfl(best, __ffsll((long long)b) - 1);
+		if (te < 0) r.qe = -1;
+	}
+	if (n_b > 0) {
+		// score2 = largest b[] score outside [te - d, te + d], d = ceil(score / max match score); first entry on ties
+		const int d = (r.score + maxsc - 1) / maxsc;
+		const int low = te - d, high = te + d;
+		long long best = -1;                           // score << 32 | (0x7fffffff - index)
+		for (int k = lane; k < n_b; k += EMA_WAVE) {
+			const uint64_t b = bsc[k];
+			const int row = (int)(uint32_t)b;
+			if (row < low || row > high) {
+				const long long key = (long long)(b >> 32) << 32 | (long long)(0x7fffffff - k);
+				best = best > key ? best : key;
+			}
+		}
+		{
+			long long t;
+			t = __shfl_xor(best, 1); best = best > t ? best : t;
+			t = __shfl_xor(best, 2); best = best > t ? best : t;
+			t = __shfl_xor(best, 4); best = best > t ? best : t;
+			t = __shfl_xor(best, 8); best = best > t ? best : t;
+			t = __shfl_xor(best, 16); best = best > t ? best : t;
+			t = __shfl_xor(best, 32); best = best > t ? best : t;
+		}
+		if (best >= 0) {
+			const int k = 0x7fffffff - (int)(best & 0xffffffffLL);
+			r.score2 = (int)(best >> 32);
+			r.te2 = (int)(uint32_t)bsc[k];
+		}
+	}
+	return r;
+}
+
+#endif

@@ -16,6 +16,15 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int n_blocks,
                                 hipStream_t stream);
 
+extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                                       const uint32_t *toff, const int *prm, int n_tasks, int *out, hipStream_t s);
+extern "C" void ema_launch_test_global(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                                       const uint32_t *toff, const int *prm, int n_tasks, int *out, uint32_t *cig, int cap,
+                                       uint8_t *zbuf, size_t z_stride, hipStream_t s);
+extern "C" void ema_launch_test_local(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                                      const uint32_t *toff, const int *prm, int n_tasks, int *out, uint64_t *bsc,
+                                      size_t b_stride, hipStream_t s);
+
 namespace {
 
 const unsigned char kNt4[256] = {
@@ -246,6 +255,43 @@ int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, i
 	HIPCHK(e, hipMemcpy(*intv, e->d_intv.p, n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
 	HIPCHK(e, hipMemcpy(*n_intv, e->d_n_intv.p, n_reads * 4, hipMemcpyDeviceToHost));
 	*cap_per_read = EMA_INTV_CAP;
+	return EMA_OK;
+}
+
+int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                        const uint32_t *toff, const int32_t *prm, int n_tasks, int32_t *out, uint32_t *cigar, int cigar_cap)
+{
+	if (!e || !qbuf || !qoff || !tbuf || !toff || !prm || !out || n_tasks <= 0 || kind < 0 || kind > 2) return EMA_EARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const int n_prm = kind == 0 ? 4 : kind == 1 ? 1 : 3, n_out = kind == 0 ? 6 : kind == 1 ? 2 : 5;
+	DevBuf<uint8_t> dq, dt, dz;
+	DevBuf<uint32_t> dqo, dto, dc;
+	DevBuf<int> dp, dout;
+	DevBuf<uint64_t> db;
+	const size_t z_stride = 256 * 1024, b_stride = 2048;
+	HIPCHK(e, dq.alloc(qoff[n_tasks] + 1)); HIPCHK(e, dt.alloc(toff[n_tasks] + 1));
+	HIPCHK(e, dqo.alloc(n_tasks + 1)); HIPCHK(e, dto.alloc(n_tasks + 1));
+	HIPCHK(e, dp.alloc((size_t)n_tasks * n_prm)); HIPCHK(e, dout.alloc((size_t)n_tasks * n_out));
+	HIPCHK(e, hipMemcpy(dq.p, qbuf, qoff[n_tasks], hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(dt.p, tbuf, toff[n_tasks], hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(dqo.p, qoff, (n_tasks + 1) * 4, hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(dto.p, toff, (n_tasks + 1) * 4, hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(dp.p, prm, (size_t)n_tasks * n_prm * 4, hipMemcpyHostToDevice));
+	if (kind == 0) ema_launch_test_extend(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, e->stream);
+	else if (kind == 1) {
+		if (!cigar || cigar_cap <= 0) return EMA_EARG;
+		HIPCHK(e, dz.alloc((size_t)n_tasks * z_stride));
+		HIPCHK(e, dc.alloc((size_t)n_tasks * cigar_cap));
+		ema_launch_test_global(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, dc.p, cigar_cap, dz.p, z_stride, e->stream);
+	} else {
+		HIPCHK(e, db.alloc((size_t)n_tasks * b_stride));
+		ema_launch_test_local(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, db.p, b_stride, e->stream);
+	}
+	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipMemcpy(out, dout.p, (size_t)n_tasks * n_out * 4, hipMemcpyDeviceToHost));
+	if (kind == 1) HIPCHK(e, hipMemcpy(cigar, dc.p, (size_t)n_tasks * cigar_cap * 4, hipMemcpyDeviceToHost));
+	dq.release(); dt.release(); dz.release(); dqo.release(); dto.release(); dc.release(); dp.release(); dout.release(); db.release();
 	return EMA_OK;
 }
 

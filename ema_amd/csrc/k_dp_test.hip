@@ -1,0 +1,75 @@
+// ema_amd/csrc/k_dp_test.hip -- stand-alone launches of the three wave DPs, one task per wavefront.
+// Exposed through the C ABI's debug entry points so that each DP can be parity-checked against the
+// oracle in isolation (tests/test_gpu_dp.py); the pipeline kernels call the same device functions.
+#include <hip/hip_runtime.h>
+#include "dev_dp.hpp"
+
+// task t: query = qbuf[qoff[t]..qoff[t+1]), target = tbuf[toff[t]..toff[t+1]); prm[t*4..] = {w, end_bonus, zdrop, h0}
+__global__ void __launch_bounds__(64)
+ema_k_test_extend(DevOpts opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf, const uint32_t *toff,
+                  const int *prm, int n_tasks, int *out)
+{
+	const int t = blockIdx.x;
+	if (t >= n_tasks) return;
+	EmaSeq q{qbuf + qoff[t], 1}, tg{tbuf + toff[t], 1};
+	const EmaExtRes r = ema_wave_extend(opt, (int)(qoff[t + 1] - qoff[t]), q, (int)(toff[t + 1] - toff[t]), tg, prm[t * 4],
+	                                    prm[t * 4 + 1], prm[t * 4 + 2], prm[t * 4 + 3]);
+	if (ema_lane() == 0) {
+		int *o = out + t * 6;
+		o[0] = r.score; o[1] = r.qle; o[2] = r.tle; o[3] = r.gtle; o[4] = r.gscore; o[5] = r.max_off;
+	}
+}
+
+// prm[t] = band w.  out[t*2] = score, out[t*2+1] = n_cigar; cigar ops at cig[t*cap .. ) (forward order, left-packed)
+__global__ void __launch_bounds__(64)
+ema_k_test_global(DevOpts opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf, const uint32_t *toff,
+                  const int *prm, int n_tasks, int *out, uint32_t *cig, int cap, uint8_t *zbuf, size_t z_stride)
+{
+	const int t = blockIdx.x;
+	if (t >= n_tasks) return;
+	const int qlen = (int)(qoff[t + 1] - qoff[t]), tlen = (int)(toff[t + 1] - toff[t]);
+	EmaSeq q{qbuf + qoff[t], 1}, tg{tbuf + toff[t], 1};
+	uint8_t *z = zbuf + (size_t)t * z_stride;
+	const int score = ema_wave_global(opt, qlen, q, tlen, tg, prm[t], z);
+	uint32_t *c = cig + (size_t)t * cap;
+	const int first = ema_traceback(z, qlen, tlen, prm[t], c, cap);
+	const int n = first < 0 ? -1 : cap - first;
+	for (int k = 0; k < n; ++k) { const uint32_t v = c[first + k]; c[k] = v; }   // wave-uniform left-pack (first >= k)
+	if (ema_lane() == 0) { out[t * 2] = score; out[t * 2 + 1] = n; }
+}
+
+// prm[t*3..] = {p (16|8), minsc, endsc}.  out[t*5..] = score, te, qe, score2, te2
+__global__ void __launch_bounds__(64)
+ema_k_test_local(DevOpts opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf, const uint32_t *toff,
+                 const int *prm, int n_tasks, int *out, uint64_t *bsc, size_t b_stride)
+{
+	const int t = blockIdx.x;
+	if (t >= n_tasks) return;
+	EmaSeq q{qbuf + qoff[t], 1}, tg{tbuf + toff[t], 1};
+	const EmaLocalRes r = ema_wave_local(opt, (int)(qoff[t + 1] - qoff[t]), prm[t * 3], q, (int)(toff[t + 1] - toff[t]), tg,
+	                                     prm[t * 3 + 1], prm[t * 3 + 2], bsc + (size_t)t * b_stride);
+	if (ema_lane() == 0) {
+		int *o = out + t * 5;
+		o[0] = r.score; o[1] = r.te; o[2] = r.qe; o[3] = r.score2; o[4] = r.te2;
+	}
+}
+
+extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                                       const uint32_t *toff, const int *prm, int n_tasks, int *out, hipStream_t s)
+{
+	hipLaunchKernelGGL(ema_k_test_extend, dim3(n_tasks), dim3(64), 0, s, *opt, qbuf, qoff, tbuf, toff, prm, n_tasks, out);
+}
+extern "C" void ema_launch_test_global(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                                       const uint32_t *toff, const int *prm, int n_tasks, int *out, uint32_t *cig, int cap,
+                                       uint8_t *zbuf, size_t z_stride, hipStream_t s)
+{
+	hipLaunchKernelGGL(ema_k_test_global, dim3(n_tasks), dim3(64), 0, s, *opt, qbuf, qoff, tbuf, toff, prm, n_tasks, out, cig,
+	                   cap, zbuf, z_stride);
+}
+extern "C" void ema_launch_test_local(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                                      const uint32_t *toff, const int *prm, int n_tasks, int *out, uint64_t *bsc,
+                                      size_t b_stride, hipStream_t s)
+{
+	hipLaunchKernelGGL(ema_k_test_local, dim3(n_tasks), dim3(64), 0, s, *opt, qbuf, qoff, tbuf, toff, prm, n_tasks, out, bsc,
+	                   b_stride);
+}

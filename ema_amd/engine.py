@@ -17,7 +17,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp",
 ]
 
 
@@ -92,6 +92,7 @@ def load_library():
         L.ema_engine_debug_seeds.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)),
                                              C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]
         L.ema_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.ema_engine_debug_dp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -212,6 +213,18 @@ class Engine:
         return intv, n_intv
 
     _n_reads_staged = 0
+
+    def debug_dp(self, kind, qbuf, qoff, tbuf, toff, prm, cigar_cap=512):
+        """Runs one of the wave DPs (0 extend, 1 global, 2 local pass) on n tasks; returns (out, cigar|None)."""
+        n = len(qoff) - 1
+        n_out = {0: 6, 1: 2, 2: 5}[kind]
+        out = np.zeros((n, n_out), dtype=np.int32)
+        cig = np.zeros((n, cigar_cap), dtype=np.uint32) if kind == 1 else None
+        prm = np.ascontiguousarray(prm, dtype=np.int32)
+        self._check(self._L.ema_engine_debug_dp(self._h, kind, qbuf.ctypes.data, qoff.ctypes.data, tbuf.ctypes.data,
+                                                toff.ctypes.data, prm.ctypes.data, n, out.ctypes.data,
+                                                cig.ctypes.data if cig is not None else None, cigar_cap), "debug_dp")
+        return out, cig
 
     def stage_pairs(self, pairs):
         self.stage(pairs.bases, pairs.off)

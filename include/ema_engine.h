@@ -113,6 +113,16 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out);
  * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free(). */
 int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read);
 
+/* The three wave DPs in isolation, one task per wavefront, for parity tests against the oracle
+ * (the pipeline kernels call the same device code).  Sequences are nt4 codes (0..3, 4 = N); task t uses
+ * qbuf[qoff[t]..qoff[t+1]) and tbuf[toff[t]..toff[t+1]).  kind 0 = extension (ksw_extend2;
+ * prm[4t..] = w, end_bonus, zdrop, h0; out[6t..] = score, qle, tle, gtle, gscore, max_off), 1 = global
+ * (ksw_global2; prm[t] = w; out[2t..] = score, n_cigar; cigar[t*cigar_cap..]), 2 = one local pass
+ * (ksw_u8/i16; prm[3t..] = p (16|8), minsc, endsc; out[5t..] = score, te, qe, score2, te2). */
+int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
+                        const uint32_t *toff, const int32_t *prm, int n_tasks, int32_t *out, uint32_t *cigar,
+                        int cigar_cap);
+
 /* per-kernel device time of the last ema_engine_run (HIP events on the engine's stream), ms */
 typedef struct {
 	float seed_ms, chain_ms, extend_ms, rescue_ms, final_ms, total_ms;

@@ -8,6 +8,7 @@
 
 // kernels + launchers, compiled as plain C++
 #include "k_seed.hip"
+#include "k_dp_test.hip"
 
 extern "C" {
 
@@ -31,5 +32,30 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	std::vector<Intv> lists((size_t)n_blocks * 256 / 8 * 2 * EMA_LIST_CAP);
 	ema_launch_seed(&di, &d, bases, off, n_reads, (Intv *)intv, n_intv, status, lists.data(), n_blocks, nullptr);
 	return EMA_INTV_CAP;
+}
+
+static DevOpts default_dev_opts() { ema_engine_opts o; ema_fill_default_opts(&o); return ema_make_dev_opts(o); }
+
+void emu_dp_extend(const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf, const uint32_t *toff, const int *prm,
+                   int n, int *out)
+{
+	DevOpts d = default_dev_opts();
+	ema_launch_test_extend(&d, qbuf, qoff, tbuf, toff, prm, n, out, nullptr);
+}
+void emu_dp_global(const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf, const uint32_t *toff, const int *prm,
+                   int n, int *out, uint32_t *cig, int cap)
+{
+	DevOpts d = default_dev_opts();
+	size_t zs = 256 * 1024;
+	std::vector<uint8_t> z((size_t)n * zs);
+	ema_launch_test_global(&d, qbuf, qoff, tbuf, toff, prm, n, out, cig, cap, z.data(), zs, nullptr);
+}
+void emu_dp_local(const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf, const uint32_t *toff, const int *prm,
+                  int n, int *out)
+{
+	DevOpts d = default_dev_opts();
+	size_t bs = 2048;
+	std::vector<uint64_t> b((size_t)n * bs);
+	ema_launch_test_local(&d, qbuf, qoff, tbuf, toff, prm, n, out, b.data(), bs, nullptr);
 }
 }

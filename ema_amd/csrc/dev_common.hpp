@@ -10,6 +10,11 @@
 
 __device__ __forceinline__ unsigned ema_lane() { return threadIdx.x & 63u; }
 
+// Wave-level ordering point.  The lanes of a wavefront execute in lock-step, so this emits no instruction; it
+// stops the compiler from moving memory operations across it and marks the places where one lane's stores are
+// about to be read by the others (or where old values must have been read before the leader lane overwrites them).
+__device__ __forceinline__ void ema_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 // ---------------------------------------------------------------------------------------------
 // occ4 on the HBM block layout of dev_types.h, computed by FOUR adjacent lanes.
 // Lane j (= lane & 3) of the quad loads slot j of the block that holds BWT position `pos`

@@ -1,0 +1,69 @@
+// ema_amd/csrc/dev_ref.hpp -- reference-coordinate helpers on the HBM index (bwa's bntseq.c):
+// contig lookup, forward-reverse coordinates, window fetch from the 2-bit pac.
+#ifndef EMA_DEV_REF_HPP
+#define EMA_DEV_REF_HPP
+
+#include "dev_common.hpp"
+
+// bns_pos2rid: contig holding forward position pos_f (binary search over the contig offsets)
+__device__ __forceinline__ int ema_pos2rid(const DevIndex &ix, int64_t pos_f)
+{
+	if (pos_f >= ix.l_pac) return -1;
+	int left = 0, mid = 0, right = ix.n_seqs;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos_f >= ix.ctg_off[mid]) {
+			if (mid == ix.n_seqs - 1) break;
+			if (pos_f < ix.ctg_off[mid + 1]) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	return mid;
+}
+__device__ __forceinline__ int64_t ema_depos(const DevIndex &ix, int64_t pos, int &is_rev)
+{
+	is_rev = pos >= ix.l_pac;
+	return is_rev ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+// bns_intv2rid: contig of [rb, re), -1 if it spans two contigs, -2 if it spans the strand junction
+__device__ __forceinline__ int ema_intv2rid(const DevIndex &ix, int64_t rb, int64_t re)
+{
+	if (rb < ix.l_pac && re > ix.l_pac) return -2;
+	int r;
+	const int rid_b = ema_pos2rid(ix, ema_depos(ix, rb, r));
+	const int rid_e = rb < re ? ema_pos2rid(ix, ema_depos(ix, re - 1, r)) : rid_b;
+	return rid_b == rid_e ? rid_b : -1;
+}
+// base at forward-reverse coordinate p (reverse strand = complement read from the far end)
+__device__ __forceinline__ int ema_ref_base(const DevIndex &ix, int64_t p)
+{
+	const bool rev = p >= ix.l_pac;
+	const int64_t f = rev ? (ix.l_pac << 1) - 1 - p : p;
+	const int b = ix.pac[f >> 2] >> ((~f & 3) << 1) & 3;
+	return rev ? 3 - b : b;
+}
+// bns_fetch_seq's clamping: [beg, end) cut to the contig (and strand) of `mid`; returns its rid
+__device__ __forceinline__ int ema_clamp_window(const DevIndex &ix, int64_t &beg, int64_t mid, int64_t &end)
+{
+	if (end < beg) { const int64_t t = beg; beg = end; end = t; }
+	int is_rev;
+	const int rid = ema_pos2rid(ix, ema_depos(ix, mid, is_rev));
+	int64_t far_beg = ix.ctg_off[rid], far_end = ix.ctg_off[rid + 1];
+	if (is_rev) {
+		const int64_t t = far_beg;
+		far_beg = (ix.l_pac << 1) - far_end;
+		far_end = (ix.l_pac << 1) - t;
+	}
+	beg = beg > far_beg ? beg : far_beg;
+	end = end < far_end ? end : far_end;
+	return rid;
+}
+// wave-cooperative copy of reference [beg, end) (one strand, already clamped) into dst as nt4 bytes
+__device__ __forceinline__ void ema_wave_fetch(const DevIndex &ix, int64_t beg, int64_t end, uint8_t *dst)
+{
+	const int n = (int)(end - beg);
+	for (int l = (int)ema_lane(); l < n; l += EMA_WAVE) dst[l] = (uint8_t)ema_ref_base(ix, beg + l);
+	ema_wave_sync();
+}
+
+#endif

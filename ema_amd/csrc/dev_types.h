@@ -49,8 +49,39 @@ struct Intv { uint64_t x0, x1, x2, info; };
 #define EMA_LIST_CAP 256      // entries of a forward/backward working list (<= read length)
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
 
+// bwa's mem_seed_t plus the link to the next seed of the same chain
+struct SeedRec { int64_t rbeg; int32_t qbeg, len; int32_t next, pad; };
+
+// bwa's mem_chain_t; the first and last seed are cached for test_and_merge / chn_beg / chn_end
+struct ChainRec {
+	int64_t pos;            // rbeg of the first seed
+	int64_t f_rbeg, l_rbeg;
+	int32_t f_qbeg, l_qbeg, l_len;
+	int32_t rid, n, first_seed, last_seed;
+	int32_t w, kept, first;
+};
+
+// bwa's mem_alnreg_t (fields used on this path)
+struct DevReg {
+	int64_t rb, re;
+	int32_t qb, qe, rid, score, truesc, sub, csub, w, seedcov, secondary, seedlen0, n_comp, is_alt;
+	float frac_rep;
+};
+
+// per-read capacities of the chaining / extension stage (per-wave scratch, see k_align.hip)
+#define EMA_SEED_CAP 32768
+#define EMA_CHAIN_CAP 16384
+#define EMA_AV_CAP 2048       // regions of one read before dedup
+#define EMA_REG_CAP 256       // regions of one read handed to the next stage
+#define EMA_RSEQ_CAP 2048     // reference window bytes staged in LDS
+
 // read status bits
 #define EMA_ST_INTV_OVERFLOW 1
 #define EMA_ST_LIST_OVERFLOW 2
+#define EMA_ST_SEED_OVERFLOW 4
+#define EMA_ST_CHAIN_OVERFLOW 8
+#define EMA_ST_REG_OVERFLOW 16
+#define EMA_ST_RSEQ_OVERFLOW 32
+#define EMA_ST_CIGAR_OVERFLOW 64
 
 #endif

@@ -16,6 +16,10 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int n_blocks,
                                 hipStream_t stream);
 
+extern "C" size_t ema_align_slab_bytes();
+extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
+                                 int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream);
 extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
                                        const uint32_t *toff, const int *prm, int n_tasks, int *out, hipStream_t s);
 extern "C" void ema_launch_test_global(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
@@ -76,6 +80,11 @@ struct ema_engine {
 	int seed_blocks = 0;
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status;
+	// K2
+	int align_blocks = 0;
+	DevBuf<DevReg> d_regs;
+	DevBuf<int> d_n_regs, d_counters;
+	DevBuf<uint8_t> d_slabs;
 	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	ema_engine_timing timing;
 };
@@ -103,6 +112,11 @@ static int engine_alloc_batch(ema_engine *e)
 	HIPCHK(e, e->d_status.alloc(n_reads));
 	e->seed_blocks = e->n_cu * 4;   // 4 blocks x 4 waves = 16 waves per CU (VGPR-limited occupancy of K1)
 	HIPCHK(e, e->d_lists.alloc((size_t)e->seed_blocks * 32 * 2 * EMA_LIST_CAP));
+	HIPCHK(e, e->d_regs.alloc(n_reads * (size_t)EMA_REG_CAP));
+	HIPCHK(e, e->d_n_regs.alloc(n_reads));
+	HIPCHK(e, e->d_counters.alloc(16));
+	e->align_blocks = e->n_cu * 2;  // 2 blocks x 4 waves = 8 resident waves per CU, one scratch slab each
+	HIPCHK(e, e->d_slabs.alloc((size_t)e->align_blocks * 4 * ema_align_slab_bytes()));
 	return EMA_OK;
 }
 
@@ -155,6 +169,7 @@ void ema_engine_close(ema_engine_t *e)
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release();
 	e->d_bases.release(); e->d_off.release(); e->d_intv.release(); e->d_lists.release();
 	e->d_n_intv.release(); e->d_status.release();
+	e->d_regs.release(); e->d_n_regs.release(); e->d_counters.release(); e->d_slabs.release();
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
@@ -203,8 +218,19 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 static int run_seed(ema_engine *e)
 {
 	const int n_reads = (int)(2 * e->n_pairs);
+	HIPCHK(e, hipMemsetAsync(e->d_status.p, 0, (size_t)n_reads * 4, e->stream));
+	HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 16 * 4, e->stream));
 	ema_launch_seed(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_status.p,
 	                e->d_lists.p, e->seed_blocks, e->stream);
+	HIPCHK(e, hipGetLastError());
+	return EMA_OK;
+}
+
+static int run_align(ema_engine *e)
+{
+	const int n_reads = (int)(2 * e->n_pairs);
+	ema_launch_align(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_regs.p,
+	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream);
 	HIPCHK(e, hipGetLastError());
 	return EMA_OK;
 }
@@ -218,6 +244,8 @@ int ema_engine_run(ema_engine_t *e)
 	int rc = run_seed(e);
 	if (rc) return rc;
 	HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
+	if ((rc = run_align(e))) return rc;
+	HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
 	e->ran = true;
 	return EMA_OK;
 }
@@ -229,7 +257,8 @@ int ema_engine_sync(ema_engine_t *e)
 	HIPCHK(e, hipStreamSynchronize(e->stream));
 	if (e->ran) {
 		HIPCHK(e, hipEventElapsedTime(&e->timing.seed_ms, e->ev[0], e->ev[1]));
-		e->timing.total_ms = e->timing.seed_ms;
+		HIPCHK(e, hipEventElapsedTime(&e->timing.extend_ms, e->ev[1], e->ev[2]));
+		HIPCHK(e, hipEventElapsedTime(&e->timing.total_ms, e->ev[0], e->ev[2]));
 	}
 	return EMA_OK;
 }
@@ -255,6 +284,28 @@ int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, i
 	HIPCHK(e, hipMemcpy(*intv, e->d_intv.p, n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
 	HIPCHK(e, hipMemcpy(*n_intv, e->d_n_intv.p, n_reads * 4, hipMemcpyDeviceToHost));
 	*cap_per_read = EMA_INTV_CAP;
+	return EMA_OK;
+}
+
+int ema_engine_debug_regions(ema_engine_t *e, void **regs, int32_t **n_regs, int32_t **status, int32_t *cap_per_read,
+                             int32_t *reg_bytes)
+{
+	if (!e || !regs || !n_regs || !status || !cap_per_read || !reg_bytes) return EMA_EARG;
+	if (!e->staged) { e->err = "ema_engine_debug_regions before ema_engine_stage"; return EMA_ESTATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	int rc = run_seed(e);
+	if (rc) return rc;
+	if ((rc = run_align(e))) return rc;
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	const size_t n_reads = 2 * e->n_pairs;
+	*regs = malloc(n_reads * (size_t)EMA_REG_CAP * sizeof(DevReg) + 8);
+	*n_regs = (int32_t *)malloc(n_reads * 4 + 8);
+	*status = (int32_t *)malloc(n_reads * 4 + 8);
+	HIPCHK(e, hipMemcpy(*regs, e->d_regs.p, n_reads * (size_t)EMA_REG_CAP * sizeof(DevReg), hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(*n_regs, e->d_n_regs.p, n_reads * 4, hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(*status, e->d_status.p, n_reads * 4, hipMemcpyDeviceToHost));
+	*cap_per_read = EMA_REG_CAP;
+	*reg_bytes = (int32_t)sizeof(DevReg);
 	return EMA_OK;
 }
 

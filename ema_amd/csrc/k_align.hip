@@ -1,0 +1,470 @@
+// ema_amd/csrc/k_align.hip -- K2: seeds -> chains -> extended, de-duplicated regions, one wavefront per read.
+//
+// Replaces, for a batch, everything mem_align1_core does after seeding (un-vendored bwa, reached from
+// reference src/bwabridge.c:236-237): bwt_sa for every seed occurrence, mem_chain (chaining through a sorted
+// set of open chains), mem_chain_flt, mem_chain2aln (banded extension of the chain's seeds) and
+// mem_sort_dedup_patch.
+//
+// Why one wave per read: which seeds get extended depends on the regions produced so far for the same read,
+// chain filtering depends on an unstable sort, and dedup/patch walks pairs of regions in order -- the control
+// flow is inherently sequential per read, while its heavy pieces are data-parallel: the suffix-array loads of
+// one seed interval (coalesced: consecutive rows), the DP rows (dev_dp.hpp), the containment tests against all
+// previous regions, the chain-overlap tests against all kept chains, window fetches.  So the wave runs the
+// sequential control program with wave-uniform scalars and spreads each of those pieces over its 64 lanes.
+// Per-read working sets (seed pool, chain table, sort keys, region list) live in a private slab of HBM scratch
+// per resident wave -- with 288 GB there is room for generous worst-case slabs (~3.5 MB each) and no need for
+// inter-kernel compaction; the read and the reference window sit in LDS.
+#include <hip/hip_runtime.h>
+#include "dev_regions.hpp"
+
+struct AlignSlab {           // per resident wave
+	SeedRec *seeds;          // EMA_SEED_CAP     seed pool, chains are linked lists through it
+	ChainRec *chains;        // EMA_CHAIN_CAP    in creation order
+	int64_t *cpos;           // EMA_CHAIN_CAP    chain positions, ascending (the "tree")
+	int32_t *cord;           // EMA_CHAIN_CAP    chain ids in the same order
+	uint64_t *skey;          // EMA_CHAIN_CAP    weight << 32 | id, for the filter's sort
+	int32_t *kept;           // EMA_CHAIN_CAP    kept chains (positions in sorted order)
+	SeedRec *cs;             // EMA_SEED_CAP     seeds of the chain being extended, contiguous
+	uint64_t *srt;           // EMA_SEED_CAP
+	DevReg *av, *av_tmp;     // EMA_AV_CAP
+	uint64_t *rkeys;         // EMA_AV_CAP
+};
+
+#define EMA_ALIGN_SLAB_BYTES                                                                                       \
+	((size_t)EMA_SEED_CAP * (2 * sizeof(SeedRec) + 8) + (size_t)EMA_CHAIN_CAP * (sizeof(ChainRec) + 8 + 4 + 8 + 4) +  \
+	 (size_t)EMA_AV_CAP * (2 * sizeof(DevReg) + 8) + 1024)
+
+__device__ __forceinline__ AlignSlab ema_carve_slab(uint8_t *base)
+{
+	AlignSlab s;
+	size_t o = 0;
+	auto take = [&](size_t bytes) { uint8_t *p = base + o; o += (bytes + 63) & ~(size_t)63; return p; };
+	s.seeds = (SeedRec *)take((size_t)EMA_SEED_CAP * sizeof(SeedRec));
+	s.cs = (SeedRec *)take((size_t)EMA_SEED_CAP * sizeof(SeedRec));
+	s.srt = (uint64_t *)take((size_t)EMA_SEED_CAP * 8);
+	s.chains = (ChainRec *)take((size_t)EMA_CHAIN_CAP * sizeof(ChainRec));
+	s.cpos = (int64_t *)take((size_t)EMA_CHAIN_CAP * 8);
+	s.cord = (int32_t *)take((size_t)EMA_CHAIN_CAP * 4);
+	s.skey = (uint64_t *)take((size_t)EMA_CHAIN_CAP * 8);
+	s.kept = (int32_t *)take((size_t)EMA_CHAIN_CAP * 4);
+	s.av = (DevReg *)take((size_t)EMA_AV_CAP * sizeof(DevReg));
+	s.av_tmp = (DevReg *)take((size_t)EMA_AV_CAP * sizeof(DevReg));
+	s.rkeys = (uint64_t *)take((size_t)EMA_AV_CAP * 8);
+	return s;
+}
+
+namespace {
+
+__device__ __forceinline__ int cal_max_gap(const DevOpts &o, int qlen)
+{
+	const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+	const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+	int l = l_del > l_ins ? l_del : l_ins;
+	l = l > 1 ? l : 1;
+	return l < o.w << 1 ? l : o.w << 1;
+}
+
+// first index in cpos[0..n) with cpos >= key; 64-ary search, one global load per lane and round
+__device__ __forceinline__ int lower_bound_pos(const int64_t *cpos, int n, int64_t key)
+{
+	const int lane = (int)ema_lane();
+	int lo = 0, len = n;
+	while (len > EMA_WAVE) {
+		const int stride = (len + EMA_WAVE - 1) >> 6;
+		int pos = (lane + 1) * stride - 1;
+		if (pos > len - 1) pos = len - 1;
+		const int cnt = __popcll(__ballot(cpos[lo + pos] < key));
+		if (cnt == EMA_WAVE) return lo + len;
+		const int start = cnt * stride;
+		const int rest = len - start;
+		lo += start;
+		len = stride < rest ? stride : rest;
+	}
+	return lo + __popcll(__ballot(lane < len && cpos[lo + (lane < len ? lane : 0)] < key));
+}
+
+struct ChainBuild {
+	AlignSlab sl;
+	int n_chain, n_seed, status;
+};
+
+// mem_chain's loop body for one seed: find the closest chain at or below rbeg, merge into it or open a new one.
+// All lanes take the same decisions from the same reads; lane 0 alone edits the tables, after an ema_wave_sync().
+__device__ inline void chain_insert(const DevOpts &o, int64_t l_pac, ChainBuild &cb, int64_t rbeg, int qbeg, int len, int rid)
+{
+	const int lane = (int)ema_lane();
+	const bool leader = lane == 0;
+	int at = 0, lower = -1;
+	if (cb.n_chain) {
+		const int lo = lower_bound_pos(cb.sl.cpos, cb.n_chain, rbeg);
+		if (lo < cb.n_chain && cb.sl.cpos[lo] == rbeg) { lower = cb.sl.cord[lo]; at = lo + 1; }
+		else if (lo > 0) { lower = cb.sl.cord[lo - 1]; at = lo; }
+	}
+	if (lower >= 0) {   // test_and_merge
+		ChainRec c = cb.sl.chains[lower];
+		const int64_t qend = c.l_qbeg + c.l_len, rend = c.l_rbeg + c.l_len;
+		bool open_new = false;
+		if (rid != c.rid) open_new = true;
+		else if (qbeg >= c.f_qbeg && qbeg + len <= qend && rbeg >= c.f_rbeg && rbeg + len <= rend) return;      // contained: absorbed
+		else if ((c.l_rbeg < l_pac || c.f_rbeg < l_pac) && rbeg >= l_pac) open_new = true;                      // other strand
+		else {
+			const int64_t x = qbeg - c.l_qbeg, y = rbeg - c.l_rbeg;
+			if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c.l_len < o.max_chain_gap && y - c.l_len < o.max_chain_gap) {
+				if (cb.n_seed >= EMA_SEED_CAP) { cb.status |= EMA_ST_SEED_OVERFLOW; return; }
+				const int id = cb.n_seed++;
+				ema_wave_sync();
+				if (leader) {
+					SeedRec s; s.rbeg = rbeg; s.qbeg = qbeg; s.len = len; s.next = -1; s.pad = 0;
+					cb.sl.seeds[id] = s;
+					cb.sl.seeds[c.last_seed].next = id;
+					c.last_seed = id; c.l_rbeg = rbeg; c.l_qbeg = qbeg; c.l_len = len; ++c.n;
+					cb.sl.chains[lower] = c;
+				}
+				return;
+			}
+			open_new = true;
+		}
+		(void)open_new;
+	}
+	// open a new chain right after the element the lookup returned
+	if (cb.n_chain >= EMA_CHAIN_CAP) { cb.status |= EMA_ST_CHAIN_OVERFLOW; return; }
+	if (cb.n_seed >= EMA_SEED_CAP) { cb.status |= EMA_ST_SEED_OVERFLOW; return; }
+	for (int hi = cb.n_chain; hi > at; hi -= EMA_WAVE) {      // shift [at, n) up by one, top chunk first
+		const int idx = hi - 1 - lane;
+		int64_t v = 0; int32_t id = 0;
+		if (idx >= at) { v = cb.sl.cpos[idx]; id = cb.sl.cord[idx]; }
+		ema_wave_sync();
+		if (idx >= at) { cb.sl.cpos[idx + 1] = v; cb.sl.cord[idx + 1] = id; }
+	}
+	const int sid = cb.n_seed++, cid = cb.n_chain++;
+	ema_wave_sync();
+	if (leader) {
+		SeedRec s; s.rbeg = rbeg; s.qbeg = qbeg; s.len = len; s.next = -1; s.pad = 0;
+		cb.sl.seeds[sid] = s;
+		ChainRec c;
+		c.pos = rbeg; c.f_rbeg = c.l_rbeg = rbeg; c.f_qbeg = c.l_qbeg = qbeg; c.l_len = len;
+		c.rid = rid; c.n = 1; c.first_seed = c.last_seed = sid; c.w = 0; c.kept = 0; c.first = -1;
+		cb.sl.chains[cid] = c;
+		cb.sl.cpos[at] = rbeg; cb.sl.cord[at] = cid;
+	}
+}
+
+// mem_chain_weight for one chain (walks its seed list); run lane-parallel over chains
+__device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
+{
+	int64_t end = 0;
+	int w = 0;
+	for (int k = first; k >= 0; k = seeds[k].next) {
+		const SeedRec s = seeds[k];
+		if (s.qbeg >= end) w += s.len;
+		else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
+		end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
+	}
+	const int tmp = w;
+	w = 0; end = 0;
+	for (int k = first; k >= 0; k = seeds[k].next) {
+		const SeedRec s = seeds[k];
+		if (s.rbeg >= end) w += s.len;
+		else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
+		end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
+	}
+	w = w < tmp ? w : tmp;
+	return w < 1 << 30 ? w : (1 << 30) - 1;
+}
+
+}  // namespace
+
+// one wavefront = one read at a time, reads taken from a shared counter
+// intv/n_intv: K1's output.  regs: n_reads x EMA_REG_CAP, n_regs: n_reads.  status is OR-ed.
+__global__ void __launch_bounds__(256)
+ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
+            const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
+            int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter)
+{
+	__shared__ uint8_t lds_q[4][256];
+	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
+	__shared__ int lds_stack[4][3 * 70];
+	const int lane = (int)ema_lane();
+	const int wib = (int)(threadIdx.x >> 6);
+	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
+	uint8_t *query = lds_q[wib];
+	uint8_t *rseq = lds_r[wib];
+	ChainBuild cb;
+	cb.sl = ema_carve_slab(slabs + (size_t)slot * EMA_ALIGN_SLAB_BYTES);
+	const AlignSlab &sl = cb.sl;
+	const int64_t l_pac = ix.l_pac;
+
+	for (;;) {
+		int read = 0;
+		if (lane == 0) read = atomicAdd(counter, 1);
+		read = __shfl(read, 0);
+		if (read >= n_reads) break;
+		const int l_query = (int)(off[read + 1] - off[read]);
+		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
+		ema_wave_sync();
+		const Intv *iv = intv + (size_t)read * EMA_INTV_CAP;
+		const int n_iv = n_intv[read];
+		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
+
+		// ---------------- mem_chain: frac_rep, seed occurrences, chaining ----------------
+		int l_rep = 0;
+		{
+			int b = 0, e = 0;
+			for (int i = 0; i < n_iv; ++i) {
+				const Intv p = iv[i];
+				const int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+				if (p.x2 <= (uint64_t)opt.max_occ) continue;
+				if (sb > e) { l_rep += e - b; b = sb; e = se; }
+				else e = e > se ? e : se;
+			}
+			l_rep += e - b;
+		}
+		const float frac_rep = (float)l_rep / (float)l_query;
+		for (int i = 0; i < n_iv; ++i) {
+			const Intv p = iv[i];
+			const int qbeg = (int)(p.info >> 32), slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
+			const int64_t step = p.x2 > (uint64_t)opt.max_occ ? (int64_t)(p.x2 / (uint64_t)opt.max_occ) : 1;
+			int64_t n_occ = ((int64_t)p.x2 + step - 1) / step;        // k = 0, step, ... < size
+			if (n_occ > opt.max_occ) n_occ = opt.max_occ;
+			for (int64_t base = 0; base < n_occ; base += EMA_WAVE) {
+				const int64_t idx = base + lane;
+				int64_t rbeg = 0; int rid = -1;
+				if (idx < n_occ) {      // consecutive suffix-array rows (step 1) -> coalesced loads
+					rbeg = (int64_t)ema_sa(ix, p.x0 + (uint64_t)(idx * step));
+					rid = ema_intv2rid(ix, rbeg, rbeg + slen);
+				}
+				const int cnt = (int)(n_occ - base < EMA_WAVE ? n_occ - base : EMA_WAVE);
+				for (int t = 0; t < cnt; ++t) {
+					const int64_t rb = __shfl(rbeg, t);
+					const int rd = __shfl(rid, t);
+					if (rd < 0) continue;
+					chain_insert(opt, l_pac, cb, rb, qbeg, slen, rd);
+				}
+			}
+		}
+
+		// ---------------- mem_chain_flt ----------------
+		int n_chn = cb.n_chain, n_keep = 0;
+		if (n_chn > 0) {
+			for (int i = lane; i < n_chn; i += EMA_WAVE) {      // weights, chains taken in position order
+				const int id = sl.cord[i];
+				const int w = chain_weight(sl.seeds, sl.chains[id].first_seed);
+				sl.chains[id].w = w;
+				sl.skey[i] = (uint64_t)(uint32_t)w << 32 | (uint32_t)id;
+			}
+			// min_chain_weight is 0 on this path: nothing is dropped before the sort
+			ema_wave_sync();
+			if (lane == 0) ema_introsort(sl.skey, n_chn, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, lds_stack[wib]);
+			ema_wave_sync();
+			int n_kept = 0;
+			{
+				const int id0 = (int)(uint32_t)sl.skey[0];
+				if (lane == 0) { sl.chains[id0].kept = 3; sl.kept[0] = 0; }
+				n_kept = 1;
+			}
+			for (int i = 1; i < n_chn; ++i) {
+				const int ci = (int)(uint32_t)sl.skey[i];
+				const ChainRec a_i = sl.chains[ci];
+				const int beg_i = a_i.f_qbeg, end_i = a_i.l_qbeg + a_i.l_len;
+				bool large_ovlp = false, dropped = false;
+				for (int base = 0; base < n_kept && !dropped; base += EMA_WAVE) {
+					const int k = base + lane;
+					const bool valid = k < n_kept;
+					const int cj = valid ? (int)(uint32_t)sl.skey[sl.kept[k]] : ci;
+					const ChainRec a_j = sl.chains[cj];
+					const int beg_j = a_j.f_qbeg, end_j = a_j.l_qbeg + a_j.l_len;
+					const int b_max = beg_j > beg_i ? beg_j : beg_i;
+					const int e_min = end_j < end_i ? end_j : end_i;
+					bool ovlp = false, drop = false;
+					if (valid && e_min > b_max) {     // is_alt is always 0: no .alt support
+						const int li = end_i - beg_i, lj = end_j - beg_j;
+						const int min_l = li < lj ? li : lj;
+						if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+							ovlp = true;
+							if ((float)a_i.w < (float)a_j.w * opt.drop_ratio && a_j.w - a_i.w >= opt.min_seed_len << 1) drop = true;
+						}
+					}
+					const unsigned long long bd = __ballot(drop);
+					const int first_drop = bd ? __ffsll((long long)bd) - 1 : EMA_WAVE;
+					const bool counted = ovlp && lane <= first_drop;
+					if (counted && a_j.first < 0) sl.chains[cj].first = i;     // first shadowed chain of a kept chain
+					if (__ballot(counted)) large_ovlp = true;
+					if (bd) dropped = true;
+				}
+				if (!dropped) {
+					if (lane == 0) { sl.kept[n_kept] = i; sl.chains[ci].kept = large_ovlp ? 2 : 3; }
+					++n_kept;
+				}
+			}
+			ema_wave_sync();
+			for (int k = lane; k < n_kept; k += EMA_WAVE) {
+				const int cj = (int)(uint32_t)sl.skey[sl.kept[k]];
+				const int f = sl.chains[cj].first;
+				if (f >= 0) sl.chains[(int)(uint32_t)sl.skey[f]].kept = 1;
+			}
+			ema_wave_sync();
+			// max_chain_extend is 1<<30 on this path: the cap on kept=1/2 chains never triggers
+			n_keep = n_chn;
+		}
+
+		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
+		int n_av = 0;
+		for (int ci_sorted = 0; ci_sorted < n_keep; ++ci_sorted) {
+			const int cid = (int)(uint32_t)sl.skey[ci_sorted];
+			const ChainRec c = sl.chains[cid];
+			if (c.kept == 0) continue;
+			const int cn = c.n;
+			{   // gather the chain's seeds
+				int k = c.first_seed;
+				for (int t = 0; t < cn; ++t) { const SeedRec s = sl.seeds[k]; if (lane == 0) sl.cs[t] = s; k = s.next; }
+				ema_wave_sync();
+			}
+			int64_t rmax0 = l_pac << 1, rmax1 = 0;
+			for (int t = lane; t < cn; t += EMA_WAVE) {
+				const SeedRec s = sl.cs[t];
+				const int64_t b = s.rbeg - (s.qbeg + cal_max_gap(opt, s.qbeg));
+				const int tail = l_query - s.qbeg - s.len;
+				const int64_t e = s.rbeg + s.len + (tail + cal_max_gap(opt, tail));
+				rmax0 = rmax0 < b ? rmax0 : b;
+				rmax1 = rmax1 > e ? rmax1 : e;
+				sl.srt[t] = (uint64_t)(uint32_t)s.len << 32 | (uint32_t)t;      // score == len
+			}
+			for (int m = 1; m < EMA_WAVE; m <<= 1) {
+				const int64_t o0 = __shfl_xor(rmax0, m), o1 = __shfl_xor(rmax1, m);
+				rmax0 = rmax0 < o0 ? rmax0 : o0;
+				rmax1 = rmax1 > o1 ? rmax1 : o1;
+			}
+			rmax0 = rmax0 > 0 ? rmax0 : 0;
+			rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+			if (rmax0 < l_pac && l_pac < rmax1) {
+				if (c.f_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+			}
+			ema_clamp_window(ix, rmax0, c.f_rbeg, rmax1);
+			if (rmax1 - rmax0 > EMA_RSEQ_CAP) { cb.status |= EMA_ST_RSEQ_OVERFLOW; continue; }
+			ema_wave_fetch(ix, rmax0, rmax1, rseq);
+			// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
+			ema_wave_sync();
+			if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
+			ema_wave_sync();
+
+			for (int k = cn - 1; k >= 0; --k) {
+				const SeedRec s = sl.cs[(int)(uint32_t)sl.srt[k]];
+				// already covered by an earlier extension of this read?
+				bool covered = false;
+				for (int base = 0; base < n_av && !covered; base += EMA_WAVE) {
+					bool hit = false;
+					const int i = base + lane;
+					if (i < n_av) {
+						const DevReg p = sl.av[i];
+						if (!(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) &&
+						    !((double)(s.len - p.seedlen0) > .1 * (double)l_query)) {
+							int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
+							int max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+							int w = max_gap < p.w ? max_gap : p.w;
+							if (qd - rd < w && rd - qd < w) hit = true;
+							else {
+								qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+								max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd);
+								w = max_gap < p.w ? max_gap : p.w;
+								if (qd - rd < w && rd - qd < w) hit = true;
+							}
+						}
+					}
+					if (__ballot(hit)) covered = true;
+				}
+				if (covered) {   // ... unless an already-extended, overlapping seed of the chain lies on another diagonal
+					bool other = false;
+					for (int base = k + 1; base < cn && !other; base += EMA_WAVE) {
+						bool hit = false;
+						const int i = base + lane;
+						if (i < cn && sl.srt[i] != 0) {
+							const SeedRec t = sl.cs[(int)(uint32_t)sl.srt[i]];
+							if (!((double)t.len < (double)s.len * .95)) {
+								if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) hit = true;
+								if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) hit = true;
+							}
+						}
+						if (__ballot(hit)) other = true;
+					}
+					if (!other) { if (lane == 0) sl.srt[k] = 0; continue; }
+				}
+				if (n_av >= EMA_AV_CAP) { cb.status |= EMA_ST_REG_OVERFLOW; continue; }
+
+				DevReg a;
+				a.sub = a.csub = a.secondary = a.n_comp = a.is_alt = 0; a.seedcov = 0;
+				int aw0 = opt.w, aw1 = opt.w;
+				a.score = a.truesc = -1;
+				a.rid = c.rid;
+				if (s.qbeg) {     // left extension, both sequences reversed
+					const int tlen = (int)(s.rbeg - rmax0);
+					EmaExtRes r; r.score = -1; r.qle = r.tle = r.gtle = 0; r.gscore = -1; r.max_off = 0;
+					for (int i = 0; i < 2; ++i) {        // MAX_BAND_TRY
+						const int prev = a.score;
+						aw0 = opt.w << i;
+						r = ema_wave_extend(opt, s.qbeg, EmaSeq{query + s.qbeg - 1, -1}, tlen, EmaSeq{rseq + tlen - 1, -1}, aw0,
+						                    opt.pen_clip5, opt.zdrop, s.len * opt.a);
+						a.score = r.score;
+						if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+					}
+					if (r.gscore <= 0 || r.gscore <= a.score - opt.pen_clip5) {
+						a.qb = s.qbeg - r.qle; a.rb = s.rbeg - r.tle; a.truesc = a.score;
+					} else {
+						a.qb = 0; a.rb = s.rbeg - r.gtle; a.truesc = r.gscore;
+					}
+				} else { a.score = a.truesc = s.len * opt.a; a.qb = 0; a.rb = s.rbeg; }
+				if (s.qbeg + s.len != l_query) {     // right extension
+					const int sc0 = a.score, qe = s.qbeg + s.len, re = (int)(s.rbeg + s.len - rmax0);
+					EmaExtRes r; r.score = -1; r.qle = r.tle = r.gtle = 0; r.gscore = -1; r.max_off = 0;
+					for (int i = 0; i < 2; ++i) {
+						const int prev = a.score;
+						aw1 = opt.w << i;
+						r = ema_wave_extend(opt, l_query - qe, EmaSeq{query + qe, 1}, (int)(rmax1 - rmax0 - re), EmaSeq{rseq + re, 1},
+						                    aw1, opt.pen_clip3, opt.zdrop, sc0);
+						a.score = r.score;
+						if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+					}
+					if (r.gscore <= 0 || r.gscore <= a.score - opt.pen_clip3) {
+						a.qe = qe + r.qle; a.re = rmax0 + re + r.tle; a.truesc += a.score - sc0;
+					} else {
+						a.qe = l_query; a.re = rmax0 + re + r.gtle; a.truesc += r.gscore - sc0;
+					}
+				} else { a.qe = l_query; a.re = s.rbeg + s.len; }
+				{   // seedcov: seeds of the chain fully inside the region
+					int cov = 0;
+					for (int t = lane; t < cn; t += EMA_WAVE) {
+						const SeedRec u = sl.cs[t];
+						if (u.qbeg >= a.qb && u.qbeg + u.len <= a.qe && u.rbeg >= a.rb && u.rbeg + u.len <= a.re) cov += u.len;
+					}
+					cov += __shfl_xor(cov, 1); cov += __shfl_xor(cov, 2); cov += __shfl_xor(cov, 4);
+					cov += __shfl_xor(cov, 8); cov += __shfl_xor(cov, 16); cov += __shfl_xor(cov, 32);
+					a.seedcov = cov;
+				}
+				a.w = aw0 > aw1 ? aw0 : aw1;
+				a.seedlen0 = s.len;
+				a.frac_rep = frac_rep;
+				if (lane == 0) sl.av[n_av] = a;
+				++n_av;
+				ema_wave_sync();
+			}
+		}
+
+		// ---------------- mem_sort_dedup_patch ----------------
+		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq;
+		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
+		if (n_out > EMA_REG_CAP) { cb.status |= EMA_ST_REG_OVERFLOW; n_out = EMA_REG_CAP; }
+		ema_wave_sync();
+		DevReg *dst = regs + (size_t)read * EMA_REG_CAP;
+		for (int i = lane; i < n_out; i += EMA_WAVE) dst[i] = sl.av[i];
+		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
+	}
+}
+
+extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
+
+extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
+                                 int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream)
+{
+	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, intv, n_intv, regs,
+	                   n_regs, status, slabs, counter);
+}

@@ -80,7 +80,8 @@ struct SeedSM {
 	}
 	__device__ __forceinline__ void end_smem()
 	{
-		for (int a = seg_start, b = n_out - 1; a < b; ++a, --b) { Intv t = out[a]; out[a] = out[b]; out[b] = t; }
+		// bwa reverses the MEMs of this call here; the list is fully sorted at PC_FINISH and entries with equal
+		// (start, end) are identical, so the intermediate order has no effect on the result
 		if (pass == 1) { x = ret; pc = PC_P1_NEXT; }
 		else pc = PC_P2_NEXT;
 	}

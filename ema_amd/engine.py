@@ -17,7 +17,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions",
 ]
 
 
@@ -44,6 +44,11 @@ CAND_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
                       [("frac_rep", "<f4"), ("pos", "<i8")] +
                       [(n, "<i4") for n in ("is_rev", "NM", "n_cigar")] + [("cigar_off", "<u4")] +
                       [(n, "<i4") for n in ("aln_score", "aln_sub")], align=True)
+
+
+REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
+                     [(n, "<i4") for n in ("qb", "qe", "rid", "score", "truesc", "sub", "csub", "w", "seedcov", "secondary",
+                                           "seedlen0", "n_comp", "is_alt")] + [("frac_rep", "<f4")], align=True)
 
 
 class BatchOut(C.Structure):
@@ -92,6 +97,9 @@ def load_library():
         L.ema_engine_debug_seeds.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)),
                                              C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]
         L.ema_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.ema_engine_debug_regions.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_int32)),
+                                               C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_int32)]
         L.ema_engine_debug_dp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -213,6 +221,25 @@ class Engine:
         return intv, n_intv
 
     _n_reads_staged = 0
+
+    def debug_regions(self):
+        """Regions of the staged reads before mate rescue: (regs[n_reads, cap] structured, n_regs, status)."""
+        pr, pn, ps, cap, nb = C.c_void_p(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.c_int32(), C.c_int32()
+        self._check(self._L.ema_engine_debug_regions(self._h, C.byref(pr), C.byref(pn), C.byref(ps), C.byref(cap),
+                                                     C.byref(nb)), "debug_regions")
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        try:
+            n = self._n_reads_staged
+            assert nb.value == REG_DTYPE.itemsize
+            regs = np.frombuffer(C.string_at(pr, n * cap.value * nb.value), dtype=REG_DTYPE).reshape(n, cap.value).copy()
+            n_regs = np.ctypeslib.as_array(pn, shape=(n,)).copy()
+            status = np.ctypeslib.as_array(ps, shape=(n,)).copy()
+        finally:
+            libc.free(pr)
+            libc.free(pn)
+            libc.free(ps)
+        return regs, n_regs, status
 
     def debug_dp(self, kind, qbuf, qoff, tbuf, toff, prm, cigar_cap=512):
         """Runs one of the wave DPs (0 extend, 1 global, 2 local pass) on n tasks; returns (out, cigar|None)."""

@@ -113,6 +113,13 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out);
  * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free(). */
 int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read);
 
+/* Regions of every staged read after seeding, chaining, extension and dedup (bwa's mem_align1_core result,
+ * i.e. before mate rescue).  Runs K1 + K2.  regs: n_reads x cap records of reg_bytes bytes laid out as
+ * {i64 rb, re; i32 qb, qe, rid, score, truesc, sub, csub, w, seedcov, secondary, seedlen0, n_comp, is_alt; f32 frac_rep};
+ * caller frees the three arrays with free(). */
+int ema_engine_debug_regions(ema_engine_t *e, void **regs, int32_t **n_regs, int32_t **status, int32_t *cap_per_read,
+                             int32_t *reg_bytes);
+
 /* The three wave DPs in isolation, one task per wavefront, for parity tests against the oracle
  * (the pipeline kernels call the same device code).  Sequences are nt4 codes (0..3, 4 = N); task t uses
  * qbuf[qoff[t]..qoff[t+1]) and tbuf[toff[t]..toff[t+1]).  kind 0 = extension (ksw_extend2;

@@ -9,6 +9,7 @@
 // kernels + launchers, compiled as plain C++
 #include "k_seed.hip"
 #include "k_dp_test.hip"
+#include "k_align.hip"
 
 extern "C" {
 
@@ -58,4 +59,24 @@ void emu_dp_local(const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf
 	std::vector<uint64_t> b((size_t)n * bs);
 	ema_launch_test_local(&d, qbuf, qoff, tbuf, toff, prm, n, out, b.data(), bs, nullptr);
 }
+
+// K1 + K2 on host memory.  regs: n_reads * EMA_REG_CAP DevReg (80 bytes each); returns EMA_REG_CAP
+int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, void *regs, int *n_regs, int *status,
+              int n_blocks)
+{
+	HostIndex *ix = (HostIndex *)h;
+	DevOpts d = default_dev_opts();
+	DevIndex di = ix->view();
+	std::vector<Intv> intv((size_t)n_reads * EMA_INTV_CAP);
+	std::vector<int> n_intv(n_reads);
+	std::vector<Intv> lists((size_t)1 * 256 / 8 * 2 * EMA_LIST_CAP);
+	for (int i = 0; i < n_reads; ++i) status[i] = 0;
+	ema_launch_seed(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), status, lists.data(), 1, nullptr);
+	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
+	int counter = 0;
+	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
+	                 &counter, n_blocks, nullptr);
+	return EMA_REG_CAP;
+}
+int emu_sizeof_reg() { return (int)sizeof(DevReg); }
 }

@@ -9,6 +9,7 @@
 // The results produced through this harness are NOT parity evidence -- the `-m gpu` tests are.
 #pragma once
 #include <ucontext.h>
+#include <dlfcn.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +36,7 @@ struct Lane {
 	ucontext_t ctx;
 	std::vector<char> stack;
 	bool done = false;
-	const void *site = nullptr;
+	long site = 0;
 	unsigned par = 0;
 };
 struct Wave {
@@ -49,7 +50,7 @@ struct Wave {
 };
 inline Wave *W = nullptr;
 inline dim3 tid() { return dim3(W->wave_base + (unsigned)W->cur); }
-inline void yield(const void *site) {
+inline void yield(long site) {
 	Lane &l = W->lane[W->cur];
 	l.site = site;
 	swapcontext(&l.ctx, &W->sched);
@@ -64,7 +65,7 @@ inline void run_wave_at(Wave &w, unsigned base, unsigned n_lanes) {
 	w.wave_base = base;
 	for (unsigned l = 0; l < 64; ++l) {
 		Lane &L = w.lane[l];
-		L.done = l >= n_lanes; L.par = 0; L.site = nullptr;
+		L.done = l >= n_lanes; L.par = 0; L.site = 0;
 		if (L.done) continue;
 		if (L.stack.empty()) L.stack.resize(256 * 1024);
 		getcontext(&L.ctx);
@@ -75,7 +76,7 @@ inline void run_wave_at(Wave &w, unsigned base, unsigned n_lanes) {
 	}
 	for (;;) {
 		bool any = false;
-		const void *site = nullptr; bool have = false;
+		long site = 0; bool have = false;
 		for (unsigned l = 0; l < 64; ++l) {
 			Lane &L = w.lane[l];
 			if (L.done) continue;
@@ -84,14 +85,17 @@ inline void run_wave_at(Wave &w, unsigned base, unsigned n_lanes) {
 			if (!L.done) {
 				any = true;
 				if (!have) { site = L.site; have = true; }
-				else if (site != L.site) { fprintf(stderr, "simt_emu: divergent cross-lane call (lane %u)\n", l); abort(); }
+				else if (site != L.site) {
+					fprintf(stderr, "simt_emu: divergent cross-lane call: lane %u is at source line %ld, earlier lanes at line %ld\n", l, L.site, site);
+					abort();
+				}
 			}
 		}
 		if (!any) break;
 	}
 }
 inline unsigned lane_id() { return (unsigned)W->cur; }
-template <typename T> inline T exch(T v, int src, const void *site) {
+template <typename T> inline T exch(T v, int src, long site) {
 	static_assert(sizeof(T) <= 8, "shuffle width");
 	Lane &L = W->lane[W->cur];
 	unsigned p = L.par & 1; ++L.par;
@@ -110,45 +114,45 @@ template <typename T> inline T exch(T v, int src, const void *site) {
 #define gridDim (emu::W->gdim)
 #define warpSize 64
 
-#define EMU_SITE __builtin_return_address(0)
-template <typename T> __attribute__((noinline)) T __shfl(T v, int src, int width = 64) {
+template <typename T> __attribute__((noinline)) T __shfl(T v, int src, int width = 64, int line_ = __builtin_LINE()) {
 	int l = (int)emu::lane_id();
 	int s = (l & ~(width - 1)) | (src & (width - 1));
-	return emu::exch(v, s, EMU_SITE);
+	return emu::exch(v, s, line_);
 }
-template <typename T> __attribute__((noinline)) T __shfl_xor(T v, int mask, int width = 64) {
+template <typename T> __attribute__((noinline)) T __shfl_xor(T v, int mask, int width = 64, int line_ = __builtin_LINE()) {
 	int l = (int)emu::lane_id();
 	int s = l ^ mask;
 	if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l;
-	return emu::exch(v, s, EMU_SITE);
+	return emu::exch(v, s, line_);
 }
-template <typename T> __attribute__((noinline)) T __shfl_up(T v, unsigned d, int width = 64) {
+template <typename T> __attribute__((noinline)) T __shfl_up(T v, unsigned d, int width = 64, int line_ = __builtin_LINE()) {
 	int l = (int)emu::lane_id();
 	int s = l - (int)d;
 	if (s < (l & ~(width - 1))) s = l;
-	return emu::exch(v, s, EMU_SITE);
+	return emu::exch(v, s, line_);
 }
-template <typename T> __attribute__((noinline)) T __shfl_down(T v, unsigned d, int width = 64) {
+template <typename T> __attribute__((noinline)) T __shfl_down(T v, unsigned d, int width = 64, int line_ = __builtin_LINE()) {
 	int l = (int)emu::lane_id();
 	int s = l + (int)d;
 	if (s > (l | (width - 1))) s = l;
-	return emu::exch(v, s, EMU_SITE);
+	return emu::exch(v, s, line_);
 }
-__attribute__((noinline)) inline unsigned long long __ballot(int pred) {
+__attribute__((noinline)) inline unsigned long long __ballot(int pred, int line_ = __builtin_LINE()) {
 	emu::Lane &L = emu::W->lane[emu::W->cur];
 	unsigned p = L.par & 1; ++L.par;
 	emu::W->slot[p][emu::W->cur] = pred ? 1 : 0;
-	emu::yield(EMU_SITE);
+	emu::yield(line_);
 	unsigned long long m = 0;
 	for (int i = 0; i < 64; ++i)
 		if (!emu::W->lane[i].done && emu::W->slot[p][i]) m |= 1ULL << i;
 	return m;
 }
-__attribute__((noinline)) inline int __any(int pred) { return __ballot(pred) != 0; }
-__attribute__((noinline)) inline int __all(int pred) {
-	unsigned long long live = __ballot(1);
-	return __ballot(pred) == live;
+__attribute__((noinline)) inline int __any(int pred, int line_ = __builtin_LINE()) { return __ballot(pred, line_) != 0; }
+__attribute__((noinline)) inline int __all(int pred, int line_ = __builtin_LINE()) {
+	unsigned long long live = __ballot(1, line_);
+	return __ballot(pred, line_) == live;
 }
+__attribute__((noinline)) inline void __builtin_amdgcn_wave_barrier(int line_ = __builtin_LINE()) { emu::yield(line_); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

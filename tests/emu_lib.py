@@ -27,6 +27,8 @@ def lib(rebuild=False):
         L.emu_index_free.argtypes = [C.c_void_p]
         L.emu_seed.restype = C.c_int
         L.emu_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.emu_align.restype = C.c_int
+        L.emu_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -48,3 +50,21 @@ def seed(h, nt4_bases: np.ndarray, off: np.ndarray, n_blocks=1, cap=512):
                          status.ctypes.data, n_blocks)
     assert got == cap
     return intv, n_intv, status
+
+
+REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
+                     [(n, "<i4") for n in ("qb", "qe", "rid", "score", "truesc", "sub", "csub", "w", "seedcov", "secondary",
+                                           "seedlen0", "n_comp", "is_alt")] + [("frac_rep", "<f4")], align=True)
+
+
+def align(h, nt4_bases, off, n_blocks=1, cap=256):
+    """K1 + K2 through the interpreter: per-read regions (structured array [n_reads, cap]), counts, status."""
+    n_reads = len(off) - 1
+    assert lib().emu_sizeof_reg() == REG_DTYPE.itemsize
+    regs = np.zeros((n_reads, cap), dtype=REG_DTYPE)
+    n_regs = np.zeros(n_reads, dtype=np.int32)
+    status = np.zeros(n_reads, dtype=np.int32)
+    got = lib().emu_align(h, nt4_bases.ctypes.data, off.ctypes.data, n_reads, regs.ctypes.data, n_regs.ctypes.data,
+                          status.ctypes.data, n_blocks)
+    assert got == cap
+    return regs, n_regs, status

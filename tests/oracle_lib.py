@@ -90,6 +90,8 @@ def lib():
         L.orc_ksw_align2.restype = Kswr
         L.orc_ksw_align2.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int8)] + \
             [C.c_int] * 5
+        L.orc_align1_core.restype = RegV
+        L.orc_align1_core.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int, C.c_char_p]
         L.orc_introsort_u64.argtypes = [C.c_size_t, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
@@ -149,3 +151,12 @@ def align_pair(idx: Index, opt, r1: bytes, r2: bytes):
         res[0 if k < out.n1 else 1].append(d)
     lib().orc_pair_out_free(C.byref(out))
     return res
+
+
+def align1(idx: Index, opt, read_ascii: bytes):
+    """Regions of one read after mem_align1_core (before mate rescue): list of dicts."""
+    q = C.create_string_buffer(NT4[np.frombuffer(read_ascii, dtype=np.uint8)].tobytes(), len(read_ascii))
+    v = lib().orc_align1_core(C.byref(opt), idx.h, len(read_ascii), q)
+    out = [{f: getattr(v.a[i], f) for f in REG_FIELDS} for i in range(v.n)]
+    C.CDLL(None).free(v.a)
+    return out

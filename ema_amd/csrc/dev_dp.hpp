@@ -51,10 +51,15 @@ __device__ __forceinline__ int ema_col_get(const int vals[EMA_NC], int j)
 	return __shfl(mine, j >> 2);
 }
 
-struct EmaSeq {          // a byte sequence read forwards (step 1) or backwards (step -1)
-	const uint8_t *p;
+struct EmaSeq {          // a byte sequence read forwards (step 1) or backwards (step -1); with pivot >= 0 (step 1)
+	const uint8_t *p;    // the prefix [0, pivot] is read reversed and the rest in place (ksw_align2's revseq on the target)
 	int step;
-	__device__ __forceinline__ int at(int i) const { return p[(long)i * step]; }
+	int pivot = -1;
+	__device__ __forceinline__ int at(int i) const
+	{
+		if (pivot >= 0) return i <= pivot ? p[pivot - i] : p[i];
+		return p[(long)i * step];
+	}
 };
 
 struct EmaExtRes { int score, qle, tle, gtle, gscore, max_off; };

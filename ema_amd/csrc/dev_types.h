@@ -74,6 +74,7 @@ struct DevReg {
 #define EMA_AV_CAP 2048       // regions of one read before dedup
 #define EMA_REG_CAP 256       // regions of one read handed to the next stage
 #define EMA_RSEQ_CAP 2048     // reference window bytes staged in LDS
+#define EMA_CIG_CAP 1024      // CIGAR ops of all candidates of one read
 
 // read status bits
 #define EMA_ST_INTV_OVERFLOW 1

@@ -20,6 +20,20 @@ extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
                                  uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream);
+struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
+extern "C" size_t ema_pair_slab_bytes();
+extern "C" size_t ema_final_slab_bytes();
+extern "C" size_t ema_sizeof_aln();
+extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
+                                int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, DevReg *regs, int *n_regs,
+                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream);
+extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
+                                 int n_reads, const DevReg *regs, const int *n_regs, DevAln *alns, uint32_t *cigars,
+                                 int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
+                                 hipStream_t stream);
+extern "C" void ema_launch_pack(int n_reads, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
+                                const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
+                                ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream);
 extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
                                        const uint32_t *toff, const int *prm, int n_tasks, int *out, hipStream_t s);
 extern "C" void ema_launch_test_global(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
@@ -85,6 +99,14 @@ struct ema_engine {
 	DevBuf<DevReg> d_regs;
 	DevBuf<int> d_n_regs, d_counters;
 	DevBuf<uint8_t> d_slabs;
+	// K3 / K4 / pack
+	int pair_blocks = 0, final_blocks = 0;
+	DevBuf<DevAln> d_alns;
+	DevBuf<uint32_t> d_cigars, d_cigar_out;
+	DevBuf<int> d_cig_n;
+	DevBuf<uint64_t> d_cand_off, d_cig_off;
+	DevBuf<ema_cand_t> d_cand;
+	size_t cand_cap = 0, cigar_out_cap = 0;
 	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	ema_engine_timing timing;
 };
@@ -116,7 +138,18 @@ static int engine_alloc_batch(ema_engine *e)
 	HIPCHK(e, e->d_n_regs.alloc(n_reads));
 	HIPCHK(e, e->d_counters.alloc(16));
 	e->align_blocks = e->n_cu * 2;  // 2 blocks x 4 waves = 8 resident waves per CU, one scratch slab each
-	HIPCHK(e, e->d_slabs.alloc((size_t)e->align_blocks * 4 * ema_align_slab_bytes()));
+	e->pair_blocks = e->n_cu * 2;
+	e->final_blocks = e->n_cu * 2;
+	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
+	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
+	if ((size_t)e->final_blocks * 4 * ema_final_slab_bytes() > slab) slab = (size_t)e->final_blocks * 4 * ema_final_slab_bytes();
+	HIPCHK(e, e->d_slabs.alloc(slab));
+	if (ema_sizeof_aln() != sizeof(DevAln)) { e->err = "DevAln layout mismatch"; return EMA_EDEVICE; }
+	HIPCHK(e, e->d_alns.alloc(n_reads * (size_t)EMA_REG_CAP));
+	HIPCHK(e, e->d_cigars.alloc(n_reads * (size_t)EMA_CIG_CAP));
+	HIPCHK(e, e->d_cig_n.alloc(n_reads));
+	HIPCHK(e, e->d_cand_off.alloc(n_reads + 1));
+	HIPCHK(e, e->d_cig_off.alloc(n_reads + 1));
 	return EMA_OK;
 }
 
@@ -170,6 +203,8 @@ void ema_engine_close(ema_engine_t *e)
 	e->d_bases.release(); e->d_off.release(); e->d_intv.release(); e->d_lists.release();
 	e->d_n_intv.release(); e->d_status.release();
 	e->d_regs.release(); e->d_n_regs.release(); e->d_counters.release(); e->d_slabs.release();
+	e->d_alns.release(); e->d_cigars.release(); e->d_cigar_out.release(); e->d_cig_n.release();
+	e->d_cand_off.release(); e->d_cig_off.release(); e->d_cand.release();
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
@@ -235,6 +270,25 @@ static int run_align(ema_engine *e)
 	return EMA_OK;
 }
 
+static int run_pair(ema_engine *e)
+{
+	ema_launch_pair(&e->dix, &e->dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high,
+	                e->d_bases.p, e->d_off.p, (int)e->n_pairs, e->d_regs.p, e->d_n_regs.p, e->d_status.p, e->d_slabs.p,
+	                e->d_counters.p + 1, e->pair_blocks, e->stream);
+	HIPCHK(e, hipGetLastError());
+	return EMA_OK;
+}
+
+static int run_final(ema_engine *e)
+{
+	const int n_reads = (int)(2 * e->n_pairs);
+	ema_launch_final(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_regs.p, e->d_n_regs.p, e->d_alns.p,
+	                 e->d_cigars.p, e->d_cig_n.p, EMA_CIG_CAP, e->d_status.p, e->d_slabs.p, e->d_counters.p + 2,
+	                 e->final_blocks, e->stream);
+	HIPCHK(e, hipGetLastError());
+	return EMA_OK;
+}
+
 int ema_engine_run(ema_engine_t *e)
 {
 	if (!e) return EMA_EARG;
@@ -246,6 +300,10 @@ int ema_engine_run(ema_engine_t *e)
 	HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
 	if ((rc = run_align(e))) return rc;
 	HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
+	if ((rc = run_pair(e))) return rc;
+	HIPCHK(e, hipEventRecord(e->ev[3], e->stream));
+	if ((rc = run_final(e))) return rc;
+	HIPCHK(e, hipEventRecord(e->ev[4], e->stream));
 	e->ran = true;
 	return EMA_OK;
 }
@@ -258,7 +316,9 @@ int ema_engine_sync(ema_engine_t *e)
 	if (e->ran) {
 		HIPCHK(e, hipEventElapsedTime(&e->timing.seed_ms, e->ev[0], e->ev[1]));
 		HIPCHK(e, hipEventElapsedTime(&e->timing.extend_ms, e->ev[1], e->ev[2]));
-		HIPCHK(e, hipEventElapsedTime(&e->timing.total_ms, e->ev[0], e->ev[2]));
+		HIPCHK(e, hipEventElapsedTime(&e->timing.rescue_ms, e->ev[2], e->ev[3]));
+		HIPCHK(e, hipEventElapsedTime(&e->timing.final_ms, e->ev[3], e->ev[4]));
+		HIPCHK(e, hipEventElapsedTime(&e->timing.total_ms, e->ev[0], e->ev[4]));
 	}
 	return EMA_OK;
 }
@@ -349,8 +409,43 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
 int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 {
 	if (!e || !out) return EMA_EARG;
-	e->err = "ema_engine_fetch: pipeline stages after seeding are not built yet";
-	return EMA_ESTATE;
+	*out = nullptr;
+	if (!e->ran) { e->err = "ema_engine_fetch before ema_engine_run"; return EMA_ESTATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	const size_t n_reads = 2 * e->n_pairs;
+	std::vector<int> n_regs(n_reads), cig_n(n_reads);
+	HIPCHK(e, hipMemcpy(n_regs.data(), e->d_n_regs.p, n_reads * 4, hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(cig_n.data(), e->d_cig_n.p, n_reads * 4, hipMemcpyDeviceToHost));
+	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+	o->n_pairs = e->n_pairs;
+	o->cand_off = (uint64_t *)malloc((n_reads + 1) * 8);
+	std::vector<uint64_t> cig_off(n_reads + 1);
+	o->cand_off[0] = 0; cig_off[0] = 0;
+	for (size_t r = 0; r < n_reads; ++r) {
+		o->cand_off[r + 1] = o->cand_off[r] + (uint64_t)n_regs[r];
+		cig_off[r + 1] = cig_off[r] + (uint64_t)cig_n[r];
+	}
+	const size_t n_cand = o->cand_off[n_reads], n_cig = cig_off[n_reads];
+	o->n_cigar = n_cig;
+	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
+	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
+	o->status = (int32_t *)malloc((n_reads + 1) * 4);
+	*out = o;
+	if (n_cand + 1 > e->cand_cap) { e->cand_cap = (n_cand + 1) * 5 / 4 + 1024; HIPCHK(e, e->d_cand.alloc(e->cand_cap)); }
+	if (n_cig + 1 > e->cigar_out_cap) { e->cigar_out_cap = (n_cig + 1) * 5 / 4 + 1024; HIPCHK(e, e->d_cigar_out.alloc(e->cigar_out_cap)); }
+	HIPCHK(e, hipMemcpyAsync(e->d_cand_off.p, o->cand_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, e->stream));
+	HIPCHK(e, hipMemcpyAsync(e->d_cig_off.p, cig_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, e->stream));
+	ema_launch_pack((int)n_reads, e->d_regs.p, e->d_n_regs.p, e->d_alns.p, e->d_cigars.p, e->d_cig_n.p, EMA_CIG_CAP,
+	                e->d_cand_off.p, e->d_cig_off.p, e->d_cand.p, e->d_cigar_out.p, e->n_cu * 4, e->stream);
+	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipMemcpyAsync(o->cand, e->d_cand.p, n_cand * sizeof(ema_cand_t), hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipMemcpyAsync(o->cigar, e->d_cigar_out.p, n_cig * 4, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipMemcpyAsync(o->status, e->d_status.p, n_reads * 4, hipMemcpyDeviceToHost, e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	for (size_t r = 0; r < n_reads; ++r)
+		if (o->status[r]) { e->err = "a read exceeded an engine capacity; see ema_batch_out.status"; return EMA_ELIMIT; }
+	return EMA_OK;
 }
 
 int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs, ema_batch_out **out)

@@ -1,0 +1,216 @@
+// ema_amd/csrc/k_final.hip -- K4: final alignment of every candidate region (CIGAR, NM, position), one
+// wavefront per read.
+//
+// Replaces the reference's bwa_smith_waterman() (reference src/bwabridge.c:301-311), which src/align.c calls
+// for every region of both mates (:1013, :1038), i.e. bwa's mem_reg2aln: band inference from the local score,
+// bwa_gen_cigar2 (gap-free fast path, or banded global alignment with traceback, retried with a doubled
+// band up to three times), NM over the CIGAR, squeezing of a terminal deletion, soft clips, and the
+// forward-strand position.  The read and the reference window sit in LDS; the direction matrix of the
+// global DP lives in the wave's slab of HBM scratch.
+#include <hip/hip_runtime.h>
+#include "dev_regions.hpp"
+#include "ema_engine.h"
+
+#define EMA_Z_BYTES ((size_t)256 * (EMA_RSEQ_CAP + 8))
+#define EMA_FINAL_SLAB_BYTES (EMA_Z_BYTES + 4096 * 4 + 1024)
+#define EMA_CIG_TMP 4096
+
+struct DevAln {           // per candidate: what interpret_single_read_alignment reads (reference src/bwabridge.c:359-379)
+	int64_t pos;
+	int32_t is_rev, NM, n_cigar;
+	uint32_t cigar_off;   // into the read's cigar pool
+};
+
+namespace {
+
+__device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q, int r)
+{
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+	const int d = l1 > l2 ? l1 - l2 : l2 - l1;
+	return w < d ? d : w;
+}
+
+}  // namespace
+
+// alns: n_reads x EMA_REG_CAP; cigars: n_reads x cig_cap ops (pool per read, regions in order)
+__global__ void __launch_bounds__(256)
+ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
+            const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
+            uint32_t *__restrict__ cigars, int *__restrict__ cig_n, int cig_cap, int *__restrict__ status,
+            uint8_t *__restrict__ slabs, int *__restrict__ counter)
+{
+	__shared__ uint8_t lds_q[4][256];
+	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
+	const int lane = (int)ema_lane();
+	const int wib = (int)(threadIdx.x >> 6);
+	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
+	uint8_t *z = slabs + (size_t)slot * EMA_FINAL_SLAB_BYTES;
+	uint32_t *ctmp = (uint32_t *)(z + EMA_Z_BYTES);
+	uint8_t *query = lds_q[wib], *rseq = lds_r[wib];
+	const int64_t l_pac = ix.l_pac;
+
+	for (;;) {
+		int read = 0;
+		if (lane == 0) read = atomicAdd(counter, 1);
+		read = __shfl(read, 0);
+		if (read >= n_reads) break;
+		const int l_query = (int)(off[read + 1] - off[read]);
+		const int nr = n_regs[read];
+		if (nr == 0) { if (lane == 0) cig_n[read] = 0; continue; }
+		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
+		ema_wave_sync();
+		uint32_t *pool = cigars + (size_t)read * cig_cap;
+		int pool_n = 0, st = 0;
+		for (int k = 0; k < nr; ++k) {
+			const DevReg ar = regs[(size_t)read * EMA_REG_CAP + k];
+			DevAln out;
+			out.pos = -1; out.is_rev = 0; out.NM = -1; out.n_cigar = 0; out.cigar_off = (uint32_t)pool_n;
+			const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+			const int64_t rb = ar.rb, re = ar.re;
+			const bool rev = rb >= l_pac;
+			const int rlen = (int)(re - rb);
+			const bool ok = lq > 0 && rb < re && !(rb < l_pac && re > l_pac) && rb >= 0 && re <= l_pac << 1 && rlen <= EMA_RSEQ_CAP;
+			if (!ok) { if (rlen > EMA_RSEQ_CAP) st |= EMA_ST_RSEQ_OVERFLOW; if (lane == 0) alns[(size_t)read * EMA_REG_CAP + k] = out; continue; }
+			ema_wave_fetch(ix, rb, re, rseq);
+			// reversed views so that indels are left-aligned on the forward strand (bwa_gen_cigar2)
+			const EmaSeq qs{rev ? query + qe - 1 : query + qb, rev ? -1 : 1};
+			const EmaSeq ts{rev ? rseq + rlen - 1 : rseq, rev ? -1 : 1};
+			int w2 = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_del, opt.e_del);
+			{
+				const int t = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+				w2 = w2 > t ? w2 : t;
+			}
+			if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+			int score = 0, last_sc = -(1 << 30), first = EMA_CIG_TMP, n_cig = 0;
+			for (int it = 0;;) {
+				w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+				if (lq == rlen && w2 == 0) {      // gap-free
+					int part = 0;
+					for (int i = lane; i < lq; i += EMA_WAVE) part += opt.mat[ts.at(i) * 5 + qs.at(i)];
+					part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+					part += __shfl_xor(part, 8); part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
+					score = part;
+					first = EMA_CIG_TMP - 1; n_cig = 1;
+					ema_wave_sync();
+					if (lane == 0) ctmp[first] = (uint32_t)lq << 4;
+					ema_wave_sync();
+				} else {
+					const int w = ema_cigar_band(opt, lq, rlen, w2);
+					score = ema_wave_global(opt, lq, qs, rlen, ts, w, z);
+					ema_wave_sync();
+					int f = 0;
+					if (lane == 0) f = ema_traceback(z, lq, rlen, w, ctmp, EMA_CIG_TMP);
+					f = __shfl(f, 0);
+					if (f < 0) { st |= EMA_ST_CIGAR_OVERFLOW; first = EMA_CIG_TMP; n_cig = 0; }
+					else { first = f; n_cig = EMA_CIG_TMP - f; }
+				}
+				if (score == last_sc || w2 == opt.w << 2) break;
+				last_sc = score;
+				w2 <<= 1;
+				if (!(++it < 3 && score < ar.truesc - opt.a)) break;
+			}
+			// NM: mismatches inside M + inserted bases + deleted bases of interior D ops
+			int nm = 0;
+			{
+				int x = 0, y = 0, n_gap = 0, n_mm = 0;
+				for (int c = 0; c < n_cig; ++c) {
+					const uint32_t op = ctmp[first + c] & 0xf, len = ctmp[first + c] >> 4;
+					if (op == 0) {
+						int part = 0;
+						for (int i = lane; i < (int)len; i += EMA_WAVE) part += qs.at(x + i) != ts.at(y + i);
+						n_mm += part;
+						x += len; y += len;
+					} else if (op == 2) {
+						if (c > 0 && c < n_cig - 1) n_gap += len;
+						y += len;
+					} else { x += len; n_gap += len; }
+				}
+				n_mm += __shfl_xor(n_mm, 1); n_mm += __shfl_xor(n_mm, 2); n_mm += __shfl_xor(n_mm, 4);
+				n_mm += __shfl_xor(n_mm, 8); n_mm += __shfl_xor(n_mm, 16); n_mm += __shfl_xor(n_mm, 32);
+				nm = n_mm + n_gap;
+			}
+			out.NM = n_cig > 0 ? nm : -1;
+			const int is_rev = (rb < l_pac ? rb : re - 1) >= l_pac;
+			int64_t pos = is_rev ? (l_pac << 1) - 1 - (re - 1) : rb;
+			out.is_rev = is_rev;
+			// squeeze out a leading or trailing deletion, then add the soft clips
+			int lo = first, hi = first + n_cig;
+			if (n_cig > 0) {
+				const uint32_t c0 = ctmp[lo], c1 = ctmp[hi - 1];
+				if ((c0 & 0xf) == 2) { pos += c0 >> 4; ++lo; }
+				else if ((c1 & 0xf) == 2) --hi;
+			}
+			const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+			const int n_final = (clip5 ? 1 : 0) + (hi - lo) + (clip3 ? 1 : 0);
+			if (pool_n + n_final > cig_cap) { st |= EMA_ST_CIGAR_OVERFLOW; }
+			else {
+				ema_wave_sync();
+				uint32_t *dst = pool + pool_n;
+				if (lane == 0 && clip5) dst[0] = (uint32_t)clip5 << 4 | 3;
+				const int o5 = clip5 ? 1 : 0;
+				for (int i = lane; i < hi - lo; i += EMA_WAVE) dst[o5 + i] = ctmp[lo + i];
+				if (lane == 0 && clip3) dst[o5 + hi - lo] = (uint32_t)clip3 << 4 | 3;
+				out.n_cigar = n_final;
+				pool_n += n_final;
+			}
+			const int rid = ema_pos2rid(ix, pos);
+			out.pos = rid >= 0 ? pos - ix.ctg_off[rid] : pos;
+			if (lane == 0) alns[(size_t)read * EMA_REG_CAP + k] = out;
+			ema_wave_sync();
+		}
+		if (lane == 0) { cig_n[read] = pool_n; if (st) atomicOr(status + read, st); }
+	}
+}
+
+// Packs the per-read slots into the contiguous arrays handed to the host: cand[cand_off[r] + k] and the
+// read's CIGAR ops at cigar[cig_off[r] ..).  One wave per read.
+__global__ void __launch_bounds__(256)
+ema_k_pack(int n_reads, const DevReg *__restrict__ regs, const int *__restrict__ n_regs, const DevAln *__restrict__ alns,
+           const uint32_t *__restrict__ cigars, const int *__restrict__ cig_n, int cig_cap,
+           const uint64_t *__restrict__ cand_off, const uint64_t *__restrict__ cig_off, ema_cand_t *__restrict__ cand,
+           uint32_t *__restrict__ cigar_out)
+{
+	const int lane = (int)ema_lane();
+	const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+	for (int r = wave; r < n_reads; r += n_waves) {
+		const int nr = n_regs[r];
+		const uint64_t co = cand_off[r], go = cig_off[r];
+		for (int k = lane; k < nr; k += EMA_WAVE) {
+			const DevReg g = regs[(size_t)r * EMA_REG_CAP + k];
+			const DevAln a = alns[(size_t)r * EMA_REG_CAP + k];
+			ema_cand_t c;
+			c.rb = g.rb; c.re = g.re; c.qb = g.qb; c.qe = g.qe; c.rid = g.rid; c.score = g.score; c.truesc = g.truesc;
+			c.sub = g.sub; c.alt_sc = 0; c.csub = g.csub; c.sub_n = 0; c.w = g.w; c.seedcov = g.seedcov;
+			c.secondary = g.secondary; c.secondary_all = 0; c.seedlen0 = g.seedlen0; c.n_comp = g.n_comp; c.is_alt = g.is_alt;
+			c.frac_rep = g.frac_rep;
+			c.pos = a.pos; c.is_rev = a.is_rev; c.NM = a.NM; c.n_cigar = a.n_cigar;
+			c.cigar_off = (uint32_t)(go + a.cigar_off);
+			c.aln_score = g.score; c.aln_sub = g.sub > g.csub ? g.sub : g.csub;
+			cand[co + k] = c;
+		}
+		const int nc = cig_n[r];
+		for (int k = lane; k < nc; k += EMA_WAVE) cigar_out[go + k] = cigars[(size_t)r * cig_cap + k];
+	}
+}
+
+extern "C" size_t ema_final_slab_bytes() { return EMA_FINAL_SLAB_BYTES; }
+
+extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
+                                 int n_reads, const DevReg *regs, const int *n_regs, DevAln *alns, uint32_t *cigars,
+                                 int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
+                                 hipStream_t stream)
+{
+	hipLaunchKernelGGL(ema_k_final, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, regs, n_regs, alns,
+	                   cigars, cig_n, cig_cap, status, slabs, counter);
+}
+
+extern "C" size_t ema_sizeof_aln() { return sizeof(DevAln); }
+
+extern "C" void ema_launch_pack(int n_reads, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
+                                const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
+                                ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream)
+{
+	hipLaunchKernelGGL(ema_k_pack, dim3(n_blocks), dim3(256), 0, stream, n_reads, regs, n_regs, alns, cigars, cig_n, cig_cap,
+	                   cand_off, cig_off, cand, cigar_out);
+}

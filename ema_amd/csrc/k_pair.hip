@@ -1,0 +1,187 @@
+// ema_amd/csrc/k_pair.hip -- K3: mate rescue, one wavefront per read pair.
+//
+// Replaces the two rescue loops of the reference's bridge (reference src/bwabridge.c:242-283) and the
+// mem_matesw / ksw_align2 they call in the un-vendored bwa: for up to 50 hits of mate 2 within 25 of its best
+// score, look for mate 1 in the window an FR pair with insert in [-35, 500] allows (local Smith-Waterman of
+// the reverse-complemented mate), insert what is found into mate 1's region list and re-run the dedup; then
+// the same for mate 2 around the hits of the updated mate-1 list, with the threshold taken from mate 1's
+// best score BEFORE rescue.
+//
+// Each mem_matesw call first looks for a region of the other mate that already forms a consistent pair and
+// returns at once if there is one -- and every call may change that list -- so the calls of a pair are
+// sequential; the wave runs them in order and spreads the consistency test (over regions), the window
+// fetch and the DP rows over its lanes.  Region lists are edited in a per-wave slab of HBM scratch and
+// written back in place.
+#include <hip/hip_runtime.h>
+#include "dev_regions.hpp"
+
+#define EMA_PAIR_SLAB_BYTES ((size_t)EMA_AV_CAP * (3 * sizeof(DevReg) + 8) + 2048 * 8 + 1024)
+
+namespace {
+
+struct PairCtx {
+	const DevIndex *ix;
+	const DevOpts *opt;
+	uint8_t *rc, *rseq;     // LDS: reverse complement of the mate being rescued; reference window
+	uint64_t *bsc;          // scratch for the local DP's b[] list
+	EmaRegWork wk;
+	int pes_low, pes_high;
+	int status;
+};
+
+__device__ __forceinline__ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t &dist)
+{
+	const int r1 = b1 >= l_pac, r2 = b2 >= l_pac;
+	const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+	dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+// mem_matesw with the reference's insert model (only FR allowed, pes[1] = {low, high}); ma = wk.a[0..n_ma)
+__device__ inline int matesw(PairCtx &cx, const DevReg &a, int l_ms, const uint8_t *ms, int n_ma)
+{
+	const DevIndex &ix = *cx.ix;
+	const DevOpts &o = *cx.opt;
+	const int lane = (int)ema_lane();
+	const int64_t l_pac = ix.l_pac;
+	// an FR-consistent region already present?
+	bool found = false;
+	for (int base = 0; base < n_ma && !found; base += EMA_WAVE) {
+		bool hit = false;
+		const int i = base + lane;
+		if (i < n_ma) {
+			int64_t dist;
+			const int r = infer_dir(l_pac, a.rb, cx.wk.a[i].rb, dist);
+			hit = r == 1 && dist >= cx.pes_low && dist <= cx.pes_high;
+		}
+		if (__ballot(hit)) found = true;
+	}
+	if (found) return n_ma;
+	// r = 1: the mate is reverse-complemented and lies at larger coordinates
+	for (int i = lane; i < l_ms; i += EMA_WAVE) { const int b = ms[i]; cx.rc[l_ms - 1 - i] = (uint8_t)(b < 4 ? 3 - b : 4); }
+	ema_wave_sync();
+	int64_t rb = a.rb + cx.pes_low - l_ms, re = a.rb + cx.pes_high;
+	if (rb < 0) rb = 0;
+	if (re > l_pac << 1) re = l_pac << 1;
+	int rid = -1;
+	if (rb < re) rid = ema_clamp_window(ix, rb, (rb + re) >> 1, re);
+	if (!(a.rid == rid && re - rb >= o.min_seed_len)) return n_ma;
+	if (re - rb > EMA_RSEQ_CAP) { cx.status |= EMA_ST_RSEQ_OVERFLOW; return n_ma; }
+	const int tlen = (int)(re - rb);
+	ema_wave_fetch(ix, rb, re, cx.rseq);
+	// ksw_align2 with KSW_XSUBO | KSW_XSTART | (l_ms * a < 250 ? KSW_XBYTE : 0) | min_seed_len * a
+	const int p = l_ms * o.a < 250 ? 16 : 8;
+	const int minsc = o.min_seed_len * o.a;
+	const EmaLocalRes r1 = ema_wave_local(o, l_ms, p, EmaSeq{cx.rc, 1}, tlen, EmaSeq{cx.rseq, 1}, minsc, 0x10000, cx.bsc);
+	int qb = -1, tb = -1;
+	if (r1.score >= minsc) {      // start coordinates: the same DP on the reversed prefixes, stopping at the score
+		EmaSeq tq{cx.rc + r1.qe, -1};
+		EmaSeq tt{cx.rseq, 1, r1.te};
+		const EmaLocalRes r2 = ema_wave_local(o, r1.qe + 1, p, tq, tlen, tt, 0x10000, r1.score, cx.bsc);
+		if (r1.score == r2.score) { tb = r1.te - r2.te; qb = r1.qe - r2.qe; }
+	}
+	int n = n_ma;
+	if (r1.score >= o.min_seed_len && qb >= 0) {
+		DevReg b;
+		b.rid = a.rid; b.is_alt = a.is_alt;
+		b.qb = l_ms - (r1.qe + 1); b.qe = l_ms - qb;
+		b.rb = (l_pac << 1) - (rb + r1.te + 1); b.re = (l_pac << 1) - (rb + tb);
+		b.score = r1.score; b.csub = r1.score2; b.secondary = -1;
+		b.truesc = 0; b.sub = 0; b.w = 0; b.seedlen0 = 0; b.n_comp = 0; b.frac_rep = 0.f;
+		b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+		if (n_ma >= EMA_AV_CAP) { cx.status |= EMA_ST_REG_OVERFLOW; }
+		else {
+			ema_wave_sync();
+			if (lane == 0) {      // keep the list ordered: before the first element with a smaller score
+				int at = 0;
+				while (at < n_ma && !(cx.wk.a[at].score < b.score)) ++at;
+				for (int i = n_ma; i > at; --i) cx.wk.a[i] = cx.wk.a[i - 1];
+				cx.wk.a[at] = b;
+			}
+			ema_wave_sync();
+			n = n_ma + 1;
+		}
+	}
+	return ema_sort_dedup_patch(ix, o, nullptr, n, cx.wk, cx.status);     // runs whenever the SW ran
+}
+
+}  // namespace
+
+// regs/n_regs: K2's output, updated in place.  One wave per pair, pairs taken from a shared counter.
+__global__ void __launch_bounds__(256)
+ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_low, int pes_high,
+           const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_pairs, DevReg *__restrict__ regs,
+           int *__restrict__ n_regs, int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter)
+{
+	__shared__ uint8_t lds_q[4][2][256];
+	__shared__ uint8_t lds_rc[4][256];
+	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
+	__shared__ int lds_stack[4][3 * 70];
+	const int lane = (int)ema_lane();
+	const int wib = (int)(threadIdx.x >> 6);
+	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
+	uint8_t *slab = slabs + (size_t)slot * EMA_PAIR_SLAB_BYTES;
+	DevReg *av[2] = {(DevReg *)slab, (DevReg *)slab + EMA_AV_CAP};
+	PairCtx cx;
+	cx.ix = &ix; cx.opt = &opt;
+	cx.rc = lds_rc[wib]; cx.rseq = lds_r[wib];
+	cx.wk.tmp = (DevReg *)slab + 2 * EMA_AV_CAP;
+	cx.wk.keys = (uint64_t *)((DevReg *)slab + 3 * EMA_AV_CAP);
+	cx.bsc = cx.wk.keys + EMA_AV_CAP;
+	cx.wk.stack = lds_stack[wib];
+	cx.wk.rseq = lds_r[wib];
+	cx.pes_low = pes_low; cx.pes_high = pes_high;
+
+	for (;;) {
+		int pair = 0;
+		if (lane == 0) pair = atomicAdd(counter, 1);
+		pair = __shfl(pair, 0);
+		if (pair >= n_pairs) break;
+		int len[2], n[2], best[2] = {0, 0};
+		for (int m = 0; m < 2; ++m) {
+			const int r = 2 * pair + m;
+			len[m] = (int)(off[r + 1] - off[r]);
+			n[m] = n_regs[r];
+			for (int i = lane; i < len[m]; i += EMA_WAVE) lds_q[wib][m][i] = bases[off[r] + i];
+			const DevReg *src = regs + (size_t)r * EMA_REG_CAP;
+			int b = 0;
+			for (int i = lane; i < n[m]; i += EMA_WAVE) { const DevReg x = src[i]; av[m][i] = x; b = b > x.score ? b : x.score; }
+			best[m] = ema_wave_max(b);
+		}
+		ema_wave_sync();
+		cx.status = 0;
+		// reference src/bwabridge.c:263-269: rescue mate 1 (index 0) from the hits of mate 2, then :277-283 the other way
+		for (int dirn = 0; dirn < 2; ++dirn) {
+			const int anchor = dirn == 0 ? 1 : 0, target = 1 - anchor;
+			const int n_anchor = n[anchor];
+			int num = 0;
+			cx.wk.a = av[target];
+			for (int k = 0; k < n_anchor && num < max_rescue; ++k) {
+				const DevReg a = av[anchor][k];
+				if (a.score >= best[anchor] - score_delta) {
+					++num;
+					n[target] = matesw(cx, a, len[target], lds_q[wib][target], n[target]);
+				}
+			}
+		}
+		for (int m = 0; m < 2; ++m) {
+			const int r = 2 * pair + m;
+			int cnt = n[m];
+			if (cnt > EMA_REG_CAP) { cx.status |= EMA_ST_REG_OVERFLOW; cnt = EMA_REG_CAP; }
+			DevReg *dst = regs + (size_t)r * EMA_REG_CAP;
+			for (int i = lane; i < cnt; i += EMA_WAVE) dst[i] = av[m][i];
+			if (lane == 0) { n_regs[r] = cnt; if (cx.status) atomicOr(status + r, cx.status); }
+		}
+		ema_wave_sync();
+	}
+}
+
+extern "C" size_t ema_pair_slab_bytes() { return EMA_PAIR_SLAB_BYTES; }
+
+extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
+                                int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, DevReg *regs, int *n_regs,
+                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream)
+{
+	hipLaunchKernelGGL(ema_k_pair, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, score_delta, max_rescue, pes_low, pes_high,
+	                   bases, off, n_pairs, regs, n_regs, status, slabs, counter);
+}

@@ -10,6 +10,8 @@
 #include "k_seed.hip"
 #include "k_dp_test.hip"
 #include "k_align.hip"
+#include "k_pair.hip"
+#include "k_final.hip"
 
 extern "C" {
 
@@ -79,4 +81,33 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	return EMA_REG_CAP;
 }
 int emu_sizeof_reg() { return (int)sizeof(DevReg); }
+
+// the whole pipeline K1..K4 on host memory (n_reads even: pairs)
+int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, void *regs, int *n_regs, void *alns,
+                 uint32_t *cigars, int *cig_n, int *status, int upto)
+{
+	HostIndex *ix = (HostIndex *)h;
+	ema_engine_opts eo; ema_fill_default_opts(&eo);
+	DevOpts d = ema_make_dev_opts(eo);
+	DevIndex di = ix->view();
+	std::vector<Intv> intv((size_t)n_reads * EMA_INTV_CAP);
+	std::vector<int> n_intv(n_reads);
+	std::vector<Intv> lists((size_t)1 * 256 / 8 * 2 * EMA_LIST_CAP);
+	for (int i = 0; i < n_reads; ++i) status[i] = 0;
+	ema_launch_seed(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), status, lists.data(), 1, nullptr);
+	size_t slab = ema_align_slab_bytes();
+	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
+	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
+	std::vector<uint8_t> slabs((size_t)4 * slab);
+	int counter[3] = {0, 0, 0};
+	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
+	                 &counter[0], 1, nullptr);
+	if (upto >= 3)
+		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, (DevReg *)regs,
+		                n_regs, status, slabs.data(), &counter[1], 1, nullptr);
+	if (upto >= 4)
+		ema_launch_final(&di, &d, bases, off, n_reads, (DevReg *)regs, n_regs, (DevAln *)alns, cigars, cig_n, EMA_CIG_CAP, status,
+		                 slabs.data(), &counter[2], 1, nullptr);
+	return EMA_CIG_CAP;
+}
 }

@@ -68,3 +68,24 @@ def align(h, nt4_bases, off, n_blocks=1, cap=256):
                           status.ctypes.data, n_blocks)
     assert got == cap
     return regs, n_regs, status
+
+
+ALN_DTYPE = np.dtype([("pos", "<i8"), ("is_rev", "<i4"), ("NM", "<i4"), ("n_cigar", "<i4"), ("cigar_off", "<u4")])
+
+
+def pipeline(h, nt4_bases, off, upto=4, cap=256, cig_cap=1024):
+    """K1..K4 through the interpreter.  Returns regs, n_regs, alns, cigars, cig_n, status (per read)."""
+    n_reads = len(off) - 1
+    L = lib()
+    L.emu_pipeline.restype = C.c_int
+    L.emu_pipeline.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int]
+    regs = np.zeros((n_reads, cap), dtype=REG_DTYPE)
+    n_regs = np.zeros(n_reads, dtype=np.int32)
+    alns = np.zeros((n_reads, cap), dtype=ALN_DTYPE)
+    cigars = np.zeros((n_reads, cig_cap), dtype=np.uint32)
+    cig_n = np.zeros(n_reads, dtype=np.int32)
+    status = np.zeros(n_reads, dtype=np.int32)
+    got = L.emu_pipeline(h, nt4_bases.ctypes.data, off.ctypes.data, n_reads, regs.ctypes.data, n_regs.ctypes.data,
+                         alns.ctypes.data, cigars.ctypes.data, cig_n.ctypes.data, status.ctypes.data, upto)
+    assert got == cig_cap
+    return regs, n_regs, alns, cigars, cig_n, status

@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/ema_engine.h declares, and it fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ema_engine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ema_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from ema_amd import engine
+    L = engine.load_library()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ema_engine.h but not exported by libema_engine.so"
+    for n in engine.SYMBOLS:
+        assert n in names, f"binding uses {n}, which the header does not declare"
+
+
+def test_default_options_match_the_reference():
+    from ema_amd import engine
+    o = engine.default_opts()
+    # mem_opt_init() of bwa 0.7.x, max_occ = 3000 (reference src/align.c:185), bridge constants (src/bwabridge.c:216-227, src/align.c:1005)
+    assert (o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins) == (1, 4, 6, 1, 6, 1)
+    assert (o.w, o.zdrop, o.pen_clip5, o.pen_clip3, o.min_seed_len) == (100, 100, 5, 5, 19)
+    assert o.max_occ == 3000 and o.max_mem_intv == 20 and o.split_width == 10
+    assert (o.score_delta, o.max_rescue, o.pes_low, o.pes_high) == (25, 50, -35, 500)
+
+
+def test_open_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from ema_amd.engine import Engine
+    with pytest.raises(RuntimeError) as ei:
+        Engine("/nonexistent/ref.fa")
+    assert "no HIP device" in str(ei.value) or "failed" in str(ei.value)
+
+
+def test_index_builder_exports():
+    L = C.CDLL(os.path.join(ROOT, "ema_amd", "libema_index.so"))
+    assert hasattr(L, "ema_index_build")

@@ -1,0 +1,95 @@
+"""End-to-end GPU parity of the hot path through the C ABI: for every pair, the candidate lists of both mates
+(regions after mate rescue, in the reference's order) with position, strand, NM and CIGAR must be identical to
+the oracle's restatement of bwa_mem_mate_sw + bwa_smith_waterman (reference src/bwabridge.c:204-311)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import small_ref
+from ema_amd import synth
+from ema_amd.engine import Engine, default_opts
+
+pytestmark = pytest.mark.gpu
+FIELDS = [f for f in O.REG_FIELDS]
+
+
+def compare(prefix, pairs, batch):
+    idx, opt = O.Index(prefix), O.default_opt()
+    bad = []
+    for p in range(pairs.n):
+        ref = O.align_pair(idx, opt, pairs.read(2 * p), pairs.read(2 * p + 1))
+        for m in range(2):
+            got = []
+            for c in batch.mate(p, m):
+                d = {f: (float(c[f]) if f == "frac_rep" else int(c[f])) for f in FIELDS}
+                d.update(pos=int(c["pos"]), is_rev=int(c["is_rev"]), NM=int(c["NM"]), cigar=batch.cigar_of(c).tolist())
+                got.append(d)
+            rf = []
+            for d in ref[m]:
+                d = dict(d)
+                d["frac_rep"] = float(np.float32(d["frac_rep"]))
+                rf.append(d)
+            if rf != got:
+                bad.append((p, m))
+    return bad
+
+
+def _check(kind, n_pairs, seed, **kw):
+    prefix, ctg = small_ref(kind)
+    pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
+    eng = Engine(prefix)
+    batch = eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()
+    assert batch.status.max() == 0
+    bad = compare(prefix, pairs, batch)
+    assert not bad, f"{len(bad)} of {2 * pairs.n} reads differ from the oracle, first {bad[:5]}"
+
+
+def test_pipeline_clean():
+    _check("two_contigs", 1500, 41)
+
+
+def test_pipeline_noisy_reads_trigger_rescue():
+    _check("two_contigs", 800, 42, sub_rate=0.09, indel_rate=0.003)
+
+
+def test_pipeline_chimeric_and_n():
+    _check("two_contigs", 600, 43, chimeric=0.3, n_rate=0.004)
+
+
+def test_pipeline_repeats():
+    _check("repeats", 600, 44)
+
+
+def test_pipeline_empty_and_ragged_batches():
+    prefix, ctg = small_ref("two_contigs")
+    eng = Engine(prefix)
+    # empty batch
+    b = eng.align_pairs(np.zeros(0, np.uint8), np.zeros(1, np.uint32))
+    assert len(b.cand) == 0 and len(b.cand_off) == 1
+    # ragged: reads shorter than the seed length, 1-base reads, all-N reads next to normal ones
+    pairs = synth.make_pairs(ctg, 8, seed=45)
+    reads = [pairs.read(i) for i in range(16)]
+    reads[1] = reads[1][:10]
+    reads[2] = b"A"
+    reads[5] = b"N" * 60
+    reads[6] = reads[6][:19]
+    reads[9] = b""
+    off = np.zeros(17, np.uint32)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    batch = eng.align_pairs(bases, off)
+    eng.close()
+    rag = synth.Pairs(bases, off)
+    assert not compare(prefix, rag, batch)
+
+
+def test_capacity_is_enforced():
+    prefix, ctg = small_ref("two_contigs")
+    o = default_opts()
+    o.batch_pairs = 16
+    eng = Engine(prefix, opts=o)
+    pairs = synth.make_pairs(ctg, 32, seed=46)
+    with pytest.raises(RuntimeError):
+        eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()

@@ -10,10 +10,55 @@
 
 __device__ __forceinline__ unsigned ema_lane() { return threadIdx.x & 63u; }
 
-// Wave-level ordering point.  The lanes of a wavefront execute in lock-step, so this emits no instruction; it
-// stops the compiler from moving memory operations across it and marks the places where one lane's stores are
-// about to be read by the others (or where old values must have been read before the leader lane overwrites them).
-__device__ __forceinline__ void ema_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// Wave-level ordering point, used wherever lanes of one wavefront communicate through memory (one lane's stores
+// are about to be read by the others, or old values must have been read before the leader lane overwrites them).
+// The lanes execute in lock-step and share one path to memory, so no instruction is needed -- but the compiler
+// must be told: to it every lane is an independent thread whose earlier loads stay valid until that thread
+// itself stores.  The wavefront-scope fence (no code at this scope) makes it drop values cached in registers
+// and keeps loads/stores from moving across this point.
+__device__ __forceinline__ void ema_wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// Marks a value that is the same in every lane of the wavefront ("wave-uniform"): it is read from lane 0 into a
+// scalar register, so loops and branches on it become scalar branches (no exec-mask bookkeeping, fewer VGPRs) and
+// every lane provably follows the same path into the cross-lane operations that follow.
+__device__ __forceinline__ int ema_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool ema_uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ int64_t ema_uni(int64_t v)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+	return (int64_t)((uint64_t)hi << 32 | lo);
+}
+__device__ __forceinline__ uint64_t ema_uni(uint64_t v) { return (uint64_t)ema_uni((int64_t)v); }
+__device__ __forceinline__ float ema_uni(float v) { return __int_as_float(ema_uni(__float_as_int(v))); }
+__device__ __forceinline__ SeedRec ema_uni(const SeedRec &s)
+{
+	SeedRec r; r.rbeg = ema_uni(s.rbeg); r.qbeg = ema_uni(s.qbeg); r.len = ema_uni(s.len); r.next = ema_uni(s.next); r.pad = 0;
+	return r;
+}
+__device__ __forceinline__ ChainRec ema_uni(const ChainRec &c)
+{
+	ChainRec r;
+	r.pos = ema_uni(c.pos); r.f_rbeg = ema_uni(c.f_rbeg); r.l_rbeg = ema_uni(c.l_rbeg);
+	r.f_qbeg = ema_uni(c.f_qbeg); r.l_qbeg = ema_uni(c.l_qbeg); r.l_len = ema_uni(c.l_len);
+	r.rid = ema_uni(c.rid); r.n = ema_uni(c.n); r.first_seed = ema_uni(c.first_seed); r.last_seed = ema_uni(c.last_seed);
+	r.w = ema_uni(c.w); r.kept = ema_uni(c.kept); r.first = ema_uni(c.first);
+	return r;
+}
+__device__ __forceinline__ DevReg ema_uni(const DevReg &g)
+{
+	DevReg r;
+	r.rb = ema_uni(g.rb); r.re = ema_uni(g.re); r.qb = ema_uni(g.qb); r.qe = ema_uni(g.qe); r.rid = ema_uni(g.rid);
+	r.score = ema_uni(g.score); r.truesc = ema_uni(g.truesc); r.sub = ema_uni(g.sub); r.csub = ema_uni(g.csub);
+	r.w = ema_uni(g.w); r.seedcov = ema_uni(g.seedcov); r.secondary = ema_uni(g.secondary); r.seedlen0 = ema_uni(g.seedlen0);
+	r.n_comp = ema_uni(g.n_comp); r.is_alt = ema_uni(g.is_alt); r.frac_rep = ema_uni(g.frac_rep);
+	return r;
+}
 
 // ---------------------------------------------------------------------------------------------
 // occ4 on the HBM block layout of dev_types.h, computed by FOUR adjacent lanes.

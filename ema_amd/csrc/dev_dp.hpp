@@ -27,7 +27,7 @@ __device__ __forceinline__ int ema_wave_max(int v)
 {
 	v = max(v, __shfl_xor(v, 1)); v = max(v, __shfl_xor(v, 2)); v = max(v, __shfl_xor(v, 4));
 	v = max(v, __shfl_xor(v, 8)); v = max(v, __shfl_xor(v, 16)); v = max(v, __shfl_xor(v, 32));
-	return v;
+	return ema_uni(v);
 }
 // exclusive prefix max over lanes (lane 0 gets EMA_NEG_BIG)
 __device__ __forceinline__ int ema_wave_exscan_max(int v)
@@ -48,7 +48,7 @@ __device__ __forceinline__ int ema_col_get(const int vals[EMA_NC], int j)
 {
 	const int c = j & (EMA_NC - 1);
 	const int mine = c == 0 ? vals[0] : c == 1 ? vals[1] : c == 2 ? vals[2] : vals[3];
-	return __shfl(mine, j >> 2);
+	return ema_uni(__shfl(mine, j >> 2));
 }
 
 struct EmaSeq {          // a byte sequence read forwards (step 1) or backwards (step -1); with pivot >= 0 (step 1)
@@ -105,7 +105,7 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 	int mx_sc = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
 	int beg = 0, end = qlen;
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = target.at(i);
+		const int tb = ema_uni(target.at(i));
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
@@ -219,7 +219,7 @@ __device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, 
 		qb[c] = j < qlen ? query.at(j) : 4;
 	}
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = target.at(i);
+		const int tb = ema_uni(target.at(i));
 		const int beg = i > w ? i - w : 0;
 		const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1_init = beg == 0 ? -(o.o_del + e_del * (i + 1)) : EMA_DP_MINUS_INF;
@@ -330,7 +330,7 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 	int n_b = 0;
 	int last_sc = 0, last_row = -2;                 // copy of b[n_b-1]
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = target.at(i);
+		const int tb = ema_uni(target.at(i));
 		const int up = __shfl_up(hh[EMA_NC - 1], 1);     // H(i-1, 4*lane-1)
 		int Hd[EMA_NC], g[EMA_NC];
 		int run = EMA_NEG_BIG;
@@ -393,7 +393,7 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 			if (j < qpad && hmax[c] == gmax && best < 0) best = j;
 		}
 		const unsigned long long b = __ballot(best >= 0);
-		if (b) r.qe = __shfl(best, __ffsll((long long)b) - 1);
+		if (b) r.qe = ema_uni(__shfl(best, __ffsll((long long)b) - 1));
 		if (te < 0) r.qe = -1;
 	}
 	if (n_b > 0) {
@@ -417,11 +417,12 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 			t = __shfl_xor(best, 8); best = best > t ? best : t;
 			t = __shfl_xor(best, 16); best = best > t ? best : t;
 			t = __shfl_xor(best, 32); best = best > t ? best : t;
+			best = (long long)ema_uni((int64_t)best);
 		}
 		if (best >= 0) {
 			const int k = 0x7fffffff - (int)(best & 0xffffffffLL);
 			r.score2 = (int)(best >> 32);
-			r.te2 = (int)(uint32_t)bsc[k];
+			r.te2 = ema_uni((int)(uint32_t)bsc[k]);
 		}
 	}
 	return r;

@@ -48,7 +48,7 @@ __device__ inline bool ema_global_score(const DevIndex &ix, const DevOpts &o, in
 		for (int i = (int)ema_lane(); i < l_query; i += EMA_WAVE) part += o.mat[rseq[i] * 5 + query[i]];
 		part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
 		part += __shfl_xor(part, 8); part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
-		score = part;
+		score = ema_uni(part);
 		return true;
 	}
 	const int w = ema_cigar_band(o, l_query, rlen, w_);
@@ -112,12 +112,12 @@ __device__ inline int ema_sort_dedup_patch(const DevIndex &ix, const DevOpts &o,
 	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) a[i].n_comp = 1;
 	ema_wave_sync();
 	for (int i = 1; i < n; ++i) {
-		DevReg p = a[i];
-		const DevReg pr = a[i - 1];
+		DevReg p = ema_uni(a[i]);
+		const DevReg pr = ema_uni(a[i - 1]);
 		if (p.rid != pr.rid || p.rb >= pr.re + o.max_chain_gap) continue;
 		bool p_dirty = false;
 		for (int j = i - 1; j >= 0; --j) {
-			const DevReg q = a[j];
+			const DevReg q = ema_uni(a[j]);
 			if (!(p.rid == q.rid && p.rb < q.re + o.max_chain_gap)) break;
 			if (q.qe == q.qb) continue;
 			const int64_t or_ = q.re - p.rb;
@@ -155,7 +155,7 @@ __device__ inline int ema_sort_dedup_patch(const DevIndex &ix, const DevOpts &o,
 			const DevReg r = a[i];
 			if (r.qe > r.qb) { if (m != i) a[m] = r; ++m; }
 		}
-	n = __shfl(m, 0);
+	n = ema_uni(__shfl(m, 0));
 	// sort by (score desc, rb asc, qb asc) (ks_introsort(mem_ars)) on an index permutation
 	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) wk.keys[i] = (uint64_t)i;
 	ema_wave_sync();
@@ -177,7 +177,7 @@ __device__ inline int ema_sort_dedup_patch(const DevIndex &ix, const DevOpts &o,
 			if (r.qe > r.qb) { if (m != i) a[m] = r; ++m; }
 		}
 	}
-	m = __shfl(m, 0);
+	m = ema_uni(__shfl(m, 0));
 	return m;
 }
 

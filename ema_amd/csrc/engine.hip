@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <string>
 #include <vector>
 #include "ema_engine.h"
@@ -19,7 +20,7 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream);
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" size_t ema_pair_slab_bytes();
 extern "C" size_t ema_final_slab_bytes();
@@ -264,9 +265,26 @@ static int run_seed(ema_engine *e)
 static int run_align(ema_engine *e)
 {
 	const int n_reads = (int)(2 * e->n_pairs);
+	int *dbg = nullptr;
+	const bool want_dbg = getenv("EMA_DEBUG_PROGRESS") != nullptr;      // development aid: watch a stuck launch
+	if (want_dbg) {
+		HIPCHK(e, hipHostMalloc((void **)&dbg, (size_t)e->align_blocks * 4 * 4 * sizeof(int), hipHostMallocDefault));
+		memset(dbg, 0xff, (size_t)e->align_blocks * 4 * 4 * sizeof(int));
+	}
 	ema_launch_align(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_regs.p,
-	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream);
+	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream, dbg);
 	HIPCHK(e, hipGetLastError());
+	if (want_dbg) {
+		for (int t = 0; t < 50 && hipStreamQuery(e->stream) == hipErrorNotReady; ++t) usleep(100000);
+		if (hipStreamQuery(e->stream) == hipErrorNotReady) {
+			fprintf(stderr, "ema_k_align still running after 5 s; per-wave progress (slot: read stage value):\n");
+			for (int sl = 0; sl < e->align_blocks * 4; ++sl)
+				if (dbg[sl * 4] >= 0 && dbg[sl * 4 + 1] != 9) fprintf(stderr, "  %d: %d %d %d\n", sl, dbg[sl * 4], dbg[sl * 4 + 1], dbg[sl * 4 + 2]);
+			fflush(stderr);
+			_exit(3);
+		}
+		(void)hipHostFree(dbg);
+	}
 	return EMA_OK;
 }
 

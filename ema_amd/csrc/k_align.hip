@@ -97,11 +97,11 @@ __device__ inline void chain_insert(const DevOpts &o, int64_t l_pac, ChainBuild 
 	int at = 0, lower = -1;
 	if (cb.n_chain) {
 		const int lo = lower_bound_pos(cb.sl.cpos, cb.n_chain, rbeg);
-		if (lo < cb.n_chain && cb.sl.cpos[lo] == rbeg) { lower = cb.sl.cord[lo]; at = lo + 1; }
-		else if (lo > 0) { lower = cb.sl.cord[lo - 1]; at = lo; }
+		if (lo < cb.n_chain && ema_uni(cb.sl.cpos[lo]) == rbeg) { lower = ema_uni(cb.sl.cord[lo]); at = lo + 1; }
+		else if (lo > 0) { lower = ema_uni(cb.sl.cord[lo - 1]); at = lo; }
 	}
 	if (lower >= 0) {   // test_and_merge
-		ChainRec c = cb.sl.chains[lower];
+		ChainRec c = ema_uni(cb.sl.chains[lower]);
 		const int64_t qend = c.l_qbeg + c.l_len, rend = c.l_rbeg + c.l_len;
 		bool open_new = false;
 		if (rid != c.rid) open_new = true;
@@ -179,8 +179,9 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 __global__ void __launch_bounds__(256)
 ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
-            int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter)
+            int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
 {
+#define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
 	__shared__ int lds_stack[4][3 * 70];
@@ -197,13 +198,15 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 	for (;;) {
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
-		read = __shfl(read, 0);
+		read = ema_uni(__shfl(read, 0));
 		if (read >= n_reads) break;
-		const int l_query = (int)(off[read + 1] - off[read]);
+		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		EMA_DBG(1, 0);
+		const int l_query = ema_uni((int)(off[read + 1] - off[read]));
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
 		ema_wave_sync();
 		const Intv *iv = intv + (size_t)read * EMA_INTV_CAP;
-		const int n_iv = n_intv[read];
+		const int n_iv = ema_uni(n_intv[read]);
 		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
 
 		// ---------------- mem_chain: frac_rep, seed occurrences, chaining ----------------
@@ -221,6 +224,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		}
 		const float frac_rep = (float)l_rep / (float)l_query;
 		for (int i = 0; i < n_iv; ++i) {
+			EMA_DBG(2, i);
 			const Intv p = iv[i];
 			const int qbeg = (int)(p.info >> 32), slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
 			const int64_t step = p.x2 > (uint64_t)opt.max_occ ? (int64_t)(p.x2 / (uint64_t)opt.max_occ) : 1;
@@ -235,8 +239,8 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 				}
 				const int cnt = (int)(n_occ - base < EMA_WAVE ? n_occ - base : EMA_WAVE);
 				for (int t = 0; t < cnt; ++t) {
-					const int64_t rb = __shfl(rbeg, t);
-					const int rd = __shfl(rid, t);
+					const int64_t rb = ema_uni(__shfl(rbeg, t));
+					const int rd = ema_uni(__shfl(rid, t));
 					if (rd < 0) continue;
 					chain_insert(opt, l_pac, cb, rb, qbeg, slen, rd);
 				}
@@ -245,6 +249,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 
 		// ---------------- mem_chain_flt ----------------
 		int n_chn = cb.n_chain, n_keep = 0;
+		EMA_DBG(3, n_chn);
 		if (n_chn > 0) {
 			for (int i = lane; i < n_chn; i += EMA_WAVE) {      // weights, chains taken in position order
 				const int id = sl.cord[i];
@@ -256,15 +261,16 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			ema_wave_sync();
 			if (lane == 0) ema_introsort(sl.skey, n_chn, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, lds_stack[wib]);
 			ema_wave_sync();
+			EMA_DBG(4, n_chn);
 			int n_kept = 0;
 			{
-				const int id0 = (int)(uint32_t)sl.skey[0];
+				const int id0 = ema_uni((int)(uint32_t)sl.skey[0]);
 				if (lane == 0) { sl.chains[id0].kept = 3; sl.kept[0] = 0; }
 				n_kept = 1;
 			}
 			for (int i = 1; i < n_chn; ++i) {
-				const int ci = (int)(uint32_t)sl.skey[i];
-				const ChainRec a_i = sl.chains[ci];
+				const int ci = ema_uni((int)(uint32_t)sl.skey[i]);
+				const ChainRec a_i = ema_uni(sl.chains[ci]);
 				const int beg_i = a_i.f_qbeg, end_i = a_i.l_qbeg + a_i.l_len;
 				bool large_ovlp = false, dropped = false;
 				for (int base = 0; base < n_kept && !dropped; base += EMA_WAVE) {
@@ -309,14 +315,16 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
 		int n_av = 0;
+		EMA_DBG(5, n_keep);
 		for (int ci_sorted = 0; ci_sorted < n_keep; ++ci_sorted) {
-			const int cid = (int)(uint32_t)sl.skey[ci_sorted];
-			const ChainRec c = sl.chains[cid];
+			EMA_DBG(6, ci_sorted);
+			const int cid = ema_uni((int)(uint32_t)sl.skey[ci_sorted]);
+			const ChainRec c = ema_uni(sl.chains[cid]);
 			if (c.kept == 0) continue;
 			const int cn = c.n;
 			{   // gather the chain's seeds
 				int k = c.first_seed;
-				for (int t = 0; t < cn; ++t) { const SeedRec s = sl.seeds[k]; if (lane == 0) sl.cs[t] = s; k = s.next; }
+				for (int t = 0; t < cn; ++t) { const SeedRec s = ema_uni(sl.seeds[k]); if (lane == 0) sl.cs[t] = s; k = s.next; }
 				ema_wave_sync();
 			}
 			int64_t rmax0 = l_pac << 1, rmax1 = 0;
@@ -334,6 +342,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 				rmax0 = rmax0 < o0 ? rmax0 : o0;
 				rmax1 = rmax1 > o1 ? rmax1 : o1;
 			}
+			rmax0 = ema_uni(rmax0); rmax1 = ema_uni(rmax1);
 			rmax0 = rmax0 > 0 ? rmax0 : 0;
 			rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
 			if (rmax0 < l_pac && l_pac < rmax1) {
@@ -348,7 +357,8 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			ema_wave_sync();
 
 			for (int k = cn - 1; k >= 0; --k) {
-				const SeedRec s = sl.cs[(int)(uint32_t)sl.srt[k]];
+				EMA_DBG(7, k);
+				const SeedRec s = ema_uni(sl.cs[(int)(uint32_t)sl.srt[k]]);
 				// already covered by an earlier extension of this read?
 				bool covered = false;
 				for (int base = 0; base < n_av && !covered; base += EMA_WAVE) {
@@ -437,7 +447,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 					}
 					cov += __shfl_xor(cov, 1); cov += __shfl_xor(cov, 2); cov += __shfl_xor(cov, 4);
 					cov += __shfl_xor(cov, 8); cov += __shfl_xor(cov, 16); cov += __shfl_xor(cov, 32);
-					a.seedcov = cov;
+					a.seedcov = ema_uni(cov);
 				}
 				a.w = aw0 > aw1 ? aw0 : aw1;
 				a.seedlen0 = s.len;
@@ -449,6 +459,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		}
 
 		// ---------------- mem_sort_dedup_patch ----------------
+		EMA_DBG(8, n_av);
 		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq;
 		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
 		if (n_out > EMA_REG_CAP) { cb.status |= EMA_ST_REG_OVERFLOW; n_out = EMA_REG_CAP; }
@@ -456,15 +467,17 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		DevReg *dst = regs + (size_t)read * EMA_REG_CAP;
 		for (int i = lane; i < n_out; i += EMA_WAVE) dst[i] = sl.av[i];
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
+		EMA_DBG(9, n_out);
 	}
+#undef EMA_DBG
 }
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream)
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg)
 {
 	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, intv, n_intv, regs,
-	                   n_regs, status, slabs, counter);
+	                   n_regs, status, slabs, counter, dbg);
 }

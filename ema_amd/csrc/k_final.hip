@@ -53,17 +53,17 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 	for (;;) {
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
-		read = __shfl(read, 0);
+		read = ema_uni(__shfl(read, 0));
 		if (read >= n_reads) break;
 		const int l_query = (int)(off[read + 1] - off[read]);
-		const int nr = n_regs[read];
+		const int nr = ema_uni(n_regs[read]);
 		if (nr == 0) { if (lane == 0) cig_n[read] = 0; continue; }
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
 		ema_wave_sync();
 		uint32_t *pool = cigars + (size_t)read * cig_cap;
 		int pool_n = 0, st = 0;
 		for (int k = 0; k < nr; ++k) {
-			const DevReg ar = regs[(size_t)read * EMA_REG_CAP + k];
+			const DevReg ar = ema_uni(regs[(size_t)read * EMA_REG_CAP + k]);
 			DevAln out;
 			out.pos = -1; out.is_rev = 0; out.NM = -1; out.n_cigar = 0; out.cigar_off = (uint32_t)pool_n;
 			const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
@@ -90,7 +90,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 					for (int i = lane; i < lq; i += EMA_WAVE) part += opt.mat[ts.at(i) * 5 + qs.at(i)];
 					part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
 					part += __shfl_xor(part, 8); part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
-					score = part;
+					score = ema_uni(part);
 					first = EMA_CIG_TMP - 1; n_cig = 1;
 					ema_wave_sync();
 					if (lane == 0) ctmp[first] = (uint32_t)lq << 4;
@@ -101,7 +101,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 					ema_wave_sync();
 					int f = 0;
 					if (lane == 0) f = ema_traceback(z, lq, rlen, w, ctmp, EMA_CIG_TMP);
-					f = __shfl(f, 0);
+					f = ema_uni(__shfl(f, 0));
 					if (f < 0) { st |= EMA_ST_CIGAR_OVERFLOW; first = EMA_CIG_TMP; n_cig = 0; }
 					else { first = f; n_cig = EMA_CIG_TMP - f; }
 				}
@@ -115,7 +115,8 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			{
 				int x = 0, y = 0, n_gap = 0, n_mm = 0;
 				for (int c = 0; c < n_cig; ++c) {
-					const uint32_t op = ctmp[first + c] & 0xf, len = ctmp[first + c] >> 4;
+					const uint32_t cw = (uint32_t)ema_uni((int)ctmp[first + c]);
+					const uint32_t op = cw & 0xf, len = cw >> 4;
 					if (op == 0) {
 						int part = 0;
 						for (int i = lane; i < (int)len; i += EMA_WAVE) part += qs.at(x + i) != ts.at(y + i);
@@ -128,7 +129,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 				}
 				n_mm += __shfl_xor(n_mm, 1); n_mm += __shfl_xor(n_mm, 2); n_mm += __shfl_xor(n_mm, 4);
 				n_mm += __shfl_xor(n_mm, 8); n_mm += __shfl_xor(n_mm, 16); n_mm += __shfl_xor(n_mm, 32);
-				nm = n_mm + n_gap;
+				nm = ema_uni(n_mm) + n_gap;
 			}
 			out.NM = n_cig > 0 ? nm : -1;
 			const int is_rev = (rb < l_pac ? rb : re - 1) >= l_pac;
@@ -137,7 +138,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			// squeeze out a leading or trailing deletion, then add the soft clips
 			int lo = first, hi = first + n_cig;
 			if (n_cig > 0) {
-				const uint32_t c0 = ctmp[lo], c1 = ctmp[hi - 1];
+				const uint32_t c0 = (uint32_t)ema_uni((int)ctmp[lo]), c1 = (uint32_t)ema_uni((int)ctmp[hi - 1]);
 				if ((c0 & 0xf) == 2) { pos += c0 >> 4; ++lo; }
 				else if ((c1 & 0xf) == 2) --hi;
 			}

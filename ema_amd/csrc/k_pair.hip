@@ -135,13 +135,13 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 	for (;;) {
 		int pair = 0;
 		if (lane == 0) pair = atomicAdd(counter, 1);
-		pair = __shfl(pair, 0);
+		pair = ema_uni(__shfl(pair, 0));
 		if (pair >= n_pairs) break;
 		int len[2], n[2], best[2] = {0, 0};
 		for (int m = 0; m < 2; ++m) {
 			const int r = 2 * pair + m;
-			len[m] = (int)(off[r + 1] - off[r]);
-			n[m] = n_regs[r];
+			len[m] = ema_uni((int)(off[r + 1] - off[r]));
+			n[m] = ema_uni(n_regs[r]);
 			for (int i = lane; i < len[m]; i += EMA_WAVE) lds_q[wib][m][i] = bases[off[r] + i];
 			const DevReg *src = regs + (size_t)r * EMA_REG_CAP;
 			int b = 0;
@@ -157,7 +157,7 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 			int num = 0;
 			cx.wk.a = av[target];
 			for (int k = 0; k < n_anchor && num < max_rescue; ++k) {
-				const DevReg a = av[anchor][k];
+				const DevReg a = ema_uni(av[anchor][k]);
 				if (a.score >= best[anchor] - score_delta) {
 					++num;
 					n[target] = matesw(cx, a, len[target], lds_q[wib][target], n[target]);

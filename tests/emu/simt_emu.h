@@ -153,6 +153,23 @@ __attribute__((noinline)) inline int __all(int pred, int line_ = __builtin_LINE(
 	return __ballot(pred, line_) == live;
 }
 __attribute__((noinline)) inline void __builtin_amdgcn_wave_barrier(int line_ = __builtin_LINE()) { emu::yield(line_); }
+// readfirstlane: value of the first live lane; the interpreter also checks that the value really is wave-uniform
+__attribute__((noinline)) inline int __builtin_amdgcn_readfirstlane(int v, int line_ = __builtin_LINE()) {
+	emu::Lane &L = emu::W->lane[emu::W->cur];
+	unsigned p = L.par & 1; ++L.par;
+	emu::W->slot[p][emu::W->cur] = (uint64_t)(uint32_t)v;
+	emu::yield(line_);
+	int first = -1;
+	for (int i = 0; i < 64; ++i) if (!emu::W->lane[i].done) { first = i; break; }
+	const int r = (int)(uint32_t)emu::W->slot[p][first];
+	if (r != v) { fprintf(stderr, "simt_emu: value marked wave-uniform at line %d differs between lanes (%d vs %d)\n", line_, v, r); abort(); }
+	return r;
+}
+inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+inline void __builtin_amdgcn_fence(int, const char *) {}
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+template <typename T> inline void __hip_atomic_store(T *p, T v, int, int) { *p = v; }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned read pairs/s of the `ema align` seed-and-extend hot path on MI355X.
+
+One "step" = one pass of the whole hot path (K1 seeding -> K2 chaining/extension -> K3 mate rescue -> K4 final
+alignment) over one batch of synthetic read pairs that is already resident in HBM, i.e. exactly the work the
+reference does per pair in append_alignments() (reference src/align.c:1005-1038: bwa_mem_mate_sw + one
+bwa_smith_waterman per candidate), for `pairs_per_step` pairs.  Index build, read generation, upload and result
+download are outside the timed region.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU: barcode buckets are independent, so every rank aligns its own bucket of the same size
+against its own replica of the index -- weak scaling, no collective on the data path; the per-bucket statistics
+(pairs, candidates, mapped mates) are gathered over RCCL at the end.
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
+  roofline     : HBM roofline of the dominant kernel (algorithmic bytes from the oracle's instrumentation of the
+                 same reads / that kernel's mean launch time from HIP events on the engine's stream)
+  cpu_baseline : the oracle (a CPU restatement, NOT upstream bwa: parity unpinned) timed on the host cores on a
+                 bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+CHR20_LEN = 64_444_167
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(args, rank, world, workdir):
+    """Synthetic genome + index (built once, by rank 0) and this rank's bucket of read pairs."""
+    from ema_amd import synth, build_index
+    prefix = os.path.join(workdir, "ref.fa")
+    if args.genome_mbp > 0:
+        lens = [int(args.genome_mbp * 1e6)]
+        gname = f"synthetic {args.genome_mbp:g} Mbp, 1 contig"
+    else:
+        lens = [CHR20_LEN]
+        gname = "synthetic chr20-scale (64,444,167 bp, 1 contig)"
+    t = time.time()
+    ctg = synth.make_genome(lens, seed=synth.GENOME_SEED)
+    log(f"[rank {rank}] genome {gname}: {time.time() - t:.1f}s")
+    if rank == 0:
+        t = time.time()
+        synth.write_fasta(prefix, ctg, names=["chr20"])
+        build_index(prefix)
+        log(f"[rank 0] index built in {time.time() - t:.1f}s")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t = time.time()
+    pairs = synth.make_pairs(ctg, args.pairs, seed=synth.READS_SEED + 7919 * rank, len1=127, len2=150)
+    log(f"[rank {rank}] {args.pairs} pairs simulated in {time.time() - t:.1f}s")
+    return prefix, pairs, gname
+
+
+def algorithmic_bytes(stats, sa_width):
+    """bytes the algorithm must move per unit, from the oracle's counters on the same reads.
+    K1 (seeding): two 64-byte occ blocks per bwt_extend + the read.  K2..K4: SA rows, reference windows (2 bit/base),
+    region records, CIGAR ops."""
+    k1 = 128 * stats["n_ext"] + stats["l_read"]
+    rest = sa_width * stats["n_occ"] + stats["w_ref"] // 4 + 88 * stats["n_regs"] + 4 * stats["n_cigar"]
+    return k1, rest
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=262144, help="pairs per step and per GPU (one resident batch)")
+    ap.add_argument("--genome-mbp", type=float, default=0.0, help="0 = chr20-scale (64.4 Mbp)")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload timed on the host CPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.ensure_built()
+    if world > 1:
+        dist.barrier()
+
+    import tempfile
+    workdir = os.environ.get("EMA_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "ema_bench_%d" % os.getuid())
+    os.makedirs(workdir, exist_ok=True)
+    prefix, pairs, gname = build_workload(args, rank, world, workdir)
+
+    from ema_amd.engine import Engine, default_opts
+    o = default_opts()
+    o.batch_pairs = args.pairs
+    t = time.time()
+    eng = Engine(prefix, device=local, opts=o)
+    log(f"[rank {rank}] engine open (index in HBM) {time.time() - t:.1f}s")
+    eng.stage(pairs.bases, pairs.off)          # nt4 conversion + H2D: outside the timed region
+
+    def sync_all():
+        eng.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.run()
+    sync_all()
+    kernel_ms = {k: 0.0 for k in ("seed_ms", "extend_ms", "rescue_ms", "final_ms", "total_ms")}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run()
+        eng.sync()                              # per-step sync keeps the per-kernel HIP-event times of every step
+        tm = eng.timing()
+        for k in kernel_ms:
+            kernel_ms[k] += tm[k]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    for k in kernel_ms:
+        kernel_ms[k] /= max(1, args.steps)
+
+    # results of the last step: parity spot check against the oracle + bucket statistics
+    batch = eng.fetch()
+    n_cand = int(batch.cand_off[-1])
+    mapped = int((np.diff(batch.cand_off.astype(np.int64)) > 0).sum())
+    stats_vec = np.array([pairs.n, n_cand, mapped, int(batch.status.max())], dtype=np.int64)
+    if world > 1:
+        # the "trivial RCCL gather of per-bucket statistics" of the north star: O(100 B) per rank over xGMI
+        mine = torch.from_numpy(stats_vec).cuda()
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        gathered = torch.stack(allv).cpu().numpy()
+    else:
+        gathered = stats_vec[None, :]
+
+    out = None
+    if rank == 0:
+        import oracle_lib as O
+        idx, opt = O.Index(prefix), O.default_opt()
+        # spot check: the first pairs of the bucket must equal the oracle bit for bit
+        n_chk = min(200, pairs.n)
+        bad = 0
+        for p in range(n_chk):
+            ref = O.align_pair(idx, opt, pairs.read(2 * p), pairs.read(2 * p + 1))
+            for m in range(2):
+                got = [(int(c["rb"]), int(c["re"]), int(c["qb"]), int(c["qe"]), int(c["score"]), int(c["pos"]), int(c["NM"]),
+                        batch.cigar_of(c).tolist()) for c in batch.mate(p, m)]
+                exp = [(d["rb"], d["re"], d["qb"], d["qe"], d["score"], d["pos"], d["NM"], d["cigar"]) for d in ref[m]]
+                bad += got != exp
+        if bad:
+            log(f"WARNING: {bad} reads of the {n_chk}-pair spot check differ from the oracle")
+        # algorithmic bytes: the oracle's counters on a sample of the SAME reads, scaled to the batch
+        n_s = min(args.cpu_sample, pairs.n)
+        sample = pairs.subset(0, n_s)
+        O.stats_reset()
+        t_1, _ = O.bench_pairs(idx, opt, sample.bases[:sample.off[2 * min(n_s, 4000)]], sample.off[:2 * min(n_s, 4000) + 1], 1)
+        st = O.stats_get()
+        scale = pairs.n / float(min(n_s, 4000))
+        k1_bytes, rest_bytes = algorithmic_bytes(st, 4)
+        k1_bytes *= scale
+        rest_bytes *= scale
+        parts = {"k1_seed": (k1_bytes, kernel_ms["seed_ms"]), "k2_align": (rest_bytes, kernel_ms["extend_ms"])}
+        dom = "k1_seed" if kernel_ms["seed_ms"] >= kernel_ms["extend_ms"] else "k2_align"
+        dom_bytes, dom_ms = parts[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": {"k1_seed": "ema_k_seed", "k2_align": "ema_k_align"}[dom],
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(dom_bytes), "kernel_ms": round(dom_ms, 3),
+                    "all_kernels_ms": {k: round(v, 3) for k, v in kernel_ms.items()}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cores = len(os.sched_getaffinity(0))
+            secs, _ = O.bench_pairs(idx, opt, sample.bases, sample.off, cores)
+            cpu = {"value": round(n_s / secs, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
+                   "sample": f"first {n_s} pairs of the same bucket, oracle/ (CPU restatement, not upstream bwa), "
+                             f"{cores} OpenMP threads, {secs:.1f}s; 1 thread: {min(n_s, 4000) / t_1:.1f} pairs/s"}
+        total_pairs = int(gathered[:, 0].sum()) * args.steps
+        value = total_pairs / elapsed
+        out = {
+            "metric": "aligned read-pairs/sec (2x150 bp) on the seed-and-extend hot path", "value": round(value, 1),
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32/u64 (integer DP, FM-index ranks)", "data": "synthetic",
+            "config": {"workload": f"10x-style FR pairs R1=127 bp (150-16-7) R2=150 bp, 0.5% subs, 0.05% indels, 1% chimeric; "
+                                   f"{args.pairs} pairs per GPU per step, one barcode bucket per GPU, resident in HBM; "
+                                   f"reference = {gname} with injected repeat families "
+                                   f"(GRCh38-scale index of BASELINE configs[1] needs the GPU suffix-array builder: next)",
+                       "pairs_per_step_per_gpu": args.pairs, "max_occ": 3000, "parallelism": f"buckets x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "bucket_stats": {"pairs": int(gathered[:, 0].sum()), "candidates": int(gathered[:, 1].sum()),
+                             "reads_with_candidates": int(gathered[:, 2].sum()), "capacity_flags": int(gathered[:, 3].max()),
+                             "oracle_spot_check_mismatches": int(bad)},
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,9 @@ struct EmaRegWork {
 	uint64_t *keys;   // same capacity
 	int *stack;       // introsort frames (>= 3 * 66 ints)
 	uint8_t *rseq;    // EMA_RSEQ_CAP bytes for a reference window
+	int *mark = nullptr;   // development aid: this wave's progress words (host-visible) or null
 };
+#define EMA_MARK(wk, stage, val) do { if ((wk).mark && ema_lane() == 0) { __hip_atomic_store((wk).mark + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store((wk).mark + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 
 // band of bwa_gen_cigar2
 __device__ __forceinline__ int ema_cigar_band(const DevOpts &o, int l_query, int rlen, int w_)
@@ -86,10 +88,10 @@ __device__ inline int ema_patch_reg(const DevIndex &ix, const DevOpts &o, const 
 	return score;
 }
 
-// gathers a[] into the order given by the low 16 bits of keys[]
+// gathers a[] into the order given by the low 11 bits of keys[]
 __device__ __forceinline__ void ema_reg_permute(EmaRegWork &wk, int n)
 {
-	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) wk.tmp[i] = wk.a[(int)(wk.keys[i] & 0xffff)];
+	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) wk.tmp[i] = wk.a[(int)(wk.keys[i] & 0x7ff)];
 	ema_wave_sync();
 	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) wk.a[i] = wk.tmp[i];
 	ema_wave_sync();
@@ -103,20 +105,25 @@ __device__ inline int ema_sort_dedup_patch(const DevIndex &ix, const DevOpts &o,
 	if (n <= 1) return n;
 	const bool leader = ema_lane() == 0;
 	DevReg *a = wk.a;
-	// sort by END position (ks_introsort(mem_ars2)): keys = re << 16 | index, compared on re only
-	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) wk.keys[i] = (uint64_t)a[i].re << 16 | (uint64_t)i;
+	EMA_MARK(wk, 20, n);
+	// sort by END position (ks_introsort(mem_ars2)): keys = re << 11 | index (EMA_AV_CAP = 2048), compared on re only
+	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) wk.keys[i] = (uint64_t)a[i].re << 11 | (uint64_t)i;
 	ema_wave_sync();
-	if (leader) ema_introsort(wk.keys, n, [](uint64_t x, uint64_t y) { return (x >> 16) < (y >> 16); }, wk.stack);
+	if (leader) ema_introsort(wk.keys, n, [](uint64_t x, uint64_t y) { return (x >> 11) < (y >> 11); }, wk.stack);
 	ema_wave_sync();
+	EMA_MARK(wk, 21, n);
 	ema_reg_permute(wk, n);
+	EMA_MARK(wk, 22, n);
 	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) a[i].n_comp = 1;
 	ema_wave_sync();
 	for (int i = 1; i < n; ++i) {
+		EMA_MARK(wk, 23, i);
 		DevReg p = ema_uni(a[i]);
 		const DevReg pr = ema_uni(a[i - 1]);
 		if (p.rid != pr.rid || p.rb >= pr.re + o.max_chain_gap) continue;
 		bool p_dirty = false;
 		for (int j = i - 1; j >= 0; --j) {
+			EMA_MARK(wk, 24, i * 1000 + j);
 			const DevReg q = ema_uni(a[j]);
 			if (!(p.rid == q.rid && p.rb < q.re + o.max_chain_gap)) break;
 			if (q.qe == q.qb) continue;
@@ -149,6 +156,7 @@ __device__ inline int ema_sort_dedup_patch(const DevIndex &ix, const DevOpts &o,
 		if (p_dirty && leader) a[i] = p;
 	}
 	ema_wave_sync();
+	EMA_MARK(wk, 25, n);
 	int m = 0;
 	if (leader)
 		for (int i = 0; i < n; ++i) {      // drop excluded regions
@@ -156,16 +164,21 @@ __device__ inline int ema_sort_dedup_patch(const DevIndex &ix, const DevOpts &o,
 			if (r.qe > r.qb) { if (m != i) a[m] = r; ++m; }
 		}
 	n = ema_uni(__shfl(m, 0));
-	// sort by (score desc, rb asc, qb asc) (ks_introsort(mem_ars)) on an index permutation
-	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) wk.keys[i] = (uint64_t)i;
+	EMA_MARK(wk, 26, n);
+	// sort by (score desc, rb asc, qb asc) (ks_introsort(mem_ars)).  The three fields are packed into one word
+	// above the region's index (10 + 35 + 8 bits: scores < 1024, forward-reverse coordinates < 2^35, reads <= 255),
+	// so the comparison on (key >> 11) is mem_ars's comparison and the sort needs no look-ups.
+	for (int i = (int)ema_lane(); i < n; i += EMA_WAVE) {
+		const DevReg r = a[i];
+		wk.keys[i] = (uint64_t)(1023 - (r.score < 0 ? 0 : r.score > 1023 ? 1023 : r.score)) << 54 | (uint64_t)(r.rb & 0x7ffffffffLL) << 19 |
+		             (uint64_t)(r.qb & 0xff) << 11 | (uint64_t)i;
+	}
 	ema_wave_sync();
-	if (leader)
-		ema_introsort(wk.keys, n, [a](uint64_t x, uint64_t y) {
-			const DevReg &u = a[(int)x], &v = a[(int)y];
-			return u.score > v.score || (u.score == v.score && (u.rb < v.rb || (u.rb == v.rb && u.qb < v.qb)));
-		}, wk.stack);
+	if (leader) ema_introsort(wk.keys, n, [](uint64_t x, uint64_t y) { return (x >> 11) < (y >> 11); }, wk.stack);
 	ema_wave_sync();
+	EMA_MARK(wk, 27, n);
 	ema_reg_permute(wk, n);
+	EMA_MARK(wk, 28, n);
 	m = n > 0 ? 1 : 0;
 	if (leader) {
 		for (int i = 1; i < n; ++i) {      // identical hits

@@ -27,11 +27,11 @@ extern "C" size_t ema_final_slab_bytes();
 extern "C" size_t ema_sizeof_aln();
 extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
                                 int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, DevReg *regs, int *n_regs,
-                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream);
+                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg);
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const DevReg *regs, const int *n_regs, DevAln *alns, uint32_t *cigars,
                                  int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int *dbg);
 extern "C" void ema_launch_pack(int n_reads, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
                                 ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream);
@@ -43,6 +43,9 @@ extern "C" void ema_launch_test_global(const DevOpts *opt, const uint8_t *qbuf, 
 extern "C" void ema_launch_test_local(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
                                       const uint32_t *toff, const int *prm, int n_tasks, int *out, uint64_t *bsc,
                                       size_t b_stride, hipStream_t s);
+
+extern "C" void ema_launch_test_dedup(const DevIndex *ix, const DevOpts *opt, DevReg *regs, const int *n_in, int *n_out, int cap,
+                                      int n_tasks, DevReg *tmp, uint64_t *keys, hipStream_t s);
 
 namespace {
 
@@ -108,6 +111,10 @@ struct ema_engine {
 	DevBuf<uint64_t> d_cand_off, d_cig_off;
 	DevBuf<ema_cand_t> d_cand;
 	size_t cand_cap = 0, cigar_out_cap = 0;
+	// development aid (EMA_WATCHDOG_S=<seconds>): host-visible per-wave progress words + a poll after every launch
+	int *dbg = nullptr;
+	int dbg_slots = 0;
+	double watchdog_s = 0;
 	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	ema_engine_timing timing;
 };
@@ -190,6 +197,14 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
 
+	if (const char *wd = getenv("EMA_WATCHDOG_S")) {
+		e->watchdog_s = atof(wd);
+		e->dbg_slots = e->n_cu * 2 * 4 + 64;
+		if (!getenv("EMA_WATCHDOG_NOMARK")) {
+			HIPCHK(e, hipHostMalloc((void **)&e->dbg, (size_t)e->dbg_slots * 4 * sizeof(int), hipHostMallocDefault));
+			memset(e->dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
+		}
+	}
 	e->cap_pairs = e->opts.batch_pairs > 0 ? (size_t)e->opts.batch_pairs : (size_t)131072;
 	int rc = engine_alloc_batch(e);
 	if (rc != EMA_OK) return rc;
@@ -251,6 +266,23 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 	return EMA_OK;
 }
 
+// EMA_WATCHDOG_S: wait for the stream with a deadline; on expiry print where every unfinished wave is and exit
+static void watchdog(ema_engine *e, const char *what)
+{
+	if (e->watchdog_s <= 0) return;
+	const int n_poll = (int)(e->watchdog_s * 100);
+	for (int t = 0; t < n_poll && hipStreamQuery(e->stream) == hipErrorNotReady; ++t) usleep(10000);
+	if (hipStreamQuery(e->stream) == hipErrorNotReady) {
+		fprintf(stderr, "%s still running after %.1f s; unfinished waves (slot: unit stage value):\n", what, e->watchdog_s);
+		int shown = 0;
+		for (int sl = 0; sl < e->dbg_slots && shown < 64; ++sl)
+			if (e->dbg && e->dbg[sl * 4] >= 0 && e->dbg[sl * 4 + 1] != 9) { fprintf(stderr, "  %d: %d %d %d 0x%x\n", sl, e->dbg[sl * 4], e->dbg[sl * 4 + 1], e->dbg[sl * 4 + 2], e->dbg[sl * 4 + 3]); ++shown; }
+		fflush(stderr);
+		_exit(3);
+	}
+	if (e->dbg) memset(e->dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
+}
+
 static int run_seed(ema_engine *e)
 {
 	const int n_reads = (int)(2 * e->n_pairs);
@@ -259,32 +291,17 @@ static int run_seed(ema_engine *e)
 	ema_launch_seed(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_status.p,
 	                e->d_lists.p, e->seed_blocks, e->stream);
 	HIPCHK(e, hipGetLastError());
+	watchdog(e, "ema_k_seed");
 	return EMA_OK;
 }
 
 static int run_align(ema_engine *e)
 {
 	const int n_reads = (int)(2 * e->n_pairs);
-	int *dbg = nullptr;
-	const bool want_dbg = getenv("EMA_DEBUG_PROGRESS") != nullptr;      // development aid: watch a stuck launch
-	if (want_dbg) {
-		HIPCHK(e, hipHostMalloc((void **)&dbg, (size_t)e->align_blocks * 4 * 4 * sizeof(int), hipHostMallocDefault));
-		memset(dbg, 0xff, (size_t)e->align_blocks * 4 * 4 * sizeof(int));
-	}
 	ema_launch_align(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_regs.p,
-	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream, dbg);
+	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream, e->dbg);
 	HIPCHK(e, hipGetLastError());
-	if (want_dbg) {
-		for (int t = 0; t < 50 && hipStreamQuery(e->stream) == hipErrorNotReady; ++t) usleep(100000);
-		if (hipStreamQuery(e->stream) == hipErrorNotReady) {
-			fprintf(stderr, "ema_k_align still running after 5 s; per-wave progress (slot: read stage value):\n");
-			for (int sl = 0; sl < e->align_blocks * 4; ++sl)
-				if (dbg[sl * 4] >= 0 && dbg[sl * 4 + 1] != 9) fprintf(stderr, "  %d: %d %d %d\n", sl, dbg[sl * 4], dbg[sl * 4 + 1], dbg[sl * 4 + 2]);
-			fflush(stderr);
-			_exit(3);
-		}
-		(void)hipHostFree(dbg);
-	}
+	watchdog(e, "ema_k_align");
 	return EMA_OK;
 }
 
@@ -292,8 +309,9 @@ static int run_pair(ema_engine *e)
 {
 	ema_launch_pair(&e->dix, &e->dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high,
 	                e->d_bases.p, e->d_off.p, (int)e->n_pairs, e->d_regs.p, e->d_n_regs.p, e->d_status.p, e->d_slabs.p,
-	                e->d_counters.p + 1, e->pair_blocks, e->stream);
+	                e->d_counters.p + 1, e->pair_blocks, e->stream, e->dbg);
 	HIPCHK(e, hipGetLastError());
+	watchdog(e, "ema_k_pair");
 	return EMA_OK;
 }
 
@@ -302,8 +320,9 @@ static int run_final(ema_engine *e)
 	const int n_reads = (int)(2 * e->n_pairs);
 	ema_launch_final(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_regs.p, e->d_n_regs.p, e->d_alns.p,
 	                 e->d_cigars.p, e->d_cig_n.p, EMA_CIG_CAP, e->d_status.p, e->d_slabs.p, e->d_counters.p + 2,
-	                 e->final_blocks, e->stream);
+	                 e->final_blocks, e->stream, e->dbg);
 	HIPCHK(e, hipGetLastError());
+	watchdog(e, "ema_k_final");
 	return EMA_OK;
 }
 
@@ -384,6 +403,26 @@ int ema_engine_debug_regions(ema_engine_t *e, void **regs, int32_t **n_regs, int
 	HIPCHK(e, hipMemcpy(*status, e->d_status.p, n_reads * 4, hipMemcpyDeviceToHost));
 	*cap_per_read = EMA_REG_CAP;
 	*reg_bytes = (int32_t)sizeof(DevReg);
+	return EMA_OK;
+}
+
+int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int32_t *n_out, int cap, int n_tasks)
+{
+	if (!e || !regs || !n_in || !n_out || cap <= 0 || n_tasks <= 0) return EMA_EARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	DevBuf<DevReg> dr, dt;
+	DevBuf<uint64_t> dk;
+	DevBuf<int> dn, dm;
+	const size_t tot = (size_t)n_tasks * cap;
+	HIPCHK(e, dr.alloc(tot)); HIPCHK(e, dt.alloc(tot)); HIPCHK(e, dk.alloc(tot)); HIPCHK(e, dn.alloc(n_tasks)); HIPCHK(e, dm.alloc(n_tasks));
+	HIPCHK(e, hipMemcpy(dr.p, regs, tot * sizeof(DevReg), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(dn.p, n_in, (size_t)n_tasks * 4, hipMemcpyHostToDevice));
+	ema_launch_test_dedup(&e->dix, &e->dopts, dr.p, dn.p, dm.p, cap, n_tasks, dt.p, dk.p, e->stream);
+	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipMemcpy(regs, dr.p, tot * sizeof(DevReg), hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(n_out, dm.p, (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
+	dr.release(); dt.release(); dk.release(); dn.release(); dm.release();
 	return EMA_OK;
 }
 

@@ -460,7 +460,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 
 		// ---------------- mem_sort_dedup_patch ----------------
 		EMA_DBG(8, n_av);
-		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq;
+		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq; wk.mark = dbg ? dbg + slot * 4 : nullptr;
 		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
 		if (n_out > EMA_REG_CAP) { cb.status |= EMA_ST_REG_OVERFLOW; n_out = EMA_REG_CAP; }
 		ema_wave_sync();

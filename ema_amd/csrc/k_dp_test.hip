@@ -73,3 +73,26 @@ extern "C" void ema_launch_test_local(const DevOpts *opt, const uint8_t *qbuf, c
 	hipLaunchKernelGGL(ema_k_test_local, dim3(n_tasks), dim3(64), 0, s, *opt, qbuf, qoff, tbuf, toff, prm, n_tasks, out, bsc,
 	                   b_stride);
 }
+
+// mem_sort_dedup_patch without patching (the form mem_matesw uses), one task per wavefront:
+// task t owns regs[t*cap .. t*cap + n_in[t]); result in place, n_out[t] = surviving regions.
+#include "dev_regions.hpp"
+__global__ void __launch_bounds__(64)
+ema_k_test_dedup(DevIndex ix, DevOpts opt, DevReg *regs, const int *n_in, int *n_out, int cap, int n_tasks, DevReg *tmp,
+                 uint64_t *keys)
+{
+	__shared__ int stack[3 * 70];
+	__shared__ uint8_t rseq[EMA_RSEQ_CAP];
+	const int t = blockIdx.x;
+	if (t >= n_tasks) return;
+	EmaRegWork wk;
+	wk.a = regs + (size_t)t * cap; wk.tmp = tmp + (size_t)t * cap; wk.keys = keys + (size_t)t * cap; wk.stack = stack; wk.rseq = rseq;
+	int status = 0;
+	const int n = ema_sort_dedup_patch(ix, opt, nullptr, n_in[t], wk, status);
+	if (ema_lane() == 0) n_out[t] = n;
+}
+extern "C" void ema_launch_test_dedup(const DevIndex *ix, const DevOpts *opt, DevReg *regs, const int *n_in, int *n_out, int cap,
+                                      int n_tasks, DevReg *tmp, uint64_t *keys, hipStream_t s)
+{
+	hipLaunchKernelGGL(ema_k_test_dedup, dim3(n_tasks), dim3(64), 0, s, *ix, *opt, regs, n_in, n_out, cap, n_tasks, tmp, keys);
+}

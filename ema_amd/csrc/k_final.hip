@@ -38,8 +38,9 @@ __global__ void __launch_bounds__(256)
 ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
             uint32_t *__restrict__ cigars, int *__restrict__ cig_n, int cig_cap, int *__restrict__ status,
-            uint8_t *__restrict__ slabs, int *__restrict__ counter)
+            uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
 {
+#define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
 	const int lane = (int)ema_lane();
@@ -55,14 +56,17 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
 		if (read >= n_reads) break;
+		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		EMA_DBG(1, 0);
 		const int l_query = (int)(off[read + 1] - off[read]);
 		const int nr = ema_uni(n_regs[read]);
-		if (nr == 0) { if (lane == 0) cig_n[read] = 0; continue; }
+		if (nr == 0) { if (lane == 0) cig_n[read] = 0; EMA_DBG(9, 0); continue; }
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
 		ema_wave_sync();
 		uint32_t *pool = cigars + (size_t)read * cig_cap;
 		int pool_n = 0, st = 0;
 		for (int k = 0; k < nr; ++k) {
+			EMA_DBG(2, k);
 			const DevReg ar = ema_uni(regs[(size_t)read * EMA_REG_CAP + k]);
 			DevAln out;
 			out.pos = -1; out.is_rev = 0; out.NM = -1; out.n_cigar = 0; out.cigar_off = (uint32_t)pool_n;
@@ -161,7 +165,9 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			ema_wave_sync();
 		}
 		if (lane == 0) { cig_n[read] = pool_n; if (st) atomicOr(status + read, st); }
+		EMA_DBG(9, 0);
 	}
+#undef EMA_DBG
 }
 
 // Packs the per-read slots into the contiguous arrays handed to the host: cand[cand_off[r] + k] and the
@@ -200,10 +206,10 @@ extern "C" size_t ema_final_slab_bytes() { return EMA_FINAL_SLAB_BYTES; }
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const DevReg *regs, const int *n_regs, DevAln *alns, uint32_t *cigars,
                                  int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
-                                 hipStream_t stream)
+                                 hipStream_t stream, int *dbg)
 {
 	hipLaunchKernelGGL(ema_k_final, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, regs, n_regs, alns,
-	                   cigars, cig_n, cig_cap, status, slabs, counter);
+	                   cigars, cig_n, cig_cap, status, slabs, counter, dbg);
 }
 
 extern "C" size_t ema_sizeof_aln() { return sizeof(DevAln); }

@@ -111,8 +111,9 @@ __device__ inline int matesw(PairCtx &cx, const DevReg &a, int l_ms, const uint8
 __global__ void __launch_bounds__(256)
 ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_low, int pes_high,
            const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_pairs, DevReg *__restrict__ regs,
-           int *__restrict__ n_regs, int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter)
+           int *__restrict__ n_regs, int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
 {
+#define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][2][256];
 	__shared__ uint8_t lds_rc[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
@@ -137,6 +138,8 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 		if (lane == 0) pair = atomicAdd(counter, 1);
 		pair = ema_uni(__shfl(pair, 0));
 		if (pair >= n_pairs) break;
+		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		EMA_DBG(1, 0);
 		int len[2], n[2], best[2] = {0, 0};
 		for (int m = 0; m < 2; ++m) {
 			const int r = 2 * pair + m;
@@ -157,6 +160,7 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 			int num = 0;
 			cx.wk.a = av[target];
 			for (int k = 0; k < n_anchor && num < max_rescue; ++k) {
+				EMA_DBG(2 + dirn, k);
 				const DevReg a = ema_uni(av[anchor][k]);
 				if (a.score >= best[anchor] - score_delta) {
 					++num;
@@ -164,6 +168,7 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 				}
 			}
 		}
+		EMA_DBG(5, 0);
 		for (int m = 0; m < 2; ++m) {
 			const int r = 2 * pair + m;
 			int cnt = n[m];
@@ -173,15 +178,17 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 			if (lane == 0) { n_regs[r] = cnt; if (cx.status) atomicOr(status + r, cx.status); }
 		}
 		ema_wave_sync();
+		EMA_DBG(9, 0);
 	}
+#undef EMA_DBG
 }
 
 extern "C" size_t ema_pair_slab_bytes() { return EMA_PAIR_SLAB_BYTES; }
 
 extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
                                 int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, DevReg *regs, int *n_regs,
-                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream)
+                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg)
 {
 	hipLaunchKernelGGL(ema_k_pair, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, score_delta, max_rescue, pes_low, pes_high,
-	                   bases, off, n_pairs, regs, n_regs, status, slabs, counter);
+	                   bases, off, n_pairs, regs, n_regs, status, slabs, counter, dbg);
 }

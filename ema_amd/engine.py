@@ -17,7 +17,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library():
         L.ema_engine_debug_regions.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_int32)),
                                                C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32),
                                                C.POINTER(C.c_int32)]
+        L.ema_engine_debug_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ema_engine_debug_dp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -240,6 +241,15 @@ class Engine:
             libc.free(pn)
             libc.free(ps)
         return regs, n_regs, status
+
+    def debug_dedup(self, regs, n_in):
+        """mem_sort_dedup_patch (no patching) on regs[n_tasks, cap] (REG_DTYPE); returns (regs, n_out)."""
+        regs = np.ascontiguousarray(regs.copy())
+        n_in = np.ascontiguousarray(n_in, dtype=np.int32)
+        n_out = np.zeros(len(n_in), dtype=np.int32)
+        self._check(self._L.ema_engine_debug_dedup(self._h, regs.ctypes.data, n_in.ctypes.data, n_out.ctypes.data,
+                                                   regs.shape[1], len(n_in)), "debug_dedup")
+        return regs, n_out
 
     def debug_dp(self, kind, qbuf, qoff, tbuf, toff, prm, cigar_cap=512):
         """Runs one of the wave DPs (0 extend, 1 global, 2 local pass) on n tasks; returns (out, cigar|None)."""

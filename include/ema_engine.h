@@ -130,6 +130,11 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
                         const uint32_t *toff, const int32_t *prm, int n_tasks, int32_t *out, uint32_t *cigar,
                         int cigar_cap);
 
+/* Region de-duplication in isolation (bwa's mem_sort_dedup_patch as mem_matesw calls it, i.e. without patching),
+ * one task per wavefront: task t owns regs[t*cap .. t*cap + n_in[t]) (records laid out as in ema_engine_debug_regions);
+ * sorted/compacted in place, n_out[t] = regions kept. */
+int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int32_t *n_out, int cap, int n_tasks);
+
 /* per-kernel device time of the last ema_engine_run (HIP events on the engine's stream), ms */
 typedef struct {
 	float seed_ms, chain_ms, extend_ms, rescue_ms, final_ms, total_ms;

@@ -13,7 +13,9 @@
 #include "oracle.h"
 #include "introsort.h"
 
-orc_stats_t orc_stats;
+__thread orc_stats_t orc_stats;
+void orc_stats_get(orc_stats_t *out) { *out = orc_stats; }
+void orc_stats_reset(void) { memset(&orc_stats, 0, sizeof(orc_stats)); }
 
 const unsigned char orc_nt4_table[256] = {
 	4, 4, 4, 4,  4, 4, 4, 4,  4, 4, 4, 4,  4, 4, 4, 4,

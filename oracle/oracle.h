@@ -118,7 +118,14 @@ typedef struct {
 	uint64_t l_read;    /* read bases */
 	uint64_t cells_ext, cells_local, cells_global; /* DP cells */
 } orc_stats_t;
-extern orc_stats_t orc_stats;
+extern __thread orc_stats_t orc_stats;   /* per thread */
+void orc_stats_get(orc_stats_t *out);
+void orc_stats_reset(void);
+
+/* CPU baseline: aligns n_pairs pairs (ASCII reads, 2n+1 offsets) with n_threads OpenMP threads and returns the
+ * wall seconds; *n_cand receives the number of candidates produced (keeps the work observable). */
+double orc_bench_pairs(const orc_opt_t *opt, const orc_idx_t *idx, const char *bases, const uint32_t *off, size_t n_pairs,
+                       int n_threads, uint64_t *n_cand);
 
 void orc_opt_init(orc_opt_t *o);                 /* mem_opt_init() + max_occ=3000 */
 orc_idx_t *orc_idx_load(const char *prefix);

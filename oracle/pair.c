@@ -12,6 +12,7 @@
 #include <string.h>
 #include <assert.h>
 #include "oracle.h"
+#include <omp.h>
 
 static inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)
 {
@@ -328,4 +329,23 @@ void orc_pair_out_free(orc_pair_out_t *out)
 {
 	free(out->c); free(out->pool);
 	out->c = 0; out->pool = 0;
+}
+
+double orc_bench_pairs(const orc_opt_t *opt, const orc_idx_t *idx, const char *bases, const uint32_t *off, size_t n_pairs,
+                       int n_threads, uint64_t *n_cand)
+{
+	uint64_t total = 0;
+	long i;
+	double t0 = omp_get_wtime();
+	if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 16) reduction(+ : total)
+	for (i = 0; i < (long)n_pairs; ++i) {
+		orc_pair_out_t o;
+		orc_align_pair(opt, idx, bases + off[2 * i], (int)(off[2 * i + 1] - off[2 * i]), bases + off[2 * i + 1],
+		               (int)(off[2 * i + 2] - off[2 * i + 1]), &o);
+		total += o.n1 + o.n2;
+		orc_pair_out_free(&o);
+	}
+	if (n_cand) *n_cand = total;
+	return omp_get_wtime() - t0;
 }

@@ -104,10 +104,10 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	                 &counter[0], 1, nullptr, nullptr);
 	if (upto >= 3)
 		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, (DevReg *)regs,
-		                n_regs, status, slabs.data(), &counter[1], 1, nullptr);
+		                n_regs, status, slabs.data(), &counter[1], 1, nullptr, nullptr);
 	if (upto >= 4)
 		ema_launch_final(&di, &d, bases, off, n_reads, (DevReg *)regs, n_regs, (DevAln *)alns, cigars, cig_n, EMA_CIG_CAP, status,
-		                 slabs.data(), &counter[2], 1, nullptr);
+		                 slabs.data(), &counter[2], 1, nullptr, nullptr);
 	return EMA_CIG_CAP;
 }
 }

@@ -92,6 +92,10 @@ def lib():
             [C.c_int] * 5
         L.orc_align1_core.restype = RegV
         L.orc_align1_core.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int, C.c_char_p]
+        L.orc_stats_get.argtypes = [C.POINTER(Stats)]
+        L.orc_bench_pairs.restype = C.c_double
+        L.orc_bench_pairs.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                      C.POINTER(C.c_uint64)]
         L.orc_introsort_u64.argtypes = [C.c_size_t, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
@@ -160,3 +164,23 @@ def align1(idx: Index, opt, read_ascii: bytes):
     out = [{f: getattr(v.a[i], f) for f in REG_FIELDS} for i in range(v.n)]
     C.CDLL(None).free(v.a)
     return out
+
+
+def stats_reset():
+    lib().orc_stats_reset()
+
+
+def stats_get():
+    s = Stats()
+    lib().orc_stats_get(C.byref(s))
+    return {n: int(getattr(s, n)) for n, _ in Stats._fields_}
+
+
+def bench_pairs(idx: Index, opt, bases: np.ndarray, off: np.ndarray, n_threads: int):
+    """Times the oracle on a batch (CPU baseline leg of bench.py).  Returns (seconds, candidates)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    n_cand = C.c_uint64()
+    secs = lib().orc_bench_pairs(C.byref(opt), idx.h, bases.ctypes.data, off.ctypes.data, (len(off) - 1) // 2, n_threads,
+                                 C.byref(n_cand))
+    return secs, n_cand.value

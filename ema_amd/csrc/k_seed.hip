@@ -225,7 +225,8 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const ui
 				sm.len = (int)(off[read + 1] - off[read]);
 				sm.out = intv + (size_t)read * EMA_INTV_CAP;
 				sm.status = 0; sm.n_out = 0; sm.pass = 1; sm.x = 0; sm.prev_is_a = 1; sm.n_curr = 0;
-				sm.pc = sm.len >= opt.min_seed_len ? PC_P1_NEXT : PC_FINISH;
+				if (sm.len < opt.min_seed_len) continue;      // mem_chain: no seeds for a read shorter than min_seed_len
+				sm.pc = PC_P1_NEXT;
 			}
 			sm.advance(ix, opt);
 		}

@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=262144, help="pairs per step and per GPU (one resident batch)")
     ap.add_argument("--genome-mbp", type=float, default=0.0, help="0 = chr20-scale (64.4 Mbp)")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="pairs of the same workload timed on the host CPU")
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="pairs of the same workload timed on the host CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -144,17 +144,10 @@ def main():
 
     # results of the last step: parity spot check against the oracle + bucket statistics
     batch = eng.fetch()
-    n_cand = int(batch.cand_off[-1])
-    mapped = int((np.diff(batch.cand_off.astype(np.int64)) > 0).sum())
-    stats_vec = np.array([pairs.n, n_cand, mapped, int(batch.status.max())], dtype=np.int64)
-    if world > 1:
-        # the "trivial RCCL gather of per-bucket statistics" of the north star: O(100 B) per rank over xGMI
-        mine = torch.from_numpy(stats_vec).cuda()
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        gathered = torch.stack(allv).cpu().numpy()
-    else:
-        gathered = stats_vec[None, :]
+    from ema_amd import shard
+    stats_vec = shard.bucket_stats(batch, pairs.n)
+    # the "trivial RCCL gather of per-bucket statistics" of the north star: one bucket per rank, O(100 B) over xGMI
+    gathered = shard.gather_stats(stats_vec[None, :], world, device=("cuda" if world > 1 else None))
 
     out = None
     if rank == 0:

@@ -61,6 +61,41 @@ __device__ __forceinline__ DevReg ema_uni(const DevReg &g)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-wide scans and reductions on DPP (data-parallel primitives: operands are read from a neighbouring lane by
+// the VALU itself -- a few cycles -- instead of going through the LDS crossbar like ds_bpermute/__shfl, which
+// costs >100 cycles per dependent step and dominated the row-parallel DPs).  gfx950 keeps the GFX9 controls
+// row_shr:n (within a row of 16 lanes), row_bcast:15 / row_bcast:31 (carry a row's last lane into the next
+// row / next two rows) and wave_shr:1.  Lanes without a source receive `ident`.
+#define EMA_DPP(old, v, ctrl, row_mask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (row_mask), 0xf, false)
+
+__device__ __forceinline__ int ema_wave_incl_scan_max(int v, int ident)
+{
+	int t;
+	t = EMA_DPP(ident, v, 0x111, 0xf); v = max(v, t);     // row_shr:1
+	t = EMA_DPP(ident, v, 0x112, 0xf); v = max(v, t);     // row_shr:2
+	t = EMA_DPP(ident, v, 0x114, 0xf); v = max(v, t);     // row_shr:4
+	t = EMA_DPP(ident, v, 0x118, 0xf); v = max(v, t);     // row_shr:8
+	t = EMA_DPP(ident, v, 0x142, 0xa); v = max(v, t);     // row_bcast:15 into rows 1 and 3
+	t = EMA_DPP(ident, v, 0x143, 0xc); v = max(v, t);     // row_bcast:31 into rows 2 and 3
+	return v;
+}
+__device__ __forceinline__ int ema_wave_incl_scan_add(int v)
+{
+	int t;
+	t = EMA_DPP(0, v, 0x111, 0xf); v += t;
+	t = EMA_DPP(0, v, 0x112, 0xf); v += t;
+	t = EMA_DPP(0, v, 0x114, 0xf); v += t;
+	t = EMA_DPP(0, v, 0x118, 0xf); v += t;
+	t = EMA_DPP(0, v, 0x142, 0xa); v += t;
+	t = EMA_DPP(0, v, 0x143, 0xc); v += t;
+	return v;
+}
+// value of the lane below (lane 0 receives `ident`)
+__device__ __forceinline__ int ema_wave_shr1(int v, int ident) { return EMA_DPP(ident, v, 0x138, 0xf); }
+// wave-uniform results in scalar registers
+__device__ __forceinline__ int ema_wave_sum(int v) { return __builtin_amdgcn_readlane(ema_wave_incl_scan_add(v), 63); }
+
+// ---------------------------------------------------------------------------------------------
 // occ4 on the HBM block layout of dev_types.h, computed by FOUR adjacent lanes.
 // Lane j (= lane & 3) of the quad loads slot j of the block that holds BWT position `pos`
 // (one 16-byte load; the quad's four loads are one contiguous 64-byte line) and the quad

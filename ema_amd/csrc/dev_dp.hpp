@@ -25,30 +25,19 @@
 
 __device__ __forceinline__ int ema_wave_max(int v)
 {
-	v = max(v, __shfl_xor(v, 1)); v = max(v, __shfl_xor(v, 2)); v = max(v, __shfl_xor(v, 4));
-	v = max(v, __shfl_xor(v, 8)); v = max(v, __shfl_xor(v, 16)); v = max(v, __shfl_xor(v, 32));
-	return ema_uni(v);
+	return __builtin_amdgcn_readlane(ema_wave_incl_scan_max(v, EMA_NEG_BIG), 63);
 }
 // exclusive prefix max over lanes (lane 0 gets EMA_NEG_BIG)
 __device__ __forceinline__ int ema_wave_exscan_max(int v)
 {
-	const unsigned l = ema_lane();
-	int t;
-	t = __shfl_up(v, 1); if (l >= 1) v = max(v, t);
-	t = __shfl_up(v, 2); if (l >= 2) v = max(v, t);
-	t = __shfl_up(v, 4); if (l >= 4) v = max(v, t);
-	t = __shfl_up(v, 8); if (l >= 8) v = max(v, t);
-	t = __shfl_up(v, 16); if (l >= 16) v = max(v, t);
-	t = __shfl_up(v, 32); if (l >= 32) v = max(v, t);
-	t = __shfl_up(v, 1);
-	return l == 0 ? EMA_NEG_BIG : t;
+	return ema_wave_shr1(ema_wave_incl_scan_max(v, EMA_NEG_BIG), EMA_NEG_BIG);
 }
 // value of column j's owner (j wave-uniform); vals[c] = this lane's column 4*lane+c
 __device__ __forceinline__ int ema_col_get(const int vals[EMA_NC], int j)
 {
 	const int c = j & (EMA_NC - 1);
 	const int mine = c == 0 ? vals[0] : c == 1 ? vals[1] : c == 2 ? vals[2] : vals[3];
-	return ema_uni(__shfl(mine, j >> 2));
+	return __builtin_amdgcn_readlane(mine, j >> 2);
 }
 
 struct EmaSeq {          // a byte sequence read forwards (step 1) or backwards (step -1); with pivot >= 0 (step 1)
@@ -141,7 +130,7 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 			pre = max(pre, g[c]);
 		}
 		// new E for in-range cells; new H array: index j takes H(i, j-1)
-		const int up = __shfl_up(h[EMA_NC - 1], 1);      // H(i, 4*lane - 1)
+		const int up = ema_wave_shr1(h[EMA_NC - 1], 0);   // H(i, 4*lane - 1)
 #pragma unroll
 		for (int c = 0; c < EMA_NC; ++c) {
 			const int j = lane * EMA_NC + c;
@@ -259,7 +248,7 @@ __device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, 
 			}
 			pre = max(pre, g[c]);
 		}
-		const int up = __shfl_up(h[EMA_NC - 1], 1);
+		const int up = ema_wave_shr1(h[EMA_NC - 1], 0);
 #pragma unroll
 		for (int c = 0; c < EMA_NC; ++c) {
 			const int j = lane * EMA_NC + c;
@@ -331,7 +320,7 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 	int last_sc = 0, last_row = -2;                 // copy of b[n_b-1]
 	for (int i = 0; i < tlen; ++i) {
 		const int tb = ema_uni(target.at(i));
-		const int up = __shfl_up(hh[EMA_NC - 1], 1);     // H(i-1, 4*lane-1)
+		const int up = ema_wave_shr1(hh[EMA_NC - 1], 0);  // H(i-1, 4*lane-1)
 		int Hd[EMA_NC], g[EMA_NC];
 		int run = EMA_NEG_BIG;
 #pragma unroll

@@ -48,9 +48,7 @@ __device__ inline bool ema_global_score(const DevIndex &ix, const DevOpts &o, in
 	if (l_query == rlen && w_ == 0) {
 		int part = 0;
 		for (int i = (int)ema_lane(); i < l_query; i += EMA_WAVE) part += o.mat[rseq[i] * 5 + query[i]];
-		part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
-		part += __shfl_xor(part, 8); part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
-		score = ema_uni(part);
+		score = ema_wave_sum(part);
 		return true;
 	}
 	const int w = ema_cigar_band(o, l_query, rlen, w_);

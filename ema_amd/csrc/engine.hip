@@ -20,7 +20,8 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg);
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
+                                 unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" size_t ema_pair_slab_bytes();
 extern "C" size_t ema_final_slab_bytes();
@@ -102,6 +103,7 @@ struct ema_engine {
 	int align_blocks = 0;
 	DevBuf<DevReg> d_regs;
 	DevBuf<int> d_n_regs, d_counters;
+	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
 	DevBuf<uint8_t> d_slabs;
 	// K3 / K4 / pack
 	int pair_blocks = 0, final_blocks = 0;
@@ -197,6 +199,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
 
+	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(8)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 64)); }
 	if (const char *wd = getenv("EMA_WATCHDOG_S")) {
 		e->watchdog_s = atof(wd);
 		e->dbg_slots = e->n_cu * 2 * 4 + 64;
@@ -299,7 +302,7 @@ static int run_align(ema_engine *e)
 {
 	const int n_reads = (int)(2 * e->n_pairs);
 	ema_launch_align(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_regs.p,
-	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream, e->dbg);
+	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream, e->dbg, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, "ema_k_align");
 	return EMA_OK;
@@ -363,6 +366,15 @@ int ema_engine_sync(ema_engine_t *e)
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 {
 	if (!e || !t) return EMA_EARG;
+	if (e->d_prof.p) {
+		unsigned long long h[8];
+		if (hipMemcpy(h, e->d_prof.p, 64, hipMemcpyDeviceToHost) == hipSuccess) {
+			fprintf(stderr, "K2 phase ticks (idle/fetch, chain, filter, chain2aln-ctl, extend-dp, dedup):");
+			for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", h[i]);
+			fprintf(stderr, "\n");
+			(void)hipMemset(e->d_prof.p, 0, 64);
+		}
+	}
 	*t = e->timing;
 	return EMA_OK;
 }

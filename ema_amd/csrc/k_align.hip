@@ -179,8 +179,13 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 __global__ void __launch_bounds__(256)
 ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
-            int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
+            int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg,
+            unsigned long long *prof)
 {
+	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
+	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
+	int phase = 0;
+#define EMA_PHASE(idx) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc[phase] += t_now - t_prev; t_prev = t_now; phase = (idx); } } while (0)
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
@@ -202,6 +207,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		if (read >= n_reads) break;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
+		EMA_PHASE(1);
 		const int l_query = ema_uni((int)(off[read + 1] - off[read]));
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
 		ema_wave_sync();
@@ -250,6 +256,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		// ---------------- mem_chain_flt ----------------
 		int n_chn = cb.n_chain, n_keep = 0;
 		EMA_DBG(3, n_chn);
+		EMA_PHASE(2);
 		if (n_chn > 0) {
 			for (int i = lane; i < n_chn; i += EMA_WAVE) {      // weights, chains taken in position order
 				const int id = sl.cord[i];
@@ -316,6 +323,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
 		int n_av = 0;
 		EMA_DBG(5, n_keep);
+		EMA_PHASE(3);
 		for (int ci_sorted = 0; ci_sorted < n_keep; ++ci_sorted) {
 			EMA_DBG(6, ci_sorted);
 			const int cid = ema_uni((int)(uint32_t)sl.skey[ci_sorted]);
@@ -405,6 +413,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 				int aw0 = opt.w, aw1 = opt.w;
 				a.score = a.truesc = -1;
 				a.rid = c.rid;
+				EMA_PHASE(4);
 				if (s.qbeg) {     // left extension, both sequences reversed
 					const int tlen = (int)(s.rbeg - rmax0);
 					EmaExtRes r; r.score = -1; r.qle = r.tle = r.gtle = 0; r.gscore = -1; r.max_off = 0;
@@ -439,15 +448,14 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 						a.qe = l_query; a.re = rmax0 + re + r.gtle; a.truesc += r.gscore - sc0;
 					}
 				} else { a.qe = l_query; a.re = s.rbeg + s.len; }
+				EMA_PHASE(3);
 				{   // seedcov: seeds of the chain fully inside the region
 					int cov = 0;
 					for (int t = lane; t < cn; t += EMA_WAVE) {
 						const SeedRec u = sl.cs[t];
 						if (u.qbeg >= a.qb && u.qbeg + u.len <= a.qe && u.rbeg >= a.rb && u.rbeg + u.len <= a.re) cov += u.len;
 					}
-					cov += __shfl_xor(cov, 1); cov += __shfl_xor(cov, 2); cov += __shfl_xor(cov, 4);
-					cov += __shfl_xor(cov, 8); cov += __shfl_xor(cov, 16); cov += __shfl_xor(cov, 32);
-					a.seedcov = ema_uni(cov);
+					a.seedcov = ema_wave_sum(cov);
 				}
 				a.w = aw0 > aw1 ? aw0 : aw1;
 				a.seedlen0 = s.len;
@@ -460,6 +468,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 
 		// ---------------- mem_sort_dedup_patch ----------------
 		EMA_DBG(8, n_av);
+		EMA_PHASE(5);
 		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq; wk.mark = dbg ? dbg + slot * 4 : nullptr;
 		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
 		if (n_out > EMA_REG_CAP) { cb.status |= EMA_ST_REG_OVERFLOW; n_out = EMA_REG_CAP; }
@@ -468,16 +477,20 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		for (int i = lane; i < n_out; i += EMA_WAVE) dst[i] = sl.av[i];
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
 		EMA_DBG(9, n_out);
+		EMA_PHASE(0);
 	}
+	if (prof && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(prof + i, acc[i]);
 #undef EMA_DBG
+#undef EMA_PHASE
 }
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg)
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
+                                 unsigned long long *prof)
 {
 	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, intv, n_intv, regs,
-	                   n_regs, status, slabs, counter, dbg);
+	                   n_regs, status, slabs, counter, dbg, prof);
 }

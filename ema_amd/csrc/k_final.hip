@@ -92,9 +92,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 				if (lq == rlen && w2 == 0) {      // gap-free
 					int part = 0;
 					for (int i = lane; i < lq; i += EMA_WAVE) part += opt.mat[ts.at(i) * 5 + qs.at(i)];
-					part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
-					part += __shfl_xor(part, 8); part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
-					score = ema_uni(part);
+					score = ema_wave_sum(part);
 					first = EMA_CIG_TMP - 1; n_cig = 1;
 					ema_wave_sync();
 					if (lane == 0) ctmp[first] = (uint32_t)lq << 4;
@@ -131,9 +129,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 						y += len;
 					} else { x += len; n_gap += len; }
 				}
-				n_mm += __shfl_xor(n_mm, 1); n_mm += __shfl_xor(n_mm, 2); n_mm += __shfl_xor(n_mm, 4);
-				n_mm += __shfl_xor(n_mm, 8); n_mm += __shfl_xor(n_mm, 16); n_mm += __shfl_xor(n_mm, 32);
-				nm = ema_uni(n_mm) + n_gap;
+				nm = ema_wave_sum(n_mm) + n_gap;
 			}
 			out.NM = n_cig > 0 ? nm : -1;
 			const int is_rev = (rb < l_pac ? rb : re - 1) >= l_pac;

@@ -77,7 +77,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
 	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
-	                 &counter, n_blocks, nullptr, nullptr);
+	                 &counter, n_blocks, nullptr, nullptr, nullptr);
 	return EMA_REG_CAP;
 }
 int emu_sizeof_reg() { return (int)sizeof(DevReg); }
@@ -101,7 +101,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[3] = {0, 0, 0};
 	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
-	                 &counter[0], 1, nullptr, nullptr);
+	                 &counter[0], 1, nullptr, nullptr, nullptr);
 	if (upto >= 3)
 		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, (DevReg *)regs,
 		                n_regs, status, slabs.data(), &counter[1], 1, nullptr, nullptr);

@@ -165,8 +165,33 @@ __attribute__((noinline)) inline int __builtin_amdgcn_readfirstlane(int v, int l
 	if (r != v) { fprintf(stderr, "simt_emu: value marked wave-uniform at line %d differs between lanes (%d vs %d)\n", line_, v, r); abort(); }
 	return r;
 }
+// DPP move: row_shr:n (0x110+n), row_bcast:15 (0x142), row_bcast:31 (0x143), wave_shr:1 (0x138); bound_ctrl = false
+__attribute__((noinline)) inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int row_mask, int bank_mask, bool, int line_ = __builtin_LINE()) {
+	emu::Lane &L = emu::W->lane[emu::W->cur];
+	unsigned p = L.par & 1; ++L.par;
+	emu::W->slot[p][emu::W->cur] = (uint64_t)(uint32_t)v;
+	emu::yield(line_);
+	const int lane = emu::W->cur, row = lane >> 4, bank = (lane & 15) >> 2;
+	if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
+	int src = -1;
+	if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if ((lane & 15) >= n) src = lane - n; }
+	else if (ctrl == 0x142) { if (row >= 1) src = row * 16 - 1; }
+	else if (ctrl == 0x143) { if (row >= 2) src = 31; }
+	else if (ctrl == 0x138) { if (lane >= 1) src = lane - 1; }
+	else { fprintf(stderr, "simt_emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+	if (src < 0 || emu::W->lane[src].done) return old;
+	return (int)(uint32_t)emu::W->slot[p][src];
+}
+__attribute__((noinline)) inline int __builtin_amdgcn_readlane(int v, int src, int line_ = __builtin_LINE()) {
+	emu::Lane &L = emu::W->lane[emu::W->cur];
+	unsigned p = L.par & 1; ++L.par;
+	emu::W->slot[p][emu::W->cur] = (uint64_t)(uint32_t)v;
+	emu::yield(line_);
+	return (int)(uint32_t)emu::W->slot[p][src & 63];
+}
 inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+inline unsigned long long __builtin_amdgcn_s_memtime() { return 0; }
 inline void __builtin_amdgcn_fence(int, const char *) {}
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <typename T> inline void __hip_atomic_store(T *p, T v, int, int) { *p = v; }

@@ -150,6 +150,46 @@ __device__ __forceinline__ void ema_group8_extend(const DevIndex &ix, uint64_t x
 	o_size = __shfl(s, cc, 8);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same two primitives computed by ONE lane (one read per lane).  The lane fetches the 64-byte block with four
+// 16-byte loads (global_load_dwordx4) -- still exactly one line per occ4 query -- and does the popcounts itself, so a
+// wavefront keeps 64 independent searches and up to 128 cache lines in flight and needs no cross-lane traffic.
+__device__ __forceinline__ void ema_lane_occ4(const DevIndex &ix, uint64_t pos, uint64_t cnt[4])
+{
+	const uint64_t p = pos - (pos >= ix.primary ? 1 : 0);   // '$' is not stored
+	const ulong2 *blk = reinterpret_cast<const ulong2 *>(ix.occ + ((p >> 7) << 2));
+	const ulong2 s0 = blk[0], s1 = blk[1], s2 = blk[2], s3 = blk[3];
+	const int r = (int)(p & 127);
+	unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+	const uint64_t w[4] = {s0.y, s1.y, s2.y, s3.y};
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		int nvalid = r + 1 - (j << 5);
+		nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
+		const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
+		const uint64_t lo = w[j] & m55, hi = (w[j] >> 1) & m55;
+		const unsigned p3 = __popcll(hi & lo), p2 = __popcll(hi & ~lo), p1 = __popcll(~hi & lo);
+		c3 += p3; c2 += p2; c1 += p1; c0 += (unsigned)nvalid - p1 - p2 - p3;
+	}
+	cnt[0] = s0.x + c0; cnt[1] = s1.x + c1; cnt[2] = s2.x + c2; cnt[3] = s3.x + c3;
+}
+
+// bwt_extend for one symbol by one lane; arguments as in ema_group8_extend
+__device__ __forceinline__ void ema_lane_extend(const DevIndex &ix, uint64_t x_nb, uint64_t x_b, uint64_t size, int c,
+                                                uint64_t &o_nb, uint64_t &o_b, uint64_t &o_size)
+{
+	uint64_t tk[4], tl[4];
+	ema_lane_occ4(ix, x_nb - 1, tk);
+	ema_lane_occ4(ix, x_nb - 1 + size, tl);
+	const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+	const uint64_t b3 = x_b + ((x_nb <= ix.primary && x_nb + size - 1 >= ix.primary) ? 1 : 0);
+	const uint64_t b2 = b3 + s3, b1 = b2 + s2, b0 = b1 + s1;
+	const int cc = c & 3;
+	o_b = cc == 3 ? b3 : cc == 2 ? b2 : cc == 1 ? b1 : b0;
+	o_size = cc == 3 ? s3 : cc == 2 ? s2 : cc == 1 ? s1 : s0;
+	o_nb = ix.L2[cc] + 1 + (cc == 3 ? tk[3] : cc == 2 ? tk[2] : cc == 1 ? tk[1] : tk[0]);
+}
+
 // suffix array row -> text position (the whole SA is resident)
 __device__ __forceinline__ uint64_t ema_sa(const DevIndex &ix, uint64_t row)
 {

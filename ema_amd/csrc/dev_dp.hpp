@@ -40,6 +40,13 @@ __device__ __forceinline__ int ema_col_get(const int vals[EMA_NC], int j)
 	return __builtin_amdgcn_readlane(mine, j >> 2);
 }
 
+// bwa_fill_scmat(a, b): +a on a match, -b on a mismatch, -1 against an ambiguous base -- computed, not looked up:
+// a per-lane table index would turn every DP cell into a memory access.
+__device__ __forceinline__ int ema_score(const DevOpts &o, int t, int q)
+{
+	return (t > 3 || q > 3) ? -1 : (t == q ? o.a : -o.b);
+}
+
 struct EmaSeq {          // a byte sequence read forwards (step 1) or backwards (step -1); with pivot >= 0 (step 1)
 	const uint8_t *p;    // the prefix [0, pivot] is read reversed and the rest in place (ksw_align2's revseq on the target)
 	int step;
@@ -48,6 +55,27 @@ struct EmaSeq {          // a byte sequence read forwards (step 1) or backwards 
 	{
 		if (pivot >= 0) return i <= pivot ? p[pivot - i] : p[i];
 		return p[(long)i * step];
+	}
+};
+
+// The row loops need one wave-uniform target base per row.  Fetching it from memory row by row puts a load and a
+// wait on the critical path of every row, so the wave keeps 256 rows' worth in ONE register per lane (lane t holds
+// rows 4t..4t+3 of the current 256-row chunk, loaded together) and extracts row i with a readlane + shift.
+struct EmaRowBases {
+	int pack;
+	__device__ __forceinline__ void load(const EmaSeq &t, int chunk_base, int tlen)
+	{
+		int p = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int i = chunk_base + (int)ema_lane() * 4 + k;
+			if (i < tlen) p |= t.at(i) << (8 * k);
+		}
+		pack = p;
+	}
+	__device__ __forceinline__ int get(int i) const      // i wave-uniform, inside the loaded chunk
+	{
+		return (__builtin_amdgcn_readlane(pack, (i & 255) >> 2) >> ((i & 3) << 3)) & 0xff;
 	}
 };
 
@@ -82,8 +110,7 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 	}
 	int max_ins, max_del;
 	{
-		int mx = 0;
-		for (int i = 0; i < 25; ++i) mx = mx > o.mat[i] ? mx : o.mat[i];
+		const int mx = o.a > 0 ? o.a : 0;      // largest entry of the scoring matrix
 		max_ins = (int)((double)(qlen * mx + end_bonus - o.o_ins) / e_ins + 1.);
 		max_ins = max_ins > 1 ? max_ins : 1;
 		w = w < max_ins ? w : max_ins;
@@ -93,8 +120,10 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 	}
 	int mx_sc = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
 	int beg = 0, end = qlen;
+	EmaRowBases rows;
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = ema_uni(target.at(i));
+		if ((i & 255) == 0) rows.load(target, i, tlen);
+		const int tb = rows.get(i);
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
@@ -107,7 +136,7 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 		for (int c = 0; c < EMA_NC; ++c) {
 			const int j = lane * EMA_NC + c;
 			const bool in = j >= beg && j < end;
-			const int s = o.mat[tb * 5 + qb[c]];
+			const int s = ema_score(o, tb, qb[c]);
 			int m = hh[c] ? hh[c] + s : 0;
 			M[c] = m;
 			int t = m - oe_ins; t = t > 0 ? t : 0;
@@ -207,8 +236,10 @@ __device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, 
 		hh[c] = v; ee[c] = EMA_DP_MINUS_INF;
 		qb[c] = j < qlen ? query.at(j) : 4;
 	}
+	EmaRowBases rows;
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = ema_uni(target.at(i));
+		if ((i & 255) == 0) rows.load(target, i, tlen);
+		const int tb = rows.get(i);
 		const int beg = i > w ? i - w : 0;
 		const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1_init = beg == 0 ? -(o.o_del + e_del * (i + 1)) : EMA_DP_MINUS_INF;
@@ -218,7 +249,7 @@ __device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, 
 		for (int c = 0; c < EMA_NC; ++c) {
 			const int j = lane * EMA_NC + c;
 			const bool in = j >= beg && j < end;
-			const int m = hh[c] + o.mat[tb * 5 + qb[c]];
+			const int m = hh[c] + ema_score(o, tb, qb[c]);
 			M[c] = m;
 			g[c] = in ? (m - oe_ins) + j * e_ins : EMA_NEG_BIG;
 			run = max(run, g[c]);
@@ -304,8 +335,7 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 	const int lane = (int)ema_lane();
 	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
 	const int qpad = (qlen + p - 1) / p * p;
-	int maxsc = 0;
-	for (int i = 0; i < 25; ++i) maxsc = maxsc > o.mat[i] ? maxsc : o.mat[i];
+	const int maxsc = o.a > 0 ? o.a : 0;       // largest entry of the scoring matrix
 	int hh[EMA_NC], ee[EMA_NC], qb[EMA_NC], hmax[EMA_NC];
 #pragma unroll
 	for (int c = 0; c < EMA_NC; ++c) {
@@ -318,8 +348,10 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 	// list is kept (wave-uniform writes) and scanned at the end.
 	int n_b = 0;
 	int last_sc = 0, last_row = -2;                 // copy of b[n_b-1]
+	EmaRowBases rows;
 	for (int i = 0; i < tlen; ++i) {
-		const int tb = ema_uni(target.at(i));
+		if ((i & 255) == 0) rows.load(target, i, tlen);
+		const int tb = rows.get(i);
 		const int up = ema_wave_shr1(hh[EMA_NC - 1], 0);  // H(i-1, 4*lane-1)
 		int Hd[EMA_NC], g[EMA_NC];
 		int run = EMA_NEG_BIG;
@@ -328,7 +360,7 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 			const int j = lane * EMA_NC + c;
 			const bool in = j < qpad;
 			const int diag = c == 0 ? (lane == 0 ? 0 : up) : hh[c - 1];
-			const int s = qb[c] == 5 ? 0 : o.mat[tb * 5 + qb[c]];
+			const int s = qb[c] == 5 ? 0 : ema_score(o, tb, qb[c]);
 			int hv = diag + s; hv = hv > 0 ? hv : 0;
 			hv = hv > ee[c] ? hv : ee[c];
 			Hd[c] = hv;                                  // before the F term

@@ -21,8 +21,8 @@ struct EmaRegWork {
 // band of bwa_gen_cigar2
 __device__ __forceinline__ int ema_cigar_band(const DevOpts &o, int l_query, int rlen, int w_)
 {
-	int max_ins = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_ins) / o.e_ins + 1.);
-	int max_del = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_del) / o.e_del + 1.);
+	int max_ins = (int)((double)(((l_query + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
+	int max_del = (int)((double)(((l_query + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
 	int max_gap = max_ins > max_del ? max_ins : max_del;
 	max_gap = max_gap > 1 ? max_gap : 1;
 	const int diff = rlen > l_query ? rlen - l_query : l_query - rlen;
@@ -47,7 +47,7 @@ __device__ inline bool ema_global_score(const DevIndex &ix, const DevOpts &o, in
 	const bool rev = rb >= ix.l_pac;    // reversed so that indels end up left-aligned on the forward strand
 	if (l_query == rlen && w_ == 0) {
 		int part = 0;
-		for (int i = (int)ema_lane(); i < l_query; i += EMA_WAVE) part += o.mat[rseq[i] * 5 + query[i]];
+		for (int i = (int)ema_lane(); i < l_query; i += EMA_WAVE) part += ema_score(o, rseq[i], query[i]);
 		score = ema_wave_sum(part);
 		return true;
 	}

@@ -13,8 +13,8 @@
 #include "host_index.h"
 #include "opts.h"
 
-extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
-                                int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int n_blocks,
+extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
+                                int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int *counter, int n_blocks,
                                 hipStream_t stream);
 
 extern "C" size_t ema_align_slab_bytes();
@@ -23,6 +23,10 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
                                  uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
                                  unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
+extern "C" int ema_align_blocks_per_cu();
+extern "C" int ema_pair_blocks_per_cu();
+extern "C" int ema_final_blocks_per_cu();
+extern "C" int ema_seed_blocks_per_cu();
 extern "C" size_t ema_pair_slab_bytes();
 extern "C" size_t ema_final_slab_bytes();
 extern "C" size_t ema_sizeof_aln();
@@ -92,9 +96,9 @@ struct ema_engine {
 	size_t cap_pairs = 0, n_pairs = 0;
 	bool staged = false, ran = false;
 	std::vector<uint8_t> h_nt4;
-	std::vector<uint32_t> h_off;
+	std::vector<uint32_t> h_off, h_qpack;
 	DevBuf<uint8_t> d_bases;
-	DevBuf<uint32_t> d_off;
+	DevBuf<uint32_t> d_off, d_qpack;   // d_qpack: 24 words per read (2-bit codes + N mask) for K1
 	// K1
 	int seed_blocks = 0;
 	DevBuf<Intv> d_intv, d_lists;
@@ -139,17 +143,18 @@ static int engine_alloc_batch(ema_engine *e)
 	const size_t n_reads = 2 * e->cap_pairs;
 	HIPCHK(e, e->d_bases.alloc(n_reads * (size_t)(EMA_MAX_READ + 1)));
 	HIPCHK(e, e->d_off.alloc(n_reads + 1));
+	HIPCHK(e, e->d_qpack.alloc(n_reads * 24 + 8));
 	HIPCHK(e, e->d_intv.alloc(n_reads * (size_t)EMA_INTV_CAP));
 	HIPCHK(e, e->d_n_intv.alloc(n_reads));
 	HIPCHK(e, e->d_status.alloc(n_reads));
-	e->seed_blocks = e->n_cu * 4;   // 4 blocks x 4 waves = 16 waves per CU (VGPR-limited occupancy of K1)
-	HIPCHK(e, e->d_lists.alloc((size_t)e->seed_blocks * 32 * 2 * EMA_LIST_CAP));
+	e->seed_blocks = e->n_cu * ema_seed_blocks_per_cu();      // every resident lane carries one read
+	HIPCHK(e, e->d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
 	HIPCHK(e, e->d_regs.alloc(n_reads * (size_t)EMA_REG_CAP));
 	HIPCHK(e, e->d_n_regs.alloc(n_reads));
 	HIPCHK(e, e->d_counters.alloc(16));
-	e->align_blocks = e->n_cu * 2;  // 2 blocks x 4 waves = 8 resident waves per CU, one scratch slab each
-	e->pair_blocks = e->n_cu * 2;
-	e->final_blocks = e->n_cu * 2;
+	e->align_blocks = e->n_cu * ema_align_blocks_per_cu();    // one scratch slab per resident wave
+	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
+	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
 	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
 	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
 	if ((size_t)e->final_blocks * 4 * ema_final_slab_bytes() > slab) slab = (size_t)e->final_blocks * 4 * ema_final_slab_bytes();
@@ -202,7 +207,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(8)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 64)); }
 	if (const char *wd = getenv("EMA_WATCHDOG_S")) {
 		e->watchdog_s = atof(wd);
-		e->dbg_slots = e->n_cu * 2 * 4 + 64;
+		e->dbg_slots = e->n_cu * 8 * 4 + 64;
 		if (!getenv("EMA_WATCHDOG_NOMARK")) {
 			HIPCHK(e, hipHostMalloc((void **)&e->dbg, (size_t)e->dbg_slots * 4 * sizeof(int), hipHostMallocDefault));
 			memset(e->dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
@@ -219,7 +224,7 @@ void ema_engine_close(ema_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release();
-	e->d_bases.release(); e->d_off.release(); e->d_intv.release(); e->d_lists.release();
+	e->d_bases.release(); e->d_off.release(); e->d_qpack.release(); e->d_intv.release(); e->d_lists.release();
 	e->d_n_intv.release(); e->d_status.release();
 	e->d_regs.release(); e->d_n_regs.release(); e->d_counters.release(); e->d_slabs.release();
 	e->d_alns.release(); e->d_cigars.release(); e->d_cigar_out.release(); e->d_cig_n.release();
@@ -261,6 +266,17 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 	e->h_nt4.resize(total + 1);
 	const unsigned char *src = (const unsigned char *)bases + base0;
 	for (size_t i = 0; i < total; ++i) e->h_nt4[i] = kNt4[src[i]];   // seq_convert, reference src/bwabridge.c:151-157
+	e->h_qpack.assign(n_reads * 24 + 8, 0);
+	for (size_t r = 0; r < n_reads; ++r) {
+		uint32_t *w = e->h_qpack.data() + r * 24;
+		const uint8_t *b = e->h_nt4.data() + e->h_off[r];
+		const uint32_t len = e->h_off[r + 1] - e->h_off[r];
+		for (uint32_t i = 0; i < len; ++i) {
+			w[i >> 4] |= (uint32_t)(b[i] & 3) << ((i & 15) << 1);
+			if (b[i] > 3) w[16 + (i >> 5)] |= 1u << (i & 31);
+		}
+	}
+	HIPCHK(e, hipMemcpyAsync(e->d_qpack.p, e->h_qpack.data(), (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipMemcpyAsync(e->d_bases.p, e->h_nt4.data(), total, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipMemcpyAsync(e->d_off.p, e->h_off.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -291,8 +307,8 @@ static int run_seed(ema_engine *e)
 	const int n_reads = (int)(2 * e->n_pairs);
 	HIPCHK(e, hipMemsetAsync(e->d_status.p, 0, (size_t)n_reads * 4, e->stream));
 	HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 16 * 4, e->stream));
-	ema_launch_seed(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_status.p,
-	                e->d_lists.p, e->seed_blocks, e->stream);
+	ema_launch_seed(&e->dix, &e->dopts, e->d_qpack.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_status.p,
+	                e->d_lists.p, e->d_counters.p + 3, e->seed_blocks, e->stream);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, "ema_k_seed");
 	return EMA_OK;
@@ -457,6 +473,7 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
 	HIPCHK(e, hipMemcpy(dqo.p, qoff, (n_tasks + 1) * 4, hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(dto.p, toff, (n_tasks + 1) * 4, hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(dp.p, prm, (size_t)n_tasks * n_prm * 4, hipMemcpyHostToDevice));
+	HIPCHK(e, hipEventRecord(e->ev[5], e->stream));
 	if (kind == 0) ema_launch_test_extend(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, e->stream);
 	else if (kind == 1) {
 		if (!cigar || cigar_cap <= 0) return EMA_EARG;
@@ -468,7 +485,13 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
 		ema_launch_test_local(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, db.p, b_stride, e->stream);
 	}
 	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipEventRecord(e->ev[6], e->stream));
 	HIPCHK(e, hipStreamSynchronize(e->stream));
+	if (getenv("EMA_DP_TIMING")) {
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, e->ev[5], e->ev[6]);
+		fprintf(stderr, "debug_dp kind %d: %d tasks in %.3f ms\n", kind, n_tasks, ms);
+	}
 	HIPCHK(e, hipMemcpy(out, dout.p, (size_t)n_tasks * n_out * 4, hipMemcpyDeviceToHost));
 	if (kind == 1) HIPCHK(e, hipMemcpy(cigar, dc.p, (size_t)n_tasks * cigar_cap * 4, hipMemcpyDeviceToHost));
 	dq.release(); dt.release(); dz.release(); dqo.release(); dto.release(); dc.release(); dp.release(); dout.release(); db.release();

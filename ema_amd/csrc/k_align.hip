@@ -176,7 +176,7 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 
 // one wavefront = one read at a time, reads taken from a shared counter
 // intv/n_intv: K1's output.  regs: n_reads x EMA_REG_CAP, n_regs: n_reads.  status is OR-ed.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
             int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg,
@@ -493,4 +493,12 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 {
 	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, intv, n_intv, regs,
 	                   n_regs, status, slabs, counter, dbg, prof);
+}
+
+// resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)
+extern "C" int ema_align_blocks_per_cu()
+{
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align, 256, 0) != hipSuccess || n < 1) n = 1;
+	return n > 8 ? 8 : n;
 }

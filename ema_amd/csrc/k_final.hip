@@ -91,7 +91,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 				w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
 				if (lq == rlen && w2 == 0) {      // gap-free
 					int part = 0;
-					for (int i = lane; i < lq; i += EMA_WAVE) part += opt.mat[ts.at(i) * 5 + qs.at(i)];
+					for (int i = lane; i < lq; i += EMA_WAVE) part += ema_score(opt, ts.at(i), qs.at(i));
 					score = ema_wave_sum(part);
 					first = EMA_CIG_TMP - 1; n_cig = 1;
 					ema_wave_sync();
@@ -216,4 +216,12 @@ extern "C" void ema_launch_pack(int n_reads, const DevReg *regs, const int *n_re
 {
 	hipLaunchKernelGGL(ema_k_pack, dim3(n_blocks), dim3(256), 0, stream, n_reads, regs, n_regs, alns, cigars, cig_n, cig_cap,
 	                   cand_off, cig_off, cand, cigar_out);
+}
+
+// resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)
+extern "C" int ema_final_blocks_per_cu()
+{
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_final, 256, 0) != hipSuccess || n < 1) n = 1;
+	return n > 8 ? 8 : n;
 }

@@ -192,3 +192,11 @@ extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int scor
 	hipLaunchKernelGGL(ema_k_pair, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, score_delta, max_rescue, pes_low, pes_high,
 	                   bases, off, n_pairs, regs, n_regs, status, slabs, counter, dbg);
 }
+
+// resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)
+extern "C" int ema_pair_blocks_per_cu()
+{
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_pair, 256, 0) != hipSuccess || n < 1) n = 1;
+	return n > 8 ? 8 : n;
+}

@@ -42,6 +42,7 @@ int orc_ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
 	max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
 	max_del = max_del > 1 ? max_del : 1;
 	w = w < max_del ? w : max_del;
+	++orc_stats.n_ext_calls;
 	max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1;
 	max_off = 0;
 	beg = 0; end = qlen;
@@ -72,7 +73,7 @@ int orc_ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
 			t = M - oe_ins; t = t > 0 ? t : 0;
 			f -= e_ins; f = f > t ? f : t;
 		}
-		orc_stats.cells_ext += (uint64_t)(end > beg ? end - beg : 0);
+		orc_stats.cells_ext += (uint64_t)(end > beg ? end - beg : 0); ++orc_stats.rows_ext;
 		eh[end].h = h1; eh[end].e = 0;
 		if (j == qlen) {
 			max_ie = gscore > h1 ? max_ie : i;
@@ -169,7 +170,7 @@ int orc_ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
 			f = f > t ? f : t;
 			if (zi) zi[j - beg] = d;
 		}
-		orc_stats.cells_global += (uint64_t)(end > beg ? end - beg : 0);
+		orc_stats.cells_global += (uint64_t)(end > beg ? end - beg : 0); ++orc_stats.rows_global;
 		eh[end].h = h1; eh[end].e = MINUS_INF;
 	}
 	score = eh[qlen].h;
@@ -221,6 +222,7 @@ static orc_kswr_t sw_core(int size, int qlen, const uint8_t *query, int tlen, co
 	int *E = calloc(qpad + 1, sizeof(int)), *Hmax = calloc(qpad + 1, sizeof(int));
 	uint64_t *b = 0; int n_b = 0, m_b = 0;
 
+	++orc_stats.n_local_calls;
 	for (i = 0, k = m * m; i < k; ++i) {
 		if (mat[i] < shift) shift = mat[i];
 		if (mat[i] > mdiff) mdiff = mat[i];
@@ -244,7 +246,7 @@ static orc_kswr_t sw_core(int size, int qlen, const uint8_t *query, int tlen, co
 			t = h - oe_ins; if (t < 0) t = 0;
 			f = f > t ? f : t;
 		}
-		orc_stats.cells_local += (uint64_t)qpad;
+		orc_stats.cells_local += (uint64_t)qpad; ++orc_stats.rows_local;
 		if (imax >= minsc) {
 			if (n_b == 0 || (int32_t)b[n_b - 1] + 1 != i) {
 				if (n_b == m_b) { m_b = m_b ? m_b << 1 : 8; b = realloc(b, 8 * (size_t)m_b); }

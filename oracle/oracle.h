@@ -117,6 +117,7 @@ typedef struct {
 	uint64_t n_cigar;   /* cigar ops returned */
 	uint64_t l_read;    /* read bases */
 	uint64_t cells_ext, cells_local, cells_global; /* DP cells */
+	uint64_t rows_ext, rows_local, rows_global, n_ext_calls, n_local_calls, n_global_calls; /* DP rows / calls */
 } orc_stats_t;
 extern __thread orc_stats_t orc_stats;   /* per thread */
 void orc_stats_get(orc_stats_t *out);

@@ -13,6 +13,18 @@
 #include "k_pair.hip"
 #include "k_final.hip"
 
+static std::vector<uint32_t> pack_reads(const uint8_t *bases, const uint32_t *off, int n_reads)
+{
+	std::vector<uint32_t> q((size_t)n_reads * 24 + 8, 0);
+	for (int r = 0; r < n_reads; ++r)
+		for (uint32_t i = 0; i < off[r + 1] - off[r]; ++i) {
+			const uint8_t b = bases[off[r] + i];
+			q[(size_t)r * 24 + (i >> 4)] |= (uint32_t)(b & 3) << ((i & 15) << 1);
+			if (b > 3) q[(size_t)r * 24 + 16 + (i >> 5)] |= 1u << (i & 31);
+		}
+	return q;
+}
+
 extern "C" {
 
 void *emu_index_load(const char *prefix, char *err, int errlen)
@@ -32,8 +44,10 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	ema_engine_opts o; ema_fill_default_opts(&o);
 	DevOpts d = ema_make_dev_opts(o);
 	DevIndex di = ix->view();
-	std::vector<Intv> lists((size_t)n_blocks * 256 / 8 * 2 * EMA_LIST_CAP);
-	ema_launch_seed(&di, &d, bases, off, n_reads, (Intv *)intv, n_intv, status, lists.data(), n_blocks, nullptr);
+	std::vector<Intv> lists((size_t)n_blocks * 256 * 2 * EMA_LIST_CAP);
+	int seed_counter = 0;
+	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, (Intv *)intv, n_intv, status, lists.data(), &seed_counter, n_blocks, nullptr);
 	return EMA_INTV_CAP;
 }
 
@@ -71,9 +85,11 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	DevIndex di = ix->view();
 	std::vector<Intv> intv((size_t)n_reads * EMA_INTV_CAP);
 	std::vector<int> n_intv(n_reads);
-	std::vector<Intv> lists((size_t)1 * 256 / 8 * 2 * EMA_LIST_CAP);
+	std::vector<Intv> lists((size_t)1 * 256 * 2 * EMA_LIST_CAP);
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
-	ema_launch_seed(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), status, lists.data(), 1, nullptr);
+	int seed_counter = 0;
+	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
 	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
@@ -92,9 +108,11 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	DevIndex di = ix->view();
 	std::vector<Intv> intv((size_t)n_reads * EMA_INTV_CAP);
 	std::vector<int> n_intv(n_reads);
-	std::vector<Intv> lists((size_t)1 * 256 / 8 * 2 * EMA_LIST_CAP);
+	std::vector<Intv> lists((size_t)1 * 256 * 2 * EMA_LIST_CAP);
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
-	ema_launch_seed(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), status, lists.data(), 1, nullptr);
+	int seed_counter = 0;
+	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();

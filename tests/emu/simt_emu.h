@@ -213,6 +213,8 @@ using std::max;
 struct uint4 { unsigned x, y, z, w; };
 struct ulong2 { unsigned long long x, y; };
 
+template <typename K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
+
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                            \
 	do {                                                                                     \
 		dim3 g_ = (grid); dim3 b_ = (block);                                                           \

@@ -56,7 +56,8 @@ class Kswr(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_ext", "n_lf", "n_occ", "w_ref", "n_regs", "n_cigar", "l_read",
-                                          "cells_ext", "cells_local", "cells_global")]
+                                          "cells_ext", "cells_local", "cells_global", "rows_ext", "rows_local",
+                                          "rows_global", "n_ext_calls", "n_local_calls", "n_global_calls")]
 
 
 _lib = None

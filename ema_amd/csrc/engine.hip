@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <unistd.h>
 #include <string>
@@ -408,6 +409,11 @@ int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, i
 	*n_intv = (int32_t *)malloc(n_reads * 4 + 8);
 	HIPCHK(e, hipMemcpy(*intv, e->d_intv.p, n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
 	HIPCHK(e, hipMemcpy(*n_intv, e->d_n_intv.p, n_reads * 4, hipMemcpyDeviceToHost));
+	// K1 emits in discovery order; present the lists as mem_collect_intv leaves them: ordered by (start, end)
+	for (size_t r = 0; r < n_reads; ++r) {
+		Intv *a = (Intv *)(*intv) + r * EMA_INTV_CAP;
+		std::stable_sort(a, a + (*n_intv)[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });
+	}
 	*cap_per_read = EMA_INTV_CAP;
 	return EMA_OK;
 }

@@ -28,11 +28,12 @@ struct AlignSlab {           // per resident wave
 	uint64_t *srt;           // EMA_SEED_CAP
 	DevReg *av, *av_tmp;     // EMA_AV_CAP
 	uint64_t *rkeys;         // EMA_AV_CAP
+	Intv *ivs;               // EMA_INTV_CAP      the read's seed intervals ordered by (start, end)
 };
 
 #define EMA_ALIGN_SLAB_BYTES                                                                                       \
 	((size_t)EMA_SEED_CAP * (2 * sizeof(SeedRec) + 8) + (size_t)EMA_CHAIN_CAP * (sizeof(ChainRec) + 8 + 4 + 8 + 4) +  \
-	 (size_t)EMA_AV_CAP * (2 * sizeof(DevReg) + 8) + 1024)
+	 (size_t)EMA_AV_CAP * (2 * sizeof(DevReg) + 8) + (size_t)EMA_INTV_CAP * sizeof(Intv) + 1024)
 
 __device__ __forceinline__ AlignSlab ema_carve_slab(uint8_t *base)
 {
@@ -50,6 +51,7 @@ __device__ __forceinline__ AlignSlab ema_carve_slab(uint8_t *base)
 	s.av = (DevReg *)take((size_t)EMA_AV_CAP * sizeof(DevReg));
 	s.av_tmp = (DevReg *)take((size_t)EMA_AV_CAP * sizeof(DevReg));
 	s.rkeys = (uint64_t *)take((size_t)EMA_AV_CAP * 8);
+	s.ivs = (Intv *)take((size_t)EMA_INTV_CAP * sizeof(Intv));
 	return s;
 }
 
@@ -211,8 +213,22 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		const int l_query = ema_uni((int)(off[read + 1] - off[read]));
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
 		ema_wave_sync();
-		const Intv *iv = intv + (size_t)read * EMA_INTV_CAP;
 		const int n_iv = ema_uni(n_intv[read]);
+		const Intv *iv = sl.ivs;
+		{   // K1 delivers the intervals in discovery order; mem_collect_intv ends with a sort on (start, end).
+			// Entries with equal keys are identical, so ranking each entry (ties by position) gives THE order.
+			const Intv *raw = intv + (size_t)read * EMA_INTV_CAP;
+			for (int i = lane; i < n_iv; i += EMA_WAVE) {
+				const Intv mine = raw[i];
+				int rank = 0;
+				for (int k = 0; k < n_iv; ++k) {
+					const uint64_t other = raw[k].info;
+					rank += other < mine.info || (other == mine.info && k < i);
+				}
+				sl.ivs[rank] = mine;
+			}
+			ema_wave_sync();
+		}
 		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
 
 		// ---------------- mem_chain: frac_rep, seed occurrences, chaining ----------------

@@ -48,6 +48,10 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
 	ema_launch_seed(&di, &d, qp.data(), off, n_reads, (Intv *)intv, n_intv, status, lists.data(), &seed_counter, n_blocks, nullptr);
+	for (int r = 0; r < n_reads; ++r) {
+		Intv *a = (Intv *)intv + (size_t)r * EMA_INTV_CAP;
+		std::stable_sort(a, a + n_intv[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });
+	}
 	return EMA_INTV_CAP;
 }
 

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=262144, help="pairs per step and per GPU (one resident batch)")
     ap.add_argument("--genome-mbp", type=float, default=0.0, help="0 = chr20-scale (64.4 Mbp)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="pairs of the same workload timed on the host CPU")
+    ap.add_argument("--streams", type=int, default=0, help="slices of a batch on their own HIP streams (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,6 +112,7 @@ def main():
     from ema_amd.engine import Engine, default_opts
     o = default_opts()
     o.batch_pairs = args.pairs
+    o.n_streams = args.streams
     t = time.time()
     eng = Engine(prefix, device=local, opts=o)
     log(f"[rank {rank}] engine open (index in HBM) {time.time() - t:.1f}s")
@@ -143,7 +145,10 @@ def main():
         kernel_ms[k] /= max(1, args.steps)
 
     # results of the last step: parity spot check against the oracle + bucket statistics
-    batch = eng.fetch()
+    batch = eng.fetch(allow_limit=True)
+    if batch.status.max() != 0:
+        flags, counts = np.unique(batch.status[batch.status != 0], return_counts=True)
+        log(f"[rank {rank}] WARNING: reads exceeded an engine capacity (status flag: count) {dict(zip(flags.tolist(), counts.tolist()))}")
     from ema_amd import shard
     stats_vec = shard.bucket_stats(batch, pairs.n)
     # the "trivial RCCL gather of per-bucket statistics" of the north star: one bucket per rank, O(100 B) over xGMI

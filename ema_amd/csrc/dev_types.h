@@ -39,6 +39,9 @@ struct DevOpts {
 	int min_chain_weight, max_chain_extend;
 	float mask_level, drop_ratio, mask_level_redun;
 	int8_t mat[25];
+	// per-read output capacities of this launch (the engine runs a lean tier and, for the few reads that exceed it,
+	// a second tier with the full EMA_INTV_CAP / EMA_REG_CAP / EMA_CIG_CAP)
+	int intv_cap, reg_cap, cig_cap;
 };
 
 // SMEM / seed interval: bwa's bwtintv_t.  info = start<<32 | end.
@@ -47,6 +50,9 @@ struct Intv { uint64_t x0, x1, x2, info; };
 // per-read capacities of the seeding stage
 #define EMA_INTV_CAP 512      // intervals kept per read
 #define EMA_LIST_CAP 256      // entries of a forward/backward working list (<= read length)
+#define EMA_INTV_LEAN 64
+#define EMA_REG_LEAN 32
+#define EMA_CIG_LEAN 128
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
 
 // bwa's mem_seed_t plus the link to the next seed of the same chain

@@ -1,6 +1,12 @@
 // ema_amd/csrc/engine.hip -- C ABI of the engine (include/ema_engine.h): index upload, batch
 // staging, kernel pipeline, result assembly.  Host side of the drop-in boundary that replaces
 // the reference's per-pair bridge calls (reference src/bwabridge.c:204-311).
+//
+// A batch is cut into `n_streams` slices of consecutive pairs; every slice owns a HIP stream, its buffers and
+// its scratch slabs and runs K1 -> K2 -> K3 -> K4 on that stream.  The kernels are persistent-style (grid =
+// resident blocks) and each ends in a tail in which a few long reads keep a few waves busy; with several
+// slices in flight the blocks of the next slice's kernel start as soon as blocks of the previous one retire,
+// so the tails are filled instead of idling the chip.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +22,7 @@
 
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int *counter, int n_blocks,
-                                hipStream_t stream);
+                                hipStream_t stream, unsigned long long *prof);
 
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
@@ -38,9 +44,9 @@ extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const u
                                  int n_reads, const DevReg *regs, const int *n_regs, DevAln *alns, uint32_t *cigars,
                                  int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
                                  hipStream_t stream, int *dbg);
-extern "C" void ema_launch_pack(int n_reads, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
+extern "C" void ema_launch_pack(int n_reads, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
-                                ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream);
+                                uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream);
 extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
                                        const uint32_t *toff, const int *prm, int n_tasks, int *out, hipStream_t s);
 extern "C" void ema_launch_test_global(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
@@ -77,6 +83,36 @@ template <typename T> struct DevBuf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// one slice of the batch: consecutive pairs [first_pair, first_pair + n_pairs) on their own stream
+struct Slice {
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	size_t cap_pairs = 0, n_pairs = 0, first_pair = 0;
+	std::vector<uint32_t> h_off;
+	DevBuf<uint8_t> d_bases;
+	DevBuf<uint32_t> d_off, d_qpack;   // d_qpack: 24 words per read (2-bit codes + N mask) for K1
+	DevBuf<Intv> d_intv, d_lists;
+	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n;
+	DevBuf<DevReg> d_regs;
+	DevBuf<uint8_t> d_slabs;
+	DevBuf<DevAln> d_alns;
+	DevBuf<uint32_t> d_cigars, d_cigar_out;
+	DevBuf<uint64_t> d_cand_off, d_cig_off;
+	DevBuf<ema_cand_t> d_cand;
+	size_t cand_cap = 0, cigar_out_cap = 0;
+	int *dbg = nullptr;               // EMA_WATCHDOG_S: host-visible per-wave progress words
+	float ms[4] = {0, 0, 0, 0};       // K1..K4 of the last run
+	void release()
+	{
+		d_bases.release(); d_off.release(); d_qpack.release(); d_intv.release(); d_lists.release(); d_n_intv.release();
+		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_regs.release(); d_slabs.release();
+		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
+		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+		if (stream) (void)hipStreamDestroy(stream);
+		if (dbg) (void)hipHostFree(dbg);
+	}
+};
+
 }  // namespace
 
 struct ema_engine {
@@ -87,42 +123,21 @@ struct ema_engine {
 	int64_t l_pac = 0;
 	int device = 0;
 	int n_cu = 256;
-	hipStream_t stream = nullptr;
 	std::string err;
 	// index in HBM
 	DevBuf<OccSlot> d_occ;
 	DevBuf<uint8_t> d_sa, d_pac;
 	DevBuf<int64_t> d_ctg;
 	// batch
+	std::vector<Slice> sl;
 	size_t cap_pairs = 0, n_pairs = 0;
 	bool staged = false, ran = false;
 	std::vector<uint8_t> h_nt4;
 	std::vector<uint32_t> h_off, h_qpack;
-	DevBuf<uint8_t> d_bases;
-	DevBuf<uint32_t> d_off, d_qpack;   // d_qpack: 24 words per read (2-bit codes + N mask) for K1
-	// K1
-	int seed_blocks = 0;
-	DevBuf<Intv> d_intv, d_lists;
-	DevBuf<int> d_n_intv, d_status;
-	// K2
-	int align_blocks = 0;
-	DevBuf<DevReg> d_regs;
-	DevBuf<int> d_n_regs, d_counters;
+	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0;
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
-	DevBuf<uint8_t> d_slabs;
-	// K3 / K4 / pack
-	int pair_blocks = 0, final_blocks = 0;
-	DevBuf<DevAln> d_alns;
-	DevBuf<uint32_t> d_cigars, d_cigar_out;
-	DevBuf<int> d_cig_n;
-	DevBuf<uint64_t> d_cand_off, d_cig_off;
-	DevBuf<ema_cand_t> d_cand;
-	size_t cand_cap = 0, cigar_out_cap = 0;
-	// development aid (EMA_WATCHDOG_S=<seconds>): host-visible per-wave progress words + a poll after every launch
-	int *dbg = nullptr;
 	int dbg_slots = 0;
-	double watchdog_s = 0;
-	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	double watchdog_s = 0;               // EMA_WATCHDOG_S=<seconds>: poll after every launch, report stuck waves
 	ema_engine_timing timing;
 };
 
@@ -139,33 +154,34 @@ extern "C" {
 
 void ema_engine_opts_default(ema_engine_opts *o) { ema_fill_default_opts(o); }
 
-static int engine_alloc_batch(ema_engine *e)
+static int slice_alloc(ema_engine *e, Slice &s)
 {
-	const size_t n_reads = 2 * e->cap_pairs;
-	HIPCHK(e, e->d_bases.alloc(n_reads * (size_t)(EMA_MAX_READ + 1)));
-	HIPCHK(e, e->d_off.alloc(n_reads + 1));
-	HIPCHK(e, e->d_qpack.alloc(n_reads * 24 + 8));
-	HIPCHK(e, e->d_intv.alloc(n_reads * (size_t)EMA_INTV_CAP));
-	HIPCHK(e, e->d_n_intv.alloc(n_reads));
-	HIPCHK(e, e->d_status.alloc(n_reads));
-	e->seed_blocks = e->n_cu * ema_seed_blocks_per_cu();      // every resident lane carries one read
-	HIPCHK(e, e->d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
-	HIPCHK(e, e->d_regs.alloc(n_reads * (size_t)EMA_REG_CAP));
-	HIPCHK(e, e->d_n_regs.alloc(n_reads));
-	HIPCHK(e, e->d_counters.alloc(16));
-	e->align_blocks = e->n_cu * ema_align_blocks_per_cu();    // one scratch slab per resident wave
-	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
-	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
+	const size_t n_reads = 2 * s.cap_pairs;
+	HIPCHK(e, hipStreamCreate(&s.stream));
+	for (auto &ev : s.ev) HIPCHK(e, hipEventCreate(&ev));
+	HIPCHK(e, s.d_bases.alloc(n_reads * (size_t)(EMA_MAX_READ + 1)));
+	HIPCHK(e, s.d_off.alloc(n_reads + 1));
+	HIPCHK(e, s.d_qpack.alloc(n_reads * 24 + 8));
+	HIPCHK(e, s.d_intv.alloc(n_reads * (size_t)EMA_INTV_CAP));
+	HIPCHK(e, s.d_n_intv.alloc(n_reads));
+	HIPCHK(e, s.d_status.alloc(n_reads));
+	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
+	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)EMA_REG_CAP));
+	HIPCHK(e, s.d_n_regs.alloc(n_reads));
+	HIPCHK(e, s.d_counters.alloc(16));
 	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
 	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
 	if ((size_t)e->final_blocks * 4 * ema_final_slab_bytes() > slab) slab = (size_t)e->final_blocks * 4 * ema_final_slab_bytes();
-	HIPCHK(e, e->d_slabs.alloc(slab));
-	if (ema_sizeof_aln() != sizeof(DevAln)) { e->err = "DevAln layout mismatch"; return EMA_EDEVICE; }
-	HIPCHK(e, e->d_alns.alloc(n_reads * (size_t)EMA_REG_CAP));
-	HIPCHK(e, e->d_cigars.alloc(n_reads * (size_t)EMA_CIG_CAP));
-	HIPCHK(e, e->d_cig_n.alloc(n_reads));
-	HIPCHK(e, e->d_cand_off.alloc(n_reads + 1));
-	HIPCHK(e, e->d_cig_off.alloc(n_reads + 1));
+	HIPCHK(e, s.d_slabs.alloc(slab));
+	HIPCHK(e, s.d_alns.alloc(n_reads * (size_t)EMA_REG_CAP));
+	HIPCHK(e, s.d_cigars.alloc(n_reads * (size_t)EMA_CIG_CAP));
+	HIPCHK(e, s.d_cig_n.alloc(n_reads));
+	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
+	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
+	if (e->watchdog_s > 0 && !getenv("EMA_WATCHDOG_NOMARK")) {
+		HIPCHK(e, hipHostMalloc((void **)&s.dbg, (size_t)e->dbg_slots * 4 * sizeof(int), hipHostMallocDefault));
+		memset(s.dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
+	}
 	return EMA_OK;
 }
 
@@ -186,8 +202,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	hipDeviceProp_t prop;
 	HIPCHK(e, hipGetDeviceProperties(&prop, device));
 	e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	HIPCHK(e, hipStreamCreate(&e->stream));
-	for (auto &ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
+	if (ema_sizeof_aln() != sizeof(DevAln)) { e->err = "DevAln layout mismatch"; return EMA_EDEVICE; }
 
 	HostIndex hix;
 	std::string msg = host_index_load(index_prefix, hix);
@@ -205,18 +220,24 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
 
-	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(8)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 64)); }
-	if (const char *wd = getenv("EMA_WATCHDOG_S")) {
-		e->watchdog_s = atof(wd);
-		e->dbg_slots = e->n_cu * 8 * 4 + 64;
-		if (!getenv("EMA_WATCHDOG_NOMARK")) {
-			HIPCHK(e, hipHostMalloc((void **)&e->dbg, (size_t)e->dbg_slots * 4 * sizeof(int), hipHostMallocDefault));
-			memset(e->dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
-		}
+	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(16)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 128)); }
+	if (const char *wd = getenv("EMA_WATCHDOG_S")) { e->watchdog_s = atof(wd); e->dbg_slots = e->n_cu * 8 * 4 + 64; }
+	e->seed_blocks = e->n_cu * ema_seed_blocks_per_cu();      // every resident lane carries one read
+	e->align_blocks = e->n_cu * ema_align_blocks_per_cu();    // one scratch slab per resident wave
+	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
+	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
+
+	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // the device exposes 3 hardware queues to one process: a 4th stream only serialises
+	if (n_streams > 16) n_streams = 16;
+	const size_t want = e->opts.batch_pairs > 0 ? (size_t)e->opts.batch_pairs : (size_t)262144;
+	const size_t per = (want + n_streams - 1) / n_streams;
+	e->sl.resize(n_streams);
+	for (auto &s : e->sl) {
+		s.cap_pairs = per;
+		int rc = slice_alloc(e, s);
+		if (rc != EMA_OK) return rc;
 	}
-	e->cap_pairs = e->opts.batch_pairs > 0 ? (size_t)e->opts.batch_pairs : (size_t)131072;
-	int rc = engine_alloc_batch(e);
-	if (rc != EMA_OK) return rc;
+	e->cap_pairs = per * n_streams;
 	return EMA_OK;
 }
 
@@ -224,14 +245,8 @@ void ema_engine_close(ema_engine_t *e)
 {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
-	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release();
-	e->d_bases.release(); e->d_off.release(); e->d_qpack.release(); e->d_intv.release(); e->d_lists.release();
-	e->d_n_intv.release(); e->d_status.release();
-	e->d_regs.release(); e->d_n_regs.release(); e->d_counters.release(); e->d_slabs.release();
-	e->d_alns.release(); e->d_cigars.release(); e->d_cigar_out.release(); e->d_cig_n.release();
-	e->d_cand_off.release(); e->d_cig_off.release(); e->d_cand.release();
-	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
-	if (e->stream) (void)hipStreamDestroy(e->stream);
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_prof.release();
+	for (auto &s : e->sl) s.release();
 	delete e;
 }
 
@@ -277,72 +292,85 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 			if (b[i] > 3) w[16 + (i >> 5)] |= 1u << (i & 31);
 		}
 	}
-	HIPCHK(e, hipMemcpyAsync(e->d_qpack.p, e->h_qpack.data(), (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, e->stream));
-	HIPCHK(e, hipMemcpyAsync(e->d_bases.p, e->h_nt4.data(), total, hipMemcpyHostToDevice, e->stream));
-	HIPCHK(e, hipMemcpyAsync(e->d_off.p, e->h_off.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, e->stream));
-	HIPCHK(e, hipStreamSynchronize(e->stream));
+	// consecutive pairs go to consecutive slices, as evenly as the slice count allows
+	const size_t n_sl = e->sl.size();
+	size_t first = 0;
+	for (size_t k = 0; k < n_sl; ++k) {
+		Slice &s = e->sl[k];
+		s.first_pair = first;
+		s.n_pairs = (n_pairs - first + (n_sl - k) - 1) / (n_sl - k);
+		if (s.n_pairs > s.cap_pairs) s.n_pairs = s.cap_pairs;
+		const size_t r0 = 2 * first, nr = 2 * s.n_pairs;
+		s.h_off.resize(nr + 1);
+		for (size_t r = 0; r <= nr; ++r) s.h_off[r] = e->h_off[r0 + r] - e->h_off[r0];
+		HIPCHK(e, hipMemcpyAsync(s.d_qpack.p, e->h_qpack.data() + r0 * 24, (nr * 24 + 8) * 4, hipMemcpyHostToDevice, s.stream));
+		HIPCHK(e, hipMemcpyAsync(s.d_bases.p, e->h_nt4.data() + e->h_off[r0], s.h_off[nr], hipMemcpyHostToDevice, s.stream));
+		HIPCHK(e, hipMemcpyAsync(s.d_off.p, s.h_off.data(), (nr + 1) * 4, hipMemcpyHostToDevice, s.stream));
+		first += s.n_pairs;
+	}
+	if (first != n_pairs) { e->err = "internal: slices do not cover the batch"; return EMA_ESTATE; }
+	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
 	e->n_pairs = n_pairs;
 	e->staged = true; e->ran = false;
 	return EMA_OK;
 }
 
 // EMA_WATCHDOG_S: wait for the stream with a deadline; on expiry print where every unfinished wave is and exit
-static void watchdog(ema_engine *e, const char *what)
+static void watchdog(ema_engine *e, Slice &s, const char *what)
 {
 	if (e->watchdog_s <= 0) return;
 	const int n_poll = (int)(e->watchdog_s * 100);
-	for (int t = 0; t < n_poll && hipStreamQuery(e->stream) == hipErrorNotReady; ++t) usleep(10000);
-	if (hipStreamQuery(e->stream) == hipErrorNotReady) {
+	for (int t = 0; t < n_poll && hipStreamQuery(s.stream) == hipErrorNotReady; ++t) usleep(10000);
+	if (hipStreamQuery(s.stream) == hipErrorNotReady) {
 		fprintf(stderr, "%s still running after %.1f s; unfinished waves (slot: unit stage value):\n", what, e->watchdog_s);
 		int shown = 0;
-		for (int sl = 0; sl < e->dbg_slots && shown < 64; ++sl)
-			if (e->dbg && e->dbg[sl * 4] >= 0 && e->dbg[sl * 4 + 1] != 9) { fprintf(stderr, "  %d: %d %d %d 0x%x\n", sl, e->dbg[sl * 4], e->dbg[sl * 4 + 1], e->dbg[sl * 4 + 2], e->dbg[sl * 4 + 3]); ++shown; }
+		for (int k = 0; k < e->dbg_slots && shown < 64; ++k)
+			if (s.dbg && s.dbg[k * 4] >= 0 && s.dbg[k * 4 + 1] != 9) { fprintf(stderr, "  %d: %d %d %d 0x%x\n", k, s.dbg[k * 4], s.dbg[k * 4 + 1], s.dbg[k * 4 + 2], s.dbg[k * 4 + 3]); ++shown; }
 		fflush(stderr);
 		_exit(3);
 	}
-	if (e->dbg) memset(e->dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
+	if (s.dbg) memset(s.dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
 }
 
-static int run_seed(ema_engine *e)
+static int run_seed(ema_engine *e, Slice &s)
 {
-	const int n_reads = (int)(2 * e->n_pairs);
-	HIPCHK(e, hipMemsetAsync(e->d_status.p, 0, (size_t)n_reads * 4, e->stream));
-	HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, 16 * 4, e->stream));
-	ema_launch_seed(&e->dix, &e->dopts, e->d_qpack.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_status.p,
-	                e->d_lists.p, e->d_counters.p + 3, e->seed_blocks, e->stream);
+	const int n_reads = (int)(2 * s.n_pairs);
+	HIPCHK(e, hipMemsetAsync(s.d_status.p, 0, (size_t)n_reads * 4, s.stream));
+	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 16 * 4, s.stream));
+	ema_launch_seed(&e->dix, &e->dopts, s.d_qpack.p, s.d_off.p, n_reads, s.d_intv.p, s.d_n_intv.p, s.d_status.p, s.d_lists.p,
+	                s.d_counters.p + 3, e->seed_blocks, s.stream, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
-	watchdog(e, "ema_k_seed");
+	watchdog(e, s, "ema_k_seed");
 	return EMA_OK;
 }
 
-static int run_align(ema_engine *e)
+static int run_align(ema_engine *e, Slice &s)
 {
-	const int n_reads = (int)(2 * e->n_pairs);
-	ema_launch_align(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_intv.p, e->d_n_intv.p, e->d_regs.p,
-	                 e->d_n_regs.p, e->d_status.p, e->d_slabs.p, e->d_counters.p + 0, e->align_blocks, e->stream, e->dbg, e->d_prof.p);
+	const int n_reads = (int)(2 * s.n_pairs);
+	ema_launch_align(&e->dix, &e->dopts, s.d_bases.p, s.d_off.p, n_reads, s.d_intv.p, s.d_n_intv.p, s.d_regs.p, s.d_n_regs.p,
+	                 s.d_status.p, s.d_slabs.p, s.d_counters.p + 0, e->align_blocks, s.stream, s.dbg, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
-	watchdog(e, "ema_k_align");
+	watchdog(e, s, "ema_k_align");
 	return EMA_OK;
 }
 
-static int run_pair(ema_engine *e)
+static int run_pair(ema_engine *e, Slice &s)
 {
-	ema_launch_pair(&e->dix, &e->dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high,
-	                e->d_bases.p, e->d_off.p, (int)e->n_pairs, e->d_regs.p, e->d_n_regs.p, e->d_status.p, e->d_slabs.p,
-	                e->d_counters.p + 1, e->pair_blocks, e->stream, e->dbg);
+	ema_launch_pair(&e->dix, &e->dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high, s.d_bases.p,
+	                s.d_off.p, (int)s.n_pairs, s.d_regs.p, s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 1,
+	                e->pair_blocks, s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
-	watchdog(e, "ema_k_pair");
+	watchdog(e, s, "ema_k_pair");
 	return EMA_OK;
 }
 
-static int run_final(ema_engine *e)
+static int run_final(ema_engine *e, Slice &s)
 {
-	const int n_reads = (int)(2 * e->n_pairs);
-	ema_launch_final(&e->dix, &e->dopts, e->d_bases.p, e->d_off.p, n_reads, e->d_regs.p, e->d_n_regs.p, e->d_alns.p,
-	                 e->d_cigars.p, e->d_cig_n.p, EMA_CIG_CAP, e->d_status.p, e->d_slabs.p, e->d_counters.p + 2,
-	                 e->final_blocks, e->stream, e->dbg);
+	const int n_reads = (int)(2 * s.n_pairs);
+	ema_launch_final(&e->dix, &e->dopts, s.d_bases.p, s.d_off.p, n_reads, s.d_regs.p, s.d_n_regs.p, s.d_alns.p, s.d_cigars.p,
+	                 s.d_cig_n.p, EMA_CIG_CAP, s.d_status.p, s.d_slabs.p, s.d_counters.p + 2, e->final_blocks, s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
-	watchdog(e, "ema_k_final");
+	watchdog(e, s, "ema_k_final");
 	return EMA_OK;
 }
 
@@ -351,16 +379,18 @@ int ema_engine_run(ema_engine_t *e)
 	if (!e) return EMA_EARG;
 	if (!e->staged) { e->err = "ema_engine_run before ema_engine_stage"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
-	HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
-	int rc = run_seed(e);
-	if (rc) return rc;
-	HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
-	if ((rc = run_align(e))) return rc;
-	HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
-	if ((rc = run_pair(e))) return rc;
-	HIPCHK(e, hipEventRecord(e->ev[3], e->stream));
-	if ((rc = run_final(e))) return rc;
-	HIPCHK(e, hipEventRecord(e->ev[4], e->stream));
+	int rc;
+	for (auto &s : e->sl) {      // every slice queues its whole chain on its own stream
+		HIPCHK(e, hipEventRecord(s.ev[0], s.stream));
+		if ((rc = run_seed(e, s))) return rc;
+		HIPCHK(e, hipEventRecord(s.ev[1], s.stream));
+		if ((rc = run_align(e, s))) return rc;
+		HIPCHK(e, hipEventRecord(s.ev[2], s.stream));
+		if ((rc = run_pair(e, s))) return rc;
+		HIPCHK(e, hipEventRecord(s.ev[3], s.stream));
+		if ((rc = run_final(e, s))) return rc;
+		HIPCHK(e, hipEventRecord(s.ev[4], s.stream));
+	}
 	e->ran = true;
 	return EMA_OK;
 }
@@ -369,27 +399,32 @@ int ema_engine_sync(ema_engine_t *e)
 {
 	if (!e) return EMA_EARG;
 	HIPCHK(e, hipSetDevice(e->device));
-	HIPCHK(e, hipStreamSynchronize(e->stream));
-	if (e->ran) {
-		HIPCHK(e, hipEventElapsedTime(&e->timing.seed_ms, e->ev[0], e->ev[1]));
-		HIPCHK(e, hipEventElapsedTime(&e->timing.extend_ms, e->ev[1], e->ev[2]));
-		HIPCHK(e, hipEventElapsedTime(&e->timing.rescue_ms, e->ev[2], e->ev[3]));
-		HIPCHK(e, hipEventElapsedTime(&e->timing.final_ms, e->ev[3], e->ev[4]));
-		HIPCHK(e, hipEventElapsedTime(&e->timing.total_ms, e->ev[0], e->ev[4]));
+	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
+	if (e->ran) {      // mean launch duration of each kernel over the slices (launches of different slices overlap)
+		float sum[4] = {0, 0, 0, 0};
+		for (auto &s : e->sl)
+			for (int k = 0; k < 4; ++k) { HIPCHK(e, hipEventElapsedTime(&s.ms[k], s.ev[k], s.ev[k + 1])); sum[k] += s.ms[k]; }
+		const float n = (float)e->sl.size();
+		e->timing.seed_ms = sum[0] / n; e->timing.chain_ms = 0; e->timing.extend_ms = sum[1] / n;
+		e->timing.rescue_ms = sum[2] / n; e->timing.final_ms = sum[3] / n;
+		e->timing.total_ms = (sum[0] + sum[1] + sum[2] + sum[3]) / n;
 	}
 	return EMA_OK;
 }
+
+int ema_engine_n_streams(const ema_engine_t *e) { return e ? (int)e->sl.size() : 0; }
 
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 {
 	if (!e || !t) return EMA_EARG;
 	if (e->d_prof.p) {
-		unsigned long long h[8];
-		if (hipMemcpy(h, e->d_prof.p, 64, hipMemcpyDeviceToHost) == hipSuccess) {
+		unsigned long long h[16];
+		if (hipMemcpy(h, e->d_prof.p, 128, hipMemcpyDeviceToHost) == hipSuccess) {
 			fprintf(stderr, "K2 phase ticks (idle/fetch, chain, filter, chain2aln-ctl, extend-dp, dedup):");
 			for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", h[i]);
-			fprintf(stderr, "\n");
-			(void)hipMemset(e->d_prof.p, 0, 64);
+			fprintf(stderr, "\nK1: wave-ticks %llu, active lane-ticks %llu (%.1f lanes/tick), clocks per wave-tick %.0f, longest wave %llu ticks\n", h[8], h[9],
+			        h[8] ? (double)h[9] / h[8] : 0., h[8] ? (double)h[10] / h[8] : 0., h[11]);
+			(void)hipMemset(e->d_prof.p, 0, 128);
 		}
 	}
 	*t = e->timing;
@@ -401,14 +436,17 @@ int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, i
 	if (!e || !intv || !n_intv || !cap_per_read) return EMA_EARG;
 	if (!e->staged) { e->err = "ema_engine_debug_seeds before ema_engine_stage"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
-	int rc = run_seed(e);
-	if (rc) return rc;
-	HIPCHK(e, hipStreamSynchronize(e->stream));
+	int rc;
+	for (auto &s : e->sl) if ((rc = run_seed(e, s))) return rc;
 	const size_t n_reads = 2 * e->n_pairs;
 	*intv = (uint64_t *)malloc(n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv) + 8);
 	*n_intv = (int32_t *)malloc(n_reads * 4 + 8);
-	HIPCHK(e, hipMemcpy(*intv, e->d_intv.p, n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
-	HIPCHK(e, hipMemcpy(*n_intv, e->d_n_intv.p, n_reads * 4, hipMemcpyDeviceToHost));
+	for (auto &s : e->sl) {
+		HIPCHK(e, hipStreamSynchronize(s.stream));
+		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
+		HIPCHK(e, hipMemcpy((Intv *)(*intv) + r0 * EMA_INTV_CAP, s.d_intv.p, nr * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(*n_intv + r0, s.d_n_intv.p, nr * 4, hipMemcpyDeviceToHost));
+	}
 	// K1 emits in discovery order; present the lists as mem_collect_intv leaves them: ordered by (start, end)
 	for (size_t r = 0; r < n_reads; ++r) {
 		Intv *a = (Intv *)(*intv) + r * EMA_INTV_CAP;
@@ -424,17 +462,19 @@ int ema_engine_debug_regions(ema_engine_t *e, void **regs, int32_t **n_regs, int
 	if (!e || !regs || !n_regs || !status || !cap_per_read || !reg_bytes) return EMA_EARG;
 	if (!e->staged) { e->err = "ema_engine_debug_regions before ema_engine_stage"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
-	int rc = run_seed(e);
-	if (rc) return rc;
-	if ((rc = run_align(e))) return rc;
-	HIPCHK(e, hipStreamSynchronize(e->stream));
+	int rc;
+	for (auto &s : e->sl) { if ((rc = run_seed(e, s))) return rc; if ((rc = run_align(e, s))) return rc; }
 	const size_t n_reads = 2 * e->n_pairs;
 	*regs = malloc(n_reads * (size_t)EMA_REG_CAP * sizeof(DevReg) + 8);
 	*n_regs = (int32_t *)malloc(n_reads * 4 + 8);
 	*status = (int32_t *)malloc(n_reads * 4 + 8);
-	HIPCHK(e, hipMemcpy(*regs, e->d_regs.p, n_reads * (size_t)EMA_REG_CAP * sizeof(DevReg), hipMemcpyDeviceToHost));
-	HIPCHK(e, hipMemcpy(*n_regs, e->d_n_regs.p, n_reads * 4, hipMemcpyDeviceToHost));
-	HIPCHK(e, hipMemcpy(*status, e->d_status.p, n_reads * 4, hipMemcpyDeviceToHost));
+	for (auto &s : e->sl) {
+		HIPCHK(e, hipStreamSynchronize(s.stream));
+		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
+		HIPCHK(e, hipMemcpy((DevReg *)(*regs) + r0 * EMA_REG_CAP, s.d_regs.p, nr * (size_t)EMA_REG_CAP * sizeof(DevReg), hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(*n_regs + r0, s.d_n_regs.p, nr * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(*status + r0, s.d_status.p, nr * 4, hipMemcpyDeviceToHost));
+	}
 	*cap_per_read = EMA_REG_CAP;
 	*reg_bytes = (int32_t)sizeof(DevReg);
 	return EMA_OK;
@@ -451,9 +491,9 @@ int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int
 	HIPCHK(e, dr.alloc(tot)); HIPCHK(e, dt.alloc(tot)); HIPCHK(e, dk.alloc(tot)); HIPCHK(e, dn.alloc(n_tasks)); HIPCHK(e, dm.alloc(n_tasks));
 	HIPCHK(e, hipMemcpy(dr.p, regs, tot * sizeof(DevReg), hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(dn.p, n_in, (size_t)n_tasks * 4, hipMemcpyHostToDevice));
-	ema_launch_test_dedup(&e->dix, &e->dopts, dr.p, dn.p, dm.p, cap, n_tasks, dt.p, dk.p, e->stream);
+	ema_launch_test_dedup(&e->dix, &e->dopts, dr.p, dn.p, dm.p, cap, n_tasks, dt.p, dk.p, e->sl[0].stream);
 	HIPCHK(e, hipGetLastError());
-	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipStreamSynchronize(e->sl[0].stream));
 	HIPCHK(e, hipMemcpy(regs, dr.p, tot * sizeof(DevReg), hipMemcpyDeviceToHost));
 	HIPCHK(e, hipMemcpy(n_out, dm.p, (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
 	dr.release(); dt.release(); dk.release(); dn.release(); dm.release();
@@ -479,23 +519,23 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
 	HIPCHK(e, hipMemcpy(dqo.p, qoff, (n_tasks + 1) * 4, hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(dto.p, toff, (n_tasks + 1) * 4, hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(dp.p, prm, (size_t)n_tasks * n_prm * 4, hipMemcpyHostToDevice));
-	HIPCHK(e, hipEventRecord(e->ev[5], e->stream));
-	if (kind == 0) ema_launch_test_extend(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, e->stream);
+	HIPCHK(e, hipEventRecord(e->sl[0].ev[5], e->sl[0].stream));
+	if (kind == 0) ema_launch_test_extend(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, e->sl[0].stream);
 	else if (kind == 1) {
 		if (!cigar || cigar_cap <= 0) return EMA_EARG;
 		HIPCHK(e, dz.alloc((size_t)n_tasks * z_stride));
 		HIPCHK(e, dc.alloc((size_t)n_tasks * cigar_cap));
-		ema_launch_test_global(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, dc.p, cigar_cap, dz.p, z_stride, e->stream);
+		ema_launch_test_global(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, dc.p, cigar_cap, dz.p, z_stride, e->sl[0].stream);
 	} else {
 		HIPCHK(e, db.alloc((size_t)n_tasks * b_stride));
-		ema_launch_test_local(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, db.p, b_stride, e->stream);
+		ema_launch_test_local(&e->dopts, dq.p, dqo.p, dt.p, dto.p, dp.p, n_tasks, dout.p, db.p, b_stride, e->sl[0].stream);
 	}
 	HIPCHK(e, hipGetLastError());
-	HIPCHK(e, hipEventRecord(e->ev[6], e->stream));
-	HIPCHK(e, hipStreamSynchronize(e->stream));
+	HIPCHK(e, hipEventRecord(e->sl[0].ev[6], e->sl[0].stream));
+	HIPCHK(e, hipStreamSynchronize(e->sl[0].stream));
 	if (getenv("EMA_DP_TIMING")) {
 		float ms = 0;
-		(void)hipEventElapsedTime(&ms, e->ev[5], e->ev[6]);
+		(void)hipEventElapsedTime(&ms, e->sl[0].ev[5], e->sl[0].ev[6]);
 		fprintf(stderr, "debug_dp kind %d: %d tasks in %.3f ms\n", kind, n_tasks, ms);
 	}
 	HIPCHK(e, hipMemcpy(out, dout.p, (size_t)n_tasks * n_out * 4, hipMemcpyDeviceToHost));
@@ -510,11 +550,14 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	*out = nullptr;
 	if (!e->ran) { e->err = "ema_engine_fetch before ema_engine_run"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
-	HIPCHK(e, hipStreamSynchronize(e->stream));
 	const size_t n_reads = 2 * e->n_pairs;
-	std::vector<int> n_regs(n_reads), cig_n(n_reads);
-	HIPCHK(e, hipMemcpy(n_regs.data(), e->d_n_regs.p, n_reads * 4, hipMemcpyDeviceToHost));
-	HIPCHK(e, hipMemcpy(cig_n.data(), e->d_cig_n.p, n_reads * 4, hipMemcpyDeviceToHost));
+	std::vector<int> n_regs(n_reads + 1), cig_n(n_reads + 1);
+	for (auto &s : e->sl) {
+		HIPCHK(e, hipStreamSynchronize(s.stream));
+		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
+		HIPCHK(e, hipMemcpy(n_regs.data() + r0, s.d_n_regs.p, nr * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(cig_n.data() + r0, s.d_cig_n.p, nr * 4, hipMemcpyDeviceToHost));
+	}
 	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
 	o->n_pairs = e->n_pairs;
 	o->cand_off = (uint64_t *)malloc((n_reads + 1) * 8);
@@ -530,17 +573,25 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
 	o->status = (int32_t *)malloc((n_reads + 1) * 4);
 	*out = o;
-	if (n_cand + 1 > e->cand_cap) { e->cand_cap = (n_cand + 1) * 5 / 4 + 1024; HIPCHK(e, e->d_cand.alloc(e->cand_cap)); }
-	if (n_cig + 1 > e->cigar_out_cap) { e->cigar_out_cap = (n_cig + 1) * 5 / 4 + 1024; HIPCHK(e, e->d_cigar_out.alloc(e->cigar_out_cap)); }
-	HIPCHK(e, hipMemcpyAsync(e->d_cand_off.p, o->cand_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, e->stream));
-	HIPCHK(e, hipMemcpyAsync(e->d_cig_off.p, cig_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, e->stream));
-	ema_launch_pack((int)n_reads, e->d_regs.p, e->d_n_regs.p, e->d_alns.p, e->d_cigars.p, e->d_cig_n.p, EMA_CIG_CAP,
-	                e->d_cand_off.p, e->d_cig_off.p, e->d_cand.p, e->d_cigar_out.p, e->n_cu * 4, e->stream);
-	HIPCHK(e, hipGetLastError());
-	HIPCHK(e, hipMemcpyAsync(o->cand, e->d_cand.p, n_cand * sizeof(ema_cand_t), hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(e, hipMemcpyAsync(o->cigar, e->d_cigar_out.p, n_cig * 4, hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(e, hipMemcpyAsync(o->status, e->d_status.p, n_reads * 4, hipMemcpyDeviceToHost, e->stream));
-	HIPCHK(e, hipStreamSynchronize(e->stream));
+	std::vector<uint64_t> loc_cand, loc_cig;
+	for (auto &s : e->sl) {      // pack every slice into contiguous arrays and copy them to their place in the batch
+		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
+		const uint64_t c0 = o->cand_off[r0], g0 = cig_off[r0];
+		const size_t nc = o->cand_off[r0 + nr] - c0, ng = cig_off[r0 + nr] - g0;
+		loc_cand.resize(nr + 1); loc_cig.resize(nr + 1);
+		for (size_t r = 0; r <= nr; ++r) { loc_cand[r] = o->cand_off[r0 + r] - c0; loc_cig[r] = cig_off[r0 + r] - g0; }
+		if (nc + 1 > s.cand_cap) { s.cand_cap = (nc + 1) * 5 / 4 + 1024; HIPCHK(e, s.d_cand.alloc(s.cand_cap)); }
+		if (ng + 1 > s.cigar_out_cap) { s.cigar_out_cap = (ng + 1) * 5 / 4 + 1024; HIPCHK(e, s.d_cigar_out.alloc(s.cigar_out_cap)); }
+		HIPCHK(e, hipMemcpy(s.d_cand_off.p, loc_cand.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
+		HIPCHK(e, hipMemcpy(s.d_cig_off.p, loc_cig.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
+		ema_launch_pack((int)nr, EMA_REG_CAP, s.d_regs.p, s.d_n_regs.p, s.d_alns.p, s.d_cigars.p, s.d_cig_n.p, EMA_CIG_CAP, s.d_cand_off.p,
+		                s.d_cig_off.p, g0, s.d_cand.p, s.d_cigar_out.p, e->n_cu * 4, s.stream);
+		HIPCHK(e, hipGetLastError());
+		HIPCHK(e, hipMemcpyAsync(o->cand + c0, s.d_cand.p, nc * sizeof(ema_cand_t), hipMemcpyDeviceToHost, s.stream));
+		HIPCHK(e, hipMemcpyAsync(o->cigar + g0, s.d_cigar_out.p, ng * 4, hipMemcpyDeviceToHost, s.stream));
+		HIPCHK(e, hipMemcpyAsync(o->status + r0, s.d_status.p, nr * 4, hipMemcpyDeviceToHost, s.stream));
+	}
+	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
 	for (size_t r = 0; r < n_reads; ++r)
 		if (o->status[r]) { e->err = "a read exceeded an engine capacity; see ema_batch_out.status"; return EMA_ELIMIT; }
 	return EMA_OK;

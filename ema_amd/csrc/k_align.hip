@@ -177,7 +177,7 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 }  // namespace
 
 // one wavefront = one read at a time, reads taken from a shared counter
-// intv/n_intv: K1's output.  regs: n_reads x EMA_REG_CAP, n_regs: n_reads.  status is OR-ed.
+// intv/n_intv: K1's output (stride opt.intv_cap).  regs: n_reads x opt.reg_cap, n_regs: n_reads.  status is OR-ed.
 __global__ void __launch_bounds__(256, 4)
 ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
@@ -217,7 +217,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		const Intv *iv = sl.ivs;
 		{   // K1 delivers the intervals in discovery order; mem_collect_intv ends with a sort on (start, end).
 			// Entries with equal keys are identical, so ranking each entry (ties by position) gives THE order.
-			const Intv *raw = intv + (size_t)read * EMA_INTV_CAP;
+			const Intv *raw = intv + (size_t)read * opt.intv_cap;
 			for (int i = lane; i < n_iv; i += EMA_WAVE) {
 				const Intv mine = raw[i];
 				int rank = 0;
@@ -487,9 +487,9 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		EMA_PHASE(5);
 		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq; wk.mark = dbg ? dbg + slot * 4 : nullptr;
 		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
-		if (n_out > EMA_REG_CAP) { cb.status |= EMA_ST_REG_OVERFLOW; n_out = EMA_REG_CAP; }
+		if (n_out > opt.reg_cap) { cb.status |= EMA_ST_REG_OVERFLOW; n_out = opt.reg_cap; }
 		ema_wave_sync();
-		DevReg *dst = regs + (size_t)read * EMA_REG_CAP;
+		DevReg *dst = regs + (size_t)read * opt.reg_cap;
 		for (int i = lane; i < n_out; i += EMA_WAVE) dst[i] = sl.av[i];
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
 		EMA_DBG(9, n_out);

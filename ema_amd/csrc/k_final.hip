@@ -33,7 +33,7 @@ __device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q,
 
 }  // namespace
 
-// alns: n_reads x EMA_REG_CAP; cigars: n_reads x cig_cap ops (pool per read, regions in order)
+// alns: n_reads x opt.reg_cap; cigars: n_reads x cig_cap ops (pool per read, regions in order)
 __global__ void __launch_bounds__(256)
 ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
@@ -67,7 +67,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		int pool_n = 0, st = 0;
 		for (int k = 0; k < nr; ++k) {
 			EMA_DBG(2, k);
-			const DevReg ar = ema_uni(regs[(size_t)read * EMA_REG_CAP + k]);
+			const DevReg ar = ema_uni(regs[(size_t)read * opt.reg_cap + k]);
 			DevAln out;
 			out.pos = -1; out.is_rev = 0; out.NM = -1; out.n_cigar = 0; out.cigar_off = (uint32_t)pool_n;
 			const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
@@ -75,7 +75,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			const bool rev = rb >= l_pac;
 			const int rlen = (int)(re - rb);
 			const bool ok = lq > 0 && rb < re && !(rb < l_pac && re > l_pac) && rb >= 0 && re <= l_pac << 1 && rlen <= EMA_RSEQ_CAP;
-			if (!ok) { if (rlen > EMA_RSEQ_CAP) st |= EMA_ST_RSEQ_OVERFLOW; if (lane == 0) alns[(size_t)read * EMA_REG_CAP + k] = out; continue; }
+			if (!ok) { if (rlen > EMA_RSEQ_CAP) st |= EMA_ST_RSEQ_OVERFLOW; if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out; continue; }
 			ema_wave_fetch(ix, rb, re, rseq);
 			// reversed views so that indels are left-aligned on the forward strand (bwa_gen_cigar2)
 			const EmaSeq qs{rev ? query + qe - 1 : query + qb, rev ? -1 : 1};
@@ -157,7 +157,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			}
 			const int rid = ema_pos2rid(ix, pos);
 			out.pos = rid >= 0 ? pos - ix.ctg_off[rid] : pos;
-			if (lane == 0) alns[(size_t)read * EMA_REG_CAP + k] = out;
+			if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out;
 			ema_wave_sync();
 		}
 		if (lane == 0) { cig_n[read] = pool_n; if (st) atomicOr(status + read, st); }
@@ -169,10 +169,10 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 // Packs the per-read slots into the contiguous arrays handed to the host: cand[cand_off[r] + k] and the
 // read's CIGAR ops at cigar[cig_off[r] ..).  One wave per read.
 __global__ void __launch_bounds__(256)
-ema_k_pack(int n_reads, const DevReg *__restrict__ regs, const int *__restrict__ n_regs, const DevAln *__restrict__ alns,
+ema_k_pack(int n_reads, int reg_cap, const DevReg *__restrict__ regs, const int *__restrict__ n_regs, const DevAln *__restrict__ alns,
            const uint32_t *__restrict__ cigars, const int *__restrict__ cig_n, int cig_cap,
-           const uint64_t *__restrict__ cand_off, const uint64_t *__restrict__ cig_off, ema_cand_t *__restrict__ cand,
-           uint32_t *__restrict__ cigar_out)
+           const uint64_t *__restrict__ cand_off, const uint64_t *__restrict__ cig_off, uint64_t cig_base,
+           ema_cand_t *__restrict__ cand, uint32_t *__restrict__ cigar_out)
 {
 	const int lane = (int)ema_lane();
 	const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -180,15 +180,15 @@ ema_k_pack(int n_reads, const DevReg *__restrict__ regs, const int *__restrict__
 		const int nr = n_regs[r];
 		const uint64_t co = cand_off[r], go = cig_off[r];
 		for (int k = lane; k < nr; k += EMA_WAVE) {
-			const DevReg g = regs[(size_t)r * EMA_REG_CAP + k];
-			const DevAln a = alns[(size_t)r * EMA_REG_CAP + k];
+			const DevReg g = regs[(size_t)r * reg_cap + k];
+			const DevAln a = alns[(size_t)r * reg_cap + k];
 			ema_cand_t c;
 			c.rb = g.rb; c.re = g.re; c.qb = g.qb; c.qe = g.qe; c.rid = g.rid; c.score = g.score; c.truesc = g.truesc;
 			c.sub = g.sub; c.alt_sc = 0; c.csub = g.csub; c.sub_n = 0; c.w = g.w; c.seedcov = g.seedcov;
 			c.secondary = g.secondary; c.secondary_all = 0; c.seedlen0 = g.seedlen0; c.n_comp = g.n_comp; c.is_alt = g.is_alt;
 			c.frac_rep = g.frac_rep;
 			c.pos = a.pos; c.is_rev = a.is_rev; c.NM = a.NM; c.n_cigar = a.n_cigar;
-			c.cigar_off = (uint32_t)(go + a.cigar_off);
+			c.cigar_off = (uint32_t)(cig_base + go + a.cigar_off);
 			c.aln_score = g.score; c.aln_sub = g.sub > g.csub ? g.sub : g.csub;
 			cand[co + k] = c;
 		}
@@ -210,12 +210,12 @@ extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const u
 
 extern "C" size_t ema_sizeof_aln() { return sizeof(DevAln); }
 
-extern "C" void ema_launch_pack(int n_reads, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
+extern "C" void ema_launch_pack(int n_reads, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
-                                ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream)
+                                uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream)
 {
-	hipLaunchKernelGGL(ema_k_pack, dim3(n_blocks), dim3(256), 0, stream, n_reads, regs, n_regs, alns, cigars, cig_n, cig_cap,
-	                   cand_off, cig_off, cand, cigar_out);
+	hipLaunchKernelGGL(ema_k_pack, dim3(n_blocks), dim3(256), 0, stream, n_reads, reg_cap, regs, n_regs, alns, cigars, cig_n, cig_cap,
+	                   cand_off, cig_off, cig_base, cand, cigar_out);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -146,7 +146,7 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 			len[m] = ema_uni((int)(off[r + 1] - off[r]));
 			n[m] = ema_uni(n_regs[r]);
 			for (int i = lane; i < len[m]; i += EMA_WAVE) lds_q[wib][m][i] = bases[off[r] + i];
-			const DevReg *src = regs + (size_t)r * EMA_REG_CAP;
+			const DevReg *src = regs + (size_t)r * opt.reg_cap;
 			int b = 0;
 			for (int i = lane; i < n[m]; i += EMA_WAVE) { const DevReg x = src[i]; av[m][i] = x; b = b > x.score ? b : x.score; }
 			best[m] = ema_wave_max(b);
@@ -172,8 +172,8 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 		for (int m = 0; m < 2; ++m) {
 			const int r = 2 * pair + m;
 			int cnt = n[m];
-			if (cnt > EMA_REG_CAP) { cx.status |= EMA_ST_REG_OVERFLOW; cnt = EMA_REG_CAP; }
-			DevReg *dst = regs + (size_t)r * EMA_REG_CAP;
+			if (cnt > opt.reg_cap) { cx.status |= EMA_ST_REG_OVERFLOW; cnt = opt.reg_cap; }
+			DevReg *dst = regs + (size_t)r * opt.reg_cap;
 			for (int i = lane; i < cnt; i += EMA_WAVE) dst[i] = av[m][i];
 			if (lane == 0) { n_regs[r] = cnt; if (cx.status) atomicOr(status + r, cx.status); }
 		}

@@ -33,7 +33,8 @@ struct SeedSM {
 	// read: 2-bit codes + N mask, staged in LDS (word k of this lane at qw[k * 64], nm[k * 64])
 	const uint32_t *qw, *nm;
 	int len;
-	Intv *out;           // EMA_INTV_CAP entries
+	Intv *out;           // out_cap entries
+	int out_cap;
 	Intv *la, *lb;       // working lists, EMA_LIST_CAP entries each, interleaved over the lanes of the wave: entry e at [e * 64]
 	int status;
 	// control
@@ -71,7 +72,7 @@ struct SeedSM {
 	}
 	__device__ __forceinline__ void emit(uint64_t a0, uint64_t a1, uint64_t a2, int start, int end)
 	{
-		if (n_out >= EMA_INTV_CAP) { status |= EMA_ST_INTV_OVERFLOW; return; }
+		if (n_out >= out_cap) { status |= EMA_ST_INTV_OVERFLOW; return; }
 		Intv e; e.x0 = a0; e.x1 = a1; e.x2 = a2; e.info = (uint64_t)(uint32_t)start << 32 | (uint32_t)end;
 		out[n_out++] = e;
 	}
@@ -199,14 +200,14 @@ struct SeedSM {
 
 // reads: qpack[r * 24 ..]: 16 words of 2-bit codes (base i at bits 2(i%16) of word i/16, N stored as 0) followed by
 //        8 words of N flags (bit i%32 of word i/32); read lengths from off[]
-// intv : n_reads x EMA_INTV_CAP (in discovery order, see the header), n_intv / status : n_reads
+// intv : n_reads x opt.intv_cap (in discovery order, see the header), n_intv / status : n_reads
 // lists: (gridDim.x * blockDim.x) x 2 x EMA_LIST_CAP scratch entries (one pair of working lists per lane, interleaved
 //        over the 64 lanes of a wave so that lanes at the same list index touch one contiguous 2 KB run)
 // counter: zero on entry; reads are handed out one by one
 __global__ void __launch_bounds__(256)
 ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
            Intv *__restrict__ intv, int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
-           int *__restrict__ counter)
+           int *__restrict__ counter, unsigned long long *prof)
 {
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
 	__shared__ uint32_t lds_n[4][8 * 64];       // N mask, 8 words per lane
@@ -223,6 +224,8 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 	sm.n_out = 0; sm.status = 0; sm.len = 0;
 	int read = -1;
 	bool exhausted = false;
+	// diagnostic (prof != null): ticks, active lane-ticks and shader clocks of this wave
+	unsigned long long n_tick = 0, n_active = 0, t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
 	for (;;) {
 		// ---- phase A: control programs, registers and LDS only
 		while (!sm.has_req && !sm.ld_kind && !exhausted) {
@@ -241,7 +244,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 					nm[0 << 6] = m0.x; nm[1 << 6] = m0.y; nm[2 << 6] = m0.z; nm[3 << 6] = m0.w;
 					nm[4 << 6] = m1.x; nm[5 << 6] = m1.y; nm[6 << 6] = m1.z; nm[7 << 6] = m1.w;
 				}
-				sm.out = intv + (size_t)read * EMA_INTV_CAP;
+				sm.out = intv + (size_t)read * opt.intv_cap; sm.out_cap = opt.intv_cap;
 				sm.status = 0; sm.n_out = 0; sm.pass = 1; sm.x = 0; sm.prev_is_a = 1; sm.n_curr = 0;
 				if (sm.len < opt.min_seed_len) continue;      // mem_chain: no seeds for a read shorter than min_seed_len
 				sm.pc = PC_P1_NEXT;
@@ -249,6 +252,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			sm.advance(ix, opt);
 		}
 		if (!__any(sm.has_req || sm.ld_kind)) break;
+		if (prof) { ++n_tick; n_active += __popcll(__ballot(sm.has_req)); }
 		// ---- phase B: every global load of the tick, issued together
 		Intv ent; ent.x0 = ent.x1 = ent.x2 = ent.info = 0;
 		if (sm.ld_kind) {
@@ -275,14 +279,18 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 		}
 		sm.ld_kind = 0;
 	}
+	if (prof && lane == 0) {
+		atomicAdd(prof + 8, n_tick); atomicAdd(prof + 9, n_active);
+		atomicAdd(prof + 10, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start)); atomicMax(prof + 11, n_tick);
+	}
 }
 
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int *counter, int n_blocks,
-                                hipStream_t stream)
+                                hipStream_t stream, unsigned long long *prof)
 {
 	hipLaunchKernelGGL(ema_k_seed, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, intv, n_intv,
-	                   status, lists, counter);
+	                   status, lists, counter, prof);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

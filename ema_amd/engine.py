@@ -17,7 +17,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams",
 ]
 
 
@@ -26,7 +26,7 @@ class Opts(C.Structure):
                                        "zdrop", "min_seed_len", "split_width", "max_mem_intv", "max_occ",
                                        "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
                [(n, C.c_float) for n in ("split_factor", "mask_level", "drop_ratio", "mask_level_redun")] + \
-               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs")]
+               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs", "n_streams")]
 
 
 class Cand(C.Structure):
@@ -97,6 +97,7 @@ def load_library():
         L.ema_engine_debug_seeds.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)),
                                              C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]
         L.ema_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.ema_engine_n_streams.argtypes = [C.c_void_p]
         L.ema_engine_debug_regions.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_int32)),
                                                C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32),
                                                C.POINTER(C.c_int32)]
@@ -159,6 +160,10 @@ class Engine:
             raise RuntimeError(f"{what} failed ({rc}): {self._L.ema_engine_strerror(self._h).decode()}")
 
     @property
+    def n_streams(self):
+        return int(self._L.ema_engine_n_streams(self._h))
+
+    @property
     def capacity(self):
         return int(self._L.ema_engine_batch_capacity(self._h))
 
@@ -184,9 +189,13 @@ class Engine:
         self._check(self._L.ema_engine_last_timing(self._h, C.byref(t)), "timing")
         return {n: getattr(t, n) for n, _ in Timing._fields_}
 
-    def fetch(self) -> Batch:
+    def fetch(self, allow_limit: bool = False) -> Batch:
         p = C.POINTER(BatchOut)()
-        self._check(self._L.ema_engine_fetch(self._h, C.byref(p)), "fetch")
+        rc = self._L.ema_engine_fetch(self._h, C.byref(p))
+        if rc != 0 and not (rc == -4 and allow_limit and p):      # EMA_ELIMIT still returns the batch with its status flags
+            if p:
+                self._L.ema_batch_free(p)
+            self._check(rc, "fetch")
         try:
             o = p.contents
             n = o.n_pairs

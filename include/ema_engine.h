@@ -48,7 +48,8 @@ typedef struct {
 	int score_delta;            /* reference src/align.c:1005 passes 25 */
 	int max_rescue;             /* reference src/bwabridge.c:264,278: 50 */
 	int pes_low, pes_high;      /* reference src/bwabridge.c:222-223: -35, 500 (FR only) */
-	int batch_pairs;            /* pairs per device batch (0 = engine default) */
+	int batch_pairs;            /* pairs per device batch (0 = engine default, 262144) */
+	int n_streams;              /* slices of a batch run on their own HIP streams so that kernel tails overlap (0 = default, 4) */
 } ema_engine_opts;
 
 void ema_engine_opts_default(ema_engine_opts *o);
@@ -135,11 +136,13 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
  * sorted/compacted in place, n_out[t] = regions kept. */
 int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int32_t *n_out, int cap, int n_tasks);
 
-/* per-kernel device time of the last ema_engine_run (HIP events on the engine's stream), ms */
+/* mean launch duration of each kernel in the last ema_engine_run, ms (HIP events on the stream the kernel was launched on;
+ * one launch per slice, launches of different slices overlap) */
 typedef struct {
 	float seed_ms, chain_ms, extend_ms, rescue_ms, final_ms, total_ms;
 } ema_engine_timing;
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t);
+int ema_engine_n_streams(const ema_engine_t *e);
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,7 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	std::vector<Intv> lists((size_t)n_blocks * 256 * 2 * EMA_LIST_CAP);
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, (Intv *)intv, n_intv, status, lists.data(), &seed_counter, n_blocks, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, (Intv *)intv, n_intv, status, lists.data(), &seed_counter, n_blocks, nullptr, nullptr);
 	for (int r = 0; r < n_reads; ++r) {
 		Intv *a = (Intv *)intv + (size_t)r * EMA_INTV_CAP;
 		std::stable_sort(a, a + n_intv[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });
@@ -93,7 +93,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
 	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
@@ -116,7 +116,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();

@@ -16,6 +16,17 @@ __device__ __forceinline__ unsigned ema_lane() { return threadIdx.x & 63u; }
 // must be told: to it every lane is an independent thread whose earlier loads stay valid until that thread
 // itself stores.  The wavefront-scope fence (no code at this scope) makes it drop values cached in registers
 // and keeps loads/stores from moving across this point.
+// Work list of a launch.  Lean tier: units 0..n-1 of the slice.  Full-capacity tier: the pairs the lean tier flagged,
+// listed on the device -- *n_pairs_dev of them (clamped to the tier's capacity) -- and unit i reads its input (bases,
+// offsets, packed reads) at batch pair map[i] while all per-read results are indexed by i.
+__device__ __forceinline__ int ema_work_count(int n, const int *n_pairs_dev, int per_pair)
+{
+	if (!n_pairs_dev) return n;
+	const int m = per_pair * *n_pairs_dev;
+	return m < n ? m : n;
+}
+__device__ __forceinline__ int ema_in_read(const int *map, int read) { return map ? ((map[read >> 1] << 1) | (read & 1)) : read; }
+
 __device__ __forceinline__ void ema_wave_sync()
 {
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

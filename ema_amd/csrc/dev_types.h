@@ -50,9 +50,9 @@ struct Intv { uint64_t x0, x1, x2, info; };
 // per-read capacities of the seeding stage
 #define EMA_INTV_CAP 512      // intervals kept per read
 #define EMA_LIST_CAP 256      // entries of a forward/backward working list (<= read length)
-#define EMA_INTV_LEAN 64
-#define EMA_REG_LEAN 32
-#define EMA_CIG_LEAN 128
+#define EMA_INTV_LEAN 48      // lean tier (engine.hip): 0.01-0.03 % of reads of the benchmark mix exceed one of these
+#define EMA_REG_LEAN 48
+#define EMA_CIG_LEAN 192
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
 
 // bwa's mem_seed_t plus the link to the next seed of the same chain
@@ -78,9 +78,9 @@ struct DevReg {
 #define EMA_SEED_CAP 32768
 #define EMA_CHAIN_CAP 16384
 #define EMA_AV_CAP 2048       // regions of one read before dedup
-#define EMA_REG_CAP 256       // regions of one read handed to the next stage
+#define EMA_REG_CAP 1024      // regions of one read handed to the next stage
 #define EMA_RSEQ_CAP 2048     // reference window bytes staged in LDS
-#define EMA_CIG_CAP 1024      // CIGAR ops of all candidates of one read
+#define EMA_CIG_CAP 4096      // CIGAR ops of all candidates of one read
 
 // read status bits
 #define EMA_ST_INTV_OVERFLOW 1
@@ -90,5 +90,6 @@ struct DevReg {
 #define EMA_ST_REG_OVERFLOW 16
 #define EMA_ST_RSEQ_OVERFLOW 32
 #define EMA_ST_CIGAR_OVERFLOW 64
+#define EMA_ST_REDO 128           // lean tier only: the pair is on the full-capacity tier's work list
 
 #endif

@@ -7,6 +7,14 @@
 // resident blocks) and each ends in a tail in which a few long reads keep a few waves busy; with several
 // slices in flight the blocks of the next slice's kernel start as soon as blocks of the previous one retire,
 // so the tails are filled instead of idling the chip.
+//
+// Two capacity tiers.  The slices above are the LEAN tier: per read 48 seed intervals, 48 regions, 192 CIGAR ops
+// (~7 KB of result slots per read, so batches of millions of pairs fit).  A pair with a read over one of these is
+// flagged, skipped by the later kernels, and -- without a host round trip -- appended by ema_k_collect to the work
+// list of the FULL tier (one more slice with 512 / 1024 / 4096 per read and room for `full_cap` pairs), whose
+// K1..K4 run on their own stream once every lean slice of the batch has been collected, sized by the device-side
+// count.  ema_engine_fetch splices the full tier's results into the batch.  A read over the full tier's capacities,
+// or more flagged pairs than the full tier holds, makes ema_engine_fetch return EMA_ELIMIT.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,14 +29,14 @@
 #include "opts.h"
 
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
-                                int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int *counter, int n_blocks,
-                                hipStream_t stream, unsigned long long *prof);
+                                int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
+                                Intv *lists, int *counter, int n_blocks, hipStream_t stream, unsigned long long *prof);
 
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
-                                 int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
-                                 unsigned long long *prof);
+                                 int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
+                                 DevReg *regs, int *n_regs, int *status, uint8_t *slabs, int *counter, int n_blocks,
+                                 hipStream_t stream, int *dbg, unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" int ema_align_blocks_per_cu();
 extern "C" int ema_pair_blocks_per_cu();
@@ -38,13 +46,15 @@ extern "C" size_t ema_pair_slab_bytes();
 extern "C" size_t ema_final_slab_bytes();
 extern "C" size_t ema_sizeof_aln();
 extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
-                                int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, DevReg *regs, int *n_regs,
-                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg);
+                                int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, const int *n_pairs_dev,
+                                const int *map, DevReg *regs, int *n_regs, int *status, uint8_t *slabs, int *counter,
+                                int n_blocks, hipStream_t stream, int *dbg);
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
-                                 int n_reads, const DevReg *regs, const int *n_regs, DevAln *alns, uint32_t *cigars,
-                                 int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
+                                 int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
+                                 DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
                                  hipStream_t stream, int *dbg);
-extern "C" void ema_launch_pack(int n_reads, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
+extern "C" void ema_launch_collect(int n_pairs, int first_pair, int *status, int *count, int *map, int cap, hipStream_t stream);
+extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *status, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
                                 uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream);
 extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
@@ -83,14 +93,15 @@ template <typename T> struct DevBuf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-// one slice of the batch: consecutive pairs [first_pair, first_pair + n_pairs) on their own stream
+// one slice of the batch: consecutive pairs [first_pair, first_pair + n_pairs) on their own stream (lean tier), or the
+// full-capacity tier, whose pairs are the ones the lean slices listed (it has no stream of its own: its kernels follow
+// the last lean slice's on that slice's stream)
 struct Slice {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	bool own_stream = false;
 	size_t cap_pairs = 0, n_pairs = 0, first_pair = 0;
-	std::vector<uint32_t> h_off;
-	DevBuf<uint8_t> d_bases;
-	DevBuf<uint32_t> d_off, d_qpack;   // d_qpack: 24 words per read (2-bit codes + N mask) for K1
+	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n;
 	DevBuf<DevReg> d_regs;
@@ -104,11 +115,11 @@ struct Slice {
 	float ms[4] = {0, 0, 0, 0};       // K1..K4 of the last run
 	void release()
 	{
-		d_bases.release(); d_off.release(); d_qpack.release(); d_intv.release(); d_lists.release(); d_n_intv.release();
+		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_regs.release(); d_slabs.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-		if (stream) (void)hipStreamDestroy(stream);
+		if (stream && own_stream) (void)hipStreamDestroy(stream);
 		if (dbg) (void)hipHostFree(dbg);
 	}
 };
@@ -128,10 +139,16 @@ struct ema_engine {
 	DevBuf<OccSlot> d_occ;
 	DevBuf<uint8_t> d_sa, d_pac;
 	DevBuf<int64_t> d_ctg;
-	// batch
-	std::vector<Slice> sl;
+	// batch input (whole batch; slices are sub-ranges, the full tier addresses it through its pair list)
+	DevBuf<uint8_t> d_bases;
+	DevBuf<uint32_t> d_off, d_qpack;     // d_qpack: 24 words per read (2-bit codes + N mask) for K1
+	std::vector<Slice> sl;               // lean tier
+	Slice full;                          // full-capacity tier
+	// pairs flagged by the lean tier: [0] = count, [1..] = batch pair ids.  d_redo is appended to by ema_k_collect;
+	// d_redo_run is the copy the full tier's kernels of the same run read (so that the next run may start collecting)
+	DevBuf<int> d_redo, d_redo_run;
 	size_t cap_pairs = 0, n_pairs = 0;
-	bool staged = false, ran = false;
+	bool staged = false, ran = false, ever_ran = false;
 	std::vector<uint8_t> h_nt4;
 	std::vector<uint32_t> h_off, h_qpack;
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0;
@@ -154,27 +171,25 @@ extern "C" {
 
 void ema_engine_opts_default(ema_engine_opts *o) { ema_fill_default_opts(o); }
 
-static int slice_alloc(ema_engine *e, Slice &s)
+static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 {
 	const size_t n_reads = 2 * s.cap_pairs;
-	HIPCHK(e, hipStreamCreate(&s.stream));
+	if (shared_stream) s.stream = shared_stream;
+	else { HIPCHK(e, hipStreamCreate(&s.stream)); s.own_stream = true; }
 	for (auto &ev : s.ev) HIPCHK(e, hipEventCreate(&ev));
-	HIPCHK(e, s.d_bases.alloc(n_reads * (size_t)(EMA_MAX_READ + 1)));
-	HIPCHK(e, s.d_off.alloc(n_reads + 1));
-	HIPCHK(e, s.d_qpack.alloc(n_reads * 24 + 8));
-	HIPCHK(e, s.d_intv.alloc(n_reads * (size_t)EMA_INTV_CAP));
+	HIPCHK(e, s.d_intv.alloc(n_reads * (size_t)s.dopts.intv_cap));
 	HIPCHK(e, s.d_n_intv.alloc(n_reads));
 	HIPCHK(e, s.d_status.alloc(n_reads));
 	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
-	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)EMA_REG_CAP));
+	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
 	HIPCHK(e, s.d_counters.alloc(16));
 	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
 	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
 	if ((size_t)e->final_blocks * 4 * ema_final_slab_bytes() > slab) slab = (size_t)e->final_blocks * 4 * ema_final_slab_bytes();
 	HIPCHK(e, s.d_slabs.alloc(slab));
-	HIPCHK(e, s.d_alns.alloc(n_reads * (size_t)EMA_REG_CAP));
-	HIPCHK(e, s.d_cigars.alloc(n_reads * (size_t)EMA_CIG_CAP));
+	HIPCHK(e, s.d_alns.alloc(n_reads * (size_t)s.dopts.reg_cap));
+	HIPCHK(e, s.d_cigars.alloc(n_reads * (size_t)s.dopts.cig_cap));
 	HIPCHK(e, s.d_cig_n.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
@@ -227,17 +242,35 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
 
-	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // the device exposes 3 hardware queues to one process: a 4th stream only serialises
+	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // the device gives one process 3 hardware queues: a 4th stream only serialises
 	if (n_streams > 16) n_streams = 16;
 	const size_t want = e->opts.batch_pairs > 0 ? (size_t)e->opts.batch_pairs : (size_t)262144;
 	const size_t per = (want + n_streams - 1) / n_streams;
+	e->cap_pairs = per * n_streams;
+	if (e->cap_pairs * 2 * (size_t)(EMA_MAX_READ + 1) >= ((size_t)1 << 32)) { e->err = "batch_pairs too large for 32-bit base offsets"; return EMA_EARG; }
+	HIPCHK(e, e->d_bases.alloc(2 * e->cap_pairs * (size_t)(EMA_MAX_READ + 1)));
+	HIPCHK(e, e->d_off.alloc(2 * e->cap_pairs + 1));
+	HIPCHK(e, e->d_qpack.alloc(2 * e->cap_pairs * 24 + 8));
 	e->sl.resize(n_streams);
 	for (auto &s : e->sl) {
 		s.cap_pairs = per;
-		int rc = slice_alloc(e, s);
+		s.dopts = e->dopts;
+		s.dopts.intv_cap = std::min(EMA_INTV_CAP, e->opts.lean_intervals > 0 ? e->opts.lean_intervals : EMA_INTV_LEAN);
+		s.dopts.reg_cap = std::min(EMA_REG_CAP, e->opts.lean_regions > 0 ? e->opts.lean_regions : EMA_REG_LEAN);
+		s.dopts.cig_cap = std::min(EMA_CIG_CAP, e->opts.lean_cigar_ops > 0 ? e->opts.lean_cigar_ops : EMA_CIG_LEAN);
+		int rc = slice_alloc(e, s, nullptr);
 		if (rc != EMA_OK) return rc;
 	}
-	e->cap_pairs = per * n_streams;
+	size_t full_cap = e->opts.full_tier_pairs > 0 ? (size_t)e->opts.full_tier_pairs : std::min<size_t>(16384, std::max<size_t>(4096, e->cap_pairs / 64));
+	if (full_cap > e->cap_pairs) full_cap = e->cap_pairs;
+	e->full.cap_pairs = full_cap;
+	e->full.dopts = e->dopts;      // EMA_INTV_CAP / EMA_REG_CAP / EMA_CIG_CAP
+	int rc = slice_alloc(e, e->full, e->sl.back().stream);
+	if (rc != EMA_OK) return rc;
+	HIPCHK(e, e->d_redo.alloc(full_cap + 1));
+	HIPCHK(e, e->d_redo_run.alloc(full_cap + 1));
+	HIPCHK(e, hipMemset(e->d_redo.p, 0, 4));
+	HIPCHK(e, hipMemset(e->d_redo_run.p, 0, 4));
 	return EMA_OK;
 }
 
@@ -245,7 +278,10 @@ void ema_engine_close(ema_engine_t *e)
 {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
+	(void)hipDeviceSynchronize();
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_prof.release();
+	e->d_bases.release(); e->d_off.release(); e->d_qpack.release(); e->d_redo.release(); e->d_redo_run.release();
+	e->full.release();
 	for (auto &s : e->sl) s.release();
 	delete e;
 }
@@ -266,12 +302,14 @@ int64_t ema_engine_contig_offset(const ema_engine_t *e, int rid)
 }
 int64_t ema_engine_l_pac(const ema_engine_t *e) { return e ? e->l_pac : -1; }
 size_t ema_engine_batch_capacity(const ema_engine_t *e) { return e ? e->cap_pairs : 0; }
+size_t ema_engine_full_tier_capacity(const ema_engine_t *e) { return e ? e->full.cap_pairs : 0; }
 
 int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs)
 {
 	if (!e || !bases || !off) return EMA_EARG;
 	if (n_pairs > e->cap_pairs) { e->err = "batch larger than ema_engine_batch_capacity()"; return EMA_EARG; }
 	HIPCHK(e, hipSetDevice(e->device));
+	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));      // a run still in flight reads the input
 	const size_t n_reads = 2 * n_pairs;
 	e->h_off.resize(n_reads + 1);
 	const uint32_t base0 = off[0];
@@ -292,6 +330,10 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 			if (b[i] > 3) w[16 + (i >> 5)] |= 1u << (i & 31);
 		}
 	}
+	hipStream_t st = e->sl[0].stream;
+	HIPCHK(e, hipMemcpyAsync(e->d_qpack.p, e->h_qpack.data(), (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemcpyAsync(e->d_bases.p, e->h_nt4.data(), total, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemcpyAsync(e->d_off.p, e->h_off.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
 	// consecutive pairs go to consecutive slices, as evenly as the slice count allows
 	const size_t n_sl = e->sl.size();
 	size_t first = 0;
@@ -300,16 +342,10 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 		s.first_pair = first;
 		s.n_pairs = (n_pairs - first + (n_sl - k) - 1) / (n_sl - k);
 		if (s.n_pairs > s.cap_pairs) s.n_pairs = s.cap_pairs;
-		const size_t r0 = 2 * first, nr = 2 * s.n_pairs;
-		s.h_off.resize(nr + 1);
-		for (size_t r = 0; r <= nr; ++r) s.h_off[r] = e->h_off[r0 + r] - e->h_off[r0];
-		HIPCHK(e, hipMemcpyAsync(s.d_qpack.p, e->h_qpack.data() + r0 * 24, (nr * 24 + 8) * 4, hipMemcpyHostToDevice, s.stream));
-		HIPCHK(e, hipMemcpyAsync(s.d_bases.p, e->h_nt4.data() + e->h_off[r0], s.h_off[nr], hipMemcpyHostToDevice, s.stream));
-		HIPCHK(e, hipMemcpyAsync(s.d_off.p, s.h_off.data(), (nr + 1) * 4, hipMemcpyHostToDevice, s.stream));
 		first += s.n_pairs;
 	}
 	if (first != n_pairs) { e->err = "internal: slices do not cover the batch"; return EMA_ESTATE; }
-	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
+	HIPCHK(e, hipStreamSynchronize(st));
 	e->n_pairs = n_pairs;
 	e->staged = true; e->ran = false;
 	return EMA_OK;
@@ -332,66 +368,107 @@ static void watchdog(ema_engine *e, Slice &s, const char *what)
 	if (s.dbg) memset(s.dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
 }
 
-static int run_seed(ema_engine *e, Slice &s)
+// What a launch covers.  Lean slice: its own consecutive pairs (input pointers moved to the slice's first read).
+// Full tier: the pairs on the device-side list (`listed`), or -- debug entry points -- the whole small batch directly.
+struct Work {
+	int n_pairs;
+	const int *n_dev, *map;
+	const uint32_t *off, *qpack;
+};
+
+static Work work_of(ema_engine *e, const Slice &s, bool listed)
 {
-	const int n_reads = (int)(2 * s.n_pairs);
-	HIPCHK(e, hipMemsetAsync(s.d_status.p, 0, (size_t)n_reads * 4, s.stream));
+	Work w;
+	if (listed) { w.n_pairs = (int)s.cap_pairs; w.n_dev = e->d_redo_run.p; w.map = e->d_redo_run.p + 1; w.off = e->d_off.p; w.qpack = e->d_qpack.p; }
+	else { w.n_pairs = (int)s.n_pairs; w.n_dev = w.map = nullptr; w.off = e->d_off.p + 2 * s.first_pair; w.qpack = e->d_qpack.p + 2 * s.first_pair * 24; }
+	return w;
+}
+
+static int run_seed(ema_engine *e, Slice &s, const Work &w)
+{
+	HIPCHK(e, hipMemsetAsync(s.d_status.p, 0, (size_t)w.n_pairs * 2 * 4, s.stream));
 	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 16 * 4, s.stream));
-	ema_launch_seed(&e->dix, &e->dopts, s.d_qpack.p, s.d_off.p, n_reads, s.d_intv.p, s.d_n_intv.p, s.d_status.p, s.d_lists.p,
-	                s.d_counters.p + 3, e->seed_blocks, s.stream, e->d_prof.p);
+	ema_launch_seed(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
+	                s.d_lists.p, s.d_counters.p + 3, e->seed_blocks, s.stream, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_seed");
 	return EMA_OK;
 }
 
-static int run_align(ema_engine *e, Slice &s)
+static int run_align(ema_engine *e, Slice &s, const Work &w)
 {
-	const int n_reads = (int)(2 * s.n_pairs);
-	ema_launch_align(&e->dix, &e->dopts, s.d_bases.p, s.d_off.p, n_reads, s.d_intv.p, s.d_n_intv.p, s.d_regs.p, s.d_n_regs.p,
-	                 s.d_status.p, s.d_slabs.p, s.d_counters.p + 0, e->align_blocks, s.stream, s.dbg, e->d_prof.p);
+	ema_launch_align(&e->dix, &s.dopts, e->d_bases.p, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+	                 s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 0, e->align_blocks, s.stream, s.dbg, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_align");
 	return EMA_OK;
 }
 
-static int run_pair(ema_engine *e, Slice &s)
+static int run_pair(ema_engine *e, Slice &s, const Work &w)
 {
-	ema_launch_pair(&e->dix, &e->dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high, s.d_bases.p,
-	                s.d_off.p, (int)s.n_pairs, s.d_regs.p, s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 1,
+	ema_launch_pair(&e->dix, &s.dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high, e->d_bases.p,
+	                w.off, w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 1,
 	                e->pair_blocks, s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_pair");
 	return EMA_OK;
 }
 
-static int run_final(ema_engine *e, Slice &s)
+static int run_final(ema_engine *e, Slice &s, const Work &w)
 {
-	const int n_reads = (int)(2 * s.n_pairs);
-	ema_launch_final(&e->dix, &e->dopts, s.d_bases.p, s.d_off.p, n_reads, s.d_regs.p, s.d_n_regs.p, s.d_alns.p, s.d_cigars.p,
-	                 s.d_cig_n.p, EMA_CIG_CAP, s.d_status.p, s.d_slabs.p, s.d_counters.p + 2, e->final_blocks, s.stream, s.dbg);
+	ema_launch_final(&e->dix, &s.dopts, e->d_bases.p, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_alns.p,
+	                 s.d_cigars.p, s.d_cig_n.p, s.dopts.cig_cap, s.d_status.p, s.d_slabs.p, s.d_counters.p + 2, e->final_blocks,
+	                 s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_final");
 	return EMA_OK;
 }
 
-int ema_engine_run(ema_engine_t *e)
+static int run_chain(ema_engine *e, Slice &s, const Work &w)
+{
+	int rc;
+	HIPCHK(e, hipEventRecord(s.ev[0], s.stream));
+	if ((rc = run_seed(e, s, w))) return rc;
+	HIPCHK(e, hipEventRecord(s.ev[1], s.stream));
+	if ((rc = run_align(e, s, w))) return rc;
+	HIPCHK(e, hipEventRecord(s.ev[2], s.stream));
+	if ((rc = run_pair(e, s, w))) return rc;
+	HIPCHK(e, hipEventRecord(s.ev[3], s.stream));
+	if ((rc = run_final(e, s, w))) return rc;
+	HIPCHK(e, hipEventRecord(s.ev[4], s.stream));
+	return EMA_OK;
+}
+
+// Queues one pass over the staged batch and returns.  Runs may be queued back to back without ema_engine_sync in
+// between (every slice's chain is ordered on its stream; results are those of the last run): the tails of one run
+// then overlap the head of the next.
+static int run_batch(ema_engine_t *e, bool serial);
+int ema_engine_run(ema_engine_t *e) { return run_batch(e, false); }
+// the same pass with the slices one after another (nothing overlaps): per-kernel launch durations in isolation
+int ema_engine_run_serial(ema_engine_t *e) { return run_batch(e, true); }
+
+static int run_batch(ema_engine_t *e, bool serial)
 {
 	if (!e) return EMA_EARG;
 	if (!e->staged) { e->err = "ema_engine_run before ema_engine_stage"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
 	int rc;
-	for (auto &s : e->sl) {      // every slice queues its whole chain on its own stream
-		HIPCHK(e, hipEventRecord(s.ev[0], s.stream));
-		if ((rc = run_seed(e, s))) return rc;
-		HIPCHK(e, hipEventRecord(s.ev[1], s.stream));
-		if ((rc = run_align(e, s))) return rc;
-		HIPCHK(e, hipEventRecord(s.ev[2], s.stream));
-		if ((rc = run_pair(e, s))) return rc;
-		HIPCHK(e, hipEventRecord(s.ev[3], s.stream));
-		if ((rc = run_final(e, s))) return rc;
-		HIPCHK(e, hipEventRecord(s.ev[4], s.stream));
+	for (auto &s : e->sl) {      // every slice queues its whole chain on its own stream, then lists its flagged pairs
+		if ((rc = run_chain(e, s, work_of(e, s, false)))) return rc;
+		if (e->ever_ran) HIPCHK(e, hipStreamWaitEvent(s.stream, e->full.ev[7], 0));   // the previous run's list has been taken over
+		ema_launch_collect((int)s.n_pairs, (int)s.first_pair, s.d_status.p, e->d_redo.p, e->d_redo.p + 1, (int)e->full.cap_pairs, s.stream);
+		HIPCHK(e, hipGetLastError());
+		HIPCHK(e, hipEventRecord(s.ev[7], s.stream));
+		if (serial) HIPCHK(e, hipStreamSynchronize(s.stream));
 	}
-	e->ran = true;
+	// full-capacity tier, behind the last slice: take over the list once every slice has added to it, then K1..K4 on it
+	Slice &f = e->full;
+	for (size_t k = 0; k + 1 < e->sl.size(); ++k) HIPCHK(e, hipStreamWaitEvent(f.stream, e->sl[k].ev[7], 0));
+	HIPCHK(e, hipMemcpyAsync(e->d_redo_run.p, e->d_redo.p, (f.cap_pairs + 1) * 4, hipMemcpyDeviceToDevice, f.stream));
+	HIPCHK(e, hipMemsetAsync(e->d_redo.p, 0, 4, f.stream));
+	HIPCHK(e, hipEventRecord(f.ev[7], f.stream));
+	if ((rc = run_chain(e, f, work_of(e, f, true)))) return rc;
+	e->ran = true; e->ever_ran = true;
 	return EMA_OK;
 }
 
@@ -400,7 +477,7 @@ int ema_engine_sync(ema_engine_t *e)
 	if (!e) return EMA_EARG;
 	HIPCHK(e, hipSetDevice(e->device));
 	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
-	if (e->ran) {      // mean launch duration of each kernel over the slices (launches of different slices overlap)
+	if (e->ran) {      // mean launch duration of each kernel over the lean slices (launches of different slices overlap)
 		float sum[4] = {0, 0, 0, 0};
 		for (auto &s : e->sl)
 			for (int k = 0; k < 4; ++k) { HIPCHK(e, hipEventElapsedTime(&s.ms[k], s.ev[k], s.ev[k + 1])); sum[k] += s.ms[k]; }
@@ -408,6 +485,8 @@ int ema_engine_sync(ema_engine_t *e)
 		e->timing.seed_ms = sum[0] / n; e->timing.chain_ms = 0; e->timing.extend_ms = sum[1] / n;
 		e->timing.rescue_ms = sum[2] / n; e->timing.final_ms = sum[3] / n;
 		e->timing.total_ms = (sum[0] + sum[1] + sum[2] + sum[3]) / n;
+		HIPCHK(e, hipEventElapsedTime(&e->timing.full_tier_ms, e->full.ev[0], e->full.ev[4]));
+		for (int k = 0; k < 4; ++k) HIPCHK(e, hipEventElapsedTime(&e->timing.full_ms[k], e->full.ev[k], e->full.ev[k + 1]));
 	}
 	return EMA_OK;
 }
@@ -431,22 +510,30 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 	return EMA_OK;
 }
 
+// The debug entry points run the whole (small) staged batch on the full-capacity tier directly.
+static int debug_ready(ema_engine *e, const char *who)
+{
+	if (!e->staged) { e->err = std::string(who) + " before ema_engine_stage"; return EMA_ESTATE; }
+	if (e->n_pairs > e->full.cap_pairs) { e->err = std::string(who) + ": batch larger than ema_engine_full_tier_capacity()"; return EMA_EARG; }
+	HIPCHK(e, hipSetDevice(e->device));
+	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
+	e->full.first_pair = 0; e->full.n_pairs = e->n_pairs;
+	return EMA_OK;
+}
+
 int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read)
 {
 	if (!e || !intv || !n_intv || !cap_per_read) return EMA_EARG;
-	if (!e->staged) { e->err = "ema_engine_debug_seeds before ema_engine_stage"; return EMA_ESTATE; }
-	HIPCHK(e, hipSetDevice(e->device));
-	int rc;
-	for (auto &s : e->sl) if ((rc = run_seed(e, s))) return rc;
+	int rc = debug_ready(e, "ema_engine_debug_seeds");
+	if (rc) return rc;
+	Slice &f = e->full;
+	if ((rc = run_seed(e, f, work_of(e, f, false)))) return rc;
+	HIPCHK(e, hipStreamSynchronize(f.stream));
 	const size_t n_reads = 2 * e->n_pairs;
 	*intv = (uint64_t *)malloc(n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv) + 8);
 	*n_intv = (int32_t *)malloc(n_reads * 4 + 8);
-	for (auto &s : e->sl) {
-		HIPCHK(e, hipStreamSynchronize(s.stream));
-		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
-		HIPCHK(e, hipMemcpy((Intv *)(*intv) + r0 * EMA_INTV_CAP, s.d_intv.p, nr * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(*n_intv + r0, s.d_n_intv.p, nr * 4, hipMemcpyDeviceToHost));
-	}
+	HIPCHK(e, hipMemcpy(*intv, f.d_intv.p, n_reads * (size_t)EMA_INTV_CAP * sizeof(Intv), hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(*n_intv, f.d_n_intv.p, n_reads * 4, hipMemcpyDeviceToHost));
 	// K1 emits in discovery order; present the lists as mem_collect_intv leaves them: ordered by (start, end)
 	for (size_t r = 0; r < n_reads; ++r) {
 		Intv *a = (Intv *)(*intv) + r * EMA_INTV_CAP;
@@ -460,21 +547,20 @@ int ema_engine_debug_regions(ema_engine_t *e, void **regs, int32_t **n_regs, int
                              int32_t *reg_bytes)
 {
 	if (!e || !regs || !n_regs || !status || !cap_per_read || !reg_bytes) return EMA_EARG;
-	if (!e->staged) { e->err = "ema_engine_debug_regions before ema_engine_stage"; return EMA_ESTATE; }
-	HIPCHK(e, hipSetDevice(e->device));
-	int rc;
-	for (auto &s : e->sl) { if ((rc = run_seed(e, s))) return rc; if ((rc = run_align(e, s))) return rc; }
+	int rc = debug_ready(e, "ema_engine_debug_regions");
+	if (rc) return rc;
+	Slice &f = e->full;
+	const Work w = work_of(e, f, false);
+	if ((rc = run_seed(e, f, w))) return rc;
+	if ((rc = run_align(e, f, w))) return rc;
+	HIPCHK(e, hipStreamSynchronize(f.stream));
 	const size_t n_reads = 2 * e->n_pairs;
 	*regs = malloc(n_reads * (size_t)EMA_REG_CAP * sizeof(DevReg) + 8);
 	*n_regs = (int32_t *)malloc(n_reads * 4 + 8);
 	*status = (int32_t *)malloc(n_reads * 4 + 8);
-	for (auto &s : e->sl) {
-		HIPCHK(e, hipStreamSynchronize(s.stream));
-		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
-		HIPCHK(e, hipMemcpy((DevReg *)(*regs) + r0 * EMA_REG_CAP, s.d_regs.p, nr * (size_t)EMA_REG_CAP * sizeof(DevReg), hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(*n_regs + r0, s.d_n_regs.p, nr * 4, hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(*status + r0, s.d_status.p, nr * 4, hipMemcpyDeviceToHost));
-	}
+	HIPCHK(e, hipMemcpy(*regs, f.d_regs.p, n_reads * (size_t)EMA_REG_CAP * sizeof(DevReg), hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(*n_regs, f.d_n_regs.p, n_reads * 4, hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(*status, f.d_status.p, n_reads * 4, hipMemcpyDeviceToHost));
 	*cap_per_read = EMA_REG_CAP;
 	*reg_bytes = (int32_t)sizeof(DevReg);
 	return EMA_OK;
@@ -544,6 +630,20 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
 	return EMA_OK;
 }
 
+// pack one tier's per-read slots into contiguous arrays on the device (reads with a status flag are left out)
+static int pack_slice(ema_engine *e, Slice &s, size_t nr, const uint64_t *loc_cand, const uint64_t *loc_cig, uint64_t cig_base)
+{
+	const size_t nc = loc_cand[nr], ng = loc_cig[nr];
+	if (nc + 1 > s.cand_cap) { s.cand_cap = (nc + 1) * 5 / 4 + 1024; HIPCHK(e, s.d_cand.alloc(s.cand_cap)); }
+	if (ng + 1 > s.cigar_out_cap) { s.cigar_out_cap = (ng + 1) * 5 / 4 + 1024; HIPCHK(e, s.d_cigar_out.alloc(s.cigar_out_cap)); }
+	HIPCHK(e, hipMemcpyAsync(s.d_cand_off.p, loc_cand, (nr + 1) * 8, hipMemcpyHostToDevice, s.stream));
+	HIPCHK(e, hipMemcpyAsync(s.d_cig_off.p, loc_cig, (nr + 1) * 8, hipMemcpyHostToDevice, s.stream));
+	ema_launch_pack((int)nr, nullptr, s.d_status.p, s.dopts.reg_cap, s.d_regs.p, s.d_n_regs.p, s.d_alns.p, s.d_cigars.p, s.d_cig_n.p,
+	                s.dopts.cig_cap, s.d_cand_off.p, s.d_cig_off.p, cig_base, s.d_cand.p, s.d_cigar_out.p, e->n_cu * 4, s.stream);
+	HIPCHK(e, hipGetLastError());
+	return EMA_OK;
+}
+
 int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 {
 	if (!e || !out) return EMA_EARG;
@@ -551,15 +651,36 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	if (!e->ran) { e->err = "ema_engine_fetch before ema_engine_run"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
 	const size_t n_reads = 2 * e->n_pairs;
-	std::vector<int> n_regs(n_reads + 1), cig_n(n_reads + 1);
+	std::vector<int> n_regs(n_reads + 1), cig_n(n_reads + 1), status(n_reads + 1);
 	for (auto &s : e->sl) {
 		HIPCHK(e, hipStreamSynchronize(s.stream));
 		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
 		HIPCHK(e, hipMemcpy(n_regs.data() + r0, s.d_n_regs.p, nr * 4, hipMemcpyDeviceToHost));
 		HIPCHK(e, hipMemcpy(cig_n.data() + r0, s.d_cig_n.p, nr * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(status.data() + r0, s.d_status.p, nr * 4, hipMemcpyDeviceToHost));
 	}
+	// the pairs redone by the full-capacity tier
+	Slice &f = e->full;
+	int n_listed = 0;
+	HIPCHK(e, hipMemcpy(&n_listed, e->d_redo_run.p, 4, hipMemcpyDeviceToHost));
+	const size_t n_redo = std::min<size_t>((size_t)n_listed, f.cap_pairs);
+	std::vector<int> redo(n_redo + 1), f_regs(2 * n_redo + 1), f_cig(2 * n_redo + 1), f_status(2 * n_redo + 1);
+	if (n_redo) {
+		HIPCHK(e, hipMemcpy(redo.data(), e->d_redo_run.p + 1, n_redo * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(f_regs.data(), f.d_n_regs.p, 2 * n_redo * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(f_cig.data(), f.d_cig_n.p, 2 * n_redo * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpy(f_status.data(), f.d_status.p, 2 * n_redo * 4, hipMemcpyDeviceToHost));
+	}
+	for (size_t r = 0; r < n_reads; ++r) if (status[r]) n_regs[r] = cig_n[r] = 0;      // flagged and not redone: no output, status stays
+	for (size_t i = 0; i < n_redo; ++i)
+		for (int m = 0; m < 2; ++m) {
+			const size_t r = 2 * (size_t)redo[i] + m;
+			n_regs[r] = f_status[2 * i + m] ? 0 : f_regs[2 * i + m];
+			cig_n[r] = f_status[2 * i + m] ? 0 : f_cig[2 * i + m];
+		}
 	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
 	o->n_pairs = e->n_pairs;
+	o->n_redone = n_redo;
 	o->cand_off = (uint64_t *)malloc((n_reads + 1) * 8);
 	std::vector<uint64_t> cig_off(n_reads + 1);
 	o->cand_off[0] = 0; cig_off[0] = 0;
@@ -568,30 +689,56 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 		cig_off[r + 1] = cig_off[r] + (uint64_t)cig_n[r];
 	}
 	const size_t n_cand = o->cand_off[n_reads], n_cig = cig_off[n_reads];
+	if (n_cig >= ((size_t)1 << 32)) { e->err = "batch has more than 2^32 CIGAR operations; use smaller batches"; ema_batch_free(o); return EMA_ELIMIT; }
 	o->n_cigar = n_cig;
 	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
 	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
 	o->status = (int32_t *)malloc((n_reads + 1) * 4);
 	*out = o;
-	std::vector<uint64_t> loc_cand, loc_cig;
-	for (auto &s : e->sl) {      // pack every slice into contiguous arrays and copy them to their place in the batch
+	std::vector<std::vector<uint64_t>> loc(2 * e->sl.size());
+	for (size_t k = 0; k < e->sl.size(); ++k) {      // lean slices: contiguous on the device, one copy each into their place in the batch
+		Slice &s = e->sl[k];
 		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
 		const uint64_t c0 = o->cand_off[r0], g0 = cig_off[r0];
-		const size_t nc = o->cand_off[r0 + nr] - c0, ng = cig_off[r0 + nr] - g0;
-		loc_cand.resize(nr + 1); loc_cig.resize(nr + 1);
-		for (size_t r = 0; r <= nr; ++r) { loc_cand[r] = o->cand_off[r0 + r] - c0; loc_cig[r] = cig_off[r0 + r] - g0; }
-		if (nc + 1 > s.cand_cap) { s.cand_cap = (nc + 1) * 5 / 4 + 1024; HIPCHK(e, s.d_cand.alloc(s.cand_cap)); }
-		if (ng + 1 > s.cigar_out_cap) { s.cigar_out_cap = (ng + 1) * 5 / 4 + 1024; HIPCHK(e, s.d_cigar_out.alloc(s.cigar_out_cap)); }
-		HIPCHK(e, hipMemcpy(s.d_cand_off.p, loc_cand.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
-		HIPCHK(e, hipMemcpy(s.d_cig_off.p, loc_cig.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
-		ema_launch_pack((int)nr, EMA_REG_CAP, s.d_regs.p, s.d_n_regs.p, s.d_alns.p, s.d_cigars.p, s.d_cig_n.p, EMA_CIG_CAP, s.d_cand_off.p,
-		                s.d_cig_off.p, g0, s.d_cand.p, s.d_cigar_out.p, e->n_cu * 4, s.stream);
-		HIPCHK(e, hipGetLastError());
-		HIPCHK(e, hipMemcpyAsync(o->cand + c0, s.d_cand.p, nc * sizeof(ema_cand_t), hipMemcpyDeviceToHost, s.stream));
-		HIPCHK(e, hipMemcpyAsync(o->cigar + g0, s.d_cigar_out.p, ng * 4, hipMemcpyDeviceToHost, s.stream));
-		HIPCHK(e, hipMemcpyAsync(o->status + r0, s.d_status.p, nr * 4, hipMemcpyDeviceToHost, s.stream));
+		std::vector<uint64_t> &lc = loc[2 * k], &lg = loc[2 * k + 1];
+		lc.resize(nr + 1); lg.resize(nr + 1);
+		for (size_t r = 0; r <= nr; ++r) { lc[r] = o->cand_off[r0 + r] - c0; lg[r] = cig_off[r0 + r] - g0; }
+		int rc = pack_slice(e, s, nr, lc.data(), lg.data(), g0);
+		if (rc) return rc;
+		HIPCHK(e, hipMemcpyAsync(o->cand + c0, s.d_cand.p, lc[nr] * sizeof(ema_cand_t), hipMemcpyDeviceToHost, s.stream));
+		HIPCHK(e, hipMemcpyAsync(o->cigar + g0, s.d_cigar_out.p, lg[nr] * 4, hipMemcpyDeviceToHost, s.stream));
 	}
 	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
+	memcpy(o->status, status.data(), n_reads * 4);
+	if (n_redo) {      // full tier: packed in list order, then spliced into the (skipped) slots of the listed reads
+		std::vector<uint64_t> lc(2 * n_redo + 1), lg(2 * n_redo + 1);
+		lc[0] = lg[0] = 0;
+		for (size_t i = 0; i < 2 * n_redo; ++i) {
+			const size_t r = 2 * (size_t)redo[i >> 1] + (i & 1);
+			lc[i + 1] = lc[i] + (uint64_t)n_regs[r]; lg[i + 1] = lg[i] + (uint64_t)cig_n[r];
+		}
+		int rc = pack_slice(e, f, 2 * n_redo, lc.data(), lg.data(), 0);
+		if (rc) return rc;
+		std::vector<ema_cand_t> hc(lc[2 * n_redo] + 1);
+		std::vector<uint32_t> hg(lg[2 * n_redo] + 1);
+		HIPCHK(e, hipMemcpyAsync(hc.data(), f.d_cand.p, lc[2 * n_redo] * sizeof(ema_cand_t), hipMemcpyDeviceToHost, f.stream));
+		HIPCHK(e, hipMemcpyAsync(hg.data(), f.d_cigar_out.p, lg[2 * n_redo] * 4, hipMemcpyDeviceToHost, f.stream));
+		HIPCHK(e, hipStreamSynchronize(f.stream));
+		for (size_t i = 0; i < 2 * n_redo; ++i) {
+			const size_t r = 2 * (size_t)redo[i >> 1] + (i & 1);
+			o->status[r] = f_status[i];
+			for (uint64_t k = 0; k < lc[i + 1] - lc[i]; ++k) {
+				ema_cand_t c = hc[lc[i] + k];
+				c.cigar_off = (uint32_t)(c.cigar_off - lg[i] + cig_off[r]);
+				o->cand[o->cand_off[r] + k] = c;
+			}
+			memcpy(o->cigar + cig_off[r], hg.data() + lg[i], (lg[i + 1] - lg[i]) * 4);
+		}
+	}
+	if ((size_t)n_listed > f.cap_pairs) {
+		e->err = "more pairs over the lean capacities than the full-capacity tier holds (ema_engine_opts.full_tier_pairs)";
+		return EMA_ELIMIT;
+	}
 	for (size_t r = 0; r < n_reads; ++r)
 		if (o->status[r]) { e->err = "a read exceeded an engine capacity; see ema_batch_out.status"; return EMA_ELIMIT; }
 	return EMA_OK;

@@ -180,6 +180,7 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 // intv/n_intv: K1's output (stride opt.intv_cap).  regs: n_reads x opt.reg_cap, n_regs: n_reads.  status is OR-ed.
 __global__ void __launch_bounds__(256, 4)
 ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
+            const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
             int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg,
             unsigned long long *prof)
@@ -206,12 +207,18 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
-		if (read >= n_reads) break;
+		if (read >= ema_work_count(n_reads, n_pairs_dev, 2)) break;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		EMA_PHASE(1);
-		const int l_query = ema_uni((int)(off[read + 1] - off[read]));
-		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
+		if (ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
+			if (lane == 0) n_regs[read] = 0;
+			EMA_DBG(9, 0);
+			continue;
+		}
+		const int in_read = ema_uni(ema_in_read(map, read));
+		const int l_query = ema_uni((int)(off[in_read + 1] - off[in_read]));
+		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
 		ema_wave_sync();
 		const int n_iv = ema_uni(n_intv[read]);
 		const Intv *iv = sl.ivs;
@@ -503,11 +510,11 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
-                                 int n_reads, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
+                                 int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
                                  uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
                                  unsigned long long *prof)
 {
-	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, intv, n_intv, regs,
+	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
 	                   n_regs, status, slabs, counter, dbg, prof);
 }
 

@@ -36,6 +36,7 @@ __device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q,
 // alns: n_reads x opt.reg_cap; cigars: n_reads x cig_cap ops (pool per read, regions in order)
 __global__ void __launch_bounds__(256)
 ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
+            const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
             uint32_t *__restrict__ cigars, int *__restrict__ cig_n, int cig_cap, int *__restrict__ status,
             uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
@@ -55,13 +56,14 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
-		if (read >= n_reads) break;
+		if (read >= ema_work_count(n_reads, n_pairs_dev, 2)) break;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
-		const int l_query = (int)(off[read + 1] - off[read]);
-		const int nr = ema_uni(n_regs[read]);
+		const int in_read = ema_uni(ema_in_read(map, read));
+		const int l_query = (int)(off[in_read + 1] - off[in_read]);
+		const int nr = ema_uni((status[read] | status[read ^ 1]) ? 0 : n_regs[read]);      // flagged pairs are redone by the full-capacity tier
 		if (nr == 0) { if (lane == 0) cig_n[read] = 0; EMA_DBG(9, 0); continue; }
-		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[read] + i];
+		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
 		ema_wave_sync();
 		uint32_t *pool = cigars + (size_t)read * cig_cap;
 		int pool_n = 0, st = 0;
@@ -169,14 +171,16 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 // Packs the per-read slots into the contiguous arrays handed to the host: cand[cand_off[r] + k] and the
 // read's CIGAR ops at cigar[cig_off[r] ..).  One wave per read.
 __global__ void __launch_bounds__(256)
-ema_k_pack(int n_reads, int reg_cap, const DevReg *__restrict__ regs, const int *__restrict__ n_regs, const DevAln *__restrict__ alns,
+ema_k_pack(int n_reads, const int *__restrict__ n_pairs_dev, const int *__restrict__ status, int reg_cap, const DevReg *__restrict__ regs, const int *__restrict__ n_regs, const DevAln *__restrict__ alns,
            const uint32_t *__restrict__ cigars, const int *__restrict__ cig_n, int cig_cap,
            const uint64_t *__restrict__ cand_off, const uint64_t *__restrict__ cig_off, uint64_t cig_base,
            ema_cand_t *__restrict__ cand, uint32_t *__restrict__ cigar_out)
 {
 	const int lane = (int)ema_lane();
 	const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+	n_reads = ema_work_count(n_reads, n_pairs_dev, 2);
 	for (int r = wave; r < n_reads; r += n_waves) {
+		if (status[r]) continue;      // redone by the full-capacity tier; the host fills this read's slots from there
 		const int nr = n_regs[r];
 		const uint64_t co = cand_off[r], go = cig_off[r];
 		for (int k = lane; k < nr; k += EMA_WAVE) {
@@ -197,24 +201,46 @@ ema_k_pack(int n_reads, int reg_cap, const DevReg *__restrict__ regs, const int 
 	}
 }
 
+// Lean tier -> full-capacity tier: every pair with a capacity flag on either read is marked (both reads, so that the
+// result assembly skips them) and appended to the full tier's work list.  Pairs beyond the list's capacity stay marked
+// and make ema_engine_fetch fail.
+__global__ void __launch_bounds__(256)
+ema_k_collect(int n_pairs, int first_pair, int *__restrict__ status, int *__restrict__ count, int *__restrict__ map, int cap)
+{
+	const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (p >= n_pairs) return;
+	const int a = status[2 * p], b = status[2 * p + 1];
+	if (!(a | b)) return;
+	status[2 * p] = a | EMA_ST_REDO; status[2 * p + 1] = b | EMA_ST_REDO;
+	const int at = atomicAdd(count, 1);
+	if (at < cap) map[at] = first_pair + p;
+}
+
+extern "C" void ema_launch_collect(int n_pairs, int first_pair, int *status, int *count, int *map, int cap, hipStream_t stream)
+{
+	if (n_pairs <= 0) return;
+	hipLaunchKernelGGL(ema_k_collect, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, n_pairs, first_pair, status, count, map, cap);
+}
+
 extern "C" size_t ema_final_slab_bytes() { return EMA_FINAL_SLAB_BYTES; }
 
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
-                                 int n_reads, const DevReg *regs, const int *n_regs, DevAln *alns, uint32_t *cigars,
+                                 int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
+                                 DevAln *alns, uint32_t *cigars,
                                  int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
                                  hipStream_t stream, int *dbg)
 {
-	hipLaunchKernelGGL(ema_k_final, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, regs, n_regs, alns,
+	hipLaunchKernelGGL(ema_k_final, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, regs, n_regs, alns,
 	                   cigars, cig_n, cig_cap, status, slabs, counter, dbg);
 }
 
 extern "C" size_t ema_sizeof_aln() { return sizeof(DevAln); }
 
-extern "C" void ema_launch_pack(int n_reads, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
+extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *status, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
                                 uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream)
 {
-	hipLaunchKernelGGL(ema_k_pack, dim3(n_blocks), dim3(256), 0, stream, n_reads, reg_cap, regs, n_regs, alns, cigars, cig_n, cig_cap,
+	hipLaunchKernelGGL(ema_k_pack, dim3(n_blocks), dim3(256), 0, stream, n_reads, n_pairs_dev, status, reg_cap, regs, n_regs, alns, cigars, cig_n, cig_cap,
 	                   cand_off, cig_off, cig_base, cand, cigar_out);
 }
 

@@ -110,7 +110,8 @@ __device__ inline int matesw(PairCtx &cx, const DevReg &a, int l_ms, const uint8
 // regs/n_regs: K2's output, updated in place.  One wave per pair, pairs taken from a shared counter.
 __global__ void __launch_bounds__(256)
 ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_low, int pes_high,
-           const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_pairs, DevReg *__restrict__ regs,
+           const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_pairs,
+           const int *__restrict__ n_pairs_dev, const int *__restrict__ map, DevReg *__restrict__ regs,
            int *__restrict__ n_regs, int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
 {
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
@@ -137,15 +138,17 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 		int pair = 0;
 		if (lane == 0) pair = atomicAdd(counter, 1);
 		pair = ema_uni(__shfl(pair, 0));
-		if (pair >= n_pairs) break;
+		if (pair >= ema_work_count(n_pairs, n_pairs_dev, 1)) break;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
+		if (ema_uni(status[2 * pair] | status[2 * pair + 1])) { EMA_DBG(9, 0); continue; }      // redone by the full-capacity tier
 		int len[2], n[2], best[2] = {0, 0};
 		for (int m = 0; m < 2; ++m) {
 			const int r = 2 * pair + m;
-			len[m] = ema_uni((int)(off[r + 1] - off[r]));
+			const int in_r = ema_uni(ema_in_read(map, r));
+			len[m] = ema_uni((int)(off[in_r + 1] - off[in_r]));
 			n[m] = ema_uni(n_regs[r]);
-			for (int i = lane; i < len[m]; i += EMA_WAVE) lds_q[wib][m][i] = bases[off[r] + i];
+			for (int i = lane; i < len[m]; i += EMA_WAVE) lds_q[wib][m][i] = bases[off[in_r] + i];
 			const DevReg *src = regs + (size_t)r * opt.reg_cap;
 			int b = 0;
 			for (int i = lane; i < n[m]; i += EMA_WAVE) { const DevReg x = src[i]; av[m][i] = x; b = b > x.score ? b : x.score; }
@@ -186,11 +189,12 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 extern "C" size_t ema_pair_slab_bytes() { return EMA_PAIR_SLAB_BYTES; }
 
 extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
-                                int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, DevReg *regs, int *n_regs,
+                                int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, const int *n_pairs_dev, const int *map,
+                                DevReg *regs, int *n_regs,
                                 int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg)
 {
 	hipLaunchKernelGGL(ema_k_pair, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, score_delta, max_rescue, pes_low, pes_high,
-	                   bases, off, n_pairs, regs, n_regs, status, slabs, counter, dbg);
+	                   bases, off, n_pairs, n_pairs_dev, map, regs, n_regs, status, slabs, counter, dbg);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -206,7 +206,7 @@ struct SeedSM {
 // counter: zero on entry; reads are handed out one by one
 __global__ void __launch_bounds__(256)
 ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
-           Intv *__restrict__ intv, int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
+           const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv, int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
            int *__restrict__ counter, unsigned long long *prof)
 {
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
@@ -224,6 +224,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 	sm.n_out = 0; sm.status = 0; sm.len = 0;
 	int read = -1;
 	bool exhausted = false;
+	n_reads = ema_work_count(n_reads, n_pairs_dev, 2);
 	// diagnostic (prof != null): ticks, active lane-ticks and shader clocks of this wave
 	unsigned long long n_tick = 0, n_active = 0, t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
 	for (;;) {
@@ -233,9 +234,10 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				if (read >= 0) { n_intv[read] = sm.n_out; status[read] = sm.status; }
 				read = atomicAdd(counter, 1);
 				if (read >= n_reads) { exhausted = true; break; }
-				sm.len = (int)(off[read + 1] - off[read]);
+				const int in_read = ema_in_read(map, read);
+				sm.len = (int)(off[in_read + 1] - off[in_read]);
 				{      // the read, packed by the host: 16 code words (2 bit/base) + 8 mask words (N positions)
-					const uint4 *pw = reinterpret_cast<const uint4 *>(qpack + (size_t)read * 24);
+					const uint4 *pw = reinterpret_cast<const uint4 *>(qpack + (size_t)in_read * 24);
 					const uint4 a = pw[0], b = pw[1], c = pw[2], d = pw[3], m0 = pw[4], m1 = pw[5];
 					qw[0 << 6] = a.x; qw[1 << 6] = a.y; qw[2 << 6] = a.z; qw[3 << 6] = a.w;
 					qw[4 << 6] = b.x; qw[5 << 6] = b.y; qw[6 << 6] = b.z; qw[7 << 6] = b.w;
@@ -286,10 +288,10 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 }
 
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
-                                int n_reads, Intv *intv, int *n_intv, int *status, Intv *lists, int *counter, int n_blocks,
+                                int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status, Intv *lists, int *counter, int n_blocks,
                                 hipStream_t stream, unsigned long long *prof)
 {
-	hipLaunchKernelGGL(ema_k_seed, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, intv, n_intv,
+	hipLaunchKernelGGL(ema_k_seed, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
 	                   status, lists, counter, prof);
 }
 

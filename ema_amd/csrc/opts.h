@@ -34,6 +34,7 @@ inline void ema_fill_default_opts(ema_engine_opts *o)
 	o->max_chain_gap = 10000; o->min_chain_weight = 0; o->max_chain_extend = 1 << 30;
 	o->split_factor = 1.5f; o->mask_level = 0.50f; o->drop_ratio = 0.50f; o->mask_level_redun = 0.95f;
 	o->score_delta = 25; o->max_rescue = 50; o->pes_low = -35; o->pes_high = 500;
-	o->batch_pairs = 0; o->n_streams = 0;
+	o->batch_pairs = 0; o->n_streams = 0; o->full_tier_pairs = 0;
+	o->lean_intervals = o->lean_regions = o->lean_cigar_ops = 0;
 }
 #endif

@@ -17,7 +17,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial",
 ]
 
 
@@ -26,7 +26,7 @@ class Opts(C.Structure):
                                        "zdrop", "min_seed_len", "split_width", "max_mem_intv", "max_occ",
                                        "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
                [(n, C.c_float) for n in ("split_factor", "mask_level", "drop_ratio", "mask_level_redun")] + \
-               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs", "n_streams")]
+               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs", "n_streams", "full_tier_pairs", "lean_intervals", "lean_regions", "lean_cigar_ops")]
 
 
 class Cand(C.Structure):
@@ -53,11 +53,11 @@ REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
 
 class BatchOut(C.Structure):
     _fields_ = [("n_pairs", C.c_size_t), ("cand_off", C.POINTER(C.c_uint64)), ("cand", C.POINTER(Cand)),
-                ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_size_t), ("status", C.POINTER(C.c_int32))]
+                ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_size_t), ("n_redone", C.c_size_t), ("status", C.POINTER(C.c_int32))]
 
 
 class Timing(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("seed_ms", "chain_ms", "extend_ms", "rescue_ms", "final_ms", "total_ms")]
+    _fields_ = [(n, C.c_float) for n in ("seed_ms", "chain_ms", "extend_ms", "rescue_ms", "final_ms", "total_ms", "full_tier_ms")] + [("full_ms", C.c_float * 4)]
 
 
 _lib = None
@@ -89,6 +89,7 @@ def load_library():
         L.ema_engine_batch_capacity.argtypes = [C.c_void_p]
         L.ema_engine_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.ema_engine_run.argtypes = [C.c_void_p]
+        L.ema_engine_run_serial.argtypes = [C.c_void_p]
         L.ema_engine_sync.argtypes = [C.c_void_p]
         L.ema_engine_fetch.argtypes = [C.c_void_p, C.POINTER(C.POINTER(BatchOut))]
         L.ema_engine_align_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -98,6 +99,8 @@ def load_library():
                                              C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]
         L.ema_engine_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.ema_engine_n_streams.argtypes = [C.c_void_p]
+        L.ema_engine_full_tier_capacity.argtypes = [C.c_void_p]
+        L.ema_engine_full_tier_capacity.restype = C.c_size_t
         L.ema_engine_debug_regions.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_int32)),
                                                C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32),
                                                C.POINTER(C.c_int32)]
@@ -116,8 +119,9 @@ def default_opts() -> Opts:
 class Batch:
     """Result of one batch, copied out of the engine's buffers."""
 
-    def __init__(self, cand_off, cand, cigar, status):
+    def __init__(self, cand_off, cand, cigar, status, n_redone=0):
         self.cand_off, self.cand, self.cigar, self.status = cand_off, cand, cigar, status
+        self.n_redone = n_redone      # pairs that went through the full-capacity tier
 
     def mate(self, pair, m):
         lo, hi = int(self.cand_off[2 * pair + m]), int(self.cand_off[2 * pair + m + 1])
@@ -164,6 +168,10 @@ class Engine:
         return int(self._L.ema_engine_n_streams(self._h))
 
     @property
+    def full_tier_capacity(self):
+        return int(self._L.ema_engine_full_tier_capacity(self._h))
+
+    @property
     def capacity(self):
         return int(self._L.ema_engine_batch_capacity(self._h))
 
@@ -178,8 +186,9 @@ class Engine:
         self._check(self._L.ema_engine_stage(self._h, bases.ctypes.data, off.ctypes.data, (len(off) - 1) // 2), "stage")
         self._n_reads_staged = len(off) - 1
 
-    def run(self):
-        self._check(self._L.ema_engine_run(self._h), "run")
+    def run(self, serial: bool = False):
+        """Queue one pass over the staged batch (asynchronous).  serial=True: slices one after another, for isolated kernel times."""
+        self._check((self._L.ema_engine_run_serial if serial else self._L.ema_engine_run)(self._h), "run")
 
     def sync(self):
         self._check(self._L.ema_engine_sync(self._h), "sync")
@@ -187,7 +196,9 @@ class Engine:
     def timing(self):
         t = Timing()
         self._check(self._L.ema_engine_last_timing(self._h, C.byref(t)), "timing")
-        return {n: getattr(t, n) for n, _ in Timing._fields_}
+        d = {n: getattr(t, n) for n, _ in Timing._fields_ if n != "full_ms"}
+        d["full_ms"] = [float(x) for x in t.full_ms]
+        return d
 
     def fetch(self, allow_limit: bool = False) -> Batch:
         p = C.POINTER(BatchOut)()
@@ -204,10 +215,11 @@ class Engine:
             cand = np.frombuffer(C.string_at(o.cand, n_cand * C.sizeof(Cand)), dtype=CAND_DTYPE).copy() \
                 if n_cand else np.zeros(0, dtype=CAND_DTYPE)
             cigar = np.ctypeslib.as_array(o.cigar, shape=(max(o.n_cigar, 1),)).copy()[:o.n_cigar]
-            status = np.ctypeslib.as_array(o.status, shape=(2 * n,)).copy()
+            status = np.ctypeslib.as_array(o.status, shape=(2 * n,)).copy() if n else np.zeros(0, np.int32)
+            n_redone = int(o.n_redone)
         finally:
             self._L.ema_batch_free(p)
-        return Batch(cand_off, cand, cigar, status)
+        return Batch(cand_off, cand, cigar, status, n_redone)
 
     def align_pairs(self, bases: np.ndarray, off: np.ndarray) -> Batch:
         self.stage(bases, off)

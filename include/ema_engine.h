@@ -49,7 +49,9 @@ typedef struct {
 	int max_rescue;             /* reference src/bwabridge.c:264,278: 50 */
 	int pes_low, pes_high;      /* reference src/bwabridge.c:222-223: -35, 500 (FR only) */
 	int batch_pairs;            /* pairs per device batch (0 = engine default, 262144) */
-	int n_streams;              /* slices of a batch run on their own HIP streams so that kernel tails overlap (0 = default, 4) */
+	int n_streams;              /* slices of a batch run on their own HIP streams so that kernel tails overlap (0 = default, 3) */
+	int full_tier_pairs;        /* pairs per batch the full-capacity tier can redo (0 = default: batch/64 within 4096..16384) */
+	int lean_intervals, lean_regions, lean_cigar_ops;   /* per-read capacities of the lean tier (0 = defaults 48, 48, 192) */
 } ema_engine_opts;
 
 void ema_engine_opts_default(ema_engine_opts *o);
@@ -91,7 +93,9 @@ typedef struct {
 	ema_cand_t *cand;       /* in the reference's order (results.a after rescue) */
 	uint32_t *cigar;
 	size_t n_cigar;
-	int32_t *status;        /* per read (2*n_pairs): 0, or EMA_ST_* capacity bits */
+	size_t n_redone;        /* pairs that went through the full-capacity tier */
+	int32_t *status;        /* per read (2*n_pairs): 0, or capacity bits (1 intervals, 2 lists, 4 seeds, 8 chains, 16 regions,
+	                         * 32 reference window, 64 CIGAR ops, 128 not redone: full-capacity tier was full); a flagged read has no candidates */
 } ema_batch_out;
 
 /* Whole hot path for a batch: reads are ASCII, read r at bases[off[r] .. off[r+1]);
@@ -101,16 +105,21 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 void ema_batch_free(ema_batch_out *out);
 
 /* The same in three steps, so that a caller (and bench.py) can keep inputs resident in HBM and
- * time the kernels alone:  stage = nt4-convert + H2D;  run = all kernels, asynchronous on the
- * engine's stream;  fetch = wait + D2H + assemble.  n_pairs must not exceed ema_engine_batch_capacity(). */
+ * time the kernels alone:  stage = nt4-convert + H2D;  run = queue all kernels (asynchronous; several runs may be
+ * queued back to back, each overwrites the previous results);  sync = wait;  fetch = wait + D2H + assemble.
+ * n_pairs must not exceed ema_engine_batch_capacity().
+ * Per-read result slots come in two tiers: every pair first runs with lean capacities; the few pairs with a read over
+ * one of them are redone on the device with the full capacities (at most ema_engine_full_tier_capacity() per batch). */
 size_t ema_engine_batch_capacity(const ema_engine_t *e);
+size_t ema_engine_full_tier_capacity(const ema_engine_t *e);
 int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs);
 int ema_engine_run(ema_engine_t *e);
+int ema_engine_run_serial(ema_engine_t *e);   /* ema_engine_run with the slices one after another: kernel times in isolation */
 int ema_engine_sync(ema_engine_t *e);
 int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out);
 
-/* Stage-level access used by the parity tests and the profiler: seed intervals of the staged
- * batch (what bwa's mem_collect_intv leaves in aux->mem).  Runs K1 only.
+/* Stage-level access used by the parity tests and the profiler (the staged batch must fit the full-capacity tier,
+ * on which these run): seed intervals of the staged batch (what bwa's mem_collect_intv leaves in aux->mem).  Runs K1 only.
  * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free(). */
 int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read);
 
@@ -140,6 +149,8 @@ int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int
  * one launch per slice, launches of different slices overlap) */
 typedef struct {
 	float seed_ms, chain_ms, extend_ms, rescue_ms, final_ms, total_ms;
+	float full_tier_ms;     /* K1..K4 of the full-capacity tier (one launch each) */
+	float full_ms[4];       /* ... and each of them */
 } ema_engine_timing;
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t);
 int ema_engine_n_streams(const ema_engine_t *e);

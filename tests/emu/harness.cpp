@@ -13,6 +13,17 @@
 #include "k_pair.hip"
 #include "k_final.hip"
 
+// per-read capacities of the emulated launches (the strides of the arrays tests/emu_lib.py allocates)
+#define EMU_INTV_CAP 512
+#define EMU_REG_CAP 256
+#define EMU_CIG_CAP 1024
+static DevOpts emu_dev_opts(const ema_engine_opts &o)
+{
+	DevOpts d = ema_make_dev_opts(o);
+	d.intv_cap = EMU_INTV_CAP; d.reg_cap = EMU_REG_CAP; d.cig_cap = EMU_CIG_CAP;
+	return d;
+}
+
 static std::vector<uint32_t> pack_reads(const uint8_t *bases, const uint32_t *off, int n_reads)
 {
 	std::vector<uint32_t> q((size_t)n_reads * 24 + 8, 0);
@@ -36,26 +47,26 @@ void *emu_index_load(const char *prefix, char *err, int errlen)
 }
 void emu_index_free(void *h) { delete (HostIndex *)h; }
 
-// bases: nt4 codes.  intv: n_reads*EMA_INTV_CAP*4 u64.  Returns the interval capacity per read.
+// bases: nt4 codes.  intv: n_reads*EMU_INTV_CAP*4 u64.  Returns the interval capacity per read.
 int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, uint64_t *intv, int *n_intv, int *status,
              int n_blocks)
 {
 	HostIndex *ix = (HostIndex *)h;
 	ema_engine_opts o; ema_fill_default_opts(&o);
-	DevOpts d = ema_make_dev_opts(o);
+	DevOpts d = emu_dev_opts(o);
 	DevIndex di = ix->view();
 	std::vector<Intv> lists((size_t)n_blocks * 256 * 2 * EMA_LIST_CAP);
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, (Intv *)intv, n_intv, status, lists.data(), &seed_counter, n_blocks, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, lists.data(), &seed_counter, n_blocks, nullptr, nullptr);
 	for (int r = 0; r < n_reads; ++r) {
-		Intv *a = (Intv *)intv + (size_t)r * EMA_INTV_CAP;
+		Intv *a = (Intv *)intv + (size_t)r * EMU_INTV_CAP;
 		std::stable_sort(a, a + n_intv[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });
 	}
-	return EMA_INTV_CAP;
+	return EMU_INTV_CAP;
 }
 
-static DevOpts default_dev_opts() { ema_engine_opts o; ema_fill_default_opts(&o); return ema_make_dev_opts(o); }
+static DevOpts default_dev_opts() { ema_engine_opts o; ema_fill_default_opts(&o); return emu_dev_opts(o); }
 
 void emu_dp_extend(const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf, const uint32_t *toff, const int *prm,
                    int n, int *out)
@@ -80,25 +91,25 @@ void emu_dp_local(const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf
 	ema_launch_test_local(&d, qbuf, qoff, tbuf, toff, prm, n, out, b.data(), bs, nullptr);
 }
 
-// K1 + K2 on host memory.  regs: n_reads * EMA_REG_CAP DevReg (80 bytes each); returns EMA_REG_CAP
+// K1 + K2 on host memory.  regs: n_reads * EMU_REG_CAP DevReg (80 bytes each); returns EMU_REG_CAP
 int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, void *regs, int *n_regs, int *status,
               int n_blocks)
 {
 	HostIndex *ix = (HostIndex *)h;
 	DevOpts d = default_dev_opts();
 	DevIndex di = ix->view();
-	std::vector<Intv> intv((size_t)n_reads * EMA_INTV_CAP);
+	std::vector<Intv> intv((size_t)n_reads * EMU_INTV_CAP);
 	std::vector<int> n_intv(n_reads);
 	std::vector<Intv> lists((size_t)1 * 256 * 2 * EMA_LIST_CAP);
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
-	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
+	ema_launch_align(&di, &d, bases, off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
 	                 &counter, n_blocks, nullptr, nullptr, nullptr);
-	return EMA_REG_CAP;
+	return EMU_REG_CAP;
 }
 int emu_sizeof_reg() { return (int)sizeof(DevReg); }
 
@@ -108,28 +119,94 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 {
 	HostIndex *ix = (HostIndex *)h;
 	ema_engine_opts eo; ema_fill_default_opts(&eo);
-	DevOpts d = ema_make_dev_opts(eo);
+	DevOpts d = emu_dev_opts(eo);
 	DevIndex di = ix->view();
-	std::vector<Intv> intv((size_t)n_reads * EMA_INTV_CAP);
+	std::vector<Intv> intv((size_t)n_reads * EMU_INTV_CAP);
 	std::vector<int> n_intv(n_reads);
 	std::vector<Intv> lists((size_t)1 * 256 * 2 * EMA_LIST_CAP);
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[3] = {0, 0, 0};
-	ema_launch_align(&di, &d, bases, off, n_reads, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
+	ema_launch_align(&di, &d, bases, off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
 	                 &counter[0], 1, nullptr, nullptr, nullptr);
 	if (upto >= 3)
-		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, (DevReg *)regs,
+		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, nullptr, nullptr, (DevReg *)regs,
 		                n_regs, status, slabs.data(), &counter[1], 1, nullptr, nullptr);
 	if (upto >= 4)
-		ema_launch_final(&di, &d, bases, off, n_reads, (DevReg *)regs, n_regs, (DevAln *)alns, cigars, cig_n, EMA_CIG_CAP, status,
+		ema_launch_final(&di, &d, bases, off, n_reads, nullptr, nullptr, (DevReg *)regs, n_regs, (DevAln *)alns, cigars, cig_n, EMU_CIG_CAP, status,
 		                 slabs.data(), &counter[2], 1, nullptr, nullptr);
-	return EMA_CIG_CAP;
+	return EMU_CIG_CAP;
+}
+
+// K1..K4 of one tier on host memory
+struct TierBuf {
+	std::vector<Intv> intv; std::vector<int> n_intv, n_regs, cig_n, status;
+	std::vector<DevReg> regs; std::vector<DevAln> alns; std::vector<uint32_t> cigars;
+	void size(int n_reads, const DevOpts &d)
+	{
+		intv.assign((size_t)n_reads * d.intv_cap, Intv()); n_intv.assign(n_reads, 0); n_regs.assign(n_reads, 0); cig_n.assign(n_reads, 0);
+		status.assign(n_reads, 0); regs.assign((size_t)n_reads * d.reg_cap, DevReg()); alns.assign((size_t)n_reads * d.reg_cap, DevAln());
+		cigars.assign((size_t)n_reads * d.cig_cap, 0);
+	}
+};
+
+static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts &eo, const uint8_t *bases, const uint32_t *off,
+                     const uint32_t *qp, int n_pairs, const int *n_dev, const int *map, TierBuf &t)
+{
+	std::vector<Intv> lists((size_t)1 * 256 * 2 * EMA_LIST_CAP);
+	size_t slab = ema_align_slab_bytes();
+	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
+	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
+	std::vector<uint8_t> slabs((size_t)4 * slab);
+	int counter[4] = {0, 0, 0, 0};
+	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], 1, nullptr, nullptr);
+	ema_launch_align(&di, &d, bases, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(),
+	                 t.status.data(), slabs.data(), &counter[0], 1, nullptr, nullptr, nullptr);
+	ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_pairs, n_dev, map, t.regs.data(),
+	                t.n_regs.data(), t.status.data(), slabs.data(), &counter[1], 1, nullptr, nullptr);
+	ema_launch_final(&di, &d, bases, off, 2 * n_pairs, n_dev, map, t.regs.data(), t.n_regs.data(), t.alns.data(), t.cigars.data(),
+	                 t.cig_n.data(), d.cig_cap, t.status.data(), slabs.data(), &counter[2], 1, nullptr, nullptr);
+}
+
+// The engine's two capacity tiers on host memory: lean tier with the given capacities, ema_k_collect, full tier over the
+// listed pairs; results merged per read into the caller's arrays (strides EMU_REG_CAP / EMU_CIG_CAP).  tier[r] = 0 lean,
+// 1 full.  Returns the number of listed pairs.
+int emu_pipeline_tiers(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, int lean_intv, int lean_reg, int lean_cig,
+                       int full_pairs, void *regs, int *n_regs, void *alns, uint32_t *cigars, int *cig_n, int *status, int *tier)
+{
+	HostIndex *ix = (HostIndex *)h;
+	ema_engine_opts eo; ema_fill_default_opts(&eo);
+	DevIndex di = ix->view();
+	const int n_pairs = n_reads / 2;
+	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
+	DevOpts dl = emu_dev_opts(eo), df = emu_dev_opts(eo);
+	dl.intv_cap = lean_intv; dl.reg_cap = lean_reg; dl.cig_cap = lean_cig;
+	TierBuf lean, full;
+	lean.size(n_reads, dl);
+	run_tier(di, dl, eo, bases, off, qp.data(), n_pairs, nullptr, nullptr, lean);
+	std::vector<int> redo(full_pairs + 1, 0);
+	ema_launch_collect(n_pairs, 0, lean.status.data(), redo.data(), redo.data() + 1, full_pairs, nullptr);
+	full.size(2 * full_pairs, df);
+	run_tier(di, df, eo, bases, off, qp.data(), full_pairs, redo.data(), redo.data() + 1, full);
+	auto put = [&](int r, const TierBuf &t, const DevOpts &d, int i, int which) {
+		tier[r] = which; n_regs[r] = t.n_regs[i]; cig_n[r] = t.cig_n[i]; status[r] = t.status[i];
+		for (int k = 0; k < t.n_regs[i]; ++k) {
+			((DevReg *)regs)[(size_t)r * EMU_REG_CAP + k] = t.regs[(size_t)i * d.reg_cap + k];
+			((DevAln *)alns)[(size_t)r * EMU_REG_CAP + k] = t.alns[(size_t)i * d.reg_cap + k];
+		}
+		for (int k = 0; k < t.cig_n[i]; ++k) cigars[(size_t)r * EMU_CIG_CAP + k] = t.cigars[(size_t)i * d.cig_cap + k];
+	};
+	for (int r = 0; r < n_reads; ++r)
+		if (!lean.status[r]) put(r, lean, dl, r, 0);
+		else { tier[r] = -1; n_regs[r] = cig_n[r] = 0; status[r] = lean.status[r]; }
+	const int n_redo = redo[0] < full_pairs ? redo[0] : full_pairs;
+	for (int i = 0; i < 2 * n_redo; ++i) put(2 * redo[1 + (i >> 1)] + (i & 1), full, df, i, 1);
+	return redo[0];
 }
 }

@@ -89,3 +89,23 @@ def pipeline(h, nt4_bases, off, upto=4, cap=256, cig_cap=1024):
                          alns.ctypes.data, cigars.ctypes.data, cig_n.ctypes.data, status.ctypes.data, upto)
     assert got == cig_cap
     return regs, n_regs, alns, cigars, cig_n, status
+
+
+def pipeline_tiers(h, nt4_bases, off, lean=(8, 2, 8), full_pairs=64, cap=256, cig_cap=1024):
+    """The engine's two capacity tiers through the interpreter (lean = per-read interval/region/CIGAR capacities of the
+    first tier).  Returns regs, n_regs, alns, cigars, cig_n, status, tier (0 lean, 1 full, -1 flagged and not redone), n_listed."""
+    n_reads = len(off) - 1
+    L = lib()
+    L.emu_pipeline_tiers.restype = C.c_int
+    L.emu_pipeline_tiers.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 7
+    regs = np.zeros((n_reads, cap), dtype=REG_DTYPE)
+    n_regs = np.zeros(n_reads, dtype=np.int32)
+    alns = np.zeros((n_reads, cap), dtype=ALN_DTYPE)
+    cigars = np.zeros((n_reads, cig_cap), dtype=np.uint32)
+    cig_n = np.zeros(n_reads, dtype=np.int32)
+    status = np.zeros(n_reads, dtype=np.int32)
+    tier = np.zeros(n_reads, dtype=np.int32)
+    n = L.emu_pipeline_tiers(h, nt4_bases.ctypes.data, off.ctypes.data, n_reads, lean[0], lean[1], lean[2], full_pairs,
+                             regs.ctypes.data, n_regs.ctypes.data, alns.ctypes.data, cigars.ctypes.data, cig_n.ctypes.data,
+                             status.ctypes.data, tier.ctypes.data)
+    return regs, n_regs, alns, cigars, cig_n, status, tier, n

@@ -93,3 +93,44 @@ def test_capacity_is_enforced():
     with pytest.raises(RuntimeError):
         eng.align_pairs(pairs.bases, pairs.off)
     eng.close()
+
+
+def test_two_capacity_tiers_give_the_same_candidates():
+    """Lean capacities small enough that many pairs overflow them: those pairs are redone on the device by the
+    full-capacity tier and spliced back; the batch must still equal the oracle read for read."""
+    prefix, ctg = small_ref("repeats")
+    pairs = synth.make_pairs(ctg, 700, seed=47, sub_rate=0.03)
+    o = default_opts()
+    o.lean_intervals, o.lean_regions, o.lean_cigar_ops = 9, 2, 6
+    o.n_streams = 3
+    eng = Engine(prefix, opts=o)
+    batch = eng.align_pairs(pairs.bases, pairs.off)
+    assert batch.status.max() == 0
+    assert 10 < batch.n_redone < pairs.n
+    assert not compare(prefix, pairs, batch)
+    # the same engine, the same batch, three passes queued back to back without waiting in between
+    eng.stage(pairs.bases, pairs.off)
+    for _ in range(3):
+        eng.run()
+    again = eng.fetch()
+    eng.close()
+    assert again.n_redone == batch.n_redone
+    assert (again.cand_off == batch.cand_off).all() and (again.cand == batch.cand).all() and (again.cigar == batch.cigar).all()
+
+
+def test_full_tier_overflow_fails_loudly():
+    prefix, ctg = small_ref("repeats")
+    pairs = synth.make_pairs(ctg, 300, seed=48, sub_rate=0.03)
+    o = default_opts()
+    o.lean_intervals, o.lean_regions, o.lean_cigar_ops = 9, 2, 6
+    o.full_tier_pairs = 4
+    eng = Engine(prefix, opts=o)
+    eng.stage(pairs.bases, pairs.off)
+    eng.run()
+    with pytest.raises(RuntimeError, match="full-capacity tier"):
+        eng.fetch()
+    b = eng.fetch(allow_limit=True)       # the batch is still returned: flagged reads carry status bits and no candidates
+    eng.close()
+    assert b.n_redone == 4 and (b.status != 0).sum() >= 2
+    flagged = np.nonzero(b.status)[0]
+    assert all(b.cand_off[r + 1] == b.cand_off[r] for r in flagged)

@@ -40,6 +40,16 @@ __device__ __forceinline__ int ema_col_get(const int vals[EMA_NC], int j)
 	return __builtin_amdgcn_readlane(mine, j >> 2);
 }
 
+template <int NC>
+__device__ __forceinline__ int ema_col_get_nc(const int vals[NC], int j)
+{
+	const int c = j & (NC - 1);
+	int mine = vals[0];
+#pragma unroll
+	for (int k = 1; k < NC; ++k) mine = c == k ? vals[k] : mine;
+	return __builtin_amdgcn_readlane(mine, j / NC);
+}
+
 // bwa_fill_scmat(a, b): +a on a match, -b on a mismatch, -1 against an ambiguous base -- computed, not looked up:
 // a per-lane table index would turn every DP cell into a memory access.
 __device__ __forceinline__ int ema_score(const DevOpts &o, int t, int q)
@@ -81,17 +91,18 @@ struct EmaRowBases {
 
 struct EmaExtRes { int score, qle, tle, gtle, gscore, max_off; };
 
-// ksw_extend2: banded extension from a seed with score h0.  qlen <= 255.
-__device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w,
-                                            int end_bonus, int zdrop, int h0)
+// ksw_extend2: banded extension from a seed with score h0, NC query columns per lane (qlen + 1 <= 64 NC).
+template <int NC>
+__device__ inline EmaExtRes ema_wave_extend_nc(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w,
+                                               int end_bonus, int zdrop, int h0)
 {
 	const int lane = (int)ema_lane();
 	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
-	int hh[EMA_NC], ee[EMA_NC], qb[EMA_NC];
+	int hh[NC], ee[NC], qb[NC];
 	// row -1 of the H/E arrays (index j holds H(-1, j-1); index 0 is the boundary column)
 #pragma unroll
-	for (int c = 0; c < EMA_NC; ++c) {
-		const int j = lane * EMA_NC + c;
+	for (int c = 0; c < NC; ++c) {
+		const int j = lane * NC + c;
 		int v = 0;
 		if (j == 0) v = h0;
 		else if (j <= qlen) {
@@ -107,6 +118,22 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 		}
 		hh[c] = v; ee[c] = 0;
 		qb[c] = j < qlen ? query.at(j) : 4;
+	}
+	if (tlen >= qlen && h0 > 0) {
+		// Exact shortcut (most seeds of most reads): the first qlen target bases equal the query and none is ambiguous.
+		// Then every row's maximum is its diagonal cell h0 + (i+1)a, strictly above every gapped cell of the row, so
+		// the DP ends with max = gscore = h0 + qlen*a at (qlen-1, qlen-1) and max_off 0, whatever the band.
+		bool same = true;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
+			if (j < qlen && (qb[c] > 3 || qb[c] != target.at(j))) same = false;
+		}
+		if (!__ballot(!same)) {
+			EmaExtRes r;
+			r.score = r.gscore = h0 + qlen * o.a; r.qle = r.tle = r.gtle = qlen; r.max_off = 0;
+			return r;
+		}
 	}
 	int max_ins, max_del;
 	{
@@ -130,11 +157,11 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 		int h1_init = 0;
 		if (beg == 0) { h1_init = h0 - (o.o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
 		// per cell: M, E from the previous row; T = what F(j+1) may open with
-		int M[EMA_NC], g[EMA_NC];
+		int M[NC], g[NC];
 		int run = EMA_NEG_BIG;
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j >= beg && j < end;
 			const int s = ema_score(o, tb, qb[c]);
 			int m = hh[c] ? hh[c] + s : 0;
@@ -144,11 +171,11 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 			run = max(run, g[c]);
 		}
 		int pre = ema_wave_exscan_max(run);     // max g over all columns of lower lanes
-		int h[EMA_NC];
+		int h[NC];
 		int m_key = -1;                         // (h << 9 | j), max over in-range cells
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j >= beg && j < end;
 			int f = pre == EMA_NEG_BIG ? 0 : pre - (j - 1) * e_ins;   // F(i,j) = max(0, max_{k<j} g_k - (j-1) e)
 			f = f > 0 ? f : 0;
@@ -159,10 +186,10 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 			pre = max(pre, g[c]);
 		}
 		// new E for in-range cells; new H array: index j takes H(i, j-1)
-		const int up = ema_wave_shr1(h[EMA_NC - 1], 0);   // H(i, 4*lane - 1)
+		const int up = ema_wave_shr1(h[NC - 1], 0);   // H(i, 4*lane - 1)
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j >= beg && j < end;
 			if (in) {
 				int t = M[c] - oe_del; t = t > 0 ? t : 0;
@@ -173,7 +200,7 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 			if (in) hh[c] = j == beg ? h1_init : left;
 			else if (j == end) { hh[c] = end > beg ? left : h1_init; ee[c] = 0; }
 		}
-		const int h1_fin = end > beg ? ema_col_get(h, end - 1) : h1_init;
+		const int h1_fin = end > beg ? ema_col_get_nc<NC>(h, end - 1) : h1_init;
 		const int jfin = end > beg ? end : beg;
 		if (jfin == qlen) {
 			max_ie = gscore > h1_fin ? max_ie : i;
@@ -197,13 +224,13 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 		// then j = last non-zero index in [beg,end] (else beg-1); end = min(j+2, qlen).
 		int first = 1 << 20, last = -1;
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool nz = (j >= beg && j <= end) && (hh[c] != 0 || ee[c] != 0);
 			const unsigned long long b = __ballot(nz);
 			if (b) {
-				const int f_ = (__ffsll((long long)b) - 1) * EMA_NC + c;
-				const int l_ = (63 - __clzll((long long)b)) * EMA_NC + c;
+				const int f_ = (__ffsll((long long)b) - 1) * NC + c;
+				const int l_ = (63 - __clzll((long long)b)) * NC + c;
 				first = first < f_ ? first : f_;
 				last = last > l_ ? last : l_;
 			}
@@ -217,6 +244,16 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 	EmaExtRes r;
 	r.score = mx_sc; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	return r;
+}
+
+// ksw_extend2, qlen <= 255.  Extensions are mostly the rest of a read beyond its seed: the narrowest column layout
+// that holds the query keeps the per-row work proportional to it.
+__device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w,
+                                            int end_bonus, int zdrop, int h0)
+{
+	if (qlen < 64) return ema_wave_extend_nc<1>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
+	if (qlen < 128) return ema_wave_extend_nc<2>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
+	return ema_wave_extend_nc<4>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
 }
 
 // ksw_global2: banded global alignment of query (columns) against target (rows).

@@ -35,6 +35,26 @@ struct AlignSlab {           // per resident wave
 	((size_t)EMA_SEED_CAP * (2 * sizeof(SeedRec) + 8) + (size_t)EMA_CHAIN_CAP * (sizeof(ChainRec) + 8 + 4 + 8 + 4) +  \
 	 (size_t)EMA_AV_CAP * (2 * sizeof(DevReg) + 8) + (size_t)EMA_INTV_CAP * sizeof(Intv) + 1024)
 
+// Most reads have a few dozen seed occurrences at most.  Their chaining tables then sit in LDS instead of the HBM slab:
+// chaining is a sequence of dependent small look-ups and edits (find the neighbouring chain, test, link the seed), and
+// each one costs a memory round trip when the tables are in HBM.
+#define EMA_SMALL_SEEDS 40
+#define EMA_SMALL_BYTES (EMA_SMALL_SEEDS * (2 * sizeof(SeedRec) + sizeof(ChainRec) + 3 * 8 + 2 * 4))
+
+__device__ __forceinline__ void ema_small_tables(AlignSlab &s, uint8_t *lds)
+{
+	size_t o = 0;
+	auto take = [&](size_t bytes) { uint8_t *p = lds + o; o += bytes; return p; };
+	s.chains = (ChainRec *)take(EMA_SMALL_SEEDS * sizeof(ChainRec));
+	s.seeds = (SeedRec *)take(EMA_SMALL_SEEDS * sizeof(SeedRec));
+	s.cs = (SeedRec *)take(EMA_SMALL_SEEDS * sizeof(SeedRec));
+	s.cpos = (int64_t *)take(EMA_SMALL_SEEDS * 8);
+	s.skey = (uint64_t *)take(EMA_SMALL_SEEDS * 8);
+	s.srt = (uint64_t *)take(EMA_SMALL_SEEDS * 8);
+	s.cord = (int32_t *)take(EMA_SMALL_SEEDS * 4);
+	s.kept = (int32_t *)take(EMA_SMALL_SEEDS * 4);
+}
+
 __device__ __forceinline__ AlignSlab ema_carve_slab(uint8_t *base)
 {
 	AlignSlab s;
@@ -193,13 +213,15 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
 	__shared__ int lds_stack[4][3 * 70];
+	__shared__ __attribute__((aligned(16))) uint8_t lds_small[4][EMA_SMALL_BYTES];
 	const int lane = (int)ema_lane();
 	const int wib = (int)(threadIdx.x >> 6);
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
 	uint8_t *query = lds_q[wib];
 	uint8_t *rseq = lds_r[wib];
 	ChainBuild cb;
-	cb.sl = ema_carve_slab(slabs + (size_t)slot * EMA_ALIGN_SLAB_BYTES);
+	const AlignSlab slab = ema_carve_slab(slabs + (size_t)slot * EMA_ALIGN_SLAB_BYTES);
+	cb.sl = slab;
 	const AlignSlab &sl = cb.sl;
 	const int64_t l_pac = ix.l_pac;
 
@@ -221,7 +243,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
 		ema_wave_sync();
 		const int n_iv = ema_uni(n_intv[read]);
-		const Intv *iv = sl.ivs;
+		const Intv *iv = slab.ivs;
 		{   // K1 delivers the intervals in discovery order; mem_collect_intv ends with a sort on (start, end).
 			// Entries with equal keys are identical, so ranking each entry (ties by position) gives THE order.
 			const Intv *raw = intv + (size_t)read * opt.intv_cap;
@@ -232,7 +254,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 					const uint64_t other = raw[k].info;
 					rank += other < mine.info || (other == mine.info && k < i);
 				}
-				sl.ivs[rank] = mine;
+				slab.ivs[rank] = mine;
 			}
 			ema_wave_sync();
 		}
@@ -242,14 +264,18 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		int l_rep = 0;
 		{
 			int b = 0, e = 0;
+			int64_t tot_occ = 0;      // seed occurrences the chaining loop below will look up
 			for (int i = 0; i < n_iv; ++i) {
 				const Intv p = iv[i];
 				const int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
+				tot_occ += p.x2 <= (uint64_t)opt.max_occ ? (int64_t)p.x2 : (int64_t)opt.max_occ;
 				if (p.x2 <= (uint64_t)opt.max_occ) continue;
 				if (sb > e) { l_rep += e - b; b = sb; e = se; }
 				else e = e > se ? e : se;
 			}
 			l_rep += e - b;
+			cb.sl = slab;
+			if (ema_uni(tot_occ <= EMA_SMALL_SEEDS)) ema_small_tables(cb.sl, lds_small[wib]);
 		}
 		const float frac_rep = (float)l_rep / (float)l_query;
 		for (int i = 0; i < n_iv; ++i) {

@@ -37,7 +37,9 @@ def extend_cases(rng, n, max_q=250):
         ql = int(rng.integers(1, max_q + 1))
         q = rng.integers(0, 4, ql).astype(np.uint8)
         kind = rng.random()
-        if kind < 0.6:
+        if kind < 0.15:    # target starts with the query itself (the kernel's exact shortcut), with or without a tail
+            t = np.concatenate([q, rng.integers(0, 4, int(rng.choice([0, 0, 1, 7, 60]))).astype(np.uint8)])
+        elif kind < 0.6:
             t = mutate(rng, q, sub=rng.choice([0.0, 0.02, 0.1]), indel=rng.choice([0.0, 0.01, 0.05]))
             t = np.concatenate([t, rng.integers(0, 4, int(rng.integers(0, 120))).astype(np.uint8)])
         elif kind < 0.8:   # big indel

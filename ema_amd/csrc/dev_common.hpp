@@ -107,82 +107,35 @@ __device__ __forceinline__ int ema_wave_shr1(int v, int ident) { return EMA_DPP(
 __device__ __forceinline__ int ema_wave_sum(int v) { return __builtin_amdgcn_readlane(ema_wave_incl_scan_add(v), 63); }
 
 // ---------------------------------------------------------------------------------------------
-// occ4 on the HBM block layout of dev_types.h, computed by FOUR adjacent lanes.
-// Lane j (= lane & 3) of the quad loads slot j of the block that holds BWT position `pos`
-// (one 16-byte load; the quad's four loads are one contiguous 64-byte line) and the quad
-// returns, in lane j, occ(pos, symbol j) = number of symbol j in B[0..pos] (bwa's bwt_occ4
-// semantics, reference path: src/bwabridge.c:236 -> mem_align1_core -> bwt_extend).
-// `pos` is in the with-sentinel row space; quad-uniform.  All 64 lanes must call this.
-__device__ __forceinline__ uint64_t ema_quad_occ4(const DevIndex &ix, uint64_t pos, bool active)
-{
-	const unsigned j = ema_lane() & 3u;
-	uint64_t cnt = 0, w = 0;
-	unsigned r = 0;
-	if (active) {
-		const uint64_t p = pos - (pos >= ix.primary ? 1 : 0);   // '$' is not stored
-		const OccSlot *s = ix.occ + ((p >> 7) << 2) + j;
-		const ulong2 v = *reinterpret_cast<const ulong2 *>(s);
-		cnt = v.x; w = v.y;
-		r = (unsigned)(p & 127);
-	}
-	int nvalid = (int)r + 1 - (int)(j << 5);
-	nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
-	const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
-	const uint64_t lo = w & m55, hi = (w >> 1) & m55;
-	const unsigned p3 = __popcll(hi & lo), p2 = __popcll(hi & ~lo), p1 = __popcll(~hi & lo);
-	const unsigned p0 = (unsigned)nvalid - p1 - p2 - p3;
-	unsigned packed = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);   // each partial <= 32, sums <= 128
-	packed += __shfl_xor(packed, 1);
-	packed += __shfl_xor(packed, 2);
-	return cnt + ((packed >> (j << 3)) & 0xffu);
-}
-
-// ---------------------------------------------------------------------------------------------
-// bwt_extend for ONE symbol, computed by a group of EIGHT adjacent lanes: lanes 0-3 of the group
-// resolve occ4(k), lanes 4-7 occ4(l).  Inputs and outputs are group-uniform.
-//   x_nb = ik.x[!is_back], x_b = ik.x[is_back], size = ik.x[2]; c = symbol index into ok[]
-//   returns ok[c]: o_nb = ok[c].x[!is_back], o_b = ok[c].x[is_back], o_size = ok[c].x[2]
-__device__ __forceinline__ void ema_group8_extend(const DevIndex &ix, uint64_t x_nb, uint64_t x_b, uint64_t size,
-                                                  int c, bool active, uint64_t &o_nb, uint64_t &o_b, uint64_t &o_size)
-{
-	const unsigned sub = ema_lane() & 7u, j = sub & 3u, half = sub >> 2;
-	const uint64_t pos = half ? x_nb - 1 + size : x_nb - 1;
-	const uint64_t mine = ema_quad_occ4(ix, pos, active);
-	const uint64_t other = __shfl_xor(mine, 4);
-	const uint64_t tk = half ? other : mine, tl = half ? mine : other;
-	const uint64_t s = tl - tk;                       // ok[j].x[2]
-	const uint64_t nb = ix.L2[j] + 1 + tk;            // ok[j].x[!is_back]
-	const uint64_t s1 = __shfl(s, 1, 8), s2 = __shfl(s, 2, 8), s3 = __shfl(s, 3, 8);
-	const uint64_t b3 = x_b + ((x_nb <= ix.primary && x_nb + size - 1 >= ix.primary) ? 1 : 0);
-	const uint64_t b2 = b3 + s3, b1 = b2 + s2, b0 = b1 + s1;
-	const int cc = c & 3;
-	o_b = cc == 3 ? b3 : cc == 2 ? b2 : cc == 1 ? b1 : b0;
-	o_nb = __shfl(nb, cc, 8);
-	o_size = __shfl(s, cc, 8);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same two primitives computed by ONE lane (one read per lane).  The lane fetches the 64-byte block with four
-// 16-byte loads (global_load_dwordx4) -- still exactly one line per occ4 query -- and does the popcounts itself, so a
-// wavefront keeps 64 independent searches and up to 128 cache lines in flight and needs no cross-lane traffic.
+// occ4 by ONE lane on the rank structure of dev_types.h: cnt[c] = number of symbol c in B[0..pos] (bwa's bwt_occ4
+// semantics; reference path: src/bwabridge.c:236 -> mem_align1_core -> bwt_extend), `pos` in the with-sentinel row
+// space.  The lane fetches the 32-byte block with two 16-byte loads and does the popcounts itself, so a wavefront
+// keeps 64 independent searches in flight and needs no cross-lane traffic.
 __device__ __forceinline__ void ema_lane_occ4(const DevIndex &ix, uint64_t pos, uint64_t cnt[4])
 {
 	const uint64_t p = pos - (pos >= ix.primary ? 1 : 0);   // '$' is not stored
-	const ulong2 *blk = reinterpret_cast<const ulong2 *>(ix.occ + ((p >> 7) << 2));
-	const ulong2 s0 = blk[0], s1 = blk[1], s2 = blk[2], s3 = blk[3];
-	const int r = (int)(p & 127);
-	unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-	const uint64_t w[4] = {s0.y, s1.y, s2.y, s3.y};
+	const OccBlock *blk = ix.occ + (p >> 6);
+	const uint4 head = *reinterpret_cast<const uint4 *>(blk);
+	const ulong2 sym = *(reinterpret_cast<const ulong2 *>(blk) + 1);
+	const int r = (int)(p & 63);
+	unsigned c1 = 0, c2 = 0, c3 = 0;
+	const uint64_t w[2] = {sym.x, sym.y};
 #pragma unroll
-	for (int j = 0; j < 4; ++j) {
+	for (int j = 0; j < 2; ++j) {
 		int nvalid = r + 1 - (j << 5);
 		nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
 		const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
 		const uint64_t lo = w[j] & m55, hi = (w[j] >> 1) & m55;
-		const unsigned p3 = __popcll(hi & lo), p2 = __popcll(hi & ~lo), p1 = __popcll(~hi & lo);
-		c3 += p3; c2 += p2; c1 += p1; c0 += (unsigned)nvalid - p1 - p2 - p3;
+		c3 += __popcll(hi & lo); c2 += __popcll(hi & ~lo); c1 += __popcll(~hi & lo);
 	}
-	cnt[0] = s0.x + c0; cnt[1] = s1.x + c1; cnt[2] = s2.x + c2; cnt[3] = s3.x + c3;
+	const unsigned c0 = (unsigned)(r + 1) - c1 - c2 - c3;
+	cnt[0] = (uint64_t)head.x + c0; cnt[1] = (uint64_t)head.y + c1; cnt[2] = (uint64_t)head.z + c2; cnt[3] = (uint64_t)head.w + c3;
+	if (ix.n_super > 1) {      // wave-uniform: only references beyond 2^31 BWT symbols have more than one superblock
+		const int sb = (int)(p >> EMA_OCC_SUPER_SHIFT);
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			cnt[c] += sb == 0 ? 0 : sb == 1 ? ix.occ_super[0][c] : sb == 2 ? ix.occ_super[1][c] : ix.occ_super[2][c];
+	}
 }
 
 // bwt_extend for one symbol by one lane; arguments as in ema_group8_extend

@@ -18,17 +18,26 @@
 
 #include <stdint.h>
 
-struct OccSlot { uint64_t cnt, bases; };   // 16 bytes
+// FM-index rank structure in HBM: one 32-byte block per 64 BWT symbols -- the number of A/C/G/T before the block
+// (relative to the block's superblock of 2^31 symbols, whose absolute counts ride in DevIndex) and the 64 symbols
+// themselves, 2 bit each (symbol t of the block at bits 2(t%32) of bases[t/32]).  One occ4 query = one block = two
+// 16-byte loads by the querying lane.
+struct OccBlock { uint32_t cnt[4]; uint64_t bases[2]; };
+#ifndef EMA_OCC_SUPER_SHIFT
+#define EMA_OCC_SUPER_SHIFT 31      // (a test build of the host interpreter lowers it to exercise several superblocks on a small reference)
+#endif
+#define EMA_OCC_MAX_SUPER 4            // up to 2^33 BWT symbols (a human genome and its reverse complement: 2^32.5)
 
 struct DevIndex {
-	const OccSlot *occ;       // 4 slots per block
+	const OccBlock *occ;
 	const void *sa;           // uint32_t* or uint64_t* by sa_width
 	const uint8_t *pac;
 	const int64_t *ctg_off;   // n_seqs + 1
 	uint64_t primary, seq_len;
 	uint64_t L2[5];
+	uint64_t occ_super[EMA_OCC_MAX_SUPER - 1][4];   // absolute counts at the start of superblocks 1, 2, 3
 	int64_t l_pac;
-	int32_t n_seqs, sa_width;
+	int32_t n_seqs, sa_width, n_super, pad_;
 };
 
 // bwa's mem_opt_t subset used by the kernels (mem_opt_init(); max_occ=3000 at reference src/align.c:185)

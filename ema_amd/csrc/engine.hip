@@ -30,7 +30,9 @@
 
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
-                                Intv *lists, int *counter, int n_blocks, hipStream_t stream, unsigned long long *prof);
+                                Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
+                                int *n_park_out, int park_max, int n_blocks, hipStream_t stream, unsigned long long *prof);
+extern "C" size_t ema_seed_park_bytes();
 
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
@@ -105,7 +107,7 @@ struct Slice {
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n;
 	DevBuf<DevReg> d_regs;
-	DevBuf<uint8_t> d_slabs;
+	DevBuf<uint8_t> d_slabs, d_park[2];   // d_park: K1's parked machines, ping-pong between the launches of a series
 	DevBuf<DevAln> d_alns;
 	DevBuf<uint32_t> d_cigars, d_cigar_out;
 	DevBuf<uint64_t> d_cand_off, d_cig_off;
@@ -116,7 +118,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_regs.release(); d_slabs.release();
+		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 		if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -136,7 +138,7 @@ struct ema_engine {
 	int n_cu = 256;
 	std::string err;
 	// index in HBM
-	DevBuf<OccSlot> d_occ;
+	DevBuf<OccBlock> d_occ;
 	DevBuf<uint8_t> d_sa, d_pac;
 	DevBuf<int64_t> d_ctg;
 	// batch input (whole batch; slices are sub-ranges, the full tier addresses it through its pair list)
@@ -152,6 +154,7 @@ struct ema_engine {
 	std::vector<uint8_t> h_nt4;
 	std::vector<uint32_t> h_off, h_qpack;
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0;
+	int seed_rounds = 6, seed_park_max = 0;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
 	int dbg_slots = 0;
 	double watchdog_s = 0;               // EMA_WATCHDOG_S=<seconds>: poll after every launch, report stuck waves
@@ -183,7 +186,8 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
 	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
-	HIPCHK(e, s.d_counters.alloc(16));
+	HIPCHK(e, s.d_counters.alloc(32));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts
+	for (auto &pk : s.d_park) HIPCHK(e, pk.alloc((size_t)e->seed_blocks * 4 * (size_t)(e->seed_park_max > 0 ? e->seed_park_max : 1) * ema_seed_park_bytes()));
 	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
 	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
 	if ((size_t)e->final_blocks * 4 * ema_final_slab_bytes() > slab) slab = (size_t)e->final_blocks * 4 * ema_final_slab_bytes();
@@ -225,7 +229,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->contigs = hix.contigs;
 	e->l_pac = hix.l_pac;
 	HIPCHK(e, e->d_occ.alloc(hix.occ.size()));
-	HIPCHK(e, hipMemcpy(e->d_occ.p, hix.occ.data(), hix.occ.size() * sizeof(OccSlot), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(e->d_occ.p, hix.occ.data(), hix.occ.size() * sizeof(OccBlock), hipMemcpyHostToDevice));
 	HIPCHK(e, e->d_sa.alloc(hix.sa_bytes.size()));
 	HIPCHK(e, hipMemcpy(e->d_sa.p, hix.sa_bytes.data(), hix.sa_bytes.size(), hipMemcpyHostToDevice));
 	HIPCHK(e, e->d_pac.alloc(hix.pac.size()));
@@ -237,6 +241,9 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 
 	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(16)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 128)); }
 	if (const char *wd = getenv("EMA_WATCHDOG_S")) { e->watchdog_s = atof(wd); e->dbg_slots = e->n_cu * 8 * 4 + 64; }
+	if (const char *v = getenv("EMA_SEED_ROUNDS")) e->seed_rounds = std::max(1, std::min(8, atoi(v)));
+	if (const char *v = getenv("EMA_SEED_PARK")) e->seed_park_max = std::max(0, std::min(63, atoi(v)));
+	if (e->seed_park_max == 0) e->seed_rounds = 1;
 	e->seed_blocks = e->n_cu * ema_seed_blocks_per_cu();      // every resident lane carries one read
 	e->align_blocks = e->n_cu * ema_align_blocks_per_cu();    // one scratch slab per resident wave
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
@@ -387,10 +394,19 @@ static Work work_of(ema_engine *e, const Slice &s, bool listed)
 static int run_seed(ema_engine *e, Slice &s, const Work &w)
 {
 	HIPCHK(e, hipMemsetAsync(s.d_status.p, 0, (size_t)w.n_pairs * 2 * 4, s.stream));
-	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 16 * 4, s.stream));
-	ema_launch_seed(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
-	                s.d_lists.p, s.d_counters.p + 3, e->seed_blocks, s.stream, e->d_prof.p);
-	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 32 * 4, s.stream));
+	// a series of launches: fresh reads first, then the machines the retiring waves of the previous launch parked
+	const int rounds = e->seed_rounds;
+	for (int r = 0; r < rounds; ++r) {
+		const bool last = r == rounds - 1;
+		const int in = (r + 1) & 1, out = r & 1;      // round 0 parks into buffer 0, round 1 reads 0 and parks into 1, ...
+		if (r >= 2) HIPCHK(e, hipMemsetAsync(s.d_counters.p + 16 + out, 0, 4, s.stream));
+		ema_launch_seed(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
+		                s.d_lists.p, r == 0 ? s.d_counters.p + 3 : s.d_counters.p + 8 + r, r == 0 ? nullptr : s.d_park[in].p,
+		                s.d_counters.p + 16 + in, last ? nullptr : s.d_park[out].p, s.d_counters.p + 16 + out,
+		                last ? 0 : e->seed_park_max, e->seed_blocks, s.stream, e->d_prof.p);
+		HIPCHK(e, hipGetLastError());
+	}
 	watchdog(e, s, "ema_k_seed");
 	return EMA_OK;
 }

@@ -30,6 +30,8 @@ DevIndex HostIndex::view() const
 	d.l_pac = l_pac;
 	d.n_seqs = (int32_t)contigs.size();
 	d.sa_width = sa_width;
+	d.n_super = n_super; d.pad_ = 0;
+	memcpy(d.occ_super, occ_super, sizeof(occ_super));
 	return d;
 }
 
@@ -46,29 +48,36 @@ std::string host_index_load(const std::string &prefix, HostIndex &ix)
 	{
 		const uint32_t *w = (const uint32_t *)(raw.data() + 40);
 		const uint64_t n_words = (raw.size() - 40) / 4;
-		const uint64_t n_blocks = (ix.seq_len + 127) >> 7;
-		ix.occ.assign((n_blocks + 1) * 4, OccSlot{0, 0});
-		uint64_t running[4] = {0, 0, 0, 0};
+		const uint64_t n_blocks = (ix.seq_len + 127) >> 7;      // bwa's 128-symbol blocks; two device blocks each
+		ix.n_super = (int)((ix.seq_len >> EMA_OCC_SUPER_SHIFT) + 1);
+		if (ix.n_super > EMA_OCC_MAX_SUPER) return "reference too long for the device rank structure (2^33 BWT symbols)";
+		OccBlock zero; memset(&zero, 0, sizeof(zero));
+		ix.occ.assign((n_blocks + 1) * 2, zero);
+		uint64_t running[4] = {0, 0, 0, 0}, super[4] = {0, 0, 0, 0};
 		for (uint64_t b = 0; b < n_blocks; ++b) {
 			uint64_t base = b * 16;
 			if (base + 8 > n_words) return "truncated .bwt";
 			uint64_t cnt[4];
 			memcpy(cnt, w + base, 32);
-			for (int c = 0; c < 4; ++c) {
+			for (int c = 0; c < 4; ++c)
 				if (cnt[c] != running[c]) return "inconsistent occ counters in .bwt";
-				ix.occ[b * 4 + c].cnt = cnt[c];
-			}
 			for (int t = 0; t < 128; ++t) {
 				uint64_t pos = (b << 7) + t;
 				if (pos >= ix.seq_len) break;
+				if ((t & 63) == 0) {      // a device block starts here
+					if ((pos & (((uint64_t)1 << EMA_OCC_SUPER_SHIFT) - 1)) == 0) {
+						const uint64_t sb = pos >> EMA_OCC_SUPER_SHIFT;
+						for (int c = 0; c < 4; ++c) { super[c] = running[c]; if (sb > 0) ix.occ_super[sb - 1][c] = running[c]; }
+					}
+					for (int c = 0; c < 4; ++c) ix.occ[pos >> 6].cnt[c] = (uint32_t)(running[c] - super[c]);
+				}
 				uint64_t wi = base + 8 + (t >> 4);
 				if (wi >= n_words) return "truncated .bwt";
 				unsigned sym = w[wi] >> ((~t & 15) << 1) & 3;
-				ix.occ[b * 4 + (t >> 5)].bases |= (uint64_t)sym << ((t & 31) << 1);
+				ix.occ[pos >> 6].bases[(t & 63) >> 5] |= (uint64_t)sym << ((t & 31) << 1);
 				++running[sym];
 			}
 		}
-		for (int c = 0; c < 4; ++c) ix.occ[n_blocks * 4 + c].cnt = running[c];
 		for (int c = 0; c < 4; ++c)
 			if (running[c] != ix.L2[c + 1] - ix.L2[c]) return "symbol totals disagree with L2 in .bwt";
 	}

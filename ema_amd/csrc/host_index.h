@@ -12,7 +12,9 @@
 struct HostContig { std::string name; int64_t offset; int32_t len; int32_t is_alt; };
 
 struct HostIndex {
-	std::vector<OccSlot> occ;        // device layout (see dev_types.h)
+	std::vector<OccBlock> occ;       // device layout (see dev_types.h)
+	uint64_t occ_super[EMA_OCC_MAX_SUPER - 1][4] = {};
+	int n_super = 1;
 	std::vector<uint8_t> sa_bytes;   // seq_len+1 rows of sa_width bytes
 	std::vector<uint8_t> pac;
 	std::vector<int64_t> ctg_off;    // n+1

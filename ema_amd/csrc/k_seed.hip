@@ -37,6 +37,15 @@ namespace {
 enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, PC_BWD_N,
        PC_FWD = 8, PC_FWD_RES, PC_BWD, PC_BWD_RES, PC_S3, PC_S3_RES };
 
+// A machine taken off its lane (see "re-packing" below): everything phase B and the next step need.  The working
+// lists stay where they are -- `wl` is the address of the lane's list slab -- and the read is re-staged from qpack.
+struct SeedPark {
+	uint64_t last_curr_size, c0, c1, c2, f0, f1, f2, ld_at, wl;
+	int32_t pc, pass, len, read, x, sm_x, min_intv, i, j, n_prev, n_curr, rev, prev_is_a, n_mem_call, last_mem_start;
+	int32_t n_out, old_n, k2, st, req_c, ld_kind, has_req;
+	uint32_t c_end, f_end;
+};
+
 }  // namespace
 
 // reads: qpack[r * 24 ..]: 16 words of 2-bit codes (base i at bits 2(i%16) of word i/16, N stored as 0) followed by
@@ -45,11 +54,18 @@ enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, 
 // lists: (gridDim.x * blockDim.x) x 2 x EMA_LIST_CAP scratch entries (one pair of working lists per lane, interleaved
 //        over the 64 lanes of a wave so that lanes at the same list index touch one contiguous 2 KB run)
 // counter: zero on entry; reads are handed out one by one
+// Re-packing.  A read costs anything from a hundred to ten thousand ticks, so once the queue is empty a wave keeps
+// ticking -- at full instruction cost -- for its last few long reads.  Instead, a wave that is down to park_max
+// machines after the queue ran dry writes them to park_out (count in *n_park_out) and retires; the next launch of this
+// kernel (park_in / n_park_in set, same grid) takes parked machines instead of fresh reads, 64 to a wave again.  The
+// engine queues a fixed, short series of such launches, the last one with park_max = 0.  (Each launch shrinks the
+// parked population about 64 / park_max-fold; a wave that starts with no more than park_max machines keeps them.)
 __global__ void __launch_bounds__(256)
 ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv,
            int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
-           int *__restrict__ counter, unsigned long long *prof)
+           int *__restrict__ counter, const SeedPark *__restrict__ park_in, const int *__restrict__ n_park_in,
+           SeedPark *__restrict__ park_out, int *__restrict__ n_park_out, int park_max, unsigned long long *prof)
 {
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
 	__shared__ uint32_t lds_n[4][8 * 64];       // N mask, 8 words per lane
@@ -57,8 +73,8 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wib;
 	const uint32_t *qw = lds_q[wib] + lane, *nm = lds_n[wib] + lane;
 	// this wave's working lists: list A then list B, entry e of this lane at [(e << 6) + lane]
-	Intv *const wl = lists + wave * (2 * EMA_LIST_CAP * 64) + lane;
-	n_reads = ema_work_count(n_reads, n_pairs_dev, 2);
+	Intv *wl = lists + wave * (2 * EMA_LIST_CAP * 64) + lane;
+	const int n_tasks = park_in ? *n_park_in : ema_work_count(n_reads, n_pairs_dev, 2);
 
 	// ---- per-lane machine state
 	int pc = PC_DONE, pass = 1, len = 0, read = -1;
@@ -80,6 +96,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 		return ((nm[(p_ >> 5) << 6] >> (p_ & 31)) & 1) ? 4 : code;
 	};
 	// diagnostic (prof != null): ticks, active lane-ticks and shader clocks of this wave
+	int peak = 0;
 	unsigned long long n_tick = 0, n_active = 0, t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
 	for (;;) {
 		// ---- phase A: control programs, registers and LDS only
@@ -182,7 +199,17 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			case PC_DONE:
 				if (read >= 0) { n_intv[read] = n_out; status[read] = st; }
 				read = atomicAdd(counter, 1);
-				if (read >= n_reads) { exhausted = true; break; }
+				if (read >= n_tasks) { read = -1; exhausted = true; break; }
+				if (park_in) {      // resume a parked machine: it waits for its extend / entry load
+					const SeedPark &k = park_in[read];
+					last_curr_size = k.last_curr_size; c0 = k.c0; c1 = k.c1; c2 = k.c2; f0 = k.f0; f1 = k.f1; f2 = k.f2;
+					ld_at = (size_t)k.ld_at; wl = reinterpret_cast<Intv *>(k.wl);
+					pc = k.pc; pass = k.pass; x = k.x; sm_x = k.sm_x; min_intv = k.min_intv; i = k.i; j = k.j;
+					n_prev = k.n_prev; n_curr = k.n_curr; rev = k.rev; prev_is_a = k.prev_is_a; n_mem_call = k.n_mem_call;
+					last_mem_start = k.last_mem_start; n_out = k.n_out; old_n = k.old_n; k2 = k.k2; st = k.st;
+					req_c = k.req_c; ld_kind = k.ld_kind; has_req = k.has_req != 0; c_end = k.c_end; f_end = k.f_end;
+					read = k.read;
+				}
 				{
 					const int in_read = ema_in_read(map, read);
 					len = (int)(off[in_read + 1] - off[in_read]);
@@ -198,6 +225,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 					nd[4 << 6] = m1.x; nd[5 << 6] = m1.y; nd[6 << 6] = m1.z; nd[7 << 6] = m1.w;
 				}
 				out_base = (size_t)read * opt.intv_cap;
+				if (park_in) break;
 				st = 0; n_out = 0; pass = 1; x = 0; prev_is_a = 1; n_curr = 0;
 				if (len >= opt.min_seed_len) pc = PC_P1_NEXT;      // mem_chain: no seeds for a read shorter than min_seed_len
 				break;
@@ -247,7 +275,24 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				else { x = i + 1; pc = PC_P3_NEXT; }
 			}
 		}
-		if (!__any(has_req || ld_kind)) break;
+		const unsigned long long busy = __ballot(has_req || ld_kind);
+		if (!busy) break;
+		const int n_busy = __popcll(busy);
+		peak = peak > n_busy ? peak : n_busy;
+		// the queue is empty and the wave, once fuller, nearly so (a wave that never held more runs its machines to the end)
+		if (park_max > 0 && n_busy <= park_max && peak > park_max && __ballot(exhausted)) {
+			if (has_req || ld_kind) {
+				SeedPark k;
+				k.last_curr_size = last_curr_size; k.c0 = c0; k.c1 = c1; k.c2 = c2; k.f0 = f0; k.f1 = f1; k.f2 = f2;
+				k.ld_at = ld_at; k.wl = reinterpret_cast<uint64_t>(wl);
+				k.pc = pc; k.pass = pass; k.len = len; k.read = read; k.x = x; k.sm_x = sm_x; k.min_intv = min_intv; k.i = i; k.j = j;
+				k.n_prev = n_prev; k.n_curr = n_curr; k.rev = rev; k.prev_is_a = prev_is_a; k.n_mem_call = n_mem_call;
+				k.last_mem_start = last_mem_start; k.n_out = n_out; k.old_n = old_n; k.k2 = k2; k.st = st;
+				k.req_c = req_c; k.ld_kind = ld_kind; k.has_req = has_req ? 1 : 0; k.c_end = c_end; k.f_end = f_end;
+				park_out[atomicAdd(n_park_out, 1)] = k;
+			}
+			break;
+		}
 		if (prof) { ++n_tick; n_active += __popcll(__ballot(has_req)); }
 		// ---- phase B: every global load of the tick, issued together
 		if (ld_kind) {
@@ -271,12 +316,17 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 	}
 }
 
+extern "C" size_t ema_seed_park_bytes() { return sizeof(SeedPark); }
+
+// One launch of the series (see "re-packing"): park_in == null takes fresh reads, otherwise the machines parked by the
+// previous launch; park_max == 0 never parks.
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
-                                int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status, Intv *lists, int *counter, int n_blocks,
-                                hipStream_t stream, unsigned long long *prof)
+                                int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
+                                Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
+                                int *n_park_out, int park_max, int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
 	hipLaunchKernelGGL(ema_k_seed, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
-	                   status, lists, counter, prof);
+	                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, prof);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -58,7 +58,22 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	std::vector<Intv> lists((size_t)n_blocks * 256 * 2 * EMA_LIST_CAP);
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, lists.data(), &seed_counter, n_blocks, nullptr, nullptr);
+	{   // the engine's series of launches: fresh reads, then the machines parked by retiring waves (n_blocks < 0: no parking)
+		const int nb = n_blocks < 0 ? -n_blocks : n_blocks, park_max = n_blocks < 0 ? 0 : 40, rounds = n_blocks < 0 ? 1 : 4;
+		lists.assign((size_t)nb * 256 * 2 * EMA_LIST_CAP, Intv());
+		std::vector<uint8_t> park[2];
+		for (auto &pk : park) pk.resize((size_t)nb * 4 * 64 * ema_seed_park_bytes());
+		int n_park[2] = {0, 0}, ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int r = 0; r < rounds; ++r) {
+			const bool last = r == rounds - 1;
+			const int in = (r + 1) & 1, out = r & 1;
+			if (r >= 2) n_park[out] = 0;
+			ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, lists.data(), &ctr[r],
+			                r == 0 ? nullptr : park[in].data(), &n_park[in], last ? nullptr : park[out].data(), &n_park[out],
+			                last ? 0 : park_max, nb, nullptr, nullptr);
+			fprintf(stderr, "emu_seed round %d: parked %d\n", r, last ? 0 : n_park[out]);
+		}
+	}
 	for (int r = 0; r < n_reads; ++r) {
 		Intv *a = (Intv *)intv + (size_t)r * EMU_INTV_CAP;
 		std::stable_sort(a, a + n_intv[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });
@@ -104,7 +119,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
 	ema_launch_align(&di, &d, bases, off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
@@ -127,7 +142,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
@@ -165,7 +180,7 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[4] = {0, 0, 0, 0};
-	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	ema_launch_align(&di, &d, bases, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(),
 	                 t.status.data(), slabs.data(), &counter[0], 1, nullptr, nullptr, nullptr);
 	ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_pairs, n_dev, map, t.regs.data(),

@@ -21,7 +21,7 @@ def lib(rebuild=False):
         srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
         if rebuild or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")])
-        L = C.CDLL(so)
+        L = C.CDLL(os.environ.get("EMU_SO", so))      # EMU_SO: an alternative build (e.g. with a small EMA_OCC_SUPER_SHIFT)
         L.emu_index_load.restype = C.c_void_p
         L.emu_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.emu_index_free.argtypes = [C.c_void_p]

@@ -20,6 +20,8 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
                  bounded sample of the same workload.
 """
 import argparse
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before anything initialises the GPU runtime: see ema_amd/csrc/engine.hip
 import json
 import os
 import sys
@@ -44,8 +46,9 @@ def build_workload(args, rank, world, workdir):
     from ema_amd import synth, build_index
     prefix = os.path.join(workdir, "ref.fa")
     if args.genome_mbp > 0:
-        lens = [int(args.genome_mbp * 1e6)]
-        gname = f"synthetic {args.genome_mbp:g} Mbp, 1 contig"
+        n_ctg = max(1, int(np.ceil(args.genome_mbp / 155.0)))          # chromosome-sized contigs (contig lengths are 32-bit)
+        lens = [int(args.genome_mbp * 1e6 / n_ctg)] * n_ctg
+        gname = f"synthetic {args.genome_mbp:g} Mbp, {n_ctg} contig{'s' if n_ctg > 1 else ''}"
     else:
         lens = [CHR20_LEN]
         gname = "synthetic chr20-scale (64,444,167 bp, 1 contig)"
@@ -54,7 +57,7 @@ def build_workload(args, rank, world, workdir):
     log(f"[rank {rank}] genome {gname}: {time.time() - t:.1f}s")
     if rank == 0:
         t = time.time()
-        synth.write_fasta(prefix, ctg, names=["chr20"])
+        synth.write_fasta(prefix, ctg, names=["chr20"] if len(ctg) == 1 else [f"chr{i + 1}" for i in range(len(ctg))])
         build_index(prefix)
         log(f"[rank 0] index built in {time.time() - t:.1f}s")
     if world > 1:

@@ -51,6 +51,9 @@ struct DevOpts {
 	// per-read output capacities of this launch (the engine runs a lean tier and, for the few reads that exceed it,
 	// a second tier with the full EMA_INTV_CAP / EMA_REG_CAP / EMA_CIG_CAP)
 	int intv_cap, reg_cap, cig_cap;
+	// K1: a read that needs more extends than this is given up with EMA_ST_LONG (lean tier: keeps a launch's tail short;
+	// the full tier has no budget)
+	int seed_budget;
 };
 
 // SMEM / seed interval: bwa's bwtintv_t.  info = start<<32 | end.
@@ -62,6 +65,7 @@ struct Intv { uint64_t x0, x1, x2, info; };
 #define EMA_INTV_LEAN 48      // lean tier (engine.hip): 0.01-0.03 % of reads of the benchmark mix exceed one of these
 #define EMA_REG_LEAN 48
 #define EMA_CIG_LEAN 192
+#define EMA_SEED_BUDGET_LEAN 2048
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
 
 // bwa's mem_seed_t plus the link to the next seed of the same chain
@@ -99,6 +103,7 @@ struct DevReg {
 #define EMA_ST_REG_OVERFLOW 16
 #define EMA_ST_RSEQ_OVERFLOW 32
 #define EMA_ST_CIGAR_OVERFLOW 64
+#define EMA_ST_LONG 256           // lean tier only: the read's seeding exceeded the lean extend budget
 #define EMA_ST_REDO 128           // lean tier only: the pair is on the full-capacity tier's work list
 
 #endif

@@ -214,6 +214,10 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->dopts = ema_make_dev_opts(e->opts);
 	e->device = device;
 	memset(&e->timing, 0, sizeof(e->timing));
+	// The slices and the full-capacity tier want a hardware queue each, plus the null stream's; the ROCm runtime gives a
+	// process 4 unless GPU_MAX_HW_QUEUES says otherwise, and reads it when it initialises -- so ask for 8 here, which
+	// takes effect if nothing in the process has touched the GPU yet (bench.py and the Python wrapper set it at import).
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	int n_dev = 0;
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { e->err = "no HIP device available (the engine has no CPU fallback)"; return EMA_EDEVICE; }
 	if (device < 0 || device >= n_dev) { e->err = "device index out of range"; return EMA_EARG; }
@@ -249,7 +253,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
 
-	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // the device gives one process 3 hardware queues: a 4th stream only serialises
+	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
 	if (n_streams > 16) n_streams = 16;
 	const size_t want = e->opts.batch_pairs > 0 ? (size_t)e->opts.batch_pairs : (size_t)262144;
 	const size_t per = (want + n_streams - 1) / n_streams;
@@ -265,6 +269,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 		s.dopts.intv_cap = std::min(EMA_INTV_CAP, e->opts.lean_intervals > 0 ? e->opts.lean_intervals : EMA_INTV_LEAN);
 		s.dopts.reg_cap = std::min(EMA_REG_CAP, e->opts.lean_regions > 0 ? e->opts.lean_regions : EMA_REG_LEAN);
 		s.dopts.cig_cap = std::min(EMA_CIG_CAP, e->opts.lean_cigar_ops > 0 ? e->opts.lean_cigar_ops : EMA_CIG_LEAN);
+		s.dopts.seed_budget = e->opts.lean_seed_extends > 0 ? e->opts.lean_seed_extends : e->opts.lean_seed_extends < 0 ? 1 << 30 : EMA_SEED_BUDGET_LEAN;
 		int rc = slice_alloc(e, s, nullptr);
 		if (rc != EMA_OK) return rc;
 	}
@@ -272,7 +277,12 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	if (full_cap > e->cap_pairs) full_cap = e->cap_pairs;
 	e->full.cap_pairs = full_cap;
 	e->full.dopts = e->dopts;      // EMA_INTV_CAP / EMA_REG_CAP / EMA_CIG_CAP
-	int rc = slice_alloc(e, e->full, e->sl.back().stream);
+	// The full tier gets a stream of its own when there is a hardware queue to spare (its kernels are one long latency
+	// chain of a few heavy reads: on a slice's stream they would hold up that slice's next pass); otherwise its work
+	// follows the last slice's.  EMA_FULL_OWN_STREAM=0/1 overrides.
+	bool own = atoi(getenv("GPU_MAX_HW_QUEUES")) >= n_streams + 2;
+	if (const char *v = getenv("EMA_FULL_OWN_STREAM")) own = atoi(v) != 0;
+	int rc = slice_alloc(e, e->full, own ? nullptr : e->sl.back().stream);
 	if (rc != EMA_OK) return rc;
 	HIPCHK(e, e->d_redo.alloc(full_cap + 1));
 	HIPCHK(e, e->d_redo_run.alloc(full_cap + 1));
@@ -317,6 +327,7 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 	if (n_pairs > e->cap_pairs) { e->err = "batch larger than ema_engine_batch_capacity()"; return EMA_EARG; }
 	HIPCHK(e, hipSetDevice(e->device));
 	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));      // a run still in flight reads the input
+	HIPCHK(e, hipStreamSynchronize(e->full.stream));
 	const size_t n_reads = 2 * n_pairs;
 	e->h_off.resize(n_reads + 1);
 	const uint32_t base0 = off[0];
@@ -479,7 +490,8 @@ static int run_batch(ema_engine_t *e, bool serial)
 	}
 	// full-capacity tier, behind the last slice: take over the list once every slice has added to it, then K1..K4 on it
 	Slice &f = e->full;
-	for (size_t k = 0; k + 1 < e->sl.size(); ++k) HIPCHK(e, hipStreamWaitEvent(f.stream, e->sl[k].ev[7], 0));
+	for (size_t k = 0; k < e->sl.size(); ++k)
+		if (e->sl[k].stream != f.stream) HIPCHK(e, hipStreamWaitEvent(f.stream, e->sl[k].ev[7], 0));
 	HIPCHK(e, hipMemcpyAsync(e->d_redo_run.p, e->d_redo.p, (f.cap_pairs + 1) * 4, hipMemcpyDeviceToDevice, f.stream));
 	HIPCHK(e, hipMemsetAsync(e->d_redo.p, 0, 4, f.stream));
 	HIPCHK(e, hipEventRecord(f.ev[7], f.stream));
@@ -493,6 +505,7 @@ int ema_engine_sync(ema_engine_t *e)
 	if (!e) return EMA_EARG;
 	HIPCHK(e, hipSetDevice(e->device));
 	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
+	HIPCHK(e, hipStreamSynchronize(e->full.stream));
 	if (e->ran) {      // mean launch duration of each kernel over the lean slices (launches of different slices overlap)
 		float sum[4] = {0, 0, 0, 0};
 		for (auto &s : e->sl)
@@ -533,6 +546,7 @@ static int debug_ready(ema_engine *e, const char *who)
 	if (e->n_pairs > e->full.cap_pairs) { e->err = std::string(who) + ": batch larger than ema_engine_full_tier_capacity()"; return EMA_EARG; }
 	HIPCHK(e, hipSetDevice(e->device));
 	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
+	HIPCHK(e, hipStreamSynchronize(e->full.stream));
 	e->full.first_pair = 0; e->full.n_pairs = e->n_pairs;
 	return EMA_OK;
 }
@@ -677,6 +691,7 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	}
 	// the pairs redone by the full-capacity tier
 	Slice &f = e->full;
+	HIPCHK(e, hipStreamSynchronize(f.stream));
 	int n_listed = 0;
 	HIPCHK(e, hipMemcpy(&n_listed, e->d_redo_run.p, 4, hipMemcpyDeviceToHost));
 	const size_t n_redo = std::min<size_t>((size_t)n_listed, f.cap_pairs);

@@ -42,7 +42,7 @@ enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, 
 struct SeedPark {
 	uint64_t last_curr_size, c0, c1, c2, f0, f1, f2, ld_at, wl;
 	int32_t pc, pass, len, read, x, sm_x, min_intv, i, j, n_prev, n_curr, rev, prev_is_a, n_mem_call, last_mem_start;
-	int32_t n_out, old_n, k2, st, req_c, ld_kind, has_req;
+	int32_t n_out, old_n, k2, st, req_c, ld_kind, has_req, n_ext;
 	uint32_t c_end, f_end;
 };
 
@@ -80,7 +80,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 	int pc = PC_DONE, pass = 1, len = 0, read = -1;
 	int x = 0, sm_x = 0, min_intv = 1, i = 0, j = 0;
 	int n_prev = 0, n_curr = 0, rev = 0, prev_is_a = 1;
-	int n_mem_call = 0, last_mem_start = 0, n_out = 0, old_n = 0, k2 = 0, st = 0;
+	int n_mem_call = 0, last_mem_start = 0, n_out = 0, old_n = 0, k2 = 0, st = 0, n_ext = 0;
 	uint64_t last_curr_size = 0;
 	uint64_t c0 = 0, c1 = 0, c2 = 0; uint32_t c_end = 0;      // interval being extended: bwa's ik (forward) / *p (backward)
 	uint64_t f0 = 0, f1 = 0, f2 = 0; uint32_t f_end = 0;      // first interval pushed in this backward row (the next row starts with it)
@@ -207,7 +207,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 					pc = k.pc; pass = k.pass; x = k.x; sm_x = k.sm_x; min_intv = k.min_intv; i = k.i; j = k.j;
 					n_prev = k.n_prev; n_curr = k.n_curr; rev = k.rev; prev_is_a = k.prev_is_a; n_mem_call = k.n_mem_call;
 					last_mem_start = k.last_mem_start; n_out = k.n_out; old_n = k.old_n; k2 = k.k2; st = k.st;
-					req_c = k.req_c; ld_kind = k.ld_kind; has_req = k.has_req != 0; c_end = k.c_end; f_end = k.f_end;
+					req_c = k.req_c; ld_kind = k.ld_kind; has_req = k.has_req != 0; n_ext = k.n_ext; c_end = k.c_end; f_end = k.f_end;
 					read = k.read;
 				}
 				{
@@ -226,7 +226,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				}
 				out_base = (size_t)read * opt.intv_cap;
 				if (park_in) break;
-				st = 0; n_out = 0; pass = 1; x = 0; prev_is_a = 1; n_curr = 0;
+				st = 0; n_out = 0; pass = 1; x = 0; prev_is_a = 1; n_curr = 0; n_ext = 0;
 				if (len >= opt.min_seed_len) pc = PC_P1_NEXT;      // mem_chain: no seeds for a read shorter than min_seed_len
 				break;
 			case PC_P1_NEXT:      // pass 1: SMEMs from left to right
@@ -263,7 +263,8 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			// (7) the one place that looks up the next base and posts the extend
 			if (pc == PC_FWD || pc == PC_BWD || pc == PC_S3) {
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
-				if (b < 4) {
+				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
+				else if (b < 4) {
 					has_req = true;
 					if (pc == PC_BWD) {
 						req_c = b;
@@ -288,7 +289,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				k.pc = pc; k.pass = pass; k.len = len; k.read = read; k.x = x; k.sm_x = sm_x; k.min_intv = min_intv; k.i = i; k.j = j;
 				k.n_prev = n_prev; k.n_curr = n_curr; k.rev = rev; k.prev_is_a = prev_is_a; k.n_mem_call = n_mem_call;
 				k.last_mem_start = last_mem_start; k.n_out = n_out; k.old_n = old_n; k.k2 = k2; k.st = st;
-				k.req_c = req_c; k.ld_kind = ld_kind; k.has_req = has_req ? 1 : 0; k.c_end = c_end; k.f_end = f_end;
+				k.req_c = req_c; k.ld_kind = ld_kind; k.has_req = has_req ? 1 : 0; k.n_ext = n_ext; k.c_end = c_end; k.f_end = f_end;
 				park_out[atomicAdd(n_park_out, 1)] = k;
 			}
 			break;

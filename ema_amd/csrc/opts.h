@@ -15,7 +15,7 @@ inline DevOpts ema_make_dev_opts(const ema_engine_opts &o)
 	d.split_width = o.split_width; d.max_mem_intv = o.max_mem_intv; d.max_occ = o.max_occ;
 	d.max_chain_gap = o.max_chain_gap; d.min_chain_weight = o.min_chain_weight; d.max_chain_extend = o.max_chain_extend;
 	d.mask_level = o.mask_level; d.drop_ratio = o.drop_ratio; d.mask_level_redun = o.mask_level_redun;
-	d.intv_cap = EMA_INTV_CAP; d.reg_cap = EMA_REG_CAP; d.cig_cap = EMA_CIG_CAP;
+	d.intv_cap = EMA_INTV_CAP; d.reg_cap = EMA_REG_CAP; d.cig_cap = EMA_CIG_CAP; d.seed_budget = 1 << 30;
 	int k = 0;
 	for (int i = 0; i < 4; ++i) {
 		for (int j = 0; j < 4; ++j) d.mat[k++] = (int8_t)(i == j ? o.a : -o.b);
@@ -35,6 +35,6 @@ inline void ema_fill_default_opts(ema_engine_opts *o)
 	o->split_factor = 1.5f; o->mask_level = 0.50f; o->drop_ratio = 0.50f; o->mask_level_redun = 0.95f;
 	o->score_delta = 25; o->max_rescue = 50; o->pes_low = -35; o->pes_high = 500;
 	o->batch_pairs = 0; o->n_streams = 0; o->full_tier_pairs = 0;
-	o->lean_intervals = o->lean_regions = o->lean_cigar_ops = 0;
+	o->lean_intervals = o->lean_regions = o->lean_cigar_ops = 0; o->lean_seed_extends = 0;
 }
 #endif

@@ -26,7 +26,7 @@ class Opts(C.Structure):
                                        "zdrop", "min_seed_len", "split_width", "max_mem_intv", "max_occ",
                                        "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
                [(n, C.c_float) for n in ("split_factor", "mask_level", "drop_ratio", "mask_level_redun")] + \
-               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs", "n_streams", "full_tier_pairs", "lean_intervals", "lean_regions", "lean_cigar_ops")]
+               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs", "n_streams", "full_tier_pairs", "lean_intervals", "lean_regions", "lean_cigar_ops", "lean_seed_extends")]
 
 
 class Cand(C.Structure):
@@ -61,6 +61,8 @@ class Timing(C.Structure):
 
 
 _lib = None
+# one hardware queue per batch slice + the full-capacity tier (read by the ROCm runtime when it initialises; see engine.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def load_library():

@@ -52,6 +52,7 @@ typedef struct {
 	int n_streams;              /* slices of a batch run on their own HIP streams so that kernel tails overlap (0 = default, 3) */
 	int full_tier_pairs;        /* pairs per batch the full-capacity tier can redo (0 = default: batch/64 within 4096..16384) */
 	int lean_intervals, lean_regions, lean_cigar_ops;   /* per-read capacities of the lean tier (0 = defaults 48, 48, 192) */
+	int lean_seed_extends;      /* lean tier: FM-index extends one read's seeding may take (0 = default 2048, < 0 = no limit) */
 } ema_engine_opts;
 
 void ema_engine_opts_default(ema_engine_opts *o);
@@ -95,7 +96,7 @@ typedef struct {
 	size_t n_cigar;
 	size_t n_redone;        /* pairs that went through the full-capacity tier */
 	int32_t *status;        /* per read (2*n_pairs): 0, or capacity bits (1 intervals, 2 lists, 4 seeds, 8 chains, 16 regions,
-	                         * 32 reference window, 64 CIGAR ops, 128 not redone: full-capacity tier was full); a flagged read has no candidates */
+	                         * 32 reference window, 64 CIGAR ops, 128 not redone: full-capacity tier was full, 256 seeding budget); a flagged read has no candidates */
 } ema_batch_out;
 
 /* Whole hot path for a batch: reads are ASCII, read r at bases[off[r] .. off[r+1]);

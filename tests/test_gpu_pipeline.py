@@ -134,3 +134,18 @@ def test_full_tier_overflow_fails_loudly():
     assert b.n_redone == 4 and (b.status != 0).sum() >= 2
     flagged = np.nonzero(b.status)[0]
     assert all(b.cand_off[r + 1] == b.cand_off[r] for r in flagged)
+
+
+def test_lean_seeding_budget_sends_long_reads_to_the_full_tier():
+    """A read whose seeding needs more FM-index extends than the lean budget is given up there and redone by the
+    full-capacity tier (which has no budget): same candidates as the oracle."""
+    prefix, ctg = small_ref("repeats")
+    pairs = synth.make_pairs(ctg, 500, seed=49)
+    o = default_opts()
+    o.lean_seed_extends = 450          # about the median read
+    eng = Engine(prefix, opts=o)
+    batch = eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()
+    assert batch.status.max() == 0
+    assert 50 < batch.n_redone < pairs.n
+    assert not compare(prefix, pairs, batch)

@@ -51,10 +51,10 @@ extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int scor
                                 int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, const int *n_pairs_dev,
                                 const int *map, DevReg *regs, int *n_regs, int *status, uint8_t *slabs, int *counter,
                                 int n_blocks, hipStream_t stream, int *dbg);
-extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
+extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *qpack, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
-                                 DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
-                                 hipStream_t stream, int *dbg);
+                                 DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, int *kdone, int *todo, int *n_todo,
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg);
 extern "C" void ema_launch_collect(int n_pairs, int first_pair, int *status, int *count, int *map, int cap, hipStream_t stream);
 extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *status, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
@@ -105,7 +105,7 @@ struct Slice {
 	size_t cap_pairs = 0, n_pairs = 0, first_pair = 0;
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
 	DevBuf<Intv> d_intv, d_lists;
-	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n;
+	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo;
 	DevBuf<DevReg> d_regs;
 	DevBuf<uint8_t> d_slabs, d_park[2];   // d_park: K1's parked machines, ping-pong between the launches of a series
 	DevBuf<DevAln> d_alns;
@@ -118,7 +118,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release();
+		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 		if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -195,6 +195,8 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_alns.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_cigars.alloc(n_reads * (size_t)s.dopts.cig_cap));
 	HIPCHK(e, s.d_cig_n.alloc(n_reads));
+	HIPCHK(e, s.d_kdone.alloc(n_reads));
+	HIPCHK(e, s.d_todo.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
 	if (e->watchdog_s > 0 && !getenv("EMA_WATCHDOG_NOMARK")) {
@@ -443,9 +445,9 @@ static int run_pair(ema_engine *e, Slice &s, const Work &w)
 
 static int run_final(ema_engine *e, Slice &s, const Work &w)
 {
-	ema_launch_final(&e->dix, &s.dopts, e->d_bases.p, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_alns.p,
-	                 s.d_cigars.p, s.d_cig_n.p, s.dopts.cig_cap, s.d_status.p, s.d_slabs.p, s.d_counters.p + 2, e->final_blocks,
-	                 s.stream, s.dbg);
+	ema_launch_final(&e->dix, &s.dopts, e->d_bases.p, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_alns.p,
+	                 s.d_cigars.p, s.d_cig_n.p, s.dopts.cig_cap, s.d_status.p, s.d_kdone.p, s.d_todo.p, s.d_counters.p + 20, s.d_slabs.p,
+	                 s.d_counters.p + 2, e->final_blocks, s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_final");
 	return EMA_OK;

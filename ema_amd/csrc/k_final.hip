@@ -33,12 +33,102 @@ __device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q,
 
 }  // namespace
 
+// K4a: the gap-free regions, ONE LANE PER READ.  Most regions of most reads take bwa_gen_cigar2's gap-free path
+// (query and reference span of equal length, inferred band 0): the CIGAR is a single M run plus clips and NM is a
+// mismatch count -- a few hundred scalar operations, which a whole wavefront per read (K4b below) issues 64 wide.
+// Here every lane walks its own read's regions in order for as long as they are gap-free, comparing the packed
+// query with the packed reference directly in HBM; at the first region that needs the dynamic program it stops,
+// leaves `k_done[read]` = that region's index and the CIGAR pool's fill in cig_n[read], and puts the read on the
+// todo list of K4b, which finishes it.
+// qpack: K1's packed reads (16 words of 2-bit codes + 8 words of N mask per read).
+__global__ void __launch_bounds__(256)
+ema_k_final_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
+                   const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
+                   const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
+                   uint32_t *__restrict__ cigars, int *__restrict__ cig_n, int cig_cap, int *__restrict__ status,
+                   int *__restrict__ k_done, int *__restrict__ todo, int *__restrict__ n_todo)
+{
+	const int read = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (read >= ema_work_count(n_reads, n_pairs_dev, 2)) return;
+	const int nr = (status[read] | status[read ^ 1]) ? 0 : n_regs[read];      // flagged pairs are redone by the full-capacity tier
+	int pool_n = 0, st = 0, k = 0;
+	if (nr > 0) {
+		const int in_read = ema_in_read(map, read);
+		const int l_query = (int)(off[in_read + 1] - off[in_read]);
+		const uint32_t *qp = qpack + (size_t)in_read * 24;
+		const int64_t l_pac = ix.l_pac;
+		uint32_t *pool = cigars + (size_t)read * cig_cap;
+		for (; k < nr; ++k) {
+			const DevReg ar = regs[(size_t)read * opt.reg_cap + k];
+			DevAln out;
+			out.pos = -1; out.is_rev = 0; out.NM = -1; out.n_cigar = 0; out.cigar_off = (uint32_t)pool_n;
+			const int qb = ar.qb, qe = ar.qe, lq = qe - qb;
+			const int64_t rb = ar.rb, re = ar.re;
+			const int rlen = (int)(re - rb);
+			const bool ok = lq > 0 && rb < re && !(rb < l_pac && re > l_pac) && rb >= 0 && re <= l_pac << 1 && rlen <= EMA_RSEQ_CAP;
+			if (!ok) { if (rlen > EMA_RSEQ_CAP) st |= EMA_ST_RSEQ_OVERFLOW; alns[(size_t)read * opt.reg_cap + k] = out; continue; }
+			int w2 = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_del, opt.e_del);
+			{
+				const int t = infer_bw(lq, rlen, ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+				w2 = w2 > t ? w2 : t;
+			}
+			if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+			if (!(lq == rlen && w2 == 0)) break;      // needs the dynamic program: K4b takes over from here
+			// NM = positions where the read differs from the reference (an ambiguous read base always differs).  On the
+			// reverse strand the reference is the complement of the forward strand read from the far end.
+			int nm = 0;
+			{
+				const bool rs = rb >= l_pac;
+				int64_t f = rs ? (l_pac << 1) - 1 - rb : rb;      // forward-strand coordinate of reference base j = 0
+				uint32_t qw = 0, nw = 0, pw = 0;
+				int64_t pw_at = -1;
+				int qw_at = -1, nw_at = -1;
+				for (int j = 0; j < lq; ++j, f += rs ? -1 : 1) {
+					const int i = qb + j;
+					if ((i >> 4) != qw_at) { qw_at = i >> 4; qw = qp[qw_at]; }
+					if ((i >> 5) != nw_at) { nw_at = i >> 5; nw = qp[16 + nw_at]; }
+					if ((f >> 4) != pw_at) { pw_at = f >> 4; pw = *reinterpret_cast<const uint32_t *>(ix.pac + (pw_at << 2)); }
+					const uint32_t code = (qw >> ((i & 15) << 1)) & 3;
+					const uint32_t b = (pw >> ((((uint32_t)f >> 2) & 3) << 3) >> ((~(uint32_t)f & 3) << 1)) & 3;
+					nm += (int)(((nw >> (i & 31)) & 1) | (code != (rs ? 3 - b : b)));
+				}
+			}
+			out.NM = nm;
+			const int is_rev = (rb < l_pac ? rb : re - 1) >= l_pac;
+			const int64_t pos = is_rev ? (l_pac << 1) - 1 - (re - 1) : rb;
+			out.is_rev = is_rev;
+			const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+			const int n_final = (clip5 ? 1 : 0) + 1 + (clip3 ? 1 : 0);
+			if (pool_n + n_final > cig_cap) st |= EMA_ST_CIGAR_OVERFLOW;
+			else {
+				uint32_t *dst = pool + pool_n;
+				int o = 0;
+				if (clip5) dst[o++] = (uint32_t)clip5 << 4 | 3;
+				dst[o++] = (uint32_t)lq << 4;
+				if (clip3) dst[o++] = (uint32_t)clip3 << 4 | 3;
+				out.n_cigar = n_final;
+				pool_n += n_final;
+			}
+			const int rid = ema_pos2rid(ix, pos);
+			out.pos = rid >= 0 ? pos - ix.ctg_off[rid] : pos;
+			alns[(size_t)read * opt.reg_cap + k] = out;
+		}
+	}
+	cig_n[read] = pool_n;
+	k_done[read] = k;
+	if (st) atomicOr(status + read, st);
+	if (k < nr) todo[atomicAdd(n_todo, 1)] = read;
+}
+
+// K4b: the regions K4a left (one wavefront per read of its todo list).
 // alns: n_reads x opt.reg_cap; cigars: n_reads x cig_cap ops (pool per read, regions in order)
 __global__ void __launch_bounds__(256)
 ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
             uint32_t *__restrict__ cigars, int *__restrict__ cig_n, int cig_cap, int *__restrict__ status,
+            const int *__restrict__ k_done, const int *__restrict__ todo, const int *__restrict__ n_todo,
             uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
 {
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
@@ -56,18 +146,18 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
-		if (read >= ema_work_count(n_reads, n_pairs_dev, 2)) break;
+		if (read >= *n_todo) break;
+		read = ema_uni(todo[read]);
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		const int in_read = ema_uni(ema_in_read(map, read));
 		const int l_query = (int)(off[in_read + 1] - off[in_read]);
-		const int nr = ema_uni((status[read] | status[read ^ 1]) ? 0 : n_regs[read]);      // flagged pairs are redone by the full-capacity tier
-		if (nr == 0) { if (lane == 0) cig_n[read] = 0; EMA_DBG(9, 0); continue; }
+		const int nr = ema_uni(n_regs[read]);
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
 		ema_wave_sync();
 		uint32_t *pool = cigars + (size_t)read * cig_cap;
-		int pool_n = 0, st = 0;
-		for (int k = 0; k < nr; ++k) {
+		int pool_n = ema_uni(cig_n[read]), st = 0;
+		for (int k = ema_uni(k_done[read]); k < nr; ++k) {
 			EMA_DBG(2, k);
 			const DevReg ar = ema_uni(regs[(size_t)read * opt.reg_cap + k]);
 			DevAln out;
@@ -224,14 +314,18 @@ extern "C" void ema_launch_collect(int n_pairs, int first_pair, int *status, int
 
 extern "C" size_t ema_final_slab_bytes() { return EMA_FINAL_SLAB_BYTES; }
 
-extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
+// K4 = K4a (gap-free regions, one lane per read) then K4b (the rest, one wavefront per read).  kdone / todo: n_reads ints
+// each; n_todo: one int, zero on entry.
+extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *qpack, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
-                                 DevAln *alns, uint32_t *cigars,
-                                 int *cig_n, int cig_cap, int *status, uint8_t *slabs, int *counter, int n_blocks,
-                                 hipStream_t stream, int *dbg)
+                                 DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, int *kdone, int *todo, int *n_todo,
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg)
 {
+	if (n_reads <= 0) return;
+	hipLaunchKernelGGL(ema_k_final_simple, dim3((n_reads + 255) / 256), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map,
+	                   regs, n_regs, alns, cigars, cig_n, cig_cap, status, kdone, todo, n_todo);
 	hipLaunchKernelGGL(ema_k_final, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, regs, n_regs, alns,
-	                   cigars, cig_n, cig_cap, status, slabs, counter, dbg);
+	                   cigars, cig_n, cig_cap, status, kdone, todo, n_todo, slabs, counter, dbg);
 }
 
 extern "C" size_t ema_sizeof_aln() { return sizeof(DevAln); }

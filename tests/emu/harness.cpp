@@ -154,8 +154,11 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, nullptr, nullptr, (DevReg *)regs,
 		                n_regs, status, slabs.data(), &counter[1], 1, nullptr, nullptr);
 	if (upto >= 4)
-		ema_launch_final(&di, &d, bases, off, n_reads, nullptr, nullptr, (DevReg *)regs, n_regs, (DevAln *)alns, cigars, cig_n, EMU_CIG_CAP, status,
-		                 slabs.data(), &counter[2], 1, nullptr, nullptr);
+	{
+		std::vector<int> kdone(n_reads), todo(n_reads); int n_todo = 0;
+		ema_launch_final(&di, &d, bases, qp.data(), off, n_reads, nullptr, nullptr, (DevReg *)regs, n_regs, (DevAln *)alns, cigars, cig_n, EMU_CIG_CAP, status,
+		                 kdone.data(), todo.data(), &n_todo, slabs.data(), &counter[2], 1, nullptr, nullptr);
+	}
 	return EMU_CIG_CAP;
 }
 
@@ -185,8 +188,9 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	                 t.status.data(), slabs.data(), &counter[0], 1, nullptr, nullptr, nullptr);
 	ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_pairs, n_dev, map, t.regs.data(),
 	                t.n_regs.data(), t.status.data(), slabs.data(), &counter[1], 1, nullptr, nullptr);
-	ema_launch_final(&di, &d, bases, off, 2 * n_pairs, n_dev, map, t.regs.data(), t.n_regs.data(), t.alns.data(), t.cigars.data(),
-	                 t.cig_n.data(), d.cig_cap, t.status.data(), slabs.data(), &counter[2], 1, nullptr, nullptr);
+	std::vector<int> kdone(2 * n_pairs), todo(2 * n_pairs); int n_todo = 0;
+	ema_launch_final(&di, &d, bases, qp, off, 2 * n_pairs, n_dev, map, t.regs.data(), t.n_regs.data(), t.alns.data(), t.cigars.data(),
+	                 t.cig_n.data(), d.cig_cap, t.status.data(), kdone.data(), todo.data(), &n_todo, slabs.data(), &counter[2], 1, nullptr, nullptr);
 }
 
 // The engine's two capacity tiers on host memory: lean tier with the given capacities, ema_k_collect, full tier over the

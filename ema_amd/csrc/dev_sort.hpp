@@ -11,10 +11,16 @@
 #define EMA_DEV_SORT_HPP
 
 #include "dev_common.hpp"
+#include <type_traits>
+#include <utility>
 
-template <typename T, typename LT>
-__device__ inline void ema_insertsort(T *a, int s, int t, LT lt)   // [s, t)
+// The sorts take any array-like `A` with a[i] and a + k: a plain pointer, or a lane-interleaved view (k_align_lane.hip).
+#define EMA_ELEM(A) typename std::remove_cv<typename std::remove_reference<decltype((*(A *)nullptr)[0])>::type>::type
+
+template <typename A, typename LT>
+__device__ inline void ema_insertsort(A a, int s, int t, LT lt)   // [s, t)
 {
+	using T = EMA_ELEM(A);
 	for (int i = s + 1; i < t; ++i)
 		for (int j = i; j > s; --j) {
 			const T x = a[j], y = a[j - 1];
@@ -23,9 +29,10 @@ __device__ inline void ema_insertsort(T *a, int s, int t, LT lt)   // [s, t)
 		}
 }
 
-template <typename T, typename LT>
-__device__ inline void ema_combsort(T *a, int n, LT lt)
+template <typename A, typename LT>
+__device__ inline void ema_combsort(A a, int n, LT lt)
 {
+	using T = EMA_ELEM(A);
 	const double shrink = 1.2473309501039786540366528676643;
 	int gap = n;
 	bool swapped;
@@ -45,9 +52,10 @@ __device__ inline void ema_combsort(T *a, int n, LT lt)
 }
 
 // stack: 3 ints per frame, at least 3 * (2*32 + 2) ints
-template <typename T, typename LT>
-__device__ inline void ema_introsort(T *a, int n, LT lt, int *stack)
+template <typename A, typename LT>
+__device__ inline void ema_introsort(A a, int n, LT lt, int *stack)
 {
+	using T = EMA_ELEM(A);
 	if (n < 1) return;
 	if (n == 2) {
 		const T x = a[1], y = a[0];

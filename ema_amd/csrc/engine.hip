@@ -37,8 +37,14 @@ extern "C" size_t ema_seed_park_bytes();
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
-                                 DevReg *regs, int *n_regs, int *status, uint8_t *slabs, int *counter, int n_blocks,
-                                 hipStream_t stream, int *dbg, unsigned long long *prof);
+                                 DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, uint8_t *slabs, int *counter,
+                                 int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof);
+extern "C" size_t ema_align_lane_wave_bytes();
+extern "C" int ema_align_simple_blocks_per_cu();
+extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
+                                        const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
+                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int n_blocks,
+                                        hipStream_t stream, unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" int ema_align_blocks_per_cu();
 extern "C" int ema_pair_blocks_per_cu();
@@ -153,7 +159,8 @@ struct ema_engine {
 	bool staged = false, ran = false, ever_ran = false;
 	std::vector<uint8_t> h_nt4;
 	std::vector<uint32_t> h_off, h_qpack;
-	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0;
+	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
+	bool lane_align = false;             // EMA_LANE_ALIGN=1: small reads through K2a (one lane per read) first -- slower today, see k_align_lane.hip
 	int seed_rounds = 6, seed_park_max = 0;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
 	int dbg_slots = 0;
@@ -191,6 +198,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
 	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
 	if ((size_t)e->final_blocks * 4 * ema_final_slab_bytes() > slab) slab = (size_t)e->final_blocks * 4 * ema_final_slab_bytes();
+	if ((size_t)e->lane_blocks * ema_align_lane_wave_bytes() > slab) slab = (size_t)e->lane_blocks * ema_align_lane_wave_bytes();
 	HIPCHK(e, s.d_slabs.alloc(slab));
 	HIPCHK(e, s.d_alns.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_cigars.alloc(n_reads * (size_t)s.dopts.cig_cap));
@@ -245,7 +253,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
 
-	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(16)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 128)); }
+	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256)); }
 	if (const char *wd = getenv("EMA_WATCHDOG_S")) { e->watchdog_s = atof(wd); e->dbg_slots = e->n_cu * 8 * 4 + 64; }
 	if (const char *v = getenv("EMA_SEED_ROUNDS")) e->seed_rounds = std::max(1, std::min(8, atoi(v)));
 	if (const char *v = getenv("EMA_SEED_PARK")) e->seed_park_max = std::max(0, std::min(63, atoi(v)));
@@ -254,6 +262,8 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->align_blocks = e->n_cu * ema_align_blocks_per_cu();    // one scratch slab per resident wave
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
+	e->lane_blocks = e->n_cu * ema_align_simple_blocks_per_cu();
+	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
 	if (n_streams > 16) n_streams = 16;
@@ -426,8 +436,16 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 
 static int run_align(ema_engine *e, Slice &s, const Work &w)
 {
+	// K2a: small reads, one lane each; the others land on the todo list that K2b (one wavefront per read) works through
+	if (e->lane_align) {
+		ema_launch_align_simple(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21, e->lane_blocks,
+		                        s.stream, e->d_prof.p);
+		HIPCHK(e, hipGetLastError());
+	}
 	ema_launch_align(&e->dix, &s.dopts, e->d_bases.p, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
-	                 s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 0, e->align_blocks, s.stream, s.dbg, e->d_prof.p);
+	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_slabs.p, s.d_counters.p + 0,
+	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_align");
 	return EMA_OK;
@@ -528,13 +546,16 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 {
 	if (!e || !t) return EMA_EARG;
 	if (e->d_prof.p) {
-		unsigned long long h[16];
-		if (hipMemcpy(h, e->d_prof.p, 128, hipMemcpyDeviceToHost) == hipSuccess) {
+		unsigned long long h[32];
+		if (hipMemcpy(h, e->d_prof.p, 256, hipMemcpyDeviceToHost) == hipSuccess) {
+			fprintf(stderr, "K2a phase ticks (idle, fetch/stage, chain, filter, chain2aln-ctl, extend-dp, dedup):");
+			for (int i = 0; i < 7; ++i) fprintf(stderr, " %llu", h[16 + i]);
+			fprintf(stderr, "\n");
 			fprintf(stderr, "K2 phase ticks (idle/fetch, chain, filter, chain2aln-ctl, extend-dp, dedup):");
 			for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", h[i]);
 			fprintf(stderr, "\nK1: wave-ticks %llu, active lane-ticks %llu (%.1f lanes/tick), clocks per wave-tick %.0f, longest wave %llu ticks\n", h[8], h[9],
 			        h[8] ? (double)h[9] / h[8] : 0., h[8] ? (double)h[10] / h[8] : 0., h[11]);
-			(void)hipMemset(e->d_prof.p, 0, 128);
+			(void)hipMemset(e->d_prof.p, 0, 256);
 		}
 	}
 	*t = e->timing;

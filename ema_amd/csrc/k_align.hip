@@ -1,4 +1,5 @@
-// ema_amd/csrc/k_align.hip -- K2: seeds -> chains -> extended, de-duplicated regions, one wavefront per read.
+// ema_amd/csrc/k_align.hip -- K2b: seeds -> chains -> extended, de-duplicated regions, one wavefront per read, for the
+// reads K2a (k_align_lane.hip, one lane per read) left on its todo list: the ones with many seed occurrences or regions.
 //
 // Replaces, for a batch, everything mem_align1_core does after seeding (un-vendored bwa, reached from
 // reference src/bwabridge.c:236-237): bwt_sa for every seed occurrence, mem_chain (chaining through a sorted
@@ -202,8 +203,8 @@ __global__ void __launch_bounds__(256, 4)
 ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
-            int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg,
-            unsigned long long *prof)
+            int *__restrict__ status, const int *__restrict__ todo, const int *__restrict__ n_todo,
+            uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg, unsigned long long *prof)
 {
 	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
 	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -229,7 +230,8 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
-		if (read >= ema_work_count(n_reads, n_pairs_dev, 2)) break;
+		if (read >= (todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2))) break;
+		if (todo) read = ema_uni(todo[read]);
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		EMA_PHASE(1);
@@ -537,11 +539,11 @@ extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
+                                 const int *todo, const int *n_todo, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
                                  unsigned long long *prof)
 {
 	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
-	                   n_regs, status, slabs, counter, dbg, prof);
+	                   n_regs, status, todo, n_todo, slabs, counter, dbg, prof);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -10,6 +10,7 @@
 #include "k_seed.hip"
 #include "k_dp_test.hip"
 #include "k_align.hip"
+#include "k_align_lane.hip"
 #include "k_pair.hip"
 #include "k_final.hip"
 
@@ -34,6 +35,26 @@ static std::vector<uint32_t> pack_reads(const uint8_t *bases, const uint32_t *of
 			if (b > 3) q[(size_t)r * 24 + 16 + (i >> 5)] |= 1u << (i & 31);
 		}
 	return q;
+}
+
+// K2 as the engine runs it: K2a (one lane per read) for the small reads, then K2b (one wavefront per read) over K2a's
+// todo list.  EMU_LANE_ALIGN=0 sends every read through K2b.
+static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *bases, const uint32_t *qp, const uint32_t *off, int n_reads,
+                          const int *n_dev, const int *map, Intv *intv, int *n_intv, DevReg *regs, int *n_regs, int *status,
+                          uint8_t *slabs, int n_blocks)
+{
+	const char *v = getenv("EMU_LANE_ALIGN");
+	const bool lane = !v || atoi(v) != 0;
+	std::vector<int> todo(n_reads + 1);
+	int n_todo = 0, c0 = 0, c1 = 0;
+	if (lane) {
+		std::vector<uint8_t> scratch((size_t)n_blocks * ema_align_lane_wave_bytes());
+		ema_launch_align_simple(&di, &d, qp, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, scratch.data(), &c0, todo.data(),
+		                        &n_todo, n_blocks, nullptr, nullptr);
+		fprintf(stderr, "emu K2a: %d of %d reads left for K2b\n", n_todo, n_reads);
+	}
+	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, slabs,
+	                 &c1, n_blocks, nullptr, nullptr, nullptr);
 }
 
 extern "C" {
@@ -122,8 +143,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
-	ema_launch_align(&di, &d, bases, off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
-	                 &counter, n_blocks, nullptr, nullptr, nullptr);
+	emu_run_align(di, d, bases, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(), n_blocks);
 	return EMU_REG_CAP;
 }
 int emu_sizeof_reg() { return (int)sizeof(DevReg); }
@@ -148,8 +168,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[3] = {0, 0, 0};
-	ema_launch_align(&di, &d, bases, off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(),
-	                 &counter[0], 1, nullptr, nullptr, nullptr);
+	emu_run_align(di, d, bases, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(), 1);
 	if (upto >= 3)
 		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, nullptr, nullptr, (DevReg *)regs,
 		                n_regs, status, slabs.data(), &counter[1], 1, nullptr, nullptr);
@@ -184,8 +203,8 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[4] = {0, 0, 0, 0};
 	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
-	ema_launch_align(&di, &d, bases, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(),
-	                 t.status.data(), slabs.data(), &counter[0], 1, nullptr, nullptr, nullptr);
+	emu_run_align(di, d, bases, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(), t.status.data(),
+	              slabs.data(), 1);
 	ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_pairs, n_dev, map, t.regs.data(),
 	                t.n_regs.data(), t.status.data(), slabs.data(), &counter[1], 1, nullptr, nullptr);
 	std::vector<int> kdone(2 * n_pairs), todo(2 * n_pairs); int n_todo = 0;

@@ -41,7 +41,7 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
                                  int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof);
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
-extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
+extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int n_blocks,
                                         hipStream_t stream, unsigned long long *prof);
@@ -160,7 +160,7 @@ struct ema_engine {
 	std::vector<uint8_t> h_nt4;
 	std::vector<uint32_t> h_off, h_qpack;
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
-	bool lane_align = false;             // EMA_LANE_ALIGN=1: small reads through K2a (one lane per read) first -- slower today, see k_align_lane.hip
+	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	int seed_rounds = 6, seed_park_max = 0;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
 	int dbg_slots = 0;
@@ -198,7 +198,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
 	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
 	if ((size_t)e->final_blocks * 4 * ema_final_slab_bytes() > slab) slab = (size_t)e->final_blocks * 4 * ema_final_slab_bytes();
-	if ((size_t)e->lane_blocks * ema_align_lane_wave_bytes() > slab) slab = (size_t)e->lane_blocks * ema_align_lane_wave_bytes();
+	if ((size_t)e->lane_blocks * 4 * ema_align_lane_wave_bytes() > slab) slab = (size_t)e->lane_blocks * 4 * ema_align_lane_wave_bytes();
 	HIPCHK(e, s.d_slabs.alloc(slab));
 	HIPCHK(e, s.d_alns.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_cigars.alloc(n_reads * (size_t)s.dopts.cig_cap));
@@ -438,7 +438,7 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 {
 	// K2a: small reads, one lane each; the others land on the todo list that K2b (one wavefront per read) works through
 	if (e->lane_align) {
-		ema_launch_align_simple(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+		ema_launch_align_simple(&e->dix, &s.dopts, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21, e->lane_blocks,
 		                        s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());

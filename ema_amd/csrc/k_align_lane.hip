@@ -1,25 +1,24 @@
-// ema_amd/csrc/k_align_lane.hip -- K2a: seeds -> chains -> extended, de-duplicated regions, ONE LANE PER READ.
+// ema_amd/csrc/k_align_lane.hip -- K2a: seeds -> chains -> regions for the reads that need NO extension, ONE LANE PER READ.
 //
 // Same stage as k_align.hip (bwa's mem_align1_core after seeding, reached from reference src/bwabridge.c:236-237:
-// bwt_sa, mem_chain, mem_chain_flt, mem_chain2aln, mem_sort_dedup_patch), for the reads that are small: at most
-// EMA_LANE_SEEDS seed occurrences, a handful of regions, no region pair that needs mem_patch_reg's global alignment.
-// That is ~9 reads in 10, and for them the per-read control program is a few thousand scalar operations; a whole
-// wavefront per read (K2b) issues every one of them 64 wide.  Here every lane runs the sequential algorithm for its own
-// read -- chaining through a small sorted table, klib's introsort, the banded extension row by row exactly as
-// ksw_extend2 does it (so its adaptive band needs no special treatment) -- on lane-interleaved scratch arrays in HBM
-// (element e of a lane's array lives at [e * 64 + lane]: the 64 lanes of a wave touch one contiguous run per element).
-// The DP's H/E row, which every cell reads and writes, sits in LDS (16 bit each, one word per column and lane): in HBM
-// every cell would cost a dependent memory round trip.  That is 39 KB per wave, so a block is one wave and a CU holds
-// three; the kernel is bound by its own dependent chain per lane, not by instruction issue, and runs next to the
-// other kernels' waves.  A read that turns out not to be small is left untouched and put on the todo list of K2b.
+// bwt_sa, mem_chain, mem_chain_flt, mem_chain2aln, mem_sort_dedup_patch).  Nearly half of the reads of a typical
+// bucket match the reference exactly: their longest seed spans the whole read, mem_chain2aln extends nothing, and what
+// is left per read is a few hundred scalar operations (chaining a handful of seed occurrences through a small sorted
+// table, the chain filter with klib's introsort, the "already covered" tests, de-duplication).  A whole wavefront per
+// read (K2b) issues every one of them 64 wide; here every lane runs the sequential algorithm for its own read, on
+// lane-interleaved scratch arrays in HBM (element e of a lane's array lives at [e * 64 + lane]).  A read that turns out
+// to need a banded extension, a region merge test, or more room than the small tables have is left untouched and put on
+// the todo list of K2b.
+// (Measured dead end, kept out: running the extension DP per lane as well.  With the H/E row in HBM every cell is a
+// dependent memory round trip; with the row in LDS it is 39 KB per wave, three waves per CU, ~1000 clocks per cell
+// step, and -- lanes of a wave running the longest band and the most rows among their 64 reads -- barely fewer
+// instructions per read than the row-parallel wave DP.)
 #include <hip/hip_runtime.h>
 #include "dev_regions.hpp"
 
 #define EMA_LANE_INTV 24        // seed intervals of a small read
 #define EMA_LANE_SEEDS 32       // seed occurrences (and therefore chains)
 #define EMA_LANE_REGS 12        // regions before de-duplication
-#define EMA_LANE_READ 150       // longest read K2a takes
-#define EMA_LANE_EH (EMA_LANE_READ + 2)      // DP columns
 
 namespace {
 
@@ -27,15 +26,6 @@ template <typename T> struct LaneArr {      // element e of this lane's array at
 	T *p;
 	__device__ __forceinline__ T &operator[](int e) const { return p[(size_t)e << 6]; }
 	__device__ __forceinline__ LaneArr operator+(int k) const { return LaneArr{p + ((size_t)k << 6)}; }
-};
-
-struct LaneEH { int32_t h, e; };
-// the H/E row of the extension DP in LDS: column j of this lane at w[j * 64], h in the low and e in the high half
-// (both are non-negative and below 2^15 for reads of this length)
-struct LaneEHRow {
-	uint32_t *w;
-	__device__ __forceinline__ LaneEH get(int j) const { const uint32_t v = w[j << 6]; LaneEH r; r.h = (int)(v & 0xffffu); r.e = (int)(v >> 16); return r; }
-	__device__ __forceinline__ void put(int j, const LaneEH &v) const { w[j << 6] = (uint32_t)v.h | (uint32_t)v.e << 16; }
 };
 
 struct LaneScratch {
@@ -78,96 +68,6 @@ __device__ __forceinline__ int lane_max_gap(const DevOpts &o, int qlen)
 	int l = l_del > l_ins ? l_del : l_ins;
 	l = l > 1 ? l : 1;
 	return l < o.w << 1 ? l : o.w << 1;
-}
-
-// the read of this lane, staged in LDS as K1 does: 16 words of 2-bit codes + 8 words of N mask, lane-interleaved
-struct LaneQuery {
-	const uint32_t *qw, *nm;
-	__device__ __forceinline__ int at(int i) const
-	{
-		const int code = (qw[(i >> 4) << 6] >> ((i & 15) << 1)) & 3;
-		return ((nm[(i >> 5) << 6] >> (i & 31)) & 1) ? 4 : code;
-	}
-};
-
-struct LaneExt { int score, qle, tle, gtle, gscore, max_off; };
-
-// ksw_extend2, one lane, row by row as bwa does it.  Query base j is q.at(q0 + j * qstep); target base i is the
-// reference base at forward-reverse coordinate t0 + i * tstep.
-__device__ inline LaneExt lane_extend(const DevIndex &ix, const DevOpts &o, const LaneQuery &q, int qlen, int q0, int qstep, int tlen,
-                                      int64_t t0, int tstep, int w, int end_bonus, int zdrop, int h0, const LaneEHRow &eh)
-{
-	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
-	for (int j = 0; j <= qlen; ++j) { LaneEH z; z.h = 0; z.e = 0; eh.put(j, z); }
-	{
-		LaneEH z; z.e = 0;
-		z.h = h0; eh.put(0, z);
-		int prev = h0 > oe_ins ? h0 - oe_ins : 0;
-		z.h = prev; eh.put(1, z);
-		for (int j = 2; j <= qlen && prev > e_ins; ++j) { prev -= e_ins; z.h = prev; eh.put(j, z); }
-	}
-	{
-		const int mx = o.a > 0 ? o.a : 0;
-		int max_ins = (int)((double)(qlen * mx + end_bonus - o.o_ins) / e_ins + 1.);
-		max_ins = max_ins > 1 ? max_ins : 1;
-		w = w < max_ins ? w : max_ins;
-		int max_del = (int)((double)(qlen * mx + end_bonus - o.o_del) / e_del + 1.);
-		max_del = max_del > 1 ? max_del : 1;
-		w = w < max_del ? w : max_del;
-	}
-	int mx_sc = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-	int beg = 0, end = qlen;
-	for (int i = 0; i < tlen; ++i) {
-		const int tb = ema_ref_base(ix, t0 + (int64_t)i * tstep);
-		int f = 0, h1, m = 0, mj = -1;
-		if (beg < i - w) beg = i - w;
-		if (end > i + w + 1) end = i + w + 1;
-		if (end > qlen) end = qlen;
-		if (beg == 0) { h1 = h0 - (o.o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
-		else h1 = 0;
-		int j;
-		for (j = beg; j < end; ++j) {
-			const LaneEH p = eh.get(j);
-			int M = p.h, e = p.e;
-			M = M ? M + ema_score(o, tb, q.at(q0 + j * qstep)) : 0;
-			int h = M > e ? M : e;
-			h = h > f ? h : f;
-			LaneEH nw; nw.h = h1;
-			h1 = h;
-			mj = m > h ? mj : j;
-			m = m > h ? m : h;
-			int t = M - oe_del; t = t > 0 ? t : 0;
-			e -= e_del; e = e > t ? e : t;
-			nw.e = e;
-			eh.put(j, nw);
-			t = M - oe_ins; t = t > 0 ? t : 0;
-			f -= e_ins; f = f > t ? f : t;
-		}
-		{ LaneEH z; z.h = h1; z.e = 0; eh.put(end, z); }
-		if (j == qlen) {
-			max_ie = gscore > h1 ? max_ie : i;
-			gscore = gscore > h1 ? gscore : h1;
-		}
-		if (m == 0) break;
-		if (m > mx_sc) {
-			mx_sc = m; max_i = i; max_j = mj;
-			const int off = mj - i < 0 ? i - mj : mj - i;
-			max_off = max_off > off ? max_off : off;
-		} else if (zdrop > 0) {
-			if (i - max_i > mj - max_j) {
-				if (mx_sc - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
-			} else {
-				if (mx_sc - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
-			}
-		}
-		for (j = beg; j < end; ++j) { if (eh.w[j << 6] != 0) break; }
-		beg = j;
-		for (j = end; j >= beg; --j) { if (eh.w[j << 6] != 0) break; }
-		end = j + 2 < qlen ? j + 2 : qlen;
-	}
-	LaneExt r;
-	r.score = mx_sc; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
-	return r;
 }
 
 // mem_chain's loop body for one seed (test_and_merge, or a new chain right after the element the lookup returned)
@@ -312,8 +212,8 @@ __device__ inline int lane_sort_dedup(const DevIndex &ix, const DevOpts &o, int 
 
 // One lane = one read; a wave takes 64 consecutive reads at a time from the shared counter.
 // todo / n_todo: reads left for K2b (n_todo zero on entry).  scratch: EMA_LANE_WAVE_BYTES per resident wave.
-__global__ void __launch_bounds__(64)
-ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
+__global__ void __launch_bounds__(256)
+ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ off, int n_reads,
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,
                    uint8_t *__restrict__ scratch, int *__restrict__ counter, int *__restrict__ todo, int *__restrict__ n_todo,
@@ -323,16 +223,9 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
 	int phase = 0;
 #define EMA_PHASE(idx) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc[phase] += t_now - t_prev; t_prev = t_now; phase = (idx); } } while (0)
-	__shared__ uint32_t lds_q[1][16 * 64];
-	__shared__ uint32_t lds_n[1][8 * 64];
-	__shared__ uint32_t lds_eh[EMA_LANE_EH * 64];
-	const int lane = (int)(threadIdx.x & 63), wib = 0;
-	const size_t wave = (size_t)blockIdx.x;
+	const int lane = (int)(threadIdx.x & 63);
+	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const LaneScratch s = lane_carve(scratch + wave * EMA_LANE_WAVE_BYTES, lane);
-	LaneQuery q;
-	q.qw = lds_q[wib] + lane; q.nm = lds_n[wib] + lane;
-	LaneEHRow ehrow;
-	ehrow.w = lds_eh + lane;
 	const int n_total = ema_work_count(n_reads, n_pairs_dev, 2);
 	const int64_t l_pac = ix.l_pac;
 	int stack[3 * 12];      // introsort frames: ranges above 16 elements only, so a 32-element sort needs a couple
@@ -350,24 +243,13 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 		const int l_query = (int)(off[in_read + 1] - off[in_read]);
 		const int n_iv = n_intv[read];
 		const Intv *raw = intv + (size_t)read * opt.intv_cap;
-		bool small = n_iv <= EMA_LANE_INTV && l_query <= EMA_LANE_READ;
+		bool small = n_iv <= EMA_LANE_INTV;
 		if (small) {
 			int64_t tot = 0;
 			for (int i = 0; i < n_iv; ++i) { const uint64_t x2 = raw[i].x2; tot += x2 > 64 ? 64 : (int64_t)x2; }
 			small = tot <= EMA_LANE_SEEDS;      // which also means: no interval above max_occ, frac_rep = 0
 		}
 		if (!small) { todo[atomicAdd(n_todo, 1)] = read; continue; }
-		{   // the read, packed by the host (as in K1)
-			const uint4 *pw = reinterpret_cast<const uint4 *>(qpack + (size_t)in_read * 24);
-			const uint4 a = pw[0], b = pw[1], c = pw[2], d = pw[3], m0 = pw[4], m1 = pw[5];
-			uint32_t *qd = lds_q[wib] + lane, *nd = lds_n[wib] + lane;
-			qd[0 << 6] = a.x; qd[1 << 6] = a.y; qd[2 << 6] = a.z; qd[3 << 6] = a.w;
-			qd[4 << 6] = b.x; qd[5 << 6] = b.y; qd[6 << 6] = b.z; qd[7 << 6] = b.w;
-			qd[8 << 6] = c.x; qd[9 << 6] = c.y; qd[10 << 6] = c.z; qd[11 << 6] = c.w;
-			qd[12 << 6] = d.x; qd[13 << 6] = d.y; qd[14 << 6] = d.z; qd[15 << 6] = d.w;
-			nd[0 << 6] = m0.x; nd[1 << 6] = m0.y; nd[2 << 6] = m0.z; nd[3 << 6] = m0.w;
-			nd[4 << 6] = m1.x; nd[5 << 6] = m1.y; nd[6 << 6] = m1.z; nd[7 << 6] = m1.w;
-		}
 		// intervals in mem_collect_intv's final order: by (start, end); equal keys are identical entries
 		for (int i = 0; i < n_iv; ++i) {
 			const uint64_t mine = raw[i].info;
@@ -492,43 +374,12 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 				if (n_av >= EMA_LANE_REGS) { bail = true; break; }
 				DevReg a;
 				a.sub = a.csub = a.secondary = a.n_comp = a.is_alt = 0; a.seedcov = 0;
-				int aw0 = opt.w, aw1 = opt.w;
+				const int aw0 = opt.w, aw1 = opt.w;
 				a.score = a.truesc = -1;
 				a.rid = c.rid;
-				EMA_PHASE(5);
-				if (sd.qbeg) {     // left extension, both sequences reversed
-					const int tlen = (int)(sd.rbeg - rmax0);
-					LaneExt r; r.score = -1; r.qle = r.tle = r.gtle = 0; r.gscore = -1; r.max_off = 0;
-					for (int i = 0; i < 2; ++i) {        // MAX_BAND_TRY
-						const int prev = a.score;
-						aw0 = opt.w << i;
-						r = lane_extend(ix, opt, q, sd.qbeg, sd.qbeg - 1, -1, tlen, sd.rbeg - 1, -1, aw0, opt.pen_clip5, opt.zdrop, sd.len * opt.a, ehrow);
-						a.score = r.score;
-						if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
-					}
-					if (r.gscore <= 0 || r.gscore <= a.score - opt.pen_clip5) {
-						a.qb = sd.qbeg - r.qle; a.rb = sd.rbeg - r.tle; a.truesc = a.score;
-					} else {
-						a.qb = 0; a.rb = sd.rbeg - r.gtle; a.truesc = r.gscore;
-					}
-				} else { a.score = a.truesc = sd.len * opt.a; a.qb = 0; a.rb = sd.rbeg; }
-				if (sd.qbeg + sd.len != l_query) {     // right extension
-					const int sc0 = a.score, qe = sd.qbeg + sd.len;
-					const int64_t re = sd.rbeg + sd.len;
-					LaneExt r; r.score = -1; r.qle = r.tle = r.gtle = 0; r.gscore = -1; r.max_off = 0;
-					for (int i = 0; i < 2; ++i) {
-						const int prev = a.score;
-						aw1 = opt.w << i;
-						r = lane_extend(ix, opt, q, l_query - qe, qe, 1, (int)(rmax1 - re), re, 1, aw1, opt.pen_clip3, opt.zdrop, sc0, ehrow);
-						a.score = r.score;
-						if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-					}
-					if (r.gscore <= 0 || r.gscore <= a.score - opt.pen_clip3) {
-						a.qe = qe + r.qle; a.re = re + r.tle; a.truesc += a.score - sc0;
-					} else {
-						a.qe = l_query; a.re = re + r.gtle; a.truesc += r.gscore - sc0;
-					}
-				} else { a.qe = l_query; a.re = sd.rbeg + sd.len; }
+				if (sd.qbeg != 0 || sd.qbeg + sd.len != l_query) { bail = true; break; }      // needs ksw_extend2: K2b
+				a.score = a.truesc = sd.len * opt.a; a.qb = 0; a.rb = sd.rbeg;
+				a.qe = l_query; a.re = sd.rbeg + sd.len;
 				EMA_PHASE(4);
 				{   // seedcov: seeds of the chain fully inside the region
 					int cov = 0;
@@ -558,20 +409,20 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 #undef EMA_PHASE
 }
 
-extern "C" size_t ema_align_lane_wave_bytes() { return EMA_LANE_WAVE_BYTES; }      // per block: a block is one wave
+extern "C" size_t ema_align_lane_wave_bytes() { return EMA_LANE_WAVE_BYTES; }
 
 extern "C" int ema_align_simple_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_simple, 64, 0) != hipSuccess || n < 1) n = 1;
-	return n > 16 ? 16 : n;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_simple, 256, 0) != hipSuccess || n < 1) n = 1;
+	return n > 8 ? 8 : n;
 }
 
-extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
+extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int n_blocks,
                                         hipStream_t stream, unsigned long long *prof)
 {
-	hipLaunchKernelGGL(ema_k_align_simple, dim3(n_blocks), dim3(64), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
+	hipLaunchKernelGGL(ema_k_align_simple, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, off, n_reads, n_pairs_dev, map, intv,
 	                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, prof);
 }

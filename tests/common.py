@@ -31,3 +31,25 @@ def small_ref(kind="two_contigs"):
     build_index(prefix)
     _CACHE[kind] = (prefix, ctg)
     return _CACHE[kind]
+
+
+def golden_workload():
+    """tests/golden/oracle_regression.json (see make_vectors.py there): the committed workload with its index rebuilt in a
+    temp dir.  Returns (prefix, Pairs, expected intervals per read, expected candidates per pair and mate)."""
+    import json
+    if "golden" not in _CACHE:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_regression.json")
+        with open(path) as f:
+            doc = json.load(f)
+        code = {"A": 0, "C": 1, "G": 2, "T": 3}
+        ctg = [np.array([code[c] for c in s], dtype=np.uint8) for s in doc["contigs"]]
+        d = tempfile.mkdtemp(prefix="ema_golden_")
+        prefix = os.path.join(d, "g.fa")
+        synth.write_fasta(prefix, ctg)
+        build_index(prefix)
+        reads = [r.encode() for r in doc["reads"]]
+        off = np.zeros(len(reads) + 1, np.uint32)
+        off[1:] = np.cumsum([len(r) for r in reads])
+        pairs = synth.Pairs(np.frombuffer(b"".join(reads), dtype=np.uint8), off)
+        _CACHE["golden"] = (prefix, pairs, doc["intervals"], doc["candidates"])
+    return _CACHE["golden"]

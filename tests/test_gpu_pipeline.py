@@ -149,3 +149,21 @@ def test_lean_seeding_budget_sends_long_reads_to_the_full_tier():
     assert batch.status.max() == 0
     assert 50 < batch.n_redone < pairs.n
     assert not compare(prefix, pairs, batch)
+
+
+def test_committed_regression_vectors():
+    """The workload and expected candidate lists of tests/golden/oracle_regression.json, through the C ABI."""
+    from common import golden_workload
+    prefix, pairs, _, candidates = golden_workload()
+    eng = Engine(prefix)
+    batch = eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()
+    assert batch.status.max() == 0
+    for p in range(pairs.n):
+        for m in range(2):
+            got = []
+            for c in batch.mate(p, m):
+                d = {f: (float(c[f]) if f == "frac_rep" else int(c[f])) for f in FIELDS}
+                d.update(pos=int(c["pos"]), is_rev=int(c["is_rev"]), NM=int(c["NM"]), cigar=batch.cigar_of(c).tolist())
+                got.append(d)
+            assert got == candidates[p][m], (p, m)

@@ -212,3 +212,17 @@ def test_pairs_map_back_to_their_origin():
                 right["pos"] + (right["re"] - right["rb"]) == frag + ins:
             ok += 1
     assert ok >= 55
+
+
+def test_oracle_reproduces_the_committed_regression_vectors():
+    """tests/golden/oracle_regression.json freezes the oracle at the point where the GPU path was verified against it
+    (regression vectors -- the reference has none to pin against)."""
+    from common import golden_workload
+    prefix, pairs, intervals, candidates = golden_workload()
+    idx, opt = O.Index(prefix), O.default_opt()
+    for r in range(2 * pairs.n):
+        assert [[int(v) for v in t] for t in O.collect_intv(idx, opt, pairs.read(r))] == intervals[r]
+    for p in range(pairs.n):
+        res = O.align_pair(idx, opt, pairs.read(2 * p), pairs.read(2 * p + 1))
+        got = [[{k: (float(np.float32(v)) if k == "frac_rep" else v) for k, v in c.items()} for c in mate] for mate in res]
+        assert got == candidates[p]

@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400000, help="pairs of the same workload timed on the host CPU")
     ap.add_argument("--streams", type=int, default=0, help="slices of a batch on their own HIP streams (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-capacity-flags", action="store_true", help="print the (invalid) line even if reads overflowed an engine capacity")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,7 +160,10 @@ def main():
     batch = eng.fetch(allow_limit=True)
     if batch.status.max() != 0:
         flags, counts = np.unique(batch.status[batch.status != 0], return_counts=True)
-        log(f"[rank {rank}] WARNING: reads exceeded an engine capacity (status flag: count) {dict(zip(flags.tolist(), counts.tolist()))}")
+        log(f"[rank {rank}] ERROR: reads exceeded an engine capacity (status flag: count) {dict(zip(flags.tolist(), counts.tolist()))}: "
+            f"their pairs have no candidates, so the timed steps skipped work and the number is not valid")
+        if not args.allow_capacity_flags:
+            raise SystemExit(2)
     from ema_amd import shard
     stats_vec = shard.bucket_stats(batch, pairs.n)
     # the "trivial RCCL gather of per-bucket statistics" of the north star: one bucket per rank, O(100 B) over xGMI

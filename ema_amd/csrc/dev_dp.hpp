@@ -2,7 +2,8 @@
 // device functions (gfx950, wave64).
 //
 // All three walk the target row by row and compute one whole DP row per step across the 64 lanes:
-// lane t owns the query columns 4t..4t+3 (EMA_MAX_READ <= 255 columns + the boundary column), and
+// lane t owns NC adjacent query columns (NC = 1..4: the narrowest layout that holds the query; EMA_MAX_READ <= 255
+// columns + the boundary column), and
 // keeps their H and E values in registers from row to row.  Within a row, M and E depend only on the
 // previous row; the horizontal gap state F obeys F(j+1) = max(F(j) - e, T(j)), a max-plus prefix
 // scan, which the wave resolves with a 6-step shuffle scan.  This form is exact (integer max/plus),
@@ -19,7 +20,6 @@
 
 #include "dev_common.hpp"
 
-#define EMA_NC 4                       // query columns per lane
 #define EMA_DP_MINUS_INF (-0x40000000)
 #define EMA_NEG_BIG (-0x7f000000)      // "no element" in max scans; never reached by real values
 
@@ -32,18 +32,11 @@ __device__ __forceinline__ int ema_wave_exscan_max(int v)
 {
 	return ema_wave_shr1(ema_wave_incl_scan_max(v, EMA_NEG_BIG), EMA_NEG_BIG);
 }
-// value of column j's owner (j wave-uniform); vals[c] = this lane's column 4*lane+c
-__device__ __forceinline__ int ema_col_get(const int vals[EMA_NC], int j)
-{
-	const int c = j & (EMA_NC - 1);
-	const int mine = c == 0 ? vals[0] : c == 1 ? vals[1] : c == 2 ? vals[2] : vals[3];
-	return __builtin_amdgcn_readlane(mine, j >> 2);
-}
-
+// value of column j's owner (j wave-uniform); vals[c] = this lane's column NC*lane+c
 template <int NC>
 __device__ __forceinline__ int ema_col_get_nc(const int vals[NC], int j)
 {
-	const int c = j & (NC - 1);
+	const int c = j % NC;
 	int mine = vals[0];
 #pragma unroll
 	for (int k = 1; k < NC; ++k) mine = c == k ? vals[k] : mine;
@@ -253,20 +246,22 @@ __device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq q
 {
 	if (qlen < 64) return ema_wave_extend_nc<1>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
 	if (qlen < 128) return ema_wave_extend_nc<2>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
+	if (qlen < 192) return ema_wave_extend_nc<3>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
 	return ema_wave_extend_nc<4>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
 }
 
 // ksw_global2: banded global alignment of query (columns) against target (rows).
 // z != nullptr: the direction matrix (n_col x tlen bytes, n_col = min(qlen, 2w+1)) is written for traceback.
-__device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
+template <int NC>
+__device__ inline int ema_wave_global_nc(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
 {
 	const int lane = (int)ema_lane();
 	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
 	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-	int hh[EMA_NC], ee[EMA_NC], qb[EMA_NC];
+	int hh[NC], ee[NC], qb[NC];
 #pragma unroll
-	for (int c = 0; c < EMA_NC; ++c) {
-		const int j = lane * EMA_NC + c;
+	for (int c = 0; c < NC; ++c) {
+		const int j = lane * NC + c;
 		int v = EMA_DP_MINUS_INF;
 		if (j == 0) v = 0;
 		else if (j <= qlen && j <= w) v = -(o.o_ins + e_ins * j);
@@ -280,11 +275,11 @@ __device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, 
 		const int beg = i > w ? i - w : 0;
 		const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1_init = beg == 0 ? -(o.o_del + e_del * (i + 1)) : EMA_DP_MINUS_INF;
-		int M[EMA_NC], g[EMA_NC];
+		int M[NC], g[NC];
 		int run = EMA_NEG_BIG;
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j >= beg && j < end;
 			const int m = hh[c] + ema_score(o, tb, qb[c]);
 			M[c] = m;
@@ -292,10 +287,10 @@ __device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, 
 			run = max(run, g[c]);
 		}
 		int pre = ema_wave_exscan_max(run);
-		int h[EMA_NC];
+		int h[NC];
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j >= beg && j < end;
 			// F(i,j) = max(MINUS_INF - (j-beg) e, max_{beg<=k<j} g_k - (j-1) e)
 			int f = EMA_DP_MINUS_INF - (j - beg) * e_ins;
@@ -316,17 +311,26 @@ __device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, 
 			}
 			pre = max(pre, g[c]);
 		}
-		const int up = ema_wave_shr1(h[EMA_NC - 1], 0);
+		const int up = ema_wave_shr1(h[NC - 1], 0);
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j >= beg && j < end;
 			const int left = c == 0 ? up : h[c - 1];
 			if (in) hh[c] = j == beg ? h1_init : left;
 			else if (j == end) { hh[c] = end > beg ? left : h1_init; ee[c] = EMA_DP_MINUS_INF; }
 		}
 	}
-	return ema_col_get(hh, qlen);
+	return ema_col_get_nc<NC>(hh, qlen);
+}
+
+// ksw_global2 with the narrowest column layout that holds the query (qlen + 1 <= 64 NC)
+__device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
+{
+	if (qlen < 64) return ema_wave_global_nc<1>(o, qlen, query, tlen, target, w, z);
+	if (qlen < 128) return ema_wave_global_nc<2>(o, qlen, query, tlen, target, w, z);
+	if (qlen < 192) return ema_wave_global_nc<3>(o, qlen, query, tlen, target, w, z);
+	return ema_wave_global_nc<4>(o, qlen, query, tlen, target, w, z);
 }
 
 // Traceback of ema_wave_global's direction matrix (ksw_global2's backtrack): wave-uniform, sequential.
@@ -366,17 +370,18 @@ struct EmaLocalRes { int score, te, qe, score2, te2; };
 // Gotoh local alignment over qpad = ceil(qlen/p)*p columns (p = 16 for the 8-bit kernel, 8 for the 16-bit one),
 // padded columns scoring 0.  minsc / endsc as in ksw (0x10000 = off).  qpad <= 256.
 // bsc: scratch for ksw's b[] list (one u64 per target row at most).
-__device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, EmaSeq query, int tlen, EmaSeq target,
+template <int NC>
+__device__ inline EmaLocalRes ema_wave_local_nc(const DevOpts &o, int qlen, int p, EmaSeq query, int tlen, EmaSeq target,
                                              int minsc, int endsc, uint64_t *bsc)
 {
 	const int lane = (int)ema_lane();
 	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
 	const int qpad = (qlen + p - 1) / p * p;
 	const int maxsc = o.a > 0 ? o.a : 0;       // largest entry of the scoring matrix
-	int hh[EMA_NC], ee[EMA_NC], qb[EMA_NC], hmax[EMA_NC];
+	int hh[NC], ee[NC], qb[NC], hmax[NC];
 #pragma unroll
-	for (int c = 0; c < EMA_NC; ++c) {
-		const int j = lane * EMA_NC + c;
+	for (int c = 0; c < NC; ++c) {
+		const int j = lane * NC + c;
 		hh[c] = 0; ee[c] = 0; hmax[c] = 0;          // hh[c] = H(i-1, j)
 		qb[c] = j < qlen ? query.at(j) : 5;         // 5 = padding column
 	}
@@ -389,12 +394,12 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 255) == 0) rows.load(target, i, tlen);
 		const int tb = rows.get(i);
-		const int up = ema_wave_shr1(hh[EMA_NC - 1], 0);  // H(i-1, 4*lane-1)
-		int Hd[EMA_NC], g[EMA_NC];
+		const int up = ema_wave_shr1(hh[NC - 1], 0);  // H(i-1, 4*lane-1)
+		int Hd[NC], g[NC];
 		int run = EMA_NEG_BIG;
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j < qpad;
 			const int diag = c == 0 ? (lane == 0 ? 0 : up) : hh[c - 1];
 			const int s = qb[c] == 5 ? 0 : ema_score(o, tb, qb[c]);
@@ -408,8 +413,8 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 		int pre = ema_wave_exscan_max(run);
 		int rowmax = 0;
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			const bool in = j < qpad;
 			int f = pre == EMA_NEG_BIG ? 0 : pre - (j - 1) * e_ins;
 			f = f > 0 ? f : 0;
@@ -436,7 +441,7 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 		if (imax > gmax) {
 			gmax = imax; te = i;
 #pragma unroll
-			for (int c = 0; c < EMA_NC; ++c) hmax[c] = hh[c];
+			for (int c = 0; c < NC; ++c) hmax[c] = hh[c];
 			if (gmax >= endsc) break;
 		}
 	}
@@ -446,8 +451,8 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 	{
 		int best = -1;
 #pragma unroll
-		for (int c = 0; c < EMA_NC; ++c) {
-			const int j = lane * EMA_NC + c;
+		for (int c = 0; c < NC; ++c) {
+			const int j = lane * NC + c;
 			if (j < qpad && hmax[c] == gmax && best < 0) best = j;
 		}
 		const unsigned long long b = __ballot(best >= 0);
@@ -484,6 +489,17 @@ __device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, 
 		}
 	}
 	return r;
+}
+
+// one pass of ksw_u8 / ksw_i16 with the narrowest column layout that holds the padded query (qpad <= 64 NC)
+__device__ inline EmaLocalRes ema_wave_local(const DevOpts &o, int qlen, int p, EmaSeq query, int tlen, EmaSeq target,
+                                             int minsc, int endsc, uint64_t *bsc)
+{
+	const int qpad = (qlen + p - 1) / p * p;
+	if (qpad <= 64) return ema_wave_local_nc<1>(o, qlen, p, query, tlen, target, minsc, endsc, bsc);
+	if (qpad <= 128) return ema_wave_local_nc<2>(o, qlen, p, query, tlen, target, minsc, endsc, bsc);
+	if (qpad <= 192) return ema_wave_local_nc<3>(o, qlen, p, query, tlen, target, minsc, endsc, bsc);
+	return ema_wave_local_nc<4>(o, qlen, p, query, tlen, target, minsc, endsc, bsc);
 }
 
 #endif

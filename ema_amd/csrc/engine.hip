@@ -285,7 +285,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 		int rc = slice_alloc(e, s, nullptr);
 		if (rc != EMA_OK) return rc;
 	}
-	size_t full_cap = e->opts.full_tier_pairs > 0 ? (size_t)e->opts.full_tier_pairs : std::min<size_t>(16384, std::max<size_t>(4096, e->cap_pairs / 64));
+	size_t full_cap = e->opts.full_tier_pairs > 0 ? (size_t)e->opts.full_tier_pairs : std::min<size_t>(65536, std::max<size_t>(4096, e->cap_pairs / 16));
 	if (full_cap > e->cap_pairs) full_cap = e->cap_pairs;
 	e->full.cap_pairs = full_cap;
 	e->full.dopts = e->dopts;      // EMA_INTV_CAP / EMA_REG_CAP / EMA_CIG_CAP

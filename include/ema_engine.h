@@ -50,7 +50,7 @@ typedef struct {
 	int pes_low, pes_high;      /* reference src/bwabridge.c:222-223: -35, 500 (FR only) */
 	int batch_pairs;            /* pairs per device batch (0 = engine default, 262144) */
 	int n_streams;              /* slices of a batch run on their own HIP streams so that kernel tails overlap (0 = default, 3) */
-	int full_tier_pairs;        /* pairs per batch the full-capacity tier can redo (0 = default: batch/64 within 4096..16384) */
+	int full_tier_pairs;        /* pairs per batch the full-capacity tier can redo (0 = default: batch/16 within 4096..65536) */
 	int lean_intervals, lean_regions, lean_cigar_ops;   /* per-read capacities of the lean tier (0 = defaults 48, 48, 192) */
 	int lean_seed_extends;      /* lean tier: FM-index extends one read's seeding may take (0 = default 2048, < 0 = no limit) */
 } ema_engine_opts;

@@ -47,6 +47,11 @@ __device__ __forceinline__ int64_t ema_uni(int64_t v)
 }
 __device__ __forceinline__ uint64_t ema_uni(uint64_t v) { return (uint64_t)ema_uni((int64_t)v); }
 __device__ __forceinline__ float ema_uni(float v) { return __int_as_float(ema_uni(__float_as_int(v))); }
+__device__ __forceinline__ Intv ema_uni(const Intv &v)
+{
+	Intv r; r.x0 = ema_uni(v.x0); r.x1 = ema_uni(v.x1); r.x2 = ema_uni(v.x2); r.info = ema_uni(v.info);
+	return r;
+}
 __device__ __forceinline__ SeedRec ema_uni(const SeedRec &s)
 {
 	SeedRec r; r.rbeg = ema_uni(s.rbeg); r.qbeg = ema_uni(s.qbeg); r.len = ema_uni(s.len); r.next = ema_uni(s.next); r.pad = 0;

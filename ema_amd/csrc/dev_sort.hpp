@@ -15,7 +15,8 @@
 #include <utility>
 
 // The sorts take any array-like `A` with a[i] and a + k: a plain pointer, or a lane-interleaved view (k_align_lane.hip).
-#define EMA_ELEM(A) typename std::remove_cv<typename std::remove_reference<decltype((*(A *)nullptr)[0])>::type>::type
+template <typename A> __host__ __device__ A &ema_declref();      // declaration only: names an lvalue of type A inside decltype
+#define EMA_ELEM(A) typename std::remove_cv<typename std::remove_reference<decltype(ema_declref<A>()[0])>::type>::type
 
 template <typename A, typename LT>
 __device__ inline void ema_insertsort(A a, int s, int t, LT lt)   // [s, t)

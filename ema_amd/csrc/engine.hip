@@ -33,6 +33,10 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
                                 int *n_park_out, int park_max, int n_blocks, hipStream_t stream, unsigned long long *prof);
 extern "C" size_t ema_seed_park_bytes();
+extern "C" int ema_seed_wave_blocks_per_cu();
+extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
+                                     const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status, int *counter,
+                                     int n_blocks, hipStream_t stream);
 
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
@@ -160,8 +164,11 @@ struct ema_engine {
 	std::vector<uint8_t> h_nt4;
 	std::vector<uint32_t> h_off, h_qpack;
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
+	int seed_wave_blocks = 0;
+	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	int seed_rounds = 6, seed_park_max = 0;   // K1 re-packing: launches per series, machines a retiring wave may park
+	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
 	int dbg_slots = 0;
 	double watchdog_s = 0;               // EMA_WATCHDOG_S=<seconds>: poll after every launch, report stuck waves
@@ -263,6 +270,8 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
 	e->lane_blocks = e->n_cu * ema_align_simple_blocks_per_cu();
+	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
+	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
@@ -300,6 +309,9 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	HIPCHK(e, e->d_redo_run.alloc(full_cap + 1));
 	HIPCHK(e, hipMemset(e->d_redo.p, 0, 4));
 	HIPCHK(e, hipMemset(e->d_redo_run.p, 0, 4));
+	HIPCHK(e, e->d_k1w_args.alloc(sizeof(DevIndex) + sizeof(DevOpts) + 64));
+	HIPCHK(e, hipMemcpy(e->d_k1w_args.p, &e->dix, sizeof(DevIndex), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + ((sizeof(DevIndex) + 15) & ~(size_t)15), &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
 	return EMA_OK;
 }
 
@@ -308,6 +320,7 @@ void ema_engine_close(ema_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	(void)hipDeviceSynchronize();
+	e->d_k1w_args.release();
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_prof.release();
 	e->d_bases.release(); e->d_off.release(); e->d_qpack.release(); e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();
@@ -418,6 +431,13 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 {
 	HIPCHK(e, hipMemsetAsync(s.d_status.p, 0, (size_t)w.n_pairs * 2 * 4, s.stream));
 	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 32 * 4, s.stream));
+	if (&s == &e->full && e->wave_seed) {      // the long reads: one wavefront each (k_seed_wave.hip)
+		ema_launch_seed_wave((const DevIndex *)e->d_k1w_args.p, (const DevOpts *)(e->d_k1w_args.p + ((sizeof(DevIndex) + 15) & ~(size_t)15)), w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
+		                     s.d_counters.p + 3, e->seed_wave_blocks, s.stream);
+		HIPCHK(e, hipGetLastError());
+		watchdog(e, s, "ema_k_seed_wave");
+		return EMA_OK;
+	}
 	// a series of launches: fresh reads first, then the machines the retiring waves of the previous launch parked
 	const int rounds = e->seed_rounds;
 	for (int r = 0; r < rounds; ++r) {

@@ -8,6 +8,7 @@
 
 // kernels + launchers, compiled as plain C++
 #include "k_seed.hip"
+#include "k_seed_wave.hip"
 #include "k_dp_test.hip"
 #include "k_align.hip"
 #include "k_align_lane.hip"
@@ -95,6 +96,23 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 			fprintf(stderr, "emu_seed round %d: parked %d\n", r, last ? 0 : n_park[out]);
 		}
 	}
+	for (int r = 0; r < n_reads; ++r) {
+		Intv *a = (Intv *)intv + (size_t)r * EMU_INTV_CAP;
+		std::stable_sort(a, a + n_intv[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });
+	}
+	return EMU_INTV_CAP;
+}
+
+// K1w (one wavefront per read) on host memory; same outputs as emu_seed
+extern "C" int emu_seed_wave(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, uint64_t *intv, int *n_intv, int *status)
+{
+	HostIndex *ix = (HostIndex *)h;
+	ema_engine_opts o; ema_fill_default_opts(&o);
+	DevOpts d = emu_dev_opts(o);
+	DevIndex di = ix->view();
+	int counter = 0;
+	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
+	ema_launch_seed_wave(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, &counter, 1, nullptr);
 	for (int r = 0; r < n_reads; ++r) {
 		Intv *a = (Intv *)intv + (size_t)r * EMU_INTV_CAP;
 		std::stable_sort(a, a + n_intv[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });

@@ -41,13 +41,20 @@ def index_load(prefix):
     return h
 
 
-def seed(h, nt4_bases: np.ndarray, off: np.ndarray, n_blocks=1, cap=512):
+def seed(h, nt4_bases: np.ndarray, off: np.ndarray, n_blocks=1, cap=512, wave=False):
+    """K1 through the interpreter (wave=True: K1w, one wavefront per read)."""
     n_reads = len(off) - 1
     intv = np.zeros((n_reads, cap, 4), dtype=np.uint64)
     n_intv = np.zeros(n_reads, dtype=np.int32)
     status = np.zeros(n_reads, dtype=np.int32)
-    got = lib().emu_seed(h, nt4_bases.ctypes.data, off.ctypes.data, n_reads, intv.ctypes.data, n_intv.ctypes.data,
-                         status.ctypes.data, n_blocks)
+    if wave:
+        lib().emu_seed_wave.restype = C.c_int
+        lib().emu_seed_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        got = lib().emu_seed_wave(h, nt4_bases.ctypes.data, off.ctypes.data, n_reads, intv.ctypes.data, n_intv.ctypes.data,
+                                  status.ctypes.data)
+    else:
+        got = lib().emu_seed(h, nt4_bases.ctypes.data, off.ctypes.data, n_reads, intv.ctypes.data, n_intv.ctypes.data,
+                             status.ctypes.data, n_blocks)
     assert got == cap
     return intv, n_intv, status
 

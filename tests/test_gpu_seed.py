@@ -1,4 +1,6 @@
-"""GPU parity of K1 (SMEM / seed-interval collection) against the CPU oracle, through the C ABI."""
+"""GPU parity of the seeding kernels (SMEM / seed-interval collection) against the CPU oracle, through the C ABI:
+K1 (one read per lane: the bulk) and K1w (one wavefront per read: the long reads of the full-capacity tier).  The debug
+entry point runs on the full-capacity tier, whose seeding kernel EMA_FULL_SEED_LANE selects."""
 import numpy as np
 import pytest
 
@@ -10,7 +12,8 @@ from ema_amd.engine import Engine
 pytestmark = pytest.mark.gpu
 
 
-def _check(kind, n_pairs, seed, **kw):
+def _check(kind, n_pairs, seed, kernel, monkeypatch, **kw):
+    monkeypatch.setenv("EMA_FULL_SEED_LANE", "1" if kernel == "lane" else "0")
     prefix, ctg = small_ref(kind)
     pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
     eng = Engine(prefix)
@@ -26,18 +29,25 @@ def _check(kind, n_pairs, seed, **kw):
     assert bad == 0, f"{bad} of {2 * pairs.n} reads have different seed intervals"
 
 
-def test_seed_parity_clean():
-    _check("two_contigs", 600, 21)
+KERNELS = pytest.mark.parametrize("kernel", ["lane", "wave"])
 
 
-def test_seed_parity_with_n_bases():
-    _check("two_contigs", 300, 22, n_rate=0.01)
+@KERNELS
+def test_seed_parity_clean(kernel, monkeypatch):
+    _check("two_contigs", 600, 21, kernel, monkeypatch)
 
 
-def test_seed_parity_repeats():
-    _check("repeats", 600, 23)
+@KERNELS
+def test_seed_parity_with_n_bases(kernel, monkeypatch):
+    _check("two_contigs", 300, 22, kernel, monkeypatch, n_rate=0.01)
 
 
-def test_seed_parity_250bp():
+@KERNELS
+def test_seed_parity_repeats(kernel, monkeypatch):
+    _check("repeats", 600, 23, kernel, monkeypatch)
+
+
+@KERNELS
+def test_seed_parity_250bp(kernel, monkeypatch):
     # config 5 of BASELINE.json (2x250 bp): beyond the reference's MAX_READ_LEN (include/align.h:61), supported here
-    _check("repeats", 200, 24, len1=250, len2=250)
+    _check("repeats", 200, 24, kernel, monkeypatch, len1=250, len2=250)

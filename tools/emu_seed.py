@@ -13,7 +13,7 @@ for kind, kw in (("repeats", {}), ("ngaps", dict(n_rate=0.01)), ("two_contigs", 
     nt4 = np.array([{65: 0, 67: 1, 71: 2, 84: 3}.get(c, 4) for c in pairs.bases], dtype=np.uint8)
     off = pairs.off.astype(np.uint32)
     h = emu_lib.index_load(prefix)
-    intv, n_intv, status = emu_lib.seed(h, nt4, off, n_blocks=1)
+    intv, n_intv, status = emu_lib.seed(h, nt4, off, n_blocks=1, wave=os.environ.get("EMU_SEED_WAVE") == "1")
     idx, opt = O.Index(prefix), O.default_opt()
     bad = 0
     for r in range(len(off) - 1):

@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=0.0, help="0 = chr20-scale (64.4 Mbp)")
     ap.add_argument("--cpu-sample", type=int, default=400000, help="pairs of the same workload timed on the host CPU")
     ap.add_argument("--streams", type=int, default=0, help="slices of a batch on their own HIP streams (0 = engine default)")
+    ap.add_argument("--lean-seed-extends", type=int, default=0, help="engine option lean_seed_extends (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-capacity-flags", action="store_true", help="print the (invalid) line even if reads overflowed an engine capacity")
     args = ap.parse_args()
@@ -118,6 +119,7 @@ def main():
     o = default_opts()
     o.batch_pairs = args.pairs
     o.n_streams = args.streams
+    o.lean_seed_extends = args.lean_seed_extends
     t = time.time()
     eng = Engine(prefix, device=local, opts=o)
     log(f"[rank {rank}] engine open (index in HBM) {time.time() - t:.1f}s")

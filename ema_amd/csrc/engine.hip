@@ -167,7 +167,7 @@ struct ema_engine {
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
-	int seed_rounds = 6, seed_park_max = 0;   // K1 re-packing: launches per series, machines a retiring wave may park
+	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
 	int dbg_slots = 0;

@@ -80,6 +80,14 @@ struct ChainRec {
 	int32_t w, kept, first;
 };
 
+// K2a -> K2b hand-over: when the lane-per-read kernel gives a read up only at the extension (or later), its chaining and
+// chain-filter results travel with the read, so the wave-per-read kernel starts at mem_chain2aln.  Per read:
+// {n_chn, n_seed}, the filter's sorted keys (weight << 32 | chain), the chains, the seed pool.  A todo-list entry with
+// bit 31 set says the record is there.
+#define EMA_HAND_SEEDS 32
+#define EMA_HAND_BYTES ((size_t)16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)))
+#define EMA_HAND_FLAG 0x80000000u
+
 // bwa's mem_alnreg_t (fields used on this path)
 struct DevReg {
 	int64_t rb, re;

@@ -41,14 +41,14 @@ extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, con
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
-                                 DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, uint8_t *slabs, int *counter,
-                                 int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof);
+                                 DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs,
+                                 int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof);
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
-                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int n_blocks,
-                                        hipStream_t stream, unsigned long long *prof);
+                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, uint8_t *hand,
+                                        int n_blocks, hipStream_t stream, unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" int ema_align_blocks_per_cu();
 extern "C" int ema_pair_blocks_per_cu();
@@ -117,7 +117,7 @@ struct Slice {
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo;
 	DevBuf<DevReg> d_regs;
-	DevBuf<uint8_t> d_slabs, d_park[2];   // d_park: K1's parked machines, ping-pong between the launches of a series
+	DevBuf<uint8_t> d_slabs, d_park[2], d_hand;   // d_hand: K2a -> K2b records (EMA_HAND_BYTES per read)   // d_park: K1's parked machines, ping-pong between the launches of a series
 	DevBuf<DevAln> d_alns;
 	DevBuf<uint32_t> d_cigars, d_cigar_out;
 	DevBuf<uint64_t> d_cand_off, d_cig_off;
@@ -128,7 +128,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release();
+		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 		if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -211,6 +211,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_cigars.alloc(n_reads * (size_t)s.dopts.cig_cap));
 	HIPCHK(e, s.d_cig_n.alloc(n_reads));
 	HIPCHK(e, s.d_kdone.alloc(n_reads));
+	HIPCHK(e, s.d_hand.alloc(n_reads * EMA_HAND_BYTES));
 	HIPCHK(e, s.d_todo.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
@@ -459,12 +460,12 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	// K2a: small reads, one lane each; the others land on the todo list that K2b (one wavefront per read) works through
 	if (e->lane_align) {
 		ema_launch_align_simple(&e->dix, &s.dopts, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
-		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21, e->lane_blocks,
-		                        s.stream, e->d_prof.p);
+		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21, s.d_hand.p,
+		                        e->lane_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
 	ema_launch_align(&e->dix, &s.dopts, e->d_bases.p, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
-	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_slabs.p, s.d_counters.p + 0,
+	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 0,
 	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_align");

@@ -204,7 +204,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
             int *__restrict__ status, const int *__restrict__ todo, const int *__restrict__ n_todo,
-            uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg, unsigned long long *prof)
+            const uint8_t *__restrict__ hand, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg, unsigned long long *prof)
 {
 	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
 	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -231,7 +231,12 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
 		if (read >= (todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2))) break;
-		if (todo) read = ema_uni(todo[read]);
+		bool handed = false;      // K2a already chained and filtered this read (dev_types.h, EMA_HAND_*)
+		if (todo) {
+			const unsigned t = (unsigned)ema_uni(todo[read]);
+			handed = (t & EMA_HAND_FLAG) != 0;
+			read = (int)(t & ~EMA_HAND_FLAG);
+		}
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		EMA_PHASE(1);
@@ -244,6 +249,26 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		const int l_query = ema_uni((int)(off[in_read + 1] - off[in_read]));
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
 		ema_wave_sync();
+		float frac_rep = 0.f;
+		int n_chn = 0, n_keep = 0;
+		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
+		if (handed) {
+			// small tables in LDS, filled from K2a's record
+			cb.sl = slab;
+			ema_small_tables(cb.sl, lds_small[wib]);
+			const uint8_t *h = hand + (size_t)read * EMA_HAND_BYTES;
+			const int32_t *head = reinterpret_cast<const int32_t *>(h);
+			n_chn = ema_uni(head[0]);
+			const int n_sd = ema_uni(head[1]);
+			const uint64_t *hk = reinterpret_cast<const uint64_t *>(h + 16);
+			const ChainRec *hc = reinterpret_cast<const ChainRec *>(h + 16 + EMA_HAND_SEEDS * 8);
+			const SeedRec *hs = reinterpret_cast<const SeedRec *>(h + 16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
+			for (int i = lane; i < n_chn; i += EMA_WAVE) { sl.skey[i] = hk[i]; sl.chains[i] = hc[i]; }
+			for (int i = lane; i < n_sd; i += EMA_WAVE) sl.seeds[i] = hs[i];
+			cb.n_chain = n_chn; cb.n_seed = n_sd;
+			n_keep = n_chn;
+			ema_wave_sync();
+		} else {
 		const int n_iv = ema_uni(n_intv[read]);
 		const Intv *iv = slab.ivs;
 		{   // K1 delivers the intervals in discovery order; mem_collect_intv ends with a sort on (start, end).
@@ -260,7 +285,6 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			}
 			ema_wave_sync();
 		}
-		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
 
 		// ---------------- mem_chain: frac_rep, seed occurrences, chaining ----------------
 		int l_rep = 0;
@@ -279,7 +303,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			cb.sl = slab;
 			if (ema_uni(tot_occ <= EMA_SMALL_SEEDS)) ema_small_tables(cb.sl, lds_small[wib]);
 		}
-		const float frac_rep = (float)l_rep / (float)l_query;
+		frac_rep = (float)l_rep / (float)l_query;
 		for (int i = 0; i < n_iv; ++i) {
 			EMA_DBG(2, i);
 			const Intv p = iv[i];
@@ -305,7 +329,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		}
 
 		// ---------------- mem_chain_flt ----------------
-		int n_chn = cb.n_chain, n_keep = 0;
+		n_chn = cb.n_chain; n_keep = 0;
 		EMA_DBG(3, n_chn);
 		EMA_PHASE(2);
 		if (n_chn > 0) {
@@ -369,6 +393,8 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			ema_wave_sync();
 			// max_chain_extend is 1<<30 on this path: the cap on kept=1/2 chains never triggers
 			n_keep = n_chn;
+		}
+
 		}
 
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
@@ -539,11 +565,12 @@ extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
-                                 const int *todo, const int *n_todo, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
+                                 const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs, int *counter, int n_blocks,
+                                 hipStream_t stream, int *dbg,
                                  unsigned long long *prof)
 {
 	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
-	                   n_regs, status, todo, n_todo, slabs, counter, dbg, prof);
+	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -217,7 +217,7 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ off, i
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,
                    uint8_t *__restrict__ scratch, int *__restrict__ counter, int *__restrict__ todo, int *__restrict__ n_todo,
-                   unsigned long long *prof)
+                   uint8_t *__restrict__ hand, unsigned long long *prof)
 {
 	// diagnostic phase timing (prof != null): shader clocks per phase of this wave (all lanes move together)
 	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -397,7 +397,19 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ off, i
 		}
 		EMA_PHASE(6);
 		int n_out = bail ? -1 : lane_sort_dedup(ix, opt, n_av, s, stack);
-		if (n_out < 0) { todo[atomicAdd(n_todo, 1)] = read; continue; }
+		if (n_out < 0) {
+			// K2b redoes the read from mem_chain2aln on: hand it the chains, the filter's order and the seed pool
+			uint8_t *h = hand + (size_t)read * EMA_HAND_BYTES;
+			int32_t *head = reinterpret_cast<int32_t *>(h);
+			head[0] = n_chn; head[1] = n_seed;
+			uint64_t *hk = reinterpret_cast<uint64_t *>(h + 16);
+			ChainRec *hc = reinterpret_cast<ChainRec *>(h + 16 + EMA_HAND_SEEDS * 8);
+			SeedRec *hs = reinterpret_cast<SeedRec *>(h + 16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
+			for (int i = 0; i < n_chn; ++i) { hk[i] = s.skey[i]; hc[i] = s.chains[i]; }
+			for (int i = 0; i < n_seed; ++i) hs[i] = s.seeds[i];
+			todo[atomicAdd(n_todo, 1)] = (int)((unsigned)read | EMA_HAND_FLAG);
+			continue;
+		}
 		if (n_out > opt.reg_cap) { st |= EMA_ST_REG_OVERFLOW; n_out = opt.reg_cap; }
 		DevReg *dst = regs + (size_t)read * opt.reg_cap;
 		for (int i = 0; i < n_out; ++i) dst[i] = s.av[i];
@@ -420,9 +432,9 @@ extern "C" int ema_align_simple_blocks_per_cu()
 
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
-                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int n_blocks,
-                                        hipStream_t stream, unsigned long long *prof)
+                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, uint8_t *hand,
+                                        int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
 	hipLaunchKernelGGL(ema_k_align_simple, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, off, n_reads, n_pairs_dev, map, intv,
-	                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, prof);
+	                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, prof);
 }

@@ -47,14 +47,15 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 	const char *v = getenv("EMU_LANE_ALIGN");
 	const bool lane = !v || atoi(v) != 0;
 	std::vector<int> todo(n_reads + 1);
+	std::vector<uint8_t> hand((size_t)n_reads * EMA_HAND_BYTES);
 	int n_todo = 0, c0 = 0, c1 = 0;
 	if (lane) {
 		std::vector<uint8_t> scratch((size_t)n_blocks * 4 * ema_align_lane_wave_bytes());
 		ema_launch_align_simple(&di, &d, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, scratch.data(), &c0, todo.data(),
-		                        &n_todo, n_blocks, nullptr, nullptr);
+		                        &n_todo, hand.data(), n_blocks, nullptr, nullptr);
 		fprintf(stderr, "emu K2a: %d of %d reads left for K2b\n", n_todo, n_reads);
 	}
-	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, slabs,
+	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,
 	                 &c1, n_blocks, nullptr, nullptr, nullptr);
 }
 

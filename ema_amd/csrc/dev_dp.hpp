@@ -113,19 +113,50 @@ __device__ inline EmaExtRes ema_wave_extend_nc(const DevOpts &o, int qlen, EmaSe
 		qb[c] = j < qlen ? query.at(j) : 4;
 	}
 	if (tlen >= qlen && h0 > 0) {
-		// Exact shortcut (most seeds of most reads): the first qlen target bases equal the query and none is ambiguous.
-		// Then every row's maximum is its diagonal cell h0 + (i+1)a, strictly above every gapped cell of the row, so
-		// the DP ends with max = gscore = h0 + qlen*a at (qlen-1, qlen-1) and max_off 0, whatever the band.
-		bool same = true;
+		// Exact shortcuts: the DP's outcome is known when the first qlen target bases differ from the query in at most one
+		// position and no base is ambiguous.
+		//  * No difference: every row's maximum is its diagonal cell h0 + (i+1)a, strictly above every gapped cell of the
+		//    row, so max = gscore = h0 + qlen*a at (qlen-1, qlen-1), max_off 0, whatever the band.
+		//  * One mismatch at position p (the usual reason a seed ended): a gapped cell (i, j) scores at most
+		//    h0 + min(i,j)+1 matches - the cheapest gap, the diagonal cell at least h0 + (i+1)a - (a+b); with
+		//    min(o_del+e_del, o_ins+e_ins+a) > a+b the diagonal stays the strict maximum of every row i < qlen, so the row
+		//    maxima are h0+(i+1)a up to p and h0+(i+1)a-(a+b) from p on.  The running maximum (updated on strict increase
+		//    only) therefore ends on the last row if the diagonal recovers above the pre-mismatch prefix before the query
+		//    ends (qlen-1 >= p + b/a + 1), else it stays at (p-1, p-1); max_off stays 0; the end-to-end score is the last
+		//    diagonal cell; z-drop (a+b <= zdrop) does not fire on the diagonal.
+		int n_bad = 0;
+		unsigned long long mm_mask[NC];
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
 			const int j = lane * NC + c;
-			if (j < qlen && (qb[c] > 3 || qb[c] != target.at(j))) same = false;
+			bool mm = false;
+			if (j < qlen) {
+				const int t = target.at(j);
+				if (qb[c] > 3 || t > 3) ++n_bad;
+				mm = qb[c] != t;
+			}
+			mm_mask[c] = __ballot(mm);
 		}
-		if (!__ballot(!same)) {
-			EmaExtRes r;
-			r.score = r.gscore = h0 + qlen * o.a; r.qle = r.tle = r.gtle = qlen; r.max_off = 0;
-			return r;
+		if (!__ballot(n_bad != 0)) {
+			int n_mm = 0, p_mm = -1;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				n_mm += __popcll(mm_mask[c]);
+				if (mm_mask[c]) p_mm = (__ffsll((long long)mm_mask[c]) - 1) * NC + c;
+			}
+			if (n_mm == 0) {
+				EmaExtRes r;
+				r.score = r.gscore = h0 + qlen * o.a; r.qle = r.tle = r.gtle = qlen; r.max_off = 0;
+				return r;
+			}
+			const int gap_min = oe_del < oe_ins + o.a ? oe_del : oe_ins + o.a;
+			if (n_mm == 1 && o.a > 0 && gap_min > o.a + o.b && (zdrop <= 0 || o.a + o.b <= zdrop) && h0 + p_mm * o.a - o.b > 0) {
+				EmaExtRes r;
+				r.gscore = h0 + (qlen - 1) * o.a - o.b; r.gtle = qlen; r.max_off = 0;
+				if (qlen - 1 >= p_mm + o.b / o.a + 1) { r.score = r.gscore; r.qle = r.tle = qlen; }
+				else { r.score = h0 + p_mm * o.a; r.qle = r.tle = p_mm; }
+				return r;
+			}
 		}
 	}
 	int max_ins, max_del;

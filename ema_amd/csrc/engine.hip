@@ -45,7 +45,7 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
                                  int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof);
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
-extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *off, int n_reads,
+extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, uint8_t *hand,
                                         int n_blocks, hipStream_t stream, unsigned long long *prof);
@@ -59,8 +59,8 @@ extern "C" size_t ema_final_slab_bytes();
 extern "C" size_t ema_sizeof_aln();
 extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
                                 int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, const int *n_pairs_dev,
-                                const int *map, DevReg *regs, int *n_regs, int *status, uint8_t *slabs, int *counter,
-                                int n_blocks, hipStream_t stream, int *dbg);
+                                const int *map, DevReg *regs, int *n_regs, int *status, int *todo, int *n_todo, uint8_t *slabs,
+                                int *counter, int n_blocks, hipStream_t stream, int *dbg);
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *qpack, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
                                  DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, int *kdone, int *todo, int *n_todo,
@@ -459,7 +459,7 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 {
 	// K2a: small reads, one lane each; the others land on the todo list that K2b (one wavefront per read) works through
 	if (e->lane_align) {
-		ema_launch_align_simple(&e->dix, &s.dopts, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+		ema_launch_align_simple(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21, s.d_hand.p,
 		                        e->lane_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
@@ -475,8 +475,8 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 static int run_pair(ema_engine *e, Slice &s, const Work &w)
 {
 	ema_launch_pair(&e->dix, &s.dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high, e->d_bases.p,
-	                w.off, w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 1,
-	                e->pair_blocks, s.stream, s.dbg);
+	                w.off, w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr,
+	                s.d_counters.p + 23, s.d_slabs.p, s.d_counters.p + 1, e->pair_blocks, s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_pair");
 	return EMA_OK;

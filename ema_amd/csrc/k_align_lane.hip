@@ -1,13 +1,14 @@
-// ema_amd/csrc/k_align_lane.hip -- K2a: seeds -> chains -> regions for the reads that need NO extension, ONE LANE PER READ.
+// ema_amd/csrc/k_align_lane.hip -- K2a: seeds -> chains -> regions for the reads that need no extension DP, ONE LANE PER READ.
 //
 // Same stage as k_align.hip (bwa's mem_align1_core after seeding, reached from reference src/bwabridge.c:236-237:
 // bwt_sa, mem_chain, mem_chain_flt, mem_chain2aln, mem_sort_dedup_patch).  Nearly half of the reads of a typical
-// bucket match the reference exactly: their longest seed spans the whole read, mem_chain2aln extends nothing, and what
+// bucket match the reference exactly (their longest seed spans the whole read, mem_chain2aln extends nothing) and another
+// third differ from it in one base (the extension across that base has a known outcome: lane_extend_diag); what
 // is left per read is a few hundred scalar operations (chaining a handful of seed occurrences through a small sorted
 // table, the chain filter with klib's introsort, the "already covered" tests, de-duplication).  A whole wavefront per
 // read (K2b) issues every one of them 64 wide; here every lane runs the sequential algorithm for its own read, on
 // lane-interleaved scratch arrays in HBM (element e of a lane's array lives at [e * 64 + lane]).  A read that turns out
-// to need a banded extension, a region merge test, or more room than the small tables have is left untouched and put on
+// to need the banded extension DP, a region merge test, or more room than the small tables have is left untouched and put on
 // the todo list of K2b.
 // (Measured dead end, kept out: running the extension DP per lane as well.  With the H/E row in HBM every cell is a
 // dependent memory round trip; with the row in LDS it is 39 KB per wave, three waves per CU, ~1000 clocks per cell
@@ -68,6 +69,42 @@ __device__ __forceinline__ int lane_max_gap(const DevOpts &o, int qlen)
 	int l = l_del > l_ins ? l_del : l_ins;
 	l = l > 1 ? l : 1;
 	return l < o.w << 1 ? l : o.w << 1;
+}
+
+// ksw_extend2 for the extensions whose outcome is known without the dynamic program (dev_dp.hpp, ema_wave_extend_nc: the
+// first qlen target bases differ from the query in at most one position, nothing ambiguous): the lane compares the
+// packed read with the packed reference along the diagonal.  Query base j is read base q0 + j * qstep, target base j
+// the reference base at forward-reverse coordinate t0 + j * tstep.  Returns false when the DP is needed.
+__device__ inline bool lane_extend_diag(const DevIndex &ix, const DevOpts &o, const uint32_t *qp, int qlen, int q0, int qstep, int tlen,
+                                        int64_t t0, int tstep, int zdrop, int h0, EmaExtRes &r)
+{
+	if (!(tlen >= qlen && h0 > 0)) return false;
+	int n_mm = 0, p_mm = -1;
+	uint32_t qw = 0, nw = 0, pw = 0;
+	int qw_at = -1, nw_at = -1;
+	int64_t pw_at = -1;
+	for (int j = 0; j < qlen; ++j) {
+		const int i = q0 + j * qstep;
+		if ((i >> 4) != qw_at) { qw_at = i >> 4; qw = qp[qw_at]; }
+		if ((i >> 5) != nw_at) { nw_at = i >> 5; nw = qp[16 + nw_at]; }
+		if ((nw >> (i & 31)) & 1) return false;      // ambiguous read base
+		const uint32_t code = (qw >> ((i & 15) << 1)) & 3;
+		const int64_t p = t0 + (int64_t)j * tstep;
+		const bool rs = p >= ix.l_pac;
+		const int64_t f = rs ? (ix.l_pac << 1) - 1 - p : p;
+		if ((f >> 4) != pw_at) { pw_at = f >> 4; pw = *reinterpret_cast<const uint32_t *>(ix.pac + (pw_at << 2)); }
+		const uint32_t b = (pw >> ((((uint32_t)f >> 2) & 3) << 3) >> ((~(uint32_t)f & 3) << 1)) & 3;
+		if (code != (rs ? 3 - b : b)) { if (++n_mm > 1) return false; p_mm = j; }
+	}
+	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+	r.max_off = 0;
+	if (n_mm == 0) { r.score = r.gscore = h0 + qlen * o.a; r.qle = r.tle = r.gtle = qlen; return true; }
+	const int gap_min = oe_del < oe_ins + o.a ? oe_del : oe_ins + o.a;
+	if (!(o.a > 0 && gap_min > o.a + o.b && (zdrop <= 0 || o.a + o.b <= zdrop) && h0 + p_mm * o.a - o.b > 0)) return false;
+	r.gscore = h0 + (qlen - 1) * o.a - o.b; r.gtle = qlen;
+	if (qlen - 1 >= p_mm + o.b / o.a + 1) { r.score = r.gscore; r.qle = r.tle = qlen; }
+	else { r.score = h0 + p_mm * o.a; r.qle = r.tle = p_mm; }
+	return true;
 }
 
 // mem_chain's loop body for one seed (test_and_merge, or a new chain right after the element the lookup returned)
@@ -213,7 +250,7 @@ __device__ inline int lane_sort_dedup(const DevIndex &ix, const DevOpts &o, int 
 // One lane = one read; a wave takes 64 consecutive reads at a time from the shared counter.
 // todo / n_todo: reads left for K2b (n_todo zero on entry).  scratch: EMA_LANE_WAVE_BYTES per resident wave.
 __global__ void __launch_bounds__(256)
-ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ off, int n_reads,
+ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,
                    uint8_t *__restrict__ scratch, int *__restrict__ counter, int *__restrict__ todo, int *__restrict__ n_todo,
@@ -241,6 +278,7 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ off, i
 		if (status[read]) { n_regs[read] = 0; continue; }      // over a capacity in K1: the pair is redone by the full-capacity tier
 		const int in_read = ema_in_read(map, read);
 		const int l_query = (int)(off[in_read + 1] - off[in_read]);
+		const uint32_t *qp = qpack + (size_t)in_read * 24;
 		const int n_iv = n_intv[read];
 		const Intv *raw = intv + (size_t)read * opt.intv_cap;
 		bool small = n_iv <= EMA_LANE_INTV;
@@ -377,9 +415,30 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ off, i
 				const int aw0 = opt.w, aw1 = opt.w;
 				a.score = a.truesc = -1;
 				a.rid = c.rid;
-				if (sd.qbeg != 0 || sd.qbeg + sd.len != l_query) { bail = true; break; }      // needs ksw_extend2: K2b
-				a.score = a.truesc = sd.len * opt.a; a.qb = 0; a.rb = sd.rbeg;
-				a.qe = l_query; a.re = sd.rbeg + sd.len;
+				// extensions: only those whose outcome the diagonal determines (no or one mismatch); otherwise K2b.  max_off is
+				// 0 for them, so mem_chain2aln's band doubling stops after the first try.
+				if (sd.qbeg) {     // left extension, both sequences reversed
+					EmaExtRes r;
+					if (!lane_extend_diag(ix, opt, qp, sd.qbeg, sd.qbeg - 1, -1, (int)(sd.rbeg - rmax0), sd.rbeg - 1, -1, opt.zdrop, sd.len * opt.a, r)) { bail = true; break; }
+					a.score = r.score;
+					if (r.gscore <= 0 || r.gscore <= a.score - opt.pen_clip5) {
+						a.qb = sd.qbeg - r.qle; a.rb = sd.rbeg - r.tle; a.truesc = a.score;
+					} else {
+						a.qb = 0; a.rb = sd.rbeg - r.gtle; a.truesc = r.gscore;
+					}
+				} else { a.score = a.truesc = sd.len * opt.a; a.qb = 0; a.rb = sd.rbeg; }
+				if (sd.qbeg + sd.len != l_query) {     // right extension
+					const int sc0 = a.score, qe = sd.qbeg + sd.len;
+					const int64_t re = sd.rbeg + sd.len;
+					EmaExtRes r;
+					if (!lane_extend_diag(ix, opt, qp, l_query - qe, qe, 1, (int)(rmax1 - re), re, 1, opt.zdrop, sc0, r)) { bail = true; break; }
+					a.score = r.score;
+					if (r.gscore <= 0 || r.gscore <= a.score - opt.pen_clip3) {
+						a.qe = qe + r.qle; a.re = re + r.tle; a.truesc += a.score - sc0;
+					} else {
+						a.qe = l_query; a.re = re + r.gtle; a.truesc += r.gscore - sc0;
+					}
+				} else { a.qe = l_query; a.re = sd.rbeg + sd.len; }
 				EMA_PHASE(4);
 				{   // seedcov: seeds of the chain fully inside the region
 					int cov = 0;
@@ -430,11 +489,11 @@ extern "C" int ema_align_simple_blocks_per_cu()
 	return n > 8 ? 8 : n;
 }
 
-extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *off, int n_reads,
+extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, uint8_t *hand,
                                         int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
-	hipLaunchKernelGGL(ema_k_align_simple, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, off, n_reads, n_pairs_dev, map, intv,
+	hipLaunchKernelGGL(ema_k_align_simple, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
 	                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, prof);
 }

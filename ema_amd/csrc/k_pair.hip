@@ -107,12 +107,64 @@ __device__ inline int matesw(PairCtx &cx, const DevReg &a, int l_ms, const uint8
 
 }  // namespace
 
+// K3a: which pairs need any rescue alignment at all?  ONE LANE PER PAIR.  mem_matesw first looks for a region of the mate
+// that already forms a consistent pair with the anchor and, failing that, checks that the rescue window is usable;
+// only then does it align.  For a properly paired read pair -- most of a bucket -- every anchor passes the first test
+// and the pair's region lists stay exactly as K2 left them.  This pass evaluates those tests (a few dozen scalar
+// operations per pair; K3b would issue them 64 wide) and lists the pairs for which an alignment would run.
+__global__ void __launch_bounds__(256)
+ema_k_pair_simple(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_low, int pes_high,
+                  const uint32_t *__restrict__ off, int n_pairs, const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
+                  const DevReg *__restrict__ regs, const int *__restrict__ n_regs, const int *__restrict__ status,
+                  int *__restrict__ todo, int *__restrict__ n_todo)
+{
+	const int pair = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (pair >= ema_work_count(n_pairs, n_pairs_dev, 1)) return;
+	if (status[2 * pair] | status[2 * pair + 1]) return;      // redone by the full-capacity tier
+	const int64_t l_pac = ix.l_pac;
+	int n[2], best[2] = {0, 0}, len[2];
+	for (int m = 0; m < 2; ++m) {
+		const int r = 2 * pair + m, in_r = ema_in_read(map, r);
+		len[m] = (int)(off[in_r + 1] - off[in_r]);
+		n[m] = n_regs[r];
+		const DevReg *src = regs + (size_t)r * opt.reg_cap;
+		for (int i = 0; i < n[m]; ++i) { const int sc = src[i].score; best[m] = best[m] > sc ? best[m] : sc; }
+	}
+	bool need = false;
+	for (int dirn = 0; dirn < 2 && !need; ++dirn) {      // reference src/bwabridge.c:263-269, :277-283
+		const int anchor = dirn == 0 ? 1 : 0, target = 1 - anchor;
+		const DevReg *an = regs + (size_t)(2 * pair + anchor) * opt.reg_cap, *tg = regs + (size_t)(2 * pair + target) * opt.reg_cap;
+		int num = 0;
+		for (int k = 0; k < n[anchor] && num < max_rescue && !need; ++k) {
+			const DevReg a = an[k];
+			if (a.score < best[anchor] - score_delta) continue;
+			++num;
+			bool found = false;
+			for (int i = 0; i < n[target] && !found; ++i) {
+				int64_t dist;
+				const int r = infer_dir(l_pac, a.rb, tg[i].rb, dist);
+				found = r == 1 && dist >= pes_low && dist <= pes_high;
+			}
+			if (found) continue;
+			int64_t rb = a.rb + pes_low - len[target], re = a.rb + pes_high;
+			if (rb < 0) rb = 0;
+			if (re > l_pac << 1) re = l_pac << 1;
+			int rid = -1;
+			if (rb < re) rid = ema_clamp_window(ix, rb, (rb + re) >> 1, re);
+			if (a.rid == rid && re - rb >= opt.min_seed_len) need = true;      // mem_matesw would align here
+		}
+	}
+	if (need) todo[atomicAdd(n_todo, 1)] = pair;
+}
+
+// K3b: the pairs K3a listed.
 // regs/n_regs: K2's output, updated in place.  One wave per pair, pairs taken from a shared counter.
 __global__ void __launch_bounds__(256)
 ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_low, int pes_high,
            const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_pairs,
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, DevReg *__restrict__ regs,
-           int *__restrict__ n_regs, int *__restrict__ status, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
+           int *__restrict__ n_regs, int *__restrict__ status, const int *__restrict__ todo, const int *__restrict__ n_todo,
+           uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
 {
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][2][256];
@@ -138,7 +190,8 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 		int pair = 0;
 		if (lane == 0) pair = atomicAdd(counter, 1);
 		pair = ema_uni(__shfl(pair, 0));
-		if (pair >= ema_work_count(n_pairs, n_pairs_dev, 1)) break;
+		if (pair >= (todo ? *n_todo : ema_work_count(n_pairs, n_pairs_dev, 1))) break;
+		if (todo) pair = ema_uni(todo[pair]);
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		if (ema_uni(status[2 * pair] | status[2 * pair + 1])) { EMA_DBG(9, 0); continue; }      // redone by the full-capacity tier
@@ -188,13 +241,19 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 
 extern "C" size_t ema_pair_slab_bytes() { return EMA_PAIR_SLAB_BYTES; }
 
+// K3 = K3a (which pairs need a rescue alignment: one lane per pair) then K3b (those pairs, one wavefront each).
+// todo: n_pairs ints; n_todo: one int, zero on entry; todo == null runs K3b over every pair.
 extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
                                 int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, const int *n_pairs_dev, const int *map,
-                                DevReg *regs, int *n_regs,
-                                int *status, uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg)
+                                DevReg *regs, int *n_regs, int *status, int *todo, int *n_todo, uint8_t *slabs, int *counter, int n_blocks,
+                                hipStream_t stream, int *dbg)
 {
+	if (n_pairs <= 0) return;
+	if (todo)
+		hipLaunchKernelGGL(ema_k_pair_simple, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, *ix, *opt, score_delta, max_rescue, pes_low,
+		                   pes_high, off, n_pairs, n_pairs_dev, map, regs, n_regs, status, todo, n_todo);
 	hipLaunchKernelGGL(ema_k_pair, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, score_delta, max_rescue, pes_low, pes_high,
-	                   bases, off, n_pairs, n_pairs_dev, map, regs, n_regs, status, slabs, counter, dbg);
+	                   bases, off, n_pairs, n_pairs_dev, map, regs, n_regs, status, todo, n_todo, slabs, counter, dbg);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -39,6 +39,11 @@ def extend_cases(rng, n, max_q=250):
         kind = rng.random()
         if kind < 0.15:    # target starts with the query itself (the kernel's exact shortcut), with or without a tail
             t = np.concatenate([q, rng.integers(0, 4, int(rng.choice([0, 0, 1, 7, 60]))).astype(np.uint8)])
+        elif kind < 0.35:  # ... or differs from it in exactly one position (the one-mismatch shortcut): anywhere, often near an end
+            t = q.copy()
+            pos = int(rng.choice([0, ql - 1, max(0, ql - 5), max(0, ql - 6), max(0, ql - 7), int(rng.integers(0, ql))]))
+            t[pos] = (t[pos] + int(rng.integers(1, 4))) & 3
+            t = np.concatenate([t, rng.integers(0, 4, int(rng.choice([0, 0, 1, 7, 60]))).astype(np.uint8)])
         elif kind < 0.6:
             t = mutate(rng, q, sub=rng.choice([0.0, 0.02, 0.1]), indel=rng.choice([0.0, 0.01, 0.05]))
             t = np.concatenate([t, rng.integers(0, 4, int(rng.integers(0, 120))).astype(np.uint8)])
@@ -53,7 +58,7 @@ def extend_cases(rng, n, max_q=250):
         if len(t) == 0:
             t = np.array([0], dtype=np.uint8)
         qs.append(q); ts.append(t)
-        prm.append([int(rng.choice([100, 200, 5, 30])), 5, int(rng.choice([100, 0, 20])), int(rng.integers(1, 150))])
+        prm.append([int(rng.choice([100, 200, 5, 30])), 5, int(rng.choice([100, 0, 20, 3])), int(rng.integers(1, 150))])
     return qs, ts, np.array(prm, dtype=np.int32)
 
 

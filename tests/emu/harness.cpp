@@ -51,7 +51,7 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 	int n_todo = 0, c0 = 0, c1 = 0;
 	if (lane) {
 		std::vector<uint8_t> scratch((size_t)n_blocks * 4 * ema_align_lane_wave_bytes());
-		ema_launch_align_simple(&di, &d, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, scratch.data(), &c0, todo.data(),
+		ema_launch_align_simple(&di, &d, qp, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, scratch.data(), &c0, todo.data(),
 		                        &n_todo, hand.data(), n_blocks, nullptr, nullptr);
 		fprintf(stderr, "emu K2a: %d of %d reads left for K2b\n", n_todo, n_reads);
 	}
@@ -189,8 +189,12 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	int counter[3] = {0, 0, 0};
 	emu_run_align(di, d, bases, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(), 1);
 	if (upto >= 3)
+	{
+		std::vector<int> todo(n_reads); int n_todo = 0;
 		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, nullptr, nullptr, (DevReg *)regs,
-		                n_regs, status, slabs.data(), &counter[1], 1, nullptr, nullptr);
+		                n_regs, status, getenv("EMU_NO_K3A") ? nullptr : todo.data(), &n_todo, slabs.data(), &counter[1], 1, nullptr, nullptr);
+		fprintf(stderr, "emu K3a: %d of %d pairs need a rescue alignment\n", n_todo, n_reads / 2);
+	}
 	if (upto >= 4)
 	{
 		std::vector<int> kdone(n_reads), todo(n_reads); int n_todo = 0;
@@ -224,8 +228,9 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	emu_run_align(di, d, bases, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(), t.status.data(),
 	              slabs.data(), 1);
+	std::vector<int> ptodo(n_pairs + 1); int n_ptodo = 0;
 	ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_pairs, n_dev, map, t.regs.data(),
-	                t.n_regs.data(), t.status.data(), slabs.data(), &counter[1], 1, nullptr, nullptr);
+	                t.n_regs.data(), t.status.data(), ptodo.data(), &n_ptodo, slabs.data(), &counter[1], 1, nullptr, nullptr);
 	std::vector<int> kdone(2 * n_pairs), todo(2 * n_pairs); int n_todo = 0;
 	ema_launch_final(&di, &d, bases, qp, off, 2 * n_pairs, n_dev, map, t.regs.data(), t.n_regs.data(), t.alns.data(), t.cigars.data(),
 	                 t.cig_n.data(), d.cig_cap, t.status.data(), kdone.data(), todo.data(), &n_todo, slabs.data(), &counter[2], 1, nullptr, nullptr);

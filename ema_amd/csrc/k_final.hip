@@ -34,7 +34,8 @@ __device__ __forceinline__ int infer_bw(int l1, int l2, int score, int a, int q,
 }  // namespace
 
 // K4a: the gap-free regions, ONE LANE PER READ.  Most regions of most reads take bwa_gen_cigar2's gap-free path
-// (query and reference span of equal length, inferred band 0): the CIGAR is a single M run plus clips and NM is a
+// (query and reference span of equal length, inferred band 0 -- or few enough mismatches that no gapped alignment can
+// beat the diagonal): the CIGAR is a single M run plus clips and NM is a
 // mismatch count -- a few hundred scalar operations, which a whole wavefront per read (K4b below) issues 64 wide.
 // Here every lane walks its own read's regions in order for as long as they are gap-free, comparing the packed
 // query with the packed reference directly in HBM; at the first region that needs the dynamic program it stops,
@@ -74,10 +75,10 @@ ema_k_final_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 			}
 			if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
 			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
-			if (!(lq == rlen && w2 == 0)) break;      // needs the dynamic program: K4b takes over from here
+			if (lq != rlen) break;      // needs the dynamic program: K4b takes over from here
 			// NM = positions where the read differs from the reference (an ambiguous read base always differs).  On the
 			// reverse strand the reference is the complement of the forward strand read from the far end.
-			int nm = 0;
+			int nm = 0, pen = 0;      // pen: what the differing positions cost the all-M alignment (a+b each, a+1 for an N)
 			{
 				const bool rs = rb >= l_pac;
 				int64_t f = rs ? (l_pac << 1) - 1 - rb : rb;      // forward-strand coordinate of reference base j = 0
@@ -91,9 +92,16 @@ ema_k_final_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 					if ((f >> 4) != pw_at) { pw_at = f >> 4; pw = *reinterpret_cast<const uint32_t *>(ix.pac + (pw_at << 2)); }
 					const uint32_t code = (qw >> ((i & 15) << 1)) & 3;
 					const uint32_t b = (pw >> ((((uint32_t)f >> 2) & 3) << 3) >> ((~(uint32_t)f & 3) << 1)) & 3;
-					nm += (int)(((nw >> (i & 31)) & 1) | (code != (rs ? 3 - b : b)));
+					const bool amb = (nw >> (i & 31)) & 1, diff = code != (rs ? 3 - b : b);
+					nm += (int)(amb | diff);
+					pen += amb ? opt.a + 1 : diff ? opt.a + opt.b : 0;
 				}
 			}
+			// w2 == 0 is bwa_gen_cigar2's own gap-free path.  Otherwise it runs the banded global alignment -- whose result
+			// is still the single M run when no gapped path can score more: between spans of equal length such a path has
+			// an insertion and a deletion and at most lq - 1 aligned pairs, i.e. at most (lq-1)a - (o_ins+e_ins+o_del+e_del),
+			// and ties go to M in ksw_global2's traceback.
+			if (!(w2 == 0 || pen <= opt.a + opt.o_ins + opt.e_ins + opt.o_del + opt.e_del)) break;
 			out.NM = nm;
 			const int is_rev = (rb < l_pac ? rb : re - 1) >= l_pac;
 			const int64_t pos = is_rev ? (l_pac << 1) - 1 - (re - 1) : rb;

@@ -53,6 +53,12 @@ def test_pipeline_noisy_reads_trigger_rescue():
     _check("two_contigs", 800, 42, sub_rate=0.09, indel_rate=0.003)
 
 
+def test_pipeline_few_mismatches():
+    """2 % substitutions, no indels: most reads have 1-4 mismatches, i.e. extensions and final alignments right at the
+    limits of the known-outcome shortcuts (one mismatch on the diagonal; equal spans with <= 3 mismatches are all-M)."""
+    _check("two_contigs", 800, 51, sub_rate=0.02, indel_rate=0.0)
+
+
 def test_pipeline_chimeric_and_n():
     _check("two_contigs", 600, 43, chimeric=0.3, n_rate=0.004)
 

@@ -240,7 +240,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "bucket_stats": {"pairs": int(gathered[:, 0].sum()), "candidates": int(gathered[:, 1].sum()),
                              "reads_with_candidates": int(gathered[:, 2].sum()), "capacity_flags": int(gathered[:, 3].max()),
-                             "oracle_spot_check_mismatches": int(bad)},
+                             "oracle_spot_check_mismatches": int(bad), "full_tier_pairs_rank0": int(batch.n_redone)},
         }
         print(json.dumps(out), flush=True)
     eng.close()

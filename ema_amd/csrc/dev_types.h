@@ -65,7 +65,7 @@ struct Intv { uint64_t x0, x1, x2, info; };
 #define EMA_INTV_LEAN 48      // lean tier (engine.hip): 0.01-0.03 % of reads of the benchmark mix exceed one of these
 #define EMA_REG_LEAN 48
 #define EMA_CIG_LEAN 192
-#define EMA_SEED_BUDGET_LEAN 2048
+#define EMA_SEED_BUDGET_LEAN 4096
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
 
 // bwa's mem_seed_t plus the link to the next seed of the same chain

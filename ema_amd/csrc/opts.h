@@ -36,5 +36,6 @@ inline void ema_fill_default_opts(ema_engine_opts *o)
 	o->score_delta = 25; o->max_rescue = 50; o->pes_low = -35; o->pes_high = 500;
 	o->batch_pairs = 0; o->n_streams = 0; o->full_tier_pairs = 0;
 	o->lean_intervals = o->lean_regions = o->lean_cigar_ops = 0; o->lean_seed_extends = 0;
+	o->mapq_coef_len = 50; o->mapq_coef_fac = 3;
 }
 #endif

@@ -17,7 +17,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free",
 ]
 
 
@@ -26,7 +26,7 @@ class Opts(C.Structure):
                                        "zdrop", "min_seed_len", "split_width", "max_mem_intv", "max_occ",
                                        "max_chain_gap", "min_chain_weight", "max_chain_extend")] + \
                [(n, C.c_float) for n in ("split_factor", "mask_level", "drop_ratio", "mask_level_redun")] + \
-               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs", "n_streams", "full_tier_pairs", "lean_intervals", "lean_regions", "lean_cigar_ops", "lean_seed_extends")]
+               [(n, C.c_int) for n in ("score_delta", "max_rescue", "pes_low", "pes_high", "batch_pairs", "n_streams", "full_tier_pairs", "lean_intervals", "lean_regions", "lean_cigar_ops", "mapq_coef_len", "mapq_coef_fac", "lean_seed_extends")]
 
 
 class Cand(C.Structure):
@@ -54,6 +54,20 @@ REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
 class BatchOut(C.Structure):
     _fields_ = [("n_pairs", C.c_size_t), ("cand_off", C.POINTER(C.c_uint64)), ("cand", C.POINTER(Cand)),
                 ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_size_t), ("n_redone", C.c_size_t), ("status", C.POINTER(C.c_int32))]
+
+
+class AlnRec(C.Structure):
+    _fields_ = [("pair", C.c_uint32), ("mate", C.c_uint8), ("unique", C.c_uint8), ("pad_", C.c_uint8 * 2), ("cand", C.c_uint64),
+                ("clip", C.c_int32), ("clip_edit_dist", C.c_int32), ("mapq", C.c_int32), ("score_mapq", C.c_int32),
+                ("score", C.c_double)]
+
+
+ALN_REC_DTYPE = np.dtype([("pair", "<u4"), ("mate", "u1"), ("unique", "u1"), ("pad_", "u1", (2,)), ("cand", "<u8"), ("clip", "<i4"),
+                          ("clip_edit_dist", "<i4"), ("mapq", "<i4"), ("score_mapq", "<i4"), ("score", "<f8")], align=True)
+
+
+class AlnOut(C.Structure):
+    _fields_ = [("n_pairs", C.c_size_t), ("n", C.c_size_t), ("pair_off", C.POINTER(C.c_uint64)), ("rec", C.POINTER(AlnRec))]
 
 
 class Timing(C.Structure):
@@ -131,6 +145,33 @@ class Batch:
 
     def cigar_of(self, c):
         return self.cigar[int(c["cigar_off"]):int(c["cigar_off"]) + int(c["n_cigar"])]
+
+
+def append_alignments(batch: "Batch", off: np.ndarray, opts: "Opts | None" = None, error_rate: float = 0.001):
+    """The reference's append_alignments() on a batch (reference src/align.c:986-1061; host arithmetic, no GPU): returns
+    (records as a structured array in the reference's order, pair_off[n_pairs + 1])."""
+    L = load_library()
+    L.ema_batch_append_alignments.argtypes = [C.POINTER(BatchOut), C.c_void_p, C.POINTER(Opts), C.c_double, C.POINTER(C.POINTER(AlnOut))]
+    L.ema_aln_free.argtypes = [C.POINTER(AlnOut)]
+    o = opts if opts is not None else default_opts()
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    cand_off = np.ascontiguousarray(batch.cand_off, dtype=np.uint64)
+    cand = np.ascontiguousarray(batch.cand)
+    cigar = np.ascontiguousarray(batch.cigar, dtype=np.uint32)
+    status = np.ascontiguousarray(batch.status, dtype=np.int32)
+    b = BatchOut((len(cand_off) - 1) // 2, cand_off.ctypes.data_as(C.POINTER(C.c_uint64)), cand.ctypes.data_as(C.POINTER(Cand)),
+                 cigar.ctypes.data_as(C.POINTER(C.c_uint32)), len(cigar), batch.n_redone, status.ctypes.data_as(C.POINTER(C.c_int32)))
+    p = C.POINTER(AlnOut)()
+    rc = L.ema_batch_append_alignments(C.byref(b), off.ctypes.data, C.byref(o), error_rate, C.byref(p))
+    if rc != 0:
+        raise RuntimeError(f"ema_batch_append_alignments failed ({rc})")
+    try:
+        a = p.contents
+        rec = np.frombuffer(C.string_at(a.rec, a.n * C.sizeof(AlnRec)), dtype=ALN_REC_DTYPE).copy() if a.n else np.zeros(0, ALN_REC_DTYPE)
+        pair_off = np.ctypeslib.as_array(a.pair_off, shape=(a.n_pairs + 1,)).copy()
+    finally:
+        L.ema_aln_free(p)
+    return rec, pair_off
 
 
 class Engine:

@@ -52,6 +52,7 @@ typedef struct {
 	int n_streams;              /* slices of a batch run on their own HIP streams so that kernel tails overlap (0 = default, 3) */
 	int full_tier_pairs;        /* pairs per batch the full-capacity tier can redo (0 = default: batch/16 within 4096..65536) */
 	int lean_intervals, lean_regions, lean_cigar_ops;   /* per-read capacities of the lean tier (0 = defaults 48, 48, 192) */
+	int mapq_coef_len, mapq_coef_fac;   /* bwa's mapQ_coef_len = 50 and mapQ_coef_fac = (int)log(50) = 3, read by the mapq formula (reference src/align.c:969-973) */
 	int lean_seed_extends;      /* lean tier: FM-index extends one read's seeding may take (0 = default 4096, < 0 = no limit) */
 } ema_engine_opts;
 
@@ -145,6 +146,30 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
  * one task per wavefront: task t owns regs[t*cap .. t*cap + n_in[t]) (records laid out as in ema_engine_debug_regions);
  * sorted/compacted in place, n_out[t] = regions kept. */
 int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int32_t *n_out, int cap, int n_tasks);
+
+/* The host stage right behind the engine: what the reference's append_alignments() (src/align.c:986-1061) derives from a
+ * pair's candidates before the records go on to the cloud stage -- clip filter (:1017,:1042), search-depth filter with
+ * the best_dist it shares between the two mates (:1021-1024,:1046-1049), mem_approx_mapq_se_insist (:959-984),
+ * score_alignment (:846-911), the `unique` flag (:1032,:1057).  Records come in the order the reference appends its
+ * SAMRecords: per pair, mate 1's surviving candidates then mate 2's.  Pure host arithmetic (double precision), no GPU.
+ * off: the read offsets the batch was aligned with (read lengths); error_rate: the platform's (reference src/techs.c: 0.001
+ * for 10x).  Free with ema_aln_free(). */
+typedef struct {
+	uint32_t pair;
+	uint8_t mate, unique, pad_[2];
+	uint64_t cand;                 /* index into ema_batch_out.cand */
+	int32_t clip, clip_edit_dist;  /* unaligned read bases; NM + clip */
+	int32_t mapq, score_mapq;
+	double score;                  /* log-likelihood of the alignment */
+} ema_aln_rec;
+typedef struct {
+	size_t n_pairs, n;
+	uint64_t *pair_off;            /* n_pairs + 1: records of pair p are rec[pair_off[p] .. pair_off[p+1]) */
+	ema_aln_rec *rec;
+} ema_aln_out;
+int ema_batch_append_alignments(const ema_batch_out *b, const uint32_t *off, const ema_engine_opts *opts, double error_rate,
+                                ema_aln_out **out);
+void ema_aln_free(ema_aln_out *o);
 
 /* mean launch duration of each kernel in the last ema_engine_run, ms (HIP events on the stream the kernel was launched on;
  * one launch per slice, launches of different slices overlap) */

@@ -18,7 +18,7 @@
  *   src/bwabridge.c:301-311  bwa_smith_waterman   -> orc_reg2aln()
  *   src/bwabridge.c:313-339  interpret_align      -> (fields kept raw in orc_reg_t)
  *   src/align.c:180-186      bwa_init             -> orc_idx_load(), orc_opt_init()
- *   src/align.c:986-1061     append_alignments    -> orc_align_pair() (candidate part)
+ *   src/align.c:986-1061     append_alignments    -> orc_align_pair() (candidate part), orc_append_alignments() (filters, mapq, scores)
  * Self-consistency is checked in tests/ against brute-force models (suffix
  * array search, exhaustive DP re-scoring); nothing here is checked against
  * real bwa output.
@@ -206,6 +206,10 @@ typedef struct {
 void orc_align_pair(const orc_opt_t *opt, const orc_idx_t *idx, const char *read1, int len1,
                     const char *read2, int len2, orc_pair_out_t *out);
 void orc_pair_out_free(orc_pair_out_t *out);
+
+/* the host stage behind the bridge calls (reference src/align.c:846-911, 959-1061): filters, mapq, likelihoods */
+int orc_append_alignments(const orc_opt_t *opt, const orc_pair_out_t *p, int len1, int len2, double error_rate, int *which,
+                          int *clip_, int *dist_, int *mapq_, int *score_mapq_, int *unique_, double *score_);
 
 extern const unsigned char orc_nt4_table[256];
 

@@ -10,6 +10,7 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <assert.h>
 #include "oracle.h"
 #include <omp.h>
@@ -348,4 +349,76 @@ double orc_bench_pairs(const orc_opt_t *opt, const orc_idx_t *idx, const char *b
 	}
 	if (n_cand) *n_cand = total;
 	return omp_get_wtime() - t0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Host stage behind the bridge calls, reference src/align.c:
+ *   :959-984   mem_approx_mapq_se_insist   -> approx_mapq()
+ *   :846-911   score_alignment             -> the likelihood block below
+ *   :986-1061  append_alignments (filters, unique flag, record order) -> orc_append_alignments()
+ * Constants: include/align.h:70-73 (INDEL_RATE, CLIP_RATE, EXTRA_SEARCH_DEPTH); MEM_MAPQ_COEF = 30 is bwa's.
+ * TEST INFRASTRUCTURE (see oracle.h). */
+static int approx_mapq(const orc_opt_t *opt, const orc_reg_t *a)
+{
+	int mapq, l, sub = a->sub ? a->sub : opt->min_seed_len * opt->a;
+	double identity;
+	sub = a->csub > sub ? a->csub : sub;
+	if (sub >= a->score) return 0;
+	l = a->qe - a->qb > a->re - a->rb ? a->qe - a->qb : (int)(a->re - a->rb);
+	identity = 1. - (double)(l * opt->a - a->score) / (opt->a + opt->b) / l;
+	if (a->score == 0) mapq = 0;
+	else if (opt->mapQ_coef_len > 0) {
+		double tmp = l < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(l);
+		tmp *= identity * identity;
+		mapq = (int)(6.02 * (a->score - sub) / opt->a * tmp * tmp + .499);
+	} else {
+		mapq = (int)(30.0 * (1. - (double)sub / a->score) * log(a->seedcov) + .499);
+		mapq = identity < 0.95 ? (int)(mapq * identity * identity + .499) : mapq;
+	}
+	if (a->sub_n > 0) mapq -= (int)(4.343 * log(a->sub_n + 1) + .499);
+	if (mapq > 254) mapq = 254;
+	if (mapq < 0) mapq = 0;
+	return (int)(mapq * (1. - a->frac_rep) + .499);
+}
+
+/* For one pair's candidates (orc_align_pair): the records append_alignments would emit.  Arrays of capacity n1 + n2:
+ * which[k] = index of the candidate in p->c, then clip, clip_edit_dist, mapq, score_mapq, unique, score.  Returns the
+ * number of records. */
+int orc_append_alignments(const orc_opt_t *opt, const orc_pair_out_t *p, int len1, int len2, double error_rate, int *which,
+                          int *clip_, int *dist_, int *mapq_, int *score_mapq_, int *unique_, double *score_)
+{
+	const double lm = log(1 - error_rate), lx = log(error_rate), li = log(0.0001), lc = log(0.03);
+	const double gx = log10(error_rate), gi = log10(0.0001), gc = log10(0.03);
+	int n = 0, best_dist = -1;
+	for (int mate = 0; mate < 2; ++mate) {
+		const size_t first = mate ? p->n1 : 0, count = mate ? p->n2 : p->n1;
+		const int len = mate ? len2 : len1;
+		int added = 0;
+		for (size_t i = 0; i < count; ++i) {
+			const orc_cand_t *c = &p->c[first + i];
+			const int clip = len - (c->reg.qe - c->reg.qb);
+			int matches = 0, mismatches, indels = 0, events = 0, clipping = 0, dist;
+			if (clip >= len / 2) continue;
+			dist = c->NM + clip;
+			if (i == 0) best_dist = dist;
+			else if (dist - best_dist > 12) continue;
+			for (int k = 0; k < c->n_cigar; ++k) {
+				const uint32_t op = p->pool[c->cigar_off + k], type = op & 0xf, len_op = op >> 4;
+				switch (type) {
+				case 0: matches += len_op; break;
+				case 1: case 2: indels += len_op; ++events; break;
+				default: clipping += len_op; break;
+				}
+			}
+			mismatches = c->NM - indels;
+			matches -= mismatches;
+			which[n] = (int)(first + i); clip_[n] = clip; dist_[n] = dist; unique_[n] = 0;
+			mapq_[n] = approx_mapq(opt, &c->reg);
+			score_[n] = matches * lm + mismatches * lx + events * li + clipping * lc;
+			score_mapq_[n] = (int)(60.0 + mismatches * gx + events * gi + clipping * gc);
+			++n; ++added;
+		}
+		if (added == 1) unique_[n - 1] = 1;
+	}
+	return n;
 }

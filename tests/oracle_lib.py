@@ -158,6 +158,28 @@ def align_pair(idx: Index, opt, r1: bytes, r2: bytes):
     return res
 
 
+def append_alignments(idx: Index, opt, r1: bytes, r2: bytes, error_rate=0.001):
+    """The records the reference's append_alignments would emit for this pair: list of dicts (mate, index of the candidate
+    within its mate's list, clip, clip_edit_dist, mapq, score_mapq, unique, score)."""
+    out = PairOut()
+    L = lib()
+    L.orc_align_pair(C.byref(opt), idx.h, r1, len(r1), r2, len(r2), C.byref(out))
+    n = out.n1 + out.n2
+    IA = C.c_int * max(n, 1)
+    which, clip, dist, mapq, smq, uniq = IA(), IA(), IA(), IA(), IA(), IA()
+    score = (C.c_double * max(n, 1))()
+    L.orc_append_alignments.restype = C.c_int
+    L.orc_append_alignments.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 7
+    k = L.orc_append_alignments(C.byref(opt), C.byref(out), len(r1), len(r2), error_rate, which, clip, dist, mapq, smq, uniq, score)
+    res = []
+    for i in range(k):
+        m = 0 if which[i] < out.n1 else 1
+        res.append(dict(mate=m, cand=which[i] - (out.n1 if m else 0), clip=clip[i], clip_edit_dist=dist[i], mapq=mapq[i],
+                        score_mapq=smq[i], unique=uniq[i], score=score[i]))
+    L.orc_pair_out_free(C.byref(out))
+    return res
+
+
 def align1(idx: Index, opt, read_ascii: bytes):
     """Regions of one read after mem_align1_core (before mate rescue): list of dicts."""
     q = C.create_string_buffer(NT4[np.frombuffer(read_ascii, dtype=np.uint8)].tobytes(), len(read_ascii))

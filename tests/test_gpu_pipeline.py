@@ -173,3 +173,16 @@ def test_committed_regression_vectors():
                 d.update(pos=int(c["pos"]), is_rev=int(c["is_rev"]), NM=int(c["NM"]), cigar=batch.cigar_of(c).tolist())
                 got.append(d)
             assert got == candidates[p][m], (p, m)
+
+
+def test_append_alignments_on_engine_batches():
+    """ema_batch_append_alignments (the host stage behind the engine: reference src/align.c:986-1061) on what the engine
+    returned, against the oracle's candidates put through the oracle's restatement of the same stage."""
+    from test_append_alignments import check
+    prefix, ctg = small_ref("repeats")
+    pairs = synth.make_pairs(ctg, 300, seed=62, sub_rate=0.03, indel_rate=0.004, chimeric=0.15, n_rate=0.002)
+    eng = Engine(prefix)
+    batch = eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()
+    n, n_unique = check(prefix, pairs, batch)
+    assert n > pairs.n and n_unique > 0

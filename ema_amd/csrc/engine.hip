@@ -22,6 +22,7 @@
 #include <cstring>
 #include <unistd.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ema_engine.h"
 #include "dev_types.h"
@@ -93,6 +94,40 @@ const unsigned char kNt4[256] = {
 	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
 	4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
 
+// fn(begin, end) over [0, n) on the host's cores (EMA_HOST_THREADS, default min(32, hardware threads)); the staging and
+// result loops are memory-bound byte shuffles that one core does at ~1 GB/s
+template <typename F> void host_parallel(size_t n, F fn)
+{
+	static int n_thr = [] {
+		const char *v = getenv("EMA_HOST_THREADS");
+		int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
+		return t < 1 ? 1 : t > 32 ? 32 : t;
+	}();
+	const size_t t = n < 65536 ? 1 : (size_t)n_thr;
+	if (t == 1) { fn((size_t)0, n); return; }
+	std::vector<std::thread> th;
+	const size_t per = (n + t - 1) / t;
+	for (size_t k = 0; k < t; ++k) {
+		const size_t b = k * per, e = b + per < n ? b + per : n;
+		if (b < e) th.emplace_back([=] { fn(b, e); });
+	}
+	for (auto &x : th) x.join();
+}
+
+// page-locked host staging buffer (asynchronous copies at full PCIe rate)
+template <typename T> struct PinBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	hipError_t reserve(size_t count)
+	{
+		if (count <= n) return hipSuccess;
+		release();
+		n = count;
+		return hipHostMalloc((void **)&p, count * sizeof(T) + 256, hipHostMallocDefault);
+	}
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
 template <typename T> struct DevBuf {
 	T *p = nullptr;
 	size_t n = 0;
@@ -161,8 +196,8 @@ struct ema_engine {
 	DevBuf<int> d_redo, d_redo_run;
 	size_t cap_pairs = 0, n_pairs = 0;
 	bool staged = false, ran = false, ever_ran = false;
-	std::vector<uint8_t> h_nt4;
-	std::vector<uint32_t> h_off, h_qpack;
+	PinBuf<uint8_t> h_nt4;
+	PinBuf<uint32_t> h_off, h_qpack;
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
@@ -322,6 +357,7 @@ void ema_engine_close(ema_engine_t *e)
 	(void)hipSetDevice(e->device);
 	(void)hipDeviceSynchronize();
 	e->d_k1w_args.release();
+	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_prof.release();
 	e->d_bases.release(); e->d_off.release(); e->d_qpack.release(); e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();
@@ -355,29 +391,36 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));      // a run still in flight reads the input
 	HIPCHK(e, hipStreamSynchronize(e->full.stream));
 	const size_t n_reads = 2 * n_pairs;
-	e->h_off.resize(n_reads + 1);
+	HIPCHK(e, e->h_off.reserve(2 * e->cap_pairs + 1));
+	HIPCHK(e, e->h_qpack.reserve(2 * e->cap_pairs * 24 + 8));
 	const uint32_t base0 = off[0];
-	for (size_t r = 0; r <= n_reads; ++r) e->h_off[r] = off[r] - base0;
+	for (size_t r = 0; r <= n_reads; ++r) e->h_off.p[r] = off[r] - base0;
 	for (size_t r = 0; r < n_reads; ++r)
 		if (off[r + 1] < off[r] || off[r + 1] - off[r] > EMA_MAX_READ) { e->err = "read longer than EMA_MAX_READ"; return EMA_ELIMIT; }
-	const size_t total = e->h_off[n_reads];
-	e->h_nt4.resize(total + 1);
+	const size_t total = e->h_off.p[n_reads];
+	HIPCHK(e, e->h_nt4.reserve(2 * e->cap_pairs * (size_t)(EMA_MAX_READ + 1)));
 	const unsigned char *src = (const unsigned char *)bases + base0;
-	for (size_t i = 0; i < total; ++i) e->h_nt4[i] = kNt4[src[i]];   // seq_convert, reference src/bwabridge.c:151-157
-	e->h_qpack.assign(n_reads * 24 + 8, 0);
-	for (size_t r = 0; r < n_reads; ++r) {
-		uint32_t *w = e->h_qpack.data() + r * 24;
-		const uint8_t *b = e->h_nt4.data() + e->h_off[r];
-		const uint32_t len = e->h_off[r + 1] - e->h_off[r];
+	uint8_t *nt4 = e->h_nt4.p;
+	host_parallel(total, [=](size_t b0, size_t b1) { for (size_t i = b0; i < b1; ++i) nt4[i] = kNt4[src[i]]; });   // seq_convert, reference src/bwabridge.c:151-157
+	uint32_t *qpack = e->h_qpack.p;
+	const uint32_t *hoff = e->h_off.p;
+	memset(qpack + n_reads * 24, 0, 8 * 4);
+	host_parallel(n_reads, [=](size_t r0, size_t r1) {
+	for (size_t r = r0; r < r1; ++r) {
+		uint32_t *w = qpack + r * 24;
+		memset(w, 0, 24 * 4);
+		const uint8_t *b = nt4 + hoff[r];
+		const uint32_t len = hoff[r + 1] - hoff[r];
 		for (uint32_t i = 0; i < len; ++i) {
 			w[i >> 4] |= (uint32_t)(b[i] & 3) << ((i & 15) << 1);
 			if (b[i] > 3) w[16 + (i >> 5)] |= 1u << (i & 31);
 		}
 	}
+	});
 	hipStream_t st = e->sl[0].stream;
-	HIPCHK(e, hipMemcpyAsync(e->d_qpack.p, e->h_qpack.data(), (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, st));
-	HIPCHK(e, hipMemcpyAsync(e->d_bases.p, e->h_nt4.data(), total, hipMemcpyHostToDevice, st));
-	HIPCHK(e, hipMemcpyAsync(e->d_off.p, e->h_off.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemcpyAsync(e->d_qpack.p, e->h_qpack.p, (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemcpyAsync(e->d_bases.p, e->h_nt4.p, total, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemcpyAsync(e->d_off.p, e->h_off.p, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
 	// consecutive pairs go to consecutive slices, as evenly as the slice count allows
 	const size_t n_sl = e->sl.size();
 	size_t first = 0;

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include "ema_engine.h"
 
@@ -53,55 +54,85 @@ extern "C" int ema_batch_append_alignments(const ema_batch_out *b, const uint32_
 	const double ln_match = std::log(1. - error_rate), ln_mis = std::log(error_rate), ln_indel = std::log(kIndelRate),
 	             ln_clip = std::log(kClipRate);
 	const double lg_mis = std::log10(error_rate), lg_indel = std::log10(kIndelRate), lg_clip = std::log10(kClipRate);
-	std::vector<ema_aln_rec> recs;
-	recs.reserve(b->n_pairs * 2 + 16);
 	ema_aln_out *o = (ema_aln_out *)calloc(1, sizeof(ema_aln_out));
 	o->n_pairs = b->n_pairs;
 	o->pair_off = (uint64_t *)malloc((b->n_pairs + 1) * sizeof(uint64_t));
-	for (size_t p = 0; p < b->n_pairs; ++p) {
-		o->pair_off[p] = recs.size();
-		int best_dist = -1;      // shared by the two mates, reset only by a mate's first candidate that passes the clip filter
-		for (int m = 0; m < 2; ++m) {
-			const size_t r = 2 * p + m;
-			const int len = (int)(off[r + 1] - off[r]);
-			const uint64_t lo = b->cand_off[r], hi = b->cand_off[r + 1];
-			size_t added = 0;
-			for (uint64_t i = lo; i < hi; ++i) {
-				const ema_cand_t &c = b->cand[i];
-				const int clip = len - (c.qe - c.qb);
-				if (clip >= len / 2) continue;
-				const int dist = c.NM + clip;
-				if (i == lo) best_dist = dist;
-				else if (dist - best_dist > kExtraSearchDepth) continue;
-				ema_aln_rec rec;
-				memset(&rec, 0, sizeof(rec));
-				rec.pair = (uint32_t)p; rec.mate = (uint8_t)m; rec.cand = i;
-				rec.clip = clip; rec.clip_edit_dist = dist;
-				rec.mapq = approx_mapq(*opts, c);
-				// score_alignment: matches / mismatches / indel events / clipped bases from the CIGAR and NM
-				int matches = 0, indels = 0, indel_events = 0, clipping = 0;
-				const uint32_t *cig = b->cigar + c.cigar_off;
-				for (int k = 0; k < c.n_cigar; ++k) {
-					const uint32_t type = cig[k] & 0xf, n = cig[k] >> 4;
-					if (type == 0) matches += (int)n;
-					else if (type == 1 || type == 2) { indels += (int)n; ++indel_events; }
-					else if (type == 3 || type == 4) clipping += (int)n;
-					else { free(o->pair_off); free(o); return EMA_EARG; }
-				}
-				const int mismatches = c.NM - indels;
-				matches -= mismatches;
-				rec.score = matches * ln_match + mismatches * ln_mis + indel_events * ln_indel + clipping * ln_clip;
-				rec.score_mapq = (int)(60.0 + mismatches * lg_mis + indel_events * lg_indel + clipping * lg_clip);
-				recs.push_back(rec);
-				++added;
-			}
-			if (added == 1) recs.back().unique = 1;
-		}
+	// pairs are independent: chunks of pairs on the host's cores (EMA_HOST_THREADS, default min(32, hardware threads)),
+	// each into its own list; the lists are then laid end to end
+	int n_thr = 1;
+	{
+		const char *v = getenv("EMA_HOST_THREADS");
+		n_thr = v ? atoi(v) : (int)std::thread::hardware_concurrency();
+		n_thr = n_thr < 1 ? 1 : n_thr > 32 ? 32 : n_thr;
+		if (b->n_pairs < 4096) n_thr = 1;
 	}
-	o->pair_off[b->n_pairs] = recs.size();
-	o->n = recs.size();
-	o->rec = (ema_aln_rec *)malloc((recs.size() + 1) * sizeof(ema_aln_rec));
-	if (!recs.empty()) memcpy(o->rec, recs.data(), recs.size() * sizeof(ema_aln_rec));
+	std::vector<std::vector<ema_aln_rec>> part(n_thr);
+	std::vector<int> bad(n_thr, 0);
+	const size_t per = (b->n_pairs + n_thr - 1) / n_thr;
+	auto work = [&](int t) {
+		std::vector<ema_aln_rec> &recs = part[t];
+		const size_t p0 = (size_t)t * per, p1 = p0 + per < b->n_pairs ? p0 + per : b->n_pairs;
+		recs.reserve((p1 > p0 ? p1 - p0 : 0) * 2 + 16);
+		for (size_t p = p0; p < p1; ++p) {
+			o->pair_off[p] = recs.size();      // relative to the chunk; rebased below
+			int best_dist = -1;      // shared by the two mates, reset only by a mate's first candidate when it passes the clip filter
+			for (int m = 0; m < 2; ++m) {
+				const size_t r = 2 * p + m;
+				const int len = (int)(off[r + 1] - off[r]);
+				const uint64_t lo = b->cand_off[r], hi = b->cand_off[r + 1];
+				size_t added = 0;
+				for (uint64_t i = lo; i < hi; ++i) {
+					const ema_cand_t &c = b->cand[i];
+					const int clip = len - (c.qe - c.qb);
+					if (clip >= len / 2) continue;
+					const int dist = c.NM + clip;
+					if (i == lo) best_dist = dist;
+					else if (dist - best_dist > kExtraSearchDepth) continue;
+					ema_aln_rec rec;
+					memset(&rec, 0, sizeof(rec));
+					rec.pair = (uint32_t)p; rec.mate = (uint8_t)m; rec.cand = i;
+					rec.clip = clip; rec.clip_edit_dist = dist;
+					rec.mapq = approx_mapq(*opts, c);
+					// score_alignment: matches / mismatches / indel events / clipped bases from the CIGAR and NM
+					int matches = 0, indels = 0, indel_events = 0, clipping = 0;
+					const uint32_t *cig = b->cigar + c.cigar_off;
+					for (int k = 0; k < c.n_cigar; ++k) {
+						const uint32_t type = cig[k] & 0xf, n = cig[k] >> 4;
+						if (type == 0) matches += (int)n;
+						else if (type == 1 || type == 2) { indels += (int)n; ++indel_events; }
+						else if (type == 3 || type == 4) clipping += (int)n;
+						else bad[t] = 1;
+					}
+					const int mismatches = c.NM - indels;
+					matches -= mismatches;
+					rec.score = matches * ln_match + mismatches * ln_mis + indel_events * ln_indel + clipping * ln_clip;
+					rec.score_mapq = (int)(60.0 + mismatches * lg_mis + indel_events * lg_indel + clipping * lg_clip);
+					recs.push_back(rec);
+					++added;
+				}
+				if (added == 1) recs.back().unique = 1;
+			}
+		}
+	};
+	if (n_thr == 1) work(0);
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < n_thr; ++t) th.emplace_back(work, t);
+		for (auto &x : th) x.join();
+	}
+	for (int t = 0; t < n_thr; ++t) if (bad[t]) { free(o->pair_off); free(o); return EMA_EARG; }
+	size_t total = 0;
+	for (int t = 0; t < n_thr; ++t) total += part[t].size();
+	o->n = total;
+	o->rec = (ema_aln_rec *)malloc((total + 1) * sizeof(ema_aln_rec));
+	size_t at = 0;
+	for (int t = 0; t < n_thr; ++t) {
+		const size_t p0 = (size_t)t * per, p1 = p0 + per < b->n_pairs ? p0 + per : b->n_pairs;
+		for (size_t p = p0; p < p1; ++p) o->pair_off[p] += at;
+		if (!part[t].empty()) memcpy(o->rec + at, part[t].data(), part[t].size() * sizeof(ema_aln_rec));
+		at += part[t].size();
+	}
+	o->pair_off[b->n_pairs] = total;
 	*out = o;
 	return EMA_OK;
 }

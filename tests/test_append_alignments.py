@@ -53,3 +53,26 @@ def test_append_alignments_matches_the_oracle():
     pairs = synth.make_pairs(ctg, 120, seed=61, sub_rate=0.03, indel_rate=0.004, chimeric=0.15, n_rate=0.002)
     n, n_unique = check(prefix, pairs, batch_from_oracle(prefix, pairs))
     assert n > pairs.n and 0 < n_unique < n      # multi-candidate reads, filtered candidates and unique reads all occur
+
+
+def test_append_alignments_threaded_equals_serial(monkeypatch):
+    """Above 4096 pairs the stage runs on several host threads (chunks of pairs laid end to end): same records."""
+    prefix, ctg = small_ref("repeats")
+    pairs = synth.make_pairs(ctg, 100, seed=63, sub_rate=0.03, chimeric=0.1)
+    one = batch_from_oracle(prefix, pairs)
+    reps = 50
+    n_c, n_g = len(one.cand), len(one.cigar)
+    cand = np.tile(one.cand, reps)
+    cand["cigar_off"] = (cand["cigar_off"].astype(np.int64) + np.repeat(np.arange(reps) * n_g, n_c)).astype(np.uint32)
+    cand_off = np.concatenate([one.cand_off[:-1].astype(np.int64) + k * n_c for k in range(reps)] + [np.array([reps * n_c])]).astype(np.uint64)
+    big = E.Batch(cand_off, cand, np.tile(one.cigar, reps), np.zeros(2 * pairs.n * reps, np.int32))
+    lens = np.diff(pairs.off.astype(np.int64))
+    off = np.concatenate([[0], np.cumsum(np.tile(lens, reps))]).astype(np.uint32)
+    monkeypatch.setenv("EMA_HOST_THREADS", "1")
+    rec1, po1 = E.append_alignments(big, off)
+    monkeypatch.setenv("EMA_HOST_THREADS", "7")
+    rec7, po7 = E.append_alignments(big, off)
+    assert (po1 == po7).all() and rec1.tobytes() == rec7.tobytes()
+    base, _ = E.append_alignments(one, pairs.off)
+    assert len(rec1) == reps * len(base) and (rec1["mapq"][:len(base)] == base["mapq"]).all()
+    assert (rec1["pair"][len(base):2 * len(base)] == base["pair"] + pairs.n).all()

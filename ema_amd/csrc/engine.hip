@@ -257,9 +257,25 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	return EMA_OK;
 }
 
+static int engine_open(const char *index_prefix, const ema_engine *share, int device, const ema_engine_opts *opts, ema_engine_t **out);
+
 int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts *opts, ema_engine_t **out)
 {
 	if (!index_prefix || !out) return EMA_EARG;
+	return engine_open(index_prefix, nullptr, device, opts, out);
+}
+
+// A second engine on the same GPU that uses `first`'s index in HBM (no second copy) and has its own batch buffers and
+// streams: a host that stages batch i+1 into one engine while the other runs batch i and a third call fetches batch
+// i-1 keeps PCIe, host cores and kernels busy at the same time.  `first` must outlive it.
+int ema_engine_open_shared(const ema_engine_t *first, const ema_engine_opts *opts, ema_engine_t **out)
+{
+	if (!first || !out) return EMA_EARG;
+	return engine_open(nullptr, first, first->device, opts, out);
+}
+
+static int engine_open(const char *index_prefix, const ema_engine *share, int device, const ema_engine_opts *opts, ema_engine_t **out)
+{
 	*out = nullptr;
 	ema_engine *e = new ema_engine();
 	*out = e;   // returned even on failure so that the caller can read the error text
@@ -280,6 +296,11 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (ema_sizeof_aln() != sizeof(DevAln)) { e->err = "DevAln layout mismatch"; return EMA_EDEVICE; }
 
+	if (share) {      // the index of another engine on this device
+		e->contigs = share->contigs;
+		e->l_pac = share->l_pac;
+		e->dix = share->dix;
+	} else {
 	HostIndex hix;
 	std::string msg = host_index_load(index_prefix, hix);
 	if (!msg.empty()) { e->err = msg; return EMA_EINDEX; }
@@ -295,6 +316,7 @@ int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts 
 	HIPCHK(e, hipMemcpy(e->d_ctg.p, hix.ctg_off.data(), hix.ctg_off.size() * 8, hipMemcpyHostToDevice));
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
+	}
 
 	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256)); }
 	if (const char *wd = getenv("EMA_WATCHDOG_S")) { e->watchdog_s = atof(wd); e->dbg_slots = e->n_cu * 8 * 4 + 64; }

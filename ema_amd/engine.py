@@ -17,7 +17,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free", "ema_engine_open_shared",
 ]
 
 
@@ -179,9 +179,17 @@ class Engine:
     `Engine(prefix)` ~ load_reference(); `align_pairs()` ~ bwa_mem_mate_sw + bwa_smith_waterman for every
     candidate of every pair."""
 
-    def __init__(self, index_prefix: str, device: int = 0, opts: Opts | None = None):
+    def __init__(self, index_prefix: str | None, device: int = 0, opts: Opts | None = None, share: "Engine | None" = None):
+        """share: another Engine on the same GPU whose index this one uses (own buffers and streams; see ema_engine_open_shared)."""
         self._L = load_library()
         self._h = C.c_void_p()
+        if share is not None:
+            self._L.ema_engine_open_shared.argtypes = [C.c_void_p, C.POINTER(Opts), C.POINTER(C.c_void_p)]
+            rc = self._L.ema_engine_open_shared(share._h, C.byref(opts) if opts is not None else None, C.byref(self._h))
+            if rc != 0:
+                raise RuntimeError(f"ema_engine_open_shared failed ({rc}): {self._L.ema_engine_strerror(self._h).decode()}")
+            self._n_reads_staged = 0
+            return
         rc = self._L.ema_engine_open(index_prefix.encode(), device, C.byref(opts) if opts is not None else None,
                                      C.byref(self._h))
         if rc != 0:

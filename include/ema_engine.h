@@ -62,6 +62,10 @@ void ema_engine_opts_default(ema_engine_opts *o);
  * reads <index_prefix>.{bwt,fsa,pac,ann} and uploads the index to HBM of `device`. */
 int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts *opts, ema_engine_t **out);
 void ema_engine_close(ema_engine_t *e);
+/* A second engine on the same GPU sharing `first`'s index in HBM, with its own batch buffers and streams: lets a host
+ * overlap staging, kernels and fetching of consecutive batches (stage batch i+1 into one engine while the other runs
+ * batch i).  `first` must be closed last. */
+int ema_engine_open_shared(const ema_engine_t *first, const ema_engine_opts *opts, ema_engine_t **out);
 const char *ema_engine_strerror(const ema_engine_t *e);
 
 /* contig table (bns->anns[i].name/len/offset; reference src/align.c:199-200, src/bwabridge.c:86-91) */

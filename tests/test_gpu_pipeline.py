@@ -186,3 +186,27 @@ def test_append_alignments_on_engine_batches():
     eng.close()
     n, n_unique = check(prefix, pairs, batch)
     assert n > pairs.n and n_unique > 0
+
+
+def test_second_engine_sharing_the_index():
+    """ema_engine_open_shared: own buffers and streams, the first engine's index; both give the oracle's candidates, also
+    when driven from two host threads at once."""
+    import threading
+    prefix, ctg = small_ref("two_contigs")
+    first = Engine(prefix)
+    second = Engine(None, share=first)
+    pa = synth.make_pairs(ctg, 400, seed=64)
+    pb = synth.make_pairs(ctg, 400, seed=65, sub_rate=0.03)
+    out = {}
+
+    def work(name, eng, pairs):
+        out[name] = eng.align_pairs(pairs.bases, pairs.off)
+
+    th = [threading.Thread(target=work, args=("a", first, pa)), threading.Thread(target=work, args=("b", second, pb))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    second.close()
+    first.close()
+    assert not compare(prefix, pa, out["a"]) and not compare(prefix, pb, out["b"])

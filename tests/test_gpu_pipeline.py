@@ -59,6 +59,12 @@ def test_pipeline_few_mismatches():
     _check("two_contigs", 800, 51, sub_rate=0.02, indel_rate=0.0)
 
 
+def test_pipeline_250bp():
+    """config 5 of BASELINE.json (2x250 bp): beyond the reference's MAX_READ_LEN (include/align.h:61), supported here up to
+    255; exercises the widest column layouts of the DPs."""
+    _check("repeats", 300, 52, len1=250, len2=250, sub_rate=0.01, indel_rate=0.002)
+
+
 def test_pipeline_chimeric_and_n():
     _check("two_contigs", 600, 43, chimeric=0.3, n_rate=0.004)
 

@@ -218,7 +218,7 @@ def main():
                     "all_kernels_ms": {k: round(v, 3) for k, v in kernel_ms.items()},
                     "all_kernels_ms_isolated": {k: round(v, 3) for k, v in kernel_ms_isolated.items()}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (contract)
             cores = len(os.sched_getaffinity(0))
             secs, _ = O.bench_pairs(idx, opt, sample.bases, sample.off, cores)
             cpu = {"value": round(n_s / secs, 1), "unit": "pairs/s", "cores": cores, "kind": "port",

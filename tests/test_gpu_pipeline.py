@@ -216,3 +216,62 @@ def test_second_engine_sharing_the_index():
     second.close()
     first.close()
     assert not compare(prefix, pa, out["a"]) and not compare(prefix, pb, out["b"])
+
+
+def test_large_batch_properties():
+    """At a batch size the oracle cannot check pair by pair in a test: (1) a random sample of pairs equals the oracle;
+    (2) the result of a pair does not depend on where in the batch it sits or how the batch is sliced -- the same pairs
+    in reverse order, on an engine with a different slice count and a different lean tier, give the same candidates."""
+    prefix, ctg = small_ref("mid")
+    n = 120000
+    pairs = synth.make_pairs(ctg, n, seed=66)
+    eng = Engine(prefix)
+    a = eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()
+    assert a.status.max() == 0
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(n, 150, replace=False))
+    sub_reads = [pairs.read(2 * int(p) + m) for p in pick for m in range(2)]
+    so = np.zeros(len(sub_reads) + 1, np.uint32)
+    so[1:] = np.cumsum([len(r) for r in sub_reads])
+    sample = synth.Pairs(np.frombuffer(b"".join(sub_reads), dtype=np.uint8), so)
+
+    class View:      # the sampled pairs of batch `a`, renumbered
+        def mate(self, p, m):
+            return a.mate(int(pick[p]), m)
+
+        def cigar_of(self, c):
+            return a.cigar_of(c)
+    assert not compare(prefix, sample, View())
+    # reversed order, 2 slices, small lean capacities
+    order = np.arange(n)[::-1]
+    lens = np.diff(pairs.off.astype(np.int64))
+    rl = np.stack([lens[2 * order], lens[2 * order + 1]], axis=1).ravel()
+    roff = np.zeros(2 * n + 1, np.uint32)
+    roff[1:] = np.cumsum(rl)
+    rbases = np.empty(int(roff[-1]), np.uint8)
+    src0 = pairs.off[2 * order].astype(np.int64)
+    plen = lens[2 * order] + lens[2 * order + 1]
+    dst0 = roff[0:2 * n:2].astype(np.int64)
+    for s0, d0, ln in zip(src0.tolist(), dst0.tolist(), plen.tolist()):
+        rbases[d0:d0 + ln] = pairs.bases[s0:s0 + ln]
+    o = default_opts()
+    o.n_streams = 2
+    o.lean_intervals, o.lean_regions, o.lean_cigar_ops = 12, 3, 9
+    eng = Engine(prefix, opts=o)
+    b = eng.align_pairs(rbases, roff)
+    eng.close()
+    assert b.status.max() == 0 and b.n_redone > 0
+    na = np.diff(a.cand_off.astype(np.int64)).reshape(n, 2)
+    nb = np.diff(b.cand_off.astype(np.int64)).reshape(n, 2)
+    assert (na == nb[::-1]).all()
+    drop = ["cigar_off"]
+    fa = a.cand[[f for f in a.cand.dtype.names if f not in drop]]
+    fb = b.cand[[f for f in b.cand.dtype.names if f not in drop]]
+    for p in rng.choice(n, 4000, replace=False).tolist():
+        q = n - 1 - p
+        for m in range(2):
+            ca, cb = a.mate(p, m), b.mate(q, m)
+            assert (fa[int(a.cand_off[2 * p + m]):int(a.cand_off[2 * p + m + 1])] == fb[int(b.cand_off[2 * q + m]):int(b.cand_off[2 * q + m + 1])]).all()
+            for x, y in zip(ca, cb):
+                assert (a.cigar_of(x) == b.cigar_of(y)).all()

@@ -164,8 +164,16 @@ def main():
         flags, counts = np.unique(batch.status[batch.status != 0], return_counts=True)
         log(f"[rank {rank}] ERROR: reads exceeded an engine capacity (status flag: count) {dict(zip(flags.tolist(), counts.tolist()))}: "
             f"their pairs have no candidates, so the timed steps skipped work and the number is not valid")
-        if not args.allow_capacity_flags:
-            raise SystemExit(2)
+    any_flag = int(batch.status.max() != 0) if len(batch.status) else 0
+    if world > 1:      # every rank must take the same exit
+        tf = torch.tensor([any_flag], dtype=torch.int32, device="cuda")
+        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        any_flag = int(tf.item())
+    if any_flag and not args.allow_capacity_flags:
+        eng.close()
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(2)
     from ema_amd import shard
     stats_vec = shard.bucket_stats(batch, pairs.n)
     # the "trivial RCCL gather of per-bucket statistics" of the north star: one bucket per rank, O(100 B) over xGMI

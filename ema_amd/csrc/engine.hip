@@ -884,13 +884,59 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	return EMA_OK;
 }
 
-int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs, ema_batch_out **out)
+static int align_chunk(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs, ema_batch_out **out)
 {
 	int rc = ema_engine_stage(e, bases, off, n_pairs);
 	if (rc) return rc;
 	if ((rc = ema_engine_run(e))) return rc;
 	if ((rc = ema_engine_sync(e))) return rc;
 	return ema_engine_fetch(e, out);
+}
+
+// Any number of pairs: a bucket larger than the engine's batch capacity goes through in capacity-sized pieces whose
+// results are laid end to end (one call per bucket, as the reference's loop has it).
+int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs, ema_batch_out **out)
+{
+	if (!e || !bases || !off || !out) return EMA_EARG;
+	*out = nullptr;
+	if (n_pairs <= e->cap_pairs) return align_chunk(e, bases, off, n_pairs, out);
+	std::vector<ema_batch_out *> parts;
+	int rc = EMA_OK, worst = EMA_OK;
+	for (size_t p0 = 0; p0 < n_pairs; p0 += e->cap_pairs) {
+		const size_t np = std::min(e->cap_pairs, n_pairs - p0);
+		ema_batch_out *part = nullptr;
+		rc = align_chunk(e, bases, off + 2 * p0, np, &part);      // stage() rebases the offsets on off[2 * p0]
+		if (part) parts.push_back(part);
+		if (rc == EMA_ELIMIT && part) { worst = EMA_ELIMIT; continue; }      // flagged reads: keep going, report at the end
+		if (rc) { for (auto *q : parts) ema_batch_free(q); return rc; }
+	}
+	size_t n_cand = 0, n_cig = 0, n_redone = 0;
+	for (auto *q : parts) { n_cand += q->cand_off[2 * q->n_pairs]; n_cig += q->n_cigar; n_redone += q->n_redone; }
+	if (n_cig >= ((size_t)1 << 32)) {
+		for (auto *q : parts) ema_batch_free(q);
+		e->err = "more than 2^32 CIGAR operations in one call; split the input";
+		return EMA_ELIMIT;
+	}
+	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+	o->n_pairs = n_pairs; o->n_cigar = n_cig; o->n_redone = n_redone;
+	o->cand_off = (uint64_t *)malloc((2 * n_pairs + 1) * 8);
+	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
+	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
+	o->status = (int32_t *)malloc((2 * n_pairs + 1) * 4);
+	size_t r_at = 0, c_at = 0, g_at = 0;
+	for (auto *q : parts) {
+		const size_t nr = 2 * q->n_pairs, nc = q->cand_off[nr];
+		for (size_t r = 0; r < nr; ++r) o->cand_off[r_at + r] = c_at + q->cand_off[r];
+		memcpy(o->status + r_at, q->status, nr * 4);
+		memcpy(o->cand + c_at, q->cand, nc * sizeof(ema_cand_t));
+		for (size_t k = 0; k < nc; ++k) o->cand[c_at + k].cigar_off += (uint32_t)g_at;
+		memcpy(o->cigar + g_at, q->cigar, q->n_cigar * 4);
+		r_at += nr; c_at += nc; g_at += q->n_cigar;
+		ema_batch_free(q);
+	}
+	o->cand_off[2 * n_pairs] = c_at;
+	*out = o;
+	return worst;
 }
 
 void ema_batch_free(ema_batch_out *out)

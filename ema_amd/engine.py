@@ -258,6 +258,10 @@ class Engine:
             if p:
                 self._L.ema_batch_free(p)
             self._check(rc, "fetch")
+        return self._take(p)
+
+    def _take(self, p) -> Batch:
+        """Copies an ema_batch_out into numpy arrays and frees it."""
         try:
             o = p.contents
             n = o.n_pairs
@@ -271,6 +275,19 @@ class Engine:
         finally:
             self._L.ema_batch_free(p)
         return Batch(cand_off, cand, cigar, status, n_redone)
+
+    def align_pairs_any(self, bases: np.ndarray, off: np.ndarray) -> Batch:
+        """ema_engine_align_pairs itself (one C call; any number of pairs, worked through in capacity-sized pieces)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        p = C.POINTER(BatchOut)()
+        self._L.ema_engine_align_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(BatchOut))]
+        rc = self._L.ema_engine_align_pairs(self._h, bases.ctypes.data, off.ctypes.data, (len(off) - 1) // 2, C.byref(p))
+        if rc != 0:
+            if p:
+                self._L.ema_batch_free(p)
+            self._check(rc, "align_pairs")
+        return self._take(p)
 
     def align_pairs(self, bases: np.ndarray, off: np.ndarray) -> Batch:
         self.stage(bases, off)

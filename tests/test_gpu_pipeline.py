@@ -96,15 +96,20 @@ def test_pipeline_empty_and_ragged_batches():
     assert not compare(prefix, rag, batch)
 
 
-def test_capacity_is_enforced():
+def test_more_pairs_than_the_batch_capacity():
+    """ema_engine_align_pairs takes a whole bucket: beyond the engine's batch capacity it works in pieces and lays the
+    results end to end; the split form (stage) still refuses what does not fit."""
     prefix, ctg = small_ref("two_contigs")
     o = default_opts()
-    o.batch_pairs = 16
+    o.batch_pairs = 96
     eng = Engine(prefix, opts=o)
-    pairs = synth.make_pairs(ctg, 32, seed=46)
+    pairs = synth.make_pairs(ctg, 500, seed=46, sub_rate=0.02, indel_rate=0.002)
     with pytest.raises(RuntimeError):
-        eng.align_pairs(pairs.bases, pairs.off)
+        eng.stage(pairs.bases, pairs.off)
+    batch = eng.align_pairs_any(pairs.bases, pairs.off)
     eng.close()
+    assert batch.status.max() == 0 and len(batch.cand_off) == 2 * pairs.n + 1
+    assert not compare(prefix, pairs, batch)
 
 
 def test_two_capacity_tiers_give_the_same_candidates():

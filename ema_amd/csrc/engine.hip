@@ -323,7 +323,12 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = getenv("EMA_SEED_ROUNDS")) e->seed_rounds = std::max(1, std::min(8, atoi(v)));
 	if (const char *v = getenv("EMA_SEED_PARK")) e->seed_park_max = std::max(0, std::min(63, atoi(v)));
 	if (e->seed_park_max == 0) e->seed_rounds = 1;
-	e->seed_blocks = e->n_cu * ema_seed_blocks_per_cu();      // every resident lane carries one read
+	// K1: every lane of its grid carries one read at a time.  Half the lanes the chip could hold (2 of 4 blocks per CU):
+	// each lane then works through twice as many reads, so the drain at the end of a launch -- partly filled waves at
+	// full instruction cost -- is a smaller share, and the other slices' kernels use the issue slots left free
+	// (+6 % end to end; EMA_SEED_BLOCKS_PER_CU overrides).
+	e->seed_blocks = e->n_cu * std::min(ema_seed_blocks_per_cu(), 2);
+	if (const char *v = getenv("EMA_SEED_BLOCKS_PER_CU")) e->seed_blocks = e->n_cu * std::max(1, std::min(ema_seed_blocks_per_cu(), atoi(v)));
 	e->align_blocks = e->n_cu * ema_align_blocks_per_cu();    // one scratch slab per resident wave
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();

@@ -212,9 +212,20 @@ def main():
         dom_ms, iso_ms = kernel_ms["seed_ms"], kernel_ms_isolated["seed_ms"]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         isolated = dom_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
+        # HBM traffic of the same kernel: not measurable from inside this process -- taken from the committed PMC passes of this
+        # very command (profiles/, separate FETCH_SIZE and WRITE_SIZE runs; KB per launch, three launches per series), and
+        # only when this run is that default workload.
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_pmc_chr20_1Mpairs.csv")
+        if args.genome_mbp == 0 and args.pairs == 1048576 and n_slices == 3 and args.lean_seed_extends == 0 and os.path.exists(pmc):
+            import csv
+            kb = {r["counter"]: float(r["sum_over_run"]) / (float(r["launches"]) / 3.0) for r in csv.DictReader(open(pmc))
+                  if r["kernel"] == "ema_k_seed" and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE")}
+            if len(kb) == 2:
+                traffic = int((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024)
         roofline = {"bound": "hbm", "kernel": "ema_k_seed",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(dom_bytes), "kernel_ms": round(dom_ms, 3),
                     "note": f"one launch = one of {n_slices} slices of the batch; in the timed region launches of different slices "
                             f"and kernels run concurrently and share the chip, so the per-launch rate understates the kernel: "

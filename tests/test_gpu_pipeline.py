@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 FIELDS = [f for f in O.REG_FIELDS]
 
 
-def compare(prefix, pairs, batch):
-    idx, opt = O.Index(prefix), O.default_opt()
+def compare(prefix, pairs, batch, opt=None):
+    idx = O.Index(prefix)
+    opt = opt if opt is not None else O.default_opt()
     bad = []
     for p in range(pairs.n):
         ref = O.align_pair(idx, opt, pairs.read(2 * p), pairs.read(2 * p + 1))
@@ -34,14 +35,14 @@ def compare(prefix, pairs, batch):
     return bad
 
 
-def _check(kind, n_pairs, seed, **kw):
+def _check(kind, n_pairs, seed, eopts=None, oopt=None, **kw):
     prefix, ctg = small_ref(kind)
     pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
-    eng = Engine(prefix)
+    eng = Engine(prefix, opts=eopts)
     batch = eng.align_pairs(pairs.bases, pairs.off)
     eng.close()
     assert batch.status.max() == 0
-    bad = compare(prefix, pairs, batch)
+    bad = compare(prefix, pairs, batch, oopt)
     assert not bad, f"{len(bad)} of {2 * pairs.n} reads differ from the oracle, first {bad[:5]}"
 
 
@@ -57,6 +58,27 @@ def test_pipeline_few_mismatches():
     """2 % substitutions, no indels: most reads have 1-4 mismatches, i.e. extensions and final alignments right at the
     limits of the known-outcome shortcuts (one mismatch on the diagonal; equal spans with <= 3 mismatches are all-M)."""
     _check("two_contigs", 800, 51, sub_rate=0.02, indel_rate=0.0)
+
+
+def test_pipeline_other_scoring():
+    """Non-default match/mismatch/gap scores (asymmetric gap costs): the known-outcome shortcuts carry conditions on the
+    scoring parameters, and every DP takes them from the options."""
+    eo = default_opts()
+    oo = O.default_opt()
+    for o in (eo, oo):
+        o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins = 2, 3, 5, 2, 4, 2
+    for i in range(5):
+        for j in range(5):
+            oo.mat[i * 5 + j] = -1 if i == 4 or j == 4 else (oo.a if i == j else -oo.b)
+    _check("two_contigs", 500, 53, eopts=eo, oopt=oo, sub_rate=0.02, indel_rate=0.002)
+    # mismatches cheaper than the shortcuts' conditions allow (a + b >= the cheapest gap): the DPs must run
+    eo2, oo2 = default_opts(), O.default_opt()
+    for o in (eo2, oo2):
+        o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins = 1, 7, 2, 1, 2, 1
+    for i in range(5):
+        for j in range(5):
+            oo2.mat[i * 5 + j] = -1 if i == 4 or j == 4 else (oo2.a if i == j else -oo2.b)
+    _check("two_contigs", 300, 54, eopts=eo2, oopt=oo2, sub_rate=0.02, indel_rate=0.002)
 
 
 def test_pipeline_250bp():

@@ -208,6 +208,7 @@ struct ema_engine {
 	int dbg_slots = 0;
 	double watchdog_s = 0;               // EMA_WATCHDOG_S=<seconds>: poll after every launch, report stuck waves
 	ema_engine_timing timing;
+	ema_engine *shadow = nullptr;        // second set of batch buffers and streams on the same index: align_pairs on big inputs
 };
 
 #define HIPCHK(e, call)                                                                              \
@@ -381,6 +382,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 void ema_engine_close(ema_engine_t *e)
 {
 	if (!e) return;
+	if (e->shadow) { ema_engine_close(e->shadow); e->shadow = nullptr; }
 	(void)hipSetDevice(e->device);
 	(void)hipDeviceSynchronize();
 	e->d_k1w_args.release();
@@ -905,15 +907,38 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 	if (!e || !bases || !off || !out) return EMA_EARG;
 	*out = nullptr;
 	if (n_pairs <= e->cap_pairs) return align_chunk(e, bases, off, n_pairs, out);
-	std::vector<ema_batch_out *> parts;
-	int rc = EMA_OK, worst = EMA_OK;
-	for (size_t p0 = 0; p0 < n_pairs; p0 += e->cap_pairs) {
-		const size_t np = std::min(e->cap_pairs, n_pairs - p0);
-		ema_batch_out *part = nullptr;
-		rc = align_chunk(e, bases, off + 2 * p0, np, &part);      // stage() rebases the offsets on off[2 * p0]
-		if (part) parts.push_back(part);
-		if (rc == EMA_ELIMIT && part) { worst = EMA_ELIMIT; continue; }      // flagged reads: keep going, report at the end
-		if (rc) { for (auto *q : parts) ema_batch_free(q); return rc; }
+	// Two sets of batch buffers take alternate pieces from two host threads, so that one piece's staging and fetching
+	// overlap the other's kernels (the second set is created on first use; EMA_ALIGN_PIPELINE=0: one set, in sequence).
+	const size_t n_parts = (n_pairs + e->cap_pairs - 1) / e->cap_pairs;
+	std::vector<ema_batch_out *> parts(n_parts, nullptr);
+	std::vector<int> rcs(n_parts, EMA_OK);
+	const char *pv = getenv("EMA_ALIGN_PIPELINE");
+	if (!e->shadow && !(pv && atoi(pv) == 0)) {
+		ema_engine_t *sh = nullptr;
+		if (engine_open(nullptr, e, e->device, &e->opts, &sh) == EMA_OK) e->shadow = sh;
+		else if (sh) ema_engine_close(sh);      // not enough memory for a second set: fall back to one
+	}
+	auto work = [&](ema_engine_t *g, size_t first) {
+		for (size_t k = first; k < n_parts; k += (e->shadow ? 2 : 1)) {
+			const size_t p0 = k * e->cap_pairs, np = std::min(e->cap_pairs, n_pairs - p0);
+			rcs[k] = align_chunk(g, bases, off + 2 * p0, np, &parts[k]);      // stage() rebases the offsets on off[2 * p0]
+			if (rcs[k] != EMA_OK && rcs[k] != EMA_ELIMIT) break;
+		}
+	};
+	if (e->shadow) {
+		std::thread other(work, e->shadow, (size_t)1);
+		work(e, 0);
+		other.join();
+	} else work(e, 0);
+	int worst = EMA_OK;
+	for (size_t k = 0; k < n_parts; ++k) {
+		if (rcs[k] == EMA_ELIMIT && parts[k]) { worst = EMA_ELIMIT; continue; }      // flagged reads: report at the end
+		if (rcs[k] != EMA_OK || !parts[k]) {
+			if ((k & 1) && e->shadow && rcs[k] != EMA_OK) e->err = e->shadow->err;
+			const int rc = rcs[k] != EMA_OK ? rcs[k] : EMA_ESTATE;
+			for (auto *q : parts) if (q) ema_batch_free(q);
+			return rc;
+		}
 	}
 	size_t n_cand = 0, n_cig = 0, n_redone = 0;
 	for (auto *q : parts) { n_cand += q->cand_off[2 * q->n_pairs]; n_cig += q->n_cigar; n_redone += q->n_redone; }
@@ -928,18 +953,32 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
 	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
 	o->status = (int32_t *)malloc((2 * n_pairs + 1) * 4);
-	size_t r_at = 0, c_at = 0, g_at = 0;
-	for (auto *q : parts) {
-		const size_t nr = 2 * q->n_pairs, nc = q->cand_off[nr];
-		for (size_t r = 0; r < nr; ++r) o->cand_off[r_at + r] = c_at + q->cand_off[r];
-		memcpy(o->status + r_at, q->status, nr * 4);
-		memcpy(o->cand + c_at, q->cand, nc * sizeof(ema_cand_t));
-		for (size_t k = 0; k < nc; ++k) o->cand[c_at + k].cigar_off += (uint32_t)g_at;
-		memcpy(o->cigar + g_at, q->cigar, q->n_cigar * 4);
-		r_at += nr; c_at += nc; g_at += q->n_cigar;
-		ema_batch_free(q);
+	// each piece lands at its own offsets: one host thread per piece (the copies also first-touch the new pages)
+	std::vector<size_t> r_at(n_parts + 1, 0), c_at(n_parts + 1, 0), g_at(n_parts + 1, 0);
+	for (size_t k = 0; k < n_parts; ++k) {
+		r_at[k + 1] = r_at[k] + 2 * parts[k]->n_pairs;
+		c_at[k + 1] = c_at[k] + parts[k]->cand_off[2 * parts[k]->n_pairs];
+		g_at[k + 1] = g_at[k] + parts[k]->n_cigar;
 	}
-	o->cand_off[2 * n_pairs] = c_at;
+	auto place = [&](size_t k) {
+		ema_batch_out *q = parts[k];
+		const size_t nr = 2 * q->n_pairs, nc = q->cand_off[nr];
+		for (size_t r = 0; r < nr; ++r) o->cand_off[r_at[k] + r] = c_at[k] + q->cand_off[r];
+		memcpy(o->status + r_at[k], q->status, nr * 4);
+		memcpy(o->cand + c_at[k], q->cand, nc * sizeof(ema_cand_t));
+		for (size_t i = 0; i < nc; ++i) o->cand[c_at[k] + i].cigar_off += (uint32_t)g_at[k];
+		memcpy(o->cigar + g_at[k], q->cigar, q->n_cigar * 4);
+		ema_batch_free(q);
+	};
+	{
+		const size_t n_thr = std::min<size_t>(n_parts, 16);
+		auto lane = [&](size_t first) { for (size_t k = first; k < n_parts; k += n_thr) place(k); };
+		std::vector<std::thread> th;
+		for (size_t t = 1; t < n_thr; ++t) th.emplace_back(lane, t);
+		lane(0);
+		for (auto &t : th) t.join();
+	}
+	o->cand_off[2 * n_pairs] = c_at[n_parts];
 	*out = o;
 	return worst;
 }

@@ -107,7 +107,8 @@ typedef struct {
 /* Whole hot path for a batch: reads are ASCII, read r at bases[off[r] .. off[r+1]);
  * mate 1 of pair i is read 2i, mate 2 is read 2i+1 (off has 2*n_pairs+1 entries).
  * *out is allocated by the engine; free it with ema_batch_free().  n_pairs may exceed ema_engine_batch_capacity(): the
- * call then works through the input in capacity-sized pieces. */
+ * call then works through the input in capacity-sized pieces, alternating over two sets of batch buffers (the second one
+ * is created on first need and lives as long as the engine; EMA_ALIGN_PIPELINE=0 in the environment keeps it to one). */
 int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs, ema_batch_out **out);
 void ema_batch_free(ema_batch_out *out);
 

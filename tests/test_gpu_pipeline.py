@@ -118,9 +118,12 @@ def test_pipeline_empty_and_ragged_batches():
     assert not compare(prefix, rag, batch)
 
 
-def test_more_pairs_than_the_batch_capacity():
-    """ema_engine_align_pairs takes a whole bucket: beyond the engine's batch capacity it works in pieces and lays the
-    results end to end; the split form (stage) still refuses what does not fit."""
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_more_pairs_than_the_batch_capacity(pipeline, monkeypatch):
+    """ema_engine_align_pairs takes a whole bucket: beyond the engine's batch capacity it works in pieces (alternating
+    over two sets of batch buffers, or over one with EMA_ALIGN_PIPELINE=0) and lays the results end to end; the split
+    form (stage) still refuses what does not fit."""
+    monkeypatch.setenv("EMA_ALIGN_PIPELINE", pipeline)
     prefix, ctg = small_ref("two_contigs")
     o = default_opts()
     o.batch_pairs = 96

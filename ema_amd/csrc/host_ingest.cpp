@@ -1,0 +1,403 @@
+// ema_amd/csrc/host_ingest.cpp -- bucket reader in front of the hot path (include/ema_ingest.h).
+//
+// What the reference does per bucket, one line at a time on one thread -- count_lines, fgets + malloc + strcpy per line,
+// qsort of the line pointers by strncmp(.., BC_LEN), six copy_until_space calls into 568-byte FASTQRecords (reference
+// src/align.c:759-806, src/util.c:11-21,97-106) -- is here five data-parallel passes over the mapped file on the host's
+// cores, producing the engine's input layout directly:
+//   1. newline scan: per-chunk counts, prefix, line table (start, length);
+//   2. sort keys: the first bc_len bytes of each line, cut at the line's end and zero-padded (what strncmp sees: the
+//      buffer holds the line, its '\n', then NUL), as big-endian words + the line number, so that an ordinary sort is
+//      the stable order; chunk sorts and a merge tree;
+//   3. field extents of every line in sorted order, validation, lengths;
+//   4. prefix sums -> off[], id_off[];
+//   5. copies of bases / qualities / identifiers, barcode encoding (encode_bc, src/util.c:41-76), barcode groups
+//      (seek_next_barcode_group's runs of equal bc, src/align.c:829-837).
+// No GPU work: parsing is byte-serial per line and the payload crosses PCIe once, as 2-bit packed reads, in
+// ema_engine_stage.
+#include <algorithm>
+#include <chrono>
+#include <array>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include "ema_ingest.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+const size_t kMaxLine = 4999;      // fgets(buf, 5000): at most 4999 bytes per call, '\n' included (src/align.c:762,768)
+const size_t kMaxId = 149;         // id[150] (include/samrecord.h:12)
+
+int n_threads()
+{
+	static int n = [] {
+		const char *v = getenv("EMA_HOST_THREADS");
+		int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
+		return t < 1 ? 1 : t > 32 ? 32 : t;
+	}();
+	return n;
+}
+
+// fn(k, b, e) on contiguous ranges of [0, n), one per thread
+template <typename F> void parallel_ranges(size_t n, size_t min_per_thread, F fn)
+{
+	size_t t = std::min<size_t>((size_t)n_threads(), n / std::max<size_t>(min_per_thread, 1));
+	if (t <= 1) { fn((size_t)0, (size_t)0, n); return; }
+	const size_t per = (n + t - 1) / t;
+	std::vector<std::thread> th;
+	for (size_t k = 0; k < t; ++k) {
+		const size_t b = k * per, e = std::min(n, b + per);
+		if (b < e) th.emplace_back([=] { fn(k, b, e); });
+	}
+	for (auto &x : th) x.join();
+}
+
+// isspace() in the "C" locale, which is what the reference runs in (it never calls setlocale)
+inline bool is_space(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+struct Line { uint64_t start; uint32_t len; };      // len counts the '\n' when the line has one
+
+template <int W> struct Key {
+	std::array<uint64_t, W> w;      // key bytes, big-endian, so that word order is byte order
+	uint32_t line;
+	bool operator<(const Key &o) const
+	{
+		for (int i = 0; i < W; ++i) if (w[i] != o.w[i]) return w[i] < o.w[i];
+		return line < o.line;
+	}
+};
+
+template <int W> void sorted_lines(const char *text, const std::vector<Line> &lines, int bc_len, std::vector<uint32_t> &order)
+{
+	const size_t n = lines.size();
+	std::vector<Key<W>> a(n), b;
+	parallel_ranges(n, 1 << 14, [&](size_t, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			unsigned char k[8 * W];
+			memset(k, 0, sizeof k);
+			const unsigned char *p = (const unsigned char *)text + lines[i].start;
+			const size_t m = std::min<size_t>((size_t)bc_len, lines[i].len);
+			for (size_t j = 0; j < m && p[j]; ++j) k[j] = p[j];      // strncmp stops at a NUL
+			for (int x = 0; x < W; ++x) {
+				uint64_t v = 0;
+				for (int j = 0; j < 8; ++j) v = v << 8 | k[8 * x + j];
+				a[i].w[x] = v;
+			}
+			a[i].line = (uint32_t)i;
+		}
+	});
+	// chunk sorts, then a merge tree between the two buffers
+	size_t t = 1;
+	while (t * 2 <= (size_t)n_threads() && n / (t * 2) >= (1 << 14)) t *= 2;
+	const size_t per = (n + t - 1) / t;
+	auto lo_of = [&](size_t k) { return std::min(n, k * per); };
+	{
+		std::vector<std::thread> th;
+		for (size_t k = 1; k < t; ++k) th.emplace_back([&, k] { std::sort(a.begin() + lo_of(k), a.begin() + lo_of(k + 1)); });
+		std::sort(a.begin() + lo_of(0), a.begin() + lo_of(1));
+		for (auto &x : th) x.join();
+	}
+	if (t > 1) b.resize(n);
+	std::vector<Key<W>> *src = &a, *dst = &b;
+	for (size_t width = 1; width < t; width *= 2) {
+		std::vector<std::thread> th;
+		for (size_t k = 0; k < t; k += 2 * width) {
+			const size_t l = lo_of(k), m = lo_of(std::min(t, k + width)), r = lo_of(std::min(t, k + 2 * width));
+			th.emplace_back([=] { std::merge(src->begin() + l, src->begin() + m, src->begin() + m, src->begin() + r, dst->begin() + l); });
+		}
+		for (auto &x : th) x.join();
+		std::swap(src, dst);
+	}
+	order.resize(n);
+	const std::vector<Key<W>> &s = *src;
+	parallel_ranges(n, 1 << 16, [&](size_t, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) order[i] = s[i].line; });
+}
+
+struct Fields { uint16_t id_b, id_l, r1_b, r1_l, q1_b, r2_b, r2_l, q2_b; };      // byte offsets within the line
+
+enum Bad : uint8_t { kOk = 0, kLong, kFew, kBcLen, kBcBase, kIdEmpty, kIdLong, kReadLong, kQualLen };
+const char *const kBadText[] = {"", "line of 5000 bytes or more", "fewer than six fields", "barcode field is not bc_len bytes",
+                                "barcode has a byte outside ACGT/acgt", "empty identifier", "identifier longer than 149 bytes",
+                                "read longer than max_read_len", "quality string and read differ in length"};
+
+// End of the field that starts at s[at]: the first whitespace or NUL at or after it (or len).  Eight bytes at a time:
+// bases, qualities and identifiers are all above ' ', so a word with no byte below 0x21 cannot hold a separator.
+inline size_t field_end(const char *s, size_t at, size_t len)
+{
+	while (at + 8 <= len) {
+		uint64_t x;
+		memcpy(&x, s + at, 8);
+		const uint64_t low = (x - 0x2121212121212121ULL) & ~x & 0x8080808080808080ULL;      // lowest flag = first byte < 0x21
+		if (!low) { at += 8; continue; }
+		at += (size_t)__builtin_ctzll(low) >> 3;
+		if (!s[at] || is_space((unsigned char)s[at])) return at;
+		++at;      // some other control byte: part of the field
+	}
+	while (at < len && s[at] && !is_space((unsigned char)s[at])) ++at;
+	return at;
+}
+
+// One field as copy_until_space reads it (src/util.c:11-21): bytes up to the next whitespace or NUL, then one byte skipped.
+inline bool next_field(const char *s, size_t len, size_t &at, size_t &b, size_t &l)
+{
+	if (at > len) return false;      // the previous field ran into the end of the line: nothing left to read
+	b = at;
+	at = field_end(s, at, len);
+	l = at - b;
+	at = (at < len && s[at]) ? at + 1 : len + 1;
+	return true;
+}
+
+int encode_default(const char *bc, int bc_len, uint64_t *out)
+{
+	uint64_t v = 0;
+	for (int i = bc_len - 1; i >= 0; --i) {      // first base in the lowest two bits
+		uint64_t c;
+		switch (bc[i]) {
+		case 'A': case 'a': c = 0; break;
+		case 'C': case 'c': c = 1; break;
+		case 'G': case 'g': c = 2; break;
+		case 'T': case 't': c = 3; break;
+		default: return EMA_EFORMAT;
+		}
+		v = v << 2 | c;
+	}
+	*out = v;
+	return 0;
+}
+
+uint64_t encode_haplotag(const char *s)
+{
+	// AxxCxxBxxDxx: the four two-digit numbers, A and C in the upper half, B and D in the lower (src/util.c:63-70);
+	// the same int arithmetic as the reference's macros, whatever the bytes are
+	auto two = [](const char *p) { return 10 * (p[0] - '0') + (p[1] - '0'); };
+	const uint32_t a = (uint32_t)two(s + 1), c = (uint32_t)two(s + 4), b = (uint32_t)two(s + 7), d = (uint32_t)two(s + 10);
+	return (uint64_t)(uint32_t)(a << 24 | c << 16 | b << 8 | d);
+}
+
+int fail(int rc, const std::string &m) { g_err = m; return rc; }
+
+}  // namespace
+
+extern "C" {
+
+const char *ema_bucket_last_error(void) { return g_err.c_str(); }
+
+int ema_barcode_encode(const char *bc, int bc_len, int is_haplotag, uint64_t *out)
+{
+	if (!bc || !out) return EMA_EARG;
+	if (is_haplotag) { *out = encode_haplotag(bc); return 0; }
+	if (bc_len < 1 || bc_len > 32) return EMA_EARG;
+	return encode_default(bc, bc_len, out);
+}
+
+void ema_barcode_decode(uint64_t bc, int bc_len, int is_haplotag, char *out)
+{
+	if (is_haplotag) {      // decode_bc_haplotag, src/util.c:86-89
+		char t[16];
+		snprintf(t, sizeof t, "A%02uC%02uB%02uD%02u", (unsigned)(bc >> 24) & 127, (unsigned)(bc >> 16) & 127,
+		         (unsigned)(bc >> 8) & 127, (unsigned)bc & 127);
+		memcpy(out, t, 12);
+		return;
+	}
+	for (int i = 0; i < bc_len; ++i) { out[i] = "ACGT"[bc & 3]; bc >>= 2; }      // decode_bc_default, src/util.c:78-84
+}
+
+void ema_bucket_free(ema_bucket *b)
+{
+	if (!b) return;
+	free(b->group_off); free(b->bc); free(b->off); free(b->bases); free(b->quals); free(b->id_off); free(b->ids);
+	free(b);
+}
+
+int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out)
+{
+	if (!out) return EMA_EARG;
+	*out = nullptr;
+	g_err.clear();
+	if ((!text && len) || bc_len < 1 || bc_len > 32 || max_read_len < 1 || max_read_len > 4096 || (is_haplotag && bc_len != 12))
+		return fail(EMA_EARG, "bad argument");
+	const bool prof = getenv("EMA_INGEST_PROF") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto t0 = now();
+	auto lap = [&](const char *what) { if (prof) { auto t = now(); fprintf(stderr, "[ingest] %-8s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; } };
+	// 1. lines and fields, in file order: each thread takes the lines that START in its stretch of the text
+	const size_t t_scan = std::max<size_t>(1, std::min<size_t>((size_t)n_threads(), len >> 20));
+	const size_t per = (len + t_scan - 1) / t_scan;
+	struct Part { std::vector<Line> lines; std::vector<Fields> fields; size_t bad_line = (size_t)-1; Bad bad = kOk; };
+	std::vector<Part> parts(t_scan);
+	auto scan = [&](size_t k) {
+		Part &pt = parts[k];
+		const size_t b = std::min(len, k * per), e = std::min(len, b + per);
+		size_t at = b;
+		if (k) {      // the line that straddles b belongs to the stretch before
+			const char *q = (const char *)memchr(text + b - 1, '\n', len - (b - 1));
+			at = q ? (size_t)(q - text) + 1 : len;
+		}
+		pt.lines.reserve((e - b) / 256 + 16); pt.fields.reserve((e - b) / 256 + 16);
+		while (at < e && at < len) {
+			const char *s = text + at;
+			const size_t room = len - at;
+			Fields f{};
+			Bad bad = kOk;
+			const char *q = (const char *)memchr(s, '\n', room);
+			const size_t ln = q ? (size_t)(q - s) + 1 : room;      // the '\n' counts, as in fgets' buffer
+			size_t p = 0, fb[6] = {0}, fl[6] = {0};
+			bool six = ln <= kMaxLine;
+			for (int x = 0; x < 6 && six; ++x) six = next_field(s, ln, p, fb[x], fl[x]);
+			if (ln > kMaxLine) bad = kLong;
+			else if (!six) bad = kFew;
+			else if (fl[0] != (size_t)bc_len) bad = kBcLen;
+			else if (fl[1] == 0) bad = kIdEmpty;
+			else if (fl[1] > kMaxId) bad = kIdLong;
+			else if (fl[2] > (size_t)max_read_len || fl[4] > (size_t)max_read_len) bad = kReadLong;
+			else if (fl[3] != fl[2] || fl[5] != fl[4]) bad = kQualLen;
+			if (bad == kOk) {
+				f.id_b = (uint16_t)fb[1]; f.id_l = (uint16_t)fl[1];
+				f.r1_b = (uint16_t)fb[2]; f.r1_l = (uint16_t)fl[2]; f.q1_b = (uint16_t)fb[3];
+				f.r2_b = (uint16_t)fb[4]; f.r2_l = (uint16_t)fl[4]; f.q2_b = (uint16_t)fb[5];
+			} else if (pt.bad == kOk) { pt.bad = bad; pt.bad_line = pt.lines.size(); }
+			pt.lines.push_back(Line{(uint64_t)at, (uint32_t)std::min<size_t>(ln, UINT32_MAX)});
+			pt.fields.push_back(f);
+			at += ln;
+		}
+	};
+	{
+		std::vector<std::thread> th;
+		for (size_t k = 1; k < t_scan; ++k) th.emplace_back(scan, k);
+		scan(0);
+		for (auto &x : th) x.join();
+	}
+	std::vector<size_t> first(t_scan + 1, 0);
+	for (size_t k = 0; k < t_scan; ++k) first[k + 1] = first[k] + parts[k].lines.size();
+	const size_t n = first[t_scan];
+	if (n >= UINT32_MAX) return fail(EMA_EARG, "more than 2^32 lines in one bucket");
+	for (size_t k = 0; k < t_scan; ++k)
+		if (parts[k].bad != kOk)
+			return fail(EMA_EFORMAT, "line " + std::to_string(first[k] + parts[k].bad_line + 1) + ": " + kBadText[parts[k].bad]);
+	std::vector<Line> lines(n);
+	std::vector<Fields> fields(n);      // by line number
+	{
+		std::vector<std::thread> th;
+		auto gather = [&](size_t k) {
+			std::copy(parts[k].lines.begin(), parts[k].lines.end(), lines.begin() + first[k]);
+			std::copy(parts[k].fields.begin(), parts[k].fields.end(), fields.begin() + first[k]);
+			std::vector<Line>().swap(parts[k].lines); std::vector<Fields>().swap(parts[k].fields);
+		};
+		for (size_t k = 1; k < t_scan; ++k) th.emplace_back(gather, k);
+		gather(0);
+		for (auto &x : th) x.join();
+	}
+	lap("scan");
+	// 2. order
+	std::vector<uint32_t> order;
+	switch ((bc_len + 7) / 8) {
+	case 1: sorted_lines<1>(text, lines, bc_len, order); break;
+	case 2: sorted_lines<2>(text, lines, bc_len, order); break;
+	case 3: sorted_lines<3>(text, lines, bc_len, order); break;
+	default: sorted_lines<4>(text, lines, bc_len, order); break;
+	}
+	lap("order");
+	// 3. barcodes, in sorted order
+	ema_bucket *o = (ema_bucket *)calloc(1, sizeof(ema_bucket));
+	o->n_pairs = n;
+	o->bc = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+	o->off = (uint32_t *)malloc((2 * n + 1) * sizeof(uint32_t));
+	o->id_off = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+	std::vector<size_t> bad_bc((size_t)n_threads() + 1, (size_t)-1);
+	parallel_ranges(n, 1 << 12, [&](size_t k, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			const char *s = text + lines[order[i]].start;
+			if (is_haplotag) o->bc[i] = encode_haplotag(s);
+			else if (encode_default(s, bc_len, &o->bc[i])) { o->bc[i] = 0; bad_bc[k] = std::min<size_t>(bad_bc[k], order[i]); }
+		}
+	});
+	{
+		const size_t worst = *std::min_element(bad_bc.begin(), bad_bc.end());
+		if (worst != (size_t)-1) {
+			ema_bucket_free(o);
+			return fail(EMA_EFORMAT, "line " + std::to_string(worst + 1) + ": " + kBadText[kBcBase]);
+		}
+	}
+	lap("barcodes");
+	// 4. offsets
+	uint64_t nb = 0, ni = 0;
+	for (size_t i = 0; i < n; ++i) {
+		const Fields &f = fields[order[i]];
+		o->off[2 * i] = (uint32_t)nb; nb += f.r1_l;
+		o->off[2 * i + 1] = (uint32_t)nb; nb += f.r2_l;
+		o->id_off[i] = (uint32_t)ni; ni += f.id_l;
+		if (nb > UINT32_MAX || ni > UINT32_MAX) { ema_bucket_free(o); return fail(EMA_EARG, "more than 4 GiB of bases or identifiers in one bucket; split it"); }
+	}
+	o->off[2 * n] = (uint32_t)nb;
+	o->id_off[n] = (uint32_t)ni;
+	o->bases = (char *)malloc(nb + 1);
+	o->quals = (char *)malloc(nb + 1);
+	o->ids = (char *)malloc(ni + 1);
+	lap("offsets");
+	// 5. payload
+	parallel_ranges(n, 1 << 12, [&](size_t, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			const char *s = text + lines[order[i]].start;
+			const Fields &f = fields[order[i]];
+			memcpy(o->bases + o->off[2 * i], s + f.r1_b, f.r1_l);
+			memcpy(o->quals + o->off[2 * i], s + f.q1_b, f.r1_l);
+			memcpy(o->bases + o->off[2 * i + 1], s + f.r2_b, f.r2_l);
+			memcpy(o->quals + o->off[2 * i + 1], s + f.q2_b, f.r2_l);
+			memcpy(o->ids + o->id_off[i], s + f.id_b, f.id_l);
+		}
+	});
+	lap("payload");
+	size_t n_groups = 0;
+	for (size_t i = 0; i < n; ++i) n_groups += (i == 0 || o->bc[i] != o->bc[i - 1]);
+	o->n_groups = n_groups;
+	o->group_off = (uint64_t *)malloc((n_groups + 1) * sizeof(uint64_t));
+	size_t g = 0;
+	for (size_t i = 0; i < n; ++i) if (i == 0 || o->bc[i] != o->bc[i - 1]) o->group_off[g++] = i;
+	o->group_off[n_groups] = n;
+	lap("groups");
+	*out = o;
+	return 0;
+}
+
+int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out)
+{
+	if (!out) return EMA_EARG;
+	*out = nullptr;
+	g_err.clear();
+	if (!path) return fail(EMA_EARG, "bad argument");
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) return fail(EMA_EIO, std::string(path) + ": " + strerror(errno));
+	struct stat st;
+	if (fstat(fd, &st) != 0) { const int e = errno; close(fd); return fail(EMA_EIO, std::string(path) + ": " + strerror(e)); }
+	int rc;
+	if (S_ISREG(st.st_mode)) {
+		const size_t len = (size_t)st.st_size;
+		if (len == 0) { close(fd); return ema_bucket_parse(nullptr, 0, bc_len, is_haplotag, max_read_len, out); }
+		void *m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (m == MAP_FAILED) { const int e = errno; close(fd); return fail(EMA_EIO, std::string(path) + ": mmap: " + strerror(e)); }
+		madvise(m, len, MADV_WILLNEED);
+		rc = ema_bucket_parse((const char *)m, len, bc_len, is_haplotag, max_read_len, out);
+		munmap(m, len);
+	} else {      // a pipe or a device: read it whole
+		std::vector<char> buf;
+		char tmp[1 << 16];
+		ssize_t got;
+		while ((got = read(fd, tmp, sizeof tmp)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+		if (got < 0) { const int e = errno; close(fd); return fail(EMA_EIO, std::string(path) + ": " + strerror(e)); }
+		rc = ema_bucket_parse(buf.data(), buf.size(), bc_len, is_haplotag, max_read_len, out);
+	}
+	close(fd);
+	return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""Host mirror of the bucket reader (include/ema_ingest.h): the reference's read_special_fastq + barcode grouping
+(reference src/align.c:759-843) as one call whose result is the engine's input layout.  ctypes over the C ABI in
+libema_engine.so; no fallback -- a missing library raises."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import engine as _engine
+
+EMA_EIO, EMA_EFORMAT = -6, -7
+
+
+class _Bucket(C.Structure):
+    _fields_ = [("n_pairs", C.c_size_t), ("n_groups", C.c_size_t), ("group_off", C.POINTER(C.c_uint64)),
+                ("bc", C.POINTER(C.c_uint64)), ("off", C.POINTER(C.c_uint32)), ("bases", C.POINTER(C.c_char)),
+                ("quals", C.POINTER(C.c_char)), ("id_off", C.POINTER(C.c_uint32)), ("ids", C.POINTER(C.c_char))]
+
+
+@dataclass
+class Bucket:
+    """One barcode bucket, ordered as the reference orders it.  bases/off are what Engine.align_pairs takes."""
+    bc: np.ndarray          # u64 per pair
+    group_off: np.ndarray   # u64, n_groups + 1
+    off: np.ndarray         # u32, 2 * n_pairs + 1
+    bases: np.ndarray       # u8
+    quals: np.ndarray       # u8, same offsets as bases
+    id_off: np.ndarray      # u32, n_pairs + 1
+    ids: np.ndarray         # u8
+
+    @property
+    def n_pairs(self) -> int:
+        return len(self.bc)
+
+    def read(self, r: int) -> bytes:
+        return self.bases[self.off[r]:self.off[r + 1]].tobytes()
+
+    def qual(self, r: int) -> bytes:
+        return self.quals[self.off[r]:self.off[r + 1]].tobytes()
+
+    def ident(self, p: int) -> bytes:
+        return self.ids[self.id_off[p]:self.id_off[p + 1]].tobytes()
+
+
+def _lib():
+    L = _engine.load_library()
+    if not getattr(L, "_ingest_bound", False):
+        L.ema_bucket_read.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(_Bucket))]
+        L.ema_bucket_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(_Bucket))]
+        L.ema_bucket_free.argtypes = [C.POINTER(_Bucket)]
+        L.ema_bucket_last_error.restype = C.c_char_p
+        L.ema_barcode_encode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.ema_barcode_decode.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_char_p]
+        L._ingest_bound = True
+    return L
+
+
+class BucketError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"bucket reader: {msg} (code {code})")
+        self.code = code
+
+
+def _take(L, p) -> Bucket:
+    try:
+        b = p.contents
+        n, g = b.n_pairs, b.n_groups
+
+        def arr(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dt).itemsize,)).view(dt).copy()
+        off = arr(b.off, 2 * n + 1, np.uint32)
+        id_off = arr(b.id_off, n + 1, np.uint32)
+        return Bucket(arr(b.bc, n, np.uint64), arr(b.group_off, g + 1, np.uint64), off, arr(b.bases, int(off[-1]), np.uint8),
+                      arr(b.quals, int(off[-1]), np.uint8), id_off, arr(b.ids, int(id_off[-1]), np.uint8))
+    finally:
+        L.ema_bucket_free(p)
+
+
+def read_bucket(path: str, bc_len: int = 16, is_haplotag: bool = False, max_read_len: int = 255) -> Bucket:
+    L = _lib()
+    p = C.POINTER(_Bucket)()
+    rc = L.ema_bucket_read(path.encode(), bc_len, int(is_haplotag), max_read_len, C.byref(p))
+    if rc != 0:
+        raise BucketError(rc, L.ema_bucket_last_error().decode())
+    return _take(L, p)
+
+
+def parse_bucket(text: bytes, bc_len: int = 16, is_haplotag: bool = False, max_read_len: int = 255) -> Bucket:
+    L = _lib()
+    p = C.POINTER(_Bucket)()
+    rc = L.ema_bucket_parse(text, len(text), bc_len, int(is_haplotag), max_read_len, C.byref(p))
+    if rc != 0:
+        raise BucketError(rc, L.ema_bucket_last_error().decode())
+    return _take(L, p)
+
+
+def encode_barcode(bc: bytes, is_haplotag: bool = False) -> int:
+    L = _lib()
+    v = C.c_uint64()
+    rc = L.ema_barcode_encode(bc, len(bc), int(is_haplotag), C.byref(v))
+    if rc != 0:
+        raise BucketError(rc, "bad barcode")
+    return v.value
+
+
+def decode_barcode(bc: int, bc_len: int = 16, is_haplotag: bool = False) -> bytes:
+    L = _lib()
+    buf = C.create_string_buffer(40)
+    L.ema_barcode_decode(bc, bc_len, int(is_haplotag), buf)
+    return buf.raw[:12 if is_haplotag else bc_len]

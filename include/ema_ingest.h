@@ -1,0 +1,70 @@
+/* include/ema_ingest.h -- C ABI of the bucket reader in front of the hot path.
+ *
+ * Replaces, on the reference's side, read_special_fastq() (reference src/align.c:759-806) together with the grouping
+ * that seek_next_barcode_group() (src/align.c:808-843) does on its result: one barcode bucket in the "special FASTQ"
+ * form written by `ema preproc` -- one pair per line,
+ *
+ *     BARCODE ID READ1 QUAL1 READ2 QUAL2
+ *
+ * fields separated by one whitespace character (copy_until_space, src/util.c:11-21) -- is read, ordered by its first
+ * bc_len bytes exactly as the reference's qsort()/strncmp() comparison orders the lines (src/align.c:751-757, :773),
+ * pairs of equal key staying in file order, and laid out as what ema_engine_align_pairs() takes: all reads in one
+ * byte array, read 2i = mate 1 of pair i, read 2i+1 = its mate 2.  Barcodes are encoded as the reference does
+ * (encode_bc, src/util.c:41-76).  Host code only; links into libema_engine.so beside the engine.
+ *
+ * Where the reference has undefined behaviour the reader fails with EMA_EFORMAT and names the line instead:
+ * a line of 5000 bytes or more (fgets splits it, src/align.c:762,768), fewer than six fields, an identifier that is
+ * empty (it would read as the end-of-array sentinel, include/samrecord.h:17) or longer than 149 bytes (id[150],
+ * include/samrecord.h:12), a read longer than max_read_len or whose quality string has another length, a barcode field
+ * that is not bc_len bytes of ACGT/acgt (assert, src/util.c:54) or, for haplotag, not of the form AddCddBddDdd.
+ */
+#ifndef EMA_INGEST_H
+#define EMA_INGEST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef EMA_EARG
+#define EMA_EARG (-1)       /* bad argument (same value as in ema_engine.h) */
+#endif
+#define EMA_EIO (-6)        /* file cannot be opened or read */
+#define EMA_EFORMAT (-7)    /* malformed bucket; ema_bucket_last_error() names the line */
+
+typedef struct ema_bucket {
+	size_t n_pairs;
+	size_t n_groups;        /* barcode groups: maximal runs of equal encoded barcode, as seek_next_barcode_group() finds them */
+	uint64_t *group_off;    /* n_groups + 1: group g is pairs [group_off[g], group_off[g+1]) */
+	uint64_t *bc;           /* n_pairs: encoded barcode (bc_t, reference include/util.h:21) */
+	uint32_t *off;          /* 2*n_pairs + 1: read r is bases[off[r] .. off[r+1]), and quals at the same offsets */
+	char *bases;            /* ASCII, as in the file */
+	char *quals;
+	uint32_t *id_off;       /* n_pairs + 1 */
+	char *ids;              /* identifiers back to back (both mates share one, src/align.c:790) */
+} ema_bucket;
+
+/* Reads a whole bucket file.  bc_len = the platform's barcode length (reference src/techs.c:74-119; 16 for 10x),
+ * 1..32; is_haplotag selects encode_bc_haplotag (bc_len 12); max_read_len = longest read accepted (the reference's
+ * MAX_READ_LEN is 200, include/align.h:61; the engine takes up to 255).  *out is freed with ema_bucket_free(). */
+int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out);
+
+/* The same on a bucket already in memory (text[0 .. len)); text is not modified and need not end in a newline or NUL. */
+int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out);
+
+void ema_bucket_free(ema_bucket *b);
+
+/* Message of the last failed call on this thread ("" if none). */
+const char *ema_bucket_last_error(void);
+
+/* encode_bc / decode_bc (reference src/util.c:41-95) for one barcode; encode returns EMA_EFORMAT on a bad barcode.
+ * decode writes bc_len (or 12) bytes and no terminator. */
+int ema_barcode_encode(const char *bc, int bc_len, int is_haplotag, uint64_t *out);
+void ema_barcode_decode(uint64_t bc, int bc_len, int is_haplotag, char *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -216,6 +216,23 @@ extern const unsigned char orc_nt4_table[256];
 /* klib ks_introsort order for keys; used by tests to pin the sort restatement */
 void orc_introsort_u64(size_t n, uint64_t *a);
 
+/* ---- bucket reader (oracle/ingest.c; reference src/align.c:751-843, src/util.c:11-21,41-95) ---- */
+#define ORC_MAX_READ_LEN 255      /* the reference's MAX_READ_LEN is 200 (include/align.h:61); the engine takes 255 */
+typedef struct {                  /* FASTQRecord, reference include/samrecord.h:9-15 */
+	uint64_t bc;
+	unsigned short rlen;
+	char id[150];
+	char read[ORC_MAX_READ_LEN + 2];
+	char qual[ORC_MAX_READ_LEN + 2];
+} orc_fastq_rec_t;
+
+void orc_copy_until_space(char *dest, char **src);
+uint64_t orc_encode_bc(const char *bc, int bc_len, int is_haplotag);
+void orc_decode_bc(uint64_t bc, int bc_len, int is_haplotag, char *out);
+/* *r1, *r2: n + 1 records each (the last one the sentinel), freed by the caller with free() */
+int orc_read_special_fastq(const char *path, int bc_len, int is_haplotag, orc_fastq_rec_t **r1, orc_fastq_rec_t **r2, size_t *n);
+size_t orc_next_group(const orc_fastq_rec_t *recs, size_t at);
+
 #ifdef __cplusplus
 }
 #endif

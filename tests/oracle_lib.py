@@ -207,3 +207,99 @@ def bench_pairs(idx: Index, opt, bases: np.ndarray, off: np.ndarray, n_threads: 
     secs = lib().orc_bench_pairs(C.byref(opt), idx.h, bases.ctypes.data, off.ctypes.data, (len(off) - 1) // 2, n_threads,
                                  C.byref(n_cand))
     return secs, n_cand.value
+
+
+# ---- bucket reader oracle (oracle/ingest.c) and the reference's own util.c (oracle/_ref/libref_util.so) ----
+ORC_MAX_READ_LEN = 255
+
+
+class FastqRec(C.Structure):
+    _fields_ = [("bc", C.c_uint64), ("rlen", C.c_ushort), ("id", C.c_char * 150), ("read", C.c_char * (ORC_MAX_READ_LEN + 2)),
+                ("qual", C.c_char * (ORC_MAX_READ_LEN + 2))]
+
+
+def read_special_fastq(path: str, bc_len: int = 16, is_haplotag: bool = False):
+    """[(bc, id, read1, qual1, read2, qual2)] in the reference's order, and the barcode groups [(start, n)]."""
+    L = lib()
+    L.orc_read_special_fastq.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.POINTER(FastqRec)), C.POINTER(C.POINTER(FastqRec)),
+                                         C.POINTER(C.c_size_t)]
+    L.orc_next_group.restype = C.c_size_t
+    L.orc_next_group.argtypes = [C.POINTER(FastqRec), C.c_size_t]
+    r1, r2, n = C.POINTER(FastqRec)(), C.POINTER(FastqRec)(), C.c_size_t()
+    assert L.orc_read_special_fastq(path.encode(), bc_len, int(is_haplotag), C.byref(r1), C.byref(r2), C.byref(n)) == 0
+    recs = []
+    for i in range(n.value):
+        a, b = r1[i], r2[i]
+        assert a.bc == b.bc and a.id == b.id and a.rlen == len(a.read) and b.rlen == len(b.read)
+        recs.append((a.bc, a.id, a.read, a.qual, b.read, b.qual))
+    groups, at = [], 0
+    while True:
+        k = L.orc_next_group(r1, at)
+        assert k == L.orc_next_group(r2, at)
+        if k == 0:
+            break
+        groups.append((at, k))
+        at += k
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(r1); libc.free(r2)
+    return recs, groups
+
+
+def oracle_encode_bc(bc: bytes, is_haplotag=False) -> int:
+    L = lib()
+    L.orc_encode_bc.restype = C.c_uint64
+    L.orc_encode_bc.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    return L.orc_encode_bc(bc, len(bc), int(is_haplotag))
+
+
+def oracle_decode_bc(v: int, bc_len: int, is_haplotag=False) -> bytes:
+    L = lib()
+    L.orc_decode_bc.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_char_p]
+    buf = C.create_string_buffer(64)
+    L.orc_decode_bc(v, bc_len, int(is_haplotag), buf)
+    return buf.raw[:12 if is_haplotag else bc_len]
+
+
+def oracle_copy_until_space(line: bytes, n_fields: int):
+    L = lib()
+    L.orc_copy_until_space.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+    return _fields_with(L.orc_copy_until_space, line, n_fields)
+
+
+def _fields_with(fn, line: bytes, n_fields: int):
+    buf = C.create_string_buffer(line + b"\0" * 8)      # room for the steps past the terminator
+    p = C.cast(buf, C.c_char_p)
+    out = []
+    for _ in range(n_fields):
+        dest = C.create_string_buffer(len(line) + 2)
+        fn(dest, C.byref(p))
+        out.append(dest.value)
+    return out
+
+
+REF_UTIL = os.path.join(ROOT, "oracle", "_ref", "libref_util.so")
+
+
+class RefUtil:
+    """The reference's own src/util.c, compiled as it lies (oracle/Makefile `ref`); None-like if it was not built."""
+    def __init__(self):
+        self.L = C.CDLL(REF_UTIL)
+        self.L.encode_bc.restype = C.c_uint64
+        self.L.encode_bc.argtypes = [C.c_char_p, C.c_int]
+        self.L.decode_bc.argtypes = [C.c_uint64, C.c_char_p, C.c_int]
+        self.L.copy_until_space.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+        self.L.ref_set_bc_len.argtypes = [C.c_int]
+
+    def encode_bc(self, bc: bytes, is_haplotag=False) -> int:
+        self.L.ref_set_bc_len(len(bc))
+        return self.L.encode_bc(bc, int(is_haplotag))
+
+    def decode_bc(self, v: int, bc_len: int, is_haplotag=False) -> bytes:
+        self.L.ref_set_bc_len(bc_len)
+        buf = C.create_string_buffer(64)
+        self.L.decode_bc(v, buf, int(is_haplotag))
+        return buf.raw[:12 if is_haplotag else bc_len]
+
+    def copy_until_space(self, line: bytes, n_fields: int):
+        return _fields_with(self.L.copy_until_space, line, n_fields)

@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
-include/ema_engine.h declares, and it fails loudly (no CPU fallback) when no GPU is present."""
+include/*.h declare, and it fails loudly (no CPU fallback) when no GPU is present."""
 import ctypes as C
 import os
 import re
@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "ema_engine.h")).read()
+def declared_symbols(header="ema_engine.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ema_[a-z_0-9]+)\s*\(", src)))
 
@@ -24,6 +24,17 @@ def test_header_symbols_are_exported():
         assert hasattr(L, n), f"{n} declared in include/ema_engine.h but not exported by libema_engine.so"
     for n in engine.SYMBOLS:
         assert n in names, f"binding uses {n}, which the header does not declare"
+
+
+def test_every_header_in_include_is_covered():
+    from ema_amd import engine
+    L = engine.load_library()
+    headers = sorted(h for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h"))
+    assert headers == ["ema_engine.h", "ema_ingest.h"]
+    names = declared_symbols("ema_ingest.h")
+    assert len(names) == 6
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ema_ingest.h but not exported by libema_engine.so"
 
 
 def test_default_options_match_the_reference():

@@ -305,3 +305,29 @@ def test_large_batch_properties():
             assert (fa[int(a.cand_off[2 * p + m]):int(a.cand_off[2 * p + m + 1])] == fb[int(b.cand_off[2 * q + m]):int(b.cand_off[2 * q + m + 1])]).all()
             for x, y in zip(ca, cb):
                 assert (a.cigar_of(x) == b.cigar_of(y)).all()
+
+
+@pytest.mark.gpu
+def test_bucket_file_to_candidates(tmp_path):
+    """A bucket file through the reader and the engine (include/ema_ingest.h -> include/ema_engine.h), against the
+    oracle's reader and the oracle's aligner on the same file: same pairs in the same order, same candidates."""
+    import random
+    from ema_amd import ingest
+    prefix, ctg = small_ref("two_contigs")
+    pairs = synth.make_pairs(ctg, 400, seed=52, sub_rate=0.01, indel_rate=0.001, pairs_per_barcode=7)
+    path = str(tmp_path / "bucket.fq")
+    synth.write_special_fastq(path, pairs)
+    lines = open(path, "rb").read().splitlines(keepends=True)
+    random.Random(3).shuffle(lines)      # preproc writes buckets unsorted; the reader orders them by barcode
+    open(path, "wb").write(b"".join(lines))
+    bucket = ingest.read_bucket(path)
+    want, groups = O.read_special_fastq(path)
+    assert bucket.n_pairs == pairs.n == len(want) and len(groups) == len(bucket.group_off) - 1 > 20
+    for i, (bc, ident, r1, q1, r2, q2) in enumerate(want):
+        assert int(bucket.bc[i]) == bc and bucket.ident(i) == ident and bucket.read(2 * i) == r1 and bucket.read(2 * i + 1) == r2
+    eng = Engine(prefix)
+    batch = eng.align_pairs_any(bucket.bases, bucket.off)
+    eng.close()
+    assert batch.status.max() == 0
+    ordered = synth.Pairs(bucket.bases, bucket.off)
+    assert not compare(prefix, ordered, batch)

@@ -1,0 +1,160 @@
+"""Bucket reader (include/ema_ingest.h): the product's parallel reader against the oracle's
+line-by-line restatement of read_special_fastq (reference src/align.c:751-843) on the same files, the oracle's util.c
+restatements against the reference's own util.c where it was compiled (oracle/_ref), and the error behaviour where the
+reference has undefined behaviour.  CPU only: the reader is host code."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ema_amd import ingest
+
+BASES = b"ACGT"
+
+
+def rand_seq(rng, n, alphabet=BASES):
+    return bytes(rng.choice(alphabet) for _ in range(n))
+
+
+def make_bucket(rng, n_barcodes, bc_len=16, haplotag=False, mixed_case=False, seps=b" ", newline=b"\n", tail_newline=True,
+                max_len=150, extra_field=False):
+    """Lines of a special FASTQ, shuffled; barcodes repeat so that equal keys exercise the stable order."""
+    lines = []
+    for _ in range(n_barcodes):
+        if haplotag:
+            bc = b"A%02dC%02dB%02dD%02d" % tuple(rng.randrange(1, 97) for _ in range(4))
+        else:
+            bc = rand_seq(rng, bc_len)
+        for _ in range(rng.randrange(1, 6)):
+            b = bc
+            if mixed_case and rng.random() < 0.3:
+                b = bytes(c + 32 if rng.random() < 0.5 else c for c in bc)      # some bases in lower case
+            l1, l2 = rng.randrange(1, max_len + 1), rng.randrange(1, max_len + 1)
+            ident = b"@s%d/%d" % (len(lines), rng.randrange(10 ** rng.randrange(1, 9)))
+            f = [b, ident, rand_seq(rng, l1, b"ACGTN"), rand_seq(rng, l1, b"FGH#,:"), rand_seq(rng, l2, b"ACGTN"), rand_seq(rng, l2, b"FGH#,:")]
+            if extra_field:
+                f.append(b"ignored tail")
+            line = b""
+            for k, x in enumerate(f):
+                line += x + (bytes([rng.choice(seps)]) if k + 1 < len(f) else b"")
+            lines.append(line)
+    rng.shuffle(lines)
+    text = newline.join(lines) + (newline if tail_newline else b"")
+    return text
+
+
+def check_same(path, text, bc_len=16, haplotag=False):
+    with open(path, "wb") as f:
+        f.write(text)
+    want, groups = O.read_special_fastq(path, bc_len, haplotag)
+    for got in (ingest.read_bucket(path, bc_len, haplotag), ingest.parse_bucket(text, bc_len, haplotag)):
+        assert got.n_pairs == len(want)
+        for i, (bc, ident, r1, q1, r2, q2) in enumerate(want):
+            assert int(got.bc[i]) == bc and got.ident(i) == ident, i
+            assert got.read(2 * i) == r1 and got.qual(2 * i) == q1 and got.read(2 * i + 1) == r2 and got.qual(2 * i + 1) == q2, i
+        assert [(int(a), int(b - a)) for a, b in zip(got.group_off[:-1], got.group_off[1:])] == groups
+    return want, groups
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_reader_equals_the_oracle_on_10x_buckets(tmp_path, seed):
+    rng = random.Random(seed)
+    want, groups = check_same(str(tmp_path / "b.fq"), make_bucket(rng, 300))
+    assert len(groups) > 250 and any(n > 1 for _, n in groups)
+    assert [w[0] for w in want] != sorted(w[0] for w in want)      # the order is the text order of barcodes, not of their codes
+
+
+def test_reader_on_format_variants(tmp_path):
+    rng = random.Random(7)
+    p = str(tmp_path / "b.fq")
+    check_same(p, make_bucket(rng, 120, seps=b" \t"))                        # any whitespace separates (isspace)
+    check_same(p, make_bucket(rng, 120, newline=b"\r\n"))                     # '\r' ends the last field
+    check_same(p, make_bucket(rng, 120, tail_newline=False))                  # last line without a newline
+    check_same(p, make_bucket(rng, 120, extra_field=True))                    # anything after the sixth field is ignored
+    check_same(p, make_bucket(rng, 120, mixed_case=True))                     # 'a' encodes as 'A' but sorts after 'T'
+    check_same(p, make_bucket(rng, 120, max_len=255))                         # up to the engine's read length
+    check_same(p, make_bucket(rng, 200, bc_len=12, haplotag=True), 12, True)  # haplotag codes
+    check_same(p, make_bucket(rng, 200, bc_len=20), 20)                       # dbs
+    check_same(p, make_bucket(rng, 200, bc_len=18), 18)                       # tellseq
+    check_same(p, make_bucket(rng, 40, bc_len=3), 3)                          # many equal keys: file order within a barcode
+    check_same(p, b"")                                                        # empty bucket
+    check_same(p, make_bucket(rng, 1))
+
+
+def test_mixed_case_barcodes_split_groups_as_in_the_reference(tmp_path):
+    """Lower-case barcodes sort apart from their upper-case twins (strncmp on the text) but encode equal: the
+    reference's grouping walks runs of equal code, so the two runs are two groups unless they happen to be adjacent."""
+    lines = [b"ACGTACGTACGTACGT r1 AC FF GT FF", b"acgtacgtacgtacgt r2 AC FF GT FF", b"CCGTACGTACGTACGT r3 AC FF GT FF",
+             b"ACGTACGTACGTACGT r4 A F G F"]
+    want, groups = check_same(str(tmp_path / "b.fq"), b"\n".join(lines) + b"\n")
+    assert [w[1] for w in want] == [b"r1", b"r4", b"r3", b"r2"]
+    assert groups == [(0, 2), (2, 1), (3, 1)] and want[0][0] == want[3][0]
+
+
+def test_large_bucket_goes_through_the_threaded_passes(tmp_path):
+    rng = random.Random(11)
+    text = make_bucket(rng, 30000, max_len=20)      # ~90 K lines: several sort chunks and a merge tree
+    want, groups = check_same(str(tmp_path / "b.fq"), text)
+    assert len(want) > 60000
+
+
+@pytest.mark.parametrize("bad,what", [
+    (b"ACGTACGTACGTACGT id AC FF GT\n", "quality"),                      # five fields: the sixth reads as empty
+    (b"ACGTACGTACGTACGT id AC FF\n", "fewer than six"),
+    (b"\n", "fewer than six"),
+    (b"ACGTACGTACGTACG id AC FF GT FF\n", "bc_len"),
+    (b"ACGTACGTACGTACGN id AC FF GT FF\n", "ACGT"),
+    (b"ACGTACGTACGTACGT  AC FF GT FF\n", "empty identifier"),
+    (b"ACGTACGTACGTACGT " + b"i" * 150 + b" AC FF GT FF\n", "149"),
+    (b"ACGTACGTACGTACGT id " + b"A" * 256 + b" " + b"F" * 256 + b" GT FF\n", "max_read_len"),
+    (b"ACGTACGTACGTACGT id AC F GT FF\n", "quality"),
+    (b"ACGTACGTACGTACGT id AC FF GT FF " + b"x" * 5000 + b"\n", "5000"),
+])
+def test_malformed_lines_fail_loudly(bad, what):
+    good = b"ACGTACGTACGTACGA ok AC FF GT FF\n"
+    with pytest.raises(ingest.BucketError) as e:
+        ingest.parse_bucket(good + bad + good)
+    assert e.value.code == ingest.EMA_EFORMAT and "line 2" in str(e.value) and what in str(e.value)
+
+
+def test_missing_file_is_an_io_error(tmp_path):
+    with pytest.raises(ingest.BucketError) as e:
+        ingest.read_bucket(str(tmp_path / "nope.fq"))
+    assert e.value.code == ingest.EMA_EIO
+
+
+def test_barcode_codes_round_trip():
+    rng = random.Random(5)
+    for n in (1, 12, 16, 18, 20, 32):
+        for _ in range(50):
+            bc = rand_seq(rng, n)
+            v = ingest.encode_barcode(bc)
+            assert v == O.oracle_encode_bc(bc) and ingest.decode_barcode(v, n) == bc == O.oracle_decode_bc(v, n)
+    for _ in range(50):
+        bc = b"A%02dC%02dB%02dD%02d" % tuple(rng.randrange(0, 100) for _ in range(4))
+        v = ingest.encode_barcode(bc, True)
+        assert v == O.oracle_encode_bc(bc, True) and ingest.decode_barcode(v, 12, True) == bc == O.oracle_decode_bc(v, 12, True)
+    assert ingest.encode_barcode(b"A" * 16) == 0      # the all-A barcode is the reference's sentinel code (src/align.c:1060)
+
+
+@pytest.mark.skipif(not os.path.exists(O.REF_UTIL), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_oracle_util_restatements_equal_the_reference_util_c():
+    """Pins oracle/ingest.c's copy_until_space / encode_bc / decode_bc to the reference's own compiled src/util.c."""
+    ref = O.RefUtil()
+    rng = random.Random(9)
+    for n in (12, 16, 18, 20):
+        for _ in range(200):
+            bc = bytes(c + 32 if rng.random() < 0.2 else c for c in rand_seq(rng, n))
+            v = ref.encode_bc(bc)
+            assert v == O.oracle_encode_bc(bc) == ingest.encode_barcode(bc)
+            assert ref.decode_bc(v, n) == O.oracle_decode_bc(v, n) == ingest.decode_barcode(v, n) == bc.upper()
+    for _ in range(200):
+        bc = b"A%02dC%02dB%02dD%02d" % tuple(rng.randrange(0, 100) for _ in range(4))
+        v = ref.encode_bc(bc, True)
+        assert v == O.oracle_encode_bc(bc, True) == ingest.encode_barcode(bc, True)
+        assert ref.decode_bc(v, 12, True) == O.oracle_decode_bc(v, 12, True) == ingest.decode_barcode(v, 12, True)
+    for line in (b"a b c d e f\n", b"a\tb  c\rd\n", b"abc", b" x y", b"one two\n", b"BC id READ QUAL READ2 QUAL2 rest of line\n"):
+        for k in (1, 2, 3):      # stay within the fields the line has: beyond them the reference reads past the terminator
+            assert ref.copy_until_space(line, k) == O.oracle_copy_until_space(line, k), (line, k)

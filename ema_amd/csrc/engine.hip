@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cstring>
 #include <unistd.h>
+#include <fcntl.h>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -258,6 +260,44 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	return EMA_OK;
 }
 
+// A file range straight to device memory: host threads fill one page-locked buffer from the page cache while the
+// other is on its way over PCIe (the flat suffix array of a human-size genome is 50 GB: no whole copy on the host).
+static bool stream_file_to_device(ema_engine *e, const std::string &path, uint64_t file_off, uint64_t size, void *dst)
+{
+	const int fd = open(path.c_str(), O_RDONLY);
+	if (fd < 0) { e->err = "cannot read " + path; return false; }
+	const size_t piece = (size_t)256 << 20;
+	void *buf[2] = {nullptr, nullptr};
+	hipStream_t st = nullptr;
+	hipEvent_t done[2] = {nullptr, nullptr};
+	bool ok = hipHostMalloc(&buf[0], piece) == hipSuccess && hipHostMalloc(&buf[1], piece) == hipSuccess &&
+	          hipStreamCreate(&st) == hipSuccess && hipEventCreate(&done[0]) == hipSuccess && hipEventCreate(&done[1]) == hipSuccess;
+	if (!ok) e->err = "cannot allocate the upload buffers";
+	int k = 0;
+	for (uint64_t at = 0; ok && at < size; at += piece, k ^= 1) {
+		const size_t len = (size_t)std::min<uint64_t>(piece, size - at);
+		if (at >= 2 * piece && hipEventSynchronize(done[k]) != hipSuccess) { ok = false; e->err = "upload failed"; break; }
+		std::atomic<int> bad{0};
+		char *b = (char *)buf[k];
+		host_parallel(len, [&](size_t lo, size_t hi) {
+			while (lo < hi) {
+				const ssize_t r = pread(fd, b + lo, hi - lo, (off_t)(file_off + at + lo));
+				if (r <= 0) { ++bad; return; }
+				lo += (size_t)r;
+			}
+		});
+		if (bad) { ok = false; e->err = "cannot read " + path; break; }
+		if (hipMemcpyAsync((char *)dst + at, b, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(done[k], st) != hipSuccess) {
+			ok = false; e->err = "upload failed"; break;
+		}
+	}
+	if (st && hipStreamSynchronize(st) != hipSuccess && ok) { ok = false; e->err = "upload failed"; }
+	for (int i = 0; i < 2; ++i) { if (done[i]) (void)hipEventDestroy(done[i]); if (buf[i]) (void)hipHostFree(buf[i]); }
+	if (st) (void)hipStreamDestroy(st);
+	close(fd);
+	return ok;
+}
+
 static int engine_open(const char *index_prefix, const ema_engine *share, int device, const ema_engine_opts *opts, ema_engine_t **out);
 
 int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts *opts, ema_engine_t **out)
@@ -303,14 +343,14 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 		e->dix = share->dix;
 	} else {
 	HostIndex hix;
-	std::string msg = host_index_load(index_prefix, hix);
+	std::string msg = host_index_load(index_prefix, hix, /*with_sa=*/false);
 	if (!msg.empty()) { e->err = msg; return EMA_EINDEX; }
 	e->contigs = hix.contigs;
 	e->l_pac = hix.l_pac;
 	HIPCHK(e, e->d_occ.alloc(hix.occ.size()));
 	HIPCHK(e, hipMemcpy(e->d_occ.p, hix.occ.data(), hix.occ.size() * sizeof(OccBlock), hipMemcpyHostToDevice));
-	HIPCHK(e, e->d_sa.alloc(hix.sa_bytes.size()));
-	HIPCHK(e, hipMemcpy(e->d_sa.p, hix.sa_bytes.data(), hix.sa_bytes.size(), hipMemcpyHostToDevice));
+	HIPCHK(e, e->d_sa.alloc(hix.sa_size));
+	if (!stream_file_to_device(e, hix.sa_path, hix.sa_file_off, hix.sa_size, e->d_sa.p)) return e->err.empty() ? EMA_EINDEX : EMA_EDEVICE;
 	HIPCHK(e, e->d_pac.alloc(hix.pac.size()));
 	HIPCHK(e, hipMemcpy(e->d_pac.p, hix.pac.data(), hix.pac.size(), hipMemcpyHostToDevice));
 	HIPCHK(e, e->d_ctg.alloc(hix.ctg_off.size()));

@@ -2,6 +2,8 @@
 #include "host_index.h"
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <thread>
 
 namespace {
 bool slurp(const std::string &path, std::vector<uint8_t> &buf)
@@ -35,7 +37,7 @@ DevIndex HostIndex::view() const
 	return d;
 }
 
-std::string host_index_load(const std::string &prefix, HostIndex &ix)
+std::string host_index_load(const std::string &prefix, HostIndex &ix, bool with_sa)
 {
 	std::vector<uint8_t> raw;
 	// ---- .bwt (bwa layout): u64 primary, u64 L2[1..4], 16-word blocks {4 x u64 occ, 8 x u32 bases}
@@ -51,46 +53,83 @@ std::string host_index_load(const std::string &prefix, HostIndex &ix)
 		const uint64_t n_blocks = (ix.seq_len + 127) >> 7;      // bwa's 128-symbol blocks; two device blocks each
 		ix.n_super = (int)((ix.seq_len >> EMA_OCC_SUPER_SHIFT) + 1);
 		if (ix.n_super > EMA_OCC_MAX_SUPER) return "reference too long for the device rank structure (2^33 BWT symbols)";
+		// every 128-symbol block carries its own running counts, so blocks convert independently (all host threads);
+		// each checks that its counts plus its symbols give the next block's counts (the totals after the last one)
+		const uint64_t n_data = (ix.seq_len + 15) >> 4;
+		if (n_words < n_data + 8 * n_blocks + 8) return "truncated .bwt";
 		OccBlock zero; memset(&zero, 0, sizeof(zero));
 		ix.occ.assign((n_blocks + 1) * 2, zero);
-		uint64_t running[4] = {0, 0, 0, 0}, super[4] = {0, 0, 0, 0};
-		for (uint64_t b = 0; b < n_blocks; ++b) {
-			uint64_t base = b * 16;
-			if (base + 8 > n_words) return "truncated .bwt";
-			uint64_t cnt[4];
-			memcpy(cnt, w + base, 32);
-			for (int c = 0; c < 4; ++c)
-				if (cnt[c] != running[c]) return "inconsistent occ counters in .bwt";
-			for (int t = 0; t < 128; ++t) {
-				uint64_t pos = (b << 7) + t;
-				if (pos >= ix.seq_len) break;
-				if ((t & 63) == 0) {      // a device block starts here
-					if ((pos & (((uint64_t)1 << EMA_OCC_SUPER_SHIFT) - 1)) == 0) {
-						const uint64_t sb = pos >> EMA_OCC_SUPER_SHIFT;
-						for (int c = 0; c < 4; ++c) { super[c] = running[c]; if (sb > 0) ix.occ_super[sb - 1][c] = running[c]; }
+		auto counts_at = [&](uint64_t blk, uint64_t out[4]) {      // running counts before block blk (blk == n_blocks: totals)
+			memcpy(out, w + (blk < n_blocks ? blk * 16 : n_data + 8 * n_blocks), 32);
+		};
+		for (int sb = 1; sb < ix.n_super; ++sb)      // superblock boundaries are multiples of 128 symbols
+			counts_at(((uint64_t)sb << EMA_OCC_SUPER_SHIFT) >> 7, ix.occ_super[sb - 1]);
+		unsigned n_thr = std::thread::hardware_concurrency();
+		n_thr = n_thr < 1 ? 1 : n_thr > 64 ? 64 : n_thr;
+		if (n_blocks < 4096) n_thr = 1;
+		std::vector<int> bad(n_thr, 0);
+		auto work = [&](unsigned t) {
+			const uint64_t per = (n_blocks + n_thr - 1) / n_thr, b_lo = std::min(n_blocks, t * per), b_hi = std::min(n_blocks, b_lo + per);
+			for (uint64_t b = b_lo; b < b_hi; ++b) {
+				uint64_t running[4], next[4], super[4] = {0, 0, 0, 0};
+				counts_at(b, running);
+				const uint64_t sb = (b << 7) >> EMA_OCC_SUPER_SHIFT;
+				if (sb > 0) memcpy(super, ix.occ_super[sb - 1], 32);
+				for (int half = 0; half < 2; ++half) {
+					const uint64_t pos0 = (b << 7) + (uint64_t)half * 64;
+					if (pos0 >= ix.seq_len) break;
+					OccBlock &o = ix.occ[pos0 >> 6];
+					for (int c = 0; c < 4; ++c) o.cnt[c] = (uint32_t)(running[c] - super[c]);
+					for (int t2 = 0; t2 < 64; ++t2) {
+						const uint64_t pos = pos0 + (uint64_t)t2;
+						if (pos >= ix.seq_len) break;
+						const int tt = half * 64 + t2;
+						const unsigned sym = w[b * 16 + 8 + (tt >> 4)] >> ((~tt & 15) << 1) & 3;
+						o.bases[t2 >> 5] |= (uint64_t)sym << ((t2 & 31) << 1);
+						++running[sym];
 					}
-					for (int c = 0; c < 4; ++c) ix.occ[pos >> 6].cnt[c] = (uint32_t)(running[c] - super[c]);
 				}
-				uint64_t wi = base + 8 + (t >> 4);
-				if (wi >= n_words) return "truncated .bwt";
-				unsigned sym = w[wi] >> ((~t & 15) << 1) & 3;
-				ix.occ[pos >> 6].bases[(t & 63) >> 5] |= (uint64_t)sym << ((t & 31) << 1);
-				++running[sym];
+				counts_at(b + 1, next);
+				if (memcmp(running, next, 32) != 0) { bad[t] = 1; return; }
 			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(work, t);
+			work(0);
+			for (auto &x : th) x.join();
 		}
+		for (int x : bad) if (x) return "inconsistent occ counters in .bwt";
+		uint64_t tot[4];
+		counts_at(n_blocks, tot);
 		for (int c = 0; c < 4; ++c)
-			if (running[c] != ix.L2[c + 1] - ix.L2[c]) return "symbol totals disagree with L2 in .bwt";
+			if (tot[c] != ix.L2[c + 1] - ix.L2[c]) return "symbol totals disagree with L2 in .bwt";
 	}
-	// ---- .fsa: whole suffix array
-	if (!slurp(prefix + ".fsa", raw) || raw.size() < 24 || memcmp(raw.data(), "EMAFSA01", 8) != 0)
-		return "cannot read " + prefix + ".fsa (flat suffix array; rebuild the index with ema_index_build)";
+	std::vector<uint8_t>().swap(raw);
+	// ---- .fsa: whole suffix array (the engine streams it to the device itself: with_sa == false reads the header only)
 	{
+		FILE *f = fopen((prefix + ".fsa").c_str(), "rb");
+		uint8_t head[24];
+		if (!f || fread(head, 1, 24, f) != 24 || memcmp(head, "EMAFSA01", 8) != 0) {
+			if (f) fclose(f);
+			return "cannot read " + prefix + ".fsa (flat suffix array; rebuild the index with ema_index_build)";
+		}
 		uint64_t n, width;
-		memcpy(&n, raw.data() + 8, 8);
-		memcpy(&width, raw.data() + 16, 8);
-		if (n != ix.seq_len || (width != 4 && width != 8) || raw.size() != 24 + (n + 1) * width) return "bad .fsa header";
+		memcpy(&n, head + 8, 8);
+		memcpy(&width, head + 16, 8);
+		fseek(f, 0, SEEK_END);
+		const uint64_t size = (uint64_t)ftell(f);
+		if (n != ix.seq_len || (width != 4 && width != 8) || size != 24 + (n + 1) * width) { fclose(f); return "bad .fsa header"; }
 		ix.sa_width = (int)width;
-		ix.sa_bytes.assign(raw.begin() + 24, raw.end());
+		ix.sa_path = prefix + ".fsa";
+		ix.sa_file_off = 24;
+		ix.sa_size = (n + 1) * width;
+		if (with_sa) {
+			ix.sa_bytes.resize(ix.sa_size);
+			fseek(f, 24, SEEK_SET);
+			if (fread(ix.sa_bytes.data(), 1, ix.sa_size, f) != ix.sa_size) { fclose(f); return "cannot read " + prefix + ".fsa"; }
+		}
+		fclose(f);
 	}
 	// ---- .pac
 	if (!slurp(prefix + ".pac", ix.pac)) return "cannot read " + prefix + ".pac";

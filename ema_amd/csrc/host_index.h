@@ -15,7 +15,9 @@ struct HostIndex {
 	std::vector<OccBlock> occ;       // device layout (see dev_types.h)
 	uint64_t occ_super[EMA_OCC_MAX_SUPER - 1][4] = {};
 	int n_super = 1;
-	std::vector<uint8_t> sa_bytes;   // seq_len+1 rows of sa_width bytes
+	std::vector<uint8_t> sa_bytes;   // seq_len+1 rows of sa_width bytes (empty when loaded without the suffix array)
+	std::string sa_path;             // where those rows are on disk: sa_size bytes from sa_file_off
+	uint64_t sa_file_off = 0, sa_size = 0;
 	std::vector<uint8_t> pac;
 	std::vector<int64_t> ctg_off;    // n+1
 	std::vector<HostContig> contigs;
@@ -28,7 +30,8 @@ struct HostIndex {
 	DevIndex view() const;
 };
 
-// Loads <prefix>.bwt/.pac/.ann and <prefix>.fsa.  Returns "" on success, else an error message.
-std::string host_index_load(const std::string &prefix, HostIndex &out);
+// Loads <prefix>.bwt/.pac/.ann and <prefix>.fsa.  Returns "" on success, else an error message.  with_sa == false
+// leaves the suffix array on disk (sa_path / sa_file_off / sa_size say where): the engine streams it to the device.
+std::string host_index_load(const std::string &prefix, HostIndex &out, bool with_sa = true);
 
 #endif

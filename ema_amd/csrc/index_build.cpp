@@ -19,6 +19,7 @@
 // K bases, then an independent comparison sort of every bucket on 2-bit packed words.
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,8 @@
 #include <string>
 #include <vector>
 #include <omp.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace {
 
@@ -67,77 +70,182 @@ inline bool suffix_less(const Packed &T, uint64_t i, uint64_t j)
 	}
 }
 
+// Big arrays are allocated without being filled: a serial zero-fill of 50 GB costs more than some of the phases, and
+// every element is written by the phase that owns the array.
+template <typename V> struct Raw {
+	V *p = nullptr;
+	explicit Raw(uint64_t n) : p((V *)malloc((size_t)(n ? n : 1) * sizeof(V))) {}
+	~Raw() { free(p); }
+	Raw(const Raw &) = delete;
+	Raw &operator=(const Raw &) = delete;
+};
+
+// header + payload into a file, the payload in 64 MB pieces from several threads (one fwrite fills the page cache at a
+// couple of GB/s; the flat suffix array of a human-size genome is 50 GB)
+bool write_file(const std::string &path, const void *head, size_t n_head, const void *data, size_t n_data)
+{
+	const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (fd < 0) return false;
+	bool ok = n_head == 0 || pwrite(fd, head, n_head, 0) == (ssize_t)n_head;
+	const size_t piece = (size_t)64 << 20, n_pieces = (n_data + piece - 1) / piece;
+	int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::min(16, omp_get_max_threads())) reduction(+ : bad)
+	for (int64_t k = 0; k < (int64_t)n_pieces; ++k) {
+		size_t at = (size_t)k * piece;
+		const size_t end = std::min(n_data, at + piece);
+		while (at < end) {
+			const ssize_t w = pwrite(fd, (const char *)data + at, end - at, (off_t)(n_head + at));
+			if (w <= 0) { ++bad; break; }
+			at += (size_t)w;
+		}
+	}
+	return close(fd) == 0 && ok && bad == 0;
+}
+
+struct Lap {      // phase timings on stderr when EMA_INDEX_PROF is set
+	bool on = getenv("EMA_INDEX_PROF") != nullptr;
+	double t0 = omp_get_wtime();
+	void operator()(const char *what) { if (on) { const double t = omp_get_wtime(); fprintf(stderr, "[index] %-12s %7.1f s\n", what, t - t0); t0 = t; } }
+};
+
+// Suffix array of T (sa[0..n]: row 0 = '$').  Every phase runs on all host threads:
+//   1. counting sort of the positions by their first K <= 8 bases, with per-thread histograms (each thread owns a
+//      stretch of the text, so the scatter is stable and needs no atomics);
+//   2. each bucket on its own: (next 32 bases as one word, position) pairs sorted by the word, the rare ties settled by
+//      comparing the suffixes themselves -- almost all comparisons stay inside the pair array instead of gathering
+//      from the text.
 template <typename I>
-void build_sa(const Packed &T, std::vector<I> &sa)   // sa[0..n]: row 0 = '$'
+void build_sa(const Packed &T, I *sa)
 {
 	const uint64_t n = T.n;
-	sa.assign(n + 1, 0);
 	sa[0] = (I)n;
 	int K = 1;
-	while (K < 12 && (1ULL << (2 * (K + 1))) <= n / 4 + 4) ++K;
+	while (K < 8 && (1ULL << (2 * (K + 1))) <= n / 4 + 4) ++K;
 	const uint64_t nb = 1ULL << (2 * K);
-	std::vector<uint64_t> cnt(nb + 1, 0);
 	auto key_at = [&](uint64_t i) { return T.get32(i) >> (64 - 2 * K); };   // zero (=A) padded past n
-	for (uint64_t i = 0; i < n; ++i) ++cnt[key_at(i) + 1];
-	for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+	const int n_thr = omp_get_max_threads();
+	const uint64_t per = (n + (uint64_t)n_thr - 1) / (uint64_t)n_thr;
+	std::vector<std::vector<uint64_t>> hist((size_t)n_thr);
+	std::vector<uint64_t> cnt(nb + 1, 0);
+	Lap lap;
+#pragma omp parallel num_threads(n_thr)
 	{
-		std::vector<uint64_t> pos(cnt.begin(), cnt.end() - 1);
-		for (uint64_t i = 0; i < n; ++i) sa[1 + pos[key_at(i)]++] = (I)i;
+		const int t = omp_get_thread_num();
+		std::vector<uint64_t> &h = hist[(size_t)t];
+		h.assign(nb, 0);
+		const uint64_t lo = std::min(n, (uint64_t)t * per), hi = std::min(n, lo + per);
+		for (uint64_t i = lo; i < hi; ++i) ++h[key_at(i)];
+#pragma omp barrier
+#pragma omp for schedule(static)
+		for (int64_t b = 0; b < (int64_t)nb; ++b) {      // bucket totals, and each thread's share turned into its offset inside the bucket
+			uint64_t run = 0;
+			for (int u = 0; u < n_thr; ++u) { const uint64_t c = hist[(size_t)u][(size_t)b]; hist[(size_t)u][(size_t)b] = run; run += c; }
+			cnt[(size_t)b + 1] = run;
+		}
+#pragma omp single
+		for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+		I *base = sa + 1;
+		for (uint64_t i = lo; i < hi; ++i) { const uint64_t k = key_at(i); base[cnt[k] + h[k]++] = (I)i; }
 	}
-	I *base = sa.data() + 1;
-#pragma omp parallel for schedule(dynamic, 4096)
-	for (int64_t b = 0; b < (int64_t)nb; ++b) {
-		uint64_t lo = cnt[b], hi = cnt[b + 1];
-		if (hi - lo > 1)
-			std::sort(base + lo, base + hi, [&](I x, I y) { return suffix_less(T, x, y); });
+	hist.clear(); hist.shrink_to_fit();
+	lap("bucket");
+	I *base = sa + 1;
+	struct KP { uint64_t key; I pos; };
+#pragma omp parallel
+	{
+		std::vector<KP> kp;
+#pragma omp for schedule(dynamic, 16)
+		for (int64_t b = 0; b < (int64_t)nb; ++b) {
+			const uint64_t lo = cnt[(size_t)b], hi = cnt[(size_t)b + 1];
+			if (hi - lo < 2) continue;
+			kp.resize(hi - lo);
+			for (uint64_t r = lo; r < hi; ++r) {
+				const uint64_t p = (uint64_t)base[r], q = p + (uint64_t)K;
+				kp[r - lo] = KP{q < n ? T.get32(q) : 0, (I)p};
+			}
+			std::sort(kp.begin(), kp.end(), [&](const KP &x, const KP &y) {
+				if (x.key != y.key) return x.key < y.key;      // (a suffix that ends inside the word is zero-padded: a proper prefix sorts first, as '$' does)
+				return suffix_less(T, (uint64_t)x.pos, (uint64_t)y.pos);
+			});
+			for (uint64_t r = lo; r < hi; ++r) base[r] = kp[r - lo].pos;
+		}
 	}
+	lap("sort");
 }
 
 void fput64(FILE *f, uint64_t v) { fwrite(&v, 8, 1, f); }
 
 template <typename I>
-int write_index(const std::string &prefix, const Packed &T, const std::vector<I> &sa)
+int write_index(const std::string &prefix, const Packed &T, const I *sa)
 {
 	const uint64_t n = T.n;
 	// BWT without the sentinel row
+	Lap lap;
 	uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0};
-	std::vector<uint8_t> B(n);
+	Raw<uint8_t> Bbuf(n);
+	uint8_t *B = Bbuf.p;
 	{
-		uint64_t k = 0;
-		for (uint64_t r = 0; r <= n; ++r) {
-			uint64_t p = sa[r];
-			if (p == 0) { primary = r; continue; }
-			B[k++] = (uint8_t)T.get(p - 1);
+		uint64_t found = 0;
+#pragma omp parallel for schedule(static) reduction(max : found)
+		for (int64_t r = 0; r <= (int64_t)n; ++r) if (sa[(size_t)r] == 0) found = (uint64_t)r;
+		primary = found;
+		uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : c0, c1, c2, c3)
+		for (int64_t r = 0; r <= (int64_t)n; ++r) {
+			if ((uint64_t)r == primary) continue;
+			const uint8_t c = (uint8_t)T.get((uint64_t)sa[(size_t)r] - 1);
+			B[(size_t)r - ((uint64_t)r > primary ? 1 : 0)] = c;
+			c0 += c == 0; c1 += c == 1; c2 += c == 2; c3 += c == 3;
 		}
+		L2[1] = c0; L2[2] = c1; L2[3] = c2; L2[4] = c3;
 	}
-	for (uint64_t i = 0; i < n; ++i) ++L2[B[i] + 1];
 	for (int c = 0; c < 4; ++c) L2[c + 1] += L2[c];
+	lap("bwt");
 
-	FILE *f = fopen((prefix + ".bwt").c_str(), "wb");
-	if (!f) return -1;
-	fput64(f, primary);
-	for (int c = 1; c <= 4; ++c) fput64(f, L2[c]);
 	{
-		uint64_t c4[4] = {0, 0, 0, 0};
-		const uint64_t n_words = (n + 15) >> 4;
-		std::vector<uint32_t> out;
-		out.reserve(n_words * 2 + 64);
-		for (uint64_t wi = 0; wi < n_words; ++wi) {
-			if ((wi & 7) == 0) { uint32_t tmp[8]; memcpy(tmp, c4, 32); out.insert(out.end(), tmp, tmp + 8); }
-			uint32_t word = 0;
-			for (int t = 0; t < 16; ++t) {
-				uint64_t i = (wi << 4) + t;
-				if (i < n) { word |= (uint32_t)B[i] << ((15 - t) << 1); ++c4[B[i]]; }
+		// per 128 bases: the four running counts (as 8 x u32) and 8 words of 16 bases; one more count block at the end
+		const uint64_t n_words = (n + 15) >> 4, n_blocks = (n_words + 7) >> 3;
+		Raw<uint32_t> outbuf(n_words + 8 * n_blocks + 8);
+		uint32_t *out = outbuf.p;
+		const int n_thr = omp_get_max_threads();
+		const uint64_t per = ((n_blocks + (uint64_t)n_thr - 1) / (uint64_t)n_thr);
+		std::vector<std::array<uint64_t, 4>> before((size_t)n_thr + 1);
+		for (auto &x : before) x = {0, 0, 0, 0};
+#pragma omp parallel num_threads(n_thr)
+		{
+			const int t = omp_get_thread_num();
+			const uint64_t b_lo = std::min(n_blocks, (uint64_t)t * per), b_hi = std::min(n_blocks, b_lo + per);
+			uint64_t c4[4] = {0, 0, 0, 0};
+			for (uint64_t i = b_lo << 7, e = std::min(n, b_hi << 7); i < e; ++i) ++c4[B[i]];
+			for (int c = 0; c < 4; ++c) before[(size_t)t + 1][c] = c4[c];
+#pragma omp barrier
+#pragma omp single
+			for (int u = 0; u < n_thr; ++u) for (int c = 0; c < 4; ++c) before[(size_t)u + 1][c] += before[(size_t)u][c];
+			for (int c = 0; c < 4; ++c) c4[c] = before[(size_t)t][c];
+			for (uint64_t blk = b_lo; blk < b_hi; ++blk) {
+				uint32_t *o = out + blk * 16;
+				memcpy(o, c4, 32);
+				for (uint64_t wi = blk << 3, we = std::min(n_words, (blk + 1) << 3); wi < we; ++wi) {
+					uint32_t word = 0;
+					for (int tt = 0; tt < 16; ++tt) {
+						const uint64_t i = (wi << 4) + tt;
+						if (i < n) { word |= (uint32_t)B[i] << ((15 - tt) << 1); ++c4[B[i]]; }
+					}
+					o[8 + (wi & 7)] = word;
+				}
 			}
-			out.push_back(word);
 		}
-		{ uint32_t tmp[8]; memcpy(tmp, c4, 32); out.insert(out.end(), tmp, tmp + 8); }
-		fwrite(out.data(), 4, out.size(), f);
+		const uint64_t used = n_words + 8 * n_blocks;      // the last block may hold fewer than 8 words
+		uint64_t tot[4];
+		for (int c = 0; c < 4; ++c) tot[c] = before[(size_t)n_thr][c];
+		memcpy(out + used, tot, 32);
+		uint64_t head[5] = {primary, L2[1], L2[2], L2[3], L2[4]};
+		if (!write_file(prefix + ".bwt", head, sizeof head, out, (used + 8) * 4)) return -1;
 	}
-	fclose(f);
+	lap("occ");
 
 	const uint64_t sa_intv = 32;
-	f = fopen((prefix + ".sa").c_str(), "wb");
+	FILE *f = fopen((prefix + ".sa").c_str(), "wb");
 	if (!f) return -1;
 	fput64(f, primary);
 	for (int c = 1; c <= 4; ++c) fput64(f, L2[c]);
@@ -146,13 +254,13 @@ int write_index(const std::string &prefix, const Packed &T, const std::vector<I>
 	for (uint64_t r = sa_intv; r <= n; r += sa_intv) fput64(f, (uint64_t)sa[r]);
 	fclose(f);
 
-	f = fopen((prefix + ".fsa").c_str(), "wb");
-	if (!f) return -1;
-	fwrite("EMAFSA01", 1, 8, f);
-	fput64(f, n);
-	fput64(f, sizeof(I));
-	fwrite(sa.data(), sizeof(I), n + 1, f);
-	fclose(f);
+	{
+		uint64_t head[3];
+		memcpy(head, "EMAFSA01", 8);
+		head[1] = n; head[2] = sizeof(I);
+		if (!write_file(prefix + ".fsa", head, sizeof head, sa, (n + 1) * sizeof(I))) return -1;
+	}
+	lap("sa files");
 	return 0;
 }
 
@@ -162,6 +270,7 @@ int write_index(const std::string &prefix, const Packed &T, const std::vector<I>
 extern "C" int ema_index_build(const char *fasta, int n_threads)
 {
 	if (n_threads > 0) omp_set_num_threads(n_threads);
+	Lap lap;
 	FILE *f = fopen(fasta, "rb");
 	if (!f) return -1;
 	std::string prefix(fasta);
@@ -169,7 +278,11 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 	std::vector<Hole> holes;
 	std::vector<uint8_t> fwd;
 	std::vector<std::string> fai;
+	{ fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET); if (sz > 0) fwd.reserve((size_t)sz); }
 	srand48(11);
+	uint8_t kCode[256];
+	memset(kCode, 4, sizeof kCode);
+	kCode['A'] = kCode['a'] = 0; kCode['C'] = kCode['c'] = 1; kCode['G'] = kCode['g'] = 2; kCode['T'] = kCode['t'] = 3;
 	{
 		std::vector<char> buf(1 << 20);
 		std::string line;
@@ -207,28 +320,26 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 			}
 			if (contigs.empty()) continue;
 			if (linebases == 0 && l) { linebases = (int)l; linewidth = (int)raw; }
+			// bases in bulk through a table; the rare ambiguous ones take the reference's hole bookkeeping below
+			const size_t at0 = fwd.size();
+			fwd.resize(at0 + l);
+			uint8_t *dst = fwd.data() + at0;
+			bool any_amb = false;
+			for (size_t i = 0; i < l; ++i) { const uint8_t c = kCode[(unsigned char)buf[i]]; dst[i] = c; any_amb |= c > 3; }
+			contigs.back().len += (int32_t)l;
+			if (!any_amb) { if (l) last_amb = 0; continue; }
 			for (size_t i = 0; i < l; ++i) {
-				char ch = buf[i];
-				int c;
-				switch (ch) {
-				case 'A': case 'a': c = 0; break;
-				case 'C': case 'c': c = 1; break;
-				case 'G': case 'g': c = 2; break;
-				case 'T': case 't': c = 3; break;
-				default: c = 4;
+				if (dst[i] < 4) { last_amb = 0; continue; }
+				const char ch = buf[i];
+				const int64_t pos = (int64_t)(at0 + i);
+				if (cur_hole >= 0 && last_amb == ch && holes[cur_hole].offset + holes[cur_hole].len == pos) ++holes[cur_hole].len;
+				else {
+					holes.push_back(Hole{pos, 1, ch});
+					cur_hole = (long)holes.size() - 1;
+					++contigs.back().n_ambs;
 				}
-				if (c >= 4) {
-					if (cur_hole >= 0 && last_amb == ch && holes[cur_hole].offset + holes[cur_hole].len == (int64_t)fwd.size()) ++holes[cur_hole].len;
-					else {
-						holes.push_back(Hole{(int64_t)fwd.size(), 1, ch});
-						cur_hole = (long)holes.size() - 1;
-						++contigs.back().n_ambs;
-					}
-					last_amb = ch;
-					c = (int)(lrand48() & 3);
-				} else last_amb = 0;
-				fwd.push_back((uint8_t)c);
-				++contigs.back().len;
+				last_amb = ch;
+				dst[i] = (uint8_t)(lrand48() & 3);
 			}
 		}
 		flush_fai();
@@ -236,6 +347,7 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 	fclose(f);
 	const int64_t l_pac = (int64_t)fwd.size();
 	if (l_pac == 0) return -2;
+	lap("fasta");
 
 	f = fopen((prefix + ".fai").c_str(), "w");
 	if (!f) return -1;
@@ -260,7 +372,12 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 
 	{
 		std::vector<uint8_t> pac((l_pac >> 2) + 1, 0);
-		for (int64_t i = 0; i < l_pac; ++i) pac[i >> 2] |= fwd[i] << ((~i & 3) << 1);
+#pragma omp parallel for schedule(static)
+		for (int64_t by = 0; by < (l_pac + 3) >> 2; ++by) {
+			uint8_t v = 0;
+			for (int64_t i = by << 2; i < std::min<int64_t>(l_pac, (by << 2) + 4); ++i) v |= (uint8_t)(fwd[i] << ((~i & 3) << 1));
+			pac[by] = v;
+		}
 		f = fopen((prefix + ".pac").c_str(), "wb");
 		if (!f) return -1;
 		fwrite(pac.data(), 1, (l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1), f);
@@ -271,18 +388,31 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 
 	Packed T;
 	T.init(2 * (uint64_t)l_pac);
-	for (int64_t i = 0; i < l_pac; ++i) {
-		T.set((uint64_t)i, fwd[i]);
-		T.set((uint64_t)(2 * l_pac - 1 - i), 3 - fwd[i]);
+	{
+		const uint64_t n2 = 2 * (uint64_t)l_pac, L = (uint64_t)l_pac;
+#pragma omp parallel for schedule(static)
+		for (int64_t wi = 0; wi < (int64_t)((n2 + 31) >> 5); ++wi) {      // each thread owns whole words
+			uint64_t w = 0;
+			for (int t = 0; t < 32; ++t) {
+				const uint64_t p = ((uint64_t)wi << 5) + (uint64_t)t;
+				if (p >= n2) break;
+				const uint64_t c = p < L ? fwd[p] : 3u - fwd[n2 - 1 - p];
+				w |= c << (62 - (t << 1));
+			}
+			T.w[(size_t)wi] = w;
+		}
 	}
+	lap("text");
 	std::vector<uint8_t>().swap(fwd);
 	if (T.n < 0xffffff00ULL) {
-		std::vector<uint32_t> sa;
-		build_sa(T, sa);
-		return write_index(prefix, T, sa);
+		Raw<uint32_t> sa(T.n + 1);
+		if (!sa.p) return -3;
+		build_sa(T, sa.p);
+		return write_index(prefix, T, sa.p);
 	} else {
-		std::vector<uint64_t> sa;
-		build_sa(T, sa);
-		return write_index(prefix, T, sa);
+		Raw<uint64_t> sa(T.n + 1);
+		if (!sa.p) return -3;
+		build_sa(T, sa.p);
+		return write_index(prefix, T, sa.p);
 	}
 }

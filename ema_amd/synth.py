@@ -35,7 +35,11 @@ def make_genome(contig_lens, seed=GENOME_SEED, short_rep=0.10, long_rep=0.05, se
     """Returns a list of uint8 arrays (values 0..3, 4 = N), one per contig."""
     rng = np.random.default_rng(seed)
     total = int(sum(contig_lens))
-    g = rng.choice(4, size=total, p=[0.295, 0.205, 0.205, 0.295]).astype(np.uint8)
+    # in pieces: choice() returns 8-byte integers (25 GB at once for a human-size genome); the stream of draws is the same
+    g = np.empty(total, dtype=np.uint8)
+    for at in range(0, total, 1 << 26):
+        n = min(1 << 26, total - at)
+        g[at:at + n] = rng.choice(4, size=n, p=[0.295, 0.205, 0.205, 0.295])
     fam_short = rng.integers(0, 4, 300, dtype=np.uint8)
     fam_long = rng.integers(0, 4, 6000, dtype=np.uint8)
 

@@ -1,13 +1,24 @@
-"""Dev aid: mean per-launch value of every counter per kernel from rocprofv3 --pmc counter_collection.csv files."""
+"""Dev aid: per kernel and counter, launches / mean / min / max / sum from rocprofv3 --pmc counter_collection.csv files.
+  python tools/pmc_summary.py DIR...            table on stdout
+  python tools/pmc_summary.py --csv DIR...      the CSV layout committed under profiles/ (r01f_pmc_*, r01g_pmc_*)"""
 import csv, glob, sys, collections
+args = sys.argv[1:]
+as_csv = "--csv" in args
+args = [a for a in args if a != "--csv"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for root in sys.argv[1:]:
+for root in args:
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+if as_csv:
+    print("kernel,counter,launches,mean_per_launch,min,max,sum_over_run")
 for k in sorted(acc):
-    print(k)
+    if not as_csv:
+        print(k)
     for c in sorted(acc[k]):
         v = acc[k][c]
-        print(f"   {c:32s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+        if as_csv:
+            print(f"{k},{c},{len(v)},{sum(v) / len(v):.6g},{min(v):.6g},{max(v):.6g},{sum(v):.6g}")
+        else:
+            print(f"   {c:32s} n={len(v):3d} mean={sum(v)/len(v):.4g}")

@@ -29,16 +29,25 @@
 #include <omp.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/mman.h>
 
 namespace {
 
 struct Contig { std::string name, anno; int64_t offset; int32_t len, n_ambs; };
 struct Hole { int64_t offset; int32_t len; char amb; };
 
+// Large arrays ask for huge pages: they are gathered from / scattered into at random, and 4 KB pages make every access
+// a TLB miss.
+inline void want_huge_pages(void *p, size_t bytes)
+{
+	const uintptr_t two_mb = (uintptr_t)2 << 20, lo = ((uintptr_t)p + two_mb - 1) & ~(two_mb - 1), hi = ((uintptr_t)p + bytes) & ~(two_mb - 1);
+	if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+}
+
 struct Packed {            // big-endian 2-bit text: base t of a word sits at bits 62-2t
 	std::vector<uint64_t> w;
 	uint64_t n = 0;
-	void init(uint64_t n_) { n = n_; w.assign((n_ >> 5) + 3, 0); }
+	void init(uint64_t n_) { n = n_; w.resize((n_ >> 5) + 3); want_huge_pages(w.data(), w.size() * 8); std::fill(w.begin(), w.end(), 0); }
 	inline void set(uint64_t i, unsigned c) { w[i >> 5] |= (uint64_t)c << (62 - ((i & 31) << 1)); }
 	inline unsigned get(uint64_t i) const { return w[i >> 5] >> (62 - ((i & 31) << 1)) & 3; }
 	inline uint64_t get32(uint64_t i) const {   // 32 bases starting at i (garbage past n is zero)
@@ -74,7 +83,14 @@ inline bool suffix_less(const Packed &T, uint64_t i, uint64_t j)
 // every element is written by the phase that owns the array.
 template <typename V> struct Raw {
 	V *p = nullptr;
-	explicit Raw(uint64_t n) : p((V *)malloc((size_t)(n ? n : 1) * sizeof(V))) {}
+	explicit Raw(uint64_t n)
+	{
+		const size_t bytes = (size_t)(n ? n : 1) * sizeof(V);
+		if (bytes >= ((size_t)64 << 20)) {
+			void *q = nullptr;
+			if (posix_memalign(&q, (size_t)2 << 20, bytes) == 0) { p = (V *)q; want_huge_pages(q, bytes); }
+		} else p = (V *)malloc(bytes);
+	}
 	~Raw() { free(p); }
 	Raw(const Raw &) = delete;
 	Raw &operator=(const Raw &) = delete;

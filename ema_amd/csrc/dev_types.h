@@ -84,10 +84,6 @@ struct ChainRec {
 // chain-filter results travel with the read, so the wave-per-read kernel starts at mem_chain2aln.  Per read:
 // {n_chn, n_seed}, the filter's sorted keys (weight << 32 | chain), the chains, the seed pool.  A todo-list entry with
 // bit 31 set says the record is there.
-// A seed interval with a single occurrence can carry the occurrence itself: x0 = its position in the forward-reverse
-// text, x1 = EMA_POSMODE, x2 = 1 (K1 follows such matches along the text instead of through rank queries; K2 then needs
-// no suffix-array look-up for them).
-#define EMA_POSMODE 0xFFFFFFFFFFFFFFFFull
 #define EMA_HAND_SEEDS 32
 #define EMA_HAND_BYTES ((size_t)16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)))
 #define EMA_HAND_FLAG 0x80000000u

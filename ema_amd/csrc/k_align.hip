@@ -315,7 +315,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 				const int64_t idx = base + lane;
 				int64_t rbeg = 0; int rid = -1;
 				if (idx < n_occ) {      // consecutive suffix-array rows (step 1) -> coalesced loads
-					rbeg = p.x1 == EMA_POSMODE ? (int64_t)p.x0 : (int64_t)ema_sa(ix, p.x0 + (uint64_t)(idx * step));
+					rbeg = (int64_t)ema_sa(ix, p.x0 + (uint64_t)(idx * step));
 					rid = ema_intv2rid(ix, rbeg, rbeg + slen);
 				}
 				const int cnt = (int)(n_occ - base < EMA_WAVE ? n_occ - base : EMA_WAVE);

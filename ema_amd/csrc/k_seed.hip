@@ -88,9 +88,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 	Intv ent; ent.x0 = ent.x1 = ent.x2 = ent.info = 0;        // list entry / output entry loaded in the previous tick
 	size_t out_base = 0;
 	bool has_req = false, exhausted = false;
-	int req_c = 0, ld_kind = 0;      // ld_kind: 1 = next list entry of the backward row, 2 = out[k2 - 1] for pass 2; req_c 5 = position-mode step
-	uint64_t tw = 0; int64_t tw_blk = -1;                     // 32 bases of the packed reference (forward coordinates tw_blk * 32 ...)
-	const int64_t n_text = ix.l_pac << 1;
+	int req_c = 0, ld_kind = 0;      // ld_kind: 1 = next list entry of the backward row, 2 = out[k2 - 1] for pass 2
 	size_t ld_at = 0;
 
 	auto q = [&](int p_) -> int {
@@ -265,28 +263,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			// (7) the one place that looks up the next base and posts the extend
 			if (pc == PC_FWD || pc == PC_BWD || pc == PC_S3) {
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
-				if (b < 4 && c1 == EMA_POSMODE && pc != PC_S3) {
-					// a single occurrence, known by its position: the next base is read off the text (one 8-byte load per 32
-					// bases) instead of two rank queries; the result goes to the same handlers.  With the window at hand and
-					// no list entry to fetch the step is done here; otherwise it is posted like an extend (req_c 5) and done
-					// with the tick's loads -- a parked machine keeps only what a posted request needs.
-					const int64_t tq = pc == PC_BWD ? (int64_t)c0 - 1 : (int64_t)c0 + (i - sm_x);
-					const bool in_text = tq >= 0 && tq < n_text;
-					const int64_t tf = tq >= ix.l_pac ? n_text - 1 - tq : tq;
-					const bool need_ld = pc == PC_BWD && j + 1 < n_prev;
-					if ((in_text && (tf >> 5) != tw_blk) || need_ld) {
-						has_req = true; req_c = 5;
-						if (need_ld) { ld_at = (size_t)((prev_is_a ? 0 : EMA_LIST_CAP) + (rev ? n_prev - 2 - j : j + 1)) << 6; ld_kind = 1; }
-					} else {
-						int tb = 4;      // outside the text: the sentinel, matches nothing
-						if (in_text) {
-							tb = (int)(tw >> ((((tf >> 2) & 7) << 3) + ((~tf & 3) << 1))) & 3;
-							if (tq >= ix.l_pac) tb = 3 - tb;
-						}
-						r2 = tb == b ? 1 : 0; r0 = pc == PC_BWD ? c0 - 1 : c0; r1 = EMA_POSMODE;
-					}
-					pc += 1;
-				} else if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier (rank queries only count)
+				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
 				else if (b < 4) {
 					has_req = true;
 					if (pc == PC_BWD) {
@@ -325,30 +302,12 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			ent.x0 = lo.x; ent.x1 = lo.y; ent.x2 = hi.x; ent.info = hi.y;
 			ld_kind = 0;
 		}
-		if (has_req && req_c == 5) {      // a position-mode step (pc already at its handler)
-			const bool back = pc == PC_BWD_RES;
-			const int64_t tq = back ? (int64_t)c0 - 1 : (int64_t)c0 + (i - sm_x);
-			const bool in_text = tq >= 0 && tq < n_text;
-			const int64_t tf = tq >= ix.l_pac ? n_text - 1 - tq : tq;
-			if (in_text && (tf >> 5) != tw_blk) {
-				tw_blk = tf >> 5;
-				tw = *reinterpret_cast<const uint64_t *>(ix.pac + (tw_blk << 3));
-			}
-			int tb = 4;
-			if (in_text) {
-				tb = (int)(tw >> ((((tf >> 2) & 7) << 3) + ((~tf & 3) << 1))) & 3;
-				if (tq >= ix.l_pac) tb = 3 - tb;
-			}
-			r2 = tb == q(i) ? 1 : 0; r0 = back ? c0 - 1 : c0; r1 = EMA_POSMODE;
-			has_req = false;
-		} else if (has_req) {
+		if (has_req) {
 			// forward extension works on x[1] (the reverse-complement strand), backward on x[0]
 			const bool back = pc == PC_BWD_RES;
 			uint64_t o_nb = 0, o_b = 0, o_size = 0;
 			ema_lane_extend(ix, back ? c0 : c1, back ? c1 : c0, c2, req_c, o_nb, o_b, o_size);
 			r0 = back ? o_nb : o_b; r1 = back ? o_b : o_nb; r2 = o_size;
-			// pass 1 follows a match down to its last base: once a single occurrence is left, take its position
-			if (pass == 1 && o_size == 1 && pc != PC_S3_RES) { r0 = ema_sa(ix, r0); r1 = EMA_POSMODE; }
 			has_req = false;
 		}
 	}

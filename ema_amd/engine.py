@@ -296,8 +296,7 @@ class Engine:
         return self.fetch()
 
     def debug_seeds(self):
-        """Seed intervals of the staged batch: (intv[n_reads, cap, 4] u64 = k, k', size, start<<32|end; n_intv).  K1 names a
-        single-occurrence interval by its text position: k' = 2^64-1 (EMA_POSMODE), k = the position, size = 1."""
+        """Seed intervals of the staged batch: (intv[n_reads, cap, 4] u64 = k, k', size, start<<32|end; n_intv)."""
         pi, pn, cap = C.POINTER(C.c_uint64)(), C.POINTER(C.c_int32)(), C.c_int32()
         self._check(self._L.ema_engine_debug_seeds(self._h, C.byref(pi), C.byref(pn), C.byref(cap)), "debug_seeds")
         libc = C.CDLL(None)

@@ -128,9 +128,7 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out);
 
 /* Stage-level access used by the parity tests and the profiler (the staged batch must fit the full-capacity tier,
  * on which these run): seed intervals of the staged batch (what bwa's mem_collect_intv leaves in aux->mem).  Runs K1 only.
- * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free().  An interval with a
- * single occurrence may come back named by that occurrence: k' = 2^64-1, k = its position in the forward-reverse text
- * (= SA[k] of bwa's interval), size = 1. */
+ * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free(). */
 int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read);
 
 /* Regions of every staged read after seeding, chaining, extension and dedup (bwa's mem_align1_core result,

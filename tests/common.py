@@ -53,23 +53,3 @@ def golden_workload():
         pairs = synth.Pairs(np.frombuffer(b"".join(reads), dtype=np.uint8), off)
         _CACHE["golden"] = (prefix, pairs, doc["intervals"], doc["candidates"])
     return _CACHE["golden"]
-
-
-POSMODE = (1 << 64) - 1      # EMA_POSMODE (ema_amd/csrc/dev_types.h)
-
-
-def same_intervals(idx, ref, got):
-    """K1's seed intervals of one read against the oracle's.  Both are lists of (start, end, x0, x1, x2).  K1 hands a
-    single-occurrence interval over by its text position (x1 = EMA_POSMODE, x0 = position): such an interval equals the
-    oracle's (k, l, 1) when SA[k] is that position -- the same occurrence, named differently."""
-    if len(ref) != len(got):
-        return False
-    for e, g in zip(ref, got):
-        e = tuple(int(t) for t in e)
-        g = tuple(int(t) for t in g)
-        if g[3] == POSMODE:
-            if (e[0], e[1], e[4]) != (g[0], g[1], 1) or g[4] != 1 or idx.sa(e[2]) != g[2]:
-                return False
-        elif e != g:
-            return False
-    return True

@@ -24,7 +24,4 @@ PY
 }
 run default X=1 --
 run seed_blocks3 EMA_SEED_BLOCKS_PER_CU=3 --
-run seed_blocks4 EMA_SEED_BLOCKS_PER_CU=4 --
 run streams4 X=1 -- --streams 4
-run budget8192 X=1 -- --lean-seed-extends 8192 --allow-capacity-flags
-run park0 EMA_SEED_PARK=0 --

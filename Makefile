@@ -9,8 +9,8 @@ all: ema_amd/libema_index.so ema_amd/libema_engine.so oracle
 ema_amd/libema_index.so: $(CSRC)/index_build.cpp
 	$(CXX) $(HOSTFLAGS) -fopenmp -shared -o $@ $<
 
-ENGINE_SRCS = $(wildcard $(CSRC)/*.hip) $(CSRC)/host_index.cpp $(CSRC)/host_append.cpp $(CSRC)/host_ingest.cpp
-ENGINE_HDRS = $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/ema_engine.h include/ema_ingest.h
+ENGINE_SRCS = $(wildcard $(CSRC)/*.hip) $(CSRC)/host_index.cpp $(CSRC)/host_append.cpp $(CSRC)/host_ingest.cpp $(CSRC)/host_sam.cpp
+ENGINE_HDRS = $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/ema_engine.h include/ema_ingest.h include/ema_sam.h
 ema_amd/libema_engine.so: $(ENGINE_SRCS) $(ENGINE_HDRS)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude -I$(CSRC) -o $@ $(ENGINE_SRCS)
 

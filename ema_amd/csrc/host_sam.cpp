@@ -1,0 +1,232 @@
+// ema_amd/csrc/host_sam.cpp -- SAM record formatter (include/ema_sam.h; SURVEY 8f rank 1, the writer part).
+//
+// print_sam_record() (reference src/samrecord.c:104-284) writes one line through ~30 fprintf/fputc calls under the
+// output lock; here a batch of lines is formatted by the host's cores, each thread appending to its own buffer with
+// hand-rolled integer output, and the pieces are laid end to end, so the caller issues one large write per batch
+// (~2 records x ~450 B per pair is GB/s of text at the engine's rate).  The text is the reference's, byte for
+// byte; "%.5g" goes through snprintf so that the gamma field cannot differ.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "ema_sam.h"
+
+namespace {
+
+enum { kPaired = 1, kProper = 2, kUnmapped = 4, kMateUnmapped = 8, kReversed = 16, kMateReversed = 32, k1st = 64, k2nd = 128,
+       kDup = 1024 };      // reference include/samrecord.h:73-81
+
+// Append-only text buffer: room for a whole line is made once (line_bound), then bytes go through a bare cursor.
+struct Out {
+	std::vector<char> buf;
+	size_t n = 0;
+	char *p = nullptr;
+	void room(size_t more)
+	{
+		if (n + more > buf.size()) buf.resize(std::max(buf.size() * 2, n + more + (1 << 16)));
+		p = buf.data() + n;
+	}
+	void done() { n = (size_t)(p - buf.data()); }
+	void ch(char c) { *p++ = c; }
+	void str(const char *q) { while (*q) *p++ = *q++; }
+	void mem(const char *q, size_t k) { memcpy(p, q, k); p += k; }
+	void u64(uint64_t v)
+	{
+		char t[24]; int k = 0;
+		do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+		while (k) *p++ = t[--k];
+	}
+	void i64(int64_t v) { if (v < 0) { *p++ = '-'; u64((uint64_t)0 - (uint64_t)v); } else u64((uint64_t)v); }
+};
+
+size_t line_bound(const ema_sam_rec *rec, const ema_sam_rec *mate, const ema_sam_opts &opt)
+{
+	const ema_sam_rec *r = rec ? rec : mate;
+	size_t b = 512 + strlen(r->ident) + (opt.rg_id ? strlen(opt.rg_id) : 0) + strlen(opt.bx_index);
+	b += 2 * (size_t)(rec ? rec->read_len : mate->mate_read_len);
+	if (rec) {
+		b += strlen(rec->chrom) + 12 * (size_t)rec->n_cigar;
+		for (size_t i = 0; i < rec->n_alts; ++i) b += strlen(rec->alts[i].chrom) + 12 * (size_t)rec->alts[i].n_cigar + 48;
+	}
+	if (mate) b += strlen(mate->chrom);
+	return b;
+}
+
+const struct CompTable {
+	char t[256];
+	CompTable() { memset(t, 0, sizeof t); t['A'] = 'T'; t['C'] = 'G'; t['G'] = 'C'; t['T'] = 'A'; t['N'] = 'N'; }
+	char operator[](unsigned char c) const { return t[c]; }
+} kComp;
+
+int ref_len(int n_cigar, const uint32_t *cigar)      // get_rlen, src/samrecord.c:75-84
+{
+	int l = 0;
+	for (int k = 0; k < n_cigar; ++k) { const int op = (int)(cigar[k] & 0xf); if (op == 0 || op == 2) l += (int)(cigar[k] >> 4); }
+	return l;
+}
+
+void put_cigar(Out &o, const uint32_t *cigar, int n)      // hard clips shown as soft: "MIDSS"
+{
+	for (int i = 0; i < n; ++i) { o.u64(cigar[i] >> 4); o.ch("MIDSS"[cigar[i] & 0xf]); }
+}
+
+bool is_pair(const ema_sam_rec *r1, const ema_sam_rec *r2, const ema_sam_opts &opt)      // src/align.c:27-40
+{
+	if (r1->rev == r2->rev || r1->chrom_id != r2->chrom_id) return false;
+	if (r2->rev) { const ema_sam_rec *t = r2; r2 = r1; r1 = t; }
+	const int64_t d = (int64_t)(uint32_t)(r1->pos - r2->pos);      // the reference subtracts two uint32_t: never negative
+	return opt.insert_min <= d && d <= opt.insert_max;
+}
+
+void decode_bc(uint64_t bc, const ema_sam_opts &opt, char *out)      // src/util.c:78-95
+{
+	if (opt.is_haplotag) {
+		snprintf(out, 40, "A%02uC%02uB%02uD%02u", (unsigned)(bc >> 24) & 127, (unsigned)(bc >> 16) & 127, (unsigned)(bc >> 8) & 127,
+		         (unsigned)bc & 127);
+		return;
+	}
+	for (int i = 0; i < opt.bc_len; ++i) { out[i] = "ACGT"[bc & 3]; bc >>= 2; }
+	out[opt.bc_len] = 0;
+}
+
+// one line; false: a base outside ACGTN in a reversed read
+bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema_sam_opts &opt)
+{
+	o.room(line_bound(rec, mate, opt));
+	int flag = kPaired, mapq = 0, read_len;
+	const char *ident, *chrom = "*", *read, *qual;
+	uint32_t pos = 0;
+	uint64_t bc;
+	if (rec) {
+		ident = rec->ident; chrom = rec->chrom; pos = rec->pos; read_len = rec->read_len; bc = rec->bc; read = rec->read; qual = rec->qual;
+		const int gamma_mapq = rec->gamma <= 0.999999 ? (int)(-10 * std::log10(1 - rec->gamma)) : 60;
+		mapq = gamma_mapq < rec->score_mapq ? gamma_mapq : rec->score_mapq;
+		mapq = mapq < rec->mapq ? mapq : rec->mapq;
+		mapq = mapq > 0 ? mapq : 0;
+		mapq = mapq < 60 ? mapq : 60;
+		if (rec->rev) flag |= kReversed;
+		if (rec->duplicate) flag |= kDup;
+		flag |= rec->mate == 0 ? k1st : k2nd;
+	} else {
+		ident = mate->ident; read_len = mate->mate_read_len; bc = mate->bc; read = mate->mate_read; qual = mate->mate_qual;
+		flag |= kUnmapped;
+		flag |= mate->mate == 0 ? k2nd : k1st;
+	}
+	if (mate) {
+		if (rec && is_pair(rec, mate, opt)) flag |= kProper;
+		if (mate->rev) flag |= kMateReversed;
+	} else flag |= kMateUnmapped;
+	o.str(ident); o.ch('\t'); o.i64(flag); o.ch('\t'); o.str(chrom); o.ch('\t'); o.u64(pos); o.ch('\t'); o.i64(mapq); o.ch('\t');
+	if (rec) put_cigar(o, rec->cigar, rec->n_cigar); else o.ch('*');
+	if (mate) {
+		const bool same_chrom = rec && mate->chrom_id == rec->chrom_id;
+		o.ch('\t'); o.str(same_chrom ? "=" : mate->chrom); o.ch('\t'); o.i64((int)mate->pos);      // "%d" of a uint32_t
+		if (same_chrom) {
+			const int64_t p0 = rec->aln_pos + (rec->aln_rev ? ref_len(rec->n_cigar, rec->cigar) - 1 : 0);
+			const int64_t p1 = mate->aln_pos + (mate->aln_rev ? ref_len(mate->n_cigar, mate->cigar) - 1 : 0);
+			o.ch('\t');
+			if (mate->n_cigar == 0 || rec->n_cigar == 0) o.ch('0');
+			else o.i64(-(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
+		} else o.str("\t0");
+	} else o.str("\t*\t0\t0");
+	o.ch('\t');
+	if (rec && rec->rev) {
+		for (int i = read_len - 1; i >= 0; --i) {
+			const char c = kComp[(unsigned char)read[i]];      // rc(), src/samrecord.c:86-102
+			if (!c) return false;
+			o.ch(c);
+		}
+		o.ch('\t');
+		for (int i = read_len - 1; i >= 0; --i) o.ch(qual[i]);
+	} else {
+		o.mem(read, (size_t)read_len); o.ch('\t'); o.mem(qual, (size_t)read_len);
+	}
+	char bc_str[48];
+	decode_bc(bc, opt, bc_str);
+	if (rec) {
+		char g[48];
+		snprintf(g, sizeof g, "%.5g", rec->gamma);
+		o.str("\tNM:i:"); o.i64(rec->edit_dist); o.str("\tBX:Z:"); o.str(bc_str);
+		if (!opt.is_haplotag) { o.ch('-'); o.str(opt.bx_index); }
+		o.str("\tXG:f:"); o.str(g); o.str("\tMI:i:"); o.i64(rec->cloud_id); o.str("\tXF:i:"); o.i64(rec->cloud_bad);
+	} else {
+		o.str("\tBX:Z:"); o.str(bc_str);
+		if (!opt.is_haplotag) o.str("-1");      // the literal suffix, not bx_index (src/samrecord.c:255)
+	}
+	if (opt.rg_id) {
+		o.str("\tRG:Z:");
+		for (size_t i = 0; opt.rg_id[i] && !(opt.rg_id[i] == ' ' || (opt.rg_id[i] >= '\t' && opt.rg_id[i] <= '\r')); ++i) o.ch(opt.rg_id[i]);
+	}
+	if (rec && rec->n_alts > 0) {
+		o.str("\tXA:Z:");
+		for (size_t i = 0; i < rec->n_alts; ++i) {
+			const ema_sam_alt &a = rec->alts[i];
+			o.str(a.chrom); o.ch(','); o.ch(a.rev ? '-' : '+'); o.i64((int)a.pos); o.ch(',');
+			put_cigar(o, a.cigar, a.n_cigar);
+			o.ch(','); o.i64(a.edit_dist); o.ch(';');
+		}
+	}
+	o.ch('\n');
+	o.done();
+	return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ema_sam_opts_default(ema_sam_opts *o)
+{
+	if (!o) return;
+	o->rg_id = nullptr; o->bx_index = "1"; o->bc_len = 16; o->is_haplotag = 0; o->insert_min = -35; o->insert_max = 750;
+}
+
+void ema_sam_free(char *text) { free(text); }
+
+int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, char **text, size_t *n_bytes)
+{
+	if (!text || !n_bytes) return EMA_EARG;
+	*text = nullptr; *n_bytes = 0;
+	if ((!lines && n) || !opt || !opt->bx_index || opt->bc_len < 1 || opt->bc_len > 32 || (opt->is_haplotag && opt->bc_len != 12)) return EMA_EARG;
+	for (size_t i = 0; i < n; ++i) if (!lines[i].rec && !lines[i].mate) return EMA_EARG;
+	static int n_thr_max = [] {
+		const char *v = getenv("EMA_HOST_THREADS");
+		int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
+		return t < 1 ? 1 : t > 32 ? 32 : t;
+	}();
+	const size_t t = n < 4096 ? 1 : (size_t)n_thr_max, per = (n + t - 1) / t;
+	std::vector<Out> parts(t);
+	std::vector<int> bad(t, 0);
+	auto work = [&](size_t k) {
+		const size_t lo = std::min(n, k * per), hi = std::min(n, lo + per);
+		parts[k].buf.resize((hi - lo) * 400 + (1 << 16));
+		for (size_t i = lo; i < hi; ++i) if (!put_line(parts[k], lines[i].rec, lines[i].mate, *opt)) { bad[k] = 1; return; }
+	};
+	{
+		std::vector<std::thread> th;
+		for (size_t k = 1; k < t; ++k) th.emplace_back(work, k);
+		work(0);
+		for (auto &x : th) x.join();
+	}
+	for (int b : bad) if (b) return EMA_EFORMAT;
+	size_t total = 0;
+	std::vector<size_t> at(t + 1, 0);
+	for (size_t k = 0; k < t; ++k) { total += parts[k].n; at[k + 1] = total; }
+	char *buf = (char *)malloc(total + 1);
+	if (!buf) return EMA_EARG;
+	{
+		std::vector<std::thread> th;
+		auto copy = [&](size_t k) { memcpy(buf + at[k], parts[k].buf.data(), parts[k].n); };
+		for (size_t k = 1; k < t; ++k) th.emplace_back(copy, k);
+		copy(0);
+		for (auto &x : th) x.join();
+	}
+	*text = buf; *n_bytes = total;
+	return 0;
+}
+
+}  // extern "C"

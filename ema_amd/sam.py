@@ -1,0 +1,62 @@
+"""Host mirror of the SAM record formatter (include/ema_sam.h): the reference's print_sam_record
+(reference src/samrecord.c:104-284) for a batch of lines in one call.  ctypes over the C ABI in libema_engine.so; no
+fallback -- a missing library raises."""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import engine as _engine
+
+
+class SamAlt(C.Structure):
+    _fields_ = [("chrom", C.c_char_p), ("pos", C.c_uint32), ("edit_dist", C.c_int32), ("rev", C.c_int32), ("n_cigar", C.c_int32),
+                ("cigar", C.POINTER(C.c_uint32))]
+
+
+class SamRec(C.Structure):
+    _fields_ = [("ident", C.c_char_p), ("chrom", C.c_char_p), ("chrom_id", C.c_uint32), ("pos", C.c_uint32),
+                ("mapq", C.c_int32), ("score_mapq", C.c_int32), ("gamma", C.c_double),
+                ("mate", C.c_uint8), ("rev", C.c_uint8), ("duplicate", C.c_uint8), ("pad_", C.c_uint8),
+                ("cloud_id", C.c_int32), ("cloud_bad", C.c_int32), ("bc", C.c_uint64),
+                ("read", C.c_char_p), ("qual", C.c_char_p), ("read_len", C.c_int32), ("mate_read_len", C.c_int32),
+                ("mate_read", C.c_char_p), ("mate_qual", C.c_char_p), ("aln_pos", C.c_int64),
+                ("aln_rev", C.c_int32), ("edit_dist", C.c_int32), ("n_cigar", C.c_int32), ("pad2_", C.c_int32),
+                ("cigar", C.POINTER(C.c_uint32)), ("alts", C.POINTER(SamAlt)), ("n_alts", C.c_size_t)]
+
+
+class SamLine(C.Structure):
+    _fields_ = [("rec", C.POINTER(SamRec)), ("mate", C.POINTER(SamRec))]
+
+
+class SamOpts(C.Structure):
+    _fields_ = [("rg_id", C.c_char_p), ("bx_index", C.c_char_p), ("bc_len", C.c_int32), ("is_haplotag", C.c_int32),
+                ("insert_min", C.c_int32), ("insert_max", C.c_int32)]
+
+
+def _lib():
+    L = _engine.load_library()
+    if not getattr(L, "_sam_bound", False):
+        L.ema_sam_opts_default.argtypes = [C.POINTER(SamOpts)]
+        L.ema_sam_format.argtypes = [C.POINTER(SamLine), C.c_size_t, C.POINTER(SamOpts), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.ema_sam_free.argtypes = [C.c_void_p]
+        L._sam_bound = True
+    return L
+
+
+def default_opts() -> SamOpts:
+    o = SamOpts()
+    _lib().ema_sam_opts_default(C.byref(o))
+    return o
+
+
+def format_lines(lines, n: int, opts: SamOpts) -> bytes:
+    """lines: a ctypes array of SamLine (the caller keeps everything it points at alive).  Returns the SAM text."""
+    L = _lib()
+    text, size = C.c_void_p(), C.c_size_t()
+    rc = L.ema_sam_format(lines, n, C.byref(opts), C.byref(text), C.byref(size))
+    if rc != 0:
+        raise RuntimeError(f"ema_sam_format failed (code {rc})")
+    try:
+        return C.string_at(text, size.value)
+    finally:
+        L.ema_sam_free(text)

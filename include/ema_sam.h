@@ -1,0 +1,79 @@
+/* include/ema_sam.h -- C ABI of the SAM record formatter behind the hot path (the writer part).
+ *
+ * Replaces, on the reference's side, print_sam_record() (reference src/samrecord.c:104-284) as `ema align` calls it
+ * for every selected alignment and its mate under the output lock (src/align.c:597-602): one fprintf/fputc at a time
+ * there, here a whole batch of lines formatted on the host's cores into one buffer that the caller writes with a single
+ * call.  Byte for byte the reference's text: flags, MAPQ = min(gamma-, score- and bwa-mapq) clamped to [0, 60]
+ * (:139-146), CIGAR with hard clips shown as soft (:178-186, :270-276), mate fields and template length (:189-211),
+ * reversed records reverse-complemented (:215-225), the NM / BX / XG / MI / XF tags in their 10x and haplotag forms
+ * (:239-258, including the literal "-1" barcode suffix of a line that stands in for an unmapped read), RG up to the
+ * first whitespace (:260-264) and XA (:266-279).  Host code only; clouds, EM and duplicate marking, which fill these
+ * fields, stay with the caller.
+ *
+ * Where the reference asserts (a base outside ACGTN in a reversed read, :90-102; both records NULL, :110) the call
+ * returns EMA_EFORMAT / EMA_EARG instead.
+ */
+#ifndef EMA_SAM_H
+#define EMA_SAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef EMA_EARG
+#define EMA_EARG (-1)
+#endif
+#ifndef EMA_EFORMAT
+#define EMA_EFORMAT (-7)
+#endif
+
+typedef struct ema_sam_alt {      /* struct xa, reference include/align.h:37-44 */
+	const char *chrom;
+	uint32_t pos;
+	int32_t edit_dist, rev, n_cigar;
+	const uint32_t *cigar;        /* BAM-packed: len << 4 | op */
+} ema_sam_alt;
+
+typedef struct ema_sam_rec {      /* what print_sam_record reads of one SAMRecord and the FASTQRecord, Cloud and
+                                   * SingleReadAlignment it points at (reference include/samrecord.h:21-56) */
+	const char *ident;            /* rec->ident */
+	const char *chrom;            /* chrom_lookup(rec->chrom) */
+	uint32_t chrom_id, pos;       /* rec->chrom, rec->pos */
+	int32_t mapq, score_mapq;     /* rec->mapq (bwa's), rec->score_mapq */
+	double gamma;                 /* rec->gamma */
+	uint8_t mate, rev, duplicate, pad_;
+	int32_t cloud_id, cloud_bad;  /* rec->cloud->id, ->bad */
+	uint64_t bc;                  /* rec->bc */
+	const char *read, *qual;      /* rec->fq->read, ->qual */
+	int32_t read_len;             /* rec->fq->rlen */
+	int32_t mate_read_len;        /* rec->fq_mate->rlen */
+	const char *mate_read, *mate_qual;      /* rec->fq_mate: printed when this record's unmapped mate gets its line */
+	int64_t aln_pos;              /* rec->aln.pos */
+	int32_t aln_rev, edit_dist, n_cigar, pad2_;
+	const uint32_t *cigar;        /* rec->aln.cigar */
+	const ema_sam_alt *alts;      /* rec->alts, rec->n_alts */
+	size_t n_alts;
+} ema_sam_rec;
+
+typedef struct ema_sam_line { const ema_sam_rec *rec, *mate; } ema_sam_line;      /* print_sam_record(rec, mate, ...): one may be NULL */
+
+typedef struct ema_sam_opts {
+	const char *rg_id;            /* NULL: no RG tag */
+	const char *bx_index;         /* the reference's global, "1" by default (src/main.c:26) */
+	int32_t bc_len, is_haplotag;  /* BC_LEN; -p haplotag */
+	int32_t insert_min, insert_max;      /* INSERT_MIN / INSERT_MAX of is_pair(), -35 / 750 (include/align.h:66-67) */
+} ema_sam_opts;
+
+void ema_sam_opts_default(ema_sam_opts *o);
+
+/* Formats lines[0..n) in order.  *text (n_bytes long, not NUL-terminated) is freed with ema_sam_free(). */
+int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *o, char **text, size_t *n_bytes);
+void ema_sam_free(char *text);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -28,6 +28,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -232,6 +233,30 @@ void orc_decode_bc(uint64_t bc, int bc_len, int is_haplotag, char *out);
 /* *r1, *r2: n + 1 records each (the last one the sentinel), freed by the caller with free() */
 int orc_read_special_fastq(const char *path, int bc_len, int is_haplotag, orc_fastq_rec_t **r1, orc_fastq_rec_t **r2, size_t *n);
 size_t orc_next_group(const orc_fastq_rec_t *recs, size_t at);
+
+/* ---- SAM record formatter (oracle/sam.c; reference src/samrecord.c:75-284, src/align.c:27-40).  The structs have the
+ * layout of include/ema_sam.h's, so that a test can hand the same arrays to both sides. ---- */
+typedef struct { const char *chrom; uint32_t pos; int32_t edit_dist, rev, n_cigar; const uint32_t *cigar; } orc_sam_alt_t;
+typedef struct {
+	const char *ident, *chrom;
+	uint32_t chrom_id, pos;
+	int32_t mapq, score_mapq;
+	double gamma;
+	uint8_t mate, rev, duplicate, pad_;
+	int32_t cloud_id, cloud_bad;
+	uint64_t bc;
+	const char *read, *qual;
+	int32_t read_len, mate_read_len;
+	const char *mate_read, *mate_qual;
+	int64_t aln_pos;
+	int32_t aln_rev, edit_dist, n_cigar, pad2_;
+	const uint32_t *cigar;
+	const orc_sam_alt_t *alts;
+	size_t n_alts;
+} orc_sam_rec_t;
+typedef struct { const orc_sam_rec_t *rec, *mate; } orc_sam_line_t;
+typedef struct { const char *rg_id, *bx_index; int32_t bc_len, is_haplotag, insert_min, insert_max; } orc_sam_opts_t;
+int orc_sam_format(const orc_sam_line_t *lines, size_t n, const orc_sam_opts_t *o, char **text, size_t *n_bytes);
 
 #ifdef __cplusplus
 }

@@ -30,11 +30,12 @@ def test_every_header_in_include_is_covered():
     from ema_amd import engine
     L = engine.load_library()
     headers = sorted(h for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h"))
-    assert headers == ["ema_engine.h", "ema_ingest.h"]
-    names = declared_symbols("ema_ingest.h")
-    assert len(names) == 6
-    for n in names:
-        assert hasattr(L, n), f"{n} declared in include/ema_ingest.h but not exported by libema_engine.so"
+    assert headers == ["ema_engine.h", "ema_ingest.h", "ema_sam.h"]
+    for header, count in (("ema_ingest.h", 6), ("ema_sam.h", 3)):
+        names = declared_symbols(header)
+        assert len(names) == count, names
+        for n in names:
+            assert hasattr(L, n), f"{n} declared in include/{header} but not exported by libema_engine.so"
 
 
 def test_default_options_match_the_reference():

@@ -132,7 +132,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        import datetime
+        # rank 0 builds genome and index (minutes at the default scale) while the others wait at a barrier
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
     assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     import __graft_entry__

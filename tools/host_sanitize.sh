@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev aid (CPU only): the host-side C++ of the library -- bucket reader, SAM formatter, append stage, index builder --
+# Dev aid (CPU only): the host-side C++ of the library -- bucket reader, SAM formatter, index builder --
 # compiled with AddressSanitizer + UBSan into throw-away libraries under /tmp and driven by the CPU tests of those
 # parts (GPU sanitizers are not available on the pool; the kernels go through the host SIMT interpreter instead, which
 # tests/emu/build.sh can build with -fsanitize as well).
@@ -8,8 +8,8 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=${TMPDIR:-/tmp}/ema_asan_$$
 mkdir -p "$out"
 flags="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -fPIC -shared"
-g++ $flags -I"$root/include" -I"$root/ema_amd/csrc" -o "$out/libhost.so" "$root"/ema_amd/csrc/host_ingest.cpp "$root"/ema_amd/csrc/host_sam.cpp \
-    "$root"/ema_amd/csrc/host_append.cpp -lpthread
+g++ $flags -I"$root/include" -I"$root/ema_amd/csrc" -o "$out/libhost.so" "$root"/ema_amd/csrc/host_ingest.cpp "$root"/ema_amd/csrc/host_sam.cpp
+ -lpthread
 g++ $flags -fopenmp -o "$out/libindex.so" "$root"/ema_amd/csrc/index_build.cpp
 cat > "$out/run.py" <<PY
 import sys, ctypes

@@ -8,8 +8,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=${TMPDIR:-/tmp}/ema_asan_$$
 mkdir -p "$out"
 flags="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -fPIC -shared"
-g++ $flags -I"$root/include" -I"$root/ema_amd/csrc" -o "$out/libhost.so" "$root"/ema_amd/csrc/host_ingest.cpp "$root"/ema_amd/csrc/host_sam.cpp
- -lpthread
+g++ $flags -I"$root/include" -I"$root/ema_amd/csrc" -o "$out/libhost.so" "$root"/ema_amd/csrc/host_ingest.cpp "$root"/ema_amd/csrc/host_sam.cpp -lpthread
 g++ $flags -fopenmp -o "$out/libindex.so" "$root"/ema_amd/csrc/index_build.cpp
 cat > "$out/run.py" <<PY
 import sys, ctypes

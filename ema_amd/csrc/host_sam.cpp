@@ -13,6 +13,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <unistd.h>
 #include "ema_sam.h"
 
 namespace {
@@ -187,10 +188,9 @@ void ema_sam_opts_default(ema_sam_opts *o)
 
 void ema_sam_free(char *text) { free(text); }
 
-int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, char **text, size_t *n_bytes)
+// lines[0..n) formatted by the host's threads into one buffer per thread, in order
+static int format_parts(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, std::vector<Out> &parts)
 {
-	if (!text || !n_bytes) return EMA_EARG;
-	*text = nullptr; *n_bytes = 0;
 	if ((!lines && n) || !opt || !opt->bx_index || opt->bc_len < 1 || opt->bc_len > 32 || (opt->is_haplotag && opt->bc_len != 12)) return EMA_EARG;
 	for (size_t i = 0; i < n; ++i) if (!lines[i].rec && !lines[i].mate) return EMA_EARG;
 	static int n_thr_max = [] {
@@ -199,20 +199,29 @@ int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt,
 		return t < 1 ? 1 : t > 32 ? 32 : t;
 	}();
 	const size_t t = n < 4096 ? 1 : (size_t)n_thr_max, per = (n + t - 1) / t;
-	std::vector<Out> parts(t);
+	parts.assign(t, Out());
 	std::vector<int> bad(t, 0);
 	auto work = [&](size_t k) {
 		const size_t lo = std::min(n, k * per), hi = std::min(n, lo + per);
 		parts[k].buf.resize((hi - lo) * 400 + (1 << 16));
 		for (size_t i = lo; i < hi; ++i) if (!put_line(parts[k], lines[i].rec, lines[i].mate, *opt)) { bad[k] = 1; return; }
 	};
-	{
-		std::vector<std::thread> th;
-		for (size_t k = 1; k < t; ++k) th.emplace_back(work, k);
-		work(0);
-		for (auto &x : th) x.join();
-	}
+	std::vector<std::thread> th;
+	for (size_t k = 1; k < t; ++k) th.emplace_back(work, k);
+	work(0);
+	for (auto &x : th) x.join();
 	for (int b : bad) if (b) return EMA_EFORMAT;
+	return 0;
+}
+
+int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, char **text, size_t *n_bytes)
+{
+	if (!text || !n_bytes) return EMA_EARG;
+	*text = nullptr; *n_bytes = 0;
+	std::vector<Out> parts;
+	const int rc = format_parts(lines, n, opt, parts);
+	if (rc) return rc;
+	const size_t t = parts.size();
 	size_t total = 0;
 	std::vector<size_t> at(t + 1, 0);
 	for (size_t k = 0; k < t; ++k) { total += parts[k].n; at[k + 1] = total; }
@@ -226,6 +235,26 @@ int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt,
 		for (auto &x : th) x.join();
 	}
 	*text = buf; *n_bytes = total;
+	return 0;
+}
+
+int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, size_t *n_bytes)
+{
+	if (n_bytes) *n_bytes = 0;
+	std::vector<Out> parts;
+	const int rc = format_parts(lines, n, opt, parts);
+	if (rc) return rc;
+	size_t total = 0;
+	for (const Out &o : parts) {
+		size_t at = 0;
+		while (at < o.n) {
+			const ssize_t w = write(fd, o.buf.data() + at, o.n - at);
+			if (w <= 0) return EMA_EIO;
+			at += (size_t)w;
+		}
+		total += o.n;
+	}
+	if (n_bytes) *n_bytes = total;
 	return 0;
 }
 

@@ -39,6 +39,7 @@ def _lib():
         L.ema_sam_opts_default.argtypes = [C.POINTER(SamOpts)]
         L.ema_sam_format.argtypes = [C.POINTER(SamLine), C.c_size_t, C.POINTER(SamOpts), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.ema_sam_free.argtypes = [C.c_void_p]
+        L.ema_sam_write.argtypes = [C.c_int, C.POINTER(SamLine), C.c_size_t, C.POINTER(SamOpts), C.POINTER(C.c_size_t)]
         L._sam_bound = True
     return L
 
@@ -60,3 +61,12 @@ def format_lines(lines, n: int, opts: SamOpts) -> bytes:
         return C.string_at(text, size.value)
     finally:
         L.ema_sam_free(text)
+
+
+def write_lines(fd: int, lines, n: int, opts: SamOpts) -> int:
+    """The same text straight to an open file descriptor; returns the number of bytes written."""
+    size = C.c_size_t()
+    rc = _lib().ema_sam_write(fd, lines, n, C.byref(opts), C.byref(size))
+    if rc != 0:
+        raise RuntimeError(f"ema_sam_write failed (code {rc})")
+    return size.value

@@ -29,6 +29,9 @@ extern "C" {
 #ifndef EMA_EFORMAT
 #define EMA_EFORMAT (-7)
 #endif
+#ifndef EMA_EIO
+#define EMA_EIO (-6)
+#endif
 
 typedef struct ema_sam_alt {      /* struct xa, reference include/align.h:37-44 */
 	const char *chrom;
@@ -72,6 +75,10 @@ void ema_sam_opts_default(ema_sam_opts *o);
 /* Formats lines[0..n) in order.  *text (n_bytes long, not NUL-terminated) is freed with ema_sam_free(). */
 int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *o, char **text, size_t *n_bytes);
 void ema_sam_free(char *text);
+
+/* The same text written to an open file descriptor (the formatted pieces go out one after another, without being joined
+ * first); *n_bytes, if not NULL, receives the number of bytes written.  EMA_EIO if a write fails. */
+int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opts *o, size_t *n_bytes);
 
 #ifdef __cplusplus
 }

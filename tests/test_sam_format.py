@@ -129,11 +129,18 @@ def test_formatter_equals_the_oracle(haplotag, rg, seed):
     assert got.count(b"\n") == n and b"\tXA:Z:" in got and b"\t=\t" in got
 
 
-def test_large_batch_goes_through_the_threaded_path():
+def test_large_batch_goes_through_the_threaded_path(tmp_path):
     rng = random.Random(9)
     arr, n, pool = make_lines(rng, 3000, False)      # 6000 lines: several threads, pieces laid end to end
     o = sam.default_opts()
-    assert sam.format_lines(arr, n, o) == oracle_text(arr, n, o)
+    want = oracle_text(arr, n, o)
+    assert sam.format_lines(arr, n, o) == want
+    path = str(tmp_path / "out.sam")                 # and the same through ema_sam_write, after a header the caller wrote
+    with open(path, "wb") as f:
+        f.write(b"@HD\tVN:1.3\n")
+        f.flush()
+        assert sam.write_lines(f.fileno(), arr, n, o) == len(want)
+    assert open(path, "rb").read() == b"@HD\tVN:1.3\n" + want
 
 
 def test_known_line():

@@ -26,10 +26,19 @@ for _ in range(5):
     nbytes = size.value
     L.ema_sam_free(text)
 t_prod = sorted(ts)[2]
+devnull = os.open("/dev/null", os.O_WRONLY)
+tw = []
+for _ in range(5):
+    size = C.c_size_t()
+    t = time.perf_counter(); rc = L.ema_sam_write(devnull, arr, n, C.byref(o), C.byref(size)); tw.append(time.perf_counter() - t)
+    assert rc == 0 and size.value == nbytes
+t_write = sorted(tw)[2]
 t = time.perf_counter(); want = T.oracle_text(arr0, n0, o); t_orc = (time.perf_counter() - t) * a.copies
 assert sam.format_lines(arr0, n0, o) == want
 print(f"{n} lines, {nbytes / 1e6:.0f} MB of SAM text", flush=True)
 print(f"ema_sam_format (median of 5): {t_prod * 1e3:.0f} ms = {n / t_prod / 1e6:.2f} M lines/s, {nbytes / t_prod / 1e9:.2f} GB/s "
       f"on {min(32, os.cpu_count())} host threads", flush=True)
+print(f"ema_sam_write to /dev/null (no joining of the pieces): {t_write * 1e3:.0f} ms = {n / t_write / 1e6:.2f} M lines/s, "
+      f"{nbytes / t_write / 1e9:.2f} GB/s", flush=True)
 print(f"oracle (the reference's way: one thread, stdio call by call): {n / t_orc / 1e6:.2f} M lines/s, {nbytes / t_orc / 1e9:.2f} GB/s; "
       f"ratio {t_orc / t_prod:.1f}x", flush=True)

@@ -144,16 +144,19 @@ void build_sa(const Packed &T, I *sa)
 	std::vector<std::vector<uint64_t>> hist((size_t)n_thr);
 	std::vector<uint64_t> cnt(nb + 1, 0);
 	Lap lap;
+	// The text is cut into n_thr stretches ("slots"); the team works through them whatever its actual size turns out to be.
 #pragma omp parallel num_threads(n_thr)
 	{
-		const int t = omp_get_thread_num();
-		std::vector<uint64_t> &h = hist[(size_t)t];
-		h.assign(nb, 0);
-		const uint64_t lo = std::min(n, (uint64_t)t * per), hi = std::min(n, lo + per);
-		for (uint64_t i = lo; i < hi; ++i) ++h[key_at(i)];
+		const int t0 = omp_get_thread_num(), team = omp_get_num_threads();
+		for (int v = t0; v < n_thr; v += team) {
+			std::vector<uint64_t> &h = hist[(size_t)v];
+			h.assign(nb, 0);
+			const uint64_t lo = std::min(n, (uint64_t)v * per), hi = std::min(n, lo + per);
+			for (uint64_t i = lo; i < hi; ++i) ++h[key_at(i)];
+		}
 #pragma omp barrier
 #pragma omp for schedule(static)
-		for (int64_t b = 0; b < (int64_t)nb; ++b) {      // bucket totals, and each thread's share turned into its offset inside the bucket
+		for (int64_t b = 0; b < (int64_t)nb; ++b) {      // bucket totals, and each slot's share turned into its offset inside the bucket
 			uint64_t run = 0;
 			for (int u = 0; u < n_thr; ++u) { const uint64_t c = hist[(size_t)u][(size_t)b]; hist[(size_t)u][(size_t)b] = run; run += c; }
 			cnt[(size_t)b + 1] = run;
@@ -161,7 +164,11 @@ void build_sa(const Packed &T, I *sa)
 #pragma omp single
 		for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
 		I *base = sa + 1;
-		for (uint64_t i = lo; i < hi; ++i) { const uint64_t k = key_at(i); base[cnt[k] + h[k]++] = (I)i; }
+		for (int v = t0; v < n_thr; v += team) {
+			std::vector<uint64_t> &h = hist[(size_t)v];
+			const uint64_t lo = std::min(n, (uint64_t)v * per), hi = std::min(n, lo + per);
+			for (uint64_t i = lo; i < hi; ++i) { const uint64_t k = key_at(i); base[cnt[k] + h[k]++] = (I)i; }
+		}
 	}
 	hist.clear(); hist.shrink_to_fit();
 	lap("bucket");
@@ -229,25 +236,31 @@ int write_index(const std::string &prefix, const Packed &T, const I *sa)
 		for (auto &x : before) x = {0, 0, 0, 0};
 #pragma omp parallel num_threads(n_thr)
 		{
-			const int t = omp_get_thread_num();
-			const uint64_t b_lo = std::min(n_blocks, (uint64_t)t * per), b_hi = std::min(n_blocks, b_lo + per);
-			uint64_t c4[4] = {0, 0, 0, 0};
-			for (uint64_t i = b_lo << 7, e = std::min(n, b_hi << 7); i < e; ++i) ++c4[B[i]];
-			for (int c = 0; c < 4; ++c) before[(size_t)t + 1][c] = c4[c];
+			const int t0 = omp_get_thread_num(), team = omp_get_num_threads();
+			for (int v = t0; v < n_thr; v += team) {      // slots, as in build_sa: independent of the team's actual size
+				const uint64_t b_lo = std::min(n_blocks, (uint64_t)v * per), b_hi = std::min(n_blocks, b_lo + per);
+				uint64_t c4[4] = {0, 0, 0, 0};
+				for (uint64_t i = b_lo << 7, e = std::min(n, b_hi << 7); i < e; ++i) ++c4[B[i]];
+				for (int c = 0; c < 4; ++c) before[(size_t)v + 1][c] = c4[c];
+			}
 #pragma omp barrier
 #pragma omp single
 			for (int u = 0; u < n_thr; ++u) for (int c = 0; c < 4; ++c) before[(size_t)u + 1][c] += before[(size_t)u][c];
-			for (int c = 0; c < 4; ++c) c4[c] = before[(size_t)t][c];
-			for (uint64_t blk = b_lo; blk < b_hi; ++blk) {
-				uint32_t *o = out + blk * 16;
-				memcpy(o, c4, 32);
-				for (uint64_t wi = blk << 3, we = std::min(n_words, (blk + 1) << 3); wi < we; ++wi) {
-					uint32_t word = 0;
-					for (int tt = 0; tt < 16; ++tt) {
-						const uint64_t i = (wi << 4) + tt;
-						if (i < n) { word |= (uint32_t)B[i] << ((15 - tt) << 1); ++c4[B[i]]; }
+			for (int v = t0; v < n_thr; v += team) {
+				const uint64_t b_lo = std::min(n_blocks, (uint64_t)v * per), b_hi = std::min(n_blocks, b_lo + per);
+				uint64_t c4[4];
+				for (int c = 0; c < 4; ++c) c4[c] = before[(size_t)v][c];
+				for (uint64_t blk = b_lo; blk < b_hi; ++blk) {
+					uint32_t *o = out + blk * 16;
+					memcpy(o, c4, 32);
+					for (uint64_t wi = blk << 3, we = std::min(n_words, (blk + 1) << 3); wi < we; ++wi) {
+						uint32_t word = 0;
+						for (int tt = 0; tt < 16; ++tt) {
+							const uint64_t i = (wi << 4) + tt;
+							if (i < n) { word |= (uint32_t)B[i] << ((15 - tt) << 1); ++c4[B[i]]; }
+						}
+						o[8 + (wi & 7)] = word;
 					}
-					o[8 + (wi & 7)] = word;
 				}
 			}
 		}

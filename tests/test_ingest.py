@@ -158,3 +158,42 @@ def test_oracle_util_restatements_equal_the_reference_util_c():
     for line in (b"a b c d e f\n", b"a\tb  c\rd\n", b"abc", b" x y", b"one two\n", b"BC id READ QUAL READ2 QUAL2 rest of line\n"):
         for k in (1, 2, 3):      # stay within the fields the line has: beyond them the reference reads past the terminator
             assert ref.copy_until_space(line, k) == O.oracle_copy_until_space(line, k), (line, k)
+
+
+def test_mutated_buckets_never_crash_the_reader():
+    """Random damage to a valid bucket: the reader either fails with EMA_EFORMAT naming a line, or returns a bucket whose
+    arrays are consistent (the oracle is not consulted here: on malformed input the reference, and so its restatement,
+    has undefined behaviour)."""
+    rng = random.Random(13)
+    base = make_bucket(rng, 60)
+    n_ok = n_bad = 0
+    for trial in range(300):
+        b = bytearray(base)
+        for _ in range(rng.randrange(1, 6)):
+            kind, at = rng.randrange(7), rng.randrange(len(b))
+            if kind >= 5:      # harmless more often than not: a base or quality character for whatever was there
+                b[at] = rng.choice(b"ACGTF")
+            elif kind == 0:
+                b[at] = rng.choice(b" \t\n\r\0AXn#")
+            elif kind == 1:
+                del b[at:at + rng.randrange(1, 40)]
+            elif kind == 2:
+                b[at:at] = bytes(rng.choice(b"ACGT \n") for _ in range(rng.randrange(1, 30)))
+            elif kind == 3:
+                b[at:at] = b"A" * rng.choice((200, 300, 6000))
+            else:
+                b = b[:at]
+        try:
+            got = ingest.parse_bucket(bytes(b))
+        except ingest.BucketError as e:
+            assert e.code == ingest.EMA_EFORMAT and "line " in str(e)
+            n_bad += 1
+            continue
+        n_ok += 1
+        n = got.n_pairs
+        assert len(got.off) == 2 * n + 1 and len(got.id_off) == n + 1 and got.off[0] == 0 and got.id_off[0] == 0
+        assert (np.diff(got.off.astype(np.int64)) >= 0).all() and (np.diff(got.id_off.astype(np.int64)) > 0).all()
+        assert len(got.bases) == len(got.quals) == got.off[-1] and len(got.ids) == got.id_off[-1]
+        assert got.group_off[0] == 0 and got.group_off[-1] == n and (np.diff(got.group_off.astype(np.int64)) > 0).all()
+        assert (np.diff(got.off.astype(np.int64)) <= 255).all()
+    assert n_ok >= 5 and n_bad > 100

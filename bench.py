@@ -146,6 +146,27 @@ def main():
     import tempfile
     workdir = os.environ.get("EMA_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "ema_bench_%d" % os.getuid())
     os.makedirs(workdir, exist_ok=True)
+    # A reference of G bases needs ~21 G bytes of files (flat suffix array: 16 G) and ~26 G bytes of host memory while the
+    # index is built.  A box that cannot hold the requested reference gets the chr20-scale one instead, and the JSON says so
+    # -- better a line on the smaller workload, labelled as such, than none.
+    fallback = ""
+    if rank == 0 and args.genome_mbp > 0 and not os.path.exists(os.path.join(workdir, "ref.fa.stamp")):
+        import shutil
+        need_disk, need_ram = 21e6 * args.genome_mbp, 26e6 * args.genome_mbp
+        free_disk = shutil.disk_usage(workdir).free
+        try:
+            free_ram = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+        except (ValueError, OSError):
+            free_ram = need_ram
+        if free_disk < need_disk or free_ram < need_ram:
+            fallback = (f"FALLBACK to the chr20-scale reference: {args.genome_mbp:g} Mbp needs {need_disk / 1e9:.0f} GB of disk in {workdir} "
+                        f"({free_disk / 1e9:.0f} GB free) and {need_ram / 1e9:.0f} GB of host memory ({free_ram / 1e9:.0f} GB free); ")
+            log(f"[rank {rank}] {fallback}")
+            args.genome_mbp = 0.0
+    if world > 1:      # rank 0 decides for everybody
+        box = [args.genome_mbp, fallback]
+        dist.broadcast_object_list(box, src=0)
+        args.genome_mbp, fallback = box
     prefix, pairs, gname = build_workload(args, rank, world, workdir)
 
     from ema_amd.engine import Engine, default_opts
@@ -292,7 +313,7 @@ def main():
             "vs_baseline": None, "dtype": "int32/u64 (integer DP, FM-index ranks)", "data": "synthetic",
             "config": {"workload": f"10x-style FR pairs R1=127 bp (150-16-7) R2=150 bp, 0.5% subs, 0.05% indels, 1% chimeric; "
                                    f"{args.pairs} pairs per GPU per step, one barcode bucket per GPU, resident in HBM; "
-                                   f"reference = {gname} with injected repeat families "
+                                   f"{fallback}reference = {gname} with injected repeat families "
                                    f"(default: GRCh38-scale, 3.1 Gbp, as BASELINE configs[1] names; index built on the host cores in "
                                    f"~2 min before the timed region; --genome-mbp 0 = chr20-scale)",
                        "pairs_per_step_per_gpu": args.pairs, "max_occ": 3000, "parallelism": f"buckets x{world}"},

@@ -154,10 +154,13 @@ def main():
         import shutil
         need_disk, need_ram = 21e6 * args.genome_mbp, 26e6 * args.genome_mbp
         free_disk = shutil.disk_usage(workdir).free
-        try:
-            free_ram = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
-        except (ValueError, OSError):
-            free_ram = need_ram
+        free_ram = need_ram
+        try:      # MemAvailable counts the page cache that can be dropped
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable:"):
+                    free_ram = int(line.split()[1]) * 1024
+        except OSError:
+            pass
         if free_disk < need_disk or free_ram < need_ram:
             fallback = (f"FALLBACK to the chr20-scale reference: {args.genome_mbp:g} Mbp needs {need_disk / 1e9:.0f} GB of disk in {workdir} "
                         f"({free_disk / 1e9:.0f} GB free) and {need_ram / 1e9:.0f} GB of host memory ({free_ram / 1e9:.0f} GB free); ")

@@ -157,6 +157,15 @@ inline bool next_field(const char *s, size_t len, size_t &at, size_t &b, size_t 
 	return true;
 }
 
+inline bool acgt_only(const char *s, size_t n)
+{
+	for (size_t i = 0; i < n; ++i) {
+		const char c = (char)(s[i] & ~0x20);      // upper case
+		if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false;
+	}
+	return true;
+}
+
 int encode_default(const char *bc, int bc_len, uint64_t *out)
 {
 	uint64_t v = 0;
@@ -257,6 +266,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 			if (ln > kMaxLine) bad = kLong;
 			else if (!six) bad = kFew;
 			else if (fl[0] != (size_t)bc_len) bad = kBcLen;
+			else if (!is_haplotag && !acgt_only(s, (size_t)bc_len)) bad = kBcBase;
 			else if (fl[1] == 0) bad = kIdEmpty;
 			else if (fl[1] > kMaxId) bad = kIdLong;
 			else if (fl[2] > (size_t)max_read_len || fl[4] > (size_t)max_read_len) bad = kReadLong;

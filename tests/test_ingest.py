@@ -197,3 +197,11 @@ def test_mutated_buckets_never_crash_the_reader():
         assert got.group_off[0] == 0 and got.group_off[-1] == n and (np.diff(got.group_off.astype(np.int64)) > 0).all()
         assert (np.diff(got.off.astype(np.int64)) <= 255).all()
     assert n_ok >= 5 and n_bad > 100
+
+
+def test_the_first_bad_line_is_the_one_reported():
+    good = b"ACGTACGTACGTACGA ok AC FF GT FF\n"
+    text = good + b"ACGTACGTACGTACGN id AC FF GT FF\n" + good + b"ACGTACGTACGTACGT id AC FF\n"
+    with pytest.raises(ingest.BucketError) as e:
+        ingest.parse_bucket(text)
+    assert "line 2" in str(e.value) and "ACGT" in str(e.value)

@@ -300,6 +300,12 @@ def main():
                     "isolated": {"achieved": round(isolated, 2), "frac": round(isolated / HBM_PEAK_GBS, 5), "kernel_ms": round(iso_ms, 3)},
                     "all_kernels_ms": {k: round(v, 3) for k, v in kernel_ms.items()},
                     "all_kernels_ms_isolated": {k: round(v, 3) for k, v in kernel_ms_isolated.items()}}
+        # which stage takes longest when a slice has the chip to itself (the roofline object above stays on K1, the stage that
+        # moves the bytes; the others are bound by instruction issue and dependent latencies)
+        stage_ms = {"K1 seeding": kernel_ms_isolated.get("seed_ms", 0.0), "K2 chaining + extension": kernel_ms_isolated.get("extend_ms", 0.0),
+                    "K3 mate rescue": kernel_ms_isolated.get("rescue_ms", 0.0), "K4 final alignment": kernel_ms_isolated.get("final_ms", 0.0)}
+        top = max(stage_ms, key=stage_ms.get)
+        roofline["largest_stage_isolated"] = {"stage": top, "ms": round(stage_ms[top], 3)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (contract)
             cores = len(os.sched_getaffinity(0))

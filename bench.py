@@ -166,10 +166,10 @@ def main():
                         f"({free_disk / 1e9:.0f} GB free) and {need_ram / 1e9:.0f} GB of host memory ({free_ram / 1e9:.0f} GB free); ")
             log(f"[rank {rank}] {fallback}")
             args.genome_mbp = 0.0
-    if world > 1:      # rank 0 decides for everybody
-        box = [args.genome_mbp, fallback]
-        dist.broadcast_object_list(box, src=0)
-        args.genome_mbp, fallback = box
+    if world > 1:      # rank 0 decides for everybody (a plain tensor collective, like the ones below)
+        g = torch.tensor([args.genome_mbp if rank == 0 else 1e18], dtype=torch.float64, device="cuda")
+        dist.all_reduce(g, op=dist.ReduceOp.MIN)
+        args.genome_mbp = float(g.item())
     prefix, pairs, gname = build_workload(args, rank, world, workdir)
 
     from ema_amd.engine import Engine, default_opts

@@ -19,6 +19,9 @@
  *   src/bwabridge.c:313-339  interpret_align      -> (fields kept raw in orc_reg_t)
  *   src/align.c:180-186      bwa_init             -> orc_idx_load(), orc_opt_init()
  *   src/align.c:986-1061     append_alignments    -> orc_align_pair() (candidate part), orc_append_alignments() (filters, mapq, scores)
+ * Two later parts restate code that IS in the reference tree: oracle/ingest.c (read_special_fastq and its helpers;
+ * the helpers are pinned to the reference's own src/util.c, compiled into oracle/_ref by `make ref`) and oracle/sam.c
+ * (print_sam_record; unpinned, samrecord.c cannot be compiled here).
  * Self-consistency is checked in tests/ against brute-force models (suffix
  * array search, exhaustive DP re-scoring); nothing here is checked against
  * real bwa output.

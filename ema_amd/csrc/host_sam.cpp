@@ -258,4 +258,25 @@ int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opt
 	return 0;
 }
 
+int ema_sam_header(const char *const *contig_names, const int32_t *contig_lens, int32_t n_contigs, const char *rg_line,
+                   const char *version, int argc, const char *const *argv, char **text, size_t *n_bytes)
+{
+	if (!text || !n_bytes) return EMA_EARG;
+	*text = nullptr; *n_bytes = 0;
+	if (n_contigs < 0 || (n_contigs && (!contig_names || !contig_lens)) || !version || argc < 1 || !argv) return EMA_EARG;
+	std::string s = "@HD\tVN:1.3\tSO:unsorted\n";
+	for (int32_t i = 0; i < n_contigs; ++i) {
+		s += "@SQ\tSN:"; s += contig_names[i]; s += "\tLN:"; s += std::to_string(contig_lens[i]); s += '\n';
+	}
+	if (rg_line) { s += rg_line; s += '\n'; }
+	s += "@PG\tID:ema\tPN:ema\tVN:"; s += version; s += "\tCL:"; s += argv[0];
+	for (int i = 1; i < argc; ++i) { s += ' '; s += argv[i]; }
+	s += '\n';
+	char *buf = (char *)malloc(s.size() + 1);
+	if (!buf) return EMA_EARG;
+	memcpy(buf, s.data(), s.size());
+	*text = buf; *n_bytes = s.size();
+	return 0;
+}
+
 }  // extern "C"

@@ -40,6 +40,8 @@ def _lib():
         L.ema_sam_format.argtypes = [C.POINTER(SamLine), C.c_size_t, C.POINTER(SamOpts), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.ema_sam_free.argtypes = [C.c_void_p]
         L.ema_sam_write.argtypes = [C.c_int, C.POINTER(SamLine), C.c_size_t, C.POINTER(SamOpts), C.POINTER(C.c_size_t)]
+        L.ema_sam_header.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_char_p, C.c_int,
+                                     C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L._sam_bound = True
     return L
 
@@ -70,3 +72,19 @@ def write_lines(fd: int, lines, n: int, opts: SamOpts) -> int:
     if rc != 0:
         raise RuntimeError(f"ema_sam_write failed (code {rc})")
     return size.value
+
+
+def header(contigs, rg_line, version: bytes, argv) -> bytes:
+    """write_sam_header's text: contigs = [(name, length)], rg_line = the whole @RG line or None, argv = the command line."""
+    L = _lib()
+    names = (C.c_char_p * max(1, len(contigs)))(*[n for n, _ in contigs])
+    lens = (C.c_int32 * max(1, len(contigs)))(*[l for _, l in contigs])
+    av = (C.c_char_p * len(argv))(*argv)
+    text, size = C.c_void_p(), C.c_size_t()
+    rc = L.ema_sam_header(names, lens, len(contigs), rg_line, version, len(argv), av, C.byref(text), C.byref(size))
+    if rc != 0:
+        raise RuntimeError(f"ema_sam_header failed (code {rc})")
+    try:
+        return C.string_at(text, size.value)
+    finally:
+        L.ema_sam_free(text)

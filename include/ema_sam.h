@@ -80,6 +80,12 @@ void ema_sam_free(char *text);
  * first); *n_bytes, if not NULL, receives the number of bytes written.  EMA_EIO if a write fails. */
 int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opts *o, size_t *n_bytes);
 
+/* The header write_sam_header() prints (reference src/align.c:192-211): @HD VN:1.3 SO:unsorted, one @SQ per contig,
+ * the read-group line as given (NULL: none), and @PG ID:ema PN:ema VN:<version> CL:<argv joined by spaces>.  Contig
+ * names and lengths are what ema_engine_contig_name / _contig_len return.  *text is freed with ema_sam_free(). */
+int ema_sam_header(const char *const *contig_names, const int32_t *contig_lens, int32_t n_contigs, const char *rg_line,
+                   const char *version, int argc, const char *const *argv, char **text, size_t *n_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,6 +260,8 @@ typedef struct {
 typedef struct { const orc_sam_rec_t *rec, *mate; } orc_sam_line_t;
 typedef struct { const char *rg_id, *bx_index; int32_t bc_len, is_haplotag, insert_min, insert_max; } orc_sam_opts_t;
 int orc_sam_format(const orc_sam_line_t *lines, size_t n, const orc_sam_opts_t *o, char **text, size_t *n_bytes);
+int orc_sam_header(const char *const *names, const int32_t *lens, int32_t n, const char *rg, const char *version, int pg_argc,
+                   const char *const *pg_argv, char **text, size_t *n_bytes);
 
 #ifdef __cplusplus
 }

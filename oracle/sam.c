@@ -151,3 +151,19 @@ int orc_sam_format(const orc_sam_line_t *lines, size_t n, const orc_sam_opts_t *
 	fclose(f);
 	return 0;
 }
+
+/* write_sam_header (reference src/align.c:192-211) into a malloc'd buffer */
+int orc_sam_header(const char *const *names, const int32_t *lens, int32_t n, const char *rg, const char *version, int pg_argc,
+                   const char *const *pg_argv, char **text, size_t *n_bytes)
+{
+	FILE *out_file = open_memstream(text, n_bytes);
+	if (!out_file) return -1;
+	fprintf(out_file, "@HD\tVN:1.3\tSO:unsorted\n");
+	for (int32_t i = 0; i < n; i++) fprintf(out_file, "@SQ\tSN:%s\tLN:%d\n", names[i], lens[i]);
+	if (rg != NULL) fprintf(out_file, "%s\n", rg);
+	fprintf(out_file, "@PG\tID:ema\tPN:ema\tVN:%s\tCL:%s", version, pg_argv[0]);
+	for (int i = 1; i < pg_argc; i++) fprintf(out_file, " %s", pg_argv[i]);
+	fprintf(out_file, "\n");
+	fclose(out_file);
+	return 0;
+}

@@ -31,7 +31,7 @@ def test_every_header_in_include_is_covered():
     L = engine.load_library()
     headers = sorted(h for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h"))
     assert headers == ["ema_engine.h", "ema_ingest.h", "ema_sam.h"]
-    for header, count in (("ema_ingest.h", 6), ("ema_sam.h", 4)):
+    for header, count in (("ema_ingest.h", 6), ("ema_sam.h", 5)):
         names = declared_symbols(header)
         assert len(names) == count, names
         for n in names:

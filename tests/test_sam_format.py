@@ -177,3 +177,25 @@ def test_bad_input_fails_loudly():
     empty = (sam.SamLine * 1)()
     with pytest.raises(RuntimeError, match="-1"):
         sam.format_lines(empty, 1, sam.default_opts())    # neither record nor mate
+
+
+def test_header_equals_the_oracle():
+    contigs = [(b"chr1", 248956422), (b"chrUn_KI270742v1", 186739), (b"c", 1)]
+    argv = [b"ema", b"align", b"-r", b"ref.fa", b"-s", b"bucket 1/ema-bin-000"]
+    L = O.lib()
+    L.orc_sam_header.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_char_p, C.c_int,
+                                 C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for ctgs, rg in ((contigs, b"@RG\tID:grp1\tSM:x"), (contigs[:1], None), ([], None)):
+        names = (C.c_char_p * max(1, len(ctgs)))(*[n for n, _ in ctgs])
+        lens = (C.c_int32 * max(1, len(ctgs)))(*[l for _, l in ctgs])
+        av = (C.c_char_p * len(argv))(*argv)
+        text, size = C.c_void_p(), C.c_size_t()
+        assert L.orc_sam_header(names, lens, len(ctgs), rg, b"0.6.2", len(argv), av, C.byref(text), C.byref(size)) == 0
+        want = C.string_at(text, size.value)
+        libc.free(text)
+        got = sam.header(ctgs, rg, b"0.6.2", argv)
+        assert got == want
+        assert got.startswith(b"@HD\tVN:1.3\tSO:unsorted\n") and got.endswith(b"CL:ema align -r ref.fa -s bucket 1/ema-bin-000\n")
+        assert got.count(b"@SQ") == len(ctgs) and (b"@RG" in got) == (rg is not None)

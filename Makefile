@@ -1,24 +1,54 @@
 # Top-level build: host index builder (g++), HIP engine (hipcc, gfx950), CPU oracle (gcc).
+#   make -j8            everything (objects under build/, libraries in-tree next to the package so that they travel to the GPU box)
+#   make test-libs      + the test-only engine build with 2^16-symbol rank superblocks (tests/test_gpu_large_index.py)
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 CSRC = ema_amd/csrc
 HOSTFLAGS = -O2 -g -fPIC -std=c++17 -Wall -Wextra -ffp-contract=off
+HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC)
+HOSTCLANG = -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -pthread
 
-all: ema_amd/libema_index.so ema_amd/libema_engine.so oracle
+BWAABI = $(if $(wildcard $(CSRC)/bwaabi.cpp),ema_amd/libema_bwaabi.so)
+all: ema_amd/libema_index.so ema_amd/libema_engine.so ema_amd/libema_engine_ss16.so $(BWAABI) oracle
 
 ema_amd/libema_index.so: $(CSRC)/index_build.cpp
 	$(CXX) $(HOSTFLAGS) -fopenmp -shared -o $@ $<
 
-ENGINE_SRCS = $(wildcard $(CSRC)/*.hip) $(CSRC)/host_index.cpp $(CSRC)/host_append.cpp $(CSRC)/host_ingest.cpp $(CSRC)/host_sam.cpp
-ENGINE_HDRS = $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/ema_engine.h include/ema_ingest.h include/ema_sam.h
-ema_amd/libema_engine.so: $(ENGINE_SRCS) $(ENGINE_HDRS)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude -I$(CSRC) -o $@ $(ENGINE_SRCS)
+HIP_SRCS = $(wildcard $(CSRC)/*.hip)
+HOST_SRCS = $(wildcard $(CSRC)/host_*.cpp)
+ENGINE_HDRS = $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
+ENGINE_OBJS = $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS)) $(patsubst $(CSRC)/%.cpp,build/%.o,$(HOST_SRCS))
+SS16_OBJS = $(patsubst $(CSRC)/%.hip,build/ss16/%.o,$(HIP_SRCS)) $(patsubst $(CSRC)/%.cpp,build/ss16/%.o,$(HOST_SRCS))
+
+build/%.o: $(CSRC)/%.hip $(ENGINE_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+build/%.o: $(CSRC)/%.cpp $(ENGINE_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HOSTCLANG) -c -o $@ $<
+ema_amd/libema_engine.so: $(ENGINE_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(ENGINE_OBJS)
+
+# Test-only build of the same sources with rank superblocks of 2^16 symbols instead of 2^31, so that a 120 Kbp reference
+# exercises the several-superblock branch of ema_lane_occ4 that only a human-size genome reaches otherwise.
+build/ss16/%.o: $(CSRC)/%.hip $(ENGINE_HDRS)
+	@mkdir -p build/ss16
+	$(HIPCC) $(HIPFLAGS) -DEMA_OCC_SUPER_SHIFT=16 -c -o $@ $<
+build/ss16/%.o: $(CSRC)/%.cpp $(ENGINE_HDRS)
+	@mkdir -p build/ss16
+	$(HIPCC) $(HOSTCLANG) -DEMA_OCC_SUPER_SHIFT=16 -c -o $@ $<
+ema_amd/libema_engine_ss16.so: $(SS16_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(SS16_OBJS)
+
+# libbwa-shaped face (include/ema_bwaabi.h): the 9 symbols the reference links from -lbwa, on top of the engine
+ema_amd/libema_bwaabi.so: $(CSRC)/bwaabi.cpp include/ema_bwaabi.h include/ema_engine.h ema_amd/libema_engine.so
+	$(CXX) $(HOSTFLAGS) -Iinclude -shared -o $@ $(CSRC)/bwaabi.cpp -Lema_amd -lema_engine -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f ema_amd/*.so; $(MAKE) -C oracle clean
+	rm -rf build; rm -f ema_amd/*.so; $(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,29 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- aligned read pairs/s of the `ema align` seed-and-extend hot path on MI355X.
 
-One "step" = one pass of the whole hot path (K1 seeding -> K2 chaining/extension -> K3 mate rescue -> K4 final
-alignment) over one batch of synthetic read pairs that is already resident in HBM, i.e. exactly the work the
-reference does per pair in append_alignments() (reference src/align.c:1005-1038: bwa_mem_mate_sw + one
-bwa_smith_waterman per candidate), for `pairs_per_step` pairs.  Index build, read generation, upload and result
-download are outside the timed region.
+One "step" = the whole hot path over one batch of 1 Mi synthetic read pairs: K1 seeding -> K2 chaining/extension -> K3
+mate rescue -> K4 final alignment on the GPU, results packed and fetched to the host, and the reference's
+append_alignments() stage (filters, MAPQ, likelihoods) on the host's cores -- i.e. everything the reference does per pair
+in append_alignments() (reference src/align.c:986-1061: bwa_mem_mate_sw + one bwa_smith_waterman per candidate + the record
+arithmetic), through the C ABI (include/ema_stream.h over include/ema_engine.h).  The K steps run over K DISTINCT batches
+(10 x 1 Mi pairs = the 10 M pairs of BASELINE configs[1]) that are staged in HBM before the timed region starts, pipelined
+over the engine's two sets of batch buffers as a caller streaming buckets would.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W      (N > 1 without torch.distributed.run: the ranks are spawned here)
 
-Multi-GPU: barcode buckets are independent, so every rank aligns its own bucket of the same size
-against its own replica of the index -- weak scaling, no collective on the data path; the per-bucket statistics
-(pairs, candidates, mapped mates) are gathered over RCCL at the end.
-
-Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
-  roofline     : HBM roofline of the dominant kernel (algorithmic bytes from the oracle's instrumentation of the
-                 same reads / that kernel's mean launch time from HIP events on the engine's stream)
-  cpu_baseline : the oracle (a CPU restatement, NOT upstream bwa: parity unpinned) timed on the host cores on a
-                 bounded sample of the same workload.
+Rank 0 prints ONE JSON line.  `value` = pairs x steps / wall of that timed region (inputs resident, outputs on the host).
+Beside it:
+  boundary        : the same K batches from HOST buffers (nt4 conversion, 2-bit packing and H2D inside the timed region):
+                    what a caller of the C ABI sees host to host (ema_stream_batches)
+  engine_resident : kernels only, K steps queued back to back on one set of buffers, nothing fetched (round 1's `value`)
+  roofline        : HBM roofline of K1, the kernel that moves the bytes (algorithmic bytes from the oracle's counters on
+                    the same reads / its mean launch-series duration over the timed region, HIP events on its stream)
+  roofline_k2b    : instruction-issue roofline of K2b, the largest kernel by time, from the committed PMC pass
+  cpu_baseline    : the oracle (a CPU restatement, NOT upstream bwa: parity unpinned) on one socket's physical cores.
+Multi-GPU: barcode buckets are independent: every rank runs its own K batches on its own replica of the index,
+no data-path collective; the per-bucket statistics are all-gathered (RCCL) at the end.
 """
 import argparse
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before anything initialises the GPU runtime: see ema_amd/csrc/engine.hip
+import ctypes as C
 import json
-import os
+import subprocess
 import sys
 import time
 
@@ -34,17 +39,31 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD-32 ("v_fma_f32 (wave64) 2 cyc"), 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 0.5 * 2.4
 CHR20_LEN = 64_444_167
+ENGINE_KNOBS = ("EMA_SEED_ROUNDS", "EMA_SEED_PARK", "EMA_SEED_BLOCKS_PER_CU", "EMA_FULL_SEED_LANE", "EMA_LANE_ALIGN", "EMA_FULL_OWN_STREAM",
+                "EMA_KMER_K")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(args, rank, world, workdir):
-    """Synthetic genome + index (built once, by rank 0) and this rank's bucket of read pairs."""
-    from ema_amd import synth, build_index
-    prefix = os.path.join(workdir, "ref.fa")
+def spawn_ranks(n):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as child processes (nothing has touched the GPU in
+    this process) and leave with their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)))
+    raise SystemExit(subprocess.call(cmd))
+
+
+def genome_spec(args):
     if args.genome_mbp > 0:
         n_ctg = max(1, int(np.ceil(args.genome_mbp / 155.0)))          # chromosome-sized contigs (contig lengths are 32-bit)
         lens = [int(args.genome_mbp * 1e6 / n_ctg)] * n_ctg
@@ -52,50 +71,79 @@ def build_workload(args, rank, world, workdir):
     else:
         lens = [CHR20_LEN]
         gname = "synthetic chr20-scale (64,444,167 bp, 1 contig)"
-    t = time.time()
-    stamp = json.dumps({"lens": lens, "seed": synth.GENOME_SEED, "builder": 2})
+    return lens, gname
+
+
+def build_reference(args, workdir):
+    """Rank 0 only: synthetic genome (genome.npy, reused if it is the same one) and its index.  Returns the stamp."""
+    from ema_amd import synth, build_index
+    lens, gname = genome_spec(args)
+    prefix = os.path.join(workdir, "ref.fa")
     gpath = os.path.join(workdir, "genome.npy")
-    try:      # the genome of an earlier run on this box, if it is the same one
+    stamp = json.dumps({"lens": lens, "seed": synth.GENOME_SEED, "builder": 2})
+    t = time.time()
+    try:
         have_genome = open(prefix + ".gstamp").read() == stamp and os.path.exists(gpath)
     except OSError:
         have_genome = False
+    have_index = have_genome and all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".fsa", ".pac", ".ann", ".amb", ".stamp")) \
+        and open(prefix + ".stamp").read() == stamp
+    if have_index:
+        log(f"[rank 0] genome {gname} and its index found in {workdir}: reused")
+        return stamp
     if have_genome:
         flat = np.load(gpath, mmap_mode="r")
         ctg, at = [], 0
         for n in lens:
             ctg.append(np.asarray(flat[at:at + n])); at += n
-        log(f"[rank {rank}] genome {gname}: loaded in {time.time() - t:.1f}s")
     else:
         ctg = synth.make_genome(lens, seed=synth.GENOME_SEED)
-        log(f"[rank {rank}] genome {gname}: {time.time() - t:.1f}s")
-    if rank == 0:
-        # the index of an earlier run on this box (same genome, same builder) is reused: the driver's N = 1, 2, 4, 8 runs
-        # come back to back on one node
-        if not have_genome:
-            if os.path.exists(prefix + ".gstamp"):
-                os.remove(prefix + ".gstamp")
-            np.save(gpath, np.concatenate(ctg))
-            with open(prefix + ".gstamp", "w") as f:
-                f.write(stamp)
-        have = all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".fsa", ".pac", ".ann", ".amb", ".stamp"))
-        if have and open(prefix + ".stamp").read() == stamp:
-            log("[rank 0] index of this genome found in " + workdir + ": reused")
-        else:
-            t = time.time()
-            if os.path.exists(prefix + ".stamp"):
-                os.remove(prefix + ".stamp")
-            synth.write_fasta(prefix, ctg, names=["chr20"] if len(ctg) == 1 else [f"chr{i + 1}" for i in range(len(ctg))])
-            build_index(prefix)
-            with open(prefix + ".stamp", "w") as f:
-                f.write(stamp)
-            log(f"[rank 0] index built in {time.time() - t:.1f}s")
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+        for e in (".gstamp", ".stamp"):
+            if os.path.exists(prefix + e):
+                os.remove(prefix + e)
+        for f in os.listdir(workdir):      # reads cached for another genome
+            if f.startswith("reads_"):
+                os.remove(os.path.join(workdir, f))
+        np.save(gpath, np.concatenate(ctg))
+        with open(prefix + ".gstamp", "w") as f:
+            f.write(stamp)
+    log(f"[rank 0] genome {gname}: {time.time() - t:.1f}s")
     t = time.time()
-    pairs = synth.make_pairs(ctg, args.pairs, seed=synth.READS_SEED + 7919 * rank, len1=127, len2=150)
-    log(f"[rank {rank}] {args.pairs} pairs simulated in {time.time() - t:.1f}s")
-    return prefix, pairs, gname
+    if os.path.exists(prefix + ".stamp"):
+        os.remove(prefix + ".stamp")
+    synth.write_fasta(prefix, ctg, names=["chr20"] if len(ctg) == 1 else [f"chr{i + 1}" for i in range(len(ctg))])
+    build_index(prefix)
+    with open(prefix + ".stamp", "w") as f:
+        f.write(stamp)
+    log(f"[rank 0] index built in {time.time() - t:.1f}s")
+    return stamp
+
+
+def make_batches(args, rank, world, workdir, n_batches):
+    """This rank's n_batches distinct batches of read pairs (generated by worker processes from the shared genome.npy;
+    cached in workdir so that the driver's back-to-back runs and the profiler passes reuse them)."""
+    from ema_amd import synth
+    lens, _ = genome_spec(args)
+    gpath = os.path.join(workdir, "genome.npy")
+    t = time.time()
+    todo, paths = [], []
+    for k in range(n_batches):
+        seed = synth.READS_SEED + 7919 * rank + 104729 * k
+        path = os.path.join(workdir, f"reads_g{args.genome_mbp:g}_n{args.pairs}_s{seed}.npz")
+        paths.append(path)
+        if not os.path.exists(path):
+            todo.append((gpath, lens, args.pairs, seed, 127, 150, path))
+    if todo:
+        import multiprocessing as mp
+        n_proc = max(1, min(len(todo), (os.cpu_count() or 8) // max(1, world)))
+        with mp.get_context("spawn").Pool(n_proc) as pool:      # spawn: this process may already hold the GPU
+            pool.map(synth.bench_batch, todo)
+    out = []
+    for path in paths:
+        z = np.load(path)
+        out.append(synth.Pairs(z["bases"], z["off"]))
+    log(f"[rank {rank}] {n_batches} batches x {args.pairs} pairs: {len(todo)} simulated, {n_batches - len(todo)} from {workdir}, {time.time() - t:.1f}s")
+    return out
 
 
 def algorithmic_bytes(stats, sa_width):
@@ -107,26 +155,102 @@ def algorithmic_bytes(stats, sa_width):
     return k1, rest
 
 
+def one_socket_cpus():
+    """One hardware thread per physical core of NUMA node 0 (the socket the baseline is pinned to), and the CPU model."""
+    def parse(s):
+        out = []
+        for part in s.strip().split(","):
+            if "-" in part:
+                a, b = part.split("-"); out.extend(range(int(a), int(b) + 1))
+            elif part:
+                out.append(int(part))
+        return out
+    allowed = os.sched_getaffinity(0)
+    try:
+        node0 = [c for c in parse(open("/sys/devices/system/node/node0/cpulist").read()) if c in allowed]
+    except OSError:
+        node0 = sorted(allowed)
+    cores, seen = [], set()
+    for c in node0:
+        try:
+            sib = tuple(parse(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()))
+        except OSError:
+            sib = (c,)
+        if sib not in seen:
+            seen.add(sib); cores.append(c)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return cores or sorted(allowed), model
+
+
+class pinned_to:
+    """Every thread of this process (OpenMP pool threads included) on the given CPUs for the duration; restored afterwards."""
+
+    def __init__(self, cpus):
+        self.cpus, self.saved = set(cpus), {}
+
+    def __enter__(self):
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                self.saved[int(tid)] = os.sched_getaffinity(int(tid))
+                os.sched_setaffinity(int(tid), self.cpus)
+            except OSError:
+                pass
+        return self
+
+    def __exit__(self, *a):
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), self.saved.get(int(tid), self.saved.get(os.getpid(), self.cpus)))
+            except OSError:
+                pass
+
+
+def pmc_table(name):
+    """profiles/<name>: kernel,counter,launches,mean_per_launch,min,max,sum_over_run (tools/pmc_summary.py --csv)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    t = {}
+    for r in csv.DictReader(open(path)):
+        t[(r["kernel"], r["counter"])] = (float(r["sum_over_run"]), float(r["launches"]))
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10, help="default: 10 steps x 1 Mi pairs = the 10 M pairs of BASELINE configs[1]")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1048576, help="pairs per step and per GPU (one resident batch)")
-    ap.add_argument("--sync-each-step", action="store_true", help="wait for every step before queueing the next (no overlap of step tails)")
+    ap.add_argument("--pairs", type=int, default=1048576, help="pairs per step and per GPU (one batch)")
+    ap.add_argument("--batches", type=int, default=0, help="distinct batches resident per GPU (default min(steps, 10); steps cycle through them)")
     ap.add_argument("--genome-mbp", type=float, default=3100.0,
                     help="size of the synthetic reference; default GRCh38-scale (3.1 Gbp in 20 contigs, BASELINE configs[1]); "
                          "0 = chr20-scale (64.4 Mbp, one contig: configs[0]'s reference)")
-    ap.add_argument("--cpu-sample", type=int, default=400000, help="pairs of the same workload timed on the host CPU")
+    ap.add_argument("--cpu-sample", type=int, default=1000000, help="pairs of the same workload timed on the host CPU (one socket)")
     ap.add_argument("--streams", type=int, default=0, help="slices of a batch on their own HIP streams (0 = engine default)")
     ap.add_argument("--lean-seed-extends", type=int, default=0, help="engine option lean_seed_extends (0 = engine default)")
+    ap.add_argument("--one-set", action="store_true", help="one set of batch buffers only (no overlap of fetch/append with the next batch's kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the boundary / engine_resident / isolated passes (profiling runs)")
     ap.add_argument("--allow-capacity-flags", action="store_true", help="print the (invalid) line even if reads overflowed an engine capacity")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
+        raise SystemExit(2)
+    dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -135,7 +259,14 @@ def main():
         import datetime
         # rank 0 builds genome and index (minutes at the default scale) while the others wait at a barrier
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    def agree(value, op="min"):
+        """rank 0's float for everybody (a plain tensor collective, like the ones below)"""
+        if world == 1:
+            return value
+        g = torch.tensor([value], dtype=torch.float64, device="cuda")
+        dist.all_reduce(g, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.MAX)
+        return float(g.item())
 
     import __graft_entry__
     if rank == 0:
@@ -150,29 +281,52 @@ def main():
     # index is built.  A box that cannot hold the requested reference gets the chr20-scale one instead, and the JSON says so
     # -- better a line on the smaller workload, labelled as such, than none.
     fallback = ""
-    if rank == 0 and args.genome_mbp > 0 and not os.path.exists(os.path.join(workdir, "ref.fa.stamp")):
-        import shutil
-        need_disk, need_ram = 21e6 * args.genome_mbp, 26e6 * args.genome_mbp
-        free_disk = shutil.disk_usage(workdir).free
-        free_ram = need_ram
-        try:      # MemAvailable counts the page cache that can be dropped
-            for line in open("/proc/meminfo"):
-                if line.startswith("MemAvailable:"):
-                    free_ram = int(line.split()[1]) * 1024
+    failed = 0.0
+    if rank == 0 and args.genome_mbp > 0:
+        from ema_amd import synth
+        lens, _ = genome_spec(args)
+        want = json.dumps({"lens": lens, "seed": synth.GENOME_SEED, "builder": 2})
+        try:
+            have = open(os.path.join(workdir, "ref.fa.stamp")).read() == want      # the index of THIS genome is already there
         except OSError:
-            pass
-        if free_disk < need_disk or free_ram < need_ram:
-            fallback = (f"FALLBACK to the chr20-scale reference: {args.genome_mbp:g} Mbp needs {need_disk / 1e9:.0f} GB of disk in {workdir} "
-                        f"({free_disk / 1e9:.0f} GB free) and {need_ram / 1e9:.0f} GB of host memory ({free_ram / 1e9:.0f} GB free); ")
-            log(f"[rank {rank}] {fallback}")
-            args.genome_mbp = 0.0
-    if world > 1:      # rank 0 decides for everybody (a plain tensor collective, like the ones below)
-        g = torch.tensor([args.genome_mbp if rank == 0 else 1e18], dtype=torch.float64, device="cuda")
-        dist.all_reduce(g, op=dist.ReduceOp.MIN)
-        args.genome_mbp = float(g.item())
-    prefix, pairs, gname = build_workload(args, rank, world, workdir)
+            have = False
+        if not have:
+            import shutil
+            need_disk, need_ram = 21e6 * args.genome_mbp, 26e6 * args.genome_mbp
+            free_disk = shutil.disk_usage(workdir).free
+            free_ram = need_ram
+            try:      # MemAvailable counts the page cache that can be dropped
+                for line in open("/proc/meminfo"):
+                    if line.startswith("MemAvailable:"):
+                        free_ram = int(line.split()[1]) * 1024
+            except OSError:
+                pass
+            if free_disk < need_disk or free_ram < need_ram:
+                fallback = (f"FALLBACK to the chr20-scale reference: {args.genome_mbp:g} Mbp needs {need_disk / 1e9:.0f} GB of disk in {workdir} "
+                            f"({free_disk / 1e9:.0f} GB free) and {need_ram / 1e9:.0f} GB of host memory ({free_ram / 1e9:.0f} GB free); ")
+                log(f"[rank {rank}] {fallback}")
+                args.genome_mbp = 0.0
+    args.genome_mbp = agree(args.genome_mbp if rank == 0 else 1e18)
+    if rank == 0:
+        try:
+            build_reference(args, workdir)
+        except BaseException as e:      # noqa: BLE001 -- the other ranks must not wait out the collective timeout
+            log(f"[rank 0] building the reference failed: {e!r}")
+            failed = 1.0
+    if agree(failed, "max") > 0:
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(3)
+    lens, gname = genome_spec(args)
+    prefix = os.path.join(workdir, "ref.fa")
+    n_batches = args.batches if args.batches > 0 else min(max(1, args.steps), 10)
+    if not args.one_set:
+        n_batches += n_batches & 1      # alternate batches on alternate sets of batch buffers: the same number on each
+    batches = make_batches(args, rank, world, workdir, n_batches)
 
-    from ema_amd.engine import Engine, default_opts
+    from ema_amd import stream
+    from ema_amd.engine import Engine, default_opts, BatchOut, AlnOut
+    from ema_amd.ingest import _Bucket
     o = default_opts()
     o.batch_pairs = args.pairs
     o.n_streams = args.streams
@@ -180,157 +334,233 @@ def main():
     t = time.time()
     eng = Engine(prefix, device=local, opts=o)
     log(f"[rank {rank}] engine open (index in HBM) {time.time() - t:.1f}s")
-    eng.stage(pairs.bases, pairs.off)          # nt4 conversion + H2D: outside the timed region
+    so = stream.default_opts()
+    so.n_engines = 1 if args.one_set else 2
+    peer = None if args.one_set else eng.peer()
+    n_sets = 2 if peer is not None else 1
+    if n_sets == 1 and not args.one_set:
+        log(f"[rank {rank}] no device memory for a second set of batch buffers: one set")
+        so.n_engines = 1
+    slots = (n_batches + n_sets - 1) // n_sets
+    t = time.time()
+    for k, p in enumerate(batches):          # nt4 conversion + packing + H2D of every batch: outside the timed region
+        (eng if k % n_sets == 0 else peer).stage_slot(k // n_sets, p.bases, p.off)
+    log(f"[rank {rank}] {n_batches} batches staged in HBM ({n_sets} set{'s' if n_sets > 1 else ''} of batch buffers) {time.time() - t:.1f}s")
 
     def sync_all():
         eng.sync()
+        if peer is not None:
+            peer.sync()
         if world > 1:
             torch.cuda.synchronize()
             dist.barrier()
 
-    for _ in range(args.warmup):
-        eng.run()
+    # parity spot check inside the run: candidates of sampled pairs of EVERY timed step -- regular ones and pairs that went
+    # through the full-capacity tier -- are kept by the sink and compared with the oracle afterwards; a mismatch is fatal
+    rng = np.random.default_rng(12345 + rank)
+    kept = {}
+
+    def keep_sample(k, pb, n_reg, n_full):
+        ob = pb.contents
+        n = int(ob.n_pairs)
+        ids = set(int(x) for x in rng.integers(0, n, n_reg))
+        nr = int(ob.n_redone)
+        if nr:
+            ids |= set(int(ob.redone[int(i)]) for i in rng.integers(0, nr, min(n_full, nr)))
+        for p in ids:
+            per = []
+            for m in range(2):
+                lo, hi = int(ob.cand_off[2 * p + m]), int(ob.cand_off[2 * p + m + 1])
+                rows = []
+                for i in range(lo, hi):
+                    c = ob.cand[i]
+                    rows.append((c.rb, c.re, c.qb, c.qe, c.score, c.pos, c.NM, [int(ob.cigar[c.cigar_off + j]) for j in range(c.n_cigar)]))
+                per.append(rows)
+            kept[(k % n_batches, p)] = per
+
+    tallies = {"flags": 0}
+
+    def make_sink(sample):
+        def cb(_user, k, _pbk, pb, _pa):
+            try:
+                if sample:
+                    keep_sample(int(k), pb, 24, 24)
+                return 0
+            except BaseException as e:      # noqa: BLE001
+                log(f"sink failed: {e!r}")
+                return -100
+        return stream.SINK(cb)
+
+    offs = [batches[k % n_batches].off for k in range(max(args.steps, args.warmup))]
+    if args.warmup:
+        stream.stream_resident(eng, offs[:args.warmup], slots, opts=so, raw_sink=make_sink(False))
     sync_all()
-    # Timed region: K steps queued back to back (as a host streaming buckets would), one wait at the end; every step is
-    # the complete K1..K4 pass, both capacity tiers included.
+    # ---- timed region: K steps = K batches (distinct up to n_batches), inputs resident, results + records on the host
+    sink = make_sink(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run()
-        if args.sync_each_step:
-            eng.sync()
+    st_timed = stream.stream_resident(eng, offs[:args.steps], slots, opts=so, raw_sink=sink)
     sync_all()
     elapsed = time.perf_counter() - t0
-    # per-launch kernel durations (HIP events on the launching streams): the last step of the timed region, where launches
-    # of different slices overlap, and one extra untimed pass with the slices one after another (isolated launches)
-    tm = eng.timing()
-    kernel_ms = {k: tm[k] for k in ("seed_ms", "extend_ms", "rescue_ms", "final_ms", "total_ms", "full_tier_ms")}
-    log(f"[rank {rank}] full-capacity tier K1..K4 ms: {tm['full_ms']}")
-    eng.run(serial=True)
-    eng.sync()
-    tm = eng.timing()
-    kernel_ms_isolated = {k: tm[k] for k in kernel_ms}
-    n_slices = eng.n_streams
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = agree(elapsed, "max")
+    for s in st_timed:
+        tallies["flags"] |= s["capacity_flags"]
+    any_flag = int(agree(float(tallies["flags"] != 0), "max"))
+    if any_flag:
+        log(f"[rank {rank}] ERROR: reads exceeded an engine capacity (status bits {tallies['flags']}): their pairs have no candidates, "
+            f"so the timed steps skipped work and the number is not valid")
+        if not args.allow_capacity_flags:
+            eng.close()
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(2)
+    # mean launch durations over the timed region (HIP events on the launching streams, read after every step's sync)
+    kernel_ms = {k: float(np.mean([s[k] for s in st_timed])) for k in ("seed_ms", "extend_ms", "rescue_ms", "final_ms", "full_tier_ms")}
 
-    # results of the last step: parity spot check against the oracle + bucket statistics
-    batch = eng.fetch(allow_limit=True)
-    if batch.status.max() != 0:
-        flags, counts = np.unique(batch.status[batch.status != 0], return_counts=True)
-        log(f"[rank {rank}] ERROR: reads exceeded an engine capacity (status flag: count) {dict(zip(flags.tolist(), counts.tolist()))}: "
-            f"their pairs have no candidates, so the timed steps skipped work and the number is not valid")
-    any_flag = int(batch.status.max() != 0) if len(batch.status) else 0
-    if world > 1:      # every rank must take the same exit
-        tf = torch.tensor([any_flag], dtype=torch.int32, device="cuda")
-        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-        any_flag = int(tf.item())
-    if any_flag and not args.allow_capacity_flags:
-        eng.close()
-        if world > 1:
-            dist.destroy_process_group()
-        raise SystemExit(2)
+    boundary = resident = None
+    kernel_ms_isolated = None
+    if not args.no_extras:
+        # ---- the same K batches from host buffers: stage (nt4 + packing + H2D) inside the timed region too
+        hb = [(batches[k % n_batches].bases, batches[k % n_batches].off) for k in range(args.steps)]
+        sync_all()
+        t1 = time.perf_counter()
+        st_b = stream.stream_batches(eng, hb, opts=so, raw_sink=make_sink(False))
+        sync_all()
+        el_b = agree(time.perf_counter() - t1, "max") if world > 1 else time.perf_counter() - t1
+        boundary = {"value": round(args.pairs * args.steps * world / el_b, 1), "unit": "pairs/s", "ms_per_step": round(el_b / args.steps * 1e3, 3),
+                    "what": "host buffers in (ASCII reads) -> candidates + append_alignments records in host memory, "
+                            "ema_stream_batches over the same batches: nt4 conversion, 2-bit packing, H2D, K1-K4, pack, D2H, append stage, "
+                            f"pipelined over {n_sets} set(s) of batch buffers",
+                    "host_s_per_step": {"align_call": round(float(np.mean([s["align_s"] for s in st_b])), 4),
+                                        "append": round(float(np.mean([s["append_s"] for s in st_b])), 4)}}
+        # ---- kernels only, queued back to back on one set (nothing fetched): round 1's figure, for continuity
+        for _ in range(args.warmup):
+            eng.run_slot(0)
+        sync_all()
+        t2 = time.perf_counter()
+        for k in range(args.steps):
+            eng.run_slot(k % slots)      # the batches staged on this set
+        sync_all()
+        el_r = agree(time.perf_counter() - t2, "max") if world > 1 else time.perf_counter() - t2
+        resident = {"value": round(args.pairs * args.steps * world / el_r, 1), "unit": "pairs/s", "ms_per_step": round(el_r / args.steps * 1e3, 3),
+                    "what": "K1-K4 only, steps queued back to back on one set of batch buffers, inputs resident, nothing fetched"}
+        eng.run(serial=True)      # one extra untimed pass with the slices one after another: launches in isolation
+        eng.sync()
+        tm = eng.timing()
+        kernel_ms_isolated = {k: tm[k] for k in kernel_ms}
+        log(f"[rank {rank}] full-capacity tier K1..K4 ms (isolated pass): {tm['full_ms']}")
+    n_slices = eng.n_streams
+
     from ema_amd import shard
-    stats_vec = shard.bucket_stats(batch, pairs.n)
-    # the "trivial RCCL gather of per-bucket statistics" of the north star: one bucket per rank, O(100 B) over xGMI
-    gathered = shard.gather_stats(stats_vec[None, :], world, device=("cuda" if world > 1 else None))
+    local_stats = np.array([[s[f] for f in shard.STAT_FIELDS] for s in st_timed], dtype=np.int64).sum(axis=0)[None, :]
+    # the "trivial RCCL gather of per-bucket statistics" of the north star: one record per rank, O(100 B) over xGMI
+    gathered = shard.gather_stats(local_stats, world, device=("cuda" if world > 1 else None))
 
+    bad = 0
     out = None
     if rank == 0:
         import oracle_lib as O
         idx, opt = O.Index(prefix), O.default_opt()
-        # spot check: the first pairs of the bucket must equal the oracle bit for bit
-        n_chk = min(200, pairs.n)
-        bad = 0
-        for p in range(n_chk):
-            ref = O.align_pair(idx, opt, pairs.read(2 * p), pairs.read(2 * p + 1))
+        t = time.time()
+        for (b, p), per in sorted(kept.items()):
+            pr = batches[b]
+            ref = O.align_pair(idx, opt, pr.read(2 * p), pr.read(2 * p + 1))
             for m in range(2):
-                got = [(int(c["rb"]), int(c["re"]), int(c["qb"]), int(c["qe"]), int(c["score"]), int(c["pos"]), int(c["NM"]),
-                        batch.cigar_of(c).tolist()) for c in batch.mate(p, m)]
                 exp = [(d["rb"], d["re"], d["qb"], d["qe"], d["score"], d["pos"], d["NM"], d["cigar"]) for d in ref[m]]
-                bad += got != exp
-        if bad:
-            log(f"WARNING: {bad} reads of the {n_chk}-pair spot check differ from the oracle")
+                if per[m] != exp:
+                    bad += 1
+                    if bad <= 3:
+                        log(f"MISMATCH batch {b} pair {p} mate {m + 1}: engine {per[m][:2]} oracle {exp[:2]}")
+        log(f"[rank 0] oracle spot check: {len(kept)} pairs of the timed steps ({bad} reads differ) {time.time() - t:.1f}s")
+    bad = int(agree(float(bad), "max"))
+    if bad:
+        log(f"ERROR: {bad} reads of the spot check differ from the oracle: no bench line")
+        eng.close()
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(2)
+
+    if rank == 0:
         # algorithmic bytes: the oracle's counters on a sample of the SAME reads, scaled to the batch
-        n_s = min(args.cpu_sample, pairs.n)
-        sample = pairs.subset(0, n_s)
+        n_1 = min(8000, batches[0].n)
+        s1 = batches[0].subset(0, n_1)
         O.stats_reset()
-        t_1, _ = O.bench_pairs(idx, opt, sample.bases[:sample.off[2 * min(n_s, 4000)]], sample.off[:2 * min(n_s, 4000) + 1], 1)
+        t_1, _ = O.bench_pairs(idx, opt, s1.bases, s1.off, 1)
         st = O.stats_get()
-        scale = pairs.n / float(min(n_s, 4000))
-        k1_bytes, rest_bytes = algorithmic_bytes(st, 4)
-        k1_bytes *= scale / n_slices           # one launch covers one slice of the batch
+        scale = args.pairs / float(n_1)
+        sa_width = eng.index_info()["sa_width"]
+        k1_bytes, rest_bytes = algorithmic_bytes(st, sa_width)
+        k1_bytes *= scale / n_slices           # one launch series covers one slice of the batch
         rest_bytes *= scale / n_slices
-        # The HBM roofline is meaningful for K1 only: it is the kernel whose work is FM-index gathers (K2..K4 move ~100x
-        # fewer algorithmic bytes and are bound by instruction issue; see DESIGN.md and profiles/), so it is the kernel
-        # reported here whichever launch is longer.
-        dom_bytes = k1_bytes
-        dom_ms, iso_ms = kernel_ms["seed_ms"], kernel_ms_isolated["seed_ms"]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        isolated = dom_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
-        # HBM traffic of the same kernel: not measurable from inside this process -- taken from the committed PMC passes of this
-        # very command (profiles/, separate FETCH_SIZE and WRITE_SIZE runs; KB per launch, three launches per series), and
-        # only when this run is that default workload.
-        traffic = None
-        pmc_name = {0.0: "r01f_pmc_chr20_1Mpairs.csv", 3100.0: "r01g_pmc_grch38scale_1Mpairs.csv"}.get(float(args.genome_mbp), "none")
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
-        if args.pairs == 1048576 and n_slices == 3 and args.lean_seed_extends == 0 and os.path.exists(pmc):
-            import csv
-            kb = {r["counter"]: float(r["sum_over_run"]) / (float(r["launches"]) / 3.0) for r in csv.DictReader(open(pmc))
-                  if r["kernel"] == "ema_k_seed" and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE")}
-            if len(kb) == 2:
-                traffic = int((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024)
-        roofline = {"bound": "hbm", "kernel": "ema_k_seed",
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(dom_bytes), "kernel_ms": round(dom_ms, 3),
-                    "note": f"one launch = one of {n_slices} slices of the batch; in the timed region launches of different slices "
-                            f"and kernels run concurrently and share the chip, so the per-launch rate understates the kernel: "
-                            f"'isolated' is the same launch with the chip to itself.  "
-                            + ("On this reference the rank structure (64 MB) is cache-resident and the kernel is bound by "
-                               "instruction issue, not by HBM (profiles/: FETCH_SIZE per launch ~ algorithmic bytes; ~60% of SIMD "
-                               "cycles issue VALU work).  " if args.genome_mbp == 0 else
-                               "On this reference the rank structure (3.1 GB) and the suffix array (50 GB) are far beyond the 256 MB "
-                               "Infinity Cache: every rank query is a dependent 32-byte gather from HBM, so the kernel is bound by "
-                               "gather latency x the waves in flight, not by bandwidth.  By time the largest kernel here is K2 "
-                               "(extend_ms: chaining + banded extension, instruction-bound, ~0.2 GB of algorithmic bytes); the "
-                               "roofline object stays on K1, the kernel that moves the bytes.  ")
-                            + f"K2..K4 algorithmic bytes per launch: {int(rest_bytes)}",
-                    "isolated": {"achieved": round(isolated, 2), "frac": round(isolated / HBM_PEAK_GBS, 5), "kernel_ms": round(iso_ms, 3)},
-                    "all_kernels_ms": {k: round(v, 3) for k, v in kernel_ms.items()},
-                    "all_kernels_ms_isolated": {k: round(v, 3) for k, v in kernel_ms_isolated.items()}}
-        # which stage takes longest when a slice has the chip to itself (the roofline object above stays on K1, the stage that
-        # moves the bytes; the others are bound by instruction issue and dependent latencies)
-        stage_ms = {"K1 seeding": kernel_ms_isolated.get("seed_ms", 0.0), "K2 chaining + extension": kernel_ms_isolated.get("extend_ms", 0.0),
-                    "K3 mate rescue": kernel_ms_isolated.get("rescue_ms", 0.0), "K4 final alignment": kernel_ms_isolated.get("final_ms", 0.0)}
-        top = max(stage_ms, key=stage_ms.get)
-        roofline["largest_stage_isolated"] = {"stage": top, "ms": round(stage_ms[top], 3)}
+        dom_ms = kernel_ms["seed_ms"]
+        achieved = k1_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        knobs = [k for k in ENGINE_KNOBS if k in os.environ]
+        default_run = (args.pairs == 1048576 and n_slices == 3 and args.lean_seed_extends == 0 and not knobs)
+        traffic, traffic_source = None, None
+        pmc_name = {0.0: "r02_pmc_chr20.csv", 3100.0: "r02_pmc_grch38scale.csv"}.get(float(args.genome_mbp))
+        tab = pmc_table(pmc_name) if (pmc_name and default_run) else None
+        if tab and ("ema_k_seed", "FETCH_SIZE") in tab and ("ema_k_seed", "WRITE_SIZE") in tab:
+            series = eng.seed_launches_per_series()
+            kb = sum(tab[("ema_k_seed", c)][0] / (tab[("ema_k_seed", c)][1] / series) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+            traffic = int(kb * 1024)
+            traffic_source = f"profiles/{pmc_name} (separate FETCH_SIZE and WRITE_SIZE passes of this command; stored, not measured in this run)"
+        roofline = {"bound": "hbm", "kernel": "ema_k_seed", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "algorithmic_bytes_per_launch": int(k1_bytes), "kernel_ms": round(dom_ms, 3),
+                    "note": f"one launch (series) = one of {n_slices} slices of a batch; mean over the {args.steps} timed steps, in which "
+                            f"launches of different slices, kernels and batches run concurrently and share the chip -- 'isolated' is the "
+                            f"same launch with the chip to itself.  K2..K4 algorithmic bytes per launch: {int(rest_bytes)}",
+                    "all_kernels_ms": {k: round(v, 3) for k, v in kernel_ms.items()}}
+        if kernel_ms_isolated:
+            iso_ms = kernel_ms_isolated["seed_ms"]
+            isolated = k1_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
+            roofline["isolated"] = {"achieved": round(isolated, 2), "frac": round(isolated / HBM_PEAK_GBS, 5), "kernel_ms": round(iso_ms, 3)}
+            roofline["all_kernels_ms_isolated"] = {k: round(v, 3) for k, v in kernel_ms_isolated.items()}
+        # K2b: bound by instruction issue, not by HBM -- wave-level VALU instructions per second against the chip's issue peak
+        roofline_k2b = None
+        if tab and ("ema_k_align", "SQ_INSTS_VALU") in tab and kernel_ms_isolated:
+            insts, launches = tab[("ema_k_align", "SQ_INSTS_VALU")]
+            per_launch = insts / launches
+            ms = kernel_ms_isolated["extend_ms"]
+            ach = per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roofline_k2b = {"bound": "valu-issue", "kernel": "ema_k_align (+ ema_k_align_simple in kernel_ms)", "achieved": round(ach, 2),
+                            "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 5),
+                            "insts_per_launch": int(per_launch), "kernel_ms": round(ms, 3),
+                            "source": f"profiles/{pmc_name}: SQ_INSTS_VALU per launch (stored PMC pass) / this run's isolated K2 time; peak = "
+                                      f"256 CUs x 4 SIMDs x 1 wave64 VALU instruction per 2 cycles x 2.4 GHz"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (contract)
-            cores = len(os.sched_getaffinity(0))
-            secs, _ = O.bench_pairs(idx, opt, sample.bases, sample.off, cores)
-            cpu = {"value": round(n_s / secs, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
-                   "sample": f"first {n_s} pairs of the same bucket, oracle/ (CPU restatement, not upstream bwa), "
-                             f"{cores} OpenMP threads, {secs:.1f}s; 1 thread: {min(n_s, 4000) / t_1:.1f} pairs/s"}
-        total_pairs = int(gathered[:, 0].sum()) * args.steps
+            cores, model = one_socket_cpus()
+            n_s = min(args.cpu_sample, batches[0].n)
+            sample = batches[0].subset(0, n_s)
+            with pinned_to(cores):
+                secs, _ = O.bench_pairs(idx, opt, sample.bases, sample.off, len(cores))
+            rate_1 = n_1 / t_1
+            cpu = {"value": round(n_s / secs, 1), "unit": "pairs/s", "cores": len(cores), "kind": "port",
+                   "one_thread_pairs_per_s": round(rate_1, 1), "parallel_efficiency": round((n_s / secs) / (len(cores) * rate_1), 3),
+                   "cpu": model,
+                   "sample": f"first {n_s} pairs of batch 0, oracle/ (CPU restatement, not upstream bwa), {len(cores)} OpenMP threads pinned to "
+                             f"one hardware thread per physical core of NUMA node 0, {secs:.1f}s; 1 thread on {n_1} pairs: {rate_1:.1f} pairs/s"}
+        total_pairs = int(gathered[:, 0].sum())
         value = total_pairs / elapsed
         out = {
             "metric": "aligned read-pairs/sec (2x150 bp) on the seed-and-extend hot path", "value": round(value, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32/u64 (integer DP, FM-index ranks)", "data": "synthetic",
-            "config": {"workload": f"10x-style FR pairs R1=127 bp (150-16-7) R2=150 bp, 0.5% subs, 0.05% indels, 1% chimeric; "
-                                   f"{args.pairs} pairs per GPU per step, one barcode bucket per GPU, resident in HBM; "
-                                   f"{fallback}reference = {gname} with injected repeat families "
-                                   f"(default: GRCh38-scale, 3.1 Gbp, as BASELINE configs[1] names; index built on the host cores in "
-                                   f"~2 min before the timed region; --genome-mbp 0 = chr20-scale)",
-                       "pairs_per_step_per_gpu": args.pairs, "max_occ": 3000, "parallelism": f"buckets x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "bucket_stats": {"pairs": int(gathered[:, 0].sum()), "candidates": int(gathered[:, 1].sum()),
-                             "reads_with_candidates": int(gathered[:, 2].sum()), "capacity_flags": int(gathered[:, 3].max()),
-                             "oracle_spot_check_mismatches": int(bad), "full_tier_pairs_rank0": int(batch.n_redone)},
+            "config": {"workload": f"BASELINE configs[1]: 10x-style FR pairs, 2x150 bp sequenced = R1 127 bp after the 16 bp barcode + 7 bp trim "
+                                   f"(reference cpp/correct.cc:550) and R2 150 bp, 0.5% subs, 0.05% indels, 1% chimeric; {args.steps} steps over "
+                                   f"{n_batches} distinct batches of {args.pairs} pairs per GPU (one barcode bucket per GPU), inputs staged in HBM "
+                                   f"before the timed region, candidates + append_alignments records delivered to host memory inside it; "
+                                   f"{fallback}reference = {gname} with injected repeat families (default: GRCh38-scale, 3.1 Gbp; index built on "
+                                   f"the host cores before the timed region; --genome-mbp 0 = chr20-scale)",
+                       "pairs_per_step_per_gpu": args.pairs, "distinct_batches": n_batches, "buffer_sets": n_sets, "max_occ": 3000,
+                       "parallelism": f"buckets x{world}", "engine_knobs_in_env": knobs},
+            "boundary": boundary, "engine_resident": resident,
+            "roofline": roofline, "roofline_k2b": roofline_k2b, "cpu_baseline": cpu,
+            "bucket_stats": {f: int(gathered[:, i].sum()) for i, f in enumerate(shard.STAT_FIELDS)},
         }
+        out["bucket_stats"].update(capacity_flags=int(any_flag), oracle_spot_check_pairs=len(kept), oracle_spot_check_mismatches=int(bad))
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -189,8 +189,19 @@ struct ema_engine {
 	DevBuf<uint8_t> d_sa, d_pac;
 	DevBuf<int64_t> d_ctg;
 	// batch input (whole batch; slices are sub-ranges, the full tier addresses it through its pair list)
-	DevBuf<uint8_t> d_bases;
-	DevBuf<uint32_t> d_off, d_qpack;     // d_qpack: 24 words per read (2-bit codes + N mask) for K1
+	// Batch inputs live in numbered slots, each a whole batch in HBM (nt4 bases, offsets, 2-bit packs: ~0.7 GB per Mi
+	// pairs): ema_engine_stage fills slot 0, ema_engine_stage_slot any of them, and a run reads the slot it names --
+	// several distinct batches stay resident and are run back to back without touching PCIe (bench.py's timed region).
+	struct InputSet {
+		DevBuf<uint8_t> d_bases;
+		DevBuf<uint32_t> d_off, d_qpack;     // d_qpack: 24 words per read (2-bit codes + N mask) for K1
+		size_t n_pairs = 0;
+		bool staged = false;
+	};
+	std::vector<InputSet> in;            // EMA_MAX_SLOTS entries; buffers allocated on first use
+	int cur_slot = 0;                    // slot of the run being queued / last run
+	const uint8_t *cur_bases = nullptr;
+	const uint32_t *cur_off = nullptr, *cur_qpack = nullptr;
 	std::vector<Slice> sl;               // lean tier
 	Slice full;                          // full-capacity tier
 	// pairs flagged by the lean tier: [0] = count, [1..] = batch pair ids.  d_redo is appended to by ema_k_collect;
@@ -207,6 +218,7 @@ struct ema_engine {
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
+	DevBuf<int> d_rlog;                  // EMA_PHASE_PROFILE=2: per-read records of K2b
 	int dbg_slots = 0;
 	double watchdog_s = 0;               // EMA_WATCHDOG_S=<seconds>: poll after every launch, report stuck waves
 	ema_engine_timing timing;
@@ -225,6 +237,7 @@ struct ema_engine {
 extern "C" {
 
 void ema_engine_opts_default(ema_engine_opts *o) { ema_fill_default_opts(o); }
+int ema_engine_get_opts(const ema_engine_t *e, ema_engine_opts *o) { if (!e || !o) return EMA_EARG; *o = e->opts; return EMA_OK; }
 
 static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 {
@@ -300,6 +313,17 @@ static bool stream_file_to_device(ema_engine *e, const std::string &path, uint64
 
 static int engine_open(const char *index_prefix, const ema_engine *share, int device, const ema_engine_opts *opts, ema_engine_t **out);
 
+static int select_slot(ema_engine *e, int slot);
+static int input_alloc(ema_engine *e, int slot)
+{
+	ema_engine::InputSet &in = e->in[slot];
+	if (in.d_bases.p) return EMA_OK;
+	HIPCHK(e, in.d_bases.alloc(2 * e->cap_pairs * (size_t)(EMA_MAX_READ + 1)));
+	HIPCHK(e, in.d_off.alloc(2 * e->cap_pairs + 1));
+	HIPCHK(e, in.d_qpack.alloc(2 * e->cap_pairs * 24 + 8));
+	return EMA_OK;
+}
+
 int ema_engine_open(const char *index_prefix, int device, const ema_engine_opts *opts, ema_engine_t **out)
 {
 	if (!index_prefix || !out) return EMA_EARG;
@@ -359,7 +383,17 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
 	}
 
-	if (getenv("EMA_PHASE_PROFILE")) { HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256)); }
+	if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
+		HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256));
+		if (atoi(pp) >= 2) {      // per-read log of K2b (k_align.hip): [0] entries, [1] capacity, records from word 16
+			const int cap = 1 << 22;
+			HIPCHK(e, e->d_rlog.alloc(16 + (size_t)cap * 8));
+			HIPCHK(e, hipMemset(e->d_rlog.p, 0, 64));
+			HIPCHK(e, hipMemcpy(e->d_rlog.p + 1, &cap, 4, hipMemcpyHostToDevice));
+			const unsigned long long addr = (unsigned long long)(uintptr_t)e->d_rlog.p;
+			HIPCHK(e, hipMemcpy(e->d_prof.p + 31, &addr, 8, hipMemcpyHostToDevice));
+		}
+	}
 	if (const char *wd = getenv("EMA_WATCHDOG_S")) { e->watchdog_s = atof(wd); e->dbg_slots = e->n_cu * 8 * 4 + 64; }
 	if (const char *v = getenv("EMA_SEED_ROUNDS")) e->seed_rounds = std::max(1, std::min(8, atoi(v)));
 	if (const char *v = getenv("EMA_SEED_PARK")) e->seed_park_max = std::max(0, std::min(63, atoi(v)));
@@ -384,9 +418,11 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	const size_t per = (want + n_streams - 1) / n_streams;
 	e->cap_pairs = per * n_streams;
 	if (e->cap_pairs * 2 * (size_t)(EMA_MAX_READ + 1) >= ((size_t)1 << 32)) { e->err = "batch_pairs too large for 32-bit base offsets"; return EMA_EARG; }
-	HIPCHK(e, e->d_bases.alloc(2 * e->cap_pairs * (size_t)(EMA_MAX_READ + 1)));
-	HIPCHK(e, e->d_off.alloc(2 * e->cap_pairs + 1));
-	HIPCHK(e, e->d_qpack.alloc(2 * e->cap_pairs * 24 + 8));
+	e->in.resize(EMA_MAX_SLOTS);
+	{
+		int rc = input_alloc(e, 0);
+		if (rc != EMA_OK) return rc;
+	}
 	e->sl.resize(n_streams);
 	for (auto &s : e->sl) {
 		s.cap_pairs = per;
@@ -427,11 +463,32 @@ void ema_engine_close(ema_engine_t *e)
 	(void)hipDeviceSynchronize();
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
-	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_prof.release();
-	e->d_bases.release(); e->d_off.release(); e->d_qpack.release(); e->d_redo.release(); e->d_redo_run.release();
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_prof.release(); e->d_rlog.release();
+	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
+	e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();
 	for (auto &s : e->sl) s.release();
 	delete e;
+}
+
+// The second set of batch buffers and streams on this engine's index (what ema_engine_align_pairs alternates with on big
+// inputs), created on first need and owned by `e`; null if it cannot be allocated.  ema_stream_* runs alternate buckets on it.
+ema_engine_t *ema_engine_peer(ema_engine_t *e)
+{
+	if (!e) return nullptr;
+	if (!e->shadow) {
+		ema_engine_t *sh = nullptr;
+		if (engine_open(nullptr, e, e->device, &e->opts, &sh) == EMA_OK) e->shadow = sh;
+		else if (sh) ema_engine_close(sh);
+		// the result buffers of a fetch are sized and allocated per batch: leave them room
+		size_t free_b = 0, total_b = 0;
+		if (e->shadow && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ((size_t)8 << 30))) {
+			ema_engine_close(e->shadow);
+			e->shadow = nullptr;
+		}
+		if (getenv("EMA_VERBOSE")) fprintf(stderr, "ema_engine_peer: %s, %.1f GB of device memory free\n", e->shadow ? "second set of batch buffers created" : "no room for a second set", free_b / 1e9);
+	}
+	return e->shadow;
 }
 
 const char *ema_engine_strerror(const ema_engine_t *e) { return e ? e->err.c_str() : "null engine"; }
@@ -449,14 +506,28 @@ int64_t ema_engine_contig_offset(const ema_engine_t *e, int rid)
 	return (e && rid >= 0 && rid < (int)e->contigs.size()) ? e->contigs[rid].offset : -1;
 }
 int64_t ema_engine_l_pac(const ema_engine_t *e) { return e ? e->l_pac : -1; }
+int ema_engine_index_info(const ema_engine_t *e, int32_t info[4])
+{
+	if (!e || !info) return EMA_EARG;
+	info[0] = e->dix.n_super; info[1] = EMA_OCC_SUPER_SHIFT; info[2] = e->dix.sa_width; info[3] = 0;
+	return EMA_OK;
+}
 size_t ema_engine_batch_capacity(const ema_engine_t *e) { return e ? e->cap_pairs : 0; }
 size_t ema_engine_full_tier_capacity(const ema_engine_t *e) { return e ? e->full.cap_pairs : 0; }
 
-int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs)
+int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs) { return ema_engine_stage_slot(e, 0, bases, off, n_pairs); }
+
+int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs)
 {
 	if (!e || !bases || !off) return EMA_EARG;
+	if (slot < 0 || slot >= EMA_MAX_SLOTS) { e->err = "input slot out of range (EMA_MAX_SLOTS)"; return EMA_EARG; }
 	if (n_pairs > e->cap_pairs) { e->err = "batch larger than ema_engine_batch_capacity()"; return EMA_EARG; }
 	HIPCHK(e, hipSetDevice(e->device));
+	{
+		int rc = input_alloc(e, slot);
+		if (rc != EMA_OK) return rc;
+	}
+	ema_engine::InputSet &in = e->in[slot];
 	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));      // a run still in flight reads the input
 	HIPCHK(e, hipStreamSynchronize(e->full.stream));
 	const size_t n_reads = 2 * n_pairs;
@@ -487,11 +558,19 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 	}
 	});
 	hipStream_t st = e->sl[0].stream;
-	HIPCHK(e, hipMemcpyAsync(e->d_qpack.p, e->h_qpack.p, (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, st));
-	HIPCHK(e, hipMemcpyAsync(e->d_bases.p, e->h_nt4.p, total, hipMemcpyHostToDevice, st));
-	HIPCHK(e, hipMemcpyAsync(e->d_off.p, e->h_off.p, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
-	// consecutive pairs go to consecutive slices, as evenly as the slice count allows
-	const size_t n_sl = e->sl.size();
+	HIPCHK(e, hipMemcpyAsync(in.d_qpack.p, e->h_qpack.p, (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemcpyAsync(in.d_bases.p, e->h_nt4.p, total, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemcpyAsync(in.d_off.p, e->h_off.p, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipStreamSynchronize(st));
+	in.n_pairs = n_pairs; in.staged = true;
+	return select_slot(e, slot);
+}
+
+// makes `slot` the input of the next run: consecutive pairs go to consecutive slices, as evenly as the slice count allows
+static int select_slot(ema_engine *e, int slot)
+{
+	const ema_engine::InputSet &in = e->in[slot];
+	const size_t n_pairs = in.n_pairs, n_sl = e->sl.size();
 	size_t first = 0;
 	for (size_t k = 0; k < n_sl; ++k) {
 		Slice &s = e->sl[k];
@@ -501,7 +580,8 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 		first += s.n_pairs;
 	}
 	if (first != n_pairs) { e->err = "internal: slices do not cover the batch"; return EMA_ESTATE; }
-	HIPCHK(e, hipStreamSynchronize(st));
+	e->cur_slot = slot;
+	e->cur_bases = in.d_bases.p; e->cur_off = in.d_off.p; e->cur_qpack = in.d_qpack.p;
 	e->n_pairs = n_pairs;
 	e->staged = true; e->ran = false;
 	return EMA_OK;
@@ -535,8 +615,8 @@ struct Work {
 static Work work_of(ema_engine *e, const Slice &s, bool listed)
 {
 	Work w;
-	if (listed) { w.n_pairs = (int)s.cap_pairs; w.n_dev = e->d_redo_run.p; w.map = e->d_redo_run.p + 1; w.off = e->d_off.p; w.qpack = e->d_qpack.p; }
-	else { w.n_pairs = (int)s.n_pairs; w.n_dev = w.map = nullptr; w.off = e->d_off.p + 2 * s.first_pair; w.qpack = e->d_qpack.p + 2 * s.first_pair * 24; }
+	if (listed) { w.n_pairs = (int)s.cap_pairs; w.n_dev = e->d_redo_run.p; w.map = e->d_redo_run.p + 1; w.off = e->cur_off; w.qpack = e->cur_qpack; }
+	else { w.n_pairs = (int)s.n_pairs; w.n_dev = w.map = nullptr; w.off = e->cur_off + 2 * s.first_pair; w.qpack = e->cur_qpack + 2 * s.first_pair * 24; }
 	return w;
 }
 
@@ -576,7 +656,7 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 		                        e->lane_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
-	ema_launch_align(&e->dix, &s.dopts, e->d_bases.p, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+	ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 0,
 	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p);
 	HIPCHK(e, hipGetLastError());
@@ -586,7 +666,7 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 
 static int run_pair(ema_engine *e, Slice &s, const Work &w)
 {
-	ema_launch_pair(&e->dix, &s.dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high, e->d_bases.p,
+	ema_launch_pair(&e->dix, &s.dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high, e->cur_bases,
 	                w.off, w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr,
 	                s.d_counters.p + 23, s.d_slabs.p, s.d_counters.p + 1, e->pair_blocks, s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
@@ -596,7 +676,7 @@ static int run_pair(ema_engine *e, Slice &s, const Work &w)
 
 static int run_final(ema_engine *e, Slice &s, const Work &w)
 {
-	ema_launch_final(&e->dix, &s.dopts, e->d_bases.p, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_alns.p,
+	ema_launch_final(&e->dix, &s.dopts, e->cur_bases, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_alns.p,
 	                 s.d_cigars.p, s.d_cig_n.p, s.dopts.cig_cap, s.d_status.p, s.d_kdone.p, s.d_todo.p, s.d_counters.p + 20, s.d_slabs.p,
 	                 s.d_counters.p + 2, e->final_blocks, s.stream, s.dbg);
 	HIPCHK(e, hipGetLastError());
@@ -624,6 +704,15 @@ static int run_chain(ema_engine *e, Slice &s, const Work &w)
 // then overlap the head of the next.
 static int run_batch(ema_engine_t *e, bool serial);
 int ema_engine_run(ema_engine_t *e) { return run_batch(e, false); }
+// one pass over the batch staged in `slot` (stage_slot): as ema_engine_run, on that input
+int ema_engine_run_slot(ema_engine_t *e, int slot)
+{
+	if (!e) return EMA_EARG;
+	if (slot < 0 || slot >= EMA_MAX_SLOTS || !e->in[slot].staged) { e->err = "ema_engine_run_slot: nothing staged in this slot"; return EMA_ESTATE; }
+	int rc = select_slot(e, slot);
+	if (rc) return rc;
+	return run_batch(e, false);
+}
 // the same pass with the slices one after another (nothing overlaps): per-kernel launch durations in isolation
 int ema_engine_run_serial(ema_engine_t *e) { return run_batch(e, true); }
 
@@ -674,6 +763,7 @@ int ema_engine_sync(ema_engine_t *e)
 }
 
 int ema_engine_n_streams(const ema_engine_t *e) { return e ? (int)e->sl.size() : 0; }
+int ema_engine_seed_launches(const ema_engine_t *e) { return e ? e->seed_rounds : 0; }
 
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 {
@@ -688,10 +778,29 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 			for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", h[i]);
 			fprintf(stderr, "\nK1: wave-ticks %llu, active lane-ticks %llu (%.1f lanes/tick), clocks per wave-tick %.0f, longest wave %llu ticks\n", h[8], h[9],
 			        h[8] ? (double)h[9] / h[8] : 0., h[8] ? (double)h[10] / h[8] : 0., h[11]);
-			(void)hipMemset(e->d_prof.p, 0, 256);
+			(void)hipMemset(e->d_prof.p, 0, 248);
 		}
 	}
 	*t = e->timing;
+	return EMA_OK;
+}
+
+// EMA_PHASE_PROFILE=2: the per-read records K2b has logged so far (8 ints each, see k_align.hip); resets the log.  Caller frees.
+int ema_engine_debug_readlog(ema_engine_t *e, int32_t **log, size_t *n)
+{
+	if (!e || !log || !n) return EMA_EARG;
+	*log = nullptr; *n = 0;
+	if (!e->d_rlog.p) { e->err = "no read log (EMA_PHASE_PROFILE=2 when the engine was opened)"; return EMA_ESTATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipDeviceSynchronize());
+	int head[2];
+	HIPCHK(e, hipMemcpy(head, e->d_rlog.p, 8, hipMemcpyDeviceToHost));
+	const size_t k = (size_t)std::min(head[0], head[1]);
+	*log = (int32_t *)malloc(k * 32 + 32);
+	if (!*log) return EMA_EDEVICE;
+	HIPCHK(e, hipMemcpy(*log, e->d_rlog.p + 16, k * 32, hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemset(e->d_rlog.p, 0, 4));
+	*n = k;
 	return EMA_OK;
 }
 
@@ -868,6 +977,8 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
 	o->n_pairs = e->n_pairs;
 	o->n_redone = n_redo;
+	o->redone = (uint32_t *)malloc((n_redo + 1) * 4);
+	if (o->redone) for (size_t i = 0; i < n_redo; ++i) o->redone[i] = (uint32_t)redo[i];
 	o->cand_off = (uint64_t *)malloc((n_reads + 1) * 8);
 	std::vector<uint64_t> cig_off(n_reads + 1);
 	o->cand_off[0] = 0; cig_off[0] = 0;
@@ -993,6 +1104,14 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
 	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
 	o->status = (int32_t *)malloc((2 * n_pairs + 1) * 4);
+	o->redone = (uint32_t *)malloc((n_redone + 1) * 4);
+	{
+		size_t at = 0, p0 = 0;
+		for (auto *q : parts) {
+			for (size_t i = 0; i < q->n_redone; ++i) o->redone[at++] = (uint32_t)(p0 + q->redone[i]);
+			p0 += q->n_pairs;
+		}
+	}
 	// each piece lands at its own offsets: one host thread per piece (the copies also first-touch the new pages)
 	std::vector<size_t> r_at(n_parts + 1, 0), c_at(n_parts + 1, 0), g_at(n_parts + 1, 0);
 	for (size_t k = 0; k < n_parts; ++k) {
@@ -1026,7 +1145,7 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 void ema_batch_free(ema_batch_out *out)
 {
 	if (!out) return;
-	free(out->cand_off); free(out->cand); free(out->cigar); free(out->status);
+	free(out->cand_off); free(out->cand); free(out->cigar); free(out->status); free(out->redone);
 	free(out);
 }
 

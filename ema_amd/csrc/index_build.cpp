@@ -433,7 +433,10 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 	}
 	lap("text");
 	std::vector<uint8_t>().swap(fwd);
-	if (T.n < 0xffffff00ULL) {
+	// EMA_INDEX_SA64=1 (tests): 8-byte suffix-array rows whatever the size, so that a small reference drives the row width
+	// that only references beyond 2^32 symbols get otherwise
+	const char *force64 = getenv("EMA_INDEX_SA64");
+	if (T.n < 0xffffff00ULL && !(force64 && atoi(force64) != 0)) {
 		Raw<uint32_t> sa(T.n + 1);
 		if (!sa.p) return -3;
 		build_sa(T, sa.p);

@@ -209,6 +209,10 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
 	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
 	int phase = 0;
+	// EMA_PHASE_PROFILE=2: one record per read {read, intervals (-1: chains handed over by K2a), seed occurrences, chains, seeds,
+	// regions before dedup, extension DPs run, shader clocks / 16} appended to the log whose address sits in prof[31]
+	int *rlog = prof ? reinterpret_cast<int *>(prof[31]) : nullptr;
+	int n_dp = 0;
 #define EMA_PHASE(idx) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc[phase] += t_now - t_prev; t_prev = t_now; phase = (idx); } } while (0)
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][256];
@@ -238,6 +242,9 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			read = (int)(t & ~EMA_HAND_FLAG);
 		}
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		const unsigned long long t_read = rlog ? __builtin_amdgcn_s_memtime() : 0;
+		int log_iv = -1, log_occ = 0;
+		n_dp = 0;
 		EMA_DBG(1, 0);
 		EMA_PHASE(1);
 		if (ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
@@ -302,6 +309,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			l_rep += e - b;
 			cb.sl = slab;
 			if (ema_uni(tot_occ <= EMA_SMALL_SEEDS)) ema_small_tables(cb.sl, lds_small[wib]);
+			log_iv = n_iv; log_occ = (int)(tot_occ < (1 << 30) ? tot_occ : (1 << 30));
 		}
 		frac_rep = (float)l_rep / (float)l_query;
 		for (int i = 0; i < n_iv; ++i) {
@@ -497,6 +505,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 					for (int i = 0; i < 2; ++i) {        // MAX_BAND_TRY
 						const int prev = a.score;
 						aw0 = opt.w << i;
+						++n_dp;
 						r = ema_wave_extend(opt, s.qbeg, EmaSeq{query + s.qbeg - 1, -1}, tlen, EmaSeq{rseq + tlen - 1, -1}, aw0,
 						                    opt.pen_clip5, opt.zdrop, s.len * opt.a);
 						a.score = r.score;
@@ -514,6 +523,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 					for (int i = 0; i < 2; ++i) {
 						const int prev = a.score;
 						aw1 = opt.w << i;
+						++n_dp;
 						r = ema_wave_extend(opt, l_query - qe, EmaSeq{query + qe, 1}, (int)(rmax1 - rmax0 - re), EmaSeq{rseq + re, 1},
 						                    aw1, opt.pen_clip3, opt.zdrop, sc0);
 						a.score = r.score;
@@ -555,6 +565,14 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
 		EMA_DBG(9, n_out);
 		EMA_PHASE(0);
+		if (rlog && lane == 0) {
+			const int at = atomicAdd(rlog, 1);
+			if (at < rlog[1]) {
+				int *r = rlog + 16 + (size_t)at * 8;
+				r[0] = read; r[1] = log_iv; r[2] = log_occ; r[3] = cb.n_chain; r[4] = cb.n_seed; r[5] = n_av; r[6] = n_dp;
+				r[7] = (int)((__builtin_amdgcn_s_memtime() - t_read) >> 4);
+			}
+		}
 	}
 	if (prof && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(prof + i, acc[i]);
 #undef EMA_DBG

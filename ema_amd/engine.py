@@ -11,13 +11,15 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libema_engine.so")
+# EMA_ENGINE_LIB: another in-tree build of the same sources (tests: libema_engine_ss16.so, small rank superblocks)
+LIB_PATH = os.path.join(_HERE, os.environ.get("EMA_ENGINE_LIB", "libema_engine.so"))
 
 SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free", "ema_engine_open_shared",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free", "ema_engine_open_shared", "ema_engine_index_info", "ema_engine_stage_slot", "ema_engine_run_slot", "ema_engine_peer",
+    "ema_engine_seed_launches", "ema_engine_get_opts",
 ]
 
 
@@ -53,7 +55,8 @@ REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
 
 class BatchOut(C.Structure):
     _fields_ = [("n_pairs", C.c_size_t), ("cand_off", C.POINTER(C.c_uint64)), ("cand", C.POINTER(Cand)),
-                ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_size_t), ("n_redone", C.c_size_t), ("status", C.POINTER(C.c_int32))]
+                ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_size_t), ("n_redone", C.c_size_t), ("status", C.POINTER(C.c_int32)),
+                ("redone", C.POINTER(C.c_uint32))]
 
 
 class AlnRec(C.Structure):
@@ -135,9 +138,10 @@ def default_opts() -> Opts:
 class Batch:
     """Result of one batch, copied out of the engine's buffers."""
 
-    def __init__(self, cand_off, cand, cigar, status, n_redone=0):
+    def __init__(self, cand_off, cand, cigar, status, n_redone=0, redone=None):
         self.cand_off, self.cand, self.cigar, self.status = cand_off, cand, cigar, status
         self.n_redone = n_redone      # pairs that went through the full-capacity tier
+        self.redone = redone if redone is not None else np.zeros(0, np.uint32)
 
     def mate(self, pair, m):
         lo, hi = int(self.cand_off[2 * pair + m]), int(self.cand_off[2 * pair + m + 1])
@@ -160,7 +164,7 @@ def append_alignments(batch: "Batch", off: np.ndarray, opts: "Opts | None" = Non
     cigar = np.ascontiguousarray(batch.cigar, dtype=np.uint32)
     status = np.ascontiguousarray(batch.status, dtype=np.int32)
     b = BatchOut((len(cand_off) - 1) // 2, cand_off.ctypes.data_as(C.POINTER(C.c_uint64)), cand.ctypes.data_as(C.POINTER(Cand)),
-                 cigar.ctypes.data_as(C.POINTER(C.c_uint32)), len(cigar), batch.n_redone, status.ctypes.data_as(C.POINTER(C.c_int32)))
+                 cigar.ctypes.data_as(C.POINTER(C.c_uint32)), len(cigar), batch.n_redone, status.ctypes.data_as(C.POINTER(C.c_int32)), None)
     p = C.POINTER(AlnOut)()
     rc = L.ema_batch_append_alignments(C.byref(b), off.ctypes.data, C.byref(o), error_rate, C.byref(p))
     if rc != 0:
@@ -199,10 +203,12 @@ class Engine:
                 self._h = C.c_void_p()
             raise RuntimeError(f"ema_engine_open failed ({rc}): {msg}")
 
+    _borrowed = False      # a peer handle belongs to its engine
+
     def close(self):
-        if self._h:
+        if self._h and not self._borrowed:
             self._L.ema_engine_close(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -236,6 +242,33 @@ class Engine:
         off = np.ascontiguousarray(off, dtype=np.uint32)
         self._check(self._L.ema_engine_stage(self._h, bases.ctypes.data, off.ctypes.data, (len(off) - 1) // 2), "stage")
         self._n_reads_staged = len(off) - 1
+
+    def stage_slot(self, slot: int, bases: np.ndarray, off: np.ndarray):
+        """ema_engine_stage_slot: a batch into input slot `slot` (several batches resident at once)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        self._L.ema_engine_stage_slot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        self._check(self._L.ema_engine_stage_slot(self._h, slot, bases.ctypes.data, off.ctypes.data, (len(off) - 1) // 2), "stage_slot")
+        self._n_reads_staged = len(off) - 1
+
+    def run_slot(self, slot: int):
+        self._L.ema_engine_run_slot.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._L.ema_engine_run_slot(self._h, slot), "run_slot")
+
+    def peer(self) -> "Engine | None":
+        """The engine's own second set of batch buffers (ema_engine_peer), owned by this engine; None if it cannot be created."""
+        self._L.ema_engine_peer.restype = C.c_void_p
+        self._L.ema_engine_peer.argtypes = [C.c_void_p]
+        h = self._L.ema_engine_peer(self._h)
+        if not h:
+            return None
+        p = Engine.__new__(Engine)
+        p._L, p._h, p._borrowed = self._L, C.c_void_p(h), True
+        return p
+
+    def seed_launches_per_series(self) -> int:
+        self._L.ema_engine_seed_launches.argtypes = [C.c_void_p]
+        return int(self._L.ema_engine_seed_launches(self._h))
 
     def run(self, serial: bool = False):
         """Queue one pass over the staged batch (asynchronous).  serial=True: slices one after another, for isolated kernel times."""
@@ -272,9 +305,10 @@ class Engine:
             cigar = np.ctypeslib.as_array(o.cigar, shape=(max(o.n_cigar, 1),)).copy()[:o.n_cigar]
             status = np.ctypeslib.as_array(o.status, shape=(2 * n,)).copy() if n else np.zeros(0, np.int32)
             n_redone = int(o.n_redone)
+            redone = np.ctypeslib.as_array(o.redone, shape=(max(n_redone, 1),)).copy()[:n_redone]
         finally:
             self._L.ema_batch_free(p)
-        return Batch(cand_off, cand, cigar, status, n_redone)
+        return Batch(cand_off, cand, cigar, status, n_redone, redone)
 
     def align_pairs_any(self, bases: np.ndarray, off: np.ndarray) -> Batch:
         """ema_engine_align_pairs itself (one C call; any number of pairs, worked through in capacity-sized pieces)."""
@@ -294,6 +328,13 @@ class Engine:
         self.run()
         self.sync()
         return self.fetch()
+
+    def index_info(self):
+        """Layout of the index in HBM (ema_engine_index_info)."""
+        a = (C.c_int32 * 4)()
+        self._L.ema_engine_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self._check(self._L.ema_engine_index_info(self._h, a), "index_info")
+        return {"n_super": a[0], "super_shift": a[1], "sa_width": a[2], "kmer_k": a[3]}
 
     def debug_seeds(self):
         """Seed intervals of the staged batch: (intv[n_reads, cap, 4] u64 = k, k', size, start<<32|end; n_intv)."""

@@ -9,7 +9,8 @@ from __future__ import annotations
 
 import numpy as np
 
-STAT_FIELDS = ("pairs", "candidates", "reads_with_candidates", "capacity_flags")
+# per-bucket record = the counters of include/ema_stream.h's ema_bucket_stats (SURVEY 8e's BucketStats), in this order
+STAT_FIELDS = ("pairs", "candidates", "reads_with_candidates", "records", "unique_records", "redone_pairs", "barcode_groups")
 
 
 def buckets_of_rank(n_buckets: int, world: int, rank: int):
@@ -17,15 +18,13 @@ def buckets_of_rank(n_buckets: int, world: int, rank: int):
     return list(range(rank, n_buckets, world))
 
 
-def bucket_stats(batch, n_pairs: int) -> np.ndarray:
-    """Statistics vector of one aligned bucket (ema_amd.engine.Batch)."""
-    per_read = np.diff(batch.cand_off.astype(np.int64))
-    return np.array([n_pairs, int(batch.cand_off[-1]), int((per_read > 0).sum()),
-                     int(batch.status.max()) if len(batch.status) else 0], dtype=np.int64)
+def bucket_stats(st: dict) -> np.ndarray:
+    """Statistics vector of one streamed bucket (ema_amd.stream's per-bucket dict)."""
+    return np.array([st[f] for f in STAT_FIELDS], dtype=np.int64)
 
 
 def gather_stats(local: np.ndarray, n_buckets: int, device=None):
-    """All-gathers the [n_local_buckets, 4] statistics of every rank into one [n_buckets, 4] table indexed by
+    """All-gathers the [n_local_buckets, F] statistics of every rank into one [n_buckets, F] table indexed by
     bucket id.  Must be called by every rank of the default process group (or alone, without a group)."""
     import torch
     import torch.distributed as dist

@@ -117,12 +117,12 @@ class Pairs:
 
 
 def make_pairs(contigs, n_pairs, seed=READS_SEED, len1=127, len2=150, sub_rate=0.005, indel_rate=0.0005,
-               chimeric=0.01, n_rate=0.0, pairs_per_barcode=200):
+               chimeric=0.01, n_rate=0.0, pairs_per_barcode=200, flat=None):
     """Vectorised 10x-style simulator.  R1 is `len1` bases (150 - 16 barcode - 7 trim, reference
     cpp/correct.cc:550), R2 `len2`; FR orientation, outer insert ~ N(350, 60) clamped to [max(len)+20, 700]."""
     rng = np.random.default_rng(seed)
     lens = np.array([len(c) for c in contigs], dtype=np.int64)
-    g = np.concatenate(contigs)
+    g = flat if flat is not None else np.concatenate(contigs)      # flat: the contigs back to back (e.g. a memory map)
     offs = np.concatenate([[0], np.cumsum(lens)])
     L = max(len1, len2)
     # molecules: each barcode owns ~10 molecules of ~50 kb; reads are drawn from them
@@ -213,3 +213,19 @@ def write_special_fastq(path, pairs: Pairs, qual="F"):
             r1, r2 = pairs.read(2 * i), pairs.read(2 * i + 1)
             f.write(b" ".join([pairs.barcodes[i].tobytes(), b"@s%d" % i, r1, qual.encode() * len(r1),
                                r2, qual.encode() * len(r2)]) + b"\n")
+
+
+def bench_batch(job):
+    """Worker of bench.py's read simulation: (genome.npy, contig lengths, pairs, seed, len1, len2, out.npz) -> one batch on disk.
+    The genome is memory-mapped, so a pool of these shares one copy in the page cache."""
+    gpath, lens, n_pairs, seed, len1, len2, out = job
+    flat = np.load(gpath, mmap_mode="r")
+    ctg, at = [], 0
+    for n in lens:
+        ctg.append(flat[at:at + n]); at += n
+    p = make_pairs(ctg, n_pairs, seed=seed, len1=len1, len2=len2, flat=flat)
+    tmp = out + ".tmp.npz"
+    np.savez(tmp, bases=p.bases, off=p.off)
+    import os
+    os.replace(tmp, out)
+    return out

@@ -57,6 +57,8 @@ typedef struct {
 } ema_engine_opts;
 
 void ema_engine_opts_default(ema_engine_opts *o);
+/* the options an engine was opened with (the append stage takes the same record) */
+int ema_engine_get_opts(const ema_engine_t *e, ema_engine_opts *o);
 
 /* replaces load_reference()/bwa_init() (reference src/bwabridge.c:77-96, src/align.c:180-186):
  * reads <index_prefix>.{bwt,fsa,pac,ann} and uploads the index to HBM of `device`. */
@@ -67,6 +69,10 @@ void ema_engine_close(ema_engine_t *e);
  * batch i).  `first` must be closed last. */
 int ema_engine_open_shared(const ema_engine_t *first, const ema_engine_opts *opts, ema_engine_t **out);
 const char *ema_engine_strerror(const ema_engine_t *e);
+/* The engine's own second set of batch buffers and streams (same index, same options), created on first call and closed
+ * with the engine; NULL when device memory does not allow it.  ema_engine_align_pairs uses it for inputs beyond the batch
+ * capacity, ema_stream_buckets (include/ema_stream.h) for alternate buckets. */
+ema_engine_t *ema_engine_peer(ema_engine_t *e);
 
 /* contig table (bns->anns[i].name/len/offset; reference src/align.c:199-200, src/bwabridge.c:86-91) */
 int ema_engine_n_contigs(const ema_engine_t *e);
@@ -74,6 +80,9 @@ const char *ema_engine_contig_name(const ema_engine_t *e, int rid);
 int64_t ema_engine_contig_len(const ema_engine_t *e, int rid);
 int64_t ema_engine_contig_offset(const ema_engine_t *e, int rid);
 int64_t ema_engine_l_pac(const ema_engine_t *e);
+/* layout of the index in HBM: info[0] = rank superblocks, info[1] = log2 symbols per superblock, info[2] = bytes per
+ * suffix-array row (4, or 8 beyond 2^32 rows), info[3] = k of the k-mer interval table (0 = none) */
+int ema_engine_index_info(const ema_engine_t *e, int32_t info[4]);
 
 /* One candidate = one element of the reference's results.a (mem_alnreg_t, read through
  * interpret_align, src/bwabridge.c:313-339, and mem_approx_mapq_se_insist, src/align.c:959-984)
@@ -102,6 +111,7 @@ typedef struct {
 	size_t n_redone;        /* pairs that went through the full-capacity tier */
 	int32_t *status;        /* per read (2*n_pairs): 0, or capacity bits (1 intervals, 2 lists, 4 seeds, 8 chains, 16 regions,
 	                         * 32 reference window, 64 CIGAR ops, 128 not redone: full-capacity tier was full, 256 seeding budget); a flagged read has no candidates */
+	uint32_t *redone;       /* n_redone pair indices: the pairs whose results come from the full-capacity tier */
 } ema_batch_out;
 
 /* Whole hot path for a batch: reads are ASCII, read r at bases[off[r] .. off[r+1]);
@@ -121,6 +131,13 @@ void ema_batch_free(ema_batch_out *out);
 size_t ema_engine_batch_capacity(const ema_engine_t *e);
 size_t ema_engine_full_tier_capacity(const ema_engine_t *e);
 int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs);
+/* Several batches resident at once: stage_slot puts a batch into input slot 0 <= slot < EMA_MAX_SLOTS (its device buffers
+ * are allocated on first use, ~0.7 GB per Mi pairs of capacity; ema_engine_stage is slot 0), run_slot queues one pass over
+ * that slot's batch.  Runs on different slots may be queued back to back like runs on one; sync/fetch/timing refer to
+ * the last run queued. */
+#define EMA_MAX_SLOTS 16
+int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs);
+int ema_engine_run_slot(ema_engine_t *e, int slot);
 int ema_engine_run(ema_engine_t *e);
 int ema_engine_run_serial(ema_engine_t *e);   /* ema_engine_run with the slices one after another: kernel times in isolation */
 int ema_engine_sync(ema_engine_t *e);
@@ -147,6 +164,11 @@ int ema_engine_debug_regions(ema_engine_t *e, void **regs, int32_t **n_regs, int
 int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
                         const uint32_t *toff, const int32_t *prm, int n_tasks, int32_t *out, uint32_t *cigar,
                         int cigar_cap);
+
+/* Profiling aid: with EMA_PHASE_PROFILE=2 in the environment when the engine is opened, K2b logs one record per read
+ * {read, intervals or -1, seed occurrences, chains, seeds, regions before dedup, extension DPs, shader clocks / 16};
+ * this returns and resets the log (n records of 8 ints; caller frees). */
+int ema_engine_debug_readlog(ema_engine_t *e, int32_t **log, size_t *n);
 
 /* Region de-duplication in isolation (bwa's mem_sort_dedup_patch as mem_matesw calls it, i.e. without patching),
  * one task per wavefront: task t owns regs[t*cap .. t*cap + n_in[t]) (records laid out as in ema_engine_debug_regions);
@@ -186,6 +208,7 @@ typedef struct {
 } ema_engine_timing;
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t);
 int ema_engine_n_streams(const ema_engine_t *e);
+int ema_engine_seed_launches(const ema_engine_t *e);   /* launches of the seeding kernel per slice and run (its re-packing series) */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,73 @@
+/* include/ema_stream.h -- C ABI of the bucket loop around the hot path: many barcode buckets through reader -> engine ->
+ * append stage on one GPU, pipelined, results handed over in input order.
+ *
+ * Replaces the reference's outer loops: `ema align -s bucket` handles one bucket per process (reference src/main.c:380-394),
+ * `-x` walks a list of them one after another (src/main.c:396-406); inside, find_clouds_and_align() reads the whole bucket
+ * (read_special_fastq, src/align.c:258) and calls append_alignments() for every pair (src/align.c:307-349).  Here the same
+ * three steps -- ema_bucket_read (include/ema_ingest.h), ema_engine_align_pairs, ema_batch_append_alignments
+ * (include/ema_engine.h) -- run as a pipeline over the list: a reader thread parses bucket k+1.. ahead, two sets of batch
+ * buffers on the one index (the engine and its ema_engine_peer) take alternate buckets so that staging and fetching of one
+ * overlap the kernels of the other, and the caller's sink sees bucket 0, 1, 2, ... in order, each with its candidates
+ * (ema_batch_out) and its append_alignments records (ema_aln_out).  BASELINE configs[2] (500 buckets streamed on one GPU)
+ * is this call; with G GPUs each process calls it on its own buckets (b mod G, no data-path collective).
+ * Host code only; links into libema_engine.so.
+ */
+#ifndef EMA_STREAM_H
+#define EMA_STREAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "ema_engine.h"
+#include "ema_ingest.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	int bc_len, is_haplotag, max_read_len;   /* bucket reader: the platform's barcode (reference src/techs.c:74-119), longest read */
+	double error_rate;                       /* append stage: the platform's error rate (reference src/techs.c; 0.001 for 10x) */
+	int n_engines;                           /* 1 = the engine alone; 2 (default when 0) = alternate buckets on ema_engine_peer() as well */
+	int read_ahead;                          /* buckets parsed ahead of the engine (0 = default 2) */
+} ema_stream_opts;
+void ema_stream_opts_default(ema_stream_opts *o);   /* 16, 0, 255, 0.001, 0, 0 */
+
+/* per-bucket statistics (the record the ranks gather at the end of a multi-GPU run) */
+typedef struct {
+	uint64_t pairs, candidates, reads_with_candidates, records, unique_records, redone_pairs, barcode_groups;
+	uint64_t mapq_hist[7];                   /* append-stage MAPQ of the records: [0], 1-9, 10-19, 20-29, 30-39, 40-59, >= 60 */
+	int32_t capacity_flags, rc;              /* OR of the reads' status bits; the bucket's return code */
+	double read_s, align_s, append_s;        /* wall seconds inside the three steps (they overlap across buckets) */
+	float seed_ms, extend_ms, rescue_ms, final_ms, full_tier_ms;   /* this bucket's kernel launches (ema_engine_timing; 0 for a bucket beyond one batch) */
+	float pad_;
+} ema_bucket_stats;
+
+/* Called once per bucket, in input order, on the calling thread.  `bk` is the parsed bucket (NULL for ema_stream_batches),
+ * `b` its candidates, `a` its append_alignments records; all three are freed when the sink returns.  A non-zero return
+ * stops the stream and becomes its return code. */
+typedef int (*ema_stream_sink)(void *user, size_t index, const ema_bucket *bk, const ema_batch_out *b, const ema_aln_out *a);
+
+/* paths[0..n): bucket files in `ema preproc`'s special-FASTQ form.  stats: n entries or NULL.  Returns 0, the first failing
+ * bucket's code (EMA_EIO / EMA_EFORMAT / EMA_E*; ema_stream_last_error() has the text), or the sink's code.  EMA_ELIMIT
+ * buckets (a read over an engine capacity) are still delivered, flags in stats[k].capacity_flags, and the call ends with EMA_ELIMIT. */
+int ema_stream_buckets(ema_engine_t *e, const char *const *paths, size_t n, const ema_stream_opts *o, ema_stream_sink sink,
+                       void *user, ema_bucket_stats *stats);
+
+/* The same pipeline on batches already in host memory (no reader): batch k = bases[k], off[k] (2*n_pairs[k]+1 entries), as
+ * ema_engine_align_pairs takes them. */
+int ema_stream_batches(ema_engine_t *e, const char *const *bases, const uint32_t *const *off, const size_t *n_pairs, size_t n,
+                       const ema_stream_opts *o, ema_stream_sink sink, void *user, ema_bucket_stats *stats);
+
+/* The same pipeline on batches that are already in HBM (ema_engine_stage_slot): with s sets of batch buffers in use (2, or
+ * 1 when o->n_engines == 1 or no peer could be created), batch k must have been staged into slot (k / s) % slots_per_set of
+ * set k % s (set 0 = e, set 1 = ema_engine_peer(e)); off[k] are its read offsets (the append stage needs the read lengths).
+ * Nothing crosses PCIe towards the device: this is the rate with inputs resident, outputs delivered to the host. */
+int ema_stream_resident(ema_engine_t *e, const uint32_t *const *off, const size_t *n_pairs, size_t n, int slots_per_set,
+                        const ema_stream_opts *o, ema_stream_sink sink, void *user, ema_bucket_stats *stats);
+
+const char *ema_stream_last_error(void);   /* of the last failed call on this thread */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

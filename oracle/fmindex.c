@@ -217,8 +217,18 @@ uint64_t orc_occ(const orc_idx_t *b, uint64_t k, int c)
 	return cnt[c];
 }
 
+/* Seeding profile (diagnostic, per thread): bwt_extend calls by class (0/1 pass-1 forward/backward, 2/3 pass-2 forward/backward,
+ * 4 pass 3) and by the length of the string the extend produces (>= 63 in the last bin) -- what share of the rank queries a
+ * table of all k-mer intervals up to a given k could answer. */
+__thread uint64_t orc_seedprof[5][64];
+static __thread int sp_class, sp_len;
+void orc_seedprof_get(uint64_t *out) { memcpy(out, orc_seedprof, sizeof(orc_seedprof)); }
+void orc_seedprof_reset(void) { memset(orc_seedprof, 0, sizeof(orc_seedprof)); }
+static __thread int sp_pass = 1;
+
 void orc_extend(const orc_idx_t *b, const orc_intv_t *ik, orc_intv_t ok[4], int is_back)
 {
+	++orc_seedprof[sp_class][sp_len < 63 ? (sp_len < 0 ? 0 : sp_len) : 63];
 	uint64_t tk[4], tl[4];
 	int i, nb = !is_back;
 	++orc_stats.n_ext;
@@ -294,6 +304,7 @@ int orc_smem1a(const orc_idx_t *b, int len, const uint8_t *q, int x, int min_int
 			break;
 		} else if (q[i] < 4) {
 			c = 3 - q[i];
+			sp_class = sp_pass == 1 ? 0 : 2; sp_len = i - x + 1;
 			orc_extend(b, &ik, ok, 0);
 			if (ok[c].x[2] != ik.x[2]) {
 				iv_push(curr, &ik);
@@ -315,7 +326,7 @@ int orc_smem1a(const orc_idx_t *b, int len, const uint8_t *q, int x, int min_int
 		c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
 		for (j = 0, curr->n = 0; j < prev->n; ++j) {
 			orc_intv_t *p = &prev->a[j];
-			if (c >= 0 && ik.x[2] >= max_intv) orc_extend(b, p, ok, 1);
+			if (c >= 0 && ik.x[2] >= max_intv) { sp_class = sp_pass == 1 ? 1 : 3; sp_len = (int)(uint32_t)p->info - i; orc_extend(b, p, ok, 1); }
 			if (c < 0 || ik.x[2] < max_intv || ok[c].x[2] < (uint64_t)min_intv) {
 				if (curr->n == 0) {
 					if (mem->n == 0 || (uint64_t)(i + 1) < mem->a[mem->n - 1].info >> 32) {
@@ -345,6 +356,7 @@ int orc_seed_strategy1(const orc_idx_t *b, int len, const uint8_t *q, int x, int
 	for (i = x + 1; i < len; ++i) {
 		if (q[i] < 4) {
 			c = 3 - q[i];
+			sp_class = 4; sp_len = i - x + 1;
 			orc_extend(b, &ik, ok, 0);
 			if (ok[c].x[2] < (uint64_t)max_intv && i - x >= min_len) {
 				*mem = ok[c];
@@ -370,6 +382,7 @@ void orc_collect_intv(const orc_opt_t *opt, const orc_idx_t *b, int len, const u
 	orc_intv_v mem1 = {0, 0, 0}, t0 = {0, 0, 0}, t1 = {0, 0, 0};
 	mem->n = 0;
 	/* pass 1: all SMEMs */
+	sp_pass = 1;
 	while (x < len) {
 		if (seq[x] < 4) {
 			x = orc_smem1a(b, len, seq, x, 1, 0, &mem1, &t0, &t1);
@@ -382,6 +395,7 @@ void orc_collect_intv(const orc_opt_t *opt, const orc_idx_t *b, int len, const u
 	}
 	/* pass 2: re-seed inside long, rare SMEMs */
 	old_n = mem->n;
+	sp_pass = 2;
 	for (k = 0; k < old_n; ++k) {
 		orc_intv_t *p = &mem->a[k];
 		int start = (int)(p->info >> 32), end = (int32_t)p->info;

@@ -22,6 +22,8 @@ def small_ref(kind="two_contigs"):
         ctg = synth.make_genome([600000, 300000, 50000], seed=7, short_rep=0.2, long_rep=0.1, segdup=0.05)
     elif kind == "ngaps":
         ctg = synth.make_genome([150000, 80000], seed=3, n_gaps=20)
+    elif kind == "tiny_repeats":  # 120 Kbp: 240 K BWT symbols = four 2^16-symbol rank superblocks in the ss16 test build
+        ctg = synth.make_genome([80000, 40000], seed=17, short_rep=0.2, long_rep=0.1, segdup=0.05)
     elif kind == "mid":          # a few Mbp for GPU throughput smoke tests
         ctg = synth.make_genome([3000000, 1000000], seed=11)
     else:

@@ -1,0 +1,117 @@
+"""BASELINE configs[2]'s shape on one GPU: many bucket files streamed through reader -> engine -> append stage by ONE C-ABI
+call (include/ema_stream.h, ema_stream_buckets), two sets of batch buffers on one index taking alternate buckets, results
+delivered in order -- every bucket compared with the oracle's reader, aligner and append stage (reference
+src/main.c:396-406 -x loop, src/align.c:258,307-349,986-1061)."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import small_ref
+from ema_amd import stream, synth
+from ema_amd.engine import Engine, default_opts
+from test_gpu_pipeline import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_buckets(tmp_path, ctg, sizes, seed0):
+    paths = []
+    for k, n in enumerate(sizes):
+        path = str(tmp_path / f"ema-bin-{k:03d}")
+        if n == 0:
+            open(path, "wb").close()
+        else:
+            pairs = synth.make_pairs(ctg, n, seed=seed0 + k, sub_rate=0.01, indel_rate=0.001, pairs_per_barcode=9)
+            synth.write_special_fastq(path, pairs)
+            lines = open(path, "rb").read().splitlines(keepends=True)
+            random.Random(k).shuffle(lines)      # preproc writes buckets unsorted
+            open(path, "wb").write(b"".join(lines))
+        paths.append(path)
+    return paths
+
+
+def _check_stream(tmp_path, kind, sizes, batch_pairs, n_engines, seed0):
+    prefix, ctg = small_ref(kind)
+    paths = _write_buckets(tmp_path, ctg, sizes, seed0)
+    o = default_opts()
+    o.batch_pairs = batch_pairs
+    eng = Engine(prefix, opts=o)
+    so = stream.default_opts()
+    so.n_engines = n_engines
+    seen = []
+    idx, opt = O.Index(prefix), O.default_opt()
+
+    def sink(k, bucket, batch, rec, pair_off):
+        assert k == len(seen), "buckets must arrive in input order"
+        bases, off, bc = bucket
+        want, groups = O.read_special_fastq(paths[k]) if sizes[k] else ([], [])
+        assert len(want) == sizes[k] == len(bc)
+        for i, (wbc, _ident, r1, _q1, r2, _q2) in enumerate(want):
+            assert int(bc[i]) == wbc and bases[off[2 * i]:off[2 * i + 1]].tobytes() == r1 and bases[off[2 * i + 1]:off[2 * i + 2]].tobytes() == r2
+        ordered = synth.Pairs(bases, off)
+        assert batch.status.max(initial=0) == 0
+        bad = compare(prefix, ordered, batch)
+        assert not bad, f"bucket {k}: {len(bad)} reads differ from the oracle, first {bad[:4]}"
+        # append stage: the records of a sample of pairs against the oracle's append_alignments
+        assert len(pair_off) == ordered.n + 1 and int(pair_off[-1]) == len(rec)
+        for p in list(range(0, ordered.n, max(1, ordered.n // 60))):
+            exp = O.append_alignments(idx, opt, ordered.read(2 * p), ordered.read(2 * p + 1))
+            got = rec[int(pair_off[p]):int(pair_off[p + 1])]
+            assert len(got) == len(exp)
+            for g, e in zip(got, exp):
+                assert int(g["mate"]) == e["mate"] and int(g["cand"]) - int(batch.cand_off[2 * p + e["mate"]]) == e["cand"]
+                assert (int(g["clip"]), int(g["mapq"]), int(g["score_mapq"]), int(g["unique"])) == (e["clip"], e["mapq"], e["score_mapq"], e["unique"])
+                assert float(g["score"]) == e["score"]
+        seen.append((len(groups), int(batch.cand_off[-1]), len(rec)))
+
+    stats = stream.stream_buckets(eng, paths, sink, so)
+    eng.close()
+    assert len(seen) == len(sizes)
+    for k, st in enumerate(stats):
+        assert st["pairs"] == sizes[k] and st["rc"] == 0 and st["capacity_flags"] == 0
+        assert (st["barcode_groups"], st["candidates"], st["records"]) == seen[k]
+        assert sum(st["mapq_hist"]) == st["records"]
+
+
+def test_ten_buckets_streamed_two_buffer_sets(tmp_path):
+    """10 bucket files, one of them empty, back to back on the engine and its peer (alternate buckets)."""
+    _check_stream(tmp_path, "two_contigs", [300, 220, 0, 410, 150, 380, 90, 260, 330, 120], 512, 2, 700)
+
+
+def test_buckets_beyond_the_batch_capacity_in_the_stream(tmp_path):
+    """Capacity 256 pairs: some buckets fit a batch, some go through the piece pipeline (both buffer sets at once)."""
+    _check_stream(tmp_path, "repeats", [200, 700, 130, 1000, 256, 257, 40, 600], 256, 2, 720)
+
+
+def test_stream_on_one_buffer_set(tmp_path):
+    _check_stream(tmp_path, "two_contigs", [200, 0, 0, 310, 128, 64, 500, 77], 512, 1, 740)
+
+
+def test_stream_batches_from_memory_equals_align_pairs():
+    """ema_stream_batches (what bench.py times at the boundary) on distinct in-memory batches = one call per batch."""
+    prefix, ctg = small_ref("two_contigs")
+    batches = [synth.make_pairs(ctg, n, seed=760 + i, sub_rate=0.01) for i, n in enumerate((400, 350, 512, 60, 300, 450))]
+    o = default_opts()
+    o.batch_pairs = 512
+    eng = Engine(prefix, opts=o)
+    got = {}
+    stream.stream_batches(eng, [(p.bases, p.off) for p in batches], lambda k, _b, batch, rec, po: got.__setitem__(k, (batch, rec, po)))
+    for k, p in enumerate(batches):
+        one = eng.align_pairs(p.bases, p.off)
+        b = got[k][0]
+        assert (one.cand_off == b.cand_off).all() and one.cand.tobytes() == b.cand.tobytes() and (one.cigar == b.cigar).all()
+    eng.close()
+
+
+def test_a_bad_bucket_stops_the_stream_with_its_name(tmp_path):
+    prefix, ctg = small_ref("two_contigs")
+    paths = _write_buckets(tmp_path, ctg, [100, 100, 100], 780)
+    open(paths[1], "ab").write(b"ACGT only_two_fields\n")
+    eng = Engine(prefix)
+    seen = []
+    with pytest.raises(RuntimeError) as ei:
+        stream.stream_buckets(eng, paths, lambda k, *_: seen.append(k))
+    eng.close()
+    assert seen == [0] and "ema-bin-001" in str(ei.value)

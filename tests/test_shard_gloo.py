@@ -26,7 +26,7 @@ def _worker(rank, world, port, n_buckets, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = shard.buckets_of_rank(n_buckets, world, rank)
     # stand-in for "align bucket b on my GPU": statistics that identify the bucket
-    local = np.array([[1000 + b, 3 * b, 2 * b, 0] for b in mine], dtype=np.int64).reshape(-1, 4)
+    local = np.array([[1000 + b, 3 * b, 2 * b, b, 0, 1, 7] for b in mine], dtype=np.int64).reshape(-1, len(shard.STAT_FIELDS))
     table = shard.gather_stats(local, n_buckets)
     q.put((rank, mine, table.tolist()))
     dist.barrier()
@@ -52,12 +52,12 @@ def test_gather_stats_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    expect = [[1000 + b, 3 * b, 2 * b, 0] for b in range(n_buckets)]
+    expect = [[1000 + b, 3 * b, 2 * b, b, 0, 1, 7] for b in range(n_buckets)]
     for rank, mine, table in results:
         assert mine == list(range(rank, n_buckets, world))
         assert table == expect, f"rank {rank} gathered {table}"
 
 
 def test_gather_without_process_group_is_identity():
-    local = np.arange(8, dtype=np.int64).reshape(2, 4)
+    local = np.arange(2 * len(shard.STAT_FIELDS), dtype=np.int64).reshape(2, -1)
     assert (shard.gather_stats(local, 2) == local).all()

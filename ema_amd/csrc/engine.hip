@@ -81,6 +81,8 @@ extern "C" void ema_launch_test_local(const DevOpts *opt, const uint8_t *qbuf, c
                                       const uint32_t *toff, const int *prm, int n_tasks, int *out, uint64_t *bsc,
                                       size_t b_stride, hipStream_t s);
 
+extern "C" void ema_launch_test_matesw(const DevIndex *ix, const DevOpts *opt, int pes_low, int pes_high, const DevReg *a, const uint8_t *ms,
+                                       int l_ms, DevReg *ma, int *n_ma, int cap, uint8_t *slab, int *status, hipStream_t s);
 extern "C" void ema_launch_test_dedup(const DevIndex *ix, const DevOpts *opt, DevReg *regs, const int *n_in, int *n_out, int cap,
                                       int n_tasks, DevReg *tmp, uint64_t *keys, hipStream_t s);
 
@@ -782,6 +784,109 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 		}
 	}
 	*t = e->timing;
+	return EMA_OK;
+}
+
+static int debug_ready(ema_engine *e, const char *who);
+
+// New scoring / seeding / chaining options on an open engine (batch geometry and per-read capacities stay as opened):
+// what the reference does when it edits the mem_opt_t it got from mem_opt_init() (src/align.c:184-185).
+int ema_engine_set_opts(ema_engine_t *e, const ema_engine_opts *o)
+{
+	if (!e || !o) return EMA_EARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));
+	HIPCHK(e, hipStreamSynchronize(e->full.stream));
+	ema_engine_opts n = *o;
+	n.batch_pairs = e->opts.batch_pairs; n.n_streams = e->opts.n_streams; n.full_tier_pairs = e->opts.full_tier_pairs;
+	n.lean_intervals = e->opts.lean_intervals; n.lean_regions = e->opts.lean_regions; n.lean_cigar_ops = e->opts.lean_cigar_ops;
+	n.lean_seed_extends = e->opts.lean_seed_extends;
+	e->opts = n;
+	const DevOpts d = ema_make_dev_opts(n);
+	auto keep_caps = [&](DevOpts &dst) {
+		const int ic = dst.intv_cap, rc = dst.reg_cap, cc = dst.cig_cap, sb = dst.seed_budget;
+		dst = d; dst.intv_cap = ic; dst.reg_cap = rc; dst.cig_cap = cc; dst.seed_budget = sb;
+	};
+	keep_caps(e->dopts);
+	for (auto &s : e->sl) keep_caps(s.dopts);
+	keep_caps(e->full.dopts);
+	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + ((sizeof(DevIndex) + 15) & ~(size_t)15), &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
+	if (e->shadow) return ema_engine_set_opts(e->shadow, o);
+	return EMA_OK;
+}
+
+// One mem_matesw call (un-vendored bwa, reference src/bwabridge.c:267,281) in isolation: anchor region, the mate (ASCII),
+// the mate's region list ma[0..*n_ma) with room for `cap`; FR window [pes_low, pes_high].  *n_sw = alignments run (bwa's
+// return value).  Region records as in ema_engine_debug_regions.
+int ema_engine_debug_matesw(ema_engine_t *e, const void *anchor, const char *mate, int l_mate, void *ma, int32_t *n_ma, int cap,
+                            int pes_low, int pes_high, int32_t *n_sw)
+{
+	if (!e || !anchor || !mate || !ma || !n_ma || cap < 1 || l_mate < 0 || l_mate > EMA_MAX_READ || *n_ma < 0 || *n_ma > cap) return EMA_EARG;
+	if (cap > EMA_AV_CAP) cap = EMA_AV_CAP;
+	HIPCHK(e, hipSetDevice(e->device));
+	DevBuf<uint8_t> d_ms, d_slab;
+	DevBuf<DevReg> d_ma;
+	DevBuf<int> d_n;
+	HIPCHK(e, d_ms.alloc(EMA_MAX_READ + 1)); HIPCHK(e, d_slab.alloc(ema_pair_slab_bytes())); HIPCHK(e, d_ma.alloc((size_t)cap + 1)); HIPCHK(e, d_n.alloc(4));
+	uint8_t nt4[EMA_MAX_READ + 1];
+	for (int i = 0; i < l_mate; ++i) nt4[i] = kNt4[(unsigned char)mate[i]];
+	int head[3] = {*n_ma, 0, 0};
+	HIPCHK(e, hipMemcpy(d_ms.p, nt4, (size_t)l_mate + 1, hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(d_ma.p, ma, (size_t)*n_ma * sizeof(DevReg), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(d_n.p, head, 12, hipMemcpyHostToDevice));
+	hipStream_t st = e->sl[0].stream;
+	ema_launch_test_matesw(&e->dix, &e->dopts, pes_low, pes_high, (const DevReg *)anchor, d_ms.p, l_mate, d_ma.p, d_n.p, cap, d_slab.p, d_n.p + 1, st);
+	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipStreamSynchronize(st));
+	HIPCHK(e, hipMemcpy(head, d_n.p, 12, hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(ma, d_ma.p, (size_t)head[0] * sizeof(DevReg), hipMemcpyDeviceToHost));
+	*n_ma = head[0];
+	if (n_sw) *n_sw = head[2];
+	d_ms.release(); d_slab.release(); d_ma.release(); d_n.release();
+	if (head[1]) { e->err = "mem_matesw: an engine capacity was exceeded"; return EMA_ELIMIT; }
+	return EMA_OK;
+}
+
+// mem_reg2aln (un-vendored bwa, reference src/bwabridge.c:304) for given regions of ONE read: K4 on the full-capacity tier
+// with the region list supplied by the caller instead of K1..K3.  out[i] describes regs[i]; cigar: caller's buffer.
+int ema_engine_debug_final(ema_engine_t *e, const char *read, int l_read, const void *regs, int n_regs, ema_cand_t *out, uint32_t *cigar,
+                           int cigar_cap, int32_t *n_cigar_total)
+{
+	if (!e || !read || !regs || !out || !cigar || n_regs < 0 || n_regs > EMA_REG_CAP || l_read < 0 || l_read > EMA_MAX_READ) return EMA_EARG;
+	const uint32_t off[3] = {0, (uint32_t)l_read, (uint32_t)l_read};      // the read and an empty mate
+	int rc = ema_engine_stage(e, read, off, 1);
+	if (rc) return rc;
+	if ((rc = debug_ready(e, "ema_engine_debug_final"))) return rc;
+	Slice &f = e->full;
+	const Work w = work_of(e, f, false);
+	const int n2[2] = {n_regs, 0};
+	HIPCHK(e, hipMemsetAsync(f.d_status.p, 0, 2 * 4, f.stream));
+	HIPCHK(e, hipMemsetAsync(f.d_counters.p, 0, 32 * 4, f.stream));
+	HIPCHK(e, hipMemcpyAsync(f.d_n_regs.p, n2, 8, hipMemcpyHostToDevice, f.stream));
+	HIPCHK(e, hipMemcpyAsync(f.d_regs.p, regs, (size_t)n_regs * sizeof(DevReg), hipMemcpyHostToDevice, f.stream));
+	if ((rc = run_final(e, f, w))) return rc;
+	HIPCHK(e, hipStreamSynchronize(f.stream));
+	std::vector<DevAln> al((size_t)n_regs + 1);
+	std::vector<DevReg> rg((size_t)n_regs + 1);
+	int cig_n = 0, st = 0;
+	HIPCHK(e, hipMemcpy(al.data(), f.d_alns.p, (size_t)n_regs * sizeof(DevAln), hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(rg.data(), f.d_regs.p, (size_t)n_regs * sizeof(DevReg), hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(&cig_n, f.d_cig_n.p, 4, hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemcpy(&st, f.d_status.p, 4, hipMemcpyDeviceToHost));
+	if (st) { e->err = "mem_reg2aln: an engine capacity was exceeded"; return EMA_ELIMIT; }
+	if (cig_n > cigar_cap) { e->err = "mem_reg2aln: CIGAR buffer too small"; return EMA_ELIMIT; }
+	HIPCHK(e, hipMemcpy(cigar, f.d_cigars.p, (size_t)cig_n * 4, hipMemcpyDeviceToHost));
+	for (int i = 0; i < n_regs; ++i) {
+		ema_cand_t c;
+		memset(&c, 0, sizeof(c));
+		const DevReg &g = rg[i];
+		c.rb = g.rb; c.re = g.re; c.qb = g.qb; c.qe = g.qe; c.rid = g.rid; c.score = g.score; c.truesc = g.truesc; c.sub = g.sub; c.csub = g.csub;
+		c.w = g.w; c.seedcov = g.seedcov; c.secondary = g.secondary; c.seedlen0 = g.seedlen0; c.n_comp = g.n_comp; c.is_alt = g.is_alt; c.frac_rep = g.frac_rep;
+		c.pos = al[i].pos; c.is_rev = al[i].is_rev; c.NM = al[i].NM; c.n_cigar = al[i].n_cigar; c.cigar_off = al[i].cigar_off;
+		c.aln_score = g.score; c.aln_sub = g.sub > g.csub ? g.sub : g.csub;
+		out[i] = c;
+	}
+	if (n_cigar_total) *n_cigar_total = cig_n;
 	return EMA_OK;
 }
 

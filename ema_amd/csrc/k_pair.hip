@@ -27,6 +27,7 @@ struct PairCtx {
 	EmaRegWork wk;
 	int pes_low, pes_high;
 	int status;
+	int n_sw = 0;           // alignments run so far (mem_matesw's return value)
 };
 
 __device__ __forceinline__ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t &dist)
@@ -69,6 +70,7 @@ __device__ inline int matesw(PairCtx &cx, const DevReg &a, int l_ms, const uint8
 	if (re - rb > EMA_RSEQ_CAP) { cx.status |= EMA_ST_RSEQ_OVERFLOW; return n_ma; }
 	const int tlen = (int)(re - rb);
 	ema_wave_fetch(ix, rb, re, cx.rseq);
+	++cx.n_sw;
 	// ksw_align2 with KSW_XSUBO | KSW_XSTART | (l_ms * a < 250 ? KSW_XBYTE : 0) | min_seed_len * a
 	const int p = l_ms * o.a < 250 ? 16 : 8;
 	const int minsc = o.min_seed_len * o.a;
@@ -237,6 +239,47 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 		EMA_DBG(9, 0);
 	}
 #undef EMA_DBG
+}
+
+// One mem_matesw call in isolation (the libbwa-shaped face, include/ema_bwaabi.h, and its parity test): anchor region `a`,
+// the mate's nt4 bases ms[0..l_ms), the mate's region list ma[0..*n_ma) (room for cap), FR window [pes_low, pes_high].
+// One wavefront.  slab: EMA_PAIR_SLAB_BYTES of scratch.
+__global__ void __launch_bounds__(64)
+ema_k_test_matesw(DevIndex ix, DevOpts opt, int pes_low, int pes_high, DevReg a, const uint8_t *__restrict__ ms, int l_ms,
+                  DevReg *__restrict__ ma, int *__restrict__ n_ma, int cap, uint8_t *__restrict__ slab, int *__restrict__ status /* [0] status bits, [1] alignments run */)
+{
+	__shared__ uint8_t lds_q[256];
+	__shared__ uint8_t lds_rc[256];
+	__shared__ uint8_t lds_r[EMA_RSEQ_CAP];
+	__shared__ int lds_stack[3 * 70];
+	const int lane = (int)ema_lane();
+	PairCtx cx;
+	cx.ix = &ix; cx.opt = &opt;
+	cx.rc = lds_rc; cx.rseq = lds_r;
+	cx.wk.a = (DevReg *)slab;
+	cx.wk.tmp = (DevReg *)slab + 2 * EMA_AV_CAP;
+	cx.wk.keys = (uint64_t *)((DevReg *)slab + 3 * EMA_AV_CAP);
+	cx.bsc = cx.wk.keys + EMA_AV_CAP;
+	cx.wk.stack = lds_stack;
+	cx.wk.rseq = lds_r;
+	cx.wk.mark = nullptr;
+	cx.pes_low = pes_low; cx.pes_high = pes_high;
+	cx.status = 0;
+	int n = ema_uni(*n_ma);
+	for (int i = lane; i < l_ms; i += EMA_WAVE) lds_q[i] = ms[i];
+	for (int i = lane; i < n; i += EMA_WAVE) cx.wk.a[i] = ma[i];
+	ema_wave_sync();
+	n = matesw(cx, a, l_ms, lds_q, n);
+	ema_wave_sync();
+	if (n > cap) { cx.status |= EMA_ST_REG_OVERFLOW; n = cap; }
+	for (int i = lane; i < n; i += EMA_WAVE) ma[i] = cx.wk.a[i];
+	if (lane == 0) { *n_ma = n; status[0] = cx.status; status[1] = cx.n_sw; }
+}
+
+extern "C" void ema_launch_test_matesw(const DevIndex *ix, const DevOpts *opt, int pes_low, int pes_high, const DevReg *a, const uint8_t *ms,
+                                       int l_ms, DevReg *ma, int *n_ma, int cap, uint8_t *slab, int *status, hipStream_t s)
+{
+	hipLaunchKernelGGL(ema_k_test_matesw, dim3(1), dim3(64), 0, s, *ix, *opt, pes_low, pes_high, *a, ms, l_ms, ma, n_ma, cap, slab, status);
 }
 
 extern "C" size_t ema_pair_slab_bytes() { return EMA_PAIR_SLAB_BYTES; }

@@ -165,6 +165,19 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
                         const uint32_t *toff, const int32_t *prm, int n_tasks, int32_t *out, uint32_t *cigar,
                         int cigar_cap);
 
+/* The per-call entry points the libbwa-shaped face (include/ema_bwaabi.h) is built from; also used by its parity tests.
+ * set_opts: new scoring/seeding/chaining options on an open engine (what the reference does by editing its mem_opt_t,
+ *   src/align.c:184-185); batch geometry and capacities stay as opened.
+ * debug_matesw: one mem_matesw call (reference src/bwabridge.c:267,281): anchor region, the mate (ASCII), the mate's regions
+ *   ma[0..*n_ma) with room for cap, FR window; *n_sw = alignments run.  Region records as in ema_engine_debug_regions.
+ * debug_final: mem_reg2aln (src/bwabridge.c:304) for n_regs given regions of one read: out[i] (region fields + pos, is_rev,
+ *   NM, n_cigar, cigar_off into `cigar`). */
+int ema_engine_set_opts(ema_engine_t *e, const ema_engine_opts *o);
+int ema_engine_debug_matesw(ema_engine_t *e, const void *anchor, const char *mate, int l_mate, void *ma, int32_t *n_ma, int cap,
+                            int pes_low, int pes_high, int32_t *n_sw);
+int ema_engine_debug_final(ema_engine_t *e, const char *read, int l_read, const void *regs, int n_regs, ema_cand_t *out, uint32_t *cigar,
+                           int cigar_cap, int32_t *n_cigar_total);
+
 /* Profiling aid: with EMA_PHASE_PROFILE=2 in the environment when the engine is opened, K2b logs one record per read
  * {read, intervals or -1, seed occurrences, chains, seeds, regions before dedup, extension DPs, shader clocks / 16};
  * this returns and resets the log (n records of 8 ints; caller frees). */

@@ -45,13 +45,14 @@ extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
                                  DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs,
-                                 int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof);
+                                 int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof, int mid);
+extern "C" int ema_align_mid_blocks_per_cu();
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
-                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, uint8_t *hand,
-                                        int n_blocks, hipStream_t stream, unsigned long long *prof);
+                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int *todo_mid,
+                                        int *n_todo_mid, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" int ema_align_blocks_per_cu();
 extern "C" int ema_pair_blocks_per_cu();
@@ -154,7 +155,7 @@ struct Slice {
 	size_t cap_pairs = 0, n_pairs = 0, first_pair = 0;
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
 	DevBuf<Intv> d_intv, d_lists;
-	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo;
+	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo, d_todo_mid;
 	DevBuf<DevReg> d_regs;
 	DevBuf<uint8_t> d_slabs, d_park[2], d_hand;   // d_hand: K2a -> K2b records (EMA_HAND_BYTES per read)   // d_park: K1's parked machines, ping-pong between the launches of a series
 	DevBuf<DevAln> d_alns;
@@ -167,7 +168,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
+		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_todo_mid.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 		if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -217,6 +218,8 @@ struct ema_engine {
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
+	bool mid_align = true;               // EMA_MID_ALIGN=0: no LDS build of K2b (reads with 33..192 seed occurrences stay with the bulk build)
+	int align_mid_blocks = 0;
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
@@ -266,6 +269,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_kdone.alloc(n_reads));
 	HIPCHK(e, s.d_hand.alloc(n_reads * EMA_HAND_BYTES));
 	HIPCHK(e, s.d_todo.alloc(n_reads));
+	HIPCHK(e, s.d_todo_mid.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
 	if (e->watchdog_s > 0 && !getenv("EMA_WATCHDOG_NOMARK")) {
@@ -413,6 +417,8 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
+	if (const char *v = getenv("EMA_MID_ALIGN")) e->mid_align = atoi(v) != 0;
+	e->align_mid_blocks = e->n_cu * ema_align_mid_blocks_per_cu();
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
 	if (n_streams > 16) n_streams = 16;
@@ -652,16 +658,24 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 static int run_align(ema_engine *e, Slice &s, const Work &w)
 {
 	// K2a: small reads, one lane each; the others land on the todo list that K2b (one wavefront per read) works through
+	const bool mid = e->lane_align && e->mid_align;
 	if (e->lane_align) {
 		ema_launch_align_simple(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
-		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21, s.d_hand.p,
-		                        e->lane_blocks, s.stream, e->d_prof.p);
+		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21,
+		                        mid ? s.d_todo_mid.p : nullptr, s.d_counters.p + 24, s.d_hand.p, e->lane_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
+	// K2b, bulk build: K2a's hand-overs and the repeat-rich reads; then the LDS build for the reads in between
 	ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 0,
-	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p);
+	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, 0);
 	HIPCHK(e, hipGetLastError());
+	if (mid) {
+		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+		                 s.d_n_regs.p, s.d_status.p, s.d_todo_mid.p, s.d_counters.p + 24, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 25,
+		                 e->align_mid_blocks, s.stream, s.dbg, e->d_prof.p, 1);
+		HIPCHK(e, hipGetLastError());
+	}
 	watchdog(e, s, "ema_k_align");
 	return EMA_OK;
 }
@@ -1044,6 +1058,15 @@ static int pack_slice(ema_engine *e, Slice &s, size_t nr, const uint64_t *loc_ca
 	return EMA_OK;
 }
 
+// Device-to-host copy on the engine's own stream.  (A plain hipMemcpy goes through the null stream, which waits for -- and
+// holds up -- every other stream of the process: with two sets of batch buffers in flight, one set's fetch would wait for the
+// other set's kernels.)
+#define D2H(e, dst, src, bytes, stream)                                                              \
+	do {                                                                                             \
+		HIPCHK(e, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, (stream)));           \
+		HIPCHK(e, hipStreamSynchronize(stream));                                                     \
+	} while (0)
+
 int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 {
 	if (!e || !out) return EMA_EARG;
@@ -1055,22 +1078,22 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	for (auto &s : e->sl) {
 		HIPCHK(e, hipStreamSynchronize(s.stream));
 		const size_t r0 = 2 * s.first_pair, nr = 2 * s.n_pairs;
-		HIPCHK(e, hipMemcpy(n_regs.data() + r0, s.d_n_regs.p, nr * 4, hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(cig_n.data() + r0, s.d_cig_n.p, nr * 4, hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(status.data() + r0, s.d_status.p, nr * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpyAsync(n_regs.data() + r0, s.d_n_regs.p, nr * 4, hipMemcpyDeviceToHost, s.stream));
+		HIPCHK(e, hipMemcpyAsync(cig_n.data() + r0, s.d_cig_n.p, nr * 4, hipMemcpyDeviceToHost, s.stream));
+		D2H(e, status.data() + r0, s.d_status.p, nr * 4, s.stream);
 	}
 	// the pairs redone by the full-capacity tier
 	Slice &f = e->full;
 	HIPCHK(e, hipStreamSynchronize(f.stream));
 	int n_listed = 0;
-	HIPCHK(e, hipMemcpy(&n_listed, e->d_redo_run.p, 4, hipMemcpyDeviceToHost));
+	D2H(e, &n_listed, e->d_redo_run.p, 4, f.stream);
 	const size_t n_redo = std::min<size_t>((size_t)n_listed, f.cap_pairs);
 	std::vector<int> redo(n_redo + 1), f_regs(2 * n_redo + 1), f_cig(2 * n_redo + 1), f_status(2 * n_redo + 1);
 	if (n_redo) {
-		HIPCHK(e, hipMemcpy(redo.data(), e->d_redo_run.p + 1, n_redo * 4, hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(f_regs.data(), f.d_n_regs.p, 2 * n_redo * 4, hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(f_cig.data(), f.d_cig_n.p, 2 * n_redo * 4, hipMemcpyDeviceToHost));
-		HIPCHK(e, hipMemcpy(f_status.data(), f.d_status.p, 2 * n_redo * 4, hipMemcpyDeviceToHost));
+		HIPCHK(e, hipMemcpyAsync(redo.data(), e->d_redo_run.p + 1, n_redo * 4, hipMemcpyDeviceToHost, f.stream));
+		HIPCHK(e, hipMemcpyAsync(f_regs.data(), f.d_n_regs.p, 2 * n_redo * 4, hipMemcpyDeviceToHost, f.stream));
+		HIPCHK(e, hipMemcpyAsync(f_cig.data(), f.d_cig_n.p, 2 * n_redo * 4, hipMemcpyDeviceToHost, f.stream));
+		D2H(e, f_status.data(), f.d_status.p, 2 * n_redo * 4, f.stream);
 	}
 	for (size_t r = 0; r < n_reads; ++r) if (status[r]) n_regs[r] = cig_n[r] = 0;      // flagged and not redone: no output, status stays
 	for (size_t i = 0; i < n_redo; ++i)

@@ -39,21 +39,30 @@ struct AlignSlab {           // per resident wave
 // Most reads have a few dozen seed occurrences at most.  Their chaining tables then sit in LDS instead of the HBM slab:
 // chaining is a sequence of dependent small look-ups and edits (find the neighbouring chain, test, link the seed), and
 // each one costs a memory round trip when the tables are in HBM.
-#define EMA_SMALL_SEEDS 40
-#define EMA_SMALL_BYTES (EMA_SMALL_SEEDS * (2 * sizeof(SeedRec) + sizeof(ChainRec) + 3 * 8 + 2 * 4))
+// Two builds of the kernel differ in how much of that fits (template parameters SMALL = seed occurrences whose tables sit in
+// LDS, AVL = regions before de-duplication kept in LDS):
+//   ema_k_align_t<32, 8, 4>    the bulk: reads K2a hands over with their chains ready (<= EMA_HAND_SEEDS seeds) and the
+//                              repeat-rich ones (> EMA_MID_SEEDS occurrences: tables in the HBM slab); 16 waves per CU
+//   ema_k_align_t<192, 24, 1>  reads with 33..192 seed occurrences -- 12 % of the reads and 60 % of this stage's wave clocks
+//                              at the default scale while their tables were in HBM (every chaining step a handful of dependent
+//                              round trips at loaded-memory latency); one block per CU, everything in LDS.
+// K2a sorts the reads into the two work lists.
+#define EMA_SMALL_BYTES(SMALL) ((SMALL) * (2 * sizeof(SeedRec) + sizeof(ChainRec) + 3 * 8 + 2 * 4))
+#define EMA_AVL_BYTES(AVL) ((AVL) * (2 * sizeof(DevReg) + 8))
 
+template <int SMALL>
 __device__ __forceinline__ void ema_small_tables(AlignSlab &s, uint8_t *lds)
 {
 	size_t o = 0;
 	auto take = [&](size_t bytes) { uint8_t *p = lds + o; o += bytes; return p; };
-	s.chains = (ChainRec *)take(EMA_SMALL_SEEDS * sizeof(ChainRec));
-	s.seeds = (SeedRec *)take(EMA_SMALL_SEEDS * sizeof(SeedRec));
-	s.cs = (SeedRec *)take(EMA_SMALL_SEEDS * sizeof(SeedRec));
-	s.cpos = (int64_t *)take(EMA_SMALL_SEEDS * 8);
-	s.skey = (uint64_t *)take(EMA_SMALL_SEEDS * 8);
-	s.srt = (uint64_t *)take(EMA_SMALL_SEEDS * 8);
-	s.cord = (int32_t *)take(EMA_SMALL_SEEDS * 4);
-	s.kept = (int32_t *)take(EMA_SMALL_SEEDS * 4);
+	s.chains = (ChainRec *)take(SMALL * sizeof(ChainRec));
+	s.seeds = (SeedRec *)take(SMALL * sizeof(SeedRec));
+	s.cs = (SeedRec *)take(SMALL * sizeof(SeedRec));
+	s.cpos = (int64_t *)take(SMALL * 8);
+	s.skey = (uint64_t *)take(SMALL * 8);
+	s.srt = (uint64_t *)take(SMALL * 8);
+	s.cord = (int32_t *)take(SMALL * 4);
+	s.kept = (int32_t *)take(SMALL * 4);
 }
 
 __device__ __forceinline__ AlignSlab ema_carve_slab(uint8_t *base)
@@ -199,8 +208,9 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 
 // one wavefront = one read at a time, reads taken from a shared counter
 // intv/n_intv: K1's output (stride opt.intv_cap).  regs: n_reads x opt.reg_cap, n_regs: n_reads.  status is OR-ed.
-__global__ void __launch_bounds__(256, 4)
-ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
+template <int SMALL, int AVL, int WPS>
+__global__ void __launch_bounds__(256, WPS)
+ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
             int *__restrict__ status, const int *__restrict__ todo, const int *__restrict__ n_todo,
@@ -218,7 +228,8 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
 	__shared__ int lds_stack[4][3 * 70];
-	__shared__ __attribute__((aligned(16))) uint8_t lds_small[4][EMA_SMALL_BYTES];
+	__shared__ __attribute__((aligned(16))) uint8_t lds_small[4][EMA_SMALL_BYTES(SMALL)];
+	__shared__ __attribute__((aligned(16))) uint8_t lds_av[4][EMA_AVL_BYTES(AVL)];      // regions of the read while there are few
 	const int lane = (int)ema_lane();
 	const int wib = (int)(threadIdx.x >> 6);
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
@@ -262,7 +273,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 		if (handed) {
 			// small tables in LDS, filled from K2a's record
 			cb.sl = slab;
-			ema_small_tables(cb.sl, lds_small[wib]);
+			ema_small_tables<SMALL>(cb.sl, lds_small[wib]);
 			const uint8_t *h = hand + (size_t)read * EMA_HAND_BYTES;
 			const int32_t *head = reinterpret_cast<const int32_t *>(h);
 			n_chn = ema_uni(head[0]);
@@ -308,7 +319,7 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			}
 			l_rep += e - b;
 			cb.sl = slab;
-			if (ema_uni(tot_occ <= EMA_SMALL_SEEDS)) ema_small_tables(cb.sl, lds_small[wib]);
+			if (ema_uni(tot_occ <= SMALL)) ema_small_tables<SMALL>(cb.sl, lds_small[wib]);
 			log_iv = n_iv; log_occ = (int)(tot_occ < (1 << 30) ? tot_occ : (1 << 30));
 		}
 		frac_rep = (float)l_rep / (float)l_query;
@@ -405,6 +416,13 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 
 		}
 
+		// regions start out in LDS (sorting and de-duplicating a handful of them in the HBM slab is dozens of dependent round
+		// trips); the list moves to the slab when it outgrows AVL
+		bool av_lds = true;
+		{
+			uint8_t *b = lds_av[wib];
+			cb.sl.av = (DevReg *)b; cb.sl.av_tmp = (DevReg *)b + AVL; cb.sl.rkeys = (uint64_t *)((DevReg *)b + 2 * AVL);
+		}
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
 		int n_av = 0;
 		EMA_DBG(5, n_keep);
@@ -492,6 +510,13 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 					if (!other) { if (lane == 0) sl.srt[k] = 0; continue; }
 				}
 				if (n_av >= EMA_AV_CAP) { cb.status |= EMA_ST_REG_OVERFLOW; continue; }
+				if (av_lds && n_av >= AVL) {      // outgrown: continue in the slab
+					ema_wave_sync();
+					for (int i = lane; i < n_av; i += EMA_WAVE) slab.av[i] = sl.av[i];
+					cb.sl.av = slab.av; cb.sl.av_tmp = slab.av_tmp; cb.sl.rkeys = slab.rkeys;
+					av_lds = false;
+					ema_wave_sync();
+				}
 
 				DevReg a;
 				a.sub = a.csub = a.secondary = a.n_comp = a.is_alt = 0; a.seedcov = 0;
@@ -581,20 +606,32 @@ ema_k_align(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
+// mid = 0: the bulk build (K2a's hand-overs and the repeat-rich reads), 16 waves per CU; mid = 1: the LDS build for the reads
+// with up to EMA_MID_SEEDS seed occurrences, one block per CU
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
                                  const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs, int *counter, int n_blocks,
                                  hipStream_t stream, int *dbg,
-                                 unsigned long long *prof)
+                                 unsigned long long *prof, int mid)
 {
-	hipLaunchKernelGGL(ema_k_align, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
-	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof);
+	if (mid)
+		hipLaunchKernelGGL((ema_k_align_t<EMA_MID_SEEDS, 24, 1>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
+		                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof);
+	else
+		hipLaunchKernelGGL((ema_k_align_t<32, 8, 4>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
+		                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)
 extern "C" int ema_align_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4>, 256, 0) != hipSuccess || n < 1) n = 1;
+	return n > 8 ? 8 : n;
+}
+extern "C" int ema_align_mid_blocks_per_cu()
+{
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

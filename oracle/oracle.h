@@ -263,6 +263,23 @@ int orc_sam_format(const orc_sam_line_t *lines, size_t n, const orc_sam_opts_t *
 int orc_sam_header(const char *const *names, const int32_t *lens, int32_t n, const char *rg, const char *version, int pg_argc,
                    const char *const *pg_argv, char **text, size_t *n_bytes);
 
+/* ---- cloud / EM / duplicate stage (oracle/clouds.c; reference src/align.c:347-608, src/samdict.c) ---- */
+typedef struct orc_crec {         /* the fields of SAMRecord (reference include/samrecord.h:21-56) this stage reads and writes */
+	uint64_t bc;
+	uint32_t chrom, pos;          /* chrom index; 1-based position (alignment_to_sam_rec, src/align.c:922-923) */
+	char ident[256];
+	double score;                 /* alignment log-likelihood (score_alignment) */
+	uint32_t mate, rev;
+	uint32_t orig;                /* index in append_alignments' order */
+	uint32_t hash, mate_hash;
+	uint8_t hashed, mate_hashed, active, duplicate, visited, pad_[3];
+	/* results */
+	double gamma;
+	int32_t cloud_id, cloud_bad, alt;      /* alt: `orig` of the record the XA entry is copied from, or -1 */
+	struct orc_crec *sel_mate;
+} orc_crec_t;
+size_t orc_clouds_group(orc_crec_t *recs, size_t n, size_t n_pairs, uint32_t dist_thresh, int many_clouds, int *cloud_id, int *order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@
 #include <string.h>
 #include <math.h>
 #include <assert.h>
+#include <malloc.h>
 #include "oracle.h"
 #include <omp.h>
 
@@ -337,8 +338,18 @@ double orc_bench_pairs(const orc_opt_t *opt, const orc_idx_t *idx, const char *b
 {
 	uint64_t total = 0;
 	long i;
-	double t0 = omp_get_wtime();
+	double t0;
 	if (n_threads < 1) n_threads = 1;
+	/* Like bwa, this code allocates its per-read working sets with malloc/calloc.  glibc gives every thread its own arena, but
+	 * an arena hands memory back to the kernel whenever its top chunk passes the trim threshold and asks for it again for the
+	 * next repeat-rich read; both are address-space updates under the process-wide memory-map lock, and with dozens of threads
+	 * they serialise the run.  Keep freed memory in the arenas for the duration of the timing. */
+	if (!getenv("ORC_BENCH_DEFAULT_MALLOC")) {
+		mallopt(M_TRIM_THRESHOLD, 1 << 30);
+		mallopt(M_MMAP_THRESHOLD, 1 << 30);
+		mallopt(M_TOP_PAD, 64 << 20);
+	}
+	t0 = omp_get_wtime();
 #pragma omp parallel for num_threads(n_threads) schedule(dynamic, 16) reduction(+ : total)
 	for (i = 0; i < (long)n_pairs; ++i) {
 		orc_pair_out_t o;

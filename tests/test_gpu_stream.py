@@ -101,7 +101,9 @@ def test_stream_batches_from_memory_equals_align_pairs():
     for k, p in enumerate(batches):
         one = eng.align_pairs(p.bases, p.off)
         b = got[k][0]
-        assert (one.cand_off == b.cand_off).all() and one.cand.tobytes() == b.cand.tobytes() and (one.cigar == b.cigar).all()
+        assert (one.cand_off == b.cand_off).all() and (one.cigar == b.cigar).all()
+        for f in one.cand.dtype.names:      # field by field: the records' padding bytes are not part of the result
+            assert (one.cand[f] == b.cand[f]).all(), (k, f)
     eng.close()
 
 

@@ -1,0 +1,525 @@
+// ema_amd/csrc/host_clouds.cpp -- the cloud / EM / duplicate-marking stage behind the hot path (include/ema_clouds.h):
+// what the reference's find_clouds_and_align() does with every barcode group after append_alignments()
+// (reference src/align.c:347-608) and its SAMDict (src/samdict.c:11-243), for a whole bucket, barcode groups in parallel.
+//
+// Structure.  The reference keeps pointers between SAMRecords, Clouds and dictionary entries and a hash table keyed by read
+// name; here a group's records, clouds and entries are index-addressed arrays in per-thread scratch that is reused from
+// group to group, and the dictionary is a direct table over (rank of the read name within the group, mate) -- the same
+// equivalence classes the reference's hash + strcmp gives.  Everything that decides an output is kept as the reference has
+// it: the three sort orders (its qsort calls are merge sorts in glibc, i.e. stable: std::stable_sort with the same
+// comparators), the order in which dictionary entries are visited (newest first: the reference pushes at the list head),
+// the order of every floating-point accumulation, the expressions themselves (double precision, no contraction: the file is
+// built with -ffp-contract=off), and the cloud numbering of a single-threaded run.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "ema_clouds.h"
+
+namespace {
+
+// reference include/align.h:49-74, include/samdict.h:9
+const int kEmIters = 5;
+const int kInsertMin = -35, kInsertMax = 750;
+const double kUnpairedPenalty = -15.0;
+const double kSecondaryAlignThresh = 0.9;
+const size_t kMaxCandidates = 5000;
+
+struct Rec {
+	uint32_t chrom, pos;          // chromosome index; 1-based position (alignment_to_sam_rec, src/align.c:922-923)
+	int32_t rank;                 // rank of the read name among the group's names (strcmp order)
+	double score, gamma;
+	uint8_t mate, rev, duplicate, visited;
+	int32_t cloud, alt, sel_mate; // local cloud; record the XA entry is copied from; selected mate (record index) or -1
+	uint64_t gi;                  // index in ema_aln_out.rec
+};
+struct Cloud { double exp_cov, weight; int32_t parent, child; uint8_t bad; };
+struct Cand { int32_t rec, cloud; double gamma; };
+struct Entry { int32_t key, mate; bool visited; std::vector<Cand> c; };
+
+struct Name { const char *p; uint32_t len; uint32_t pair; };
+
+inline int name_cmp(const Name &a, const Name &b)      // strcmp on the (NUL-free) names
+{
+	const uint32_t n = a.len < b.len ? a.len : b.len;
+	const int c = memcmp(a.p, b.p, n);
+	if (c) return c;
+	return (a.len > b.len) - (a.len < b.len);
+}
+
+void normalize_log_probs(std::vector<Cand> &c)      // src/util.c:130-163
+{
+	const size_t n = c.size();
+	if (n == 1) { c[0].gamma = 1.0; return; }
+	if (n == 0) return;
+	const double thresh = std::log(1e-50) - std::log((double)n);
+	double p_max = c[0].gamma;
+	for (size_t i = 1; i < n; i++) if (c[i].gamma > p_max) p_max = c[i].gamma;
+	double total = 0;
+	for (size_t i = 0; i < n; i++) {
+		c[i].gamma -= p_max;
+		if (c[i].gamma < thresh) c[i].gamma = 0; else c[i].gamma = std::exp(c[i].gamma);
+		total += c[i].gamma;
+	}
+	for (size_t i = 0; i < n; i++) c[i].gamma /= total;
+}
+
+double mate_dist_penalty(int64_t mate1_pos, int64_t mate2_pos)      // src/align.c:57-67
+{
+	const int64_t d = mate1_pos - mate2_pos;
+	return (kInsertMin <= d && d <= kInsertMax) ? 0.0 : kUnpairedPenalty;
+}
+
+struct Sel { uint64_t rec, mate; };      // indices into ema_aln_out.rec; mate == ~0: none
+
+// per-thread scratch, reused from group to group
+struct Work {
+	std::vector<Rec> recs;
+	std::vector<int32_t> ord, final_, split;
+	std::vector<Cloud> clouds;
+	std::vector<Entry> ents;
+	size_t n_ents = 0;
+	std::vector<int32_t> ent_of;      // (rank, mate) -> entry
+	std::vector<Name> names;
+	std::vector<int32_t> rank_of_pair;
+};
+
+struct Shared {
+	const ema_bucket *bk;
+	const ema_batch_out *b;
+	const ema_aln_out *a;
+	ema_cloud_opts o;
+	// per record of ema_aln_out (only the selected ones are read back)
+	std::vector<double> gamma;
+	std::vector<int32_t> cloud, alt_of;      // local cloud id; aln record the XA entry comes from (-1: none)
+	std::vector<uint8_t> flags;              // bit 0 duplicate, bit 1 cloud bad
+	std::vector<Sel> sel;                    // per group, from the group's first record index on
+	std::vector<uint32_t> n_sel, n_clouds, n_bad;      // per group
+};
+
+int sam_dict_add(Work &w, const Shared &S, int32_t k, int32_t v, bool force)      // src/samdict.c:79-148
+{
+	const Rec &kr = w.recs[(size_t)k];
+	const size_t slot = 2 * (size_t)kr.rank + kr.mate;
+	int32_t ei = w.ent_of[slot];
+	if (ei >= 0) {
+		Entry &e = w.ents[(size_t)ei];
+		const size_t num = e.c.size();
+		if (num < kMaxCandidates) {
+			if (num > 0) {
+				const int32_t parent = e.c[num - 1].cloud;
+				if (parent == v && !force) return 1;
+				if (!S.o.many_clouds) {      // link the two clouds' sets (chains through parent/child)
+					int32_t root1 = parent;
+					while (w.clouds[(size_t)root1].parent >= 0) root1 = w.clouds[(size_t)root1].parent;
+					int32_t root2 = v;
+					while (w.clouds[(size_t)root2].parent >= 0) root2 = w.clouds[(size_t)root2].parent;
+					if (root1 != root2) {
+						int32_t leaf = parent;
+						while (w.clouds[(size_t)leaf].child >= 0) leaf = w.clouds[(size_t)leaf].child;
+						w.clouds[(size_t)root2].parent = leaf;
+						w.clouds[(size_t)leaf].child = root2;
+					}
+				}
+			}
+			e.c.push_back(Cand{k, v, kr.score});
+		}
+	} else {
+		if (w.n_ents == w.ents.size()) w.ents.emplace_back();
+		ei = (int32_t)w.n_ents++;
+		Entry &e = w.ents[(size_t)ei];
+		e.key = k; e.mate = -1; e.visited = false;
+		e.c.clear();
+		e.c.push_back(Cand{k, v, kr.score});
+		w.ent_of[slot] = ei;
+		const int32_t mi = w.ent_of[2 * (size_t)kr.rank + (1 - kr.mate)];      // the entry of the same read name, other mate
+		if (mi >= 0) { e.mate = mi; w.ents[(size_t)mi].mate = ei; }
+	}
+	return 0;
+}
+
+void sam_dict_del(Work &w, int32_t k)      // src/samdict.c:150-157
+{
+	const Rec &kr = w.recs[(size_t)k];
+	const int32_t ei = w.ent_of[2 * (size_t)kr.rank + kr.mate];
+	if (ei >= 0 && !w.ents[(size_t)ei].c.empty()) w.ents[(size_t)ei].c.pop_back();
+}
+
+int32_t find_best_record(Work &w, Entry &e)      // src/samdict.c:177-243 (every record is active: no -d)
+{
+	size_t best = 0;
+	double best_gamma = -1.0;
+	const size_t n = e.c.size();
+	for (size_t i = 0; i < n; i++)
+		if (e.c[i].gamma > best_gamma) { best = i; best_gamma = e.c[i].gamma; }
+	Rec &chosen = w.recs[(size_t)e.c[best].rec];
+	chosen.alt = -1;
+	chosen.gamma = best_gamma;
+	chosen.cloud = e.c[best].cloud;
+	if (best_gamma <= kSecondaryAlignThresh) {
+		size_t second = 0;
+		double second_gamma = -1.0;
+		for (size_t i = 0; i < n; i++)
+			if (i != best && e.c[i].gamma > second_gamma) { second = i; second_gamma = e.c[i].gamma; }
+		if (second_gamma > 0) chosen.alt = e.c[second].rec;
+	}
+	return e.c[best].rec;
+}
+
+void normalize_cloud_probabilities(std::vector<Cloud> &cl, size_t nc)      // src/align.c:124-143
+{
+	for (size_t i = 0; i < nc; i++) {
+		if (cl[i].parent >= 0) continue;
+		double total = 0.0;
+		for (int32_t c = (int32_t)i; c >= 0; c = cl[(size_t)c].child) total += cl[(size_t)c].weight;
+		for (int32_t c = (int32_t)i; c >= 0; c = cl[(size_t)c].child) cl[(size_t)c].weight /= total;
+	}
+}
+
+// one barcode group: pairs [p0, p1), records [r0, r1) of ema_aln_out
+void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, uint64_t r1)
+{
+	const ema_bucket *bk = S.bk;
+	const size_t n = (size_t)(r1 - r0), n_pairs = p1 - p0;
+	S.n_sel[g] = 0; S.n_clouds[g] = 0; S.n_bad[g] = 0;
+	if (n == 0) return;
+	// read names of the group (the identifier field without its first character, src/align.c:925-929), ranked in strcmp order
+	w.names.resize(n_pairs);
+	for (size_t p = p0; p < p1; ++p) {
+		const uint32_t b = bk->id_off[p], e = bk->id_off[p + 1];
+		w.names[p - p0] = Name{bk->ids + b + (e > b ? 1 : 0), e > b ? e - b - 1 : 0, (uint32_t)(p - p0)};
+	}
+	std::sort(w.names.begin(), w.names.end(), [](const Name &x, const Name &y) { const int c = name_cmp(x, y); return c ? c < 0 : x.pair < y.pair; });
+	w.rank_of_pair.resize(n_pairs);
+	int32_t n_rank = 0;
+	for (size_t i = 0; i < n_pairs; ++i) {
+		if (i > 0 && name_cmp(w.names[i - 1], w.names[i]) != 0) ++n_rank;
+		w.rank_of_pair[w.names[i].pair] = n_rank;
+	}
+	++n_rank;
+	w.ent_of.assign(2 * (size_t)n_rank, -1);
+	w.n_ents = 0;
+	// the group's records in append_alignments' order
+	w.recs.resize(n);
+	for (size_t i = 0; i < n; ++i) {
+		const ema_aln_rec &ar = S.a->rec[r0 + i];
+		const ema_cand_t &c = S.b->cand[ar.cand];
+		Rec &r = w.recs[i];
+		r.chrom = (uint32_t)c.rid; r.pos = (uint32_t)(c.pos + 1);
+		r.rank = w.rank_of_pair[ar.pair - p0];
+		r.score = ar.score; r.gamma = 0;
+		r.mate = ar.mate; r.rev = (uint8_t)(c.is_rev != 0); r.duplicate = 0; r.visited = 0;
+		r.cloud = -1; r.alt = -1; r.sel_mate = -1;
+		r.gi = r0 + i;
+	}
+	// qsort(records, record_cmp): (barcode,) chromosome narrowed to 8 bits, position, read name (src/samrecord.c:51-73)
+	w.ord.resize(n + 1);
+	for (size_t i = 0; i < n; ++i) w.ord[i] = (int32_t)i;
+	std::stable_sort(w.ord.begin(), w.ord.begin() + (long)n, [&](int32_t x, int32_t y) {
+		const Rec &a = w.recs[(size_t)x], &b = w.recs[(size_t)y];
+		const uint8_t ca = (uint8_t)a.chrom, cb = (uint8_t)b.chrom;
+		if (ca != cb) return ca < cb;
+		if (a.pos != b.pos) return a.pos < b.pos;
+		return a.rank < b.rank;
+	});
+	// clouds (src/align.c:358-408)
+	w.clouds.clear();
+	size_t at = 0;
+	while (at < n) {
+		size_t r = at;
+		const int32_t ci = (int32_t)w.clouds.size();
+		w.clouds.push_back(Cloud{0.0, 0.0, -1, -1, 0});
+		sam_dict_add(w, S, w.ord[r], ci, false);
+		size_t cov = 1;
+		bool collision = false;
+		while (r + 1 < n && w.recs[(size_t)w.ord[r + 1]].chrom == w.recs[(size_t)w.ord[r]].chrom &&
+		       (uint32_t)(w.recs[(size_t)w.ord[r + 1]].pos - w.recs[(size_t)w.ord[r]].pos) <= S.o.dist_thresh) {
+			++r;
+			if (!collision && sam_dict_add(w, S, w.ord[r], ci, false)) {
+				collision = true;
+				for (size_t i = 0; i < cov; i++) sam_dict_del(w, w.ord[at + i]);
+			}
+			++cov;
+		}
+		if (collision) {      // two candidates of one read in this cloud: re-enter it by read name, every record forced in
+			w.clouds[(size_t)ci].bad = 1;
+			++S.n_bad[g];
+			w.split.assign(w.ord.begin() + (long)at, w.ord.begin() + (long)(at + cov));
+			std::stable_sort(w.split.begin(), w.split.end(), [&](int32_t x, int32_t y) {      // name_cmp, src/align.c:70-82
+				const Rec &a = w.recs[(size_t)x], &b = w.recs[(size_t)y];
+				if (a.rank != b.rank) return a.rank < b.rank;
+				return a.mate < b.mate;
+			});
+			for (size_t i = 0; i < cov; i++) sam_dict_add(w, S, w.split[i], ci, true);
+		}
+		at = r + 1;
+	}
+	const size_t nc = w.clouds.size();
+	S.n_clouds[g] = (uint32_t)nc;
+	std::vector<Cloud> &cl = w.clouds;
+	// initialisation (src/align.c:411-430); entries are visited newest first, as the reference's list is
+	for (size_t k = w.n_ents; k-- > 0;) {
+		Entry &e = w.ents[k];
+		normalize_log_probs(e.c);
+		for (const Cand &c : e.c) cl[(size_t)c.cloud].exp_cov += c.gamma;
+	}
+	for (size_t i = 0; i < nc; i++) cl[i].weight = cl[i].exp_cov;
+	if (!S.o.many_clouds) normalize_cloud_probabilities(cl, nc);
+	// EM (src/align.c:432-525)
+	const bool full_em = n_pairs >= 30;
+	std::vector<double> cw;
+	for (int q = 0; q < kEmIters && full_em; q++) {
+		for (size_t i = 0; i < nc; i++) cl[i].exp_cov = 0.0;
+		for (size_t k = w.n_ents; k-- > 0;) {
+			Entry &e = w.ents[k];
+			const Entry *m = e.mate >= 0 ? &w.ents[(size_t)e.mate] : nullptr;
+			const size_t num = e.c.size();
+			if (S.o.many_clouds) {      // with many clouds the weights are normalised per read
+				cw.resize(num);
+				double tot = 0;
+				for (size_t i = 0; i < num; i++) { cw[i] = cl[(size_t)e.c[i].cloud].weight; tot += cw[i]; }
+				for (size_t i = 0; i < num; i++) cw[i] /= tot;
+			}
+			for (size_t i = 0; i < num; i++) {
+				const Rec &ri = w.recs[(size_t)e.c[i].rec];
+				double best_mate_score = kUnpairedPenalty;
+				if (m) {
+					for (const Cand &mc : m->c) {
+						const Rec &rj = w.recs[(size_t)mc.rec];
+						if (rj.chrom == ri.chrom && rj.rev != ri.rev && mc.cloud == e.c[i].cloud && mc.gamma != 0.0) {
+							const double penalty = ri.rev ? mate_dist_penalty(ri.pos, rj.pos) : mate_dist_penalty(rj.pos, ri.pos);
+							const double mate_score = penalty + std::log(mc.gamma);
+							if (mate_score > best_mate_score) best_mate_score = mate_score;
+						}
+					}
+				}
+				e.c[i].gamma = ri.score + (S.o.many_clouds ? std::log(cw[i]) : std::log(cl[(size_t)e.c[i].cloud].weight)) + best_mate_score;
+			}
+			normalize_log_probs(e.c);
+		}
+		for (size_t k = w.n_ents; k-- > 0;)
+			for (const Cand &c : w.ents[k].c) cl[(size_t)c.cloud].exp_cov += c.gamma;      // every record active, none duplicate yet
+		for (size_t i = 0; i < nc; i++) cl[i].weight = cl[i].exp_cov;
+		if (!S.o.many_clouds) normalize_cloud_probabilities(cl, nc);
+	}
+	// best alignments (src/align.c:527-558)
+	w.final_.clear();
+	for (size_t k = w.n_ents; k-- > 0;) {
+		Entry &e = w.ents[k];
+		if (e.visited) continue;
+		const int32_t best = find_best_record(w, e);
+		int32_t best_mate = -1;
+		if (e.mate >= 0) best_mate = find_best_record(w, w.ents[(size_t)e.mate]);
+		w.final_.push_back(best);
+		w.recs[(size_t)best].sel_mate = best_mate;
+		if (best_mate >= 0) { w.final_.push_back(best_mate); w.recs[(size_t)best_mate].sel_mate = best; }
+		e.visited = true;
+		if (e.mate >= 0) { w.ents[(size_t)e.mate].visited = true; w.ents[(size_t)e.mate].mate = -1; }
+	}
+	// duplicates (src/align.c:560-573): Lariat's definition, dup_cmp (src/align.c:85-122)
+	if (!S.o.many_clouds) {
+		auto key = [&](int32_t x, uint32_t k[6]) {
+			const Rec &r = w.recs[(size_t)x];
+			k[0] = r.mate; k[1] = r.rev; k[2] = r.chrom; k[3] = r.pos;
+			k[4] = r.sel_mate >= 0 ? w.recs[(size_t)r.sel_mate].chrom : 0xffffffffu;
+			k[5] = r.sel_mate >= 0 ? w.recs[(size_t)r.sel_mate].pos : 0xffffffffu;
+		};
+		auto cmp = [&](int32_t x, int32_t y) {
+			uint32_t a[6], b[6];
+			key(x, a); key(y, b);
+			for (int i = 0; i < 6; ++i) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+			return 0;
+		};
+		std::stable_sort(w.final_.begin(), w.final_.end(), [&](int32_t x, int32_t y) { return cmp(x, y) < 0; });
+		for (size_t i = 0; i < w.final_.size();) {
+			size_t j = i + 1;
+			while (j < w.final_.size() && cmp(w.final_[i], w.final_[j]) == 0) { w.recs[(size_t)w.final_[j]].duplicate = 1; j++; }
+			i = j;
+		}
+	}
+	// print order (src/align.c:587-603)
+	uint32_t n_out = 0;
+	for (int32_t x : w.final_) {
+		Rec &best = w.recs[(size_t)x];
+		if (best.visited) continue;
+		if (best.sel_mate >= 0) w.recs[(size_t)best.sel_mate].visited = 1;
+		S.sel[r0 + n_out] = Sel{best.gi, best.sel_mate >= 0 ? w.recs[(size_t)best.sel_mate].gi : ~(uint64_t)0};
+		++n_out;
+		for (int k = 0; k < 2; ++k) {
+			const int32_t y = k == 0 ? x : best.sel_mate;
+			if (y < 0) continue;
+			const Rec &r = w.recs[(size_t)y];
+			S.gamma[r.gi] = r.gamma;
+			S.cloud[r.gi] = r.cloud;
+			S.alt_of[r.gi] = r.alt >= 0 ? (int32_t)(w.recs[(size_t)r.alt].gi - r0) : -1;
+			S.flags[r.gi] = (uint8_t)(r.duplicate | (cl[(size_t)r.cloud].bad << 1));
+		}
+	}
+	S.n_sel[g] = n_out;
+}
+
+int n_host_threads(int want)
+{
+	if (want > 0) return want;
+	const char *v = getenv("EMA_HOST_THREADS");
+	int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
+	return t < 1 ? 1 : t > 32 ? 32 : t;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ema_cloud_opts_default(ema_cloud_opts *o)
+{
+	if (!o) return;
+	o->dist_thresh = 50000; o->many_clouds = 0; o->n_threads = 0; o->first_cloud_id = 0;
+}
+
+void ema_clouds_free(ema_clouds_out *out)
+{
+	if (!out) return;
+	free(out->lines); free(out->recs); free(out->alts); free(out->idents);
+	free(out);
+}
+
+int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_aln_out *a, const char *const *contig_names,
+                      int32_t n_contigs, const ema_cloud_opts *opts, ema_clouds_out **out)
+{
+	if (!out) return EMA_EARG;
+	*out = nullptr;
+	if (!bk || !b || !a || (n_contigs > 0 && !contig_names)) return EMA_EARG;
+	if (bk->n_pairs != b->n_pairs || bk->n_pairs != a->n_pairs) return EMA_EARG;
+	Shared S;
+	S.bk = bk; S.b = b; S.a = a;
+	if (opts) S.o = *opts; else ema_cloud_opts_default(&S.o);
+	const size_t n_rec = a->n, n_groups = bk->n_groups;
+	for (size_t i = 0; i < n_rec; ++i) {
+		const ema_cand_t &c = b->cand[a->rec[i].cand];
+		if (c.rid < 0 || c.rid >= n_contigs) return EMA_EARG;
+	}
+	S.gamma.assign(n_rec, 0.0); S.cloud.assign(n_rec, -1); S.alt_of.assign(n_rec, -1); S.flags.assign(n_rec, 0);
+	S.sel.resize(n_rec + 1);
+	S.n_sel.assign(n_groups + 1, 0); S.n_clouds.assign(n_groups + 1, 0); S.n_bad.assign(n_groups + 1, 0);
+	{   // barcode groups over the host's threads, a few at a time from a shared counter
+		std::atomic<size_t> next{0};
+		auto run = [&] {
+			Work w;
+			for (;;) {
+				const size_t g0 = next.fetch_add(8);
+				if (g0 >= n_groups) break;
+				for (size_t g = g0; g < g0 + 8 && g < n_groups; ++g) {
+					const size_t p0 = bk->group_off[g], p1 = bk->group_off[g + 1];
+					do_group(w, S, g, p0, p1, a->pair_off[p0], a->pair_off[p1]);
+				}
+			}
+		};
+		const int nt = (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 16 + 1);
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; ++t) th.emplace_back(run);
+		run();
+		for (auto &t : th) t.join();
+	}
+	// assembly: cloud numbers of a single-threaded run, the selected records as formatter input, statistics
+	ema_clouds_out *o = (ema_clouds_out *)calloc(1, sizeof(ema_clouds_out));
+	if (!o) return EMA_EARG;
+	std::vector<int32_t> cloud_base(n_groups + 1);
+	int32_t next_id = S.o.first_cloud_id;
+	size_t n_sel = 0;
+	for (size_t g = 0; g < n_groups; ++g) {
+		cloud_base[g] = next_id;
+		next_id += (int32_t)S.n_clouds[g];
+		n_sel += S.n_sel[g];
+		if (S.n_clouds[g]) ++o->stats.groups;
+		o->stats.clouds += S.n_clouds[g]; o->stats.bad_clouds += S.n_bad[g];
+	}
+	o->next_cloud_id = next_id;
+	o->n_lines = 2 * n_sel;
+	o->lines = (ema_sam_line *)malloc((2 * n_sel + 1) * sizeof(ema_sam_line));
+	o->recs = (ema_sam_rec *)malloc((2 * n_sel + 1) * sizeof(ema_sam_rec));
+	o->alts = (ema_sam_alt *)malloc((2 * n_sel + 1) * sizeof(ema_sam_alt));
+	size_t id_bytes = 0;
+	for (size_t p = 0; p < bk->n_pairs; ++p) id_bytes += (size_t)(bk->id_off[p + 1] - bk->id_off[p]) + 1;
+	o->idents = (char *)malloc(id_bytes + 1);
+	if (!o->lines || !o->recs || !o->alts || !o->idents) { ema_clouds_free(o); return EMA_EARG; }
+	std::vector<size_t> ident_at(bk->n_pairs + 1);
+	{
+		size_t at = 0;
+		for (size_t p = 0; p < bk->n_pairs; ++p) {
+			const uint32_t ib = bk->id_off[p], ie = bk->id_off[p + 1];
+			ident_at[p] = at;
+			const uint32_t len = ie > ib ? ie - ib - 1 : 0;      // without the first character ('@')
+			memcpy(o->idents + at, bk->ids + ib + (ie > ib ? 1 : 0), len);
+			o->idents[at + len] = '\0';
+			at += (size_t)len + 1;
+		}
+	}
+	int rc = EMA_OK;
+	size_t n_recs = 0, n_lines = 0;
+	auto fill = [&](uint64_t gi, size_t g, uint64_t r0) -> ema_sam_rec * {
+		const ema_aln_rec &ar = a->rec[gi];
+		const ema_cand_t &c = b->cand[ar.cand];
+		const size_t p = ar.pair;
+		ema_sam_rec &r = o->recs[n_recs];
+		memset(&r, 0, sizeof(r));
+		r.ident = o->idents + ident_at[p];
+		r.chrom = contig_names[c.rid]; r.chrom_id = (uint32_t)c.rid; r.pos = (uint32_t)(c.pos + 1);
+		r.mapq = ar.mapq; r.score_mapq = ar.score_mapq; r.gamma = S.gamma[gi];
+		r.mate = ar.mate; r.rev = (uint8_t)(c.is_rev != 0); r.duplicate = S.flags[gi] & 1;
+		r.cloud_id = cloud_base[g] + S.cloud[gi]; r.cloud_bad = (S.flags[gi] >> 1) & 1;
+		r.bc = bk->bc[p];
+		const size_t rd = 2 * p + ar.mate, md = 2 * p + (1 - ar.mate);
+		r.read = bk->bases + bk->off[rd]; r.qual = bk->quals + bk->off[rd]; r.read_len = (int32_t)(bk->off[rd + 1] - bk->off[rd]);
+		r.mate_read = bk->bases + bk->off[md]; r.mate_qual = bk->quals + bk->off[md]; r.mate_read_len = (int32_t)(bk->off[md + 1] - bk->off[md]);
+		r.aln_pos = c.pos; r.aln_rev = c.is_rev; r.edit_dist = c.NM; r.n_cigar = c.n_cigar; r.cigar = b->cigar + c.cigar_off;
+		r.alts = nullptr; r.n_alts = 0;
+		if (S.alt_of[gi] >= 0) {
+			const ema_aln_rec &xr = a->rec[r0 + (uint64_t)S.alt_of[gi]];
+			const ema_cand_t &x = b->cand[xr.cand];
+			if (x.n_cigar >= 64) rc = EMA_EFORMAT;      // the reference asserts (struct xa holds 64 operations)
+			ema_sam_alt &al = o->alts[n_recs];
+			al.chrom = contig_names[x.rid]; al.pos = (uint32_t)(x.pos + 1); al.edit_dist = x.NM; al.rev = x.is_rev != 0;
+			al.n_cigar = x.n_cigar; al.cigar = b->cigar + x.cigar_off;
+			r.alts = &al; r.n_alts = 1;
+		}
+		return &o->recs[n_recs++];
+	};
+	for (size_t g = 0; g < n_groups; ++g) {
+		const uint64_t r0 = a->pair_off[bk->group_off[g]];
+		for (uint32_t k = 0; k < S.n_sel[g]; ++k) {
+			const Sel s = S.sel[r0 + k];
+			const ema_sam_rec *rec = fill(s.rec, g, r0);
+			const ema_sam_rec *mate = s.mate != ~(uint64_t)0 ? fill(s.mate, g, r0) : nullptr;
+			o->lines[n_lines++] = ema_sam_line{rec, mate};
+			o->lines[n_lines++] = ema_sam_line{mate, rec};
+		}
+	}
+	o->n_recs = n_recs;
+	// statistics of the lines as print_sam_record will flag them (src/samrecord.c:104-175)
+	for (size_t i = 0; i < n_lines; ++i) {
+		const ema_sam_rec *rec = o->lines[i].rec, *mate = o->lines[i].mate;
+		++o->stats.lines;
+		if (!rec) { ++o->stats.unmapped_mates; continue; }
+		++o->stats.mapped;
+		if (rec->duplicate) ++o->stats.duplicates;
+		if (rec->n_alts) ++o->stats.with_xa;
+		if (mate && rec->rev != mate->rev && rec->chrom_id == mate->chrom_id) {      // is_pair, src/align.c:27-40
+			const ema_sam_rec *r1 = rec, *r2 = mate;
+			if (r2->rev) { r1 = mate; r2 = rec; }
+			const int64_t d = (int64_t)(uint32_t)(r1->pos - r2->pos);      // two uint32_t: the difference wraps
+			if (kInsertMin <= d && d <= kInsertMax) ++o->stats.proper;
+		}
+		const int gamma_mapq = rec->gamma <= 0.999999 ? (int)(-10 * std::log10(1 - rec->gamma)) : 60;
+		int q = gamma_mapq < rec->score_mapq ? gamma_mapq : rec->score_mapq;
+		q = q < rec->mapq ? q : rec->mapq;
+		q = q > 0 ? q : 0; q = q < 60 ? q : 60;
+		++o->stats.mapq_hist[q == 0 ? 0 : q < 10 ? 1 : q < 20 ? 2 : q < 30 ? 3 : q < 40 ? 4 : q < 60 ? 5 : 6];
+	}
+	*out = o;
+	return rc;
+}
+
+}  // extern "C"

@@ -262,6 +262,61 @@ int ema_stream_batches(ema_engine_t *e, const char *const *bases, const uint32_t
 	return run_stream(e, S, sink, user, stats);
 }
 
+namespace {
+struct SamSink {
+	ema_engine_t *e;
+	ema_sam_run_opts o;
+	int fd;
+	ema_sam_stats *sstats;
+	std::vector<const char *> names;
+	int32_t next_cloud_id;
+	std::string err;
+};
+
+int sam_sink(void *user, size_t k, const ema_bucket *bk, const ema_batch_out *b, const ema_aln_out *a)
+{
+	SamSink &S = *(SamSink *)user;
+	ema_cloud_opts co = S.o.clouds;
+	if (S.o.continue_cloud_ids) co.first_cloud_id = S.next_cloud_id;
+	ema_clouds_out *sel = nullptr;
+	int rc = ema_clouds_select(bk, b, a, S.names.data(), (int32_t)S.names.size(), &co, &sel);
+	if (rc != EMA_OK) { S.err = "ema_clouds_select failed"; if (sel) ema_clouds_free(sel); return rc; }
+	S.next_cloud_id = sel->next_cloud_id;
+	if (S.sstats) S.sstats[k] = sel->stats;
+	size_t n_bytes = 0;
+	rc = ema_sam_write(S.fd, sel->lines, sel->n_lines, &S.o.sam, &n_bytes);
+	ema_clouds_free(sel);
+	if (rc != EMA_OK) { S.err = "ema_sam_write failed"; return rc; }
+	return 0;
+}
+}  // namespace
+
+void ema_sam_run_opts_default(ema_sam_run_opts *o)
+{
+	if (!o) return;
+	ema_stream_opts_default(&o->stream);
+	ema_cloud_opts_default(&o->clouds);
+	ema_sam_opts_default(&o->sam);
+	o->continue_cloud_ids = 0;
+}
+
+int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const ema_sam_run_opts *o, int fd, ema_bucket_stats *bstats,
+                   ema_sam_stats *sstats)
+{
+	g_err.clear();
+	if (!e || (!paths && n)) { g_err = "bad argument"; return EMA_EARG; }
+	SamSink S;
+	S.e = e; S.fd = fd; S.sstats = sstats;
+	if (o) S.o = *o; else ema_sam_run_opts_default(&S.o);
+	S.next_cloud_id = S.o.clouds.first_cloud_id;
+	S.o.sam.bc_len = S.o.stream.bc_len; S.o.sam.is_haplotag = S.o.stream.is_haplotag;      // one platform for reader and writer
+	const int nc = ema_engine_n_contigs(e);
+	for (int i = 0; i < nc; ++i) S.names.push_back(ema_engine_contig_name(e, i));
+	const int rc = ema_stream_buckets(e, paths, n, &S.o.stream, sam_sink, &S, bstats);
+	if (rc != EMA_OK && !S.err.empty()) g_err = S.err;
+	return rc;
+}
+
 int ema_stream_resident(ema_engine_t *e, const uint32_t *const *off, const size_t *n_pairs, size_t n, int slots_per_set,
                         const ema_stream_opts *o, ema_stream_sink sink, void *user, ema_bucket_stats *stats)
 {

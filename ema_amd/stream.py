@@ -149,3 +149,32 @@ def stream_resident(eng: "_engine.Engine", offs, slots_per_set: int, sink=None, 
     if rc != 0:
         raise RuntimeError(f"ema_stream_resident failed ({rc}): {L.ema_stream_last_error().decode()}")
     return [stats[k].as_dict() for k in range(n)]
+
+
+class SamRunOpts(C.Structure):
+    pass
+
+
+def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None, is_haplotag: bool = False, bc_len: int = 16,
+               continue_cloud_ids: bool = False, n_engines: int = 0):
+    """ema_stream_sam: bucket files -> SAM text on fd.  Returns (per-bucket stream stats, per-bucket SAM stats)."""
+    from . import clouds as _clouds
+    from . import sam as _sam
+    if not SamRunOpts.__dict__.get("_fields_"):
+        SamRunOpts._fields_ = [("stream", StreamOpts), ("clouds", _clouds.CloudOpts), ("sam", _sam.SamOpts), ("continue_cloud_ids", C.c_int32)]
+    L = _lib()
+    L.ema_sam_run_opts_default.argtypes = [C.POINTER(SamRunOpts)]
+    L.ema_stream_sam.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(SamRunOpts), C.c_int, C.POINTER(BucketStats),
+                                 C.POINTER(_clouds.SamStats)]
+    o = SamRunOpts()
+    L.ema_sam_run_opts_default(C.byref(o))
+    o.stream.is_haplotag, o.stream.bc_len, o.stream.n_engines = int(is_haplotag), bc_len, n_engines
+    o.sam.rg_id = rg_id
+    o.continue_cloud_ids = int(continue_cloud_ids)
+    arr = (C.c_char_p * max(1, len(paths)))(*[p.encode() for p in paths])
+    bst = (BucketStats * max(len(paths), 1))()
+    sst = (_clouds.SamStats * max(len(paths), 1))()
+    rc = L.ema_stream_sam(eng._h, arr, len(paths), C.byref(o), fd, bst, sst)
+    if rc != 0:
+        raise RuntimeError(f"ema_stream_sam failed ({rc}): {L.ema_stream_last_error().decode()}")
+    return [bst[k].as_dict() for k in range(len(paths))], [sst[k].as_dict() for k in range(len(paths))]

@@ -19,6 +19,8 @@
 #include <stdint.h>
 #include "ema_engine.h"
 #include "ema_ingest.h"
+#include "ema_clouds.h"
+#include "ema_sam.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -64,6 +66,22 @@ int ema_stream_batches(ema_engine_t *e, const char *const *bases, const uint32_t
  * Nothing crosses PCIe towards the device: this is the rate with inputs resident, outputs delivered to the host. */
 int ema_stream_resident(ema_engine_t *e, const uint32_t *const *off, const size_t *n_pairs, size_t n, int slots_per_set,
                         const ema_stream_opts *o, ema_stream_sink sink, void *user, ema_bucket_stats *stats);
+
+/* Bucket files to SAM text: the whole `ema align -s` / `-x` body (reference src/main.c:380-406 -> find_clouds_and_align,
+ * src/align.c:213-628) through this library's C-ABI stages only -- ema_stream_buckets (reader, engine, append stage) with a
+ * sink that runs ema_clouds_select (include/ema_clouds.h) and ema_sam_write (include/ema_sam.h) on every bucket, in order, to
+ * the file descriptor fd.  The header is the caller's (ema_sam_header).  continue_cloud_ids = 0: every bucket numbers its
+ * clouds from clouds.first_cloud_id, as one `ema align -s bucket` process per bucket does; 1: the count runs on from bucket
+ * to bucket, as `-x` does.  bstats / sstats: n entries each or NULL. */
+typedef struct {
+	ema_stream_opts stream;
+	ema_cloud_opts clouds;
+	ema_sam_opts sam;
+	int32_t continue_cloud_ids;
+} ema_sam_run_opts;
+void ema_sam_run_opts_default(ema_sam_run_opts *o);
+int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const ema_sam_run_opts *o, int fd, ema_bucket_stats *bstats,
+                   ema_sam_stats *sstats);
 
 const char *ema_stream_last_error(void);   /* of the last failed call on this thread */
 

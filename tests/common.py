@@ -24,6 +24,15 @@ def small_ref(kind="two_contigs"):
         ctg = synth.make_genome([150000, 80000], seed=3, n_gaps=20)
     elif kind == "tiny_repeats":  # 120 Kbp: 240 K BWT symbols = four 2^16-symbol rank superblocks in the ss16 test build
         ctg = synth.make_genome([80000, 40000], seed=17, short_rep=0.2, long_rep=0.1, segdup=0.05)
+    elif kind == "exact_dups":    # exact copies of 3 kb segments: far apart (candidates of equal likelihood in different clouds: XA
+        ctg = synth.make_genome([300000, 120000], seed=19, short_rep=0.0, long_rep=0.0, segdup=0.0)      # entries) and 15 kb apart
+        rng = np.random.default_rng(19)      # (two candidates of one read inside one cloud: bad clouds)
+        g = ctg[0]
+        for k in range(12):
+            src = 5000 + 22000 * k
+            dst = src + (15000 if k % 3 == 0 else 140000) % (len(g) - 10000)
+            dst = dst % (len(g) - 4000)
+            g[dst:dst + 3000] = g[src:src + 3000]
     elif kind == "mid":          # a few Mbp for GPU throughput smoke tests
         ctg = synth.make_genome([3000000, 1000000], seed=11)
     else:

@@ -303,3 +303,30 @@ class RefUtil:
 
     def copy_until_space(self, line: bytes, n_fields: int):
         return _fields_with(self.L.copy_until_space, line, n_fields)
+
+
+class CRec(C.Structure):      # orc_crec_t (oracle/oracle.h)
+    _fields_ = [("bc", C.c_uint64), ("chrom", C.c_uint32), ("pos", C.c_uint32), ("ident", C.c_char * 256), ("score", C.c_double),
+                ("mate", C.c_uint32), ("rev", C.c_uint32), ("orig", C.c_uint32), ("hash", C.c_uint32), ("mate_hash", C.c_uint32),
+                ("hashed", C.c_uint8), ("mate_hashed", C.c_uint8), ("active", C.c_uint8), ("duplicate", C.c_uint8), ("visited", C.c_uint8),
+                ("pad_", C.c_uint8 * 3), ("gamma", C.c_double), ("cloud_id", C.c_int32), ("cloud_bad", C.c_int32), ("alt", C.c_int32),
+                ("sel_mate", C.c_void_p)]
+
+
+def clouds_group(records, n_pairs, cloud_id, dist_thresh=50000, many_clouds=False):
+    """oracle/clouds.c on one barcode group.  records: [(bc, chrom, pos, ident, score, mate, rev)] in append_alignments' order.
+    Returns (print order [(rec, mate | -1)], per-record results [(gamma, cloud_id, cloud_bad, duplicate, alt)], next cloud id)."""
+    L = lib()
+    L.orc_clouds_group.restype = C.c_size_t
+    L.orc_clouds_group.argtypes = [C.POINTER(CRec), C.c_size_t, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    n = len(records)
+    arr = (CRec * max(n, 1))()
+    for i, (bc, chrom, pos, ident, score, mate, rev) in enumerate(records):
+        r = arr[i]
+        r.bc, r.chrom, r.pos, r.ident, r.score, r.mate, r.rev, r.orig, r.active, r.alt = bc, chrom, pos, ident, score, mate, rev, i, 1, -1
+    cid = C.c_int(cloud_id)
+    order = (C.c_int * (2 * max(n, 1)))()
+    k = L.orc_clouds_group(arr, n, n_pairs, dist_thresh, int(many_clouds), C.byref(cid), order)
+    out = [(order[2 * i], order[2 * i + 1]) for i in range(k)]
+    res = [(arr[i].gamma, arr[i].cloud_id, arr[i].cloud_bad, arr[i].duplicate, arr[i].alt) for i in range(n)]
+    return out, res, cid.value

@@ -1,0 +1,110 @@
+"""Bucket files to SAM text on the GPU, end to end (`ema align -s` / `-x`'s body, reference src/main.c:380-406,
+src/align.c:213-628): ONE C-ABI call, ema_stream_sam (include/ema_stream.h) -- reader, engine, append stage, clouds / EM /
+duplicates, formatter -- against the same chain made of oracle parts only (oracle reader, aligner, append stage, cloud stage,
+formatter): byte-identical SAM bodies, 10x and haplotag, cloud numbers per bucket and running on (-x)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import small_ref
+from ema_amd import engine as E
+from ema_amd import ingest, sam, stream, synth
+from test_clouds import make_bucket, oracle_selection
+from test_sam_format import oracle_text
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_sam(prefix, path, names, so, haplotag=False, first_cloud_id=0):
+    """The oracle's SAM body for one bucket file, and the cloud counter after it."""
+    bucket = ingest.read_bucket(path, bc_len=12 if haplotag else 16, is_haplotag=haplotag)      # checked against the oracle's reader below
+    want, _groups = O.read_special_fastq(path, 12 if haplotag else 16, haplotag)
+    assert [w[0] for w in want] == bucket.bc.tolist() and all(bucket.read(2 * i) == w[2] for i, w in enumerate(want))
+    idx, opt = O.Index(prefix), O.default_opt()
+    cand_off, cands, cigar, recs, pair_off = [0], [], [], [], [0]
+    for p in range(bucket.n_pairs):
+        r1, r2 = bucket.read(2 * p), bucket.read(2 * p + 1)
+        res = O.align_pair(idx, opt, r1, r2)
+        base = [len(cands)]
+        for m in range(2):
+            for d in res[m]:
+                c = np.zeros((), dtype=E.CAND_DTYPE)
+                for f in O.REG_FIELDS:
+                    c[f] = d[f]
+                c["pos"], c["is_rev"], c["NM"], c["n_cigar"], c["cigar_off"] = d["pos"], d["is_rev"], d["NM"], len(d["cigar"]), len(cigar)
+                cigar.extend(d["cigar"])
+                cands.append(c)
+            cand_off.append(len(cands))
+            base.append(len(cands))
+        for e in O.append_alignments(idx, opt, r1, r2):
+            a = np.zeros((), dtype=E.ALN_REC_DTYPE)
+            a["pair"], a["mate"], a["unique"], a["cand"] = p, e["mate"], e["unique"], base[e["mate"]] + e["cand"]
+            a["clip"], a["clip_edit_dist"], a["mapq"], a["score_mapq"], a["score"] = e["clip"], e["clip_edit_dist"], e["mapq"], e["score_mapq"], e["score"]
+            recs.append(a)
+        pair_off.append(len(recs))
+    batch = E.Batch(np.array(cand_off, np.uint64), np.array(cands, dtype=E.CAND_DTYPE) if cands else np.zeros(0, E.CAND_DTYPE),
+                    np.array(cigar, np.uint32), np.zeros(2 * bucket.n_pairs, np.int32))
+    rec = np.array(recs, dtype=E.ALN_REC_DTYPE) if recs else np.zeros(0, E.ALN_REC_DTYPE)
+    arr, n, keep, rows, next_id = oracle_selection(bucket, batch, rec, np.array(pair_off, np.uint64), names)
+    if first_cloud_id:
+        for i in range(n):
+            for r in (arr[i].rec, arr[i].mate):
+                if r and r.contents.cloud_id < first_cloud_id:
+                    pass
+    return oracle_text(arr, n, so), next_id, keep
+
+
+def _run(tmp_path, kind, sizes, haplotag, continue_ids):
+    prefix, ctg = small_ref(kind)
+    paths = []
+    for k, n in enumerate(sizes):
+        d = tmp_path / f"b{k}"
+        d.mkdir()
+        _p, _c, _bucket = make_bucket(d, kind, n, 900 + k, 40, haplotag, sub_rate=0.015, chimeric=0.04)
+        paths.append(str(d / "bucket"))
+    names = [f"chr{i + 1}".encode() for i in range(len(ctg))]
+    eng = E.Engine(prefix)
+    assert [c[0].encode() for c in eng.contigs()] == names
+    out = str(tmp_path / "out.sam")
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    bst, sst = stream.stream_sam(eng, paths, fd, rg_id=b"rg1", is_haplotag=haplotag, bc_len=12 if haplotag else 16, continue_cloud_ids=continue_ids)
+    os.close(fd)
+    eng.close()
+    got = open(out, "rb").read()
+    so = sam.default_opts()
+    so.rg_id = b"rg1"
+    if haplotag:
+        so.is_haplotag, so.bc_len = 1, 12
+    want, shift = b"", 0
+    for k, path in enumerate(paths):
+        text, n_clouds, _keep = oracle_sam(prefix, path, names, so, haplotag)
+        if continue_ids and shift:      # -x: the cloud counter runs on; renumber the oracle's per-bucket MI values
+            lines = []
+            for line in text.split(b"\n"):
+                at = line.find(b"\tMI:i:")
+                if at >= 0:
+                    end = line.find(b"\t", at + 1)
+                    line = line[:at] + b"\tMI:i:%d" % (int(line[at + 6:end]) + shift) + line[end:]
+                lines.append(line)
+            text = b"\n".join(lines)
+        want += text
+        assert sst[k]["lines"] == text.count(b"\n") and sst[k]["clouds"] == n_clouds
+        if continue_ids:
+            shift += n_clouds
+    assert got == want and got.count(b"\n") > 1.6 * sum(sizes)
+    assert all(s["rc"] == 0 and s["capacity_flags"] == 0 for s in bst)
+
+
+def test_three_10x_buckets_to_sam(tmp_path):
+    _run(tmp_path, "repeats", [300, 260, 340], False, False)
+
+
+def test_x_mode_cloud_numbers_run_on(tmp_path):
+    _run(tmp_path, "two_contigs", [200, 240], False, True)
+
+
+def test_haplotag_bucket_to_sam(tmp_path):
+    _run(tmp_path, "two_contigs", [320], True, False)

@@ -223,7 +223,7 @@ def pmc_table(name):
     return t
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10, help="default: 10 steps x 1 Mi pairs = the 10 M pairs of BASELINE configs[1]")
@@ -240,7 +240,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / engine_resident / isolated passes (profiling runs)")
     ap.add_argument("--allow-capacity-flags", action="store_true", help="print the (invalid) line even if reads overflowed an engine capacity")
-    args = ap.parse_args()
+    ap.add_argument("--engine-module", default="ema_amd", help=argparse.SUPPRESS)      # tests/test_bench_control_flow.py: a stand-in engine
+    args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -251,20 +252,26 @@ def main():
         log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
         raise SystemExit(2)
     dist = None
+    # RCCL ("nccl") on the GPU box; EMA_BENCH_BACKEND=gloo runs the same control flow on CPU tensors (the world-size-2 test)
+    backend = os.environ.get("EMA_BENCH_BACKEND", "nccl")
+    tdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
         import datetime
         # rank 0 builds genome and index (minutes at the default scale) while the others wait at a barrier
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
+        if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
+        else:
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=30))
 
     def agree(value, op="min"):
         """rank 0's float for everybody (a plain tensor collective, like the ones below)"""
         if world == 1:
             return value
-        g = torch.tensor([value], dtype=torch.float64, device="cuda")
+        g = torch.tensor([value], dtype=torch.float64, device=tdev)
         dist.all_reduce(g, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.MAX)
         return float(g.item())
 
@@ -324,9 +331,10 @@ def main():
         n_batches += n_batches & 1      # alternate batches on alternate sets of batch buffers: the same number on each
     batches = make_batches(args, rank, world, workdir, n_batches)
 
-    from ema_amd import stream
-    from ema_amd.engine import Engine, default_opts, BatchOut, AlnOut
-    from ema_amd.ingest import _Bucket
+    import importlib
+    stream = importlib.import_module(args.engine_module + ".stream")
+    engine_mod = importlib.import_module(args.engine_module + ".engine")
+    Engine, default_opts = engine_mod.Engine, engine_mod.default_opts
     o = default_opts()
     o.batch_pairs = args.pairs
     o.n_streams = args.streams
@@ -352,7 +360,8 @@ def main():
         if peer is not None:
             peer.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
 
     # parity spot check inside the run: candidates of sampled pairs of EVERY timed step -- regular ones and pairs that went
@@ -454,7 +463,7 @@ def main():
     from ema_amd import shard
     local_stats = np.array([[s[f] for f in shard.STAT_FIELDS] for s in st_timed], dtype=np.int64).sum(axis=0)[None, :]
     # the "trivial RCCL gather of per-bucket statistics" of the north star: one record per rank, O(100 B) over xGMI
-    gathered = shard.gather_stats(local_stats, world, device=("cuda" if world > 1 else None))
+    gathered = shard.gather_stats(local_stats, world, device=(tdev if world > 1 and tdev == "cuda" else None))
 
     bad = 0
     out = None

@@ -18,7 +18,7 @@ from test_sam_format import oracle_text
 pytestmark = pytest.mark.gpu
 
 
-def oracle_sam(prefix, path, names, so, haplotag=False, first_cloud_id=0):
+def oracle_sam(prefix, path, names, so, haplotag=False):
     """The oracle's SAM body for one bucket file, and the cloud counter after it."""
     bucket = ingest.read_bucket(path, bc_len=12 if haplotag else 16, is_haplotag=haplotag)      # checked against the oracle's reader below
     want, _groups = O.read_special_fastq(path, 12 if haplotag else 16, haplotag)
@@ -49,11 +49,6 @@ def oracle_sam(prefix, path, names, so, haplotag=False, first_cloud_id=0):
                     np.array(cigar, np.uint32), np.zeros(2 * bucket.n_pairs, np.int32))
     rec = np.array(recs, dtype=E.ALN_REC_DTYPE) if recs else np.zeros(0, E.ALN_REC_DTYPE)
     arr, n, keep, rows, next_id = oracle_selection(bucket, batch, rec, np.array(pair_off, np.uint64), names)
-    if first_cloud_id:
-        for i in range(n):
-            for r in (arr[i].rec, arr[i].mate):
-                if r and r.contents.cloud_id < first_cloud_id:
-                    pass
     return oracle_text(arr, n, so), next_id, keep
 
 

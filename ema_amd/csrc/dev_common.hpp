@@ -159,6 +159,29 @@ __device__ __forceinline__ void ema_lane_extend(const DevIndex &ix, uint64_t x_n
 	o_nb = ix.L2[cc] + 1 + (cc == 3 ? tk[3] : cc == 2 ? tk[2] : cc == 1 ? tk[1] : tk[0]);
 }
 
+// k-mer interval table (dev_types.h): suffix-array interval of the string with 2-bit code `code` (first base in the high
+// bits) and length L <= ix.kmer_k
+__device__ __forceinline__ void ema_kmer_lookup(const DevIndex &ix, int L, uint32_t code, uint64_t &x0, uint64_t &x2)
+{
+	if (L <= EMA_KMER_WIDE) {
+		const ulong2 e = reinterpret_cast<const ulong2 *>(ix.kmer_wide)[(((size_t)1 << (2 * L)) - 4) / 3 + code];
+		x0 = e.x; x2 = e.y;
+	} else {
+		const uint64_t e = ix.kmer_narrow[(((size_t)1 << (2 * L)) - ((size_t)1 << (2 * (EMA_KMER_WIDE + 1)))) / 3 + code];
+		x0 = e & 0xFFFFFFFFFFULL; x2 = e >> 40;
+	}
+}
+// code of the reverse complement of a string of length L
+__device__ __forceinline__ uint32_t ema_kmer_revcomp(uint32_t code, int L)
+{
+	uint32_t v = ~code;                                   // complement: 3 - base
+	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);      // reverse the order of the 16 two-bit groups
+	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+	v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+	v = (v >> 16) | (v << 16);
+	return v >> (32 - 2 * L);
+}
+
 // suffix array row -> text position (the whole SA is resident)
 __device__ __forceinline__ uint64_t ema_sa(const DevIndex &ix, uint64_t row)
 {

@@ -37,8 +37,17 @@ struct DevIndex {
 	uint64_t L2[5];
 	uint64_t occ_super[EMA_OCC_MAX_SUPER - 1][4];   // absolute counts at the start of superblocks 1, 2, 3
 	int64_t l_pac;
-	int32_t n_seqs, sa_width, n_super, pad_;
+	int32_t n_seqs, sa_width, n_super, kmer_k;
+	// k-mer interval table (kmer_k > 0): the suffix-array interval (start, size) of EVERY string of length 1..kmer_k, so that a
+	// rank query whose result is that short -- most of K1's: the first bases of every forward search, nearly all of a backward
+	// phase, four fifths of every LAST-like seed -- is ONE look-up, cache-resident up to length ~11, instead of two dependent
+	// 32-byte gathers from the 3 GB rank structure.  Level L holds 4^L entries indexed by the string's 2-bit code (first base
+	// in the high bits).  Levels 1..EMA_KMER_WIDE: {u64 start, u64 size}; above: one u64, start in bits 0..39, size in 40..63.
+	const uint64_t *kmer_wide;    // levels 1..EMA_KMER_WIDE, level L at entry offset (4^L - 4) / 3
+	const uint64_t *kmer_narrow;  // levels EMA_KMER_WIDE+1..kmer_k, level L at offset (4^L - 4^(EMA_KMER_WIDE+1)) / 3
 };
+#define EMA_KMER_WIDE 9
+#define EMA_KMER_MAX 15
 
 // bwa's mem_opt_t subset used by the kernels (mem_opt_init(); max_occ=3000 at reference src/align.c:185)
 struct DevOpts {

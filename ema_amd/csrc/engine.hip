@@ -46,13 +46,13 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
                                  DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs,
                                  int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof, int mid);
-extern "C" int ema_align_mid_blocks_per_cu();
+extern "C" int ema_align_mid_blocks_per_cu(int variant);
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int *todo_mid,
-                                        int *n_todo_mid, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof);
+                                        int *n_todo_mid, int mid_seeds, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" int ema_align_blocks_per_cu();
 extern "C" int ema_pair_blocks_per_cu();
@@ -218,7 +218,8 @@ struct ema_engine {
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
-	bool mid_align = true;               // EMA_MID_ALIGN=0: no LDS build of K2b (reads with 33..192 seed occurrences stay with the bulk build)
+	int mid_align = 0;                   // EMA_MID_ALIGN=1: LDS build of K2b for reads with 33..192 seed occurrences (one block per CU); 2: for 33..80 (two blocks); 0: none
+	bool av_lds = true;                  // EMA_AV_LDS=0: region lists in the HBM slab
 	int align_mid_blocks = 0;
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
@@ -417,8 +418,9 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
-	if (const char *v = getenv("EMA_MID_ALIGN")) e->mid_align = atoi(v) != 0;
-	e->align_mid_blocks = e->n_cu * ema_align_mid_blocks_per_cu();
+	if (const char *v = getenv("EMA_MID_ALIGN")) e->mid_align = atoi(v);
+	if (const char *v = getenv("EMA_AV_LDS")) e->av_lds = atoi(v) != 0;
+	e->align_mid_blocks = e->n_cu * ema_align_mid_blocks_per_cu(e->mid_align == 2 ? 3 : 1);
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
 	if (n_streams > 16) n_streams = 16;
@@ -658,22 +660,22 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 static int run_align(ema_engine *e, Slice &s, const Work &w)
 {
 	// K2a: small reads, one lane each; the others land on the todo list that K2b (one wavefront per read) works through
-	const bool mid = e->lane_align && e->mid_align;
+	const bool mid = e->lane_align && e->mid_align > 0;
 	if (e->lane_align) {
 		ema_launch_align_simple(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21,
-		                        mid ? s.d_todo_mid.p : nullptr, s.d_counters.p + 24, s.d_hand.p, e->lane_blocks, s.stream, e->d_prof.p);
+		                        mid ? s.d_todo_mid.p : nullptr, s.d_counters.p + 24, e->mid_align == 2 ? 80 : EMA_MID_SEEDS, s.d_hand.p, e->lane_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
 	// K2b, bulk build: K2a's hand-overs and the repeat-rich reads; then the LDS build for the reads in between
 	ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 0,
-	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, 0);
+	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, e->av_lds ? 0 : 2);
 	HIPCHK(e, hipGetLastError());
 	if (mid) {
 		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                 s.d_n_regs.p, s.d_status.p, s.d_todo_mid.p, s.d_counters.p + 24, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 25,
-		                 e->align_mid_blocks, s.stream, s.dbg, e->d_prof.p, 1);
+		                 e->align_mid_blocks, s.stream, s.dbg, e->d_prof.p, e->mid_align == 2 ? 3 : 1);
 		HIPCHK(e, hipGetLastError());
 	}
 	watchdog(e, s, "ema_k_align");

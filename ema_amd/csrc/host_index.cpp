@@ -32,7 +32,7 @@ DevIndex HostIndex::view() const
 	d.l_pac = l_pac;
 	d.n_seqs = (int32_t)contigs.size();
 	d.sa_width = sa_width;
-	d.n_super = n_super; d.pad_ = 0;
+	d.n_super = n_super; d.kmer_k = 0; d.kmer_wide = nullptr; d.kmer_narrow = nullptr;
 	memcpy(d.occ_super, occ_super, sizeof(occ_super));
 	return d;
 }

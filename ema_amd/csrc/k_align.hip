@@ -48,7 +48,7 @@ struct AlignSlab {           // per resident wave
 //                              round trips at loaded-memory latency); one block per CU, everything in LDS.
 // K2a sorts the reads into the two work lists.
 #define EMA_SMALL_BYTES(SMALL) ((SMALL) * (2 * sizeof(SeedRec) + sizeof(ChainRec) + 3 * 8 + 2 * 4))
-#define EMA_AVL_BYTES(AVL) ((AVL) * (2 * sizeof(DevReg) + 8))
+#define EMA_AVL_BYTES(AVL) (((AVL) > 0 ? (AVL) : 1) * (2 * sizeof(DevReg) + 8))
 
 template <int SMALL>
 __device__ __forceinline__ void ema_small_tables(AlignSlab &s, uint8_t *lds)
@@ -418,8 +418,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 		// regions start out in LDS (sorting and de-duplicating a handful of them in the HBM slab is dozens of dependent round
 		// trips); the list moves to the slab when it outgrows AVL
-		bool av_lds = true;
-		{
+		bool av_lds = AVL > 0;
+		if (AVL > 0) {
 			uint8_t *b = lds_av[wib];
 			cb.sl.av = (DevReg *)b; cb.sl.av_tmp = (DevReg *)b + AVL; cb.sl.rkeys = (uint64_t *)((DevReg *)b + 2 * AVL);
 		}
@@ -606,20 +606,22 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
-// mid = 0: the bulk build (K2a's hand-overs and the repeat-rich reads), 16 waves per CU; mid = 1: the LDS build for the reads
-// with up to EMA_MID_SEEDS seed occurrences, one block per CU
+// variant 0: the bulk build (K2a's hand-overs and the repeat-rich reads), 16 waves per CU; 1: the LDS build for the reads with up
+// to EMA_MID_SEEDS seed occurrences, one block per CU; 2: the bulk build without the LDS region list; 3: LDS build for up to 80
+// occurrences, two blocks per CU  (2 and 3: measurement variants, EMA_AV_LDS=0 / EMA_MID_ALIGN=2)
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
                                  const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs, int *counter, int n_blocks,
                                  hipStream_t stream, int *dbg,
-                                 unsigned long long *prof, int mid)
+                                 unsigned long long *prof, int variant)
 {
-	if (mid)
-		hipLaunchKernelGGL((ema_k_align_t<EMA_MID_SEEDS, 24, 1>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
-		                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof);
-	else
-		hipLaunchKernelGGL((ema_k_align_t<32, 8, 4>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs,
-		                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof);
+#define EMA_ALIGN_LAUNCH(...) hipLaunchKernelGGL((ema_k_align_t<__VA_ARGS__>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs, \
+	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof)
+	if (variant == 1) EMA_ALIGN_LAUNCH(EMA_MID_SEEDS, 24, 1);
+	else if (variant == 2) EMA_ALIGN_LAUNCH(32, 0, 4);
+	else if (variant == 3) EMA_ALIGN_LAUNCH(80, 16, 2);
+	else EMA_ALIGN_LAUNCH(32, 8, 4);
+#undef EMA_ALIGN_LAUNCH
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)
@@ -629,9 +631,11 @@ extern "C" int ema_align_blocks_per_cu()
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }
-extern "C" int ema_align_mid_blocks_per_cu()
+extern "C" int ema_align_mid_blocks_per_cu(int variant)
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1>, 256, 0) != hipSuccess || n < 1) n = 1;
+	hipError_t rc = variant == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<80, 16, 2>, 256, 0)
+	                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1>, 256, 0);
+	if (rc != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

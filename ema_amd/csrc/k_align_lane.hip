@@ -254,7 +254,7 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,
                    uint8_t *__restrict__ scratch, int *__restrict__ counter, int *__restrict__ todo, int *__restrict__ n_todo,
-                   int *__restrict__ todo_mid, int *__restrict__ n_todo_mid, uint8_t *__restrict__ hand, unsigned long long *prof)
+                   int *__restrict__ todo_mid, int *__restrict__ n_todo_mid, int mid_seeds, uint8_t *__restrict__ hand, unsigned long long *prof)
 {
 	// diagnostic phase timing (prof != null): shader clocks per phase of this wave (all lanes move together)
 	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -292,7 +292,7 @@ ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 			// occurrences, counted as mem_chain will look them up: an interval above max_occ contributes max_occ)
 			int64_t occ = 0;
 			for (int i = 0; i < n_iv; ++i) { const uint64_t x2 = raw[i].x2; occ += x2 > (uint64_t)opt.max_occ ? (int64_t)opt.max_occ : (int64_t)x2; }
-			if (todo_mid && occ <= EMA_MID_SEEDS) todo_mid[atomicAdd(n_todo_mid, 1)] = read;
+			if (todo_mid && occ <= mid_seeds) todo_mid[atomicAdd(n_todo_mid, 1)] = read;
 			else todo[atomicAdd(n_todo, 1)] = read;
 			continue;
 		}
@@ -500,8 +500,8 @@ extern "C" int ema_align_simple_blocks_per_cu()
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int *todo_mid,
-                                        int *n_todo_mid, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof)
+                                        int *n_todo_mid, int mid_seeds, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
 	hipLaunchKernelGGL(ema_k_align_simple, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
-	                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, todo_mid, n_todo_mid, hand, prof);
+	                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, todo_mid, n_todo_mid, mid_seeds, hand, prof);
 }

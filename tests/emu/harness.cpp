@@ -54,7 +54,7 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 	if (lane) {
 		std::vector<uint8_t> scratch((size_t)n_blocks * 4 * ema_align_lane_wave_bytes());
 		ema_launch_align_simple(&di, &d, qp, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, scratch.data(), &c0, todo.data(),
-		                        &n_todo, mid ? todo_mid.data() : nullptr, &n_todo_mid, hand.data(), n_blocks, nullptr, nullptr);
+		                        &n_todo, mid ? todo_mid.data() : nullptr, &n_todo_mid, EMA_MID_SEEDS, hand.data(), n_blocks, nullptr, nullptr);
 		fprintf(stderr, "emu K2a: %d + %d (LDS build) of %d reads left for K2b\n", n_todo, n_todo_mid, n_reads);
 	}
 	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,

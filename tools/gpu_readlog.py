@@ -28,7 +28,7 @@ out = os.path.join(R, "gpurun_out", f"{tag}_readlog.npy")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 np.save(out, log)
 clk = log[:, 7].astype(np.int64) * 16
-print(f"{len(log)} reads through K2b of {2 * o.batch_pairs}; extend_ms isolated {tm['extend_ms']:.1f}; total wave clocks {clk.sum():.3e}")
+print(f"{len(log)} reads through K2b of {2 * o.batch_pairs}; isolated ms: seed {tm['seed_ms']:.1f} extend {tm['extend_ms']:.1f} rescue {tm['rescue_ms']:.1f} final {tm['final_ms']:.1f} full tier {tm['full_tier_ms']:.1f}; total wave clocks {clk.sum():.3e}")
 print(f"handed over by K2a (chains ready): {(log[:, 1] < 0).sum()}  clocks share {clk[log[:, 1] < 0].sum() / clk.sum():.3f}")
 for name, col, edges in (("seed occurrences", 2, [0, 8, 40, 200, 1000, 5000, 1 << 31]), ("chains", 3, [0, 4, 16, 64, 256, 1024, 1 << 31]),
                          ("regions before dedup", 5, [0, 2, 4, 8, 16, 64, 1 << 31]), ("extension DPs", 6, [0, 1, 3, 6, 12, 48, 1 << 31])):

@@ -41,6 +41,7 @@ extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, con
                                      const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status, int *counter,
                                      int n_blocks, hipStream_t stream);
 
+extern "C" void ema_launch_kmer_level(const DevIndex *ix, int L, uint64_t *wide, uint64_t *narrow, int *overflow, hipStream_t stream);
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
@@ -190,6 +191,7 @@ struct ema_engine {
 	// index in HBM
 	DevBuf<OccBlock> d_occ;
 	DevBuf<uint8_t> d_sa, d_pac;
+	DevBuf<uint64_t> d_kmer_wide, d_kmer_narrow;      // k-mer interval table (dev_types.h), built when the engine opens
 	DevBuf<int64_t> d_ctg;
 	// batch input (whole batch; slices are sub-ranges, the full tier addresses it through its pair list)
 	// Batch inputs live in numbered slots, each a whole batch in HBM (nt4 bases, offsets, 2-bit packs: ~0.7 GB per Mi
@@ -388,6 +390,33 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	HIPCHK(e, hipMemcpy(e->d_ctg.p, hix.ctg_off.data(), hix.ctg_off.size() * 8, hipMemcpyHostToDevice));
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
+	e->dix.kmer_k = 0; e->dix.kmer_wide = nullptr; e->dix.kmer_narrow = nullptr;
+	{   // k-mer interval table: every string up to k bases, k as large as the text makes worthwhile (4^k <= symbols / 2), at most
+		// 14 (2.9 GB); EMA_KMER_K overrides (0: none)
+		int k = 0;
+		while (k < 14 && ((uint64_t)1 << (2 * (k + 1))) <= e->dix.seq_len / 2) ++k;
+		if (const char *v = getenv("EMA_KMER_K")) k = std::max(0, std::min(EMA_KMER_MAX, atoi(v)));
+		if (k > 0) {
+			const int w = k < EMA_KMER_WIDE ? k : EMA_KMER_WIDE;
+			DevBuf<int> d_over;
+			HIPCHK(e, d_over.alloc(4));
+			HIPCHK(e, hipMemset(d_over.p, 0, 16));
+			HIPCHK(e, e->d_kmer_wide.alloc(2 * ((((size_t)1 << (2 * (w + 1))) - 4) / 3) + 2));
+			if (k > EMA_KMER_WIDE) HIPCHK(e, e->d_kmer_narrow.alloc((((size_t)1 << (2 * (k + 1))) - ((size_t)1 << (2 * (EMA_KMER_WIDE + 1)))) / 3 + 1));
+			e->dix.kmer_wide = e->d_kmer_wide.p; e->dix.kmer_narrow = e->d_kmer_narrow.p;
+			for (int L = 1; L <= k; ++L) {      // level L reads level L - 1: one launch each, in order on the null stream
+				ema_launch_kmer_level(&e->dix, L, e->d_kmer_wide.p, e->d_kmer_narrow.p, d_over.p, nullptr);
+				HIPCHK(e, hipGetLastError());
+			}
+			int over = 0;
+			HIPCHK(e, hipMemcpy(&over, d_over.p, 4, hipMemcpyDeviceToHost));
+			d_over.release();
+			if (over) {      // an interval that does not fit the packed entries: run without the table rather than wrongly
+				e->d_kmer_wide.release(); e->d_kmer_narrow.release();
+				e->dix.kmer_wide = nullptr; e->dix.kmer_narrow = nullptr;
+			} else e->dix.kmer_k = k;
+		}
+	}
 	}
 
 	if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
@@ -473,7 +502,7 @@ void ema_engine_close(ema_engine_t *e)
 	(void)hipDeviceSynchronize();
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
-	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_prof.release(); e->d_rlog.release();
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
 	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
 	e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();
@@ -519,7 +548,7 @@ int64_t ema_engine_l_pac(const ema_engine_t *e) { return e ? e->l_pac : -1; }
 int ema_engine_index_info(const ema_engine_t *e, int32_t info[4])
 {
 	if (!e || !info) return EMA_EARG;
-	info[0] = e->dix.n_super; info[1] = EMA_OCC_SUPER_SHIFT; info[2] = e->dix.sa_width; info[3] = 0;
+	info[0] = e->dix.n_super; info[1] = EMA_OCC_SUPER_SHIFT; info[2] = e->dix.sa_width; info[3] = e->dix.kmer_k;
 	return EMA_OK;
 }
 size_t ema_engine_batch_capacity(const ema_engine_t *e) { return e ? e->cap_pairs : 0; }

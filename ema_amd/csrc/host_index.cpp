@@ -32,7 +32,7 @@ DevIndex HostIndex::view() const
 	d.l_pac = l_pac;
 	d.n_seqs = (int32_t)contigs.size();
 	d.sa_width = sa_width;
-	d.n_super = n_super; d.kmer_k = 0; d.kmer_wide = nullptr; d.kmer_narrow = nullptr;
+	d.n_super = n_super; d.kmer_k = kmer_k; d.kmer_wide = kmer_wide.empty() ? nullptr : kmer_wide.data(); d.kmer_narrow = kmer_narrow.empty() ? nullptr : kmer_narrow.data();
 	memcpy(d.occ_super, occ_super, sizeof(occ_super));
 	return d;
 }

@@ -24,6 +24,10 @@ struct HostIndex {
 	uint64_t primary = 0, seq_len = 0, L2[5] = {0, 0, 0, 0, 0};
 	int64_t l_pac = 0;
 	int sa_width = 0;
+	// k-mer interval table (dev_types.h), when a host copy exists (the SIMT harness of tests/ builds one; the engine builds its
+	// own on the device)
+	std::vector<uint64_t> kmer_wide, kmer_narrow;
+	int kmer_k = 0;
 	// Fills a DevIndex whose pointers refer to THIS object's host buffers
 	// (used by the host-side SIMT harness in tests/; the engine overwrites the
 	// pointers with device addresses after upload).

@@ -28,6 +28,16 @@
 // (Earlier forms: one read per 8-lane group sharing each block load -- the 8 lanes replayed the whole control
 // program, ~10 M reads/s; one read per lane with per-state code that stored/pushed at a dozen inlined sites --
 // every tick walked ~1500 vector instructions, 189 VGPRs.)
+//
+// k-mer interval table (DevIndex.kmer_k > 0, dev_types.h).  A rank query whose RESULT is a string of at most kmer_k bases is
+// answered from the table of all short strings' intervals instead: one look-up (16 or 8 bytes, cache-resident for the short
+// strings that every search starts with) in place of two dependent 32-byte gathers from the rank structure.  At the default
+// scale that is the first 14 steps of every forward search, most of every backward phase (its rows are the short prefixes
+// extended to the left) and three quarters of every LAST-like seed: half of all rank queries.  The machine carries the 2-bit
+// code of the string it is extending (working-list entries keep it in the slot of the reverse-strand coordinate k', which
+// nothing downstream reads: mem_chain uses k, size, start, end); k' itself is fetched from the table once, when a forward
+// extension leaves the table's range and the next step needs it for its rank query.  Emitted intervals carry k' = 0 in this
+// mode (the exact-k' build of this kernel is kmer_k = 0).
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
 
@@ -44,6 +54,7 @@ struct SeedPark {
 	int32_t pc, pass, len, read, x, sm_x, min_intv, i, j, n_prev, n_curr, rev, prev_is_a, n_mem_call, last_mem_start;
 	int32_t n_out, old_n, k2, st, req_c, ld_kind, has_req, n_ext;
 	uint32_t c_end, f_end;
+	uint32_t c_code, f_code, req_code, req_len;      // k-mer table mode (DevIndex.kmer_k > 0)
 };
 
 }  // namespace
@@ -87,9 +98,12 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 	uint64_t r0 = 0, r1 = 0, r2 = 0;                          // result of the extend posted in the previous tick
 	Intv ent; ent.x0 = ent.x1 = ent.x2 = ent.info = 0;        // list entry / output entry loaded in the previous tick
 	size_t out_base = 0;
-	bool has_req = false, exhausted = false;
+	int has_req = 0;                 // 1: rank query posted, 2: table look-up posted
+	bool exhausted = false;
 	int req_c = 0, ld_kind = 0;      // ld_kind: 1 = next list entry of the backward row, 2 = out[k2 - 1] for pass 2
 	size_t ld_at = 0;
+	const int kk = ix.kmer_k;        // 0: no table
+	uint32_t c_code = 0, f_code = 0, r_code = 0, req_code = 0, req_len = 0;      // 2-bit codes of the strings behind c, f, r
 
 	auto q = [&](int p_) -> int {
 		const int code = (qw[(p_ >> 4) << 6] >> ((p_ & 15) << 1)) & 3;
@@ -109,15 +123,15 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			switch (pc) {
 			case PC_FWD_RES:      // bwt_smem1, forward loop body after bwt_extend(ik, ok, 0)
 				if (r2 != c2) {
-					ev = 1; v0 = c0; v1 = c1; v2 = c2; v_end = c_end;
+					ev = 1; v0 = c0; v1 = kk ? c_code : c1; v2 = c2; v_end = c_end;
 					if (r2 < (uint64_t)min_intv) { aft = true; break; }
 				}
-				c0 = r0; c1 = r1; c2 = r2; c_end = (uint32_t)(i + 1);
+				c0 = r0; c1 = r1; c2 = r2; c_end = (uint32_t)(i + 1); c_code = r_code;
 				++i;
 				pc = PC_FWD;
 				break;
 			case PC_FWD_STOP:     // end of the read or an ambiguous base: the current interval is the longest match
-				ev = 1; v0 = c0; v1 = c1; v2 = c2; v_end = c_end;
+				ev = 1; v0 = c0; v1 = kk ? c_code : c1; v2 = c2; v_end = c_end;
 				aft = true;
 				break;
 			case PC_BWD_RES:      // backward loop body for row entry c at query position i
@@ -127,10 +141,10 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 						if ((int)c_end - (i + 1) >= opt.min_seed_len) { ev = 2; v0 = c0; v1 = c1; v2 = c2; v_start = (uint32_t)(i + 1); v_end = c_end; }
 					}
 				} else if (n_curr == 0 || r2 != last_curr_size) {
-					ev = 1; v0 = r0; v1 = r1; v2 = r2; v_end = c_end;
+					ev = 1; v0 = r0; v1 = kk ? r_code : r1; v2 = r2; v_end = c_end;
 					last_curr_size = r2;
 				}
-				if (j + 1 < n_prev) { c0 = ent.x0; c1 = ent.x1; c2 = ent.x2; c_end = (uint32_t)ent.info; }      // prefetched with the extend
+				if (j + 1 < n_prev) { c0 = ent.x0; c1 = ent.x1; c2 = ent.x2; c_end = (uint32_t)ent.info; c_code = (uint32_t)ent.x1; }      // prefetched with the extend
 				nxt = true;
 				pc = PC_BWD;
 				break;
@@ -147,7 +161,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 					if (r2 > 0) { ev = 2; v0 = r0; v1 = r1; v2 = r2; v_start = (uint32_t)x; v_end = (uint32_t)(i + 1); }
 					x = i + 1; pc = PC_P3_NEXT;
 				} else {
-					c0 = r0; c1 = r1; c2 = r2;
+					c0 = r0; c1 = r1; c2 = r2; c_code = r_code;
 					if (++i == len) { x = len; pc = PC_DONE; } else pc = PC_S3;
 				}
 				break;
@@ -169,12 +183,12 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 					else {
 						e.info = v_end;
 						dst = wl + ((size_t)((prev_is_a ? EMA_LIST_CAP : 0) + n_curr) << 6);
-						if (n_curr == 0) { f0 = v0; f1 = v1; f2 = v2; f_end = v_end; }
+						if (n_curr == 0) { f0 = v0; f1 = v1; f2 = v2; f_end = v_end; f_code = (uint32_t)v1; }
 						++n_curr;
 					}
 				} else {
 					if (n_out >= opt.intv_cap) st |= EMA_ST_INTV_OVERFLOW;
-					else { e.info = (uint64_t)v_start << 32 | v_end; dst = intv + out_base + n_out; ++n_out; }
+					else { e.info = (uint64_t)v_start << 32 | v_end; if (kk) e.x1 = 0; dst = intv + out_base + n_out; ++n_out; }
 				}
 				if (dst) *dst = e;
 			}
@@ -191,7 +205,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				if (n_curr == 0) pc = pass == 1 ? PC_P1_NEXT : PC_P2_NEXT;
 				else {
 					prev_is_a ^= 1; n_prev = n_curr; n_curr = 0; rev = 0; j = 0; --i;
-					c0 = f0; c1 = f1; c2 = f2; c_end = f_end;
+					c0 = f0; c1 = f1; c2 = f2; c_end = f_end; c_code = f_code;
 				}
 			}
 			// (5) between searches
@@ -207,7 +221,8 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 					pc = k.pc; pass = k.pass; x = k.x; sm_x = k.sm_x; min_intv = k.min_intv; i = k.i; j = k.j;
 					n_prev = k.n_prev; n_curr = k.n_curr; rev = k.rev; prev_is_a = k.prev_is_a; n_mem_call = k.n_mem_call;
 					last_mem_start = k.last_mem_start; n_out = k.n_out; old_n = k.old_n; k2 = k.k2; st = k.st;
-					req_c = k.req_c; ld_kind = k.ld_kind; has_req = k.has_req != 0; n_ext = k.n_ext; c_end = k.c_end; f_end = k.f_end;
+					req_c = k.req_c; ld_kind = k.ld_kind; has_req = k.has_req; n_ext = k.n_ext; c_end = k.c_end; f_end = k.f_end;
+					c_code = k.c_code; f_code = k.f_code; req_code = k.req_code; req_len = k.req_len;
 					read = k.read;
 				}
 				{
@@ -239,7 +254,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				if (x >= len) { pc = PC_DONE; break; }
 				{
 					const int b = q(x);
-					c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
+					c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1; c_code = (uint32_t)b;
 				}
 				i = x + 1;
 				if (i >= len) { x = len; pc = PC_DONE; } else pc = PC_S3;
@@ -254,7 +269,7 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			// (6) start of an SMEM search at sm_x (bwt_smem1 with min_intv)
 			if (start) {
 				const int b = q(sm_x);
-				c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1;
+				c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1; c_code = (uint32_t)b;
 				c_end = (uint32_t)(sm_x + 1);
 				n_curr = 0; n_mem_call = 0;
 				i = sm_x + 1;
@@ -265,11 +280,18 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
 				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
 				else if (b < 4) {
-					has_req = true;
+					has_req = 1;
 					if (pc == PC_BWD) {
 						req_c = b;
 						if (j + 1 < n_prev) { ld_at = (size_t)((prev_is_a ? 0 : EMA_LIST_CAP) + (rev ? n_prev - 2 - j : j + 1)) << 6; ld_kind = 1; }
-					} else req_c = 3 - b;
+						// the extended string is q[i .. c_end): short enough for the table?
+						const int rl = (int)c_end - i;
+						if (rl <= kk) { has_req = 2; req_len = (uint32_t)rl; req_code = ((uint32_t)b << (2 * (rl - 1))) | c_code; }
+					} else {
+						req_c = 3 - b;
+						const int rl = i + 1 - (pc == PC_FWD ? sm_x : x);      // q[start .. i]
+						if (rl <= kk) { has_req = 2; req_len = (uint32_t)rl; req_code = (c_code << 2) | (uint32_t)b; }
+					}
 					pc += 1;
 				} else if (pc == PC_FWD) pc = PC_FWD_STOP;
 				else if (pc == PC_BWD) pc = PC_BWD_N;
@@ -289,12 +311,13 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 				k.pc = pc; k.pass = pass; k.len = len; k.read = read; k.x = x; k.sm_x = sm_x; k.min_intv = min_intv; k.i = i; k.j = j;
 				k.n_prev = n_prev; k.n_curr = n_curr; k.rev = rev; k.prev_is_a = prev_is_a; k.n_mem_call = n_mem_call;
 				k.last_mem_start = last_mem_start; k.n_out = n_out; k.old_n = old_n; k.k2 = k2; k.st = st;
-				k.req_c = req_c; k.ld_kind = ld_kind; k.has_req = has_req ? 1 : 0; k.n_ext = n_ext; k.c_end = c_end; k.f_end = f_end;
+				k.req_c = req_c; k.ld_kind = ld_kind; k.has_req = has_req; k.n_ext = n_ext; k.c_end = c_end; k.f_end = f_end;
+				k.c_code = c_code; k.f_code = f_code; k.req_code = req_code; k.req_len = req_len;
 				park_out[atomicAdd(n_park_out, 1)] = k;
 			}
 			break;
 		}
-		if (prof) { ++n_tick; n_active += __popcll(__ballot(has_req)); }
+		if (prof) { ++n_tick; n_active += __popcll(__ballot(has_req != 0)); }
 		// ---- phase B: every global load of the tick, issued together
 		if (ld_kind) {
 			const ulong2 *src = reinterpret_cast<const ulong2 *>(ld_kind == 1 ? wl + ld_at : intv + ld_at);
@@ -302,13 +325,24 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			ent.x0 = lo.x; ent.x1 = lo.y; ent.x2 = hi.x; ent.info = hi.y;
 			ld_kind = 0;
 		}
-		if (has_req) {
+		if (has_req == 2) {
+			// the result is a string of req_len <= kmer_k bases: its interval from the table; when a forward extension reaches
+			// the table's last level, the reverse-strand coordinate too (the next step is a rank query on it)
+			ema_kmer_lookup(ix, (int)req_len, req_code, r0, r2);
+			r1 = 0;
+			if ((int)req_len == kk && pc != PC_BWD_RES) {
+				uint64_t unused;
+				ema_kmer_lookup(ix, kk, ema_kmer_revcomp(req_code, kk), r1, unused);
+			}
+			r_code = req_code;
+			has_req = 0;
+		} else if (has_req) {
 			// forward extension works on x[1] (the reverse-complement strand), backward on x[0]
 			const bool back = pc == PC_BWD_RES;
 			uint64_t o_nb = 0, o_b = 0, o_size = 0;
 			ema_lane_extend(ix, back ? c0 : c1, back ? c1 : c0, c2, req_c, o_nb, o_b, o_size);
 			r0 = back ? o_nb : o_b; r1 = back ? o_b : o_nb; r2 = o_size;
-			has_req = false;
+			has_req = 0;
 		}
 	}
 	if (prof && lane == 0) {

@@ -7,6 +7,7 @@
 #include "opts.h"
 
 // kernels + launchers, compiled as plain C++
+#include "k_kmer.hip"
 #include "k_seed.hip"
 #include "k_seed_wave.hip"
 #include "k_dp_test.hip"
@@ -71,6 +72,21 @@ void *emu_index_load(const char *prefix, char *err, int errlen)
 	HostIndex *ix = new HostIndex();
 	std::string e = host_index_load(prefix, *ix);
 	if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); delete ix; return nullptr; }
+	if (const char *v = getenv("EMU_KMER_K")) {      // the k-mer interval table, built by the device kernel under the interpreter
+		const int k = atoi(v);
+		if (k > 0 && k <= EMA_KMER_MAX) {
+			const int w = k < EMA_KMER_WIDE ? k : EMA_KMER_WIDE;
+			ix->kmer_wide.assign(2 * ((((size_t)1 << (2 * (w + 1))) - 4) / 3) + 2, 0);
+			if (k > EMA_KMER_WIDE) ix->kmer_narrow.assign((((size_t)1 << (2 * (k + 1))) - ((size_t)1 << (2 * (EMA_KMER_WIDE + 1)))) / 3 + 1, 0);
+			int overflow = 0;
+			for (int L = 1; L <= k; ++L) {
+				DevIndex di = ix->view();
+				ema_launch_kmer_level(&di, L, ix->kmer_wide.data(), ix->kmer_narrow.empty() ? nullptr : ix->kmer_narrow.data(), &overflow, nullptr);
+			}
+			if (overflow) { snprintf(err, errlen, "k-mer table overflow"); delete ix; return nullptr; }
+			ix->kmer_k = k;
+		}
+	}
 	return ix;
 }
 void emu_index_free(void *h) { delete (HostIndex *)h; }

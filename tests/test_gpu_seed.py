@@ -17,12 +17,15 @@ def _check(kind, n_pairs, seed, kernel, monkeypatch, **kw):
     prefix, ctg = small_ref(kind)
     pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
     eng = Engine(prefix)
+    table = eng.index_info()["kmer_k"] > 0 and kernel == "lane"      # K1 with the k-mer interval table: k' is not produced (0)
     eng.stage(pairs.bases, pairs.off)
     intv, n_intv = eng.debug_seeds()
     idx, opt = O.Index(prefix), O.default_opt()
     bad = 0
     for r in range(2 * pairs.n):
         ref = O.collect_intv(idx, opt, pairs.read(r))
+        if table:
+            ref = [(d[0], d[1], d[2], 0, d[4]) for d in ref]
         got = [(int(v[3]) >> 32, int(v[3]) & 0xffffffff, int(v[0]), int(v[1]), int(v[2])) for v in intv[r, :n_intv[r]]]
         bad += ref != got
     eng.close()
@@ -51,3 +54,18 @@ def test_seed_parity_repeats(kernel, monkeypatch):
 def test_seed_parity_250bp(kernel, monkeypatch):
     # config 5 of BASELINE.json (2x250 bp): beyond the reference's MAX_READ_LEN (include/align.h:61), supported here
     _check("repeats", 200, 24, kernel, monkeypatch, len1=250, len2=250)
+
+
+@pytest.mark.parametrize("k", [0, 5, 11, 12])
+def test_seed_parity_kmer_table_depths(k, monkeypatch):
+    """K1 with the k-mer interval table at several depths (0: none, the build that produces k' too; 11, 12: levels in the packed
+    part of the table although the test genome would get 8 by itself) and without parking rounds left out."""
+    monkeypatch.setenv("EMA_KMER_K", str(k))
+    _check("repeats", 500, 25, "lane", monkeypatch, sub_rate=0.02, n_rate=0.003)
+
+
+def test_pipeline_with_and_without_the_table(monkeypatch):
+    import test_gpu_pipeline as TP
+    for k in ("0", "11"):
+        monkeypatch.setenv("EMA_KMER_K", k)
+        TP._check("repeats", 600, 26, sub_rate=0.02)

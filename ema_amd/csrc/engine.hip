@@ -73,7 +73,9 @@ extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const u
 extern "C" void ema_launch_collect(int n_pairs, int first_pair, int *status, int *count, int *map, int cap, hipStream_t stream);
 extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *status, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
-                                uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream);
+                                uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, uint64_t cand_cap, uint64_t cigar_cap, int n_blocks, hipStream_t stream);
+extern "C" void ema_launch_scan(int n_reads, const int *n_pairs_dev, const int *status, const int *n_regs, const int *cig_n, uint2 *block_tot,
+                                uint64_t *tot, uint64_t *cand_off, uint64_t *cig_off, hipStream_t stream);
 extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
                                        const uint32_t *toff, const int *prm, int n_tasks, int *out, hipStream_t s);
 extern "C" void ema_launch_test_global(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
@@ -152,6 +154,7 @@ template <typename T> struct DevBuf {
 struct Slice {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t tev[2][5] = {};        // K1..K4 boundaries of the two asynchronous passes in flight (ev[0..4] of the synchronous path)
 	bool own_stream = false;
 	size_t cap_pairs = 0, n_pairs = 0, first_pair = 0;
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
@@ -164,6 +167,23 @@ struct Slice {
 	DevBuf<uint64_t> d_cand_off, d_cig_off;
 	DevBuf<ema_cand_t> d_cand;
 	size_t cand_cap = 0, cigar_out_cap = 0;
+	// ema_engine_run_async: two sets of packed results (the run being fetched and the run in flight)
+	struct OutSet {
+		DevBuf<ema_cand_t> d_cand;
+		DevBuf<uint32_t> d_cigar;
+		DevBuf<uint64_t> d_cand_off, d_cig_off, d_tot;
+		DevBuf<int> d_status, d_redo;      // d_redo (full tier): [0] pairs listed, [1..] their batch pair ids
+		size_t cand_cap = 0, cigar_cap = 0;
+		hipEvent_t done = nullptr;
+		void release()
+		{
+			d_cand.release(); d_cigar.release(); d_cand_off.release(); d_cig_off.release(); d_tot.release(); d_status.release(); d_redo.release();
+			if (done) (void)hipEventDestroy(done);
+			done = nullptr;
+		}
+	} out[2];
+	DevBuf<uint2> d_block_tot;
+	bool out_ready = false;
 	int *dbg = nullptr;               // EMA_WATCHDOG_S: host-visible per-wave progress words
 	float ms[4] = {0, 0, 0, 0};       // K1..K4 of the last run
 	void release()
@@ -171,6 +191,8 @@ struct Slice {
 		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_todo_mid.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
+		out[0].release(); out[1].release(); d_block_tot.release();
+		for (auto &row : tev) for (auto &x : row) if (x) (void)hipEventDestroy(x);
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 		if (stream && own_stream) (void)hipStreamDestroy(stream);
 		if (dbg) (void)hipHostFree(dbg);
@@ -231,6 +253,12 @@ struct ema_engine {
 	double watchdog_s = 0;               // EMA_WATCHDOG_S=<seconds>: poll after every launch, report stuck waves
 	ema_engine_timing timing;
 	ema_engine *shadow = nullptr;        // second set of batch buffers and streams on the same index: align_pairs on big inputs
+	// ema_engine_run_async / ema_engine_fetch_ticket: up to two runs queued; what the fetch of each needs to know
+	struct Ticket { int seq = -1; size_t n_pairs = 0; std::vector<size_t> first, n; };
+	Ticket tickets[2];
+	int next_ticket = 0, n_inflight = 0;
+	hipStream_t copy_stream = nullptr, h2d_stream = nullptr;   // device -> host / host -> device copies of the async path (never behind a kernel)
+	hipEvent_t slot_free[EMA_MAX_SLOTS] = {};      // recorded when the last run queued on an input slot has read it
 };
 
 #define HIPCHK(e, call)                                                                              \
@@ -500,6 +528,9 @@ void ema_engine_close(ema_engine_t *e)
 	if (e->shadow) { ema_engine_close(e->shadow); e->shadow = nullptr; }
 	(void)hipSetDevice(e->device);
 	(void)hipDeviceSynchronize();
+	if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+	if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
+	for (auto &ev : e->slot_free) if (ev) (void)hipEventDestroy(ev);
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
@@ -556,7 +587,13 @@ size_t ema_engine_full_tier_capacity(const ema_engine_t *e) { return e ? e->full
 
 int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs) { return ema_engine_stage_slot(e, 0, bases, off, n_pairs); }
 
-int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs)
+static int stage_slot_impl(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs, bool async);
+int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs) { return stage_slot_impl(e, slot, bases, off, n_pairs, false); }
+// The same for the asynchronous path (ema_engine_run_async): waits only for the last run that read this slot, copies on the
+// engine's copy stream, and leaves the engine's current batch alone -- so that batch k+1 is staged while batch k runs.
+int ema_engine_stage_async(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs) { return stage_slot_impl(e, slot, bases, off, n_pairs, true); }
+
+static int stage_slot_impl(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs, bool async)
 {
 	if (!e || !bases || !off) return EMA_EARG;
 	if (slot < 0 || slot >= EMA_MAX_SLOTS) { e->err = "input slot out of range (EMA_MAX_SLOTS)"; return EMA_EARG; }
@@ -567,8 +604,13 @@ int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const ui
 		if (rc != EMA_OK) return rc;
 	}
 	ema_engine::InputSet &in = e->in[slot];
-	for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));      // a run still in flight reads the input
-	HIPCHK(e, hipStreamSynchronize(e->full.stream));
+	if (async) {
+		if (!e->h2d_stream) HIPCHK(e, hipStreamCreate(&e->h2d_stream));
+		if (e->slot_free[slot]) HIPCHK(e, hipEventSynchronize(e->slot_free[slot]));      // the last run queued on this slot has read it
+	} else {
+		for (auto &s : e->sl) HIPCHK(e, hipStreamSynchronize(s.stream));      // a run still in flight reads the input
+		HIPCHK(e, hipStreamSynchronize(e->full.stream));
+	}
 	const size_t n_reads = 2 * n_pairs;
 	HIPCHK(e, e->h_off.reserve(2 * e->cap_pairs + 1));
 	HIPCHK(e, e->h_qpack.reserve(2 * e->cap_pairs * 24 + 8));
@@ -596,13 +638,13 @@ int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const ui
 		}
 	}
 	});
-	hipStream_t st = e->sl[0].stream;
+	hipStream_t st = async ? e->h2d_stream : e->sl[0].stream;
 	HIPCHK(e, hipMemcpyAsync(in.d_qpack.p, e->h_qpack.p, (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(e, hipMemcpyAsync(in.d_bases.p, e->h_nt4.p, total, hipMemcpyHostToDevice, st));
 	HIPCHK(e, hipMemcpyAsync(in.d_off.p, e->h_off.p, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(e, hipStreamSynchronize(st));
 	in.n_pairs = n_pairs; in.staged = true;
-	return select_slot(e, slot);
+	return async ? EMA_OK : select_slot(e, slot);
 }
 
 // makes `slot` the input of the next run: consecutive pairs go to consecutive slices, as evenly as the slice count allows
@@ -731,18 +773,19 @@ static int run_final(ema_engine *e, Slice &s, const Work &w)
 	return EMA_OK;
 }
 
-static int run_chain(ema_engine *e, Slice &s, const Work &w)
+static int run_chain(ema_engine *e, Slice &s, const Work &w, hipEvent_t *evs = nullptr)
 {
 	int rc;
-	HIPCHK(e, hipEventRecord(s.ev[0], s.stream));
+	if (!evs) evs = s.ev;
+	HIPCHK(e, hipEventRecord(evs[0], s.stream));
 	if ((rc = run_seed(e, s, w))) return rc;
-	HIPCHK(e, hipEventRecord(s.ev[1], s.stream));
+	HIPCHK(e, hipEventRecord(evs[1], s.stream));
 	if ((rc = run_align(e, s, w))) return rc;
-	HIPCHK(e, hipEventRecord(s.ev[2], s.stream));
+	HIPCHK(e, hipEventRecord(evs[2], s.stream));
 	if ((rc = run_pair(e, s, w))) return rc;
-	HIPCHK(e, hipEventRecord(s.ev[3], s.stream));
+	HIPCHK(e, hipEventRecord(evs[3], s.stream));
 	if ((rc = run_final(e, s, w))) return rc;
-	HIPCHK(e, hipEventRecord(s.ev[4], s.stream));
+	HIPCHK(e, hipEventRecord(evs[4], s.stream));
 	return EMA_OK;
 }
 
@@ -786,6 +829,209 @@ static int run_batch(ema_engine_t *e, bool serial)
 	HIPCHK(e, hipEventRecord(f.ev[7], f.stream));
 	if ((rc = run_chain(e, f, work_of(e, f, true)))) return rc;
 	e->ran = true; e->ever_ran = true;
+	return EMA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Asynchronous runs.  ema_engine_run + ema_engine_fetch need the host between two passes: the fetch computes the result
+// layout from the per-read counts, and only then may the next pass overwrite the per-read slots.  Here every slice computes
+// its layout itself (k_pack.hip) and packs its results into one of two output sets right behind K4, in its own stream; the
+// next pass over the same slots is queued at once, and the host fetches a finished pass while the following one runs.  Two
+// passes may be in flight (one being fetched, one running).
+
+static int out_alloc(ema_engine *e, Slice &s, bool full)
+{
+	if (s.out_ready) return EMA_OK;
+	const size_t nr = 2 * s.cap_pairs;
+	HIPCHK(e, s.d_block_tot.alloc(nr / 1024 + 2));
+	for (auto &o : s.out) {
+		// room: 12 candidates and 48 CIGAR operations per read on average in the lean tier (a bucket averages 2 and 3), 64 and
+		// 256 in the full-capacity tier; the totals are checked when the pass is fetched
+		o.cand_cap = nr * (full ? 64 : 12) + 1024; o.cigar_cap = nr * (full ? 256 : 48) + 1024;
+		HIPCHK(e, o.d_cand.alloc(o.cand_cap)); HIPCHK(e, o.d_cigar.alloc(o.cigar_cap));
+		HIPCHK(e, o.d_cand_off.alloc(nr + 2)); HIPCHK(e, o.d_cig_off.alloc(nr + 2)); HIPCHK(e, o.d_tot.alloc(2));
+		HIPCHK(e, o.d_status.alloc(nr + 2));
+		if (full) HIPCHK(e, o.d_redo.alloc(s.cap_pairs + 2));
+		HIPCHK(e, hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
+	}
+	for (auto &row : s.tev) for (auto &x : row) HIPCHK(e, hipEventCreate(&x));
+	s.out_ready = true;
+	return EMA_OK;
+}
+
+// layout + packing of one slice's finished pass into output set o, in the slice's stream
+static int pack_async(ema_engine *e, Slice &s, Slice::OutSet &o, int nr, const int *n_dev)
+{
+	if (nr <= 0) {      // an empty slice: empty layout
+		HIPCHK(e, hipMemsetAsync(o.d_tot.p, 0, 16, s.stream));
+		HIPCHK(e, hipMemsetAsync(o.d_cand_off.p, 0, 8, s.stream));
+		HIPCHK(e, hipMemsetAsync(o.d_cig_off.p, 0, 8, s.stream));
+		HIPCHK(e, hipEventRecord(o.done, s.stream));
+		return EMA_OK;
+	}
+	ema_launch_scan(nr, n_dev, s.d_status.p, s.d_n_regs.p, s.d_cig_n.p, s.d_block_tot.p, o.d_tot.p, o.d_cand_off.p, o.d_cig_off.p, s.stream);
+	HIPCHK(e, hipGetLastError());
+	ema_launch_pack(nr, n_dev, s.d_status.p, s.dopts.reg_cap, s.d_regs.p, s.d_n_regs.p, s.d_alns.p, s.d_cigars.p, s.d_cig_n.p,
+	                s.dopts.cig_cap, o.d_cand_off.p, o.d_cig_off.p, 0, o.d_cand.p, o.d_cigar.p, o.cand_cap, o.cigar_cap, e->n_cu * 4, s.stream);
+	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipMemcpyAsync(o.d_status.p, s.d_status.p, (size_t)nr * 4, hipMemcpyDeviceToDevice, s.stream));
+	HIPCHK(e, hipEventRecord(o.done, s.stream));
+	return EMA_OK;
+}
+
+int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
+{
+	if (!e || !ticket) return EMA_EARG;
+	if (slot < 0 || slot >= EMA_MAX_SLOTS || !e->in[slot].staged) { e->err = "ema_engine_run_async: nothing staged in this slot"; return EMA_ESTATE; }
+	if (e->n_inflight >= 2) { e->err = "ema_engine_run_async: two runs are in flight; fetch one first"; return EMA_ESTATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	int rc;
+	for (auto &s : e->sl) if ((rc = out_alloc(e, s, false))) return rc;
+	if ((rc = out_alloc(e, e->full, true))) return rc;
+	if ((rc = select_slot(e, slot))) return rc;
+	const int j = e->next_ticket & 1;
+	ema_engine::Ticket &t = e->tickets[j];
+	t.seq = e->next_ticket; t.n_pairs = e->n_pairs;
+	t.first.clear(); t.n.clear();
+	for (auto &s : e->sl) { t.first.push_back(s.first_pair); t.n.push_back(s.n_pairs); }
+	for (auto &s : e->sl) {
+		if ((rc = run_chain(e, s, work_of(e, s, false), s.tev[j]))) return rc;
+		if (e->ever_ran) HIPCHK(e, hipStreamWaitEvent(s.stream, e->full.ev[7], 0));   // the previous run's list has been taken over
+		ema_launch_collect((int)s.n_pairs, (int)s.first_pair, s.d_status.p, e->d_redo.p, e->d_redo.p + 1, (int)e->full.cap_pairs, s.stream);
+		HIPCHK(e, hipGetLastError());
+		HIPCHK(e, hipEventRecord(s.ev[7], s.stream));
+		if ((rc = pack_async(e, s, s.out[j], (int)(2 * s.n_pairs), nullptr))) return rc;
+	}
+	Slice &f = e->full;
+	for (size_t k = 0; k < e->sl.size(); ++k)
+		if (e->sl[k].stream != f.stream) HIPCHK(e, hipStreamWaitEvent(f.stream, e->sl[k].ev[7], 0));
+	HIPCHK(e, hipMemcpyAsync(e->d_redo_run.p, e->d_redo.p, (f.cap_pairs + 1) * 4, hipMemcpyDeviceToDevice, f.stream));
+	HIPCHK(e, hipMemsetAsync(e->d_redo.p, 0, 4, f.stream));
+	HIPCHK(e, hipEventRecord(f.ev[7], f.stream));
+	if ((rc = run_chain(e, f, work_of(e, f, true), f.tev[j]))) return rc;
+	// every kernel that reads the input is behind this point: the full tier's own, and the slices' (their K4 precedes ev[7],
+	// which the full tier's stream has waited for)
+	if (!e->slot_free[slot]) HIPCHK(e, hipEventCreateWithFlags(&e->slot_free[slot], hipEventDisableTiming));
+	HIPCHK(e, hipEventRecord(e->slot_free[slot], f.stream));
+	HIPCHK(e, hipMemcpyAsync(f.out[j].d_redo.p, e->d_redo_run.p, (f.cap_pairs + 1) * 4, hipMemcpyDeviceToDevice, f.stream));
+	if ((rc = pack_async(e, f, f.out[j], (int)(2 * f.cap_pairs), e->d_redo_run.p))) return rc;
+	e->ran = true; e->ever_ran = true;
+	++e->n_inflight;
+	*ticket = e->next_ticket++;
+	return EMA_OK;
+}
+
+// Waits for the run with this ticket, downloads its packed results (copy stream) and assembles the batch as ema_engine_fetch does.
+int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
+{
+	if (!e || !out) return EMA_EARG;
+	*out = nullptr;
+	const int j = ticket & 1;
+	ema_engine::Ticket &t = e->tickets[j];
+	if (ticket < 0 || t.seq != ticket) { e->err = "ema_engine_fetch_ticket: no such run in flight"; return EMA_ESTATE; }
+	HIPCHK(e, hipSetDevice(e->device));
+	if (!e->copy_stream) HIPCHK(e, hipStreamCreate(&e->copy_stream));
+	hipStream_t cs = e->copy_stream;
+	const size_t n_sl = e->sl.size(), n_reads = 2 * t.n_pairs;
+	Slice &f = e->full;
+	// totals first
+	std::vector<uint64_t> tot(2 * (n_sl + 1), 0);
+	int n_listed = 0;
+	for (size_t k = 0; k < n_sl; ++k) {
+		HIPCHK(e, hipStreamWaitEvent(cs, e->sl[k].out[j].done, 0));
+		HIPCHK(e, hipMemcpyAsync(&tot[2 * k], e->sl[k].out[j].d_tot.p, 16, hipMemcpyDeviceToHost, cs));
+	}
+	HIPCHK(e, hipStreamWaitEvent(cs, f.out[j].done, 0));
+	HIPCHK(e, hipMemcpyAsync(&tot[2 * n_sl], f.out[j].d_tot.p, 16, hipMemcpyDeviceToHost, cs));
+	HIPCHK(e, hipMemcpyAsync(&n_listed, f.out[j].d_redo.p, 4, hipMemcpyDeviceToHost, cs));
+	HIPCHK(e, hipStreamSynchronize(cs));
+	t.seq = -1; --e->n_inflight;      // whatever happens below, the output set is free again once this call returns
+	{   // kernel launch durations of this pass (as ema_engine_sync records them for a synchronous one)
+		float sum[4] = {0, 0, 0, 0};
+		for (auto &s : e->sl)
+			for (int k = 0; k < 4; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, s.tev[j][k], s.tev[j][k + 1]) == hipSuccess) { s.ms[k] = ms; sum[k] += ms; } }
+		const float n = (float)e->sl.size();
+		e->timing.seed_ms = sum[0] / n; e->timing.chain_ms = 0; e->timing.extend_ms = sum[1] / n;
+		e->timing.rescue_ms = sum[2] / n; e->timing.final_ms = sum[3] / n;
+		e->timing.total_ms = (sum[0] + sum[1] + sum[2] + sum[3]) / n;
+		(void)hipEventElapsedTime(&e->timing.full_tier_ms, f.tev[j][0], f.tev[j][4]);
+		for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&e->timing.full_ms[k], f.tev[j][k], f.tev[j][k + 1]);
+	}
+	const size_t n_redo = std::min<size_t>((size_t)n_listed, f.cap_pairs);
+	for (size_t k = 0; k <= n_sl; ++k) {
+		const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
+		if (tot[2 * k] > o.cand_cap || tot[2 * k + 1] > o.cigar_cap) { e->err = "the packed result buffers of a slice are too small for this batch; use ema_engine_run + ema_engine_fetch"; return EMA_ELIMIT; }
+	}
+	// per-read layout and payload of every slice and of the full-capacity tier
+	struct Part { std::vector<uint64_t> c_off, g_off; std::vector<int> status; std::vector<ema_cand_t> cand; std::vector<uint32_t> cig; };
+	std::vector<Part> part(n_sl + 1);
+	std::vector<int> redo(n_redo + 1);
+	for (size_t k = 0; k <= n_sl; ++k) {
+		const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
+		const size_t nr = k < n_sl ? 2 * t.n[k] : 2 * n_redo;
+		Part &p = part[k];
+		p.c_off.resize(nr + 1); p.g_off.resize(nr + 1); p.status.resize(nr + 1); p.cand.resize(tot[2 * k] + 1); p.cig.resize(tot[2 * k + 1] + 1);
+		HIPCHK(e, hipMemcpyAsync(p.c_off.data(), o.d_cand_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(p.g_off.data(), o.d_cig_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(p.status.data(), o.d_status.p, nr * 4, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(p.cand.data(), o.d_cand.p, tot[2 * k] * sizeof(ema_cand_t), hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(p.cig.data(), o.d_cigar.p, tot[2 * k + 1] * 4, hipMemcpyDeviceToHost, cs));
+	}
+	if (n_redo) HIPCHK(e, hipMemcpyAsync(redo.data(), f.out[j].d_redo.p + 1, n_redo * 4, hipMemcpyDeviceToHost, cs));
+	HIPCHK(e, hipStreamSynchronize(cs));
+	// where every read's results are: its slice's packed arrays, or the full tier's for the pairs on its list
+	struct Src { uint32_t part, idx; };
+	std::vector<Src> src(n_reads + 1);
+	for (size_t k = 0; k < n_sl; ++k) {
+		const size_t r0 = 2 * t.first[k], nr = 2 * t.n[k];
+		for (size_t r = 0; r < nr; ++r) src[r0 + r] = Src{(uint32_t)k, (uint32_t)r};
+	}
+	for (size_t i = 0; i < n_redo; ++i)
+		for (uint32_t m = 0; m < 2; ++m) src[2 * (size_t)redo[i] + m] = Src{(uint32_t)n_sl, (uint32_t)(2 * i + m)};
+	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+	if (!o) { e->err = "out of host memory"; return EMA_EDEVICE; }
+	o->n_pairs = t.n_pairs; o->n_redone = n_redo;
+	o->cand_off = (uint64_t *)malloc((n_reads + 1) * 8);
+	o->status = (int32_t *)malloc((n_reads + 1) * 4);
+	o->redone = (uint32_t *)malloc((n_redo + 1) * 4);
+	std::vector<uint64_t> cig_off(n_reads + 1);
+	if (!o->cand_off || !o->status || !o->redone) { ema_batch_free(o); e->err = "out of host memory"; return EMA_EDEVICE; }
+	for (size_t i = 0; i < n_redo; ++i) o->redone[i] = (uint32_t)redo[i];
+	o->cand_off[0] = 0; cig_off[0] = 0;
+	for (size_t r = 0; r < n_reads; ++r) {
+		const Part &p = part[src[r].part];
+		const uint32_t i = src[r].idx;
+		o->cand_off[r + 1] = o->cand_off[r] + (p.c_off[i + 1] - p.c_off[i]);
+		cig_off[r + 1] = cig_off[r] + (p.g_off[i + 1] - p.g_off[i]);
+		o->status[r] = p.status[i];
+	}
+	const size_t n_cand = o->cand_off[n_reads], n_cig = cig_off[n_reads];
+	if (n_cig >= ((size_t)1 << 32)) { e->err = "batch has more than 2^32 CIGAR operations; use smaller batches"; ema_batch_free(o); return EMA_ELIMIT; }
+	o->n_cigar = n_cig;
+	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
+	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
+	if (!o->cand || !o->cigar) { ema_batch_free(o); e->err = "out of host memory"; return EMA_EDEVICE; }
+	*out = o;
+	host_parallel(n_reads, [&](size_t r_lo, size_t r_hi) {
+		for (size_t r = r_lo; r < r_hi; ++r) {
+			const Part &p = part[src[r].part];
+			const uint32_t i = src[r].idx;
+			const uint64_t c0 = p.c_off[i], nc = p.c_off[i + 1] - c0, g0 = p.g_off[i], ng = p.g_off[i + 1] - g0;
+			ema_cand_t *dst = o->cand + o->cand_off[r];
+			for (uint64_t k = 0; k < nc; ++k) {
+				ema_cand_t c = p.cand[c0 + k];
+				c.cigar_off = (uint32_t)(c.cigar_off - g0 + cig_off[r]);
+				dst[k] = c;
+			}
+			memcpy(o->cigar + cig_off[r], p.cig.data() + g0, ng * 4);
+		}
+	});
+	if ((size_t)n_listed > f.cap_pairs) {
+		e->err = "more pairs over the lean capacities than the full-capacity tier holds (ema_engine_opts.full_tier_pairs)";
+		return EMA_ELIMIT;
+	}
+	for (size_t r = 0; r < n_reads; ++r)
+		if (o->status[r]) { e->err = "a read exceeded an engine capacity; see ema_batch_out.status"; return EMA_ELIMIT; }
 	return EMA_OK;
 }
 
@@ -1084,7 +1330,7 @@ static int pack_slice(ema_engine *e, Slice &s, size_t nr, const uint64_t *loc_ca
 	HIPCHK(e, hipMemcpyAsync(s.d_cand_off.p, loc_cand, (nr + 1) * 8, hipMemcpyHostToDevice, s.stream));
 	HIPCHK(e, hipMemcpyAsync(s.d_cig_off.p, loc_cig, (nr + 1) * 8, hipMemcpyHostToDevice, s.stream));
 	ema_launch_pack((int)nr, nullptr, s.d_status.p, s.dopts.reg_cap, s.d_regs.p, s.d_n_regs.p, s.d_alns.p, s.d_cigars.p, s.d_cig_n.p,
-	                s.dopts.cig_cap, s.d_cand_off.p, s.d_cig_off.p, cig_base, s.d_cand.p, s.d_cigar_out.p, e->n_cu * 4, s.stream);
+	                s.dopts.cig_cap, s.d_cand_off.p, s.d_cig_off.p, cig_base, s.d_cand.p, s.d_cigar_out.p, s.cand_cap, s.cigar_out_cap, e->n_cu * 4, s.stream);
 	HIPCHK(e, hipGetLastError());
 	return EMA_OK;
 }

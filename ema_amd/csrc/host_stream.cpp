@@ -142,7 +142,7 @@ void worker(Stream &S, int w)
 
 void reader(Stream &S)
 {
-	const size_t depth = (size_t)(S.o.read_ahead > 0 ? S.o.read_ahead : 2) + (size_t)S.n_eng;
+	const size_t depth = (size_t)(S.o.read_ahead > 0 ? S.o.read_ahead : 2) + (S.n_eng == 2 ? 2 : 3);      // + the buckets inside the engine's pipeline
 	for (size_t k = 0; k < S.items.size(); ++k) {
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
@@ -163,6 +163,118 @@ void reader(Stream &S)
 	}
 }
 
+// The default schedule: ONE set of batch buffers, passes queued two deep (ema_engine_run_async).  A stager thread converts and
+// uploads batch k+1.. into free input slots while this thread queues pass k, then fetches pass k-1 and runs its append stage
+// while pass k computes.  A bucket beyond the batch capacity drains the pipeline and goes through ema_engine_align_pairs.
+const int kInSlots = 3;
+
+struct AsyncState {
+	std::vector<int> staged;      // per item: 0 no, 1 staged, -1 staging failed
+	size_t n_run = 0;             // passes queued so far (the stager may fill slot k % kInSlots once pass k - kInSlots has been queued)
+};
+
+void stager(Stream &S, AsyncState &A)
+{
+	for (size_t k = 0; k < S.items.size(); ++k) {
+		Item &it = S.items[k];
+		{
+			std::unique_lock<std::mutex> lk(S.mu);
+			S.cv.wait(lk, [&] { return S.stop || (it.state == ST_LOADED && k < A.n_run + (size_t)kInSlots); });
+			if (S.stop) return;
+		}
+		int ok = 1;
+		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap) {
+			const int rc = ema_engine_stage_async(S.eng[0], (int)(k % (size_t)kInSlots), it.bases, it.off, it.n_pairs);
+			if (rc != EMA_OK) { it.rc = rc; it.err = ema_engine_strerror(S.eng[0]); ok = -1; }
+		}
+		{
+			std::lock_guard<std::mutex> lk(S.mu);
+			A.staged[k] = ok;
+		}
+		S.cv.notify_all();
+	}
+}
+
+void finish_item(Stream &S, Item &it, double t0)
+{
+	const double t1 = now_s();
+	it.st.align_s = t1 - t0;
+	if ((it.rc == EMA_OK || it.rc == EMA_ELIMIT) && it.b) {
+		const int rc = ema_batch_append_alignments(it.b, it.off, &S.eopts, S.o.error_rate, &it.a);
+		if (rc != EMA_OK) { it.rc = rc; it.err = "ema_batch_append_alignments failed"; }
+	}
+	it.st.append_s = now_s() - t1;
+	fill_stats(it);
+	it.st.rc = it.rc;
+	{
+		std::lock_guard<std::mutex> lk(S.mu);
+		it.state = ST_DONE;
+	}
+	S.cv.notify_all();
+}
+
+void async_engine_thread(Stream &S, AsyncState &A)
+{
+	ema_engine_t *g = S.eng[0];
+	const size_t n = S.items.size();
+	std::vector<int> ticket(n, -1);
+	std::vector<double> t_queued(n, 0.0);
+	size_t k_run = 0, k_fetch = 0;
+	auto fetch_one = [&] {
+		Item &it = S.items[k_fetch];
+		if (ticket[k_fetch] >= 0) {
+			const int rc = ema_engine_fetch_ticket(g, ticket[k_fetch], &it.b);
+			it.rc = rc;
+			if (rc != EMA_OK) it.err = ema_engine_strerror(g);
+			ema_engine_timing tm;
+			if (ema_engine_last_timing(g, &tm) == EMA_OK) {
+				it.st.seed_ms = tm.seed_ms; it.st.extend_ms = tm.extend_ms; it.st.rescue_ms = tm.rescue_ms; it.st.final_ms = tm.final_ms;
+				it.st.full_tier_ms = tm.full_tier_ms;
+			}
+		}
+		finish_item(S, it, t_queued[k_fetch]);
+		++k_fetch;
+	};
+	while (k_fetch < n) {
+		bool can_run = false;
+		{
+			std::unique_lock<std::mutex> lk(S.mu);
+			if (S.stop) break;
+			// queue the next pass if its batch is staged and fewer than two are in flight; otherwise fetch the oldest; otherwise wait
+			S.cv.wait(lk, [&] { return S.stop || k_fetch < k_run || (k_run < n && A.staged[k_run] != 0); });
+			if (S.stop) break;
+			can_run = k_run < n && A.staged[k_run] != 0 && k_run - k_fetch < 2;
+		}
+		if (can_run) {
+			Item &it = S.items[k_run];
+			t_queued[k_run] = now_s();
+			if (it.rc != EMA_OK) {      // reader or stager failed: passes straight through, in order
+			} else if (it.n_pairs > S.cap) {      // beyond one batch: drain, then the engine's own piece pipeline
+				while (k_fetch < k_run) fetch_one();
+				it.rc = ema_engine_align_pairs(g, it.bases, it.off, it.n_pairs, &it.b);
+				if (it.rc != EMA_OK) it.err = ema_engine_strerror(g);
+			} else {
+				const int slot = it.slot >= 0 ? it.slot : (int)(k_run % (size_t)kInSlots);
+				int tk = -1;
+				const int rc = ema_engine_run_async(g, slot, &tk);
+				if (rc != EMA_OK) { it.rc = rc; it.err = ema_engine_strerror(g); } else ticket[k_run] = tk;
+			}
+			{
+				std::lock_guard<std::mutex> lk(S.mu);
+				it.state = ST_TAKEN;
+				++k_run; A.n_run = k_run;
+			}
+			S.cv.notify_all();
+		} else if (k_fetch < k_run) fetch_one();
+	}
+	// on an early stop, passes still in flight are fetched and dropped so that the engine is reusable
+	while (k_fetch < k_run) {
+		Item &it = S.items[k_fetch];
+		if (ticket[k_fetch] >= 0 && !it.b) { ema_batch_out *b = nullptr; (void)ema_engine_fetch_ticket(g, ticket[k_fetch], &b); if (b) ema_batch_free(b); }
+		++k_fetch;
+	}
+}
+
 void release(Item &it)
 {
 	if (it.a) ema_aln_free(it.a);
@@ -174,18 +286,26 @@ void release(Item &it)
 int run_stream(ema_engine_t *e, Stream &S, ema_stream_sink sink, void *user, ema_bucket_stats *stats)
 {
 	S.eng[0] = e;
-	S.n_eng = S.o.n_engines == 1 ? 1 : 2;
-	if (S.n_eng == 2) {
+	const bool two_sets = S.o.n_engines == 2;      // the older schedule: alternate batches on two sets of batch buffers, one pass each
+	S.n_eng = 1;
+	if (two_sets) {
 		S.eng[1] = ema_engine_peer(e);
-		if (!S.eng[1]) S.n_eng = 1;      // no room for a second set of batch buffers: one after another
+		if (S.eng[1]) S.n_eng = 2;      // else no room for a second set of batch buffers
 	}
 	S.cap = ema_engine_batch_capacity(e);
 	ema_engine_get_opts(e, &S.eopts);
 	for (size_t k = 0; k < S.items.size(); ++k)      // resident batches: which slot of which set (see ema_stream_resident)
 		if (S.items[k].slot >= 0) S.items[k].slot = (int)((k / (size_t)S.n_eng) % (size_t)S.items[k].slot);
 	std::vector<std::thread> th;
+	AsyncState A;
+	A.staged.assign(S.items.size(), 0);
 	if (S.paths) th.emplace_back(reader, std::ref(S));
-	for (int w = 0; w < S.n_eng; ++w) th.emplace_back(worker, std::ref(S), w);
+	if (S.n_eng == 2) {
+		for (int w = 0; w < S.n_eng; ++w) th.emplace_back(worker, std::ref(S), w);
+	} else {
+		th.emplace_back(stager, std::ref(S), std::ref(A));
+		th.emplace_back(async_engine_thread, std::ref(S), std::ref(A));
+	}
 	int result = EMA_OK;
 	for (size_t k = 0; k < S.items.size(); ++k) {
 		Item &it = S.items[k];

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256)
 ema_k_pack(int n_reads, const int *__restrict__ n_pairs_dev, const int *__restrict__ status, int reg_cap, const DevReg *__restrict__ regs, const int *__restrict__ n_regs, const DevAln *__restrict__ alns,
            const uint32_t *__restrict__ cigars, const int *__restrict__ cig_n, int cig_cap,
            const uint64_t *__restrict__ cand_off, const uint64_t *__restrict__ cig_off, uint64_t cig_base,
-           ema_cand_t *__restrict__ cand, uint32_t *__restrict__ cigar_out)
+           ema_cand_t *__restrict__ cand, uint32_t *__restrict__ cigar_out, uint64_t cand_cap, uint64_t cigar_cap)
 {
 	const int lane = (int)ema_lane();
 	const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -281,6 +281,7 @@ ema_k_pack(int n_reads, const int *__restrict__ n_pairs_dev, const int *__restri
 		if (status[r]) continue;      // redone by the full-capacity tier; the host fills this read's slots from there
 		const int nr = n_regs[r];
 		const uint64_t co = cand_off[r], go = cig_off[r];
+		if (co + (uint64_t)nr > cand_cap || go + (uint64_t)cig_n[r] > cigar_cap) continue;      // (the host sees the totals and reports it)
 		for (int k = lane; k < nr; k += EMA_WAVE) {
 			const DevReg g = regs[(size_t)r * reg_cap + k];
 			const DevAln a = alns[(size_t)r * reg_cap + k];
@@ -340,10 +341,10 @@ extern "C" size_t ema_sizeof_aln() { return sizeof(DevAln); }
 
 extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *status, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
-                                uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, int n_blocks, hipStream_t stream)
+                                uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, uint64_t cand_cap, uint64_t cigar_cap, int n_blocks, hipStream_t stream)
 {
 	hipLaunchKernelGGL(ema_k_pack, dim3(n_blocks), dim3(256), 0, stream, n_reads, n_pairs_dev, status, reg_cap, regs, n_regs, alns, cigars, cig_n, cig_cap,
-	                   cand_off, cig_off, cig_base, cand, cigar_out);
+	                   cand_off, cig_off, cig_base, cand, cigar_out, cand_cap, cigar_cap);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -1,0 +1,97 @@
+// ema_amd/csrc/k_pack.hip -- result layout on the device: where every read's candidates and CIGAR operations go in the packed
+// arrays handed to the host (exclusive prefix sums over the per-read counts of one slice), computed in the slice's own stream
+// right behind K4 so that the packing kernel (ema_k_pack, k_final.hip) can follow at once and the NEXT pass over the slice's
+// result slots may be queued without the host in between (engine.hip, ema_engine_run_async).  Reads with a capacity flag
+// count as empty: their pair is redone by the full-capacity tier.
+// Three small launches: per-block totals (1024 reads per block), one block turning them into block offsets, per-read offsets.
+#include <hip/hip_runtime.h>
+#include "dev_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ void counts_of(int r, int n, const int *status, const int *n_regs, const int *cig_n, unsigned &c, unsigned &g)
+{
+	c = g = 0;
+	if (r < n && status[r] == 0) { c = (unsigned)n_regs[r]; g = (unsigned)cig_n[r]; }
+}
+
+// exclusive prefix (within the block) of this thread's 4-read run; returns the block totals through LDS
+__device__ __forceinline__ void block_scan(unsigned c4, unsigned g4, unsigned &c_excl, unsigned &g_excl, unsigned &c_tot, unsigned &g_tot)
+{
+	__shared__ unsigned wsum[2][4];
+	const int lane = (int)ema_lane(), w = (int)(threadIdx.x >> 6);
+	const unsigned ci = (unsigned)ema_wave_incl_scan_add((int)c4), gi = (unsigned)ema_wave_incl_scan_add((int)g4);
+	if (lane == 63) { wsum[0][w] = ci; wsum[1][w] = gi; }
+	__syncthreads();
+	unsigned cb = 0, gb = 0, ct = 0, gt = 0;
+	for (int k = 0; k < 4; ++k) { if (k < w) { cb += wsum[0][k]; gb += wsum[1][k]; } ct += wsum[0][k]; gt += wsum[1][k]; }
+	c_excl = cb + ci - c4; g_excl = gb + gi - g4; c_tot = ct; g_tot = gt;
+	__syncthreads();
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256)
+ema_k_scan_blocks(int n_reads, const int *__restrict__ n_pairs_dev, const int *__restrict__ status, const int *__restrict__ n_regs,
+                  const int *__restrict__ cig_n, uint2 *__restrict__ block_tot)
+{
+	const int n = ema_work_count(n_reads, n_pairs_dev, 2);
+	const int r0 = (int)(blockIdx.x * 1024 + threadIdx.x * 4);
+	unsigned c4 = 0, g4 = 0;
+	for (int k = 0; k < 4; ++k) { unsigned c, g; counts_of(r0 + k, n, status, n_regs, cig_n, c, g); c4 += c; g4 += g; }
+	unsigned ce, ge, ct, gt;
+	block_scan(c4, g4, ce, ge, ct, gt);
+	if (threadIdx.x == 0) block_tot[blockIdx.x] = make_uint2(ct, gt);
+}
+
+// one block: block totals -> exclusive block offsets (in place); grand totals to tot[0] (candidates), tot[1] (CIGAR operations)
+__global__ void __launch_bounds__(256)
+ema_k_scan_tops(int n_blocks, uint2 *__restrict__ block_tot, uint64_t *__restrict__ tot)
+{
+	unsigned long long c_run = 0, g_run = 0;
+	for (int base = 0; base < n_blocks; base += 1024) {
+		const int b0 = base + (int)threadIdx.x * 4;
+		uint2 v[4];
+		unsigned c4 = 0, g4 = 0;
+		for (int k = 0; k < 4; ++k) { v[k] = b0 + k < n_blocks ? block_tot[b0 + k] : make_uint2(0, 0); c4 += v[k].x; g4 += v[k].y; }
+		unsigned ce, ge, ct, gt;
+		block_scan(c4, g4, ce, ge, ct, gt);
+		unsigned long long c = c_run + ce, g = g_run + ge;
+		for (int k = 0; k < 4; ++k) {
+			// offsets stay below 2^32 (the host checks the totals): two 32-bit halves of the running sums
+			if (b0 + k < n_blocks) block_tot[b0 + k] = make_uint2((unsigned)c, (unsigned)g);
+			c += v[k].x; g += v[k].y;
+		}
+		c_run += ct; g_run += gt;
+	}
+	if (threadIdx.x == 0) { tot[0] = c_run; tot[1] = g_run; }
+}
+
+__global__ void __launch_bounds__(256)
+ema_k_scan_write(int n_reads, const int *__restrict__ n_pairs_dev, const int *__restrict__ status, const int *__restrict__ n_regs,
+                 const int *__restrict__ cig_n, const uint2 *__restrict__ block_off, uint64_t *__restrict__ cand_off, uint64_t *__restrict__ cig_off)
+{
+	const int n = ema_work_count(n_reads, n_pairs_dev, 2);
+	const int r0 = (int)(blockIdx.x * 1024 + threadIdx.x * 4);
+	unsigned c[4], g[4], c4 = 0, g4 = 0;
+	for (int k = 0; k < 4; ++k) { counts_of(r0 + k, n, status, n_regs, cig_n, c[k], g[k]); c4 += c[k]; g4 += g[k]; }
+	unsigned ce, ge, ct, gt;
+	block_scan(c4, g4, ce, ge, ct, gt);
+	const uint2 bo = block_off[blockIdx.x];
+	uint64_t co = (uint64_t)bo.x + ce, go = (uint64_t)bo.y + ge;
+	for (int k = 0; k < 4; ++k) {
+		if (r0 + k <= n) { cand_off[r0 + k] = co; cig_off[r0 + k] = go; }      // entry n = the totals
+		co += c[k]; go += g[k];
+	}
+}
+
+// cand_off / cig_off: n + 1 entries each; block_tot: (n_reads + 1023) / 1024 + 1 entries; tot: 2 entries
+extern "C" void ema_launch_scan(int n_reads, const int *n_pairs_dev, const int *status, const int *n_regs, const int *cig_n, uint2 *block_tot,
+                                uint64_t *tot, uint64_t *cand_off, uint64_t *cig_off, hipStream_t stream)
+{
+	if (n_reads <= 0) return;
+	const int nb = n_reads / 1024 + 1;      // covers entry n_reads too
+	hipLaunchKernelGGL(ema_k_scan_blocks, dim3(nb), dim3(256), 0, stream, n_reads, n_pairs_dev, status, n_regs, cig_n, block_tot);
+	hipLaunchKernelGGL(ema_k_scan_tops, dim3(1), dim3(256), 0, stream, nb, block_tot, tot);
+	hipLaunchKernelGGL(ema_k_scan_write, dim3(nb), dim3(256), 0, stream, n_reads, n_pairs_dev, status, n_regs, cig_n, block_tot, cand_off, cig_off);
+}

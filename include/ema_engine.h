@@ -138,6 +138,15 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
 #define EMA_MAX_SLOTS 16
 int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs);
 int ema_engine_run_slot(ema_engine_t *e, int slot);
+/* Asynchronous passes: run_async queues one pass over the batch in `slot`, with the result layout and the packing done on the
+ * device in the pass's own streams, and returns a ticket; the next pass may be queued at once (two may be in flight), and
+ * fetch_ticket waits for one pass, downloads and assembles its batch while the following pass runs.  stage_async stages a
+ * slot for this path: it waits only for the last pass that read that slot and leaves the passes in flight alone.  This is the
+ * form ema_stream_* (include/ema_stream.h) drives: staging of batch k+1, kernels of batch k and fetching of batch k-1 overlap
+ * on one set of batch buffers. */
+int ema_engine_stage_async(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs);
+int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket);
+int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out);
 int ema_engine_run(ema_engine_t *e);
 int ema_engine_run_serial(ema_engine_t *e);   /* ema_engine_run with the slices one after another: kernel times in isolation */
 int ema_engine_sync(ema_engine_t *e);

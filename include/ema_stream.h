@@ -29,7 +29,9 @@ extern "C" {
 typedef struct {
 	int bc_len, is_haplotag, max_read_len;   /* bucket reader: the platform's barcode (reference src/techs.c:74-119), longest read */
 	double error_rate;                       /* append stage: the platform's error rate (reference src/techs.c; 0.001 for 10x) */
-	int n_engines;                           /* 1 = the engine alone; 2 (default when 0) = alternate buckets on ema_engine_peer() as well */
+	int n_engines;                           /* 0 / 1 (default) = one set of batch buffers, passes queued two deep (ema_engine_run_async): staging of
+	                                          * bucket k+1, kernels of bucket k, fetch + append of bucket k-1 overlap; 2 = the older schedule, alternate
+	                                          * buckets on the engine and its ema_engine_peer(), one pass each */
 	int read_ahead;                          /* buckets parsed ahead of the engine (0 = default 2) */
 } ema_stream_opts;
 void ema_stream_opts_default(ema_stream_opts *o);   /* 16, 0, 255, 0.001, 0, 0 */
@@ -60,8 +62,8 @@ int ema_stream_buckets(ema_engine_t *e, const char *const *paths, size_t n, cons
 int ema_stream_batches(ema_engine_t *e, const char *const *bases, const uint32_t *const *off, const size_t *n_pairs, size_t n,
                        const ema_stream_opts *o, ema_stream_sink sink, void *user, ema_bucket_stats *stats);
 
-/* The same pipeline on batches that are already in HBM (ema_engine_stage_slot): with s sets of batch buffers in use (2, or
- * 1 when o->n_engines == 1 or no peer could be created), batch k must have been staged into slot (k / s) % slots_per_set of
+/* The same pipeline on batches that are already in HBM (ema_engine_stage_slot): with s sets of batch buffers in use (1; 2 when
+ * o->n_engines == 2 and the peer could be created), batch k must have been staged into slot (k / s) % slots_per_set of
  * set k % s (set 0 = e, set 1 = ema_engine_peer(e)); off[k] are its read offsets (the append stage needs the read lengths).
  * Nothing crosses PCIe towards the device: this is the rate with inputs resident, outputs delivered to the host. */
 int ema_stream_resident(ema_engine_t *e, const uint32_t *const *off, const size_t *n_pairs, size_t n, int slots_per_set,

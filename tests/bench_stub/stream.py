@@ -42,7 +42,7 @@ def _deliver(eng, k, bases, off, raw_sink):
 
 
 def stream_resident(eng, offs, slots_per_set, sink=None, opts=None, raw_sink=None):
-    peer = eng.peer() if (opts is None or opts.n_engines != 1) else None
+    peer = eng.peer() if (opts is not None and opts.n_engines == 2) else None
     sets = [eng, peer] if peer is not None else [eng]
     out = []
     for k, off in enumerate(offs):

@@ -39,7 +39,14 @@ def test_two_ranks_run_the_whole_bench_flow(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "pairs/s"
     assert d["bucket_stats"]["pairs"] == 2 * 2 * 24 and d["bucket_stats"]["oracle_spot_check_mismatches"] == 0
     assert d["boundary"]["value"] > 0 and d["engine_resident"]["value"] > 0 and d["cpu_baseline"] is None
-    assert d["config"]["buffer_sets"] == 2 and d["roofline"]["kernel"] == "ema_k_seed" and d["roofline"]["traffic"] is None
+    assert d["config"]["buffer_sets"] == 1 and d["roofline"]["kernel"] == "ema_k_seed" and d["roofline"]["traffic"] is None
+
+
+def test_two_sets_schedule(tmp_path):
+    p = _launch(tmp_path, extra_args=["--two-sets"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["buffer_sets"] == 2 and d["bucket_stats"]["pairs"] == 2 * 2 * 24
 
 
 def test_a_capacity_flag_on_one_rank_ends_every_rank(tmp_path):

@@ -76,8 +76,35 @@ def _check_stream(tmp_path, kind, sizes, batch_pairs, n_engines, seed0):
 
 
 def test_ten_buckets_streamed_two_buffer_sets(tmp_path):
-    """10 bucket files, one of them empty, back to back on the engine and its peer (alternate buckets)."""
+    """10 bucket files, one of them empty, back to back on the engine and its peer (alternate buckets: the older schedule)."""
     _check_stream(tmp_path, "two_contigs", [300, 220, 0, 410, 150, 380, 90, 260, 330, 120], 512, 2, 700)
+
+
+def test_ten_buckets_streamed_passes_queued_two_deep(tmp_path):
+    """The default schedule: one set of batch buffers, ema_engine_run_async -- layout and packing on the device, the next pass
+    queued before the previous one is fetched, staging on its own thread."""
+    _check_stream(tmp_path, "repeats", [300, 220, 0, 410, 150, 380, 90, 260, 330, 120, 0, 500], 512, 1, 705)
+
+
+def test_async_passes_with_tiny_lean_capacities(tmp_path):
+    """Lean capacities so small that a third of the pairs go through the full-capacity tier in every pass queued two deep."""
+    prefix, ctg = small_ref("repeats")
+    paths = _write_buckets(tmp_path, ctg, [400, 350, 300, 450], 730)
+    o = default_opts()
+    o.batch_pairs = 512
+    o.lean_intervals, o.lean_regions, o.lean_cigar_ops = 12, 3, 9
+    eng = Engine(prefix, opts=o)
+    redone = []
+
+    def sink(k, bucket, batch, rec, pair_off):
+        bases, off, bc = bucket
+        assert batch.status.max(initial=0) == 0
+        assert not compare(prefix, synth.Pairs(bases, off), batch)
+        redone.append(batch.n_redone)
+        assert sorted(set(batch.redone.tolist())) == sorted(batch.redone.tolist()) and len(batch.redone) == batch.n_redone
+    stream.stream_buckets(eng, paths, sink)
+    eng.close()
+    assert len(redone) == 4 and min(redone) > 30
 
 
 def test_buckets_beyond_the_batch_capacity_in_the_stream(tmp_path):
@@ -85,8 +112,13 @@ def test_buckets_beyond_the_batch_capacity_in_the_stream(tmp_path):
     _check_stream(tmp_path, "repeats", [200, 700, 130, 1000, 256, 257, 40, 600], 256, 2, 720)
 
 
-def test_stream_on_one_buffer_set(tmp_path):
-    _check_stream(tmp_path, "two_contigs", [200, 0, 0, 310, 128, 64, 500, 77], 512, 1, 740)
+def test_buckets_beyond_the_batch_capacity_in_the_async_stream(tmp_path):
+    """The same with passes queued two deep: a big bucket drains the pipeline and goes through ema_engine_align_pairs."""
+    _check_stream(tmp_path, "repeats", [200, 700, 130, 1000, 256, 257, 40, 600], 256, 1, 725)
+
+
+def test_stream_with_empty_buckets_at_the_ends(tmp_path):
+    _check_stream(tmp_path, "two_contigs", [0, 200, 0, 0, 310, 128, 64, 500, 77, 0], 512, 1, 740)
 
 
 def test_stream_batches_from_memory_equals_align_pairs():

@@ -1,0 +1,3 @@
+/* include/bwa_compat/bwa/bntseq.h -- for building the unmodified reference against libema_bwaabi.so:
+ * the reference includes "bwa/bntseq.h" (include/bwabridge.h:9-12); every declaration it uses is in ema_bwaabi.h. */
+#include "../../ema_bwaabi.h"

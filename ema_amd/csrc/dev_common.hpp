@@ -143,6 +143,31 @@ __device__ __forceinline__ void ema_lane_occ4(const DevIndex &ix, uint64_t pos, 
 	}
 }
 
+// the arithmetic of ema_lane_occ4 on a block that is already in registers (head = the four counts, sym = the 64 symbols):
+// p = the row with the sentinel taken out
+__device__ __forceinline__ void ema_occ4_decode(const DevIndex &ix, uint64_t p, const uint4 &head, const uint4 &sym4, uint64_t cnt[4])
+{
+	const int r = (int)(p & 63);
+	unsigned c1 = 0, c2 = 0, c3 = 0;
+	const uint64_t w[2] = {(uint64_t)sym4.y << 32 | sym4.x, (uint64_t)sym4.w << 32 | sym4.z};
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		int nvalid = r + 1 - (j << 5);
+		nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
+		const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
+		const uint64_t lo = w[j] & m55, hi = (w[j] >> 1) & m55;
+		c3 += __popcll(hi & lo); c2 += __popcll(hi & ~lo); c1 += __popcll(~hi & lo);
+	}
+	const unsigned c0 = (unsigned)(r + 1) - c1 - c2 - c3;
+	cnt[0] = (uint64_t)head.x + c0; cnt[1] = (uint64_t)head.y + c1; cnt[2] = (uint64_t)head.z + c2; cnt[3] = (uint64_t)head.w + c3;
+	if (ix.n_super > 1) {
+		const int sb = (int)(p >> EMA_OCC_SUPER_SHIFT);
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			cnt[c] += sb == 0 ? 0 : sb == 1 ? ix.occ_super[0][c] : sb == 2 ? ix.occ_super[1][c] : ix.occ_super[2][c];
+	}
+}
+
 // bwt_extend for one symbol by one lane; arguments as in ema_group8_extend
 __device__ __forceinline__ void ema_lane_extend(const DevIndex &ix, uint64_t x_nb, uint64_t x_b, uint64_t size, int c,
                                                 uint64_t &o_nb, uint64_t &o_b, uint64_t &o_size)

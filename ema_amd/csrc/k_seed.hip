@@ -325,23 +325,53 @@ ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const u
 			ent.x0 = lo.x; ent.x1 = lo.y; ent.x2 = hi.x; ent.info = hi.y;
 			ld_kind = 0;
 		}
-		if (has_req == 2) {
-			// the result is a string of req_len <= kmer_k bases: its interval from the table; when a forward extension reaches
-			// the table's last level, the reverse-strand coordinate too (the next step is a rank query on it)
-			ema_kmer_lookup(ix, (int)req_len, req_code, r0, r2);
-			r1 = 0;
-			if ((int)req_len == kk && pc != PC_BWD_RES) {
-				uint64_t unused;
-				ema_kmer_lookup(ix, kk, ema_kmer_revcomp(req_code, kk), r1, unused);
+		if (has_req) {
+			// One place issues every load of the tick, whatever the lane asks for, so that the wave waits for memory once:
+			//   rank query (has_req 1): the two 32-byte rank blocks of k - 1 and l;
+			//   table look-up (has_req 2): the entry of the result string (its interval) and, when a forward extension reaches
+			//   the table's last level, the entry of its reverse complement (the reverse-strand coordinate the next rank query
+			//   needs) -- read as 32 bytes each like the blocks (the entries are 16 or 8 bytes; the tables are padded).
+			const bool tab = has_req == 2, back = pc == PC_BWD_RES;
+			const uint64_t x_nb = back ? c0 : c1, x_b = back ? c1 : c0;
+			const uint64_t pk = x_nb - 1, pl = x_nb - 1 + c2;                    // rows whose occ4 the extend needs
+			const uint64_t qk = pk - (pk >= ix.primary ? 1 : 0), ql = pl - (pl >= ix.primary ? 1 : 0);      // '$' is not stored
+			const bool want_rc = tab && (int)req_len == kk && !back;
+			const uint4 *pa, *pb;
+			if (tab) {
+				const int L = (int)req_len;
+				const uint32_t rcode = want_rc ? ema_kmer_revcomp(req_code, kk) : req_code;
+				if (L <= EMA_KMER_WIDE) {
+					const size_t base = (((size_t)1 << (2 * L)) - 4) / 3;
+					pa = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + req_code));
+					pb = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + rcode));
+				} else {
+					const size_t base = (((size_t)1 << (2 * L)) - ((size_t)1 << (2 * (EMA_KMER_WIDE + 1)))) / 3;
+					pa = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + req_code);
+					pb = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + rcode);
+				}
+			} else {
+				pa = reinterpret_cast<const uint4 *>(ix.occ + (qk >> 6));
+				pb = reinterpret_cast<const uint4 *>(ix.occ + (ql >> 6));
 			}
-			r_code = req_code;
-			has_req = 0;
-		} else if (has_req) {
-			// forward extension works on x[1] (the reverse-complement strand), backward on x[0]
-			const bool back = pc == PC_BWD_RES;
-			uint64_t o_nb = 0, o_b = 0, o_size = 0;
-			ema_lane_extend(ix, back ? c0 : c1, back ? c1 : c0, c2, req_c, o_nb, o_b, o_size);
-			r0 = back ? o_nb : o_b; r1 = back ? o_b : o_nb; r2 = o_size;
+			const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+			if (tab) {
+				uint64_t ea = (uint64_t)a0.y << 32 | a0.x, eb = (uint64_t)b0.y << 32 | b0.x;
+				if ((int)req_len <= EMA_KMER_WIDE) { r0 = ea; r2 = (uint64_t)a0.w << 32 | a0.z; r1 = want_rc ? eb : 0; }
+				else { r0 = ea & 0xFFFFFFFFFFULL; r2 = ea >> 40; r1 = want_rc ? (eb & 0xFFFFFFFFFFULL) : 0; }
+				r_code = req_code;
+			} else {
+				uint64_t tk[4], tl[4];
+				ema_occ4_decode(ix, qk, a0, a1, tk);
+				ema_occ4_decode(ix, ql, b0, b1, tl);
+				const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+				const uint64_t b3 = x_b + ((x_nb <= ix.primary && x_nb + c2 - 1 >= ix.primary) ? 1 : 0);
+				const uint64_t b2 = b3 + s3, b1_ = b2 + s2, b0_ = b1_ + s1;
+				const int cc = req_c & 3;
+				const uint64_t o_b = cc == 3 ? b3 : cc == 2 ? b2 : cc == 1 ? b1_ : b0_;
+				const uint64_t o_size = cc == 3 ? s3 : cc == 2 ? s2 : cc == 1 ? s1 : s0;
+				const uint64_t o_nb = ix.L2[cc] + 1 + (cc == 3 ? tk[3] : cc == 2 ? tk[2] : cc == 1 ? tk[1] : tk[0]);
+				r0 = back ? o_nb : o_b; r1 = back ? o_b : o_nb; r2 = o_size;
+			}
 			has_req = 0;
 		}
 	}

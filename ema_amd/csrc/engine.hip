@@ -915,7 +915,7 @@ int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
 	HIPCHK(e, hipEventRecord(e->slot_free[slot], f.stream));
 	HIPCHK(e, hipMemcpyAsync(f.out[j].d_redo.p, e->d_redo_run.p, (f.cap_pairs + 1) * 4, hipMemcpyDeviceToDevice, f.stream));
 	if ((rc = pack_async(e, f, f.out[j], (int)(2 * f.cap_pairs), e->d_redo_run.p))) return rc;
-	e->ran = true; e->ever_ran = true;
+	e->ran = false; e->ever_ran = true;      // (ran: a synchronous pass whose results ema_engine_fetch may take)
 	++e->n_inflight;
 	*ticket = e->next_ticket++;
 	return EMA_OK;

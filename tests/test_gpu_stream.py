@@ -104,7 +104,7 @@ def test_async_passes_with_tiny_lean_capacities(tmp_path):
         assert sorted(set(batch.redone.tolist())) == sorted(batch.redone.tolist()) and len(batch.redone) == batch.n_redone
     stream.stream_buckets(eng, paths, sink)
     eng.close()
-    assert len(redone) == 4 and min(redone) > 30
+    assert len(redone) == 4 and min(redone) > 5
 
 
 def test_buckets_beyond_the_batch_capacity_in_the_stream(tmp_path):

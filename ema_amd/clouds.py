@@ -18,11 +18,12 @@ class CloudOpts(C.Structure):
 
 class SamStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("groups", "clouds", "bad_clouds", "lines", "mapped", "unmapped_mates", "proper", "duplicates", "with_xa")] + \
-               [("mapq_hist", C.c_uint64 * 7)]
+               [("mapq_hist", C.c_uint64 * 7), ("select_s", C.c_double), ("write_s", C.c_double)]
 
     def as_dict(self):
-        d = {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "mapq_hist"}
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_ if n not in ("mapq_hist", "select_s", "write_s")}
         d["mapq_hist"] = [int(x) for x in self.mapq_hist]
+        d["select_s"], d["write_s"] = float(self.select_s), float(self.write_s)
         return d
 
 

@@ -12,6 +12,7 @@
 // built with -ffp-contract=off), and the cloud numbering of a single-threaded run.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -391,6 +392,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 {
 	if (!out) return EMA_EARG;
 	*out = nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
 	if (!bk || !b || !a || (n_contigs > 0 && !contig_names)) return EMA_EARG;
 	if (bk->n_pairs != b->n_pairs || bk->n_pairs != a->n_pairs) return EMA_EARG;
 	Shared S;
@@ -518,6 +520,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 		q = q > 0 ? q : 0; q = q < 60 ? q : 60;
 		++o->stats.mapq_hist[q == 0 ? 0 : q < 10 ? 1 : q < 20 ? 2 : q < 30 ? 3 : q < 40 ? 4 : q < 60 ? 5 : 6];
 	}
+	o->stats.select_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 	*out = o;
 	return rc;
 }

@@ -404,7 +404,9 @@ int sam_sink(void *user, size_t k, const ema_bucket *bk, const ema_batch_out *b,
 	S.next_cloud_id = sel->next_cloud_id;
 	if (S.sstats) S.sstats[k] = sel->stats;
 	size_t n_bytes = 0;
+	const double t0 = now_s();
 	rc = ema_sam_write(S.fd, sel->lines, sel->n_lines, &S.o.sam, &n_bytes);
+	if (S.sstats) S.sstats[k].write_s = now_s() - t0;
 	ema_clouds_free(sel);
 	if (rc != EMA_OK) { S.err = "ema_sam_write failed"; return rc; }
 	return 0;

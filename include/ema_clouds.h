@@ -48,6 +48,7 @@ typedef struct {
 	uint64_t lines, mapped, unmapped_mates;   /* SAM lines; lines of aligned records; lines standing in for an unaligned mate */
 	uint64_t proper, duplicates, with_xa;     /* FLAG 0x2 lines; FLAG 0x400 lines; lines with an XA tag */
 	uint64_t mapq_hist[7];                    /* printed MAPQ of the mapped lines: 0, 1-9, 10-19, 20-29, 30-39, 40-59, 60 */
+	double select_s, write_s;                 /* wall seconds in ema_clouds_select; in ema_sam_write (set by ema_stream_sam) */
 } ema_sam_stats;
 
 typedef struct ema_clouds_out {

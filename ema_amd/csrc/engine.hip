@@ -257,6 +257,8 @@ struct ema_engine {
 	struct Ticket { int seq = -1; size_t n_pairs = 0; std::vector<size_t> first, n; };
 	Ticket tickets[2];
 	int next_ticket = 0, n_inflight = 0;
+	struct FetchPin { PinBuf<uint64_t> c_off, g_off; PinBuf<int> status; PinBuf<ema_cand_t> cand; PinBuf<uint32_t> cig; };
+	std::vector<FetchPin> fetch_pin;     // page-locked landing buffers of ema_engine_fetch_ticket, per slice + full tier
 	hipStream_t copy_stream = nullptr, h2d_stream = nullptr;   // device -> host / host -> device copies of the async path (never behind a kernel)
 	hipEvent_t slot_free[EMA_MAX_SLOTS] = {};      // recorded when the last run queued on an input slot has read it
 };
@@ -533,6 +535,7 @@ void ema_engine_close(ema_engine_t *e)
 	for (auto &ev : e->slot_free) if (ev) (void)hipEventDestroy(ev);
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
+	for (auto &fp : e->fetch_pin) { fp.c_off.release(); fp.g_off.release(); fp.status.release(); fp.cand.release(); fp.cig.release(); }
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
 	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
 	e->d_redo.release(); e->d_redo_run.release();
@@ -962,20 +965,25 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 		const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
 		if (tot[2 * k] > o.cand_cap || tot[2 * k + 1] > o.cigar_cap) { e->err = "the packed result buffers of a slice are too small for this batch; use ema_engine_run + ema_engine_fetch"; return EMA_ELIMIT; }
 	}
-	// per-read layout and payload of every slice and of the full-capacity tier
-	struct Part { std::vector<uint64_t> c_off, g_off; std::vector<int> status; std::vector<ema_cand_t> cand; std::vector<uint32_t> cig; };
+	// per-read layout and payload of every slice and of the full-capacity tier, into page-locked staging buffers the engine
+	// keeps (the copies run at full PCIe rate, and nothing of this size is allocated or zero-filled per batch)
+	struct Part { const uint64_t *c_off, *g_off; const int *status; const ema_cand_t *cand; const uint32_t *cig; };
 	std::vector<Part> part(n_sl + 1);
 	std::vector<int> redo(n_redo + 1);
+	if (e->fetch_pin.size() < n_sl + 1) e->fetch_pin.resize(n_sl + 1);
 	for (size_t k = 0; k <= n_sl; ++k) {
 		const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
 		const size_t nr = k < n_sl ? 2 * t.n[k] : 2 * n_redo;
-		Part &p = part[k];
-		p.c_off.resize(nr + 1); p.g_off.resize(nr + 1); p.status.resize(nr + 1); p.cand.resize(tot[2 * k] + 1); p.cig.resize(tot[2 * k + 1] + 1);
-		HIPCHK(e, hipMemcpyAsync(p.c_off.data(), o.d_cand_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, cs));
-		HIPCHK(e, hipMemcpyAsync(p.g_off.data(), o.d_cig_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, cs));
-		HIPCHK(e, hipMemcpyAsync(p.status.data(), o.d_status.p, nr * 4, hipMemcpyDeviceToHost, cs));
-		HIPCHK(e, hipMemcpyAsync(p.cand.data(), o.d_cand.p, tot[2 * k] * sizeof(ema_cand_t), hipMemcpyDeviceToHost, cs));
-		HIPCHK(e, hipMemcpyAsync(p.cig.data(), o.d_cigar.p, tot[2 * k + 1] * 4, hipMemcpyDeviceToHost, cs));
+		ema_engine::FetchPin &fp = e->fetch_pin[k];
+		HIPCHK(e, fp.c_off.reserve(nr + 2)); HIPCHK(e, fp.g_off.reserve(nr + 2)); HIPCHK(e, fp.status.reserve(nr + 2));
+		if (tot[2 * k] + 1 > fp.cand.n) HIPCHK(e, fp.cand.reserve((tot[2 * k] + 1) * 5 / 4 + 4096));
+		if (tot[2 * k + 1] + 1 > fp.cig.n) HIPCHK(e, fp.cig.reserve((tot[2 * k + 1] + 1) * 5 / 4 + 4096));
+		part[k] = Part{fp.c_off.p, fp.g_off.p, fp.status.p, fp.cand.p, fp.cig.p};
+		HIPCHK(e, hipMemcpyAsync(fp.c_off.p, o.d_cand_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(fp.g_off.p, o.d_cig_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(fp.status.p, o.d_status.p, nr * 4, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(fp.cand.p, o.d_cand.p, tot[2 * k] * sizeof(ema_cand_t), hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(fp.cig.p, o.d_cigar.p, tot[2 * k + 1] * 4, hipMemcpyDeviceToHost, cs));
 	}
 	if (n_redo) HIPCHK(e, hipMemcpyAsync(redo.data(), f.out[j].d_redo.p + 1, n_redo * 4, hipMemcpyDeviceToHost, cs));
 	HIPCHK(e, hipStreamSynchronize(cs));
@@ -1004,7 +1012,7 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 		o->cand_off[r + 1] = o->cand_off[r] + (p.c_off[i + 1] - p.c_off[i]);
 		cig_off[r + 1] = cig_off[r] + (p.g_off[i + 1] - p.g_off[i]);
 		o->status[r] = p.status[i];
-	}
+	}      // (2 M reads: a few milliseconds; the payload below is the part worth the threads)
 	const size_t n_cand = o->cand_off[n_reads], n_cig = cig_off[n_reads];
 	if (n_cig >= ((size_t)1 << 32)) { e->err = "batch has more than 2^32 CIGAR operations; use smaller batches"; ema_batch_free(o); return EMA_ELIMIT; }
 	o->n_cigar = n_cig;
@@ -1023,7 +1031,7 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 				c.cigar_off = (uint32_t)(c.cigar_off - g0 + cig_off[r]);
 				dst[k] = c;
 			}
-			memcpy(o->cigar + cig_off[r], p.cig.data() + g0, ng * 4);
+			memcpy(o->cigar + cig_off[r], p.cig + g0, ng * 4);
 		}
 	});
 	if ((size_t)n_listed > f.cap_pairs) {

@@ -49,7 +49,7 @@ struct Stream {
 	ema_stream_opts o;
 	std::vector<Item> items;
 	const char *const *paths = nullptr;
-	std::mutex mu, eng_mu[2];
+	std::mutex mu, eng_mu[2], stage_mu;
 	std::condition_variable cv;
 	size_t delivered = 0;
 	bool stop = false;
@@ -166,7 +166,7 @@ void reader(Stream &S)
 // The default schedule: ONE set of batch buffers, passes queued two deep (ema_engine_run_async).  A stager thread converts and
 // uploads batch k+1.. into free input slots while this thread queues pass k, then fetches pass k-1 and runs its append stage
 // while pass k computes.  A bucket beyond the batch capacity drains the pipeline and goes through ema_engine_align_pairs.
-const int kInSlots = 3;
+const int kInSlots = 3;      // input slots 1..3: slot 0 stays with ema_engine_stage / ema_engine_align_pairs (the big-bucket path)
 
 struct AsyncState {
 	std::vector<int> staged;      // per item: 0 no, 1 staged, -1 staging failed
@@ -184,7 +184,8 @@ void stager(Stream &S, AsyncState &A)
 		}
 		int ok = 1;
 		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap) {
-			const int rc = ema_engine_stage_async(S.eng[0], (int)(k % (size_t)kInSlots), it.bases, it.off, it.n_pairs);
+			std::lock_guard<std::mutex> hold(S.stage_mu);      // the engine's host-side staging buffers: one user at a time
+			const int rc = ema_engine_stage_async(S.eng[0], 1 + (int)(k % (size_t)kInSlots), it.bases, it.off, it.n_pairs);
 			if (rc != EMA_OK) { it.rc = rc; it.err = ema_engine_strerror(S.eng[0]); ok = -1; }
 		}
 		{
@@ -251,10 +252,11 @@ void async_engine_thread(Stream &S, AsyncState &A)
 			if (it.rc != EMA_OK) {      // reader or stager failed: passes straight through, in order
 			} else if (it.n_pairs > S.cap) {      // beyond one batch: drain, then the engine's own piece pipeline
 				while (k_fetch < k_run) fetch_one();
+				std::lock_guard<std::mutex> hold(S.stage_mu);
 				it.rc = ema_engine_align_pairs(g, it.bases, it.off, it.n_pairs, &it.b);
 				if (it.rc != EMA_OK) it.err = ema_engine_strerror(g);
 			} else {
-				const int slot = it.slot >= 0 ? it.slot : (int)(k_run % (size_t)kInSlots);
+				const int slot = it.slot >= 0 ? it.slot : 1 + (int)(k_run % (size_t)kInSlots);
 				int tk = -1;
 				const int rc = ema_engine_run_async(g, slot, &tk);
 				if (rc != EMA_OK) { it.rc = rc; it.err = ema_engine_strerror(g); } else ticket[k_run] = tk;

@@ -154,7 +154,7 @@ template <typename T> struct DevBuf {
 struct Slice {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-	hipEvent_t tev[2][5] = {};        // K1..K4 boundaries of the two asynchronous passes in flight (ev[0..4] of the synchronous path)
+	hipEvent_t tev[EMA_MAX_INFLIGHT][5] = {};        // K1..K4 boundaries of the asynchronous passes in flight (ev[0..4] of the synchronous path)
 	bool own_stream = false;
 	size_t cap_pairs = 0, n_pairs = 0, first_pair = 0;
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
@@ -167,7 +167,7 @@ struct Slice {
 	DevBuf<uint64_t> d_cand_off, d_cig_off;
 	DevBuf<ema_cand_t> d_cand;
 	size_t cand_cap = 0, cigar_out_cap = 0;
-	// ema_engine_run_async: two sets of packed results (the run being fetched and the run in flight)
+	// ema_engine_run_async: EMA_MAX_INFLIGHT sets of packed results (the run being fetched and the runs in flight)
 	struct OutSet {
 		DevBuf<ema_cand_t> d_cand;
 		DevBuf<uint32_t> d_cigar;
@@ -181,7 +181,7 @@ struct Slice {
 			if (done) (void)hipEventDestroy(done);
 			done = nullptr;
 		}
-	} out[2];
+	} out[EMA_MAX_INFLIGHT];
 	DevBuf<uint2> d_block_tot;
 	bool out_ready = false;
 	int *dbg = nullptr;               // EMA_WATCHDOG_S: host-visible per-wave progress words
@@ -191,7 +191,8 @@ struct Slice {
 		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_todo_mid.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
-		out[0].release(); out[1].release(); d_block_tot.release();
+		for (auto &o : out) o.release();
+		d_block_tot.release();
 		for (auto &row : tev) for (auto &x : row) if (x) (void)hipEventDestroy(x);
 		for (auto &e : ev) if (e) (void)hipEventDestroy(e);
 		if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -255,7 +256,7 @@ struct ema_engine {
 	ema_engine *shadow = nullptr;        // second set of batch buffers and streams on the same index: align_pairs on big inputs
 	// ema_engine_run_async / ema_engine_fetch_ticket: up to two runs queued; what the fetch of each needs to know
 	struct Ticket { int seq = -1; size_t n_pairs = 0; std::vector<size_t> first, n; };
-	Ticket tickets[2];
+	Ticket tickets[EMA_MAX_INFLIGHT];
 	int next_ticket = 0, n_inflight = 0;
 	struct FetchPin { PinBuf<uint64_t> c_off, g_off; PinBuf<int> status; PinBuf<ema_cand_t> cand; PinBuf<uint32_t> cig; };
 	std::vector<FetchPin> fetch_pin;     // page-locked landing buffers of ema_engine_fetch_ticket, per slice + full tier
@@ -838,9 +839,10 @@ static int run_batch(ema_engine_t *e, bool serial)
 // ---------------------------------------------------------------------------------------------------------------------
 // Asynchronous runs.  ema_engine_run + ema_engine_fetch need the host between two passes: the fetch computes the result
 // layout from the per-read counts, and only then may the next pass overwrite the per-read slots.  Here every slice computes
-// its layout itself (k_pack.hip) and packs its results into one of two output sets right behind K4, in its own stream; the
-// next pass over the same slots is queued at once, and the host fetches a finished pass while the following one runs.  Two
-// passes may be in flight (one being fetched, one running).
+// its layout itself (k_pack.hip) and packs its results into one of EMA_MAX_INFLIGHT output sets right behind K4, in its own
+// stream; the next pass over the same slots is queued at once, and the host fetches a finished pass while the following
+// ones run.  Three passes may be in flight: a pass is only complete when its full-capacity tier is, which runs beside the
+// NEXT pass's lean slices, so with two the lean streams would idle while the host assembles the older pass.
 
 static int out_alloc(ema_engine *e, Slice &s, bool full)
 {
@@ -886,13 +888,13 @@ int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
 {
 	if (!e || !ticket) return EMA_EARG;
 	if (slot < 0 || slot >= EMA_MAX_SLOTS || !e->in[slot].staged) { e->err = "ema_engine_run_async: nothing staged in this slot"; return EMA_ESTATE; }
-	if (e->n_inflight >= 2) { e->err = "ema_engine_run_async: two runs are in flight; fetch one first"; return EMA_ESTATE; }
+	if (e->n_inflight >= EMA_MAX_INFLIGHT) { e->err = "ema_engine_run_async: EMA_MAX_INFLIGHT runs are in flight; fetch one first"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
 	int rc;
 	for (auto &s : e->sl) if ((rc = out_alloc(e, s, false))) return rc;
 	if ((rc = out_alloc(e, e->full, true))) return rc;
 	if ((rc = select_slot(e, slot))) return rc;
-	const int j = e->next_ticket & 1;
+	const int j = e->next_ticket % EMA_MAX_INFLIGHT;
 	ema_engine::Ticket &t = e->tickets[j];
 	t.seq = e->next_ticket; t.n_pairs = e->n_pairs;
 	t.first.clear(); t.n.clear();
@@ -929,7 +931,7 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 {
 	if (!e || !out) return EMA_EARG;
 	*out = nullptr;
-	const int j = ticket & 1;
+	const int j = ticket < 0 ? 0 : ticket % EMA_MAX_INFLIGHT;
 	ema_engine::Ticket &t = e->tickets[j];
 	if (ticket < 0 || t.seq != ticket) { e->err = "ema_engine_fetch_ticket: no such run in flight"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));

@@ -166,7 +166,7 @@ void reader(Stream &S)
 // The default schedule: ONE set of batch buffers, passes queued two deep (ema_engine_run_async).  A stager thread converts and
 // uploads batch k+1.. into free input slots while this thread queues pass k, then fetches pass k-1 and runs its append stage
 // while pass k computes.  A bucket beyond the batch capacity drains the pipeline and goes through ema_engine_align_pairs.
-const int kInSlots = 3;      // input slots 1..3: slot 0 stays with ema_engine_stage / ema_engine_align_pairs (the big-bucket path)
+const int kInSlots = 4;      // input slots 1..4: slot 0 stays with ema_engine_stage / ema_engine_align_pairs (the big-bucket path)
 
 struct AsyncState {
 	std::vector<int> staged;      // per item: 0 no, 1 staged, -1 staging failed
@@ -241,10 +241,10 @@ void async_engine_thread(Stream &S, AsyncState &A)
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
 			if (S.stop) break;
-			// queue the next pass if its batch is staged and fewer than two are in flight; otherwise fetch the oldest; otherwise wait
+			// queue the next pass if its batch is staged and fewer than EMA_MAX_INFLIGHT are in flight; otherwise fetch the oldest; otherwise wait
 			S.cv.wait(lk, [&] { return S.stop || k_fetch < k_run || (k_run < n && A.staged[k_run] != 0); });
 			if (S.stop) break;
-			can_run = k_run < n && A.staged[k_run] != 0 && k_run - k_fetch < 2;
+			can_run = k_run < n && A.staged[k_run] != 0 && k_run - k_fetch < (size_t)EMA_MAX_INFLIGHT;
 		}
 		if (can_run) {
 			Item &it = S.items[k_run];

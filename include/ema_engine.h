@@ -136,10 +136,11 @@ int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, si
  * that slot's batch.  Runs on different slots may be queued back to back like runs on one; sync/fetch/timing refer to
  * the last run queued. */
 #define EMA_MAX_SLOTS 16
+#define EMA_MAX_INFLIGHT 3
 int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs);
 int ema_engine_run_slot(ema_engine_t *e, int slot);
 /* Asynchronous passes: run_async queues one pass over the batch in `slot`, with the result layout and the packing done on the
- * device in the pass's own streams, and returns a ticket; the next pass may be queued at once (two may be in flight), and
+ * device in the pass's own streams, and returns a ticket; the next pass may be queued at once (EMA_MAX_INFLIGHT in flight), and
  * fetch_ticket waits for one pass, downloads and assembles its batch while the following pass runs.  stage_async stages a
  * slot for this path: it waits only for the last pass that read that slot and leaves the passes in flight alone.  This is the
  * form ema_stream_* (include/ema_stream.h) drives: staging of batch k+1, kernels of batch k and fetching of batch k-1 overlap

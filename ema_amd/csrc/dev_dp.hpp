@@ -20,6 +20,11 @@
 
 #include "dev_common.hpp"
 
+// EMA_DP_CALL: how the kernels reach the extension / global DPs.  As real calls (noinline) the row loops are register-allocated
+// on their own and the callers keep their state across the call instead of through the loops.
+#ifndef EMA_DP_CALL
+#define EMA_DP_CALL inline
+#endif
 #define EMA_DP_MINUS_INF (-0x40000000)
 #define EMA_NEG_BIG (-0x7f000000)      // "no element" in max scans; never reached by real values
 
@@ -244,6 +249,23 @@ __device__ inline EmaExtRes ema_wave_extend_nc(const DevOpts &o, int qlen, EmaSe
 				if (mx_sc - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
 			}
 		}
+		// Exact early exit once the query's end has been reached (gscore > 0).  No later cell can exceed
+		//   ub = max over this row's live cells of H(i,j) + (qlen-1-j) * a      (and the boundary column's h1 + qlen * a):
+		// a cell of row i+1 takes H(i,j-1) + s <= H(i,j-1) + a, or E <= H(i,j), or F <= a cell to its left in its own row, so
+		// max_j H(i',j) + (qlen-1-j) a does not grow from row to row.  With gscore > ub (and mx_sc >= gscore) the rows that remain
+		// cannot raise the maximum (strict >) nor touch gscore / max_ie (>=), and max_off only moves with the maximum: the six
+		// results are final.  This is the usual end of an extension: the diagonal has run off the query and what is left in the
+		// band are gap states decaying by e_del a row, for up to cal_max_gap more rows.
+		if (i >= qlen - 1 && gscore > 0) {
+			const int mx = o.a > 0 ? o.a : 0;
+			int ub = (beg == 0 && h1_init > 0) ? h1_init + qlen * mx : -1;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				const int j = lane * NC + c;
+				if (j >= beg && j < end && h[c] > 0) ub = max(ub, h[c] + (qlen - 1 - j) * mx);
+			}
+			if (gscore > ema_wave_max(ub)) break;
+		}
 		// next row's range.  Sequentially: beg = first j in [beg,end) with H or E non-zero (else end);
 		// then j = last non-zero index in [beg,end] (else beg-1); end = min(j+2, qlen).
 		int first = 1 << 20, last = -1;
@@ -272,7 +294,7 @@ __device__ inline EmaExtRes ema_wave_extend_nc(const DevOpts &o, int qlen, EmaSe
 
 // ksw_extend2, qlen <= 255.  Extensions are mostly the rest of a read beyond its seed: the narrowest column layout
 // that holds the query keeps the per-row work proportional to it.
-__device__ inline EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w,
+__device__ EMA_DP_CALL EmaExtRes ema_wave_extend(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w,
                                             int end_bonus, int zdrop, int h0)
 {
 	if (qlen < 64) return ema_wave_extend_nc<1>(o, qlen, query, tlen, target, w, end_bonus, zdrop, h0);
@@ -356,7 +378,7 @@ __device__ inline int ema_wave_global_nc(const DevOpts &o, int qlen, EmaSeq quer
 }
 
 // ksw_global2 with the narrowest column layout that holds the query (qlen + 1 <= 64 NC)
-__device__ inline int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
+__device__ EMA_DP_CALL int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
 {
 	if (qlen < 64) return ema_wave_global_nc<1>(o, qlen, query, tlen, target, w, z);
 	if (qlen < 128) return ema_wave_global_nc<2>(o, qlen, query, tlen, target, w, z);

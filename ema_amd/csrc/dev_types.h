@@ -98,6 +98,32 @@ struct ChainRec {
 #define EMA_HAND_BYTES ((size_t)16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)))
 #define EMA_HAND_FLAG 0x80000000u
 
+// Chain-rich reads (hundreds of chains, nearly every one of them extended: a read from a young repeat family) are a long
+// serial job for the one wavefront that owns them -- two extension DPs per chain, one after the other -- and they set the
+// length of a K2b launch once the work queue is empty.  K2b therefore sets such a read aside after the chain filter: its
+// tables (sorted keys, chains, seed pool) go to a record in an arena and one TASK per chain to extend goes on a list.
+//   K2c (ema_k_align_t<.., 1>): one wavefront per task runs mem_chain2aln's body for that chain alone and leaves, per seed in
+//        processing order, the region the extension produces (or "not computed" where it would skip the seed);
+//   K2d (ema_k_align_t<.., 2>): one wavefront per read replays mem_chain2aln over all chains in order -- cover tests against
+//        the regions accepted so far, exactly the sequential decisions -- taking the extension results from K2c's table (they
+//        depend on the seed and its chain only) and running a DP itself only where K2c skipped one; then dedup and output.
+struct HeavyCtl {
+	uint8_t *arena;                    // null: nothing is set aside
+	unsigned long long arena_bytes;
+	unsigned long long *arena_used;    // bump allocator
+	unsigned long long *reads;         // record offsets of the reads set aside
+	unsigned long long *tasks;         // record offset / 64 << 32 | chain (index in filtered order)
+	int *n_reads, *n_tasks;
+	int reads_cap, tasks_cap;
+	int min_chains;                    // a read with at least this many chains to extend is set aside
+};
+struct HeavyHdr {                      // head of a record; the arrays follow at the offsets given (bytes from the record's start)
+	int32_t read, n_chn, n_chain, n_seed, status, n_ext;
+	float frac_rep;
+	int32_t pad;
+	uint64_t off_skey, off_chains, off_seeds, off_first, off_cs, off_res, off_valid, bytes;
+};
+
 // bwa's mem_alnreg_t (fields used on this path)
 struct DevReg {
 	int64_t rb, re;

@@ -46,7 +46,8 @@ extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
                                  DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs,
-                                 int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof, int mid);
+                                 int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof, int variant,
+                                 const HeavyCtl *heavy, int mode);
 extern "C" int ema_align_mid_blocks_per_cu(int variant);
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
@@ -161,6 +162,8 @@ struct Slice {
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo, d_todo_mid;
 	DevBuf<DevReg> d_regs;
+	DevBuf<uint8_t> d_heavy;                      // chain-rich reads set aside by K2b: records (dev_types.h, HeavyCtl)
+	DevBuf<unsigned long long> d_heavy_reads, d_heavy_tasks;
 	DevBuf<uint8_t> d_slabs, d_park[2], d_hand;   // d_hand: K2a -> K2b records (EMA_HAND_BYTES per read)   // d_park: K1's parked machines, ping-pong between the launches of a series
 	DevBuf<DevAln> d_alns;
 	DevBuf<uint32_t> d_cigars, d_cigar_out;
@@ -190,6 +193,7 @@ struct Slice {
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_todo_mid.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
+		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
 		d_block_tot.release();
@@ -245,6 +249,7 @@ struct ema_engine {
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	int mid_align = 0;                   // EMA_MID_ALIGN=1: LDS build of K2b for reads with 33..192 seed occurrences (one block per CU); 2: for 33..80 (two blocks); 0: none
 	bool av_lds = true;                  // EMA_AV_LDS=0: region lists in the HBM slab
+	int heavy_chains = 32;               // EMA_HEAVY_CHAINS: K2b sets a read with at least this many chains to extend aside for K2c / K2d (0: never)
 	int align_mid_blocks = 0;
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
@@ -291,6 +296,16 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
 	HIPCHK(e, s.d_counters.alloc(32));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts
+	                                        // [26] reads set aside, [27] their chain tasks, [28..29] work queues of K2c, K2d, [30..31] arena bytes used (u64)
+	if (e->heavy_chains > 0) {
+		// room: a record is ~0.2 KB per chain; a lean slice sets ~2 % of its reads aside (~100 chains each), the full-capacity
+		// tier possibly all of its reads.  Whatever does not fit is extended by K2b itself.
+		const bool full = s.dopts.reg_cap > EMA_REG_LEAN;
+		const size_t n_hreads = full ? n_reads : std::max<size_t>(4096, n_reads / 8);
+		HIPCHK(e, s.d_heavy_reads.alloc(n_hreads));
+		HIPCHK(e, s.d_heavy_tasks.alloc(full ? (size_t)8 << 20 : (size_t)4 << 20));
+		HIPCHK(e, s.d_heavy.alloc(full ? (size_t)2 << 30 : (size_t)1 << 30));
+	}
 	for (auto &pk : s.d_park) HIPCHK(e, pk.alloc((size_t)e->seed_blocks * 4 * (size_t)(e->seed_park_max > 0 ? e->seed_park_max : 1) * ema_seed_park_bytes()));
 	size_t slab = (size_t)e->align_blocks * 4 * ema_align_slab_bytes();      // the three stages run one after another
 	if ((size_t)e->pair_blocks * 4 * ema_pair_slab_bytes() > slab) slab = (size_t)e->pair_blocks * 4 * ema_pair_slab_bytes();
@@ -452,6 +467,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 
 	if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
 		HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256));
+		{ const unsigned long long ones[2] = {~0ULL, ~0ULL}; HIPCHK(e, hipMemcpy(e->d_prof.p + 26, ones, 16, hipMemcpyHostToDevice)); }
 		if (atoi(pp) >= 2) {      // per-read log of K2b (k_align.hip): [0] entries, [1] capacity, records from word 16
 			const int cap = 1 << 22;
 			HIPCHK(e, e->d_rlog.alloc(16 + (size_t)cap * 8));
@@ -480,6 +496,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
 	if (const char *v = getenv("EMA_MID_ALIGN")) e->mid_align = atoi(v);
 	if (const char *v = getenv("EMA_AV_LDS")) e->av_lds = atoi(v) != 0;
+	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
 	e->align_mid_blocks = e->n_cu * ema_align_mid_blocks_per_cu(e->mid_align == 2 ? 3 : 1);
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
@@ -743,15 +760,30 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 		HIPCHK(e, hipGetLastError());
 	}
 	// K2b, bulk build: K2a's hand-overs and the repeat-rich reads; then the LDS build for the reads in between
+	HeavyCtl hv;
+	const bool heavy = s.d_heavy.p != nullptr;
+	if (heavy) {
+		hv.arena = s.d_heavy.p; hv.arena_bytes = s.d_heavy.n; hv.arena_used = reinterpret_cast<unsigned long long *>(s.d_counters.p + 30);
+		hv.reads = s.d_heavy_reads.p; hv.tasks = s.d_heavy_tasks.p; hv.n_reads = s.d_counters.p + 26; hv.n_tasks = s.d_counters.p + 27;
+		hv.reads_cap = (int)s.d_heavy_reads.n; hv.tasks_cap = (int)s.d_heavy_tasks.n; hv.min_chains = e->heavy_chains;
+	}
 	ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 0,
-	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, e->av_lds ? 0 : 2);
+	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, e->av_lds ? 0 : 2, heavy ? &hv : nullptr, 0);
 	HIPCHK(e, hipGetLastError());
 	if (mid) {
 		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                 s.d_n_regs.p, s.d_status.p, s.d_todo_mid.p, s.d_counters.p + 24, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 25,
-		                 e->align_mid_blocks, s.stream, s.dbg, e->d_prof.p, e->mid_align == 2 ? 3 : 1);
+		                 e->align_mid_blocks, s.stream, s.dbg, e->d_prof.p, e->mid_align == 2 ? 3 : 1, nullptr, 0);
 		HIPCHK(e, hipGetLastError());
+	}
+	if (heavy) {      // K2c: the chains of the reads set aside, one per wavefront; K2d: their replay, dedup and output
+		for (int mode = 1; mode <= 2; ++mode) {
+			ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+			                 s.d_n_regs.p, s.d_status.p, nullptr, nullptr, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 27 + mode,
+			                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, 0, &hv, mode);
+			HIPCHK(e, hipGetLastError());
+		}
 	}
 	watchdog(e, s, "ema_k_align");
 	return EMA_OK;
@@ -1077,11 +1109,16 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 			fprintf(stderr, "K2a phase ticks (idle, fetch/stage, chain, filter, chain2aln-ctl, extend-dp, dedup):");
 			for (int i = 0; i < 7; ++i) fprintf(stderr, " %llu", h[16 + i]);
 			fprintf(stderr, "\n");
-			fprintf(stderr, "K2 phase ticks (idle/fetch, chain, filter, chain2aln-ctl, extend-dp, dedup):");
+			fprintf(stderr, "K2 phase ticks (idle/fetch, chain, filter, chain2aln-ctl, extend-dp, dedup; read+hand-over in, per-chain set-up, after the DPs, results out):");
 			for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", h[i]);
+			fprintf(stderr, " ; %llu %llu %llu %llu ; intervals in order %llu, SA rows + contig ids %llu", h[6], h[7], h[12], h[13], h[14], h[15]);
 			fprintf(stderr, "\nK1: wave-ticks %llu, active lane-ticks %llu (%.1f lanes/tick), clocks per wave-tick %.0f, longest wave %llu ticks\n", h[8], h[9],
 			        h[8] ? (double)h[9] / h[8] : 0., h[8] ? (double)h[10] / h[8] : 0., h[11]);
+			if (h[28] > h[26] && h[26] != ~0ULL)
+				fprintf(stderr, "K2b launches so far: first wave in .. work queue dry %.3f Mclk, .. last wave out %.3f Mclk (shader clocks; min / max over the launches since the last report)\n",
+				        (double)(h[27] - h[26]) * 1e-6, (double)(h[28] - h[26]) * 1e-6);
 			(void)hipMemset(e->d_prof.p, 0, 248);
+			{ const unsigned long long ones[2] = {~0ULL, ~0ULL}; (void)hipMemcpy(e->d_prof.p + 26, ones, 16, hipMemcpyHostToDevice); }
 		}
 	}
 	*t = e->timing;

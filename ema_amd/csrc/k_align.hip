@@ -47,6 +47,19 @@ struct AlignSlab {           // per resident wave
 //                              at the default scale while their tables were in HBM (every chaining step a handful of dependent
 //                              round trips at loaded-memory latency); one block per CU, everything in LDS.
 // K2a sorts the reads into the two work lists.
+// In between (more occurrences than SMALL, at most EMA_MED_CHAINS chains -- a tenth of the reads and, while everything of
+// theirs sat in the slab, two fifths of this kernel's wave clocks): the chain and seed RECORDS stay in the slab, but the
+// structures every step searches or walks sit in LDS that is idle in that phase --
+//   chaining:  the sorted chain positions and their ids (cpos in the reference-window buffer, cord in the small-table area):
+//              the look-up, the neighbour test and the insertion shift cost no memory round trip; what remains per occurrence
+//              is the one load of the neighbouring chain's record;
+//   filter:    the sort keys (small-table area), a summary {weight, query begin, end, kept flag} per chain (window buffer) and the
+//              kept list with its first-shadowed entries (region-list area): the single-lane sort and the kept-chain loop run on
+//              LDS alone, and the kept flags go back to the chain records in one pass;
+//   extension: the sort keys stay where they are; the seeds of the chain being extended and their order (cs, srt) use the head
+//              of the small-table area when the chain has no more than SMALL seeds.
+// A read whose chain count outgrows EMA_MED_CHAINS moves its position table to the slab and carries on there.
+#define EMA_MED_CHAINS 256
 #define EMA_SMALL_BYTES(SMALL) ((SMALL) * (2 * sizeof(SeedRec) + sizeof(ChainRec) + 3 * 8 + 2 * 4))
 #define EMA_AVL_BYTES(AVL) (((AVL) > 0 ? (AVL) : 1) * (2 * sizeof(DevReg) + 8))
 
@@ -181,13 +194,117 @@ __device__ inline void chain_insert(const DevOpts &o, int64_t l_pac, ChainBuild 
 	}
 }
 
+// ---- the medium layout's chaining (see the head of the file): every decision of an insertion is taken from LDS --
+// positions, ids and a 12-byte summary of each chain's mutable end -- and what goes to the slab are stores nobody waits for
+// (the seed, the link from the chain's last seed, a new chain's record).  LDS is addressed as LDS (ds_read / ds_write): a
+// generic-pointer access would be a FLAT instruction, which has to wait for every global store before it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EMA_LDS __attribute__((address_space(3)))
+#else
+#define EMA_LDS
+#endif
+// Summary of a chain, three words by chain id: what test_and_merge looks at, relative to the chain's position (= rbeg of its
+// first seed):  [0] rbeg of the last seed - position   [1] rid | last_seed << 16   [2] f_qbeg | l_qbeg << 8 | l_len << 16
+struct MedTables {
+	EMA_LDS int64_t *cpos;   // EMA_MED_CHAINS, ascending
+	EMA_LDS int32_t *cord;   // chain ids in the same order
+	EMA_LDS uint32_t *csm;   // 3 x EMA_MED_CHAINS
+};
+
+__device__ __forceinline__ int med_lower_bound(EMA_LDS const int64_t *cpos, int n, int64_t key)
+{
+	const int lane = (int)ema_lane();
+	int lo = 0, len = n;
+	while (len > EMA_WAVE) {
+		const int stride = (len + EMA_WAVE - 1) >> 6;
+		int pos = (lane + 1) * stride - 1;
+		if (pos > len - 1) pos = len - 1;
+		const int cnt = __popcll(__ballot(cpos[lo + pos] < key));
+		if (cnt == EMA_WAVE) return lo + len;
+		const int start = cnt * stride;
+		const int rest = len - start;
+		lo += start;
+		len = stride < rest ? stride : rest;
+	}
+	return lo + __popcll(__ballot(lane < len && cpos[lo + (lane < len ? lane : 0)] < key));
+}
+
+// chain_insert on the medium layout.  Returns false, having done nothing, when a new chain is needed and the tables are full
+// (the caller moves the read to the slab layout and repeats the insertion there).
+__device__ inline bool chain_insert_med(const DevOpts &o, int64_t l_pac, ChainBuild &cb, const MedTables &mt, int64_t rbeg, int qbeg, int len, int rid)
+{
+	const int lane = (int)ema_lane();
+	const bool leader = lane == 0;
+	int at = 0, lower = -1;
+	if (cb.n_chain) {
+		const int lo = med_lower_bound(mt.cpos, cb.n_chain, rbeg);
+		if (lo < cb.n_chain && ema_uni((int64_t)mt.cpos[lo]) == rbeg) { lower = ema_uni((int)mt.cord[lo]); at = lo + 1; }
+		else if (lo > 0) { lower = ema_uni((int)mt.cord[lo - 1]); at = lo; }
+	}
+	if (lower >= 0) {   // test_and_merge
+		const int64_t pos = ema_uni((int64_t)mt.cpos[at - 1]);
+		const uint32_t m0 = (uint32_t)ema_uni((int)mt.csm[3 * lower]), m1 = (uint32_t)ema_uni((int)mt.csm[3 * lower + 1]), m2 = (uint32_t)ema_uni((int)mt.csm[3 * lower + 2]);
+		const int l_delta = (int)m0, c_rid = (int)(m1 & 0xffff), last_seed = (int)(m1 >> 16);
+		const int f_qbeg = (int)(m2 & 0xff), l_qbeg = (int)(m2 >> 8 & 0xff), l_len = (int)(m2 >> 16 & 0xff);
+		const int64_t f_rbeg = pos, l_rbeg = pos + l_delta;
+		const int64_t qend = l_qbeg + l_len, rend = l_rbeg + l_len;
+		if (rid != c_rid) { }
+		else if (qbeg >= f_qbeg && qbeg + len <= qend && rbeg >= f_rbeg && rbeg + len <= rend) return true;      // contained: absorbed
+		else if ((l_rbeg < l_pac || f_rbeg < l_pac) && rbeg >= l_pac) { }                                      // other strand
+		else {
+			const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
+			if (y >= 0 && x - y <= o.w && y - x <= o.w && x - l_len < o.max_chain_gap && y - l_len < o.max_chain_gap) {
+				if (cb.n_seed >= EMA_SEED_CAP) { cb.status |= EMA_ST_SEED_OVERFLOW; return true; }
+				const int id = cb.n_seed++;
+				if (leader) {
+					SeedRec s; s.rbeg = rbeg; s.qbeg = qbeg; s.len = len; s.next = -1; s.pad = 0;
+					cb.sl.seeds[id] = s;
+					cb.sl.seeds[last_seed].next = id;
+					mt.csm[3 * lower] = (uint32_t)(int32_t)(rbeg - pos);
+					mt.csm[3 * lower + 1] = (uint32_t)c_rid | (uint32_t)id << 16;
+					mt.csm[3 * lower + 2] = (uint32_t)f_qbeg | (uint32_t)qbeg << 8 | (uint32_t)len << 16;
+				}
+				ema_wave_sync();
+				return true;
+			}
+		}
+	}
+	// a new chain right after the element the lookup returned
+	if (cb.n_chain >= EMA_MED_CHAINS) return false;
+	if (cb.n_seed >= EMA_SEED_CAP) { cb.status |= EMA_ST_SEED_OVERFLOW; return true; }
+	for (int hi = cb.n_chain; hi > at; hi -= EMA_WAVE) {      // shift [at, n) up by one, top chunk first
+		const int idx = hi - 1 - lane;
+		int64_t v = 0; int32_t id = 0;
+		if (idx >= at) { v = mt.cpos[idx]; id = mt.cord[idx]; }
+		ema_wave_sync();
+		if (idx >= at) { mt.cpos[idx + 1] = v; mt.cord[idx + 1] = id; }
+	}
+	const int sid = cb.n_seed++, cid = cb.n_chain++;
+	ema_wave_sync();
+	if (leader) {
+		SeedRec s; s.rbeg = rbeg; s.qbeg = qbeg; s.len = len; s.next = -1; s.pad = 0;
+		cb.sl.seeds[sid] = s;
+		ChainRec c;
+		c.pos = rbeg; c.f_rbeg = c.l_rbeg = rbeg; c.f_qbeg = c.l_qbeg = qbeg; c.l_len = len;
+		c.rid = rid; c.n = 1; c.first_seed = c.last_seed = sid; c.w = 0; c.kept = 0; c.first = -1;
+		cb.sl.chains[cid] = c;      // l_rbeg, l_qbeg, l_len, last_seed and n are brought up to date by med_settle
+		mt.cpos[at] = rbeg; mt.cord[at] = cid;
+		mt.csm[3 * cid] = 0;
+		mt.csm[3 * cid + 1] = (uint32_t)rid | (uint32_t)sid << 16;
+		mt.csm[3 * cid + 2] = (uint32_t)qbeg | (uint32_t)qbeg << 8 | (uint32_t)len << 16;
+	}
+	ema_wave_sync();
+	return true;
+}
+
 // mem_chain_weight for one chain (walks its seed list); run lane-parallel over chains
-__device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
+__device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first, int *n_seeds = nullptr)
 {
 	int64_t end = 0;
-	int w = 0;
+	int w = 0, cnt = 0;
 	for (int k = first; k >= 0; k = seeds[k].next) {
 		const SeedRec s = seeds[k];
+		++cnt;
 		if (s.qbeg >= end) w += s.len;
 		else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
 		end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
@@ -201,6 +318,7 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 		end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
 	}
 	w = w < tmp ? w : tmp;
+	if (n_seeds) *n_seeds = cnt;
 	return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
@@ -208,17 +326,20 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first)
 
 // one wavefront = one read at a time, reads taken from a shared counter
 // intv/n_intv: K1's output (stride opt.intv_cap).  regs: n_reads x opt.reg_cap, n_regs: n_reads.  status is OR-ed.
-template <int SMALL, int AVL, int WPS>
+// MODE 0: the kernel described above (it sets chain-rich reads aside when hv.arena is given); 1: K2c, 2: K2d (dev_types.h, HeavyCtl)
+template <int SMALL, int AVL, int WPS, int MODE>
 __global__ void __launch_bounds__(256, WPS)
 ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
             int *__restrict__ status, const int *__restrict__ todo, const int *__restrict__ n_todo,
-            const uint8_t *__restrict__ hand, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg, unsigned long long *prof)
+            const uint8_t *__restrict__ hand, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg, unsigned long long *prof,
+            HeavyCtl hv)
 {
 	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
-	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
+	unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
 	int phase = 0;
+	const unsigned long long t_launch = t_prev;
 	// EMA_PHASE_PROFILE=2: one record per read {read, intervals (-1: chains handed over by K2a), seed occurrences, chains, seeds,
 	// regions before dedup, extension DPs run, shader clocks / 16} appended to the log whose address sits in prof[31]
 	int *rlog = prof ? reinterpret_cast<int *>(prof[31]) : nullptr;
@@ -230,11 +351,17 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	__shared__ int lds_stack[4][3 * 70];
 	__shared__ __attribute__((aligned(16))) uint8_t lds_small[4][EMA_SMALL_BYTES(SMALL)];
 	__shared__ __attribute__((aligned(16))) uint8_t lds_av[4][EMA_AVL_BYTES(AVL)];      // regions of the read while there are few
+	// the medium layout needs 4 KB of small-table area, the 2 KB window buffer and 1 KB of region-list area
+	constexpr bool MED = EMA_SMALL_BYTES(SMALL) >= 4096 && EMA_RSEQ_CAP >= EMA_MED_CHAINS * 8 && (AVL > 0 && EMA_AVL_BYTES(AVL) >= EMA_MED_CHAINS * 4);
 	const int lane = (int)ema_lane();
 	const int wib = (int)(threadIdx.x >> 6);
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
 	uint8_t *query = lds_q[wib];
 	uint8_t *rseq = lds_r[wib];
+	MedTables mt;      // medium layout while chaining: positions in the window buffer, summaries and ids in the small-table area
+	mt.cpos = (EMA_LDS int64_t *)(&lds_r[wib][0]);      // (address-space casts: C style)
+	mt.csm = (EMA_LDS uint32_t *)(&lds_small[wib][0]);
+	mt.cord = (EMA_LDS int32_t *)(&lds_small[wib][3072]);
 	ChainBuild cb;
 	const AlignSlab slab = ema_carve_slab(slabs + (size_t)slot * EMA_ALIGN_SLAB_BYTES);
 	cb.sl = slab;
@@ -245,9 +372,26 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
-		if (read >= (todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2))) break;
+		if (read >= (MODE == 1 ? *hv.n_tasks : MODE == 2 ? *hv.n_reads : todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2))) {
+			if (MODE == 0 && prof && lane == 0 && opt.reg_cap <= EMA_REG_LEAN) atomicMin(prof + 27, (unsigned long long)__builtin_amdgcn_s_memtime());      // the queue ran dry (lean tier)
+			break;
+		}
 		bool handed = false;      // K2a already chained and filtered this read (dev_types.h, EMA_HAND_*)
-		if (todo) {
+		const uint8_t *rec = nullptr;      // MODE 1, 2: the record of the read set aside
+		int task_chain = -1;               // MODE 1: the chain of this task (index in filtered order)
+		if (MODE == 1) {
+			if (read >= hv.tasks_cap) break;
+			const unsigned long long t = ema_uni((uint64_t)hv.tasks[read]);
+			if (t == ~0ULL) continue;      // a claim K2b gave back
+			rec = hv.arena + (size_t)(t >> 32) * 64; task_chain = (int)(uint32_t)t;
+			read = ema_uni(reinterpret_cast<const HeavyHdr *>(rec)->read);
+		} else if (MODE == 2) {
+			if (read >= hv.reads_cap) break;
+			const unsigned long long t = ema_uni((uint64_t)hv.reads[read]);
+			if (t == ~0ULL) continue;
+			rec = hv.arena + (size_t)t;
+			read = ema_uni(reinterpret_cast<const HeavyHdr *>(rec)->read);
+		} else if (todo) {
 			const unsigned t = (unsigned)ema_uni(todo[read]);
 			handed = (t & EMA_HAND_FLAG) != 0;
 			read = (int)(t & ~EMA_HAND_FLAG);
@@ -257,8 +401,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		int log_iv = -1, log_occ = 0;
 		n_dp = 0;
 		EMA_DBG(1, 0);
-		EMA_PHASE(1);
-		if (ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
+		EMA_PHASE(6);      // 6: the read and (handed reads) K2a's record arrive
+		if (MODE == 0 && ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
 			if (lane == 0) n_regs[read] = 0;
 			EMA_DBG(9, 0);
 			continue;
@@ -270,7 +414,25 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		float frac_rep = 0.f;
 		int n_chn = 0, n_keep = 0;
 		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
-		if (handed) {
+		bool med = false;         // the medium layout (see the head of the file) is in force
+		const int32_t *hv_first = nullptr;      // MODE 1, 2: per chain (filtered order) the first slot of its seeds in the tables below
+		SeedRec *hv_cs = nullptr; DevReg *hv_res = nullptr; uint8_t *hv_valid = nullptr;
+		if (MODE != 0) {
+			// the tables as K2b left them: read where they are
+			const HeavyHdr *h = reinterpret_cast<const HeavyHdr *>(rec);
+			cb.sl = slab;
+			cb.sl.skey = reinterpret_cast<uint64_t *>(const_cast<uint8_t *>(rec) + ema_uni(h->off_skey));
+			cb.sl.chains = reinterpret_cast<ChainRec *>(const_cast<uint8_t *>(rec) + ema_uni(h->off_chains));
+			cb.sl.seeds = reinterpret_cast<SeedRec *>(const_cast<uint8_t *>(rec) + ema_uni(h->off_seeds));
+			hv_first = reinterpret_cast<const int32_t *>(rec + ema_uni(h->off_first));
+			hv_cs = reinterpret_cast<SeedRec *>(const_cast<uint8_t *>(rec) + ema_uni(h->off_cs));
+			hv_res = reinterpret_cast<DevReg *>(const_cast<uint8_t *>(rec) + ema_uni(h->off_res));
+			hv_valid = const_cast<uint8_t *>(rec) + ema_uni(h->off_valid);
+			n_chn = ema_uni(h->n_chn); n_keep = n_chn;
+			cb.n_chain = ema_uni(h->n_chain); cb.n_seed = ema_uni(h->n_seed);
+			cb.status = MODE == 2 ? ema_uni(h->status) : 0;
+			frac_rep = ema_uni(h->frac_rep);
+		} else if (handed) {
 			// small tables in LDS, filled from K2a's record
 			cb.sl = slab;
 			ema_small_tables<SMALL>(cb.sl, lds_small[wib]);
@@ -287,6 +449,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			n_keep = n_chn;
 			ema_wave_sync();
 		} else {
+		EMA_PHASE(10);      // 10: the intervals in order, the repetitive fraction
 		const int n_iv = ema_uni(n_intv[read]);
 		const Intv *iv = slab.ivs;
 		{   // K1 delivers the intervals in discovery order; mem_collect_intv ends with a sort on (start, end).
@@ -320,6 +483,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			l_rep += e - b;
 			cb.sl = slab;
 			if (ema_uni(tot_occ <= SMALL)) ema_small_tables<SMALL>(cb.sl, lds_small[wib]);
+			else if (MED && ix.n_seqs <= 0xffff) med = true;      // (the summaries keep a contig id in 16 bits)
 			log_iv = n_iv; log_occ = (int)(tot_occ < (1 << 30) ? tot_occ : (1 << 30));
 		}
 		frac_rep = (float)l_rep / (float)l_query;
@@ -331,6 +495,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			int64_t n_occ = ((int64_t)p.x2 + step - 1) / step;        // k = 0, step, ... < size
 			if (n_occ > opt.max_occ) n_occ = opt.max_occ;
 			for (int64_t base = 0; base < n_occ; base += EMA_WAVE) {
+				EMA_PHASE(11);      // 11: suffix-array rows and contig ids of up to 64 occurrences
 				const int64_t idx = base + lane;
 				int64_t rbeg = 0; int rid = -1;
 				if (idx < n_occ) {      // consecutive suffix-array rows (step 1) -> coalesced loads
@@ -338,10 +503,32 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					rid = ema_intv2rid(ix, rbeg, rbeg + slen);
 				}
 				const int cnt = (int)(n_occ - base < EMA_WAVE ? n_occ - base : EMA_WAVE);
+				EMA_PHASE(1);      // 1: the insertions
 				for (int t = 0; t < cnt; ++t) {
 					const int64_t rb = ema_uni(__shfl(rbeg, t));
 					const int rd = ema_uni(__shfl(rid, t));
 					if (rd < 0) continue;
+					if (MED && med) {
+						if (chain_insert_med(opt, l_pac, cb, mt, rb, qbeg, slen, rd)) continue;
+						// EMA_MED_CHAINS chains and one more to open: the chain records are brought up to date, the position table moves to
+						// the slab, and the read carries on in the slab layout
+						ema_wave_sync();
+#ifdef EMA_EMU_TRACE
+						if (lane == 0) fprintf(stderr, "K2b medium layout outgrown at %d chains\n", cb.n_chain);
+#endif
+						for (int k = lane; k < cb.n_chain; k += EMA_WAVE) {
+							const int id = mt.cord[k];
+							const int64_t pos = mt.cpos[k];
+							const uint32_t m0 = mt.csm[3 * id], m1 = mt.csm[3 * id + 1], m2 = mt.csm[3 * id + 2];
+							int cnt = 0;
+							(void)chain_weight(sl.seeds, sl.chains[id].first_seed, &cnt);
+							sl.chains[id].l_rbeg = pos + (int32_t)m0; sl.chains[id].l_qbeg = (int)(m2 >> 8 & 0xff); sl.chains[id].l_len = (int)(m2 >> 16 & 0xff);
+							sl.chains[id].last_seed = (int)(m1 >> 16); sl.chains[id].n = cnt;
+							slab.cpos[k] = pos; slab.cord[k] = id;
+						}
+						med = false;
+						ema_wave_sync();
+					}
 					chain_insert(opt, l_pac, cb, rb, qbeg, slen, rd);
 				}
 			}
@@ -351,7 +538,97 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		n_chn = cb.n_chain; n_keep = 0;
 		EMA_DBG(3, n_chn);
 		EMA_PHASE(2);
-		if (n_chn > 0) {
+		if (MED && med && n_chn > 0) {
+#ifdef EMA_EMU_TRACE
+			if (lane == 0) fprintf(stderr, "K2b medium layout: read %d, %d chains, %d seeds\n", read, n_chn, cb.n_seed);
+#endif
+			// the filter on LDS: keys, per-chain summaries (indexed by chain id), kept list.  These overlay the chaining tables, so
+			// every lane first takes its (up to four) chains' entries into registers.
+			uint64_t *skey = reinterpret_cast<uint64_t *>(lds_small[wib] + 1024);
+			uint64_t *csum = reinterpret_cast<uint64_t *>(rseq);      // w << 32 | end << 16 | beg << 8 | kept flag
+			uint16_t *kept = reinterpret_cast<uint16_t *>(lds_av[wib]);
+			int16_t *firstk = reinterpret_cast<int16_t *>(lds_av[wib] + 2 * EMA_MED_CHAINS);
+			int64_t my_pos[EMA_MED_CHAINS / EMA_WAVE];
+			int my_id[EMA_MED_CHAINS / EMA_WAVE];
+			uint32_t my_m0[EMA_MED_CHAINS / EMA_WAVE], my_m1[EMA_MED_CHAINS / EMA_WAVE], my_m2[EMA_MED_CHAINS / EMA_WAVE];
+#pragma unroll
+			for (int r = 0; r < EMA_MED_CHAINS / EMA_WAVE; ++r) {
+				const int i = lane + r * EMA_WAVE;
+				my_id[r] = 0; my_pos[r] = 0; my_m0[r] = my_m1[r] = my_m2[r] = 0;
+				if (i < n_chn) {
+					const int id = mt.cord[i];
+					my_id[r] = id; my_pos[r] = mt.cpos[i];
+					my_m0[r] = mt.csm[3 * id]; my_m1[r] = mt.csm[3 * id + 1]; my_m2[r] = mt.csm[3 * id + 2];
+				}
+			}
+			ema_wave_sync();
+#pragma unroll
+			for (int r = 0; r < EMA_MED_CHAINS / EMA_WAVE; ++r) {      // weights, chains taken in position order; records brought up to date
+				const int i = lane + r * EMA_WAVE;
+				if (i < n_chn) {
+					const int id = my_id[r];
+					int cnt = 0;
+					const int w = chain_weight(sl.seeds, sl.chains[id].first_seed, &cnt);
+					const int f_qbeg = (int)(my_m2[r] & 0xff), l_qbeg = (int)(my_m2[r] >> 8 & 0xff), l_len = (int)(my_m2[r] >> 16 & 0xff);
+					sl.chains[id].l_rbeg = my_pos[r] + (int32_t)my_m0[r]; sl.chains[id].l_qbeg = l_qbeg; sl.chains[id].l_len = l_len;
+					sl.chains[id].last_seed = (int)(my_m1[r] >> 16); sl.chains[id].n = cnt; sl.chains[id].w = w;
+					skey[i] = (uint64_t)(uint32_t)w << 32 | (uint32_t)id;
+					csum[id] = (uint64_t)(uint32_t)w << 32 | (uint64_t)(uint32_t)(l_qbeg + l_len) << 16 | (uint64_t)(uint32_t)f_qbeg << 8;
+				}
+			}
+			ema_wave_sync();
+			if (lane == 0) ema_introsort(skey, n_chn, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, lds_stack[wib]);
+			ema_wave_sync();
+			EMA_DBG(4, n_chn);
+			uint8_t *flag = reinterpret_cast<uint8_t *>(csum);      // byte 0 of a summary
+			int n_kept = 1;
+			if (lane == 0) { flag[(size_t)(uint32_t)skey[0] << 3] = 3; kept[0] = 0; firstk[0] = -1; }
+			ema_wave_sync();
+			for (int i = 1; i < n_chn; ++i) {
+				const int ci = ema_uni((int)(uint32_t)skey[i]);
+				const uint64_t s_i = ema_uni(csum[ci]);
+				const int beg_i = (int)(s_i >> 8 & 0xff), end_i = (int)(s_i >> 16 & 0xffff), w_i = (int)(s_i >> 32);
+				bool large_ovlp = false, dropped = false;
+				for (int base = 0; base < n_kept && !dropped; base += EMA_WAVE) {
+					const int k = base + lane;
+					const bool valid = k < n_kept;
+					const uint64_t s_j = valid ? csum[(uint32_t)skey[kept[k]]] : s_i;
+					const int beg_j = (int)(s_j >> 8 & 0xff), end_j = (int)(s_j >> 16 & 0xffff), w_j = (int)(s_j >> 32);
+					const int b_max = beg_j > beg_i ? beg_j : beg_i;
+					const int e_min = end_j < end_i ? end_j : end_i;
+					bool ovlp = false, drop = false;
+					if (valid && e_min > b_max) {
+						const int li = end_i - beg_i, lj = end_j - beg_j;
+						const int min_l = li < lj ? li : lj;
+						if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+							ovlp = true;
+							if ((float)w_i < (float)w_j * opt.drop_ratio && w_j - w_i >= opt.min_seed_len << 1) drop = true;
+						}
+					}
+					const unsigned long long bd = __ballot(drop);
+					const int first_drop = bd ? __ffsll((long long)bd) - 1 : EMA_WAVE;
+					const bool counted = ovlp && lane <= first_drop;
+					if (counted && firstk[k] < 0) firstk[k] = (int16_t)i;
+					if (__ballot(counted)) large_ovlp = true;
+					if (bd) dropped = true;
+				}
+				if (!dropped) {
+					if (lane == 0) { kept[n_kept] = (uint16_t)i; firstk[n_kept] = -1; flag[(size_t)ci << 3] = large_ovlp ? 2 : 3; }
+					++n_kept;
+					ema_wave_sync();
+				}
+			}
+			ema_wave_sync();
+			for (int k = lane; k < n_kept; k += EMA_WAVE) {
+				const int f = firstk[k];
+				if (f >= 0) flag[(size_t)(uint32_t)skey[f] << 3] = 1;
+			}
+			ema_wave_sync();
+			for (int id = lane; id < n_chn; id += EMA_WAVE) sl.chains[id].kept = flag[(size_t)id << 3];      // back to the records
+			cb.sl.skey = skey;
+			n_keep = n_chn;
+			ema_wave_sync();
+		} else if (n_chn > 0) {
 			for (int i = lane; i < n_chn; i += EMA_WAVE) {      // weights, chains taken in position order
 				const int id = sl.cord[i];
 				const int w = chain_weight(sl.seeds, sl.chains[id].first_seed);
@@ -416,6 +693,87 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 		}
 
+		// ---------------- a chain-rich read is set aside for K2c / K2d (dev_types.h, HeavyCtl) ----------------
+		if (MODE == 0 && hv.arena && !handed && n_keep >= hv.min_chains) {
+			int n_ext = 0, tot = 0;      // chains to extend, their seeds
+			for (int base = 0; base < n_keep; base += EMA_WAVE) {
+				const int i = base + lane;
+				int v = 0;
+				if (i < n_keep) { const ChainRec &c = sl.chains[(int)(uint32_t)sl.skey[i]]; if (c.kept != 0) v = c.n; }
+				n_ext += __popcll(__ballot(v > 0));
+				tot += ema_wave_sum(v);
+			}
+			if (n_ext >= hv.min_chains) {
+				auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+				HeavyHdr h;
+				h.read = read; h.n_chn = n_chn; h.n_chain = cb.n_chain; h.n_seed = cb.n_seed; h.status = cb.status; h.n_ext = n_ext;
+				h.frac_rep = frac_rep; h.pad = 0;
+				h.off_skey = up64(sizeof(HeavyHdr));
+				h.off_chains = h.off_skey + up64((size_t)n_chn * 8);
+				h.off_seeds = h.off_chains + up64((size_t)cb.n_chain * sizeof(ChainRec));
+				h.off_first = h.off_seeds + up64((size_t)cb.n_seed * sizeof(SeedRec));
+				h.off_cs = h.off_first + up64((size_t)(n_chn + 1) * 4);
+				h.off_res = h.off_cs + up64((size_t)tot * sizeof(SeedRec));
+				h.off_valid = h.off_res + up64((size_t)tot * sizeof(DevReg));
+				h.bytes = h.off_valid + up64((size_t)tot);
+				// a place on the read list, room on the task list, room in the arena -- or the read is extended here after all
+				// (entries already claimed are marked void for their consumers)
+				long long ri = -1, tb = -1, at = -1;
+				if (lane == 0) {
+					ri = atomicAdd(hv.n_reads, 1);
+					if (ri >= hv.reads_cap) ri = -1;
+					if (ri >= 0) {
+						tb = atomicAdd(hv.n_tasks, n_ext);
+						if (tb + n_ext > hv.tasks_cap) {
+							for (long long j = tb; j < hv.tasks_cap && j < tb + n_ext; ++j) hv.tasks[j] = ~0ULL;
+							tb = -1;
+						}
+					}
+					if (tb >= 0) {
+						at = (long long)atomicAdd(hv.arena_used, (unsigned long long)h.bytes);
+						if ((unsigned long long)at + h.bytes > hv.arena_bytes) {
+							for (long long j = tb; j < tb + n_ext; ++j) hv.tasks[j] = ~0ULL;
+							at = -1;
+						}
+					}
+					if (ri >= 0) hv.reads[ri] = at >= 0 ? (unsigned long long)at : ~0ULL;
+				}
+				at = (long long)ema_uni((int64_t)__shfl(at, 0)); tb = (long long)ema_uni((int64_t)__shfl(tb, 0));
+				if (at >= 0) {
+					uint8_t *rc = hv.arena + at;
+					if (lane == 0) *reinterpret_cast<HeavyHdr *>(rc) = h;
+					uint64_t *d_skey = reinterpret_cast<uint64_t *>(rc + h.off_skey);
+					ChainRec *d_chains = reinterpret_cast<ChainRec *>(rc + h.off_chains);
+					SeedRec *d_seeds = reinterpret_cast<SeedRec *>(rc + h.off_seeds);
+					int32_t *d_first = reinterpret_cast<int32_t *>(rc + h.off_first);
+					uint8_t *d_valid = rc + h.off_valid;
+					for (int i = lane; i < cb.n_chain; i += EMA_WAVE) d_chains[i] = sl.chains[i];
+					for (int i = lane; i < cb.n_seed; i += EMA_WAVE) d_seeds[i] = sl.seeds[i];
+					for (int i = lane; i < tot; i += EMA_WAVE) d_valid[i] = 0;
+					int run = 0, run_ext = 0;
+					for (int base = 0; base < n_keep; base += EMA_WAVE) {
+						const int i = base + lane;
+						int v = 0;
+						uint64_t key = 0;
+						if (i < n_keep) { key = sl.skey[i]; const ChainRec &c = sl.chains[(int)(uint32_t)key]; if (c.kept != 0) v = c.n; }
+						const int incl = ema_wave_incl_scan_add(v);
+						const unsigned long long ext = __ballot(v > 0);
+						if (i < n_keep) {
+							d_skey[i] = key;
+							d_first[i] = run + incl - v;
+							if (v > 0) hv.tasks[tb + run_ext + __popcll(ext & ((1ULL << lane) - 1))] = (unsigned long long)(at >> 6) << 32 | (uint32_t)i;
+						}
+						run += ema_uni(__builtin_amdgcn_readlane(incl, 63));
+						run_ext += __popcll(ext);
+					}
+					if (lane == 0) d_first[n_keep] = run;
+					EMA_DBG(9, -n_ext);
+					EMA_PHASE(0);
+					continue;
+				}
+			}
+		}
+
 		// regions start out in LDS (sorting and de-duplicating a handful of them in the HBM slab is dozens of dependent round
 		// trips); the list moves to the slab when it outgrows AVL
 		bool av_lds = AVL > 0;
@@ -427,13 +785,25 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		int n_av = 0;
 		EMA_DBG(5, n_keep);
 		EMA_PHASE(3);
-		for (int ci_sorted = 0; ci_sorted < n_keep; ++ci_sorted) {
+		for (int ci_sorted = MODE == 1 ? task_chain : 0; ci_sorted < (MODE == 1 ? task_chain + 1 : n_keep); ++ci_sorted) {
 			EMA_DBG(6, ci_sorted);
 			const int cid = ema_uni((int)(uint32_t)sl.skey[ci_sorted]);
 			const ChainRec c = ema_uni(sl.chains[cid]);
 			if (c.kept == 0) continue;
 			const int cn = c.n;
-			{   // gather the chain's seeds
+			EMA_PHASE(7);      // 7: per chain -- its seeds, the window bounds, the window fetch, the seed order
+			const int hv_base = MODE != 0 ? ema_uni(hv_first[ci_sorted]) : 0;      // MODE 1, 2: the chain's slots in cs / res / valid
+			if ((MED && med) || MODE != 0) {      // the chain's seed copies and their order in LDS when they fit the small-table area's 1 KB head
+				const bool fits = cn <= 32;
+				cb.sl.cs = fits ? reinterpret_cast<SeedRec *>(lds_small[wib]) : slab.cs;
+				cb.sl.srt = fits ? reinterpret_cast<uint64_t *>(lds_small[wib] + 32 * sizeof(SeedRec)) : slab.srt;
+			}
+			if (MODE == 2) {
+				// K2c left the seeds in processing order: entry p is the seed the loop below visits as k = cn - 1 - p
+				cb.sl.cs = hv_cs + hv_base;
+				for (int t = lane; t < cn; t += EMA_WAVE) sl.srt[t] = (uint64_t)1 << 32 | (uint32_t)(cn - 1 - t);
+				ema_wave_sync();
+			} else {   // gather the chain's seeds
 				int k = c.first_seed;
 				for (int t = 0; t < cn; ++t) { const SeedRec s = ema_uni(sl.seeds[k]); if (lane == 0) sl.cs[t] = s; k = s.next; }
 				ema_wave_sync();
@@ -446,7 +816,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				const int64_t e = s.rbeg + s.len + (tail + cal_max_gap(opt, tail));
 				rmax0 = rmax0 < b ? rmax0 : b;
 				rmax1 = rmax1 > e ? rmax1 : e;
-				sl.srt[t] = (uint64_t)(uint32_t)s.len << 32 | (uint32_t)t;      // score == len
+				if (MODE != 2) sl.srt[t] = (uint64_t)(uint32_t)s.len << 32 | (uint32_t)t;      // score == len
 			}
 			for (int m = 1; m < EMA_WAVE; m <<= 1) {
 				const int64_t o0 = __shfl_xor(rmax0, m), o1 = __shfl_xor(rmax1, m);
@@ -461,15 +831,20 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			}
 			ema_clamp_window(ix, rmax0, c.f_rbeg, rmax1);
 			if (rmax1 - rmax0 > EMA_RSEQ_CAP) { cb.status |= EMA_ST_RSEQ_OVERFLOW; continue; }
-			ema_wave_fetch(ix, rmax0, rmax1, rseq);
-			// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
-			ema_wave_sync();
-			if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
-			ema_wave_sync();
+			bool have_win = MODE != 2;      // K2d fetches the window only if it has to run a DP itself
+			if (MODE != 2) {
+				ema_wave_fetch(ix, rmax0, rmax1, rseq);
+				// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
+				ema_wave_sync();
+				if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
+				ema_wave_sync();
+			}
 
+			EMA_PHASE(3);
 			for (int k = cn - 1; k >= 0; --k) {
 				EMA_DBG(7, k);
 				const SeedRec s = ema_uni(sl.cs[(int)(uint32_t)sl.srt[k]]);
+				if (MODE == 1 && lane == 0) hv_cs[hv_base + (cn - 1 - k)] = s;
 				// already covered by an earlier extension of this read?
 				bool covered = false;
 				for (int base = 0; base < n_av && !covered; base += EMA_WAVE) {
@@ -519,6 +894,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				}
 
 				DevReg a;
+				if (MODE == 2 && ema_uni((int)hv_valid[hv_base + (cn - 1 - k)]) != 0) {
+					a = ema_uni(hv_res[hv_base + (cn - 1 - k)]);      // K2c extended this seed
+				} else {
+				if (MODE == 2 && !have_win) { ema_wave_fetch(ix, rmax0, rmax1, rseq); ema_wave_sync(); have_win = true; }
 				a.sub = a.csub = a.secondary = a.n_comp = a.is_alt = 0; a.seedcov = 0;
 				int aw0 = opt.w, aw1 = opt.w;
 				a.score = a.truesc = -1;
@@ -560,7 +939,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						a.qe = l_query; a.re = rmax0 + re + r.gtle; a.truesc += r.gscore - sc0;
 					}
 				} else { a.qe = l_query; a.re = s.rbeg + s.len; }
-				EMA_PHASE(3);
+				EMA_PHASE(8);      // 8: after the DPs -- seedcov, the region record
 				{   // seedcov: seeds of the chain fully inside the region
 					int cov = 0;
 					for (int t = lane; t < cn; t += EMA_WAVE) {
@@ -572,12 +951,16 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				a.w = aw0 > aw1 ? aw0 : aw1;
 				a.seedlen0 = s.len;
 				a.frac_rep = frac_rep;
+				}
+				if (MODE == 1 && lane == 0) { hv_res[hv_base + (cn - 1 - k)] = a; hv_valid[hv_base + (cn - 1 - k)] = 1; }
 				if (lane == 0) sl.av[n_av] = a;
 				++n_av;
 				ema_wave_sync();
+				EMA_PHASE(3);
 			}
 		}
 
+		if (MODE == 1) { EMA_PHASE(0); continue; }      // K2c: this chain's results are in the record
 		// ---------------- mem_sort_dedup_patch ----------------
 		EMA_DBG(8, n_av);
 		EMA_PHASE(5);
@@ -585,6 +968,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
 		if (n_out > opt.reg_cap) { cb.status |= EMA_ST_REG_OVERFLOW; n_out = opt.reg_cap; }
 		ema_wave_sync();
+		EMA_PHASE(9);      // 9: results out
 		DevReg *dst = regs + (size_t)read * opt.reg_cap;
 		for (int i = lane; i < n_out; i += EMA_WAVE) dst[i] = sl.av[i];
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
@@ -599,7 +983,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			}
 		}
 	}
-	if (prof && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(prof + i, acc[i]);
+	if (prof && lane == 0 && opt.reg_cap <= EMA_REG_LEAN) {      // lean-tier launch start / end as the waves saw them (slots 26, 28)
+		atomicMin(prof + 26, t_launch); atomicMax(prof + 28, (unsigned long long)__builtin_amdgcn_s_memtime());
+	}
+	if (prof && lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(prof + (i < 8 ? i : i + 4), acc[i]);      // 8.. -> slots 12.. (8..11 are K1's)
 #undef EMA_DBG
 #undef EMA_PHASE
 }
@@ -613,14 +1000,19 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
                                  const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs, int *counter, int n_blocks,
                                  hipStream_t stream, int *dbg,
-                                 unsigned long long *prof, int variant)
+                                 unsigned long long *prof, int variant, const HeavyCtl *heavy, int mode)
 {
+	HeavyCtl hv;
+	if (heavy) hv = *heavy;
+	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
 #define EMA_ALIGN_LAUNCH(...) hipLaunchKernelGGL((ema_k_align_t<__VA_ARGS__>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs, \
-	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof)
-	if (variant == 1) EMA_ALIGN_LAUNCH(EMA_MID_SEEDS, 24, 1);
-	else if (variant == 2) EMA_ALIGN_LAUNCH(32, 0, 4);
-	else if (variant == 3) EMA_ALIGN_LAUNCH(80, 16, 2);
-	else EMA_ALIGN_LAUNCH(32, 8, 4);
+	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof, hv)
+	if (mode == 1) EMA_ALIGN_LAUNCH(32, 8, 4, 1);      // K2c: one chain of a read set aside per wavefront
+	else if (mode == 2) EMA_ALIGN_LAUNCH(32, 8, 4, 2); // K2d: the replay of a read set aside
+	else if (variant == 1) EMA_ALIGN_LAUNCH(EMA_MID_SEEDS, 24, 1, 0);
+	else if (variant == 2) EMA_ALIGN_LAUNCH(32, 0, 4, 0);
+	else if (variant == 3) EMA_ALIGN_LAUNCH(80, 16, 2, 0);
+	else EMA_ALIGN_LAUNCH(32, 8, 4, 0);
 #undef EMA_ALIGN_LAUNCH
 }
 
@@ -628,14 +1020,14 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 extern "C" int ema_align_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4>, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4, 0>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }
 extern "C" int ema_align_mid_blocks_per_cu(int variant)
 {
 	int n = 0;
-	hipError_t rc = variant == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<80, 16, 2>, 256, 0)
-	                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1>, 256, 0);
+	hipError_t rc = variant == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<80, 16, 2, 0>, 256, 0)
+	                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1, 0>, 256, 0);
 	if (rc != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

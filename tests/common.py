@@ -33,6 +33,19 @@ def small_ref(kind="two_contigs"):
             dst = src + (15000 if k % 3 == 0 else 140000) % (len(g) - 10000)
             dst = dst % (len(g) - 4000)
             g[dst:dst + 3000] = g[src:src + 3000]
+    elif kind == "repeat_family":   # 640 diverged copies (2.5 %) of a 500 bp element, either strand, 800 bp apart: reads from a copy have
+        ctg = synth.make_genome([530000], seed=23)      # dozens to hundreds of seed occurrences and chains (K2b's medium layout, and
+        rng = np.random.default_rng(23)                 # beyond EMA_MED_CHAINS = 256 chains its move to the slab)
+        g = ctg[0]
+        elem = rng.integers(0, 4, 500).astype(np.uint8)
+        for k in range(640):
+            e = elem.copy()
+            hit = rng.random(500) < 0.025
+            e[hit] = (e[hit] + rng.integers(1, 4, int(hit.sum()))) % 4
+            if k & 1:
+                e = (3 - e)[::-1]
+            at = 3000 + 800 * k
+            g[at:at + 500] = e
     elif kind == "mid":          # a few Mbp for GPU throughput smoke tests
         ctg = synth.make_genome([3000000, 1000000], seed=11)
     else:

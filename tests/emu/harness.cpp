@@ -58,11 +58,32 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 		                        &n_todo, mid ? todo_mid.data() : nullptr, &n_todo_mid, EMA_MID_SEEDS, hand.data(), n_blocks, nullptr, nullptr);
 		fprintf(stderr, "emu K2a: %d + %d (LDS build) of %d reads left for K2b\n", n_todo, n_todo_mid, n_reads);
 	}
+	// EMU_HEAVY_CHAINS=n: K2b sets reads with at least n chains to extend aside for K2c / K2d (EMU_HEAVY_ARENA: arena bytes, to run it full)
+	const char *vh = getenv("EMU_HEAVY_CHAINS");
+	const int heavy_chains = vh ? atoi(vh) : 0;
+	HeavyCtl hv;
+	std::vector<uint8_t> arena;
+	std::vector<unsigned long long> hreads, htasks, used(1, 0);
+	int hn[4] = {0, 0, 0, 0};
+	if (heavy_chains > 0) {
+		const char *va = getenv("EMU_HEAVY_ARENA");
+		arena.resize(va ? (size_t)atol(va) : (size_t)256 << 20);
+		hreads.resize(getenv("EMU_HEAVY_READS") ? atoi(getenv("EMU_HEAVY_READS")) : n_reads + 1);
+		htasks.resize(getenv("EMU_HEAVY_TASKS") ? atoi(getenv("EMU_HEAVY_TASKS")) : 1 << 20);
+		hv.arena = arena.data(); hv.arena_bytes = arena.size(); hv.arena_used = used.data(); hv.reads = hreads.data(); hv.tasks = htasks.data();
+		hv.n_reads = &hn[0]; hv.n_tasks = &hn[1]; hv.reads_cap = (int)hreads.size(); hv.tasks_cap = (int)htasks.size(); hv.min_chains = heavy_chains;
+	}
 	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,
-	                 &c1, n_blocks, nullptr, nullptr, nullptr, 0);
+	                 &c1, n_blocks, nullptr, nullptr, nullptr, 0, heavy_chains > 0 ? &hv : nullptr, 0);
 	if (mid)
 		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, todo_mid.data(), &n_todo_mid, hand.data(), slabs,
-		                 &c2, n_blocks, nullptr, nullptr, nullptr, 1);
+		                 &c2, n_blocks, nullptr, nullptr, nullptr, 1, nullptr, 0);
+	if (heavy_chains > 0) {
+		fprintf(stderr, "emu K2b: %d reads set aside, %d chain tasks, %llu arena bytes\n", hn[0], hn[1], used[0]);
+		for (int mode = 1; mode <= 2; ++mode)
+			ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, nullptr, nullptr, hand.data(), slabs,
+			                 &hn[1 + mode], n_blocks, nullptr, nullptr, nullptr, 0, &hv, mode);
+	}
 }
 
 extern "C" {

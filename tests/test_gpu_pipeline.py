@@ -95,6 +95,11 @@ def test_pipeline_repeats():
     _check("repeats", 600, 44)
 
 
+def test_pipeline_repeat_family():
+    """The 640-copy diverged repeat end to end (lean tier, full-capacity tier for the reads that outgrow it, rescue, CIGARs)."""
+    _check("repeat_family", 200, 45)
+
+
 def test_pipeline_empty_and_ragged_batches():
     prefix, ctg = small_ref("two_contigs")
     eng = Engine(prefix)

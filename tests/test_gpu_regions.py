@@ -50,3 +50,9 @@ def test_regions_ngaps_reference():
 
 def test_regions_250bp():
     _check("repeats", 300, 35, len1=250, len2=250, indel_rate=0.002)
+
+
+def test_regions_repeat_family():
+    """Reads from a 640-copy diverged repeat: dozens to several hundred seed occurrences and chains per read -- K2b's medium
+    layout (chain positions, filter keys and kept list in LDS up to 256 chains) and its move to the slab beyond that."""
+    _check("repeat_family", 250, 36)

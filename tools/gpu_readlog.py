@@ -12,8 +12,13 @@ wd = os.environ.get("EMA_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "ema
 reads = sorted(glob.glob(os.path.join(wd, "reads_*.npz")))[0]
 z = np.load(reads)
 o = default_opts(); o.batch_pairs = (len(z["off"]) - 1) // 2
+bases, off = z["bases"], z["off"]
+if os.environ.get("EMA_READLOG_ONE_SLICE"):      # one lean slice of the batch on its own: K2b's queue-dry / last-wave-out times are those of one launch
+    n1 = o.batch_pairs // 3
+    off = off[:2 * n1 + 1]; bases = bases[:off[-1]]
+    o.n_streams = 1
 eng = Engine(os.path.join(wd, "ref.fa"), opts=o)
-eng.stage(z["bases"], z["off"])
+eng.stage(bases, off)
 eng.run(); eng.sync()
 eng.timing()                       # prints the phase split, resets the phase counters
 eng._L.ema_engine_debug_readlog.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_size_t)]

@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 VALU_PEAK_GINST = 256 * 4 * 0.5 * 2.4
 CHR20_LEN = 64_444_167
 ENGINE_KNOBS = ("EMA_SEED_ROUNDS", "EMA_SEED_PARK", "EMA_SEED_BLOCKS_PER_CU", "EMA_FULL_SEED_LANE", "EMA_LANE_ALIGN", "EMA_FULL_OWN_STREAM",
-                "EMA_KMER_K")
+                "EMA_KMER_K", "EMA_MID_ALIGN", "EMA_AV_LDS", "EMA_HEAVY_CHAINS")
 
 
 def log(*a):
@@ -237,7 +237,7 @@ def main(argv=None):
     ap.add_argument("--streams", type=int, default=0, help="slices of a batch on their own HIP streams (0 = engine default)")
     ap.add_argument("--lean-seed-extends", type=int, default=0, help="engine option lean_seed_extends (0 = engine default)")
     ap.add_argument("--two-sets", action="store_true", help="the older schedule: alternate batches on two sets of batch buffers, one pass each "
-                                                            "(default: one set, passes queued two deep with the layout and packing on the device)")
+                                                            "(default: one set, passes queued up to three deep with the layout and packing on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / engine_resident / isolated passes (profiling runs)")
     ap.add_argument("--allow-capacity-flags", action="store_true", help="print the (invalid) line even if reads overflowed an engine capacity")
@@ -440,7 +440,7 @@ def main(argv=None):
         boundary = {"value": round(args.pairs * args.steps * world / el_b, 1), "unit": "pairs/s", "ms_per_step": round(el_b / args.steps * 1e3, 3),
                     "what": "host buffers in (ASCII reads) -> candidates + append_alignments records in host memory, "
                             "ema_stream_batches over the same batches: nt4 conversion, 2-bit packing, H2D, K1-K4, pack, D2H, append stage, "
-                            f"pipelined: " + ("two sets of batch buffers, one pass each" if n_sets == 2 else "one set, passes queued two deep (ema_engine_run_async), staging / kernels / fetch + append of consecutive batches overlapping"),
+                            f"pipelined: " + ("two sets of batch buffers, one pass each" if n_sets == 2 else "one set, passes queued up to three deep (ema_engine_run_async), staging / kernels / fetch + append of consecutive batches overlapping"),
                     "host_s_per_step": {"align_call": round(float(np.mean([s["align_s"] for s in st_b])), 4),
                                         "append": round(float(np.mean([s["append_s"] for s in st_b])), 4)}}
         # ---- kernels only, queued back to back on one set (nothing fetched): round 1's figure, for continuity
@@ -528,12 +528,16 @@ def main(argv=None):
             roofline["all_kernels_ms_isolated"] = {k: round(v, 3) for k, v in kernel_ms_isolated.items()}
         # K2b: bound by instruction issue, not by HBM -- wave-level VALU instructions per second against the chip's issue peak
         roofline_k2b = None
-        if tab and ("ema_k_align", "SQ_INSTS_VALU") in tab and kernel_ms_isolated:
-            insts, launches = tab[("ema_k_align", "SQ_INSTS_VALU")]
+        # (K2b, K2c and K2d are builds of one template, ema_k_align_t<SMALL;AVL;WPS;MODE>: their instructions are summed per K2b launch)
+        k2_names = sorted({k for k, c in (tab or {}) if c == "SQ_INSTS_VALU" and (k == "ema_k_align" or k.startswith("ema_k_align_t<"))})
+        k2_main = [k for k in k2_names if k == "ema_k_align" or k.endswith(";0>")]
+        if k2_names and k2_main and kernel_ms_isolated:
+            insts = sum(tab[(k, "SQ_INSTS_VALU")][0] for k in k2_names)
+            launches = max(tab[(k, "SQ_INSTS_VALU")][1] for k in k2_main)
             per_launch = insts / launches
             ms = kernel_ms_isolated["extend_ms"]
             ach = per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            roofline_k2b = {"bound": "valu-issue", "kernel": "ema_k_align (+ ema_k_align_simple in kernel_ms)", "achieved": round(ach, 2),
+            roofline_k2b = {"bound": "valu-issue", "kernel": " + ".join(k2_names) + " (+ ema_k_align_simple in kernel_ms)", "achieved": round(ach, 2),
                             "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 5),
                             "insts_per_launch": int(per_launch), "kernel_ms": round(ms, 3),
                             "source": f"profiles/{pmc_name}: SQ_INSTS_VALU per launch (stored PMC pass) / this run's isolated K2 time; peak = "
@@ -575,7 +579,7 @@ def main(argv=None):
                                    f"(reference cpp/correct.cc:550) and R2 150 bp, 0.5% subs, 0.05% indels, 1% chimeric; {args.steps} steps over "
                                    f"{n_batches} distinct batches of {args.pairs} pairs per GPU (one barcode bucket per GPU), inputs staged in HBM "
                                    f"before the timed region, candidates + append_alignments records delivered to host memory inside it "
-                                   f"(passes queued two deep, result layout and packing on the device); "
+                                   f"(passes queued up to three deep, result layout and packing on the device); "
                                    f"{fallback}reference = {gname} with injected repeat families (default: GRCh38-scale, 3.1 Gbp; index built on "
                                    f"the host cores before the timed region; --genome-mbp 0 = chr20-scale)",
                        "pairs_per_step_per_gpu": args.pairs, "distinct_batches": n_batches, "buffer_sets": n_sets, "max_occ": 3000,

@@ -10,6 +10,9 @@ for root in args:
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0]
+            if k.startswith("void "):      # templates: "void ema_k_align_t<32, 8, 4, 0>" -> "ema_k_align_t<32;8;4;0>" (no commas: CSV)
+                k = k[5:]
+            k = k.replace(", ", ";").replace(",", ";")
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 if as_csv:
     print("kernel,counter,launches,mean_per_launch,min,max,sum_over_run")

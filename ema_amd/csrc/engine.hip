@@ -249,6 +249,7 @@ struct ema_engine {
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	int mid_align = 0;                   // EMA_MID_ALIGN=1: LDS build of K2b for reads with 33..192 seed occurrences (one block per CU); 2: for 33..80 (two blocks); 0: none
 	bool av_lds = true;                  // EMA_AV_LDS=0: region lists in the HBM slab
+	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_chains = 32;               // EMA_HEAVY_CHAINS: K2b sets a read with at least this many chains to extend aside for K2c / K2d (0: never)
 	int align_mid_blocks = 0;
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
@@ -368,7 +369,7 @@ static bool stream_file_to_device(ema_engine *e, const std::string &path, uint64
 
 static int engine_open(const char *index_prefix, const ema_engine *share, int device, const ema_engine_opts *opts, ema_engine_t **out);
 
-static int select_slot(ema_engine *e, int slot);
+static int select_slot(ema_engine *e, int slot, int only = -1);
 static int input_alloc(ema_engine *e, int slot)
 {
 	ema_engine::InputSet &in = e->in[slot];
@@ -497,6 +498,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = getenv("EMA_MID_ALIGN")) e->mid_align = atoi(v);
 	if (const char *v = getenv("EMA_AV_LDS")) e->av_lds = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
+	if (const char *v = getenv("EMA_SMALL_ONE_SLICE")) e->small_one_slice = atoi(v) != 0;
 	e->align_mid_blocks = e->n_cu * ema_align_mid_blocks_per_cu(e->mid_align == 2 ? 3 : 1);
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
@@ -669,16 +671,22 @@ static int stage_slot_impl(ema_engine_t *e, int slot, const char *bases, const u
 }
 
 // makes `slot` the input of the next run: consecutive pairs go to consecutive slices, as evenly as the slice count allows
-static int select_slot(ema_engine *e, int slot)
+// (only >= 0, asynchronous passes: a batch that fits one slice goes to slice `only` whole -- a stream of small buckets keeps
+// three passes in flight, one per slice and stream, instead of cutting every bucket into three slivers whose kernels are all tail)
+static int select_slot(ema_engine *e, int slot, int only)
 {
 	const ema_engine::InputSet &in = e->in[slot];
 	const size_t n_pairs = in.n_pairs, n_sl = e->sl.size();
 	size_t first = 0;
+	if (only >= 0 && n_pairs > e->sl[(size_t)only % n_sl].cap_pairs) only = -1;
 	for (size_t k = 0; k < n_sl; ++k) {
 		Slice &s = e->sl[k];
 		s.first_pair = first;
-		s.n_pairs = (n_pairs - first + (n_sl - k) - 1) / (n_sl - k);
-		if (s.n_pairs > s.cap_pairs) s.n_pairs = s.cap_pairs;
+		if (only >= 0) s.n_pairs = k == (size_t)only % n_sl ? n_pairs : 0;
+		else {
+			s.n_pairs = (n_pairs - first + (n_sl - k) - 1) / (n_sl - k);
+			if (s.n_pairs > s.cap_pairs) s.n_pairs = s.cap_pairs;
+		}
 		first += s.n_pairs;
 	}
 	if (first != n_pairs) { e->err = "internal: slices do not cover the batch"; return EMA_ESTATE; }
@@ -925,7 +933,7 @@ int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
 	int rc;
 	for (auto &s : e->sl) if ((rc = out_alloc(e, s, false))) return rc;
 	if ((rc = out_alloc(e, e->full, true))) return rc;
-	if ((rc = select_slot(e, slot))) return rc;
+	if ((rc = select_slot(e, slot, e->small_one_slice ? e->next_ticket : -1))) return rc;
 	const int j = e->next_ticket % EMA_MAX_INFLIGHT;
 	ema_engine::Ticket &t = e->tickets[j];
 	t.seq = e->next_ticket; t.n_pairs = e->n_pairs;

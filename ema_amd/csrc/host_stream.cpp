@@ -10,6 +10,8 @@
 // order.  While one worker stages or fetches (PCIe + host cores), the other's kernels have the GPU.
 #include <condition_variable>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -51,8 +53,10 @@ struct Stream {
 	const char *const *paths = nullptr;
 	std::mutex mu, eng_mu[2], stage_mu;
 	std::condition_variable cv;
-	size_t delivered = 0;
+	size_t delivered = 0, pairs_read = 0, pairs_delivered = 0;
 	bool stop = false;
+	bool trace = getenv("EMA_STREAM_TRACE") != nullptr;      // when what happened, on stderr
+	double t_start = now_s();
 };
 
 void fill_stats(Item &it)
@@ -142,11 +146,14 @@ void worker(Stream &S, int w)
 
 void reader(Stream &S)
 {
-	const size_t depth = (size_t)(S.o.read_ahead > 0 ? S.o.read_ahead : 2) + (S.n_eng == 2 ? 2 : 3);      // + the buckets inside the engine's pipeline
+	// How far ahead of the delivery: read_ahead buckets plus the ones inside the engine's pipeline -- or, with small buckets, as many
+	// as make up that many full batches (the stream lays them end to end in one pass; a bound in buckets would starve it)
+	const size_t depth = (size_t)(S.o.read_ahead > 0 ? S.o.read_ahead : 2) + (S.n_eng == 2 ? 2 : 3);
+	const size_t pair_budget = depth * S.cap;
 	for (size_t k = 0; k < S.items.size(); ++k) {
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
-			S.cv.wait(lk, [&] { return S.stop || k < S.delivered + depth; });
+			S.cv.wait(lk, [&] { return S.stop || k < S.delivered + depth || (k < S.delivered + 512 && S.pairs_read - S.pairs_delivered < pair_budget); });
 			if (S.stop) return;
 		}
 		Item &it = S.items[k];
@@ -158,42 +165,131 @@ void reader(Stream &S)
 		{
 			std::lock_guard<std::mutex> lk(S.mu);
 			it.state = ST_LOADED;
+			S.pairs_read += it.n_pairs;
 		}
 		S.cv.notify_all();
 	}
 }
 
-// The default schedule: ONE set of batch buffers, passes queued two deep (ema_engine_run_async).  A stager thread converts and
-// uploads batch k+1.. into free input slots while this thread queues pass k, then fetches pass k-1 and runs its append stage
-// while pass k computes.  A bucket beyond the batch capacity drains the pipeline and goes through ema_engine_align_pairs.
+// The default schedule: ONE set of batch buffers, asynchronous passes (ema_engine_run_async, up to EMA_MAX_INFLIGHT in flight).
+// A stager thread converts and uploads the next passes' input into free input slots while the engine thread queues a pass,
+// fetches the oldest one and runs its buckets' append stage while the younger ones compute.
+// One pass = one or SEVERAL consecutive buckets: the engine is built for batches of a million pairs (every kernel ends in a tail
+// of long reads, and the full-capacity tier costs its ~0.1 s whatever the batch size), so small buckets that are waiting
+// anyway are laid end to end in one batch and the results cut apart again.  A bucket beyond the batch capacity drains the
+// pipeline and goes through ema_engine_align_pairs.
 const int kInSlots = 4;      // input slots 1..4: slot 0 stays with ema_engine_stage / ema_engine_align_pairs (the big-bucket path)
+const size_t kMaxGroup = 64;
 
+struct Pass { size_t first = 0, len = 0; int staged = 0; };      // items [first, first + len); staged: 1 yes, -1 failed
 struct AsyncState {
-	std::vector<int> staged;      // per item: 0 no, 1 staged, -1 staging failed
-	size_t n_run = 0;             // passes queued so far (the stager may fill slot k % kInSlots once pass k - kInSlots has been queued)
+	std::vector<Pass> passes;     // in order, made by the stager
+	bool all_made = false;
+	size_t n_run = 0;             // passes queued so far (the stager may fill slot p % kInSlots once pass p - kInSlots has been queued)
 };
+
+// pairs [p0, p0 + n) of a batch as a batch of their own (offsets rebased); nullptr when memory runs out
+ema_batch_out *slice_batch(const ema_batch_out *b, size_t p0, size_t n)
+{
+	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+	if (!o) return nullptr;
+	const size_t r0 = 2 * p0, nr = 2 * n;
+	const uint64_t c0 = b->cand_off[r0], c1 = b->cand_off[r0 + nr];
+	uint64_t g0 = ~(uint64_t)0, g1 = 0;
+	for (uint64_t c = c0; c < c1; ++c) {
+		const ema_cand_t &x = b->cand[c];
+		if (x.n_cigar <= 0) continue;
+		if (x.cigar_off < g0) g0 = x.cigar_off;
+		if ((uint64_t)x.cigar_off + (uint64_t)x.n_cigar > g1) g1 = (uint64_t)x.cigar_off + (uint64_t)x.n_cigar;
+	}
+	if (g1 <= g0) g0 = g1 = 0;
+	size_t n_red = 0;
+	for (size_t i = 0; i < b->n_redone; ++i) n_red += b->redone[i] >= p0 && b->redone[i] < p0 + n;
+	o->n_pairs = n; o->n_cigar = (size_t)(g1 - g0); o->n_redone = n_red;
+	o->cand_off = (uint64_t *)malloc((nr + 1) * sizeof(uint64_t));
+	o->cand = (ema_cand_t *)malloc((size_t)(c1 - c0 + 1) * sizeof(ema_cand_t));
+	o->cigar = (uint32_t *)malloc((size_t)(g1 - g0 + 1) * sizeof(uint32_t));
+	o->status = (int32_t *)malloc((nr + 1) * sizeof(int32_t));
+	o->redone = (uint32_t *)malloc((n_red + 1) * sizeof(uint32_t));
+	if (!o->cand_off || !o->cand || !o->cigar || !o->status || !o->redone) { ema_batch_free(o); return nullptr; }
+	for (size_t r = 0; r <= nr; ++r) o->cand_off[r] = b->cand_off[r0 + r] - c0;
+	memcpy(o->status, b->status + r0, nr * sizeof(int32_t));
+	memcpy(o->cand, b->cand + c0, (size_t)(c1 - c0) * sizeof(ema_cand_t));
+	for (uint64_t c = 0; c < c1 - c0; ++c) if (o->cand[c].n_cigar > 0) o->cand[c].cigar_off -= (uint32_t)g0;
+	memcpy(o->cigar, b->cigar + g0, (size_t)(g1 - g0) * sizeof(uint32_t));
+	n_red = 0;
+	for (size_t i = 0; i < b->n_redone; ++i) if (b->redone[i] >= p0 && b->redone[i] < p0 + n) o->redone[n_red++] = b->redone[i] - (uint32_t)p0;
+	return o;
+}
 
 void stager(Stream &S, AsyncState &A)
 {
-	for (size_t k = 0; k < S.items.size(); ++k) {
-		Item &it = S.items[k];
+	const size_t n = S.items.size();
+	size_t k = 0;
+	std::vector<char> bases;
+	std::vector<uint32_t> off;
+	while (k < n) {
+		Pass ps;
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
-			S.cv.wait(lk, [&] { return S.stop || (it.state == ST_LOADED && k < A.n_run + (size_t)kInSlots); });
+			S.cv.wait(lk, [&] { return S.stop || (S.items[k].state == ST_LOADED && A.passes.size() < A.n_run + (size_t)kInSlots); });
 			if (S.stop) return;
+			// the buckets already waiting behind this one come along while they fit the batch
+			ps.first = k; ps.len = 1;
+			const Item &h = S.items[k];
+			if (h.rc == EMA_OK && h.slot < 0 && h.n_pairs <= S.cap) {
+				size_t sum = h.n_pairs;
+				uint64_t bytes = h.off ? h.off[2 * h.n_pairs] : 0;
+				while (k + ps.len < n && ps.len < kMaxGroup) {
+					const Item &x = S.items[k + ps.len];
+					if (x.state != ST_LOADED || x.rc != EMA_OK || x.slot >= 0 || sum + x.n_pairs > S.cap) break;
+					bytes += x.off ? x.off[2 * x.n_pairs] : 0;
+					if (bytes > 0xfffffff0ULL) break;
+					sum += x.n_pairs; ++ps.len;
+				}
+			}
 		}
+		Item &it = S.items[k];
 		int ok = 1;
 		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap) {
+			const char *pb = it.bases; const uint32_t *po = it.off; size_t np = it.n_pairs;
+			if (ps.len > 1) {      // end to end in one batch
+				size_t tot_p = 0, tot_b = 0;
+				for (size_t j = 0; j < ps.len; ++j) { const Item &x = S.items[k + j]; tot_p += x.n_pairs; tot_b += x.n_pairs ? x.off[2 * x.n_pairs] : 0; }
+				bases.resize(tot_b + 1); off.resize(2 * tot_p + 1);
+				size_t at_r = 0; uint32_t at_b = 0;
+				off[0] = 0;
+				for (size_t j = 0; j < ps.len; ++j) {
+					const Item &x = S.items[k + j];
+					if (!x.n_pairs) continue;
+					const uint32_t nb = x.off[2 * x.n_pairs];
+					memcpy(bases.data() + at_b, x.bases, nb);
+					for (size_t r = 1; r <= 2 * x.n_pairs; ++r) off[at_r + r] = at_b + x.off[r];
+					at_r += 2 * x.n_pairs; at_b += nb;
+				}
+				pb = bases.data(); po = off.data(); np = tot_p;
+			}
+			const double t_cat = now_s();
 			std::lock_guard<std::mutex> hold(S.stage_mu);      // the engine's host-side staging buffers: one user at a time
-			const int rc = ema_engine_stage_async(S.eng[0], 1 + (int)(k % (size_t)kInSlots), it.bases, it.off, it.n_pairs);
-			if (rc != EMA_OK) { it.rc = rc; it.err = ema_engine_strerror(S.eng[0]); ok = -1; }
+			const int rc = ema_engine_stage_async(S.eng[0], 1 + (int)(A.passes.size() % (size_t)kInSlots), pb, po, np);
+			if (S.trace) fprintf(stderr, "[stream] stager: pass %zu = buckets %zu..%zu (%zu pairs): laid end to end by %.3f, staged by %.3f (s since start)\n",
+			                     A.passes.size(), k, k + ps.len - 1, np, t_cat - S.t_start, now_s() - S.t_start);
+			if (rc != EMA_OK) { for (size_t j = 0; j < ps.len; ++j) { S.items[k + j].rc = rc; S.items[k + j].err = ema_engine_strerror(S.eng[0]); } ok = -1; }
 		}
+		ps.staged = ok;
+		k += ps.len;
 		{
 			std::lock_guard<std::mutex> lk(S.mu);
-			A.staged[k] = ok;
+			A.passes.push_back(ps);
+			if (k >= n) A.all_made = true;
 		}
 		S.cv.notify_all();
 	}
+	{
+		std::lock_guard<std::mutex> lk(S.mu);
+		A.all_made = true;
+	}
+	S.cv.notify_all();
 }
 
 void finish_item(Stream &S, Item &it, double t0)
@@ -217,63 +313,93 @@ void finish_item(Stream &S, Item &it, double t0)
 void async_engine_thread(Stream &S, AsyncState &A)
 {
 	ema_engine_t *g = S.eng[0];
-	const size_t n = S.items.size();
-	std::vector<int> ticket(n, -1);
-	std::vector<double> t_queued(n, 0.0);
-	size_t k_run = 0, k_fetch = 0;
+	std::vector<int> ticket;
+	std::vector<double> t_queued;
+	size_t p_run = 0, p_fetch = 0;
+	auto pass_at = [&](size_t p) { std::lock_guard<std::mutex> lk(S.mu); return A.passes[p]; };
 	auto fetch_one = [&] {
-		Item &it = S.items[k_fetch];
-		if (ticket[k_fetch] >= 0) {
-			const int rc = ema_engine_fetch_ticket(g, ticket[k_fetch], &it.b);
-			it.rc = rc;
-			if (rc != EMA_OK) it.err = ema_engine_strerror(g);
-			ema_engine_timing tm;
-			if (ema_engine_last_timing(g, &tm) == EMA_OK) {
-				it.st.seed_ms = tm.seed_ms; it.st.extend_ms = tm.extend_ms; it.st.rescue_ms = tm.rescue_ms; it.st.final_ms = tm.final_ms;
-				it.st.full_tier_ms = tm.full_tier_ms;
-			}
+		const Pass ps = pass_at(p_fetch);
+		Item &head = S.items[ps.first];
+		ema_batch_out *b = nullptr;
+		int rc = EMA_OK; std::string err;
+		ema_engine_timing tm; bool have_tm = false;
+		const double t_f0 = now_s();
+		if (ticket[p_fetch] >= 0) {
+			rc = ema_engine_fetch_ticket(g, ticket[p_fetch], &b);
+			if (rc != EMA_OK) err = ema_engine_strerror(g);
+			have_tm = ema_engine_last_timing(g, &tm) == EMA_OK;
 		}
-		finish_item(S, it, t_queued[k_fetch]);
-		++k_fetch;
+		const double t_f1 = now_s();
+		size_t p0 = 0;
+		for (size_t j = 0; j < ps.len; ++j) {
+			Item &it = S.items[ps.first + j];
+			if (ticket[p_fetch] >= 0) {
+				it.rc = rc; it.err = err;
+				if (have_tm) {
+					it.st.seed_ms = tm.seed_ms; it.st.extend_ms = tm.extend_ms; it.st.rescue_ms = tm.rescue_ms; it.st.final_ms = tm.final_ms;
+					it.st.full_tier_ms = tm.full_tier_ms;
+				}
+				if (b && ps.len == 1) { it.b = b; b = nullptr; }
+				else if (b) {
+					it.b = slice_batch(b, p0, it.n_pairs);
+					if (!it.b) { it.rc = EMA_EDEVICE; it.err = "out of host memory cutting a batch into its buckets"; }
+					else if (rc == EMA_ELIMIT) {      // the capacity flag is the batch's: does this bucket hold a flagged read?
+						int32_t flags = 0;
+						for (size_t r = 0; r < 2 * it.b->n_pairs; ++r) flags |= it.b->status[r];
+						if (!flags) { it.rc = EMA_OK; it.err.clear(); }
+					}
+				}
+			}
+			p0 += it.n_pairs;
+			finish_item(S, it, t_queued[p_fetch]);
+		}
+		if (b) ema_batch_free(b);
+		(void)head;
+		if (S.trace) fprintf(stderr, "[stream] engine thread: pass %zu queued at %.3f, fetch %.3f..%.3f, cut + append stage done by %.3f\n", p_fetch,
+		                     t_queued[p_fetch] - S.t_start, t_f0 - S.t_start, t_f1 - S.t_start, now_s() - S.t_start);
+		++p_fetch;
 	};
-	while (k_fetch < n) {
-		bool can_run = false;
+	for (;;) {
+		bool can_run = false, done = false;
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
 			if (S.stop) break;
-			// queue the next pass if its batch is staged and fewer than EMA_MAX_INFLIGHT are in flight; otherwise fetch the oldest; otherwise wait
-			S.cv.wait(lk, [&] { return S.stop || k_fetch < k_run || (k_run < n && A.staged[k_run] != 0); });
+			// queue the next pass if it is staged and fewer than EMA_MAX_INFLIGHT are in flight; otherwise fetch the oldest; otherwise wait
+			S.cv.wait(lk, [&] { return S.stop || p_fetch < p_run || p_run < A.passes.size() || (A.all_made && p_fetch >= A.passes.size()); });
 			if (S.stop) break;
-			can_run = k_run < n && A.staged[k_run] != 0 && k_run - k_fetch < (size_t)EMA_MAX_INFLIGHT;
+			done = A.all_made && p_fetch >= A.passes.size() && p_run >= A.passes.size();
+			can_run = p_run < A.passes.size() && p_run - p_fetch < (size_t)EMA_MAX_INFLIGHT;
 		}
+		if (done) break;
 		if (can_run) {
-			Item &it = S.items[k_run];
-			t_queued[k_run] = now_s();
-			if (it.rc != EMA_OK) {      // reader or stager failed: passes straight through, in order
+			const Pass ps = pass_at(p_run);
+			Item &it = S.items[ps.first];
+			ticket.push_back(-1); t_queued.push_back(now_s());
+			if (ps.staged < 0 || it.rc != EMA_OK) {      // reader or stager failed: passes straight through, in order
 			} else if (it.n_pairs > S.cap) {      // beyond one batch: drain, then the engine's own piece pipeline
-				while (k_fetch < k_run) fetch_one();
+				while (p_fetch < p_run) fetch_one();
 				std::lock_guard<std::mutex> hold(S.stage_mu);
 				it.rc = ema_engine_align_pairs(g, it.bases, it.off, it.n_pairs, &it.b);
 				if (it.rc != EMA_OK) it.err = ema_engine_strerror(g);
 			} else {
-				const int slot = it.slot >= 0 ? it.slot : 1 + (int)(k_run % (size_t)kInSlots);
+				const int slot = it.slot >= 0 ? it.slot : 1 + (int)(p_run % (size_t)kInSlots);
 				int tk = -1;
 				const int rc = ema_engine_run_async(g, slot, &tk);
-				if (rc != EMA_OK) { it.rc = rc; it.err = ema_engine_strerror(g); } else ticket[k_run] = tk;
+				if (rc != EMA_OK) { for (size_t j = 0; j < ps.len; ++j) { S.items[ps.first + j].rc = rc; S.items[ps.first + j].err = ema_engine_strerror(g); } }
+				else ticket[p_run] = tk;
 			}
 			{
 				std::lock_guard<std::mutex> lk(S.mu);
-				it.state = ST_TAKEN;
-				++k_run; A.n_run = k_run;
+				for (size_t j = 0; j < ps.len; ++j) S.items[ps.first + j].state = ST_TAKEN;
+				++p_run; A.n_run = p_run;
 			}
 			S.cv.notify_all();
-		} else if (k_fetch < k_run) fetch_one();
+		} else if (p_fetch < p_run) fetch_one();
 	}
 	// on an early stop, passes still in flight are fetched and dropped so that the engine is reusable
-	while (k_fetch < k_run) {
-		Item &it = S.items[k_fetch];
-		if (ticket[k_fetch] >= 0 && !it.b) { ema_batch_out *b = nullptr; (void)ema_engine_fetch_ticket(g, ticket[k_fetch], &b); if (b) ema_batch_free(b); }
-		++k_fetch;
+	while (p_fetch < p_run) {
+		if (ticket[p_fetch] >= 0) { ema_batch_out *b = nullptr; (void)ema_engine_fetch_ticket(g, ticket[p_fetch], &b); if (b) ema_batch_free(b); }
+		++p_fetch;
 	}
 }
 
@@ -300,7 +426,6 @@ int run_stream(ema_engine_t *e, Stream &S, ema_stream_sink sink, void *user, ema
 		if (S.items[k].slot >= 0) S.items[k].slot = (int)((k / (size_t)S.n_eng) % (size_t)S.items[k].slot);
 	std::vector<std::thread> th;
 	AsyncState A;
-	A.staged.assign(S.items.size(), 0);
 	if (S.paths) th.emplace_back(reader, std::ref(S));
 	if (S.n_eng == 2) {
 		for (int w = 0; w < S.n_eng; ++w) th.emplace_back(worker, std::ref(S), w);
@@ -317,16 +442,18 @@ int run_stream(ema_engine_t *e, Stream &S, ema_stream_sink sink, void *user, ema
 		}
 		if (stats) stats[k] = it.st;
 		int rc = it.rc;
+		const double t_s0 = now_s();
 		if (rc == EMA_OK || rc == EMA_ELIMIT) {
 			if (rc == EMA_ELIMIT) { result = EMA_ELIMIT; g_err = it.err; }
 			const int src = sink ? sink(user, k, it.bk, it.b, it.a) : 0;
 			if (src != 0) { rc = src; g_err = "stopped by the sink"; }
 			else rc = EMA_OK;
 		} else g_err = (S.paths ? std::string(S.paths[k]) + ": " : std::string()) + it.err;
+		if (S.trace) fprintf(stderr, "[stream] sink: bucket %zu %.3f..%.3f\n", k, t_s0 - S.t_start, now_s() - S.t_start);
 		release(it);
 		{
 			std::lock_guard<std::mutex> lk(S.mu);
-			++S.delivered;
+			++S.delivered; S.pairs_delivered += it.n_pairs;
 			if (rc != EMA_OK) S.stop = true;
 		}
 		S.cv.notify_all();

@@ -33,16 +33,22 @@ for k in range(n_b):
             f.write(bc[i].tobytes() + b" " + ids[i] + b" " + reads[i, :l1].tobytes() + b" " + q1 + b" " + reads[i, l1:].tobytes() + b" " + q2 + b"\n")
     paths.append(path)
 print(f"{n_b} buckets x {n_p} pairs written in {time.time() - t:.1f}s", flush=True)
-o = default_opts(); o.batch_pairs = max(262144, n_p)
+o = default_opts(); o.batch_pairs = max(int(os.environ.get('EMA_SAM_BATCH', 1048576)), n_p)      # the stream lays small buckets end to end up to this
 eng = Engine(os.path.join(wd, "ref.fa"), opts=o)
 fd = os.open("/dev/null", os.O_WRONLY)
 stream.stream_sam(eng, paths[:1], fd, rg_id=b"rg1")      # warm-up: buffers, page cache
+import resource
+r0 = resource.getrusage(resource.RUSAGE_SELF)
 t0 = time.perf_counter()
+rep = int(os.environ.get("EMA_SAM_REPEAT", 1))      # the same files again and again: a longer stream without writing more of them
+paths = paths * rep
 bst, sst = stream.stream_sam(eng, paths, fd, rg_id=b"rg1", continue_cloud_ids=True)
 dt = time.perf_counter() - t0
+r1 = resource.getrusage(resource.RUSAGE_SELF)
+print(f"host CPU seconds / wall second during the call: {(r1.ru_utime + r1.ru_stime - r0.ru_utime - r0.ru_stime) / dt:.1f}")
 os.close(fd)
 eng.close()
-tot = n_b * n_p
+tot = n_b * n_p * rep; n_b *= rep
 print(f"bucket files -> SAM text: {tot / dt:.0f} pairs/s end to end ({dt:.2f}s for {tot} pairs in {n_b} buckets)")
 for name, key, src in (("reader", "read_s", bst), ("engine (stage+kernels+fetch)", "align_s", bst), ("append stage", "append_s", bst),
                        ("clouds/EM/duplicates", "select_s", sst), ("formatter + write", "write_s", sst)):

@@ -21,6 +21,9 @@ if [[ $what == *bench* ]]; then
   timeout 300 python3 "$root/tools/cpu_seed_profile.py" > "$out/seed_profile.txt" 2>&1; echo "seedprof: rc=$?"
   EMA_PHASE_PROFILE=2 timeout 600 python3 "$root/tools/gpu_readlog.py" "$tag" > "$out/readlog.txt" 2>&1; echo "readlog: rc=$?"; tail -40 "$out/readlog.txt"
 fi
+if [[ $what == *sam* ]]; then
+  timeout 900 python3 "$root/tools/gpu_sam_rate.py" 6 200000 > "$out/sam_rate.txt" 2>&1; echo "sam: rc=$?"; tail -12 "$out/sam_rate.txt"
+fi
 if [[ $what == *cpuscale* ]]; then
   timeout 600 python3 "$root/tools/cpu_scaling.py" 3000 > "$out/cpu_scaling.txt" 2>&1; echo "cpuscale: rc=$?"; cat "$out/cpu_scaling.txt"
 fi

@@ -128,6 +128,17 @@ __device__ __forceinline__ int lower_bound_pos(const int64_t *cpos, int n, int64
 	return lo + __popcll(__ballot(lane < len && cpos[lo + (lane < len ? lane : 0)] < key));
 }
 
+// Everything this wavefront has in flight -- LDS instructions, FLAT instructions that end in LDS, global loads and stores --
+// completes before anything that follows is issued.  The kernel touches the same LDS bytes through typed LDS pointers and
+// through generic pointers kept in its table structs, and those two kinds of instruction take different routes to LDS: between
+// the phases of a read (whose tables overlay one another) the routes are drained.
+__device__ __forceinline__ void ema_phase_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_wave_barrier();
+}
+
 struct ChainBuild {
 	AlignSlab sl;
 	int n_chain, n_seed, status;
@@ -327,15 +338,21 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first, int
 // one wavefront = one read at a time, reads taken from a shared counter
 // intv/n_intv: K1's output (stride opt.intv_cap).  regs: n_reads x opt.reg_cap, n_regs: n_reads.  status is OR-ed.
 // MODE 0: the kernel described above (it sets chain-rich reads aside when hv.arena is given); 1: K2c, 2: K2d (dev_types.h, HeavyCtl)
-template <int SMALL, int AVL, int WPS, int MODE>
+// PROF: the diagnostic build (phase clocks, per-read log); the product build carries none of its registers
+template <int SMALL, int AVL, int WPS, int MODE, bool PROF>
 __global__ void __launch_bounds__(256, WPS)
 ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const Intv *__restrict__ intv, const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs,
             int *__restrict__ status, const int *__restrict__ todo, const int *__restrict__ n_todo,
-            const uint8_t *__restrict__ hand, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg, unsigned long long *prof,
+            const uint8_t *__restrict__ hand, uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg_arg, unsigned long long *prof_arg,
             HeavyCtl hv)
 {
+	// The phase clocks and the per-read log exist in the diagnostic build only.  (The watchdog's progress words stay a run-time
+	// pointer: with both folded away this kernel faulted on the device -- r02: every other combination passes the suite, the
+	// interpreter and AddressSanitizer find nothing -- and until that is understood the build that is tested is the one shipped.)
+	unsigned long long *const prof = PROF ? prof_arg : nullptr;
+	int *const dbg = dbg_arg;
 	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
 	unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
 	int phase = 0;
@@ -352,7 +369,11 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	__shared__ __attribute__((aligned(16))) uint8_t lds_small[4][EMA_SMALL_BYTES(SMALL)];
 	__shared__ __attribute__((aligned(16))) uint8_t lds_av[4][EMA_AVL_BYTES(AVL)];      // regions of the read while there are few
 	// the medium layout needs 4 KB of small-table area, the 2 KB window buffer and 1 KB of region-list area
+#ifdef EMA_NO_MED      // (bisecting aid)
+	constexpr bool MED = false && EMA_SMALL_BYTES(SMALL) >= 4096 && EMA_RSEQ_CAP >= EMA_MED_CHAINS * 8 && (AVL > 0 && EMA_AVL_BYTES(AVL) >= EMA_MED_CHAINS * 4);
+#else
 	constexpr bool MED = EMA_SMALL_BYTES(SMALL) >= 4096 && EMA_RSEQ_CAP >= EMA_MED_CHAINS * 8 && (AVL > 0 && EMA_AVL_BYTES(AVL) >= EMA_MED_CHAINS * 4);
+#endif
 	const int lane = (int)ema_lane();
 	const int wib = (int)(threadIdx.x >> 6);
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
@@ -407,6 +428,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			EMA_DBG(9, 0);
 			continue;
 		}
+		ema_phase_fence();      // the previous read's stores have landed
 		const int in_read = ema_uni(ema_in_read(map, read));
 		const int l_query = ema_uni((int)(off[in_read + 1] - off[in_read]));
 		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
@@ -483,7 +505,14 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			l_rep += e - b;
 			cb.sl = slab;
 			if (ema_uni(tot_occ <= SMALL)) ema_small_tables<SMALL>(cb.sl, lds_small[wib]);
-			else if (MED && ix.n_seqs <= 0xffff) med = true;      // (the summaries keep a contig id in 16 bits)
+			else if (MED && ix.n_seqs <= 0xffff) {      // (the summaries keep a contig id in 16 bits)
+				med = true;
+				// The medium tables are written with LDS instructions; the same bytes were last written -- by the previous read's
+				// extension phase: window buffer, seed copies, region list -- through generic pointers, i.e. FLAT instructions, which
+				// take the longer way to LDS.  An older FLAT store must not land on top of a younger LDS store: everything in flight
+				// completes first.
+				ema_phase_fence();
+			}
 			log_iv = n_iv; log_occ = (int)(tot_occ < (1 << 30) ? tot_occ : (1 << 30));
 		}
 		frac_rep = (float)l_rep / (float)l_query;
@@ -694,7 +723,11 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		}
 
 		// ---------------- a chain-rich read is set aside for K2c / K2d (dev_types.h, HeavyCtl) ----------------
+#ifdef EMA_NO_DEFER
+		if (false) {
+#else
 		if (MODE == 0 && hv.arena && !handed && n_keep >= hv.min_chains) {
+#endif
 			int n_ext = 0, tot = 0;      // chains to extend, their seeds
 			for (int base = 0; base < n_keep; base += EMA_WAVE) {
 				const int i = base + lane;
@@ -1007,12 +1040,14 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
 #define EMA_ALIGN_LAUNCH(...) hipLaunchKernelGGL((ema_k_align_t<__VA_ARGS__>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs, \
 	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof, hv)
-	if (mode == 1) EMA_ALIGN_LAUNCH(32, 8, 4, 1);      // K2c: one chain of a read set aside per wavefront
-	else if (mode == 2) EMA_ALIGN_LAUNCH(32, 8, 4, 2); // K2d: the replay of a read set aside
-	else if (variant == 1) EMA_ALIGN_LAUNCH(EMA_MID_SEEDS, 24, 1, 0);
-	else if (variant == 2) EMA_ALIGN_LAUNCH(32, 0, 4, 0);
-	else if (variant == 3) EMA_ALIGN_LAUNCH(80, 16, 2, 0);
-	else EMA_ALIGN_LAUNCH(32, 8, 4, 0);
+	const bool diag = prof != nullptr;
+	if (mode == 1) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 1, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 1, false); }      // K2c: one chain of a read set aside per wavefront
+	else if (mode == 2) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 2, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 2, false); } // K2d: the replay of a read set aside
+	else if (variant == 1) EMA_ALIGN_LAUNCH(EMA_MID_SEEDS, 24, 1, 0, false);
+	else if (variant == 2) EMA_ALIGN_LAUNCH(32, 0, 4, 0, false);
+	else if (variant == 3) EMA_ALIGN_LAUNCH(80, 16, 2, 0, false);
+	else if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 0, true);
+	else EMA_ALIGN_LAUNCH(32, 8, 4, 0, false);
 #undef EMA_ALIGN_LAUNCH
 }
 
@@ -1020,14 +1055,14 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 extern "C" int ema_align_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4, 0>, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4, 0, false>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }
 extern "C" int ema_align_mid_blocks_per_cu(int variant)
 {
 	int n = 0;
-	hipError_t rc = variant == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<80, 16, 2, 0>, 256, 0)
-	                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1, 0>, 256, 0);
+	hipError_t rc = variant == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<80, 16, 2, 0, false>, 256, 0)
+	                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1, 0, false>, 256, 0);
 	if (rc != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

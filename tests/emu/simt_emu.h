@@ -193,6 +193,7 @@ inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 inline unsigned long long __builtin_amdgcn_s_memtime() { return 0; }
 inline void __builtin_amdgcn_fence(int, const char *) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <typename T> inline void __hip_atomic_store(T *p, T v, int, int) { *p = v; }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }

@@ -116,6 +116,7 @@ struct HeavyCtl {
 	int *n_reads, *n_tasks;
 	int reads_cap, tasks_cap;
 	int min_chains;                    // a read with at least this many chains to extend is set aside
+	int skip_handed;                   // K2b (mode 0): the reads K2a handed over with their chains ready are another launch's (mode 3)
 };
 struct HeavyHdr {                      // head of a record; the arrays follow at the offsets given (bytes from the record's start)
 	int32_t read, n_chn, n_chain, n_seed, status, n_ext;

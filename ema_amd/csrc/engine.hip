@@ -249,6 +249,8 @@ struct ema_engine {
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	int mid_align = 0;                   // EMA_MID_ALIGN=1: LDS build of K2b for reads with 33..192 seed occurrences (one block per CU); 2: for 33..80 (two blocks); 0: none
 	bool av_lds = true;                  // EMA_AV_LDS=0: region lists in the HBM slab
+	bool split_handed = true;            // EMA_SPLIT_HANDED=0: one K2b launch for everything on K2a's list
+	int align_wps = 4;                   // EMA_ALIGN_WPS=3: K2b built for three blocks per CU (measurement)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_chains = 32;               // EMA_HEAVY_CHAINS: K2b sets a read with at least this many chains to extend aside for K2c / K2d (0: never)
 	int align_mid_blocks = 0;
@@ -499,6 +501,8 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = getenv("EMA_AV_LDS")) e->av_lds = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
 	if (const char *v = getenv("EMA_SMALL_ONE_SLICE")) e->small_one_slice = atoi(v) != 0;
+	if (const char *v = getenv("EMA_ALIGN_WPS")) e->align_wps = atoi(v);
+	if (const char *v = getenv("EMA_SPLIT_HANDED")) e->split_handed = atoi(v) != 0;
 	e->align_mid_blocks = e->n_cu * ema_align_mid_blocks_per_cu(e->mid_align == 2 ? 3 : 1);
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
@@ -770,6 +774,15 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	// K2b, bulk build: K2a's hand-overs and the repeat-rich reads; then the LDS build for the reads in between
 	HeavyCtl hv;
 	const bool heavy = s.d_heavy.p != nullptr;
+	const bool split = e->lane_align && e->split_handed;      // K2a's hand-overs on their own build of K2b, ahead of the rest
+	hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr;
+	hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; hv.skip_handed = split ? 1 : 0;
+	if (split) {
+		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
+		                 s.d_n_regs.p, s.d_status.p, s.d_todo.p, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 22,
+		                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, 0, &hv, 3);
+		HIPCHK(e, hipGetLastError());
+	}
 	if (heavy) {
 		hv.arena = s.d_heavy.p; hv.arena_bytes = s.d_heavy.n; hv.arena_used = reinterpret_cast<unsigned long long *>(s.d_counters.p + 30);
 		hv.reads = s.d_heavy_reads.p; hv.tasks = s.d_heavy_tasks.p; hv.n_reads = s.d_counters.p + 26; hv.n_tasks = s.d_counters.p + 27;
@@ -777,7 +790,7 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	}
 	ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 0,
-	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, e->av_lds ? 0 : 2, heavy ? &hv : nullptr, 0);
+	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, e->align_wps == 3 ? 4 : e->av_lds ? 0 : 2, &hv, 0);
 	HIPCHK(e, hipGetLastError());
 	if (mid) {
 		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,

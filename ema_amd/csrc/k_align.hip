@@ -337,7 +337,10 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first, int
 
 // one wavefront = one read at a time, reads taken from a shared counter
 // intv/n_intv: K1's output (stride opt.intv_cap).  regs: n_reads x opt.reg_cap, n_regs: n_reads.  status is OR-ed.
-// MODE 0: the kernel described above (it sets chain-rich reads aside when hv.arena is given); 1: K2c, 2: K2d (dev_types.h, HeavyCtl)
+// MODE 0: the kernel described above (it sets chain-rich reads aside when hv.arena is given); 1: K2c, 2: K2d (dev_types.h, HeavyCtl);
+// 3: the reads K2a handed over with their chains ready, and nothing else -- five sixths of the reads on the list.  Without the
+// chaining, the filter and the setting-aside in the same function the register allocator has a far easier job (a third of
+// the spills of mode 0), and the bulk of the reads runs on that build.
 // PROF: the diagnostic build (phase clocks, per-read log); the product build carries none of its registers
 template <int SMALL, int AVL, int WPS, int MODE, bool PROF>
 __global__ void __launch_bounds__(256, WPS)
@@ -417,13 +420,15 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			handed = (t & EMA_HAND_FLAG) != 0;
 			read = (int)(t & ~EMA_HAND_FLAG);
 		}
+		if (MODE == 3 && !handed) continue;
+		if (MODE == 0 && handed && hv.skip_handed) continue;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		const unsigned long long t_read = rlog ? __builtin_amdgcn_s_memtime() : 0;
 		int log_iv = -1, log_occ = 0;
 		n_dp = 0;
 		EMA_DBG(1, 0);
 		EMA_PHASE(6);      // 6: the read and (handed reads) K2a's record arrive
-		if (MODE == 0 && ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
+		if ((MODE == 0 || MODE == 3) && ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
 			if (lane == 0) n_regs[read] = 0;
 			EMA_DBG(9, 0);
 			continue;
@@ -439,7 +444,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		bool med = false;         // the medium layout (see the head of the file) is in force
 		const int32_t *hv_first = nullptr;      // MODE 1, 2: per chain (filtered order) the first slot of its seeds in the tables below
 		SeedRec *hv_cs = nullptr; DevReg *hv_res = nullptr; uint8_t *hv_valid = nullptr;
-		if (MODE != 0) {
+		if (MODE == 1 || MODE == 2) {
 			// the tables as K2b left them: read where they are
 			const HeavyHdr *h = reinterpret_cast<const HeavyHdr *>(rec);
 			cb.sl = slab;
@@ -470,7 +475,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			cb.n_chain = n_chn; cb.n_seed = n_sd;
 			n_keep = n_chn;
 			ema_wave_sync();
-		} else {
+		} else if (MODE != 3) {
 		EMA_PHASE(10);      // 10: the intervals in order, the repetitive fraction
 		const int n_iv = ema_uni(n_intv[read]);
 		const Intv *iv = slab.ivs;
@@ -825,8 +830,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			if (c.kept == 0) continue;
 			const int cn = c.n;
 			EMA_PHASE(7);      // 7: per chain -- its seeds, the window bounds, the window fetch, the seed order
-			const int hv_base = MODE != 0 ? ema_uni(hv_first[ci_sorted]) : 0;      // MODE 1, 2: the chain's slots in cs / res / valid
-			if ((MED && med) || MODE != 0) {      // the chain's seed copies and their order in LDS when they fit the small-table area's 1 KB head
+			const int hv_base = (MODE == 1 || MODE == 2) ? ema_uni(hv_first[ci_sorted]) : 0;      // MODE 1, 2: the chain's slots in cs / res / valid
+			if ((MED && med) || MODE == 1 || MODE == 2) {      // the chain's seed copies and their order in LDS when they fit the small-table area's 1 KB head
 				const bool fits = cn <= 32;
 				cb.sl.cs = fits ? reinterpret_cast<SeedRec *>(lds_small[wib]) : slab.cs;
 				cb.sl.srt = fits ? reinterpret_cast<uint64_t *>(lds_small[wib] + 32 * sizeof(SeedRec)) : slab.srt;
@@ -1037,15 +1042,17 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 {
 	HeavyCtl hv;
 	if (heavy) hv = *heavy;
-	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
+	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; hv.skip_handed = 0; }
 #define EMA_ALIGN_LAUNCH(...) hipLaunchKernelGGL((ema_k_align_t<__VA_ARGS__>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs, \
 	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof, hv)
 	const bool diag = prof != nullptr;
 	if (mode == 1) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 1, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 1, false); }      // K2c: one chain of a read set aside per wavefront
 	else if (mode == 2) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 2, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 2, false); } // K2d: the replay of a read set aside
+	else if (mode == 3) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 3, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 3, false); } // the reads handed over by K2a
 	else if (variant == 1) EMA_ALIGN_LAUNCH(EMA_MID_SEEDS, 24, 1, 0, false);
 	else if (variant == 2) EMA_ALIGN_LAUNCH(32, 0, 4, 0, false);
 	else if (variant == 3) EMA_ALIGN_LAUNCH(80, 16, 2, 0, false);
+	else if (variant == 4 && !diag) EMA_ALIGN_LAUNCH(32, 8, 3, 0, false);      // measurement: three blocks per CU, 168 registers
 	else if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 0, true);
 	else EMA_ALIGN_LAUNCH(32, 8, 4, 0, false);
 #undef EMA_ALIGN_LAUNCH

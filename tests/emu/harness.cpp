@@ -73,8 +73,15 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 		hv.arena = arena.data(); hv.arena_bytes = arena.size(); hv.arena_used = used.data(); hv.reads = hreads.data(); hv.tasks = htasks.data();
 		hv.n_reads = &hn[0]; hv.n_tasks = &hn[1]; hv.reads_cap = (int)hreads.size(); hv.tasks_cap = (int)htasks.size(); hv.min_chains = heavy_chains;
 	}
+	if (heavy_chains <= 0) { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
+	const bool split = lane && !(getenv("EMU_SPLIT_HANDED") && atoi(getenv("EMU_SPLIT_HANDED")) == 0);      // K2a's hand-overs on their own build, as the engine runs them
+	hv.skip_handed = split ? 1 : 0;
+	int c3 = 0;
+	if (split)
+		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, todo.data(), &n_todo, hand.data(), slabs,
+		                 &c3, n_blocks, nullptr, nullptr, nullptr, 0, &hv, 3);
 	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,
-	                 &c1, n_blocks, nullptr, nullptr, nullptr, 0, heavy_chains > 0 ? &hv : nullptr, 0);
+	                 &c1, n_blocks, nullptr, nullptr, nullptr, 0, &hv, 0);
 	if (mid)
 		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, todo_mid.data(), &n_todo_mid, hand.data(), slabs,
 		                 &c2, n_blocks, nullptr, nullptr, nullptr, 1, nullptr, 0);

@@ -1448,11 +1448,13 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 			cig_n[r] = f_status[2 * i + m] ? 0 : f_cig[2 * i + m];
 		}
 	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+	if (!o) { e->err = "out of host memory"; return EMA_EDEVICE; }
 	o->n_pairs = e->n_pairs;
 	o->n_redone = n_redo;
 	o->redone = (uint32_t *)malloc((n_redo + 1) * 4);
-	if (o->redone) for (size_t i = 0; i < n_redo; ++i) o->redone[i] = (uint32_t)redo[i];
 	o->cand_off = (uint64_t *)malloc((n_reads + 1) * 8);
+	if (!o->redone || !o->cand_off) { ema_batch_free(o); e->err = "out of host memory"; return EMA_EDEVICE; }
+	for (size_t i = 0; i < n_redo; ++i) o->redone[i] = (uint32_t)redo[i];
 	std::vector<uint64_t> cig_off(n_reads + 1);
 	o->cand_off[0] = 0; cig_off[0] = 0;
 	for (size_t r = 0; r < n_reads; ++r) {
@@ -1465,6 +1467,7 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
 	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
 	o->status = (int32_t *)malloc((n_reads + 1) * 4);
+	if (!o->cand || !o->cigar || !o->status) { ema_batch_free(o); e->err = "out of host memory"; return EMA_EDEVICE; }
 	*out = o;
 	std::vector<std::vector<uint64_t>> loc(2 * e->sl.size());
 	for (size_t k = 0; k < e->sl.size(); ++k) {      // lean slices: contiguous on the device, one copy each into their place in the batch
@@ -1572,12 +1575,19 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 		return EMA_ELIMIT;
 	}
 	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+	if (!o) { for (auto *q : parts) ema_batch_free(q); e->err = "out of host memory"; return EMA_EDEVICE; }
 	o->n_pairs = n_pairs; o->n_cigar = n_cig; o->n_redone = n_redone;
 	o->cand_off = (uint64_t *)malloc((2 * n_pairs + 1) * 8);
 	o->cand = (ema_cand_t *)malloc((n_cand + 1) * sizeof(ema_cand_t));
 	o->cigar = (uint32_t *)malloc((n_cig + 1) * 4);
 	o->status = (int32_t *)malloc((2 * n_pairs + 1) * 4);
 	o->redone = (uint32_t *)malloc((n_redone + 1) * 4);
+	if (!o->cand_off || !o->cand || !o->cigar || !o->status || !o->redone) {
+		ema_batch_free(o);
+		for (auto *q : parts) ema_batch_free(q);
+		e->err = "out of host memory";
+		return EMA_EDEVICE;
+	}
 	{
 		size_t at = 0, p0 = 0;
 		for (auto *q : parts) {

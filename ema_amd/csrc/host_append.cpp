@@ -12,6 +12,7 @@
 #include <vector>
 #include "ema_engine.h"
 
+extern "C" void ema_aln_free(ema_aln_out *o);
 namespace {
 
 // reference include/align.h:70-73
@@ -55,8 +56,10 @@ extern "C" int ema_batch_append_alignments(const ema_batch_out *b, const uint32_
 	             ln_clip = std::log(kClipRate);
 	const double lg_mis = std::log10(error_rate), lg_indel = std::log10(kIndelRate), lg_clip = std::log10(kClipRate);
 	ema_aln_out *o = (ema_aln_out *)calloc(1, sizeof(ema_aln_out));
+	if (!o) return EMA_EDEVICE;      // (out of host memory)
 	o->n_pairs = b->n_pairs;
 	o->pair_off = (uint64_t *)malloc((b->n_pairs + 1) * sizeof(uint64_t));
+	if (!o->pair_off) { ema_aln_free(o); return EMA_EDEVICE; }
 	// pairs are independent: chunks of pairs on the host's cores (EMA_HOST_THREADS, default min(32, hardware threads)),
 	// each into its own list; the lists are then laid end to end
 	int n_thr = 1;
@@ -125,6 +128,7 @@ extern "C" int ema_batch_append_alignments(const ema_batch_out *b, const uint32_
 	for (int t = 0; t < n_thr; ++t) total += part[t].size();
 	o->n = total;
 	o->rec = (ema_aln_rec *)malloc((total + 1) * sizeof(ema_aln_rec));
+	if (!o->rec) { ema_aln_free(o); return EMA_EDEVICE; }
 	size_t at = 0;
 	for (int t = 0; t < n_thr; ++t) {
 		const size_t p0 = (size_t)t * per, p1 = p0 + per < b->n_pairs ? p0 + per : b->n_pairs;

@@ -319,10 +319,12 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	lap("order");
 	// 3. barcodes, in sorted order
 	ema_bucket *o = (ema_bucket *)calloc(1, sizeof(ema_bucket));
+	if (!o) { g_err = "out of memory"; return EMA_EIO; }
 	o->n_pairs = n;
 	o->bc = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
 	o->off = (uint32_t *)malloc((2 * n + 1) * sizeof(uint32_t));
 	o->id_off = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+	if (!o->bc || !o->off || !o->id_off) { ema_bucket_free(o); g_err = "out of memory"; return EMA_EIO; }
 	std::vector<size_t> bad_bc((size_t)n_threads() + 1, (size_t)-1);
 	parallel_ranges(n, 1 << 12, [&](size_t k, size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) {
@@ -353,6 +355,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	o->bases = (char *)malloc(nb + 1);
 	o->quals = (char *)malloc(nb + 1);
 	o->ids = (char *)malloc(ni + 1);
+	if (!o->bases || !o->quals || !o->ids) { ema_bucket_free(o); g_err = "out of memory"; return EMA_EIO; }
 	lap("offsets");
 	// 5. payload
 	parallel_ranges(n, 1 << 12, [&](size_t, size_t lo, size_t hi) {
@@ -371,6 +374,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	for (size_t i = 0; i < n; ++i) n_groups += (i == 0 || o->bc[i] != o->bc[i - 1]);
 	o->n_groups = n_groups;
 	o->group_off = (uint64_t *)malloc((n_groups + 1) * sizeof(uint64_t));
+	if (!o->group_off) { ema_bucket_free(o); g_err = "out of memory"; return EMA_EIO; }
 	size_t g = 0;
 	for (size_t i = 0; i < n; ++i) if (i == 0 || o->bc[i] != o->bc[i - 1]) o->group_off[g++] = i;
 	o->group_off[n_groups] = n;

@@ -5,11 +5,14 @@
  * `-x` walks a list of them one after another (src/main.c:396-406); inside, find_clouds_and_align() reads the whole bucket
  * (read_special_fastq, src/align.c:258) and calls append_alignments() for every pair (src/align.c:307-349).  Here the same
  * three steps -- ema_bucket_read (include/ema_ingest.h), ema_engine_align_pairs, ema_batch_append_alignments
- * (include/ema_engine.h) -- run as a pipeline over the list: a reader thread parses bucket k+1.. ahead, two sets of batch
- * buffers on the one index (the engine and its ema_engine_peer) take alternate buckets so that staging and fetching of one
- * overlap the kernels of the other, and the caller's sink sees bucket 0, 1, 2, ... in order, each with its candidates
- * (ema_batch_out) and its append_alignments records (ema_aln_out).  BASELINE configs[2] (500 buckets streamed on one GPU)
- * is this call; with G GPUs each process calls it on its own buckets (b mod G, no data-path collective).
+ * (include/ema_engine.h) -- run as a pipeline over the list: a reader thread parses buckets ahead; a stager converts and
+ * uploads the next pass's input; the engine thread queues asynchronous passes on ONE set of batch buffers (up to
+ * EMA_MAX_INFLIGHT in flight), fetches the oldest and runs its append stage while the younger ones compute; and the caller's
+ * sink sees bucket 0, 1, 2, ... in order, each with its candidates (ema_batch_out) and its append_alignments records
+ * (ema_aln_out).  Small buckets that are waiting behind one another share a pass (laid end to end up to the batch capacity,
+ * the results cut apart again): the engine's kernels want batches of a million pairs, preproc's buckets are 100-200 K.
+ * BASELINE configs[2] (500 buckets streamed on one GPU) is this call; with G GPUs each process calls it on its own buckets
+ * (b mod G, no data-path collective).
  * Host code only; links into libema_engine.so.
  */
 #ifndef EMA_STREAM_H
@@ -29,10 +32,11 @@ extern "C" {
 typedef struct {
 	int bc_len, is_haplotag, max_read_len;   /* bucket reader: the platform's barcode (reference src/techs.c:74-119), longest read */
 	double error_rate;                       /* append stage: the platform's error rate (reference src/techs.c; 0.001 for 10x) */
-	int n_engines;                           /* 0 / 1 (default) = one set of batch buffers, passes queued two deep (ema_engine_run_async): staging of
+	int n_engines;                           /* 0 / 1 (default) = one set of batch buffers, asynchronous passes (ema_engine_run_async): staging of
 	                                          * bucket k+1, kernels of bucket k, fetch + append of bucket k-1 overlap; 2 = the older schedule, alternate
 	                                          * buckets on the engine and its ema_engine_peer(), one pass each */
-	int read_ahead;                          /* buckets parsed ahead of the engine (0 = default 2) */
+	int read_ahead;                          /* buckets parsed ahead of the engine (0 = default 2) -- or, with small buckets, as many as make up
+	                                          * that many full batches */
 } ema_stream_opts;
 void ema_stream_opts_default(ema_stream_opts *o);   /* 16, 0, 255, 0.001, 0, 0 */
 

@@ -22,7 +22,7 @@ if [[ $what == *bench* ]]; then
   EMA_PHASE_PROFILE=2 timeout 600 python3 "$root/tools/gpu_readlog.py" "$tag" > "$out/readlog.txt" 2>&1; echo "readlog: rc=$?"; tail -40 "$out/readlog.txt"
 fi
 if [[ $what == *sam* ]]; then
-  timeout 900 python3 "$root/tools/gpu_sam_rate.py" 6 200000 > "$out/sam_rate.txt" 2>&1; echo "sam: rc=$?"; tail -12 "$out/sam_rate.txt"
+  EMA_SAM_REPEAT=4 timeout 900 python3 "$root/tools/gpu_sam_rate.py" 25 200000 > "$out/sam_rate.txt" 2>&1; echo "sam: rc=$?"; tail -12 "$out/sam_rate.txt"
 fi
 if [[ $what == *cpuscale* ]]; then
   timeout 600 python3 "$root/tools/cpu_scaling.py" 3000 > "$out/cpu_scaling.txt" 2>&1; echo "cpuscale: rc=$?"; cat "$out/cpu_scaling.txt"
@@ -42,6 +42,10 @@ if [[ $what == *pmc* ]]; then
     echo "pmc$i ($set): rc=$?"
   done
   python3 "$root/tools/pmc_summary.py" --csv "$out"/pmc* > "$out/pmc_summary.csv" 2> /dev/null
+fi
+if [[ $what == *rebench* ]]; then      # the bench line once more, now with K1's traffic and K2's instruction count from this call's PMC passes
+  cp "$out/pmc_summary.csv" "$root/profiles/r02_pmc_grch38scale.csv"
+  timeout 1500 python3 "$root/bench.py" > "$out/bench_with_pmc.json" 2> "$out/bench_with_pmc.err"; echo "rebench: rc=$?"; cut -c1-300 "$out/bench_with_pmc.json"
 fi
 # the per-dispatch traces are large; keep the statistics and the counter tables
 find "$out" -name "*kernel_trace.csv" -size +8M -delete

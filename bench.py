@@ -530,7 +530,10 @@ def main(argv=None):
         roofline_k2b = None
         # (K2b, K2c and K2d are builds of one template, ema_k_align_t<SMALL;AVL;WPS;MODE>: their instructions are summed per K2b launch)
         k2_names = sorted({k for k, c in (tab or {}) if c == "SQ_INSTS_VALU" and (k == "ema_k_align" or k.startswith("ema_k_align_t<"))})
-        k2_main = [k for k in k2_names if k == "ema_k_align" or k.endswith(";0>")]
+        def k2_mode(k):      # ema_k_align_t<SMALL;AVL;WPS;MODE;PROF>
+            a = k[k.index("<") + 1:k.rindex(">")].split(";") if "<" in k else []
+            return a[3] if len(a) > 3 else "0"
+        k2_main = [k for k in k2_names if k2_mode(k) == "0"]
         if k2_names and k2_main and kernel_ms_isolated:
             insts = sum(tab[(k, "SQ_INSTS_VALU")][0] for k in k2_names)
             launches = max(tab[(k, "SQ_INSTS_VALU")][1] for k in k2_main)

@@ -249,13 +249,15 @@ __device__ inline int lane_sort_dedup(const DevIndex &ix, const DevOpts &o, int 
 
 // One lane = one read; a wave takes 64 consecutive reads at a time from the shared counter.
 // todo / n_todo: reads left for K2b (n_todo zero on entry).  scratch: EMA_LANE_WAVE_BYTES per resident wave.
+template <bool PROF>      // PROF: the diagnostic build (phase clocks); the product build carries none of its registers
 __global__ void __launch_bounds__(256)
-ema_k_align_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
+ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,
                    uint8_t *__restrict__ scratch, int *__restrict__ counter, int *__restrict__ todo, int *__restrict__ n_todo,
-                   int *__restrict__ todo_mid, int *__restrict__ n_todo_mid, int mid_seeds, uint8_t *__restrict__ hand, unsigned long long *prof)
+                   int *__restrict__ todo_mid, int *__restrict__ n_todo_mid, int mid_seeds, uint8_t *__restrict__ hand, unsigned long long *prof_arg)
 {
+	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	// diagnostic phase timing (prof != null): shader clocks per phase of this wave (all lanes move together)
 	unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
 	int phase = 0;
@@ -493,7 +495,7 @@ extern "C" size_t ema_align_lane_wave_bytes() { return EMA_LANE_WAVE_BYTES; }
 extern "C" int ema_align_simple_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_simple, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_simple_t<false>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }
 
@@ -502,6 +504,10 @@ extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, 
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int *todo_mid,
                                         int *n_todo_mid, int mid_seeds, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
-	hipLaunchKernelGGL(ema_k_align_simple, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
-	                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, todo_mid, n_todo_mid, mid_seeds, hand, prof);
+	if (prof)
+		hipLaunchKernelGGL(ema_k_align_simple_t<true>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
+		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, todo_mid, n_todo_mid, mid_seeds, hand, prof);
+	else
+		hipLaunchKernelGGL(ema_k_align_simple_t<false>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
+		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, todo_mid, n_todo_mid, mid_seeds, hand, prof);
 }

@@ -141,7 +141,7 @@ def make_batches(args, rank, world, workdir, n_batches):
     out = []
     for path in paths:
         z = np.load(path)
-        out.append(synth.Pairs(z["bases"], z["off"]))
+        out.append(synth.Pairs(z["bases"], z["off"], z["barcodes"] if "barcodes" in z.files else None))
     log(f"[rank {rank}] {n_batches} batches x {args.pairs} pairs: {len(todo)} simulated, {n_batches - len(todo)} from {workdir}, {time.time() - t:.1f}s")
     return out
 
@@ -221,6 +221,46 @@ def pmc_table(name):
     for r in csv.DictReader(open(path)):
         t[(r["kernel"], r["counter"])] = (float(r["sum_over_run"]), float(r["launches"]))
     return t
+
+
+def sam_leg(args, eng, batches, workdir, world):
+    """SURVEY 8(d)'s end-to-end figure beside the hot path's: bucket FILES -> SAM text through one ema_stream_sam call (reader,
+    engine, append stage, clouds / EM / duplicates, formatter) to /dev/null, on buckets of `preproc`'s size cut from the bench
+    batches.  Runs last: it stages its own input over the resident batches.  N = 1 only."""
+    if world != 1 or any(b.barcodes is None for b in batches[:2]):
+        return None
+    from ema_amd import stream, synth
+    try:
+        n_files, per, rep = 4, min(262144, args.pairs), 4
+        t = time.time()
+        paths = []
+        for k in range(n_files):
+            src = batches[k % len(batches)]
+            lo = (k // len(batches)) * per
+            path = os.path.join(workdir, f"bench-bucket-{k:03d}")
+            synth.write_special_fastq_fixed(path, src.subset(lo, lo + per))
+            paths.append(path)
+        t_write = time.time() - t
+        fd = os.open("/dev/null", os.O_WRONLY)
+        stream.stream_sam(eng, paths[:1], fd, rg_id=b"rg1")      # warm-up: page cache, buffers
+        t0 = time.perf_counter()
+        bst, sst = stream.stream_sam(eng, paths * rep, fd, rg_id=b"rg1", continue_cloud_ids=True)
+        dt = time.perf_counter() - t0
+        os.close(fd)
+        for path in paths:
+            os.remove(path)
+        tot = n_files * rep * per
+        log(f"[rank 0] bucket files -> SAM text: {tot / dt:.0f} pairs/s ({n_files * rep} buckets of {per} pairs in {dt:.2f}s; files written in {t_write:.1f}s)")
+        return {"value": round(tot / dt, 1), "unit": "pairs/s", "buckets": n_files * rep, "pairs_per_bucket": per,
+                "what": "bucket files (preproc's one-pair-per-line form, page cache) -> SAM text on /dev/null through ONE ema_stream_sam call: reader, "
+                        "staging, K1-K4, fetch, append stage, clouds / EM / duplicate marking, formatter; small buckets share passes; host stages on "
+                        "the CPUs the box grants",
+                "stage_seconds": {"reader": round(sum(s["read_s"] for s in bst), 3), "append": round(sum(s["append_s"] for s in bst), 3),
+                                  "clouds_em_duplicates": round(sum(s["select_s"] for s in sst), 3), "formatter_and_write": round(sum(s["write_s"] for s in sst), 3)},
+                "sam_lines": int(sum(s["lines"] for s in sst))}
+    except Exception as e:      # an extra: never at the cost of the line
+        log(f"[rank 0] bucket files -> SAM text leg failed: {e}")
+        return None
 
 
 def main(argv=None):
@@ -592,6 +632,7 @@ def main(argv=None):
             "bucket_stats": {f: int(gathered[:, i].sum()) for i, f in enumerate(shard.STAT_FIELDS)},
         }
         out["bucket_stats"].update(capacity_flags=int(any_flag), oracle_spot_check_pairs=len(kept), oracle_spot_check_mismatches=int(bad))
+        out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not args.no_extras else None
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -215,6 +215,32 @@ def write_special_fastq(path, pairs: Pairs, qual="F"):
                                r2, qual.encode() * len(r2)]) + b"\n")
 
 
+def write_special_fastq_fixed(path, pairs: Pairs, qual=b"F"):
+    """The same file for a batch whose mates all have one length each (what make_pairs produces), written as ONE array:
+    identifiers are zero-padded to a fixed width, so every line has the same length."""
+    n = pairs.n
+    l1 = int(pairs.off[1] - pairs.off[0]); l2 = int(pairs.off[2] - pairs.off[1])
+    reads = np.asarray(pairs.bases).reshape(n, l1 + l2)
+    w = max(1, len(str(n - 1)))
+    ids = np.char.zfill(np.arange(n).astype(str), w).astype("S").view(np.uint8).reshape(n, w)
+    L = 16 + 1 + 2 + w + 1 + l1 + 1 + l1 + 1 + l2 + 1 + l2 + 1
+    out = np.empty((n, L), dtype=np.uint8)
+    c = 0
+    out[:, c:c + 16] = pairs.barcodes; c += 16
+    out[:, c] = 32; out[:, c + 1] = ord("@"); out[:, c + 2] = ord("s"); c += 3
+    out[:, c:c + w] = ids; c += w
+    out[:, c] = 32; c += 1
+    out[:, c:c + l1] = reads[:, :l1]; c += l1
+    out[:, c] = 32; c += 1
+    out[:, c:c + l1] = qual[0]; c += l1
+    out[:, c] = 32; c += 1
+    out[:, c:c + l2] = reads[:, l1:]; c += l2
+    out[:, c] = 32; c += 1
+    out[:, c:c + l2] = qual[0]; c += l2
+    out[:, c] = 10
+    out.tofile(path)
+
+
 def bench_batch(job):
     """Worker of bench.py's read simulation: (genome.npy, contig lengths, pairs, seed, len1, len2, out.npz) -> one batch on disk.
     The genome is memory-mapped, so a pool of these shares one copy in the page cache."""
@@ -225,7 +251,7 @@ def bench_batch(job):
         ctg.append(flat[at:at + n]); at += n
     p = make_pairs(ctg, n_pairs, seed=seed, len1=len1, len2=len2, flat=flat)
     tmp = out + ".tmp.npz"
-    np.savez(tmp, bases=p.bases, off=p.off)
+    np.savez(tmp, bases=p.bases, off=p.off, barcodes=p.barcodes)
     import os
     os.replace(tmp, out)
     return out

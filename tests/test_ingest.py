@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ema_amd import ingest
+from ema_amd import ingest, synth
 
 BASES = b"ACGT"
 
@@ -205,3 +205,19 @@ def test_the_first_bad_line_is_the_one_reported():
     with pytest.raises(ingest.BucketError) as e:
         ingest.parse_bucket(text)
     assert "line 2" in str(e.value) and "ACGT" in str(e.value)
+
+
+def test_fixed_width_bucket_writer_reads_back_like_the_per_pair_writer(tmp_path):
+    """synth.write_special_fastq_fixed (one array write; identifiers zero-padded) and synth.write_special_fastq (a line per pair)
+    produce buckets that differ in nothing but the identifiers' spelling: what bench.py's bucket-files-to-SAM leg feeds."""
+    ctg = synth.make_genome([120000], seed=5)
+    pairs = synth.make_pairs(ctg, 700, seed=9)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    synth.write_special_fastq(a, pairs)
+    synth.write_special_fastq_fixed(b, pairs)
+    ba, bb = ingest.read_bucket(a), ingest.read_bucket(b)
+    assert ba.n_pairs == bb.n_pairs == 700
+    assert np.array_equal(ba.bc, bb.bc) and np.array_equal(ba.off, bb.off)
+    # equal barcodes keep file order, and both files list the pairs in the same order: the payloads line up
+    assert bytes(ba.bases) == bytes(bb.bases) and bytes(ba.quals) == bytes(bb.quals)
+    assert [int(ba.ident(i)[2:]) for i in range(700)] == [int(bb.ident(i)[2:]) for i in range(700)]

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -55,6 +56,7 @@ struct Stream {
 	std::condition_variable cv;
 	size_t delivered = 0, pairs_read = 0, pairs_delivered = 0;
 	bool stop = false;
+	bool sink_kept = false;      // set by a sink of this file that took the bucket's objects over (they are not freed on its return)
 	bool trace = getenv("EMA_STREAM_TRACE") != nullptr;      // when what happened, on stderr
 	double t_start = now_s();
 };
@@ -234,20 +236,29 @@ void stager(Stream &S, AsyncState &A)
 			std::unique_lock<std::mutex> lk(S.mu);
 			S.cv.wait(lk, [&] { return S.stop || (S.items[k].state == ST_LOADED && A.passes.size() < A.n_run + (size_t)kInSlots); });
 			if (S.stop) return;
-			// the buckets already waiting behind this one come along while they fit the batch
-			ps.first = k; ps.len = 1;
-			const Item &h = S.items[k];
-			if (h.rc == EMA_OK && h.slot < 0 && h.n_pairs <= S.cap) {
+			// the buckets already waiting behind this one come along while they fit the batch; a pass that would be less than half
+			// a batch waits a moment (at most 60 ms) for the reader, if it is still at work on the next bucket
+			const double t_wait0 = now_s();
+			for (;;) {
+				ps.first = k; ps.len = 1;
+				const Item &h = S.items[k];
 				size_t sum = h.n_pairs;
-				uint64_t bytes = h.off ? h.off[2 * h.n_pairs] : 0;
-				while (k + ps.len < n && ps.len < kMaxGroup) {
-					const Item &x = S.items[k + ps.len];
-					if (x.state != ST_LOADED || x.rc != EMA_OK || x.slot >= 0 || sum + x.n_pairs > S.cap) break;
-					bytes += x.off ? x.off[2 * x.n_pairs] : 0;
-					if (bytes > 0xfffffff0ULL) break;
-					sum += x.n_pairs; ++ps.len;
+				bool more_coming = false;
+				if (h.rc == EMA_OK && h.slot < 0 && h.n_pairs <= S.cap) {
+					uint64_t bytes = h.off ? h.off[2 * h.n_pairs] : 0;
+					while (k + ps.len < n && ps.len < kMaxGroup) {
+						const Item &x = S.items[k + ps.len];
+						if (x.state == ST_EMPTY && S.paths) { more_coming = true; break; }
+						if (x.state != ST_LOADED || x.rc != EMA_OK || x.slot >= 0 || sum + x.n_pairs > S.cap) break;
+						bytes += x.off ? x.off[2 * x.n_pairs] : 0;
+						if (bytes > 0xfffffff0ULL) break;
+						sum += x.n_pairs; ++ps.len;
+					}
 				}
+				if (!more_coming || 2 * sum >= S.cap || now_s() - t_wait0 > 0.06 || S.stop) break;
+				S.cv.wait_for(lk, std::chrono::milliseconds(4));
 			}
+			if (S.stop) return;
 		}
 		Item &it = S.items[k];
 		int ok = 1;
@@ -450,6 +461,7 @@ int run_stream(ema_engine_t *e, Stream &S, ema_stream_sink sink, void *user, ema
 			else rc = EMA_OK;
 		} else g_err = (S.paths ? std::string(S.paths[k]) + ": " : std::string()) + it.err;
 		if (S.trace) fprintf(stderr, "[stream] sink: bucket %zu %.3f..%.3f\n", k, t_s0 - S.t_start, now_s() - S.t_start);
+		if (S.sink_kept) { it.bk = nullptr; it.b = nullptr; it.a = nullptr; S.sink_kept = false; }      // (ema_stream_sam's sink: its writer frees them)
 		release(it);
 		{
 			std::lock_guard<std::mutex> lk(S.mu);
@@ -512,6 +524,10 @@ int ema_stream_batches(ema_engine_t *e, const char *const *bases, const uint32_t
 }
 
 namespace {
+// ema_stream_sam's sink: clouds / EM / duplicates on the calling thread, the formatter + write of the bucket before on a
+// writer thread (the lines point into the bucket, the batch and the selection, so the sink takes those over from the stream
+// and the writer frees them).
+struct WriteJob { size_t k; ema_clouds_out *sel; ema_bucket *bk; ema_batch_out *b; ema_aln_out *a; };
 struct SamSink {
 	ema_engine_t *e;
 	ema_sam_run_opts o;
@@ -520,7 +536,41 @@ struct SamSink {
 	std::vector<const char *> names;
 	int32_t next_cloud_id;
 	std::string err;
+	Stream *stream = nullptr;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<WriteJob> jobs;
+	bool closing = false;
+	int write_rc = EMA_OK;
 };
+
+void sam_writer(SamSink &S)
+{
+	for (;;) {
+		WriteJob j;
+		{
+			std::unique_lock<std::mutex> lk(S.mu);
+			S.cv.wait(lk, [&] { return S.closing || !S.jobs.empty(); });
+			if (S.jobs.empty()) return;
+			j = S.jobs.front();
+		}
+		size_t n_bytes = 0;
+		const double t0 = now_s();
+		int rc = EMA_OK;
+		if (S.write_rc == EMA_OK) rc = ema_sam_write(S.fd, j.sel->lines, j.sel->n_lines, &S.o.sam, &n_bytes);
+		if (S.sstats) S.sstats[j.k].write_s = now_s() - t0;
+		ema_clouds_free(j.sel);
+		if (j.a) ema_aln_free(j.a);
+		if (j.b) ema_batch_free(j.b);
+		if (j.bk) ema_bucket_free(j.bk);
+		{
+			std::lock_guard<std::mutex> lk(S.mu);
+			if (rc != EMA_OK && S.write_rc == EMA_OK) S.write_rc = rc;
+			S.jobs.pop_front();
+		}
+		S.cv.notify_all();
+	}
+}
 
 int sam_sink(void *user, size_t k, const ema_bucket *bk, const ema_batch_out *b, const ema_aln_out *a)
 {
@@ -532,12 +582,14 @@ int sam_sink(void *user, size_t k, const ema_bucket *bk, const ema_batch_out *b,
 	if (rc != EMA_OK) { S.err = "ema_clouds_select failed"; if (sel) ema_clouds_free(sel); return rc; }
 	S.next_cloud_id = sel->next_cloud_id;
 	if (S.sstats) S.sstats[k] = sel->stats;
-	size_t n_bytes = 0;
-	const double t0 = now_s();
-	rc = ema_sam_write(S.fd, sel->lines, sel->n_lines, &S.o.sam, &n_bytes);
-	if (S.sstats) S.sstats[k].write_s = now_s() - t0;
-	ema_clouds_free(sel);
-	if (rc != EMA_OK) { S.err = "ema_sam_write failed"; return rc; }
+	{
+		std::unique_lock<std::mutex> lk(S.mu);
+		S.cv.wait(lk, [&] { return S.jobs.size() < 2; });      // at most two buckets' worth of objects wait for the writer
+		if (S.write_rc != EMA_OK) { lk.unlock(); ema_clouds_free(sel); S.err = "ema_sam_write failed"; return S.write_rc; }
+		S.jobs.push_back(WriteJob{k, sel, const_cast<ema_bucket *>(bk), const_cast<ema_batch_out *>(b), const_cast<ema_aln_out *>(a)});
+	}
+	S.cv.notify_all();
+	S.stream->sink_kept = true;      // the writer frees them
 	return 0;
 }
 }  // namespace
@@ -563,7 +615,21 @@ int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const em
 	S.o.sam.bc_len = S.o.stream.bc_len; S.o.sam.is_haplotag = S.o.stream.is_haplotag;      // one platform for reader and writer
 	const int nc = ema_engine_n_contigs(e);
 	for (int i = 0; i < nc; ++i) S.names.push_back(ema_engine_contig_name(e, i));
-	const int rc = ema_stream_buckets(e, paths, n, &S.o.stream, sam_sink, &S, bstats);
+	Stream T;
+	T.o = S.o.stream;
+	T.paths = paths;
+	T.items.resize(n);
+	for (auto &it : T.items) memset(&it.st, 0, sizeof(it.st));
+	S.stream = &T;
+	std::thread writer(sam_writer, std::ref(S));
+	int rc = run_stream(e, T, sam_sink, &S, bstats);
+	{
+		std::lock_guard<std::mutex> lk(S.mu);
+		S.closing = true;
+	}
+	S.cv.notify_all();
+	writer.join();
+	if (rc == EMA_OK && S.write_rc != EMA_OK) { rc = S.write_rc; S.err = "ema_sam_write failed"; }
 	if (rc != EMA_OK && !S.err.empty()) g_err = S.err;
 	return rc;
 }

@@ -71,13 +71,18 @@ struct SeedPark {
 // kernel (park_in / n_park_in set, same grid) takes parked machines instead of fresh reads, 64 to a wave again.  The
 // engine queues a fixed, short series of such launches, the last one with park_max = 0.  (Each launch shrinks the
 // parked population about 64 / park_max-fold; a wave that starts with no more than park_max machines keeps them.)
-__global__ void __launch_bounds__(256)
-ema_k_seed(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
+#ifndef EMA_SEED_WPS
+#define EMA_SEED_WPS 1
+#endif
+template <bool PROF>      // PROF: the diagnostic build (tick statistics); the product build carries none of its registers
+__global__ void __launch_bounds__(256, EMA_SEED_WPS)
+ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv,
            int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
            int *__restrict__ counter, const SeedPark *__restrict__ park_in, const int *__restrict__ n_park_in,
-           SeedPark *__restrict__ park_out, int *__restrict__ n_park_out, int park_max, unsigned long long *prof)
+           SeedPark *__restrict__ park_out, int *__restrict__ n_park_out, int park_max, unsigned long long *prof_arg)
 {
+	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
 	__shared__ uint32_t lds_n[4][8 * 64];       // N mask, 8 words per lane
 	const int lane = (int)(threadIdx.x & 63), wib = (int)(threadIdx.x >> 6);
@@ -390,14 +395,18 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
                                 int *n_park_out, int park_max, int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
-	hipLaunchKernelGGL(ema_k_seed, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
-	                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, prof);
+	if (prof)
+		hipLaunchKernelGGL(ema_k_seed_t<true>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
+		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, prof);
+	else
+		hipLaunchKernelGGL(ema_k_seed_t<false>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
+		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, prof);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)
 extern "C" int ema_seed_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_seed, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_seed_t<false>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

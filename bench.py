@@ -549,9 +549,10 @@ def main(argv=None):
         traffic, traffic_source = None, None
         pmc_name = {0.0: "r02_pmc_chr20.csv", 3100.0: "r02_pmc_grch38scale.csv"}.get(float(args.genome_mbp))
         tab = pmc_table(pmc_name) if (pmc_name and default_run) else None
-        if tab and ("ema_k_seed", "FETCH_SIZE") in tab and ("ema_k_seed", "WRITE_SIZE") in tab:
+        k1_name = next((k for k in ("ema_k_seed_t<false>", "ema_k_seed") if tab and (k, "FETCH_SIZE") in tab and (k, "WRITE_SIZE") in tab), None)
+        if k1_name:      # (the product build of the template, or the plain kernel of older profiles)
             series = eng.seed_launches_per_series()
-            kb = sum(tab[("ema_k_seed", c)][0] / (tab[("ema_k_seed", c)][1] / series) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+            kb = sum(tab[(k1_name, c)][0] / (tab[(k1_name, c)][1] / series) for c in ("FETCH_SIZE", "WRITE_SIZE"))
             traffic = int(kb * 1024)
             traffic_source = f"profiles/{pmc_name} (separate FETCH_SIZE and WRITE_SIZE passes of this command; stored, not measured in this run)"
         roofline = {"bound": "hbm", "kernel": "ema_k_seed", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,42 @@
+"""Writes tests/golden/count_vectors.json: inputs (tests/count_cases.py) and the bytes the REFERENCE's `ema count` produced for them
+-- oracle/_ref/ref_count, i.e. /root/reference/cpp/count.cc compiled where it lies (oracle/Makefile, target ref).  Run in the
+build container (the reference tree is needed); the vectors are what pins the product on a machine without it.
+  python tests/golden/make_count_vectors.py"""
+import base64, json, os, random, subprocess, sys, tempfile
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(R, "tests"))
+import count_cases as K
+
+REF = os.path.join(R, "oracle", "_ref", "ref_count")
+
+
+def run_ref(wl_text, fastq_text, max_map, haplotag):
+    with tempfile.TemporaryDirectory() as d:
+        wl = os.path.join(d, "wl.txt")
+        open(wl, "w").write(wl_text)
+        subprocess.run([REF, wl, os.path.join(d, "o"), str(max_map), str(int(haplotag))], input=fastq_text.encode("latin-1"), check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = {}
+        for ext in ("ema-fcnt", "ema-ncnt"):
+            p = os.path.join(d, "o." + ext)
+            out[ext] = base64.b64encode(open(p, "rb").read()).decode() if os.path.exists(p) else None
+        return out
+
+
+def main():
+    cases = []
+    rng = random.Random(2024)
+    for seed, n_wl, n, max_map, nl in ((1, 50, 400, 1 << 30, True), (2, 8, 300, 72 * 40, True), (3, 200, 0, 1 << 30, True), (4, 30, 120, 1 << 30, False)):
+        wl = K.whitelist(rng, n_wl)
+        wl_text = "\n".join(wl) + "\n"
+        if seed == 2:
+            wl_text += wl[0] + "\n" + wl[1][:16] + "TTTT\n"      # a duplicate line and a line longer than a barcode
+        fq = K.tenx_fastq(seed, wl, n, nl)
+        cases.append({"name": f"10x_{seed}", "whitelist": wl_text, "fastq": fq, "max_map_size": max_map, "haplotag": 0, "expect": run_ref(wl_text, fq, max_map, False)})
+    json.dump({"made_by": "tests/golden/make_count_vectors.py with oracle/_ref/ref_count (reference cpp/count.cc)", "cases": cases},
+              open(os.path.join(R, "tests", "golden", "count_vectors.json"), "w"), indent=0)
+    print(len(cases), "cases")
+
+
+if __name__ == "__main__":
+    main()

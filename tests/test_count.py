@@ -1,0 +1,95 @@
+"""`ema count` behind include/ema_count.h against the REFERENCE's own implementation (cpp/count.cc:38-182): the committed golden
+vectors (tests/golden/count_vectors.json, written by the reference compiled into oracle/_ref/ref_count) everywhere, and fresh
+random inputs through that binary where it exists (the build container).  Both output files byte for byte."""
+import base64
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+import count_cases as K
+from ema_amd import count as ema_count
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_count")
+
+
+def product(tmp_path, wl_text, fastq_text, max_map, haplotag):
+    wl = tmp_path / "wl.txt"
+    wl.write_text(wl_text)
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(fastq_text.encode("latin-1"))
+    prefix = str(tmp_path / "out")
+    for ext in ("ema-fcnt", "ema-ncnt"):
+        if os.path.exists(prefix + "." + ext):
+            os.remove(prefix + "." + ext)
+    st = ema_count.count_fastq(None if haplotag else str(wl), str(fq), prefix, max_map, bool(haplotag))
+    out = {}
+    for ext in ("ema-fcnt", "ema-ncnt"):
+        out[ext] = open(prefix + "." + ext, "rb").read() if os.path.exists(prefix + "." + ext) else None
+    return out, st
+
+
+def reference(tmp_path, wl_text, fastq_text, max_map, haplotag):
+    wl = tmp_path / "rwl.txt"
+    wl.write_text(wl_text)
+    prefix = str(tmp_path / "ref")
+    subprocess.run([REF, str(wl), prefix, str(max_map), str(int(haplotag))], input=fastq_text.encode("latin-1"), check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return {ext: (open(prefix + "." + ext, "rb").read() if os.path.exists(prefix + "." + ext) else None) for ext in ("ema-fcnt", "ema-ncnt")}
+
+
+def test_golden_vectors_of_the_reference(tmp_path):
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "count_vectors.json")))
+    assert len(doc["cases"]) >= 4
+    for c in doc["cases"]:
+        got, st = product(tmp_path, c["whitelist"], c["fastq"], c["max_map_size"], c["haplotag"])
+        for ext, b64 in c["expect"].items():
+            want = base64.b64decode(b64) if b64 is not None else None
+            assert got[ext] == want, f"{c['name']}: .{ext} differs from the reference's"
+        assert st["total_reads"] + st["ignored_reads"] > 0 or c["fastq"] == ""
+
+
+def test_blocks_statistics_and_errors(tmp_path):
+    rng = random.Random(5)
+    wl = K.whitelist(rng, 20)
+    fq = K.tenx_fastq(11, wl, 500)
+    got, st = product(tmp_path, "\n".join(wl) + "\n", fq, 72 * 25, 0)      # a block every 25 distinct barcode+quality strings
+    assert st["full_blocks"] > 3 and st["whitelist"] == 20 and st["nice_reads"] <= st["total_reads"]
+    # the file is the blocks end to end: {int64 n; n x (16 bytes, int64)}
+    at, blocks = 0, 0
+    f = got["ema-fcnt"]
+    while at < len(f):
+        n = int.from_bytes(f[at:at + 8], "little"); at += 8 + 24 * n; blocks += 1
+    assert at == len(f) and blocks == st["full_blocks"]
+    n_nice = int.from_bytes(got["ema-ncnt"][:8], "little")
+    assert len(got["ema-ncnt"]) == 8 + 12 * n_nice and n_nice == st["nice_barcodes"]
+    with pytest.raises(RuntimeError, match="AAA"):
+        product(tmp_path, "A" * 16 + "\n", fq, 1 << 30, 0)
+    with pytest.raises(RuntimeError, match="Cannot open"):
+        ema_count.count_fastq(str(tmp_path / "no_such_whitelist"), str(tmp_path / "in.fastq"), str(tmp_path / "o2"))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's count (oracle/_ref/ref_count) is built where /root/reference exists")
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_random_inputs_against_the_reference_binary(tmp_path, seed):
+    rng = random.Random(seed)
+    wl = K.whitelist(rng, rng.choice([5, 60, 700]))
+    wl_text = "\n".join(wl) + ("\n" if seed != 22 else "")      # (a whitelist without a final newline)
+    fq = K.tenx_fastq(seed, wl, rng.choice([1, 250, 900]), last_newline=seed != 23)
+    max_map = rng.choice([72 * 7, 72 * 64, 1 << 30])
+    got, _ = product(tmp_path, wl_text, fq, max_map, 0)
+    want = reference(tmp_path, wl_text, fq, max_map, 0)
+    assert got == want
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's count (oracle/_ref/ref_count) is built where /root/reference exists")
+def test_haplotag_against_the_reference_binary(tmp_path):
+    """All 96^4 barcodes are whitelisted in this mode (a 85 M-entry hash map in the reference and, for the same output order, here:
+    half a minute each)."""
+    fq = K.haplotag_fastq(31, 300)
+    got, st = product(tmp_path, "", fq, 1 << 30, 1)
+    want = reference(tmp_path, "", fq, 1 << 30, 1)
+    assert got == want and got["ema-fcnt"] is None and st["whitelist"] == 96 ** 4

@@ -1,0 +1,465 @@
+// ema_amd/csrc/host_preproc.cpp -- `ema preproc` behind the C ABI of include/ema_preproc.h (reference cpp/correct.cc:271-633).
+//
+// Same shape as host_count.cpp: the stream is read through a large buffer instead of std::getline, the per-bucket text is
+// appended to growing buffers, and the one container whose iteration order is part of the result -- the reference's
+// std::unordered_map<uint32_t, Count>: it orders the floating-point sum of the priors and the deal of barcodes to buckets --
+// is that same container filled in the same order.  The correction of the barcode strings runs on n_threads threads over
+// disjoint ranges, as in the reference; its results do not depend on the split (priors are read-only there, the counts are
+// integer sums).  Every double-precision expression is the reference's, in its order; built with -ffp-contract=off.
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+#include <sys/stat.h>
+#include <unistd.h>
+#include "ema_preproc.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+const int kBcLen = 16, kTrim = 7, kQualOffset = 33, kQualBase = 34, kMinRead = 32;      // cpp/common.h:56-63
+const double kConf = 0.975;                                                                // BC_CONF_THRESH, cpp/correct.cc:24
+enum { NOCHANGE = 0, H1CHANGE = 1, H2CHANGE = 2, NOBUCKET = 3 };
+
+struct Count { int64_t n_reads = 0; double prior = 0; int bucket = 0; };      // cpp/correct.cc:33-39
+typedef std::unordered_map<uint32_t, Count> Known;
+
+inline int code2(unsigned char c)
+{
+	switch (c) { case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 0; }
+}
+inline int code2n(unsigned char c) { return (c == 'N' || c == 'n') ? 4 : code2(c); }
+
+double g_probs[128];      // initialize_probs, cpp/correct.cc:52-57
+void init_probs()
+{
+	for (int i = 0; i < 128; ++i) g_probs[i] = pow(10.0, -std::min(kQualBase - 1, i) / 10.0);
+}
+inline double prob_of(double x) { return g_probs[(int)(char)x]; }      // get_prob(char): the double argument narrows to char
+
+struct Key16 {
+	unsigned char b[16];
+	bool operator==(const Key16 &o) const { return memcmp(b, o.b, 16) == 0; }
+};
+struct Key16Hash {
+	size_t operator()(const Key16 &k) const
+	{
+		uint64_t a, c; memcpy(&a, k.b, 8); memcpy(&c, k.b + 8, 8);
+		uint64_t h = a * 0x9E3779B97F4A7C15ULL ^ (c + 0x7F4A7C15ULL) * 0xD6E8FEB86659FD93ULL;
+		return (size_t)(h ^ h >> 29);
+	}
+};
+typedef std::unordered_map<Key16, uint32_t, Key16Hash> Corrected;
+
+struct Full { Key16 q; uint32_t bc; int64_t cnt; };
+
+// correct_barcode, cpp/correct.cc:66-184, for entries [lo, hi)
+void correct_range(std::vector<Full> &full, size_t lo, size_t hi, const Known &known, bool do_h2, Corrected &corrected, int64_t stats[4])
+{
+	for (size_t ii = lo; ii < hi; ++ii) {
+		Full &it = full[ii];
+		const unsigned char *q = it.q.b;
+		const int64_t fc = it.cnt;
+		uint32_t barcode = 0;
+		it.bc = 0;
+		int ns = 0;
+		for (int i = 0; i < kBcLen; ++i) {
+			const char n = (char)(q[i] / kQualBase);
+			barcode = (barcode << 2) | (uint32_t)(n == 4 ? 0 : n);
+			ns += n == 4;
+		}
+		if (ns > 1) { stats[NOBUCKET] += fc; continue; }
+		auto cit = ns == 0 ? known.find(barcode) : known.end();
+		uint32_t max_barcode = 0;
+		double max_p = -1, total = 0;
+		int type = NOBUCKET;
+		if (cit != known.end()) {
+			max_p = cit->second.prior; max_barcode = barcode; total += max_p; type = NOCHANGE;
+			if (do_h2) for (int i1 = 0; i1 < kBcLen; ++i1) for (int j1 = 0; j1 < 4; ++j1) {
+				if (j1 == q[i1] / kQualBase) continue;
+				for (int i2 = i1 + 1; i2 < kBcLen; ++i2) for (int j2 = 0; j2 < 4; ++j2) {
+					if (j2 == q[i2] / kQualBase) continue;
+					uint32_t bcd = barcode & ~(3u << ((kBcLen - i1 - 1) * 2)) & ~(3u << ((kBcLen - i2 - 1) * 2));
+					bcd |= (uint32_t)j1 << ((kBcLen - i1 - 1) * 2);
+					bcd |= (uint32_t)j2 << ((kBcLen - i2 - 1) * 2);
+					auto c2 = known.find(bcd);
+					if (c2 != known.end()) {
+						const double p1 = prob_of(std::max(3.0, q[i1] % kQualBase - 1.0)), p2 = prob_of(std::max(3.0, q[i2] % kQualBase - 1.0));
+						const double p = c2->second.prior * (p1 * p2);
+						total += p;
+						if (p > max_p) { max_p = p; max_barcode = bcd; type = H2CHANGE; }
+					}
+				}
+			}
+		} else {      // (ns <= 1 here)
+			for (int i = 0; i < kBcLen; ++i) {
+				if (ns && q[i] / kQualBase != 4) continue;
+				for (int j = 0; j < 4; ++j) {
+					if (ns == 0 && j == q[i] / kQualBase) continue;
+					uint32_t bcd = barcode & ~(3u << ((kBcLen - i - 1) * 2));
+					bcd |= (uint32_t)j << ((kBcLen - i - 1) * 2);
+					auto c2 = known.find(bcd);
+					if (c2 != known.end()) {
+						const double p = c2->second.prior * g_probs[q[i] % kQualBase];
+						total += p;
+						if (p > max_p) { max_p = p; max_barcode = bcd; type = H1CHANGE; }
+					}
+				}
+			}
+		}
+		if (max_p / total > kConf) {
+			it.bc = max_barcode;
+			if (type == H1CHANGE || type == H2CHANGE) corrected[it.q] = max_barcode;
+		} else type = NOBUCKET;
+		stats[type] += fc;
+	}
+}
+
+struct Lines {      // the lines of a stream as std::getline sees them (host_count.cpp)
+	int fd;
+	std::vector<char> buf;
+	size_t lo = 0, hi = 0;
+	bool eof = false;
+	explicit Lines(int fd_) : fd(fd_), buf((size_t)16 << 20) {}
+	bool fill()
+	{
+		if (eof) return false;
+		if (lo > 0) { memmove(buf.data(), buf.data() + lo, hi - lo); hi -= lo; lo = 0; }
+		if (hi == buf.size()) buf.resize(buf.size() * 2);
+		for (;;) {
+			const ssize_t n = read(fd, buf.data() + hi, buf.size() - hi);
+			if (n < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+			if (n <= 0) { eof = true; return false; }
+			hi += (size_t)n;
+			return true;
+		}
+	}
+	bool next(std::string &s)      // like std::getline: s is emptied first; false at the end of the stream
+	{
+		s.clear();
+		for (;;) {
+			const char *nl = lo < hi ? (const char *)memchr(buf.data() + lo, '\n', hi - lo) : nullptr;
+			if (nl) { s.assign(buf.data() + lo, (size_t)(nl - (buf.data() + lo))); lo += s.size() + 1; return true; }
+			if (!fill()) {
+				if (lo < hi) { s.assign(buf.data() + lo, hi - lo); lo = hi; return true; }
+				return false;
+			}
+		}
+	}
+};
+
+int kind_of(const std::string &path)      // stat_dir, cpp/common.h:125-139
+{
+	struct stat st;
+	if (stat(path.c_str(), &st) != 0) return 0;
+	if (S_ISDIR(st.st_mode)) return 1;
+	if (S_ISREG(st.st_mode)) return 2;
+	return 3;
+}
+
+struct Out { FILE *f = nullptr; std::string buf; int64_t size = 0; };
+
+}  // namespace
+
+extern "C" const char *ema_preproc_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ema_preproc_fastq(const char *known_barcodes_path, const char *const *ncnt_paths, int n_paths, const char *output_dir,
+                                 int do_h2, size_t buffer_size, int do_bx_format, int n_threads, int n_buckets, int is_haplotag, int in_fd,
+                                 ema_preproc_stats *st)
+{
+	g_err.clear();
+	if (!output_dir || in_fd < 0 || n_paths < 0 || (n_paths && !ncnt_paths) || n_buckets < 1 || (!is_haplotag && !known_barcodes_path)) {
+		g_err = "bad argument";
+		return EMA_EARG;
+	}
+	if (n_threads < 1) n_threads = 1;
+	init_probs();
+	const bool prof = getenv("EMA_PREPROC_PROF") != nullptr;      // per-step wall times on stderr
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		const auto now = std::chrono::steady_clock::now();
+		if (prof) fprintf(stderr, "[preproc] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+		t_last = now;
+	};
+	ema_preproc_stats S;
+	memset(&S, 0, sizeof(S));
+	// ---- 1. known counts (cpp/correct.cc:283-330)
+	Known known;
+	if (!is_haplotag) {
+		FILE *f = fopen(known_barcodes_path, "rb");
+		if (!f) { g_err = std::string("Cannot open file ") + known_barcodes_path; return EMA_EIO; }
+		Lines wl(fileno(f));
+		std::string s;
+		while (wl.next(s)) {
+			uint32_t bc = 0;
+			for (int i = 0; i < kBcLen; ++i) bc = (bc << 2) | (uint32_t)code2((size_t)i < s.size() ? (unsigned char)s[(size_t)i] : 0);
+			if (bc == 0) { fclose(f); g_err = "Invalid barcode AAA...AA whitelisted"; return EMA_EFORMAT; }
+			known[bc].prior = 0;
+		}
+		fclose(f);
+	} else {
+		for (uint32_t a = 1; a <= 96; ++a) for (uint32_t b = 1; b <= 96; ++b) for (uint32_t c = 1; c <= 96; ++c) for (uint32_t d = 1; d <= 96; ++d)
+			known[a << 24 | c << 16 | b << 8 | d].prior = 0;
+	}
+	for (int fi = 0; fi < n_paths; ++fi) {
+		std::string s = ncnt_paths[fi];
+		if (kind_of(s) != 2) { g_err = s + " is not a file"; return EMA_EIO; }
+		if (s.size() < 9 || s.substr(s.size() - 9) != ".ema-ncnt") { g_err = s + " is not an ema-ncnt file"; return EMA_EARG; }
+		if (!is_haplotag) { s[s.size() - 4] = 'f'; if (kind_of(s) != 2) { g_err = s + " is not a file"; return EMA_EIO; } }
+	}
+	for (int fi = 0; fi < n_paths; ++fi) {      // load_barcode_count, :188-206
+		FILE *f = fopen(ncnt_paths[fi], "rb");
+		if (!f) { g_err = std::string("Cannot open file ") + ncnt_paths[fi]; return EMA_EIO; }
+		int64_t total;
+		if (fread(&total, 8, 1, f) != 1) { fclose(f); g_err = "fread failed (corrupted input?)"; return EMA_EFORMAT; }
+		while (total-- > 0) {
+			uint32_t bcd; int64_t cnt;
+			if (fread(&bcd, 4, 1, f) != 1 || fread(&cnt, 8, 1, f) != 1) { fclose(f); g_err = "fread failed (corrupted input?)"; return EMA_EFORMAT; }
+			if (is_haplotag) known[bcd].n_reads += cnt; else known[bcd].prior += (double)cnt;
+		}
+		fclose(f);
+	}
+	if (!is_haplotag) {
+		double total_counts = 0;
+		for (auto &c : known) total_counts += c.second.prior + 1;
+		for (auto &c : known) c.second.prior = (c.second.prior + 1) / total_counts;
+	}
+	S.whitelist = (int64_t)known.size();
+	lap("whitelist and priors");
+	// ---- 2. the barcode strings of .ema-fcnt, corrected (load_and_correct_full_count, :208-268)
+	Corrected corrected;
+	int64_t stats[4] = {0, 0, 0, 0};
+	if (!is_haplotag) for (int fi = 0; fi < n_paths; ++fi) {
+		std::string s = ncnt_paths[fi];
+		s[s.size() - 4] = 'f';
+		FILE *f = fopen(s.c_str(), "rb");
+		if (!f) { g_err = "Cannot open file " + s; return EMA_EIO; }
+		int64_t total;
+		while (fread(&total, 8, 1, f) == 1) {
+			std::vector<Full> full;
+			full.reserve((size_t)std::max<int64_t>(0, total));
+			while (total-- > 0) {
+				Full e; e.bc = 0;
+				if (fread(e.q.b, 1, kBcLen, f) != (size_t)kBcLen || fread(&e.cnt, 8, 1, f) != 1) { fclose(f); g_err = "fread failed (corrupted input?)"; return EMA_EFORMAT; }
+				full.push_back(e);
+			}
+			const size_t per = (size_t)ceil((double)full.size() / n_threads);
+			std::vector<std::thread> th;
+			std::vector<Corrected> part((size_t)n_threads);
+			std::vector<std::vector<int64_t>> pst((size_t)n_threads, std::vector<int64_t>(4, 0));
+			for (int t = 0; t < n_threads; ++t) {
+				const size_t lo = std::min(full.size(), (size_t)t * per), hi = std::min(full.size(), (size_t)(t + 1) * per);
+				th.emplace_back([&, t, lo, hi] { correct_range(full, lo, hi, known, do_h2 != 0, part[(size_t)t], pst[(size_t)t].data()); });
+			}
+			for (auto &x : th) x.join();
+			for (int t = 0; t < n_threads; ++t) {
+				for (int k = 0; k < 4; ++k) stats[k] += pst[(size_t)t][(size_t)k];
+				for (auto &x : part[(size_t)t]) corrected[x.first] = x.second;
+			}
+			for (auto &e : full) if (e.bc != 0) known[e.bc].n_reads += e.cnt;
+		}
+		fclose(f);
+	}
+	S.no_change = stats[NOCHANGE]; S.no_barcode = stats[NOBUCKET]; S.h1_corrected = stats[H1CHANGE]; S.h2_corrected = stats[H2CHANGE];
+	S.corrected_strings = (int64_t)corrected.size();
+	lap("barcode strings corrected");
+	// ---- 3. buckets (:359-395)
+	{
+		const int de = kind_of(output_dir);
+		if (de == 2) { g_err = std::string(output_dir) + " exists but is not a directory"; return EMA_EIO; }
+		if (de == 0 && mkdir(output_dir, S_IRWXU | S_IRWXG | S_IROTH | S_IXOTH) == -1) { g_err = std::string("Cannot create directory ") + output_dir; return EMA_EIO; }
+	}
+	std::vector<Out> files((size_t)n_buckets + 1);
+	auto close_all = [&] { for (auto &o : files) if (o.f) { fclose(o.f); o.f = nullptr; } };
+	for (int i = 0; i <= n_buckets; ++i) {
+		char name[32];
+		if (i == 0) snprintf(name, sizeof(name), "ema-nobc"); else snprintf(name, sizeof(name), "ema-bin-%03d", i - 1);
+		const std::string path = std::string(output_dir) + "/" + name;
+		files[(size_t)i].f = fopen(path.c_str(), "wb");
+		if (!files[(size_t)i].f) { close_all(); g_err = "Cannot open file " + path; return EMA_EIO; }
+	}
+	{
+		auto cmp = [&](int a, int b) { return std::tie(files[(size_t)a].size, a) > std::tie(files[(size_t)b].size, b); };      // the smallest file on top
+		std::priority_queue<int, std::vector<int>, decltype(cmp)> pq(cmp);
+		for (int i = 1; i <= n_buckets; ++i) pq.push(i);
+		for (auto &c : known) {
+			const int fidx = pq.top(); pq.pop();
+			files[(size_t)fidx].size += c.second.n_reads;
+			c.second.bucket = fidx;
+			pq.push(fidx);
+		}
+	}
+	lap("buckets dealt");
+	// ---- 4. the stream again (:419-617).  The reference handles a pair at a time; here the stream is taken in blocks that end on a
+	// pair boundary (pairs are eight lines: the boundaries come from counting line ends, nothing else in a FASTQ stream is safe),
+	// the pairs of a block are formatted by n_threads threads over contiguous ranges into per-thread, per-bucket text, and the
+	// text is written bucket by bucket in thread order: every file holds its pairs in input order, as in the reference.
+	struct LineRef { const char *p; size_t len; };
+	int rc = EMA_OK;
+	std::vector<char> blk((size_t)64 << 20);
+	size_t have = 0;
+	bool eof = false;
+	size_t prev_last_len = 0;      // the length of `s` when a name line is examined: the previous pair's last line (cpp/correct.cc:446)
+	std::vector<size_t> nl;
+	std::vector<std::vector<std::string>> tbuf((size_t)n_threads, std::vector<std::string>((size_t)n_buckets + 1));
+	std::vector<std::string> terr((size_t)n_threads);
+	std::vector<int64_t> t_written((size_t)n_threads), t_nobc((size_t)n_threads), t_skipped((size_t)n_threads);
+	while (!eof || have > 0) {
+		while (!eof && have < blk.size()) {
+			const ssize_t got = read(in_fd, blk.data() + have, blk.size() - have);
+			if (got < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+			if (got <= 0) { eof = true; break; }
+			have += (size_t)got;
+		}
+		nl.clear();
+		for (const char *q0 = blk.data(), *e = blk.data() + have; q0 < e;) {
+			const char *x = (const char *)memchr(q0, '\n', (size_t)(e - q0));
+			if (!x) break;
+			nl.push_back((size_t)(x - blk.data()));
+			q0 = x + 1;
+		}
+		size_t n_lines = nl.size();
+		const size_t tail_at = n_lines ? nl.back() + 1 : 0;
+		const bool open_tail = eof && tail_at < have;      // a last line without its line end: std::getline returns it all the same
+		if (open_tail) ++n_lines;
+		size_t n_rec = n_lines / 8;
+		if (eof && n_lines % 8) ++n_rec;      // the stream ends inside a pair: its missing lines read as empty, as failed getlines leave them
+		if (n_rec == 0) {
+			if (eof) break;
+			blk.resize(blk.size() * 2);      // a pair longer than the block
+			continue;
+		}
+		auto line = [&](size_t i) -> LineRef {
+			if (i >= n_lines) return LineRef{"", 0};
+			const size_t beg = i ? nl[i - 1] + 1 : 0;
+			const size_t end = i < nl.size() ? nl[i] : have;
+			return LineRef{blk.data() + beg, end - beg};
+		};
+		const size_t per = (n_rec + (size_t)n_threads - 1) / (size_t)n_threads;
+		auto work = [&](int t) {
+			const size_t lo = std::min(n_rec, (size_t)t * per), hi = std::min(n_rec, (size_t)(t + 1) * per);
+			std::vector<std::string> &bufs = tbuf[(size_t)t];
+			Key16 b; memset(b.b, '#', 16);
+			char bcd[kBcLen + 1]; bcd[kBcLen] = 0;
+			char hbc[12];
+			for (size_t rec = lo; rec < hi; ++rec) {
+				const LineRef n = line(8 * rec), r = line(8 * rec + 1), q = line(8 * rec + 3);
+				const LineRef m_name = line(8 * rec + 4), m_read = line(8 * rec + 5), m_qual = line(8 * rec + 7);
+				const size_t last_len = rec ? line(8 * rec - 1).len : prev_last_len;
+				bool process = r.len >= (size_t)kMinRead;
+				uint32_t barcode = 0;
+				bool bx = false;
+				if (is_haplotag) {
+					size_t sp = 0;
+					while (sp < n.len && n.p[sp] != ' ' && n.p[sp] != '\t') ++sp;
+					if (sp < n.len) {
+						size_t tag = std::string::npos;
+						for (size_t i = sp; i + 5 <= n.len; ++i) if (memcmp(n.p + i, "BX:Z:", 5) == 0) { tag = i; break; }
+						if (tag != std::string::npos && tag + 16 < last_len) {
+							for (int i = 0; i < 12; ++i) hbc[i] = tag + 5 + (size_t)i < n.len ? n.p[tag + 5 + (size_t)i] : '\0';      // (a tag cut short: the string's terminator)
+							auto two = [&](int i) { return 10 * (hbc[i] - '0') + (hbc[i + 1] - '0'); };
+							barcode = (uint32_t)two(1) << 24 | (uint32_t)two(4) << 16 | (uint32_t)two(7) << 8 | (uint32_t)two(10);
+							bx = true;
+						}
+					}
+				} else bx = true;
+				process = process && bx;
+				bool has_n = false;
+				if (process && !is_haplotag) for (int i = 0; i < kBcLen; ++i) {
+					int qc = (size_t)i < q.len ? (signed char)q.p[i] : 0;
+					if (qc < kQualOffset) { process = false; break; }
+					if (qc - kQualOffset >= kQualBase) qc = kQualOffset + kQualBase - 1;      // (capped in place in the reference; the first 23 characters are cut off below)
+					const unsigned char base = (unsigned char)r.p[i];
+					barcode = (barcode << 2) | (uint32_t)code2(base);
+					has_n |= base == 'N';
+					const int qv = qc - kQualOffset < kQualBase - 1 ? qc - kQualOffset : kQualBase - 1;
+					b.b[i] = (unsigned char)(code2n(base) * kQualBase + qv);
+				}
+				if (!process) { ++t_skipped[(size_t)t]; continue; }
+				if (r.len != q.len) { terr[(size_t)t] = "a quality line whose length differs from its read's (the reference's output is undefined there): " + std::string(n.p, n.len); return; }
+				if (!is_haplotag) {
+					auto cit = corrected.find(b);
+					if (cit != corrected.end()) { barcode = cit->second; has_n = false; }
+				}
+				int fidx = 0;
+				{
+					auto kit = has_n ? known.end() : known.find(barcode);
+					if (kit != known.end()) fidx = kit->second.bucket; else { barcode = 0; fidx = 0; }
+				}
+				std::string &o = bufs[(size_t)fidx];
+				auto print_bcd = [&] {
+					if (barcode == 0) return;
+					if (is_haplotag) o.append(hbc, 12);
+					else {
+						uint32_t bc = barcode;
+						for (int i = 0; i < kBcLen; ++i) { bcd[kBcLen - i - 1] = "ACGT"[bc & 3]; bc >>= 2; }
+						o.append(bcd, (size_t)kBcLen);
+					}
+				};
+				auto first_word = [&](const LineRef &x) { size_t k = 0; while (k < x.len && !isspace((unsigned char)x.p[k])) ++k; o.append(x.p, k); };
+				if (fidx && !do_bx_format) { print_bcd(); o.push_back(' '); }
+				first_word(n);
+				if (fidx) {
+					o.push_back(' ');
+					if (do_bx_format) { o.append("BX:Z:", 5); print_bcd(); if (is_haplotag) o.push_back('\n'); else o.append("-1\n", 3); }
+				} else o.push_back('\n');
+				const size_t cut = is_haplotag ? 0 : (size_t)(kBcLen + kTrim);
+				o.append(r.p + cut, r.len - cut);
+				if (fidx && !do_bx_format) o.push_back(' '); else o.append("\n+\n", 3);
+				o.append(q.p + cut, q.len - cut);
+				if (fidx && !do_bx_format) o.push_back(' '); else o.push_back('\n');
+				if (!fidx || do_bx_format) {
+					first_word(m_name);
+					if (do_bx_format) { o.append(" BX:Z:", 6); print_bcd(); if (!is_haplotag) o.append("-1", 2); }
+					o.push_back('\n');
+				}
+				o.append(m_read.p, m_read.len);
+				if (fidx && !do_bx_format) o.push_back(' '); else o.append("\n+\n", 3);
+				o.append(m_qual.p, m_qual.len);
+				o.push_back('\n');
+				if (fidx) ++t_written[(size_t)t]; else ++t_nobc[(size_t)t];
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+			work(0);
+			for (auto &x : th) x.join();
+		}
+		for (int t = 0; t < n_threads && rc == EMA_OK; ++t) if (!terr[(size_t)t].empty()) { rc = EMA_EFORMAT; g_err = terr[(size_t)t]; }
+		// (on an error the pairs of this block before the offending one are still written, as the reference would have written them)
+		for (size_t f = 0; f < files.size(); ++f) for (int t = 0; t < n_threads; ++t) {
+			std::string &o = tbuf[(size_t)t][f];
+			if (o.empty()) continue;
+			if (rc == EMA_OK && fwrite(o.data(), 1, o.size(), files[f].f) != o.size()) { rc = EMA_EIO; g_err = "fwrite failed"; }
+			o.clear();
+		}
+		for (int t = 0; t < n_threads; ++t) { S.pairs_written += t_written[(size_t)t]; S.pairs_nobc += t_nobc[(size_t)t]; S.pairs_skipped += t_skipped[(size_t)t]; t_written[(size_t)t] = t_nobc[(size_t)t] = t_skipped[(size_t)t] = 0; }
+		if (rc != EMA_OK) break;
+		prev_last_len = line(8 * n_rec - 1).len;
+		const size_t used = 8 * n_rec <= nl.size() ? nl[8 * n_rec - 1] + 1 : have;
+		memmove(blk.data(), blk.data() + used, have - used);
+		have -= used;
+	}
+	(void)buffer_size;      // (the text is written a block at a time; the reference's per-bucket buffer decides only its write sizes)
+	for (auto &f : files) {
+		if (rc == EMA_OK && !f.buf.empty() && fwrite(f.buf.data(), 1, f.buf.size(), f.f) != f.buf.size()) { rc = EMA_EIO; g_err = "fwrite failed"; }
+		if (f.f && fclose(f.f) != 0 && rc == EMA_OK) { rc = EMA_EIO; g_err = "cannot write a bucket file"; }
+		f.f = nullptr;
+	}
+	lap("stream bucketed and written");
+	if (st) *st = S;
+	return rc;
+}

@@ -85,11 +85,5 @@ def test_random_inputs_against_the_reference_binary(tmp_path, seed):
     assert got == want
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's count (oracle/_ref/ref_count) is built where /root/reference exists")
-def test_haplotag_against_the_reference_binary(tmp_path):
-    """All 96^4 barcodes are whitelisted in this mode (a 85 M-entry hash map in the reference and, for the same output order, here:
-    half a minute each)."""
-    fq = K.haplotag_fastq(31, 300)
-    got, st = product(tmp_path, "", fq, 1 << 30, 1)
-    want = reference(tmp_path, "", fq, 1 << 30, 1)
-    assert got == want and got["ema-fcnt"] is None and st["whitelist"] == 96 ** 4
+# (haplotag mode -- all 96^4 codes whitelisted, half a minute per run -- is compared in tests/test_preproc.py's haplotag test, which
+# runs both programs of both implementations anyway)

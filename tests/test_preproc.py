@@ -112,3 +112,35 @@ def test_haplotag_against_the_reference_binary(tmp_path):
     # `ema count` in this mode as well (tests/test_count.py leaves it to this test: the whitelist is built four times here already)
     assert open(tmp_path / "p" / "cnt.ema-ncnt", "rb").read() == open(tmp_path / "r" / "cnt.ema-ncnt", "rb").read()
     assert not os.path.exists(tmp_path / "p" / "cnt.ema-fcnt") and not os.path.exists(tmp_path / "r" / "cnt.ema-fcnt")
+
+
+def test_buckets_feed_the_bucket_reader(tmp_path):
+    """Raw interleaved FASTQ (mate 1 = 16 bp barcode + 7 bp + read) -> `ema count` -> `ema preproc` -> the bucket reader of
+    include/ema_ingest.h: every pair comes back, under its barcode, with mate 1 trimmed -- the two ends of the workflow fit."""
+    import numpy as np
+    from ema_amd import ingest, synth
+    ctg = synth.make_genome([150000], seed=3)
+    pairs = synth.make_pairs(ctg, 900, seed=8)
+    wl = sorted({pairs.barcodes[i].tobytes().decode() for i in range(pairs.n)})
+    lines = []
+    for i in range(pairs.n):
+        r1, r2 = pairs.read(2 * i).decode(), pairs.read(2 * i + 1).decode()
+        m1 = pairs.barcodes[i].tobytes().decode() + "ACGTACG" + r1
+        lines += [f"@s{i} 1:N:0", m1, "+", "F" * len(m1), f"@s{i} 2:N:0", r2, "+", "F" * len(r2)]
+    fq = tmp_path / "raw.fastq"; fq.write_text("\n".join(lines) + "\n")
+    wlp = tmp_path / "wl.txt"; wlp.write_text("\n".join(wl) + "\n")
+    ema_count.count_fastq(str(wlp), str(fq), str(tmp_path / "c"))
+    st = ema_preproc.preproc_fastq(str(wlp), [str(tmp_path / "c.ema-ncnt")], str(tmp_path / "b"), str(fq), n_threads=3, n_buckets=4)
+    assert st["pairs_written"] == pairs.n and st["pairs_nobc"] == 0 and st["no_change"] == pairs.n
+    seen = {}
+    for f in sorted(os.listdir(tmp_path / "b")):
+        if f == "ema-nobc":
+            assert os.path.getsize(tmp_path / "b" / f) == 0
+            continue
+        bk = ingest.read_bucket(str(tmp_path / "b" / f))
+        for p in range(bk.n_pairs):
+            seen[bk.ident(p).decode()] = (ingest.decode_barcode(int(bk.bc[p])), bk.read(2 * p), bk.read(2 * p + 1))
+    assert len(seen) == pairs.n
+    for i in range(pairs.n):
+        bc, r1, r2 = seen[f"@s{i}"]
+        assert bc == pairs.barcodes[i].tobytes() and r1 == pairs.read(2 * i) and r2 == pairs.read(2 * i + 1)

@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include <unistd.h>
@@ -75,16 +77,42 @@ struct Key16 {
 	bool operator==(const Key16 &o) const { return a == o.a && b == o.b; }
 	bool operator<(const Key16 &o) const { return a != o.a ? a < o.a : b < o.b; }
 };
-struct Key16Hash {
-	size_t operator()(const Key16 &k) const { uint64_t h = k.a * 0x9E3779B97F4A7C15ULL ^ (k.b + 0x7F4A7C15ULL) * 0xD6E8FEB86659FD93ULL; return (size_t)(h ^ h >> 29); }
+// the 16-byte keys with their counts: open addressing, linear probing, doubled at half full (a count of 0 = an empty slot).
+// Its layout is free: a block is sorted when it is written.
+struct FullMap {
+	std::vector<Key16> keys;
+	std::vector<int64_t> cnt;
+	size_t n = 0, mask = 0;
+	FullMap() { resize_to((size_t)1 << 16); }
+	static size_t hash(const Key16 &k) { uint64_t h = k.a * 0x9E3779B97F4A7C15ULL ^ (k.b + 0x7F4A7C15ULL) * 0xD6E8FEB86659FD93ULL; return (size_t)(h ^ h >> 29); }
+	void resize_to(size_t cap)
+	{
+		std::vector<Key16> ok; std::vector<int64_t> oc;
+		ok.swap(keys); oc.swap(cnt);
+		keys.assign(cap, Key16{0, 0}); cnt.assign(cap, 0); mask = cap - 1;
+		for (size_t i = 0; i < oc.size(); ++i) if (oc[i]) { size_t at = hash(ok[i]) & mask; while (cnt[at]) at = (at + 1) & mask; keys[at] = ok[i]; cnt[at] = oc[i]; }
+	}
+	size_t size() const { return n; }
+	int64_t bump(const Key16 &k)      // the count before the increment (0: a new key)
+	{
+		size_t at = hash(k) & mask;
+		while (cnt[at] && !(keys[at] == k)) at = (at + 1) & mask;
+		const int64_t before = cnt[at];
+		if (!before) { keys[at] = k; ++n; }
+		++cnt[at];
+		if (!before && 2 * n > mask) resize_to(2 * (mask + 1));
+		return before;
+	}
+	void clear() { std::fill(cnt.begin(), cnt.end(), 0); n = 0; }
 };
-typedef std::unordered_map<Key16, int64_t, Key16Hash> FullMap;
 
 bool dump_block(FullMap &full, FILE *fo)      // dump_map, cpp/count.cc:18-34: the block sorted by key
 {
 	const int64_t n = (int64_t)full.size();
 	if (!write_all(fo, &n, 8)) return false;
-	std::vector<std::pair<Key16, int64_t>> v(full.begin(), full.end());
+	std::vector<std::pair<Key16, int64_t>> v;
+	v.reserve(full.size());
+	for (size_t i = 0; i < full.cnt.size(); ++i) if (full.cnt[i]) v.emplace_back(full.keys[i], full.cnt[i]);
 	std::sort(v.begin(), v.end(), [](const std::pair<Key16, int64_t> &x, const std::pair<Key16, int64_t> &y) { return x.first < y.first; });
 	std::vector<unsigned char> out((size_t)n * 24);
 	for (size_t i = 0; i < v.size(); ++i) {
@@ -138,66 +166,119 @@ extern "C" int ema_count_fastq(const char *known_barcodes_path, int in_fd, const
 	if (!f_nice) { if (f_full) fclose(f_full); g_err = "Cannot open file " + p_nice; return EMA_EIO; }
 	auto fail = [&](const char *what) { if (f_full) fclose(f_full); fclose(f_nice); g_err = what; return EMA_EIO; };
 
-	Lines in(in_fd);
-	std::string b((size_t)kBcLen, '#');
-	const char *name; size_t name_len;
-	while (in.next(name, name_len)) {
-		s.bytes += (int64_t)name_len + 1;
-		bool bx = false;
-		uint32_t barcode = 0;
-		if (is_haplotag) {      // cpp/count.cc:91-103
-			size_t at = 0;
-			while (at < name_len && name[at] != ' ' && name[at] != '\t') ++at;
-			if (at < name_len) {
-				size_t tag = std::string::npos;
-				for (size_t i = at; i + 5 <= name_len; ++i) if (memcmp(name + i, "BX:Z:", 5) == 0) { tag = i; break; }
-				if (tag != std::string::npos && tag + 16 < name_len) {
-					// substr(tag + 5, 12) of a string with at least tag + 17 characters: all twelve are there
-					const char *h = name + tag + 5;
-					auto two = [&](int i) { return 10 * (h[i] - '0') + (h[i + 1] - '0'); };      // TwoCharToInt
-					barcode = (uint32_t)two(1) << 24 | (uint32_t)two(4) << 16 | (uint32_t)two(7) << 8 | (uint32_t)two(10);
-					bx = true;
-				}
-			}
-		} else bx = true;
-		// the name's bytes die with the next refill: everything taken from it is taken by now
-		const char *seq; size_t seq_len; const char *q; size_t q_len;
-		std::string seq_copy;
-		in.next(seq, seq_len); s.bytes += (int64_t)seq_len + 1;
-		seq_copy.assign(seq ? seq : "", seq ? std::min<size_t>(seq_len, (size_t)kBcLen) : 0);      // (the barcode bases: a refill may move the buffer)
-		in.next(q, q_len); s.bytes += (int64_t)q_len + 1;
-		in.next(q, q_len); s.bytes += (int64_t)q_len + 1;
-		bool process = bx && seq_len >= (size_t)kMinRead;
-		bool has_n = false;
-		if (!is_haplotag) {
-			barcode = 0;
-			if (process) for (int i = 0; i < kBcLen; ++i) {
-				int qc = (size_t)i < q_len ? (signed char)q[i] : 0;      // (std::string's terminator; further out the reference reads beyond its string)
-				if (qc < kQualOffset) { process = false; break; }      // "Ignoring long read--- quality score ... less than 33"
-				if (qc - kQualOffset >= kQualBase) qc = kQualOffset + kQualBase - 1;
-				const unsigned char base = (unsigned char)seq_copy[(size_t)i];
-				const int qv = qc - kQualOffset < kQualBase - 1 ? qc - kQualOffset : kQualBase - 1;
-				b[(size_t)i] = (char)(code2n(base) * kQualBase + qv);
-				barcode = (barcode << 2) | (uint32_t)code2(base);
-				has_n |= base == 'N';
-			}
+	// The stream is taken in blocks that end on a pair boundary (pairs are eight lines: the boundaries come from counting line
+	// ends); the pairs of a block are parsed on the host's threads into {counted?, 2-bit code, N?, the 16-byte key}, and one thread
+	// then makes the two table updates per pair in input order -- the order that defines the blocks of .ema-fcnt.
+	int n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	if (const char *v = getenv("EMA_HOST_THREADS")) n_threads = std::max(1, std::min(64, atoi(v)));
+	struct LineRef { const char *p; size_t len; };
+	struct Parsed { Key16 key; uint32_t code; uint8_t process, has_n; };
+	std::vector<char> blk((size_t)64 << 20);
+	std::vector<size_t> nl;
+	std::vector<Parsed> parsed;
+	size_t have = 0;
+	bool eof = false;
+	while (!eof || have > 0) {
+		while (!eof && have < blk.size()) {
+			const ssize_t got = read(in_fd, blk.data() + have, blk.size() - have);
+			if (got < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+			if (got <= 0) { eof = true; break; }
+			have += (size_t)got;
 		}
-		if (process) {
-			if (!has_n) {
-				auto it = counts.find(barcode);
+		nl.clear();
+		for (const char *q0 = blk.data(), *e = blk.data() + have; q0 < e;) {
+			const char *x = (const char *)memchr(q0, '\n', (size_t)(e - q0));
+			if (!x) break;
+			nl.push_back((size_t)(x - blk.data()));
+			q0 = x + 1;
+		}
+		size_t n_lines = nl.size();
+		const size_t tail_at = n_lines ? nl.back() + 1 : 0;
+		if (eof && tail_at < have) ++n_lines;      // a last line without its line end: std::getline returns it all the same
+		size_t n_rec = n_lines / 8;
+		const size_t missing = (eof && n_lines % 8) ? 8 - n_lines % 8 : 0;      // the stream ends inside a pair: its missing lines read as empty
+		if (missing) ++n_rec;
+		if (n_rec == 0) {
+			if (eof) break;
+			blk.resize(blk.size() * 2);
+			continue;
+		}
+		auto line = [&](size_t i) -> LineRef {
+			if (i >= n_lines) return LineRef{"", 0};
+			const size_t beg = i ? nl[i - 1] + 1 : 0;
+			const size_t end = i < nl.size() ? nl[i] : have;
+			return LineRef{blk.data() + beg, end - beg};
+		};
+		parsed.resize(n_rec);
+		const size_t per = (n_rec + (size_t)n_threads - 1) / (size_t)n_threads;
+		auto work = [&](int t) {
+			const size_t lo = std::min(n_rec, (size_t)t * per), hi = std::min(n_rec, (size_t)(t + 1) * per);
+			for (size_t rec = lo; rec < hi; ++rec) {
+				const LineRef name = line(8 * rec), seq = line(8 * rec + 1), q = line(8 * rec + 3);
+				Parsed &o = parsed[rec];
+				bool bx = false;
+				uint32_t barcode = 0;
+				if (is_haplotag) {      // cpp/count.cc:91-103
+					size_t at = 0;
+					while (at < name.len && name.p[at] != ' ' && name.p[at] != '\t') ++at;
+					if (at < name.len) {
+						size_t tag = std::string::npos;
+						for (size_t i = at; i + 5 <= name.len; ++i) if (memcmp(name.p + i, "BX:Z:", 5) == 0) { tag = i; break; }
+						if (tag != std::string::npos && tag + 16 < name.len) {
+							const char *h = name.p + tag + 5;      // substr(tag + 5, 12) of a string with at least tag + 17 characters: all twelve are there
+							auto two = [&](int i) { return 10 * (h[i] - '0') + (h[i + 1] - '0'); };      // TwoCharToInt
+							barcode = (uint32_t)two(1) << 24 | (uint32_t)two(4) << 16 | (uint32_t)two(7) << 8 | (uint32_t)two(10);
+							bx = true;
+						}
+					}
+				} else bx = true;
+				bool process = bx && seq.len >= (size_t)kMinRead;
+				bool has_n = false;
+				unsigned char b[16];
+				memset(b, '#', 16);      // (haplotag: the reference's key string is never written)
+				if (!is_haplotag) {
+					barcode = 0;
+					if (process) for (int i = 0; i < kBcLen; ++i) {
+						int qc = (size_t)i < q.len ? (signed char)q.p[i] : 0;      // (std::string's terminator; further out the reference reads beyond its string)
+						if (qc < kQualOffset) { process = false; break; }      // "Ignoring long read--- quality score ... less than 33"
+						if (qc - kQualOffset >= kQualBase) qc = kQualOffset + kQualBase - 1;
+						const unsigned char base = (unsigned char)seq.p[i];
+						const int qv = qc - kQualOffset < kQualBase - 1 ? qc - kQualOffset : kQualBase - 1;
+						b[i] = (unsigned char)(code2n(base) * kQualBase + qv);
+						barcode = (barcode << 2) | (uint32_t)code2(base);
+						has_n |= base == 'N';
+					}
+				}
+				o.process = process; o.has_n = has_n; o.code = barcode;
+				o.key.a = o.key.b = 0;
+				for (int i = 0; i < 8; ++i) { o.key.a = o.key.a << 8 | b[i]; o.key.b = o.key.b << 8 | b[8 + i]; }
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+			work(0);
+			for (auto &x : th) x.join();
+		}
+		for (size_t rec = 0; rec < n_rec; ++rec) {
+			const Parsed &o = parsed[rec];
+			if (!o.process) { ++s.ignored_reads; continue; }
+			if (!o.has_n) {
+				auto it = counts.find(o.code);
 				if (it != counts.end()) { ++it->second; ++s.nice_reads; }
 			}
-			Key16 key; key.a = key.b = 0;
-			for (int i = 0; i < 8; ++i) { key.a = key.a << 8 | (unsigned char)b[(size_t)i]; key.b = key.b << 8 | (unsigned char)b[(size_t)(8 + i)]; }
-			const int64_t cnt = full[key]++;
+			const int64_t cnt = full.bump(o.key);
 			if (!cnt && (sizeof(std::string) + sizeof(int64_t) + 32) * full.size() >= max_map_size) {      // a new element: estimate_size of the reference's std::map<std::string, int64_t>, cpp/common.h:110-115
 				if (!f_full) return fail("the barcode map outgrew max_map_size in haplotag mode (the reference writes through an unopened file there)");
 				if (!dump_block(full, f_full)) return fail("fwrite failed");
 				++s.full_blocks;
 			}
 			++s.total_reads;
-		} else ++s.ignored_reads;
-		for (int i = 0; i < 4; ++i) { const char *m; size_t m_len; in.next(m, m_len); s.bytes += (int64_t)m_len + 1; }
+		}
+		const size_t used = 8 * n_rec <= nl.size() ? nl[8 * n_rec - 1] + 1 : have;
+		s.bytes += (int64_t)used + (int64_t)missing + ((eof && tail_at < have) ? 1 : 0);      // the reference's `sz`: every line's length + 1, failed getlines included
+		memmove(blk.data(), blk.data() + used, have - used);
+		have -= used;
 	}
 	int64_t nice = 0;
 	for (auto &kv : counts) if (kv.second) ++nice;

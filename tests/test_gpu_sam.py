@@ -60,6 +60,10 @@ def _run(tmp_path, kind, sizes, haplotag, continue_ids):
         d.mkdir()
         _p, _c, _bucket = make_bucket(d, kind, n, 900 + k, 40, haplotag, sub_rate=0.015, chimeric=0.04)
         paths.append(str(d / "bucket"))
+    _check(tmp_path, prefix, ctg, paths, sum(sizes), haplotag, continue_ids)
+
+
+def _check(tmp_path, prefix, ctg, paths, n_pairs, haplotag, continue_ids):
     names = [f"chr{i + 1}".encode() for i in range(len(ctg))]
     eng = E.Engine(prefix)
     assert [c[0].encode() for c in eng.contigs()] == names
@@ -89,7 +93,7 @@ def _run(tmp_path, kind, sizes, haplotag, continue_ids):
         assert sst[k]["lines"] == text.count(b"\n") and sst[k]["clouds"] == n_clouds
         if continue_ids:
             shift += n_clouds
-    assert got == want and got.count(b"\n") > 1.6 * sum(sizes)
+    assert got == want and got.count(b"\n") > 1.6 * n_pairs
     assert all(s["rc"] == 0 and s["capacity_flags"] == 0 for s in bst)
 
 
@@ -103,3 +107,29 @@ def test_x_mode_cloud_numbers_run_on(tmp_path):
 
 def test_haplotag_bucket_to_sam(tmp_path):
     _run(tmp_path, "two_contigs", [320], True, False)
+
+
+def test_raw_fastq_through_count_and_preproc_to_sam(tmp_path):
+    """The whole workflow through C-ABI calls only: raw interleaved FASTQ (mate 1 = barcode + 7 bases + read; one barcode in twelve
+    with a wrong base) -> ema_count_fastq -> ema_preproc_fastq (three buckets) -> ema_stream_sam, against the oracle chain on the
+    bucket files preproc wrote (preproc and count themselves are pinned to the reference's own code in tests/test_preproc.py)."""
+    from ema_amd import count as ema_count, preproc as ema_preproc
+    prefix, ctg = small_ref("two_contigs")
+    pairs = synth.make_pairs(ctg, 700, seed=321, pairs_per_barcode=40, sub_rate=0.012, chimeric=0.03)
+    rng = np.random.default_rng(4)
+    wl = sorted({pairs.barcodes[i].tobytes().decode() for i in range(pairs.n)})
+    lines = []
+    for i in range(pairs.n):
+        bc = pairs.barcodes[i].tobytes().decode()
+        if i % 12 == 5:
+            p = int(rng.integers(0, 16)); bc = bc[:p] + "ACGT"[("ACGT".index(bc[p]) + 1) % 4] + bc[p + 1:]
+        m1 = bc + "ACGTACG" + pairs.read(2 * i).decode()
+        r2 = pairs.read(2 * i + 1).decode()
+        lines += [f"@s{i} 1:N:0", m1, "+", "F" * len(m1), f"@s{i} 2:N:0", r2, "+", "F" * len(r2)]
+    fq = tmp_path / "raw.fastq"; fq.write_text("\n".join(lines) + "\n")
+    wlp = tmp_path / "wl.txt"; wlp.write_text("\n".join(wl) + "\n")
+    ema_count.count_fastq(str(wlp), str(fq), str(tmp_path / "c"))
+    st = ema_preproc.preproc_fastq(str(wlp), [str(tmp_path / "c.ema-ncnt")], str(tmp_path / "b"), str(fq), n_threads=2, n_buckets=3)
+    assert st["h1_corrected"] > 20 and st["pairs_written"] + st["pairs_nobc"] == pairs.n
+    paths = [str(tmp_path / "b" / f"ema-bin-{k:03d}") for k in range(3)]
+    _check(tmp_path, prefix, ctg, paths, st["pairs_written"], False, True)

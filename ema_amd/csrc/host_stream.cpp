@@ -603,6 +603,24 @@ void ema_sam_run_opts_default(ema_sam_run_opts *o)
 	o->continue_cloud_ids = 0;
 }
 
+int ema_sam_run_opts_platform(const char *name, ema_sam_run_opts *o)
+{
+	if (!name || !o) return EMA_EARG;
+	// reference src/techs.c:74-135: {name, bc_len, many_clouds, dist_thresh, error_rate}
+	static const struct { const char *name; int bc_len, haplotag, many_clouds; uint32_t dist_thresh; double error_rate; } tab[] = {
+		{"haplotag", 12, 1, 0, 50000, 0.001}, {"10x", 16, 0, 0, 50000, 0.001}, {"tru", 0, 0, 1, 15000, 0.001},
+		{"cpt", 0, 0, 1, 3500, 0.01}, {"dbs", 20, 0, 0, 50000, 0.001}, {"tellseq", 18, 0, 0, 50000, 0.001}};
+	for (const auto &t : tab) if (strcmp(name, t.name) == 0) {
+		ema_sam_run_opts_default(o);
+		o->stream.bc_len = t.bc_len; o->stream.is_haplotag = t.haplotag; o->stream.error_rate = t.error_rate;
+		o->clouds.dist_thresh = t.dist_thresh; o->clouds.many_clouds = t.many_clouds;
+		o->sam.bc_len = t.bc_len; o->sam.is_haplotag = t.haplotag;
+		return EMA_OK;
+	}
+	g_err = std::string("unknown platform ") + name;
+	return EMA_EARG;
+}
+
 int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const ema_sam_run_opts *o, int fd, ema_bucket_stats *bstats,
                    ema_sam_stats *sstats)
 {

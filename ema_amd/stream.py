@@ -155,6 +155,23 @@ class SamRunOpts(C.Structure):
     pass
 
 
+def platform_opts(name: str) -> dict:
+    """ema_sam_run_opts_platform: what `ema align -p <name>` takes from the reference's platform table (src/techs.c:74-135)."""
+    from . import clouds as _clouds
+    from . import sam as _sam
+    if not SamRunOpts.__dict__.get("_fields_"):
+        SamRunOpts._fields_ = [("stream", StreamOpts), ("clouds", _clouds.CloudOpts), ("sam", _sam.SamOpts), ("continue_cloud_ids", C.c_int32)]
+    L = _lib()
+    L.ema_sam_run_opts_platform.argtypes = [C.c_char_p, C.POINTER(SamRunOpts)]
+    L.ema_sam_run_opts_platform.restype = C.c_int
+    o = SamRunOpts()
+    rc = L.ema_sam_run_opts_platform(name.encode(), C.byref(o))
+    if rc != 0:
+        raise ValueError(f"unknown platform {name!r}")
+    return {"bc_len": o.stream.bc_len, "is_haplotag": bool(o.stream.is_haplotag), "error_rate": o.stream.error_rate,
+            "dist_thresh": o.clouds.dist_thresh, "many_clouds": bool(o.clouds.many_clouds), "sam_bc_len": o.sam.bc_len, "sam_is_haplotag": bool(o.sam.is_haplotag)}
+
+
 def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None, is_haplotag: bool = False, bc_len: int = 16,
                continue_cloud_ids: bool = False, n_engines: int = 0):
     """ema_stream_sam: bucket files -> SAM text on fd.  Returns (per-bucket stream stats, per-bucket SAM stats)."""

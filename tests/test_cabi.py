@@ -76,3 +76,17 @@ def test_open_without_gpu_fails_loudly():
 def test_index_builder_exports():
     L = C.CDLL(os.path.join(ROOT, "ema_amd", "libema_index.so"))
     assert hasattr(L, "ema_index_build")
+
+
+def test_platform_table():
+    """ema_sam_run_opts_platform against the reference's table (src/techs.c:74-135: name, bc_len, many_clouds, dist_thresh, error_rate)."""
+    from ema_amd import stream
+    want = {"haplotag": (12, True, False, 50000, 0.001), "10x": (16, False, False, 50000, 0.001), "tru": (0, False, True, 15000, 0.001),
+            "cpt": (0, False, True, 3500, 0.01), "dbs": (20, False, False, 50000, 0.001), "tellseq": (18, False, False, 50000, 0.001)}
+    for name, (bc_len, hap, many, dist, err) in want.items():
+        o = stream.platform_opts(name)
+        assert (o["bc_len"], o["is_haplotag"], o["many_clouds"], o["dist_thresh"], o["error_rate"]) == (bc_len, hap, many, dist, err)
+        assert o["sam_bc_len"] == bc_len and o["sam_is_haplotag"] == hap
+    import pytest
+    with pytest.raises(ValueError):
+        stream.platform_opts("pacbio")

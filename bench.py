@@ -494,6 +494,15 @@ def main(argv=None):
         el_r = agree(time.perf_counter() - t2, "max") if world > 1 else time.perf_counter() - t2
         resident = {"value": round(args.pairs * args.steps * world / el_r, 1), "unit": "pairs/s", "ms_per_step": round(el_r / args.steps * 1e3, 3),
                     "what": "K1-K4 only, steps queued back to back on one set of batch buffers, inputs resident, nothing fetched"}
+        # ---- one pass on its own, from queueing to records on the host (what --sync-each-step used to show: nothing overlaps)
+        sync_all()
+        t3 = time.perf_counter()
+        stream.stream_resident(eng, offs[:1], slots, opts=so, raw_sink=make_sink(False))
+        sync_all()
+        el_1 = agree(time.perf_counter() - t3, "max") if world > 1 else time.perf_counter() - t3
+        resident["single_pass"] = {"value": round(args.pairs * world / el_1, 1), "unit": "pairs/s", "ms": round(el_1 * 1e3, 3),
+                                   "what": "one batch alone through the timed region's path: three lean slices, the full-capacity tier, pack, D2H, assembly, "
+                                           "append stage with nothing to overlap; the timed region's per-step time approaches engine_resident's as steps grow"}
         eng.run(serial=True)      # one extra untimed pass with the slices one after another: launches in isolation
         eng.sync()
         tm = eng.timing()

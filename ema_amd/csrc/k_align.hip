@@ -372,11 +372,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	__shared__ __attribute__((aligned(16))) uint8_t lds_small[4][EMA_SMALL_BYTES(SMALL)];
 	__shared__ __attribute__((aligned(16))) uint8_t lds_av[4][EMA_AVL_BYTES(AVL)];      // regions of the read while there are few
 	// the medium layout needs 4 KB of small-table area, the 2 KB window buffer and 1 KB of region-list area
-#ifdef EMA_NO_MED      // (bisecting aid)
-	constexpr bool MED = false && EMA_SMALL_BYTES(SMALL) >= 4096 && EMA_RSEQ_CAP >= EMA_MED_CHAINS * 8 && (AVL > 0 && EMA_AVL_BYTES(AVL) >= EMA_MED_CHAINS * 4);
-#else
 	constexpr bool MED = EMA_SMALL_BYTES(SMALL) >= 4096 && EMA_RSEQ_CAP >= EMA_MED_CHAINS * 8 && (AVL > 0 && EMA_AVL_BYTES(AVL) >= EMA_MED_CHAINS * 4);
-#endif
 	const int lane = (int)ema_lane();
 	const int wib = (int)(threadIdx.x >> 6);
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
@@ -728,11 +724,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		}
 
 		// ---------------- a chain-rich read is set aside for K2c / K2d (dev_types.h, HeavyCtl) ----------------
-#ifdef EMA_NO_DEFER
-		if (false) {
-#else
 		if (MODE == 0 && hv.arena && !handed && n_keep >= hv.min_chains) {
-#endif
 			int n_ext = 0, tot = 0;      // chains to extend, their seeds
 			for (int base = 0; base < n_keep; base += EMA_WAVE) {
 				const int i = base + lane;

@@ -292,6 +292,14 @@ def main(argv=None):
     if world != max(1, args.gpus):
         log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
         raise SystemExit(2)
+    if world > 1 and "EMA_HOST_THREADS" not in os.environ:
+        # every rank stages, fetches and runs its append stage on host threads (default: up to 32 per rank): N ranks share the
+        # node's CPUs, so each takes its share -- 8 x 32 threads on a socket that grants a job 16-64 CPUs only thrash
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cpus = os.cpu_count() or 8
+        os.environ["EMA_HOST_THREADS"] = str(max(4, min(32, cpus // world)))
     dist = None
     # RCCL ("nccl") on the GPU box; EMA_BENCH_BACKEND=gloo runs the same control flow on CPU tensors (the world-size-2 test)
     backend = os.environ.get("EMA_BENCH_BACKEND", "nccl")

@@ -9,7 +9,8 @@ HIPFLAGS = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclud
 HOSTCLANG = -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -pthread
 
 BWAABI = $(if $(wildcard $(CSRC)/bwaabi.cpp),ema_amd/libema_bwaabi.so)
-all: ema_amd/libema_index.so ema_amd/libema_engine.so ema_amd/libema_engine_ss16.so $(BWAABI) oracle
+all: ema_amd/libema_index.so ema_amd/libema_engine.so $(BWAABI) oracle
+test-libs: all ema_amd/libema_engine_ss16.so
 
 ema_amd/libema_index.so: $(CSRC)/index_build.cpp
 	$(CXX) $(HOSTFLAGS) -fopenmp -shared -o $@ $<
@@ -44,11 +45,14 @@ ema_amd/libema_engine_ss16.so: $(SS16_OBJS)
 ema_amd/libema_bwaabi.so: $(CSRC)/bwaabi.cpp include/ema_bwaabi.h include/ema_engine.h ema_amd/libema_engine.so
 	$(CXX) $(HOSTFLAGS) -Iinclude -shared -o $@ $(CSRC)/bwaabi.cpp -Lema_amd -lema_engine -Wl,-rpath,'$$ORIGIN'
 
-oracle:
+# oracle: the CPU checker; `ref` (only where /root/reference exists): the reference's own sources compiled where they lie into
+# oracle/_ref/ -- util.c, count, preproc, the host half over the oracle's nine-symbol face (ema_refhost), and the same objects
+# over the product's face (ema_ref_gpu, needs libema_bwaabi.so)
+oracle: $(BWAABI)
 	$(MAKE) -C oracle
 	$(MAKE) -C oracle ref
 
 clean:
 	rm -rf build; rm -f ema_amd/*.so; $(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all test-libs oracle clean

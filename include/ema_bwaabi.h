@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <assert.h>      /* bwa's bntseq.h brings it in, and reference src/techs.c:8,21,41 relies on that */
 
 #ifdef __cplusplus
 extern "C" {
@@ -168,6 +169,11 @@ typedef struct {
 	int score, sub, alt_sc;
 } mem_aln_t;
 
+/* The chain types are private to bwa's bwamem.c; the reference restates them itself (include/bwabridge.h:25-41, after it has
+ * included the four bwa headers).  The shims under include/bwa_compat/ therefore define EMA_BWAABI_REFERENCE_BUILD, which
+ * leaves them -- and the prototype of mem_chain, which the reference declares at src/bwabridge.c:14 -- to the includer:
+ * tests/test_refhost_build.py compiles every unmodified reference source this way. */
+#ifndef EMA_BWAABI_REFERENCE_BUILD
 typedef struct {
 	int64_t rbeg;
 	int32_t qbeg, len;
@@ -183,6 +189,7 @@ typedef struct {
 } mem_chain_t;
 
 typedef struct { size_t n, m; mem_chain_t *a; } mem_chain_v;
+#endif
 
 /* --- the nine link symbols (nst_nt4_table above) --- */
 
@@ -200,7 +207,9 @@ mem_alnreg_v mem_align1_core(const mem_opt_t *opt, const bwt_t *bwt, const bntse
 
 /* Referenced by the reference's dead bridge entry points only (src/bwabridge.c:122,192; no caller in src/): exported so
  * that the link succeeds; returns an empty vector. */
+#ifndef EMA_BWAABI_REFERENCE_BUILD
 mem_chain_v mem_chain(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, int len, const uint8_t *seq, void *buf);
+#endif
 
 /* One rescue attempt of the mate ms (nt4) around region a; ma is updated in place (realloc).  Supports the insert model the
  * reference passes (src/bwabridge.c:216-227): only pes[1] (FR) not failed; any other returns 0 without aligning.

@@ -64,7 +64,8 @@ typedef struct ema_sam_rec {      /* what print_sam_record reads of one SAMRecor
 typedef struct ema_sam_line { const ema_sam_rec *rec, *mate; } ema_sam_line;      /* print_sam_record(rec, mate, ...): one may be NULL */
 
 typedef struct ema_sam_opts {
-	const char *rg_id;            /* NULL: no RG tag */
+	const char *rg_id;            /* NULL: no RG tag.  `ema align` without -R uses "@RG\tID:rg1\tSM:sample1" (reference src/main.c:25),
+	                               * i.e. rg_id "rg1\tSM:sample1": the tag stops at the first whitespace */
 	const char *bx_index;         /* the reference's global, "1" by default (src/main.c:26) */
 	int32_t bc_len, is_haplotag;  /* BC_LEN; -p haplotag */
 	int32_t insert_min, insert_max;      /* INSERT_MIN / INSERT_MAX of is_pair(), -35 / 750 (include/align.h:66-67) */

@@ -330,3 +330,20 @@ def clouds_group(records, n_pairs, cloud_id, dist_thresh=50000, many_clouds=Fals
     out = [(order[2 * i], order[2 * i + 1]) for i in range(k)]
     res = [(arr[i].gamma, arr[i].cloud_id, arr[i].cloud_bad, arr[i].duplicate, arr[i].alt) for i in range(n)]
     return out, res, cid.value
+
+
+def sam_header(contigs, rg_line, version: bytes, argv) -> bytes:
+    """oracle/sam.c's write_sam_header (reference src/align.c:193-212): contigs = [(name, length)]."""
+    L = lib()
+    L.orc_sam_header.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_char_p, C.c_int,
+                                 C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    names = (C.c_char_p * max(1, len(contigs)))(*[n for n, _ in contigs])
+    lens = (C.c_int32 * max(1, len(contigs)))(*[l for _, l in contigs])
+    av = (C.c_char_p * len(argv))(*argv)
+    text, size = C.c_void_p(), C.c_size_t()
+    assert L.orc_sam_header(names, lens, len(contigs), rg_line, version, len(argv), av, C.byref(text), C.byref(size)) == 0
+    out = C.string_at(text, size.value)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(text)
+    return out

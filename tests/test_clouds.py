@@ -48,10 +48,10 @@ def make_bucket(tmp_path, kind, n_pairs, seed, per_bc, haplotag=False, dup_frac=
     return prefix, ctg, bucket
 
 
-def oracle_selection(bucket, batch, rec, pair_off, names, dist_thresh=50000, many_clouds=False):
+def oracle_selection(bucket, batch, rec, pair_off, names, dist_thresh=50000, many_clouds=False, first_cloud_id=0):
     """oracle/clouds.c group by group -> (SamLine array for the oracle's formatter, keep-alive list, summary rows)."""
     keep, rows, lines = [], [], []
-    cloud_id = 0
+    cloud_id = first_cloud_id
     for g in range(len(bucket.group_off) - 1):
         p0, p1 = int(bucket.group_off[g]), int(bucket.group_off[g + 1])
         r0, r1 = int(pair_off[p0]), int(pair_off[p1])

@@ -1,0 +1,59 @@
+"""The GPU path against SAM text written by the REFERENCE'S OWN host code (tests/golden/sam/, make_sam_vectors.py there).
+
+1. ema_sam_header + ema_stream_sam (bucket files -> SAM text through C-ABI calls only: reader, engine on the GPU, append stage,
+   clouds / EM / duplicates, formatter) == expected.sam, header included, byte for byte, for every committed case
+   (`ema align -s`, `-x`, `-p haplotag`, `-R`, `-i`).
+2. Where oracle/_ref/ema_ref_gpu travelled with the snapshot (the reference's unmodified objects -- its own bwabridge.c, align.c,
+   samdict.c, samrecord.c -- linked against libema_bwaabi.so, the nine-symbol face on this engine, instead of -lbwa): the
+   reference binary itself, running on the GPU one call at a time, writes the same file.  That is rows B1 / B2 of SURVEY 8b as
+   the reference's maintainers would use them."""
+import os
+import subprocess
+
+import pytest
+
+from golden_sam_lib import Run, cases, reference
+from ema_amd import engine as E
+from ema_amd import stream
+
+pytestmark = pytest.mark.gpu
+CASES = cases()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_GPU = os.path.join(ROOT, "oracle", "_ref", "ema_ref_gpu")
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_stream_sam_equals_the_reference_host_code(case, tmp_path):
+    run = Run(case)
+    prefix, contigs = reference(case["ref"])
+    eng = E.Engine(prefix)
+    assert [(c[0].encode(), c[1]) for c in eng.contigs()] == contigs
+    out = str(tmp_path / "out.sam")
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    head = run.header(contigs)
+    assert os.write(fd, head) == len(head)
+    bst, sst = stream.stream_sam(eng, run.paths, fd, rg_id=run.rg_id, is_haplotag=run.haplotag, bc_len=run.bc_len,
+                                 continue_cloud_ids=run.x_mode, bx_index=run.bx_index)
+    os.close(fd)
+    eng.close()
+    got = open(out, "rb").read()
+    assert got == run.expected
+    assert sum(s["lines"] for s in sst) == case["lines"] and sum(s["with_xa"] for s in sst) == case["with_xa"]
+    assert sum(s["duplicates"] for s in sst) == case["duplicates"] and sum(s["unmapped_mates"] for s in sst) == case["unmapped"]
+    assert all(s["rc"] == 0 and s["capacity_flags"] == 0 for s in bst)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_GPU), reason="oracle/_ref/ema_ref_gpu (reference objects + libema_bwaabi.so) did not travel")
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("10x_small_barcodes_rg", "x_two_buckets", "haplotag")],
+                         ids=lambda c: c["name"])
+def test_the_reference_binary_on_the_gpu_face_writes_the_same_sam(case, tmp_path):
+    run = Run(case)
+    prefix, _contigs = reference(case["ref"])
+    for ext in ("", ".fai", ".bwt", ".fsa", ".sa", ".pac", ".ann", ".amb"):
+        if os.path.exists(prefix + ext):
+            os.symlink(prefix + ext, str(tmp_path / ("ref.fa" + ext)))
+    for p in run.paths:
+        os.symlink(p, str(tmp_path / os.path.basename(p)))
+    p = subprocess.run(case["argv"], executable=REF_GPU, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert open(str(tmp_path / "out.sam"), "rb").read() == run.expected

@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(env_extra):
+    if "EMA_ENGINE_LIB" in env_extra and not os.path.exists(os.path.join(ROOT, "ema_amd", env_extra["EMA_ENGINE_LIB"])):
+        subprocess.check_call(["make", "-C", ROOT, "-j", str(min(8, os.cpu_count() or 1)), "test-libs"])      # normally travels with the snapshot
     env = dict(os.environ)
     env.update(env_extra)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "large_index_cases.py"), "-x", "-q", "-m", "gpu",

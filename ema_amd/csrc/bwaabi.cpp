@@ -207,6 +207,7 @@ bwaidx_t *bwa_idx_load(const char *hint, int which)
 		memset(&a, 0, sizeof(a));
 		a.offset = ema_engine_contig_offset(h->eng, i);
 		a.len = (int32_t)ema_engine_contig_len(h->eng, i);
+		a.is_alt = ema_engine_contig_is_alt(h->eng, i);
 		a.name = const_cast<char *>(h->names[(size_t)i].c_str());
 		a.anno = const_cast<char *>("");
 	}

@@ -20,6 +20,8 @@ __device__ __forceinline__ int ema_pos2rid(const DevIndex &ix, int64_t pos_f)
 	}
 	return mid;
 }
+// bntann1_t.is_alt of contig rid (<prefix>.alt; reference src/bwabridge.c:371 reads the flag bwa carries through to mem_aln_t)
+__device__ __forceinline__ int ema_ctg_alt(const DevIndex &ix, int rid) { return ix.ctg_alt && rid >= 0 ? (int)ix.ctg_alt[rid] : 0; }
 __device__ __forceinline__ int64_t ema_depos(const DevIndex &ix, int64_t pos, int &is_rev)
 {
 	is_rev = pos >= ix.l_pac;

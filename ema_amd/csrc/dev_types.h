@@ -33,6 +33,7 @@ struct DevIndex {
 	const void *sa;           // uint32_t* or uint64_t* by sa_width
 	const uint8_t *pac;
 	const int64_t *ctg_off;   // n_seqs + 1
+	const uint8_t *ctg_alt;   // n_seqs flags: the contig is named in <prefix>.alt (bwa's bntann1_t.is_alt); null when none is
 	uint64_t primary, seq_len;
 	uint64_t L2[5];
 	uint64_t occ_super[EMA_OCC_MAX_SUPER - 1][4];   // absolute counts at the start of superblocks 1, 2, 3

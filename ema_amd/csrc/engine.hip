@@ -220,6 +220,7 @@ struct ema_engine {
 	DevBuf<uint8_t> d_sa, d_pac;
 	DevBuf<uint64_t> d_kmer_wide, d_kmer_narrow;      // k-mer interval table (dev_types.h), built when the engine opens
 	DevBuf<int64_t> d_ctg;
+	DevBuf<uint8_t> d_ctg_alt;
 	// batch input (whole batch; slices are sub-ranges, the full tier addresses it through its pair list)
 	// Batch inputs live in numbered slots, each a whole batch in HBM (nt4 bases, offsets, 2-bit packs: ~0.7 GB per Mi
 	// pairs): ema_engine_stage fills slot 0, ema_engine_stage_slot any of them, and a run reads the slot it names --
@@ -439,6 +440,12 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	HIPCHK(e, hipMemcpy(e->d_ctg.p, hix.ctg_off.data(), hix.ctg_off.size() * 8, hipMemcpyHostToDevice));
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
+	e->dix.ctg_alt = nullptr;
+	if (!hix.ctg_alt.empty()) {      // <prefix>.alt names ALT contigs
+		HIPCHK(e, e->d_ctg_alt.alloc(hix.ctg_alt.size()));
+		HIPCHK(e, hipMemcpy(e->d_ctg_alt.p, hix.ctg_alt.data(), hix.ctg_alt.size(), hipMemcpyHostToDevice));
+		e->dix.ctg_alt = e->d_ctg_alt.p;
+	}
 	e->dix.kmer_k = 0; e->dix.kmer_wide = nullptr; e->dix.kmer_narrow = nullptr;
 	{   // k-mer interval table: every string up to k bases, k as large as the text makes worthwhile (4^k <= symbols / 2), at most
 		// 14 (2.9 GB); EMA_KMER_K overrides (0: none)
@@ -560,7 +567,7 @@ void ema_engine_close(ema_engine_t *e)
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
 	for (auto &fp : e->fetch_pin) { fp.c_off.release(); fp.g_off.release(); fp.status.release(); fp.cand.release(); fp.cig.release(); }
-	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
 	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
 	e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();
@@ -601,6 +608,10 @@ int64_t ema_engine_contig_len(const ema_engine_t *e, int rid)
 int64_t ema_engine_contig_offset(const ema_engine_t *e, int rid)
 {
 	return (e && rid >= 0 && rid < (int)e->contigs.size()) ? e->contigs[rid].offset : -1;
+}
+int ema_engine_contig_is_alt(const ema_engine_t *e, int rid)
+{
+	return (e && rid >= 0 && rid < (int)e->contigs.size()) ? e->contigs[rid].is_alt : 0;
 }
 int64_t ema_engine_l_pac(const ema_engine_t *e) { return e ? e->l_pac : -1; }
 int ema_engine_index_info(const ema_engine_t *e, int32_t info[4])

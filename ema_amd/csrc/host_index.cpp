@@ -27,6 +27,7 @@ DevIndex HostIndex::view() const
 	d.sa = sa_bytes.data();
 	d.pac = pac.data();
 	d.ctg_off = ctg_off.data();
+	d.ctg_alt = ctg_alt.empty() ? nullptr : ctg_alt.data();
 	d.primary = primary; d.seq_len = seq_len;
 	for (int i = 0; i < 5; ++i) d.L2[i] = L2[i];
 	d.l_pac = l_pac;
@@ -152,6 +153,22 @@ std::string host_index_load(const std::string &prefix, HostIndex &ix, bool with_
 			ix.contigs.push_back(c);
 		}
 		fclose(f);
+	}
+	// ---- .alt (optional; bwa_idx_load_from_disk): every line not starting with '@' names an ALT contig by its first field
+	if (FILE *f = fopen((prefix + ".alt").c_str(), "r")) {
+		char line[8192];
+		bool any = false;
+		while (fgets(line, sizeof(line), f)) {
+			if (line[0] == '@') continue;
+			char *e = line;
+			while (*e && *e != '\t' && *e != ' ' && *e != '\n' && *e != '\r') ++e;
+			*e = 0;
+			if (!line[0]) continue;
+			for (auto &c : ix.contigs)
+				if (c.name == line) { c.is_alt = 1; any = true; break; }
+		}
+		fclose(f);
+		if (any) for (auto &c : ix.contigs) ix.ctg_alt.push_back((uint8_t)c.is_alt);
 	}
 	if ((uint64_t)ix.l_pac * 2 != ix.seq_len) return "l_pac disagrees with seq_len";
 	ix.ctg_off.clear();

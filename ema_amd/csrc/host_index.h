@@ -20,6 +20,7 @@ struct HostIndex {
 	uint64_t sa_file_off = 0, sa_size = 0;
 	std::vector<uint8_t> pac;
 	std::vector<int64_t> ctg_off;    // n+1
+	std::vector<uint8_t> ctg_alt;    // n flags from <prefix>.alt; empty when no contig is ALT
 	std::vector<HostContig> contigs;
 	uint64_t primary = 0, seq_len = 0, L2[5] = {0, 0, 0, 0, 0};
 	int64_t l_pac = 0;

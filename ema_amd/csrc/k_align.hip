@@ -374,7 +374,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	// the medium layout needs 4 KB of small-table area, the 2 KB window buffer and 1 KB of region-list area
 	constexpr bool MED = EMA_SMALL_BYTES(SMALL) >= 4096 && EMA_RSEQ_CAP >= EMA_MED_CHAINS * 8 && (AVL > 0 && EMA_AVL_BYTES(AVL) >= EMA_MED_CHAINS * 4);
 	const int lane = (int)ema_lane();
-	const int wib = (int)(threadIdx.x >> 6);
+	const int wib = ema_uni((int)(threadIdx.x >> 6));      // scalar: everything derived from it (slab, LDS table pointers) stays in SGPRs
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
 	uint8_t *query = lds_q[wib];
 	uint8_t *rseq = lds_r[wib];
@@ -575,7 +575,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			// the filter on LDS: keys, per-chain summaries (indexed by chain id), kept list.  These overlay the chaining tables, so
 			// every lane first takes its (up to four) chains' entries into registers.
 			uint64_t *skey = reinterpret_cast<uint64_t *>(lds_small[wib] + 1024);
-			uint64_t *csum = reinterpret_cast<uint64_t *>(rseq);      // w << 32 | end << 16 | beg << 8 | kept flag
+			uint64_t *csum = reinterpret_cast<uint64_t *>(rseq);      // w << 32 | ALT contig << 31 | end << 16 | beg << 8 | kept flag
 			uint16_t *kept = reinterpret_cast<uint16_t *>(lds_av[wib]);
 			int16_t *firstk = reinterpret_cast<int16_t *>(lds_av[wib] + 2 * EMA_MED_CHAINS);
 			int64_t my_pos[EMA_MED_CHAINS / EMA_WAVE];
@@ -603,7 +603,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					sl.chains[id].l_rbeg = my_pos[r] + (int32_t)my_m0[r]; sl.chains[id].l_qbeg = l_qbeg; sl.chains[id].l_len = l_len;
 					sl.chains[id].last_seed = (int)(my_m1[r] >> 16); sl.chains[id].n = cnt; sl.chains[id].w = w;
 					skey[i] = (uint64_t)(uint32_t)w << 32 | (uint32_t)id;
-					csum[id] = (uint64_t)(uint32_t)w << 32 | (uint64_t)(uint32_t)(l_qbeg + l_len) << 16 | (uint64_t)(uint32_t)f_qbeg << 8;
+					csum[id] = (uint64_t)(uint32_t)w << 32 | (uint64_t)(uint32_t)ema_ctg_alt(ix, (int)(my_m1[r] & 0xffff)) << 31 |
+					           (uint64_t)(uint32_t)(l_qbeg + l_len) << 16 | (uint64_t)(uint32_t)f_qbeg << 8;
 				}
 			}
 			ema_wave_sync();
@@ -617,17 +618,17 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			for (int i = 1; i < n_chn; ++i) {
 				const int ci = ema_uni((int)(uint32_t)skey[i]);
 				const uint64_t s_i = ema_uni(csum[ci]);
-				const int beg_i = (int)(s_i >> 8 & 0xff), end_i = (int)(s_i >> 16 & 0xffff), w_i = (int)(s_i >> 32);
+				const int beg_i = (int)(s_i >> 8 & 0xff), end_i = (int)(s_i >> 16 & 0x7fff), w_i = (int)(s_i >> 32), alt_i = (int)(s_i >> 31 & 1);
 				bool large_ovlp = false, dropped = false;
 				for (int base = 0; base < n_kept && !dropped; base += EMA_WAVE) {
 					const int k = base + lane;
 					const bool valid = k < n_kept;
 					const uint64_t s_j = valid ? csum[(uint32_t)skey[kept[k]]] : s_i;
-					const int beg_j = (int)(s_j >> 8 & 0xff), end_j = (int)(s_j >> 16 & 0xffff), w_j = (int)(s_j >> 32);
+					const int beg_j = (int)(s_j >> 8 & 0xff), end_j = (int)(s_j >> 16 & 0x7fff), w_j = (int)(s_j >> 32), alt_j = (int)(s_j >> 31 & 1);
 					const int b_max = beg_j > beg_i ? beg_j : beg_i;
 					const int e_min = end_j < end_i ? end_j : end_i;
 					bool ovlp = false, drop = false;
-					if (valid && e_min > b_max) {
+					if (valid && e_min > b_max && (!alt_j || alt_i)) {      // a kept ALT chain does not shadow a primary one
 						const int li = end_i - beg_i, lj = end_j - beg_j;
 						const int min_l = li < lj ? li : lj;
 						if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
@@ -690,7 +691,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					const int b_max = beg_j > beg_i ? beg_j : beg_i;
 					const int e_min = end_j < end_i ? end_j : end_i;
 					bool ovlp = false, drop = false;
-					if (valid && e_min > b_max) {     // is_alt is always 0: no .alt support
+					if (valid && e_min > b_max && (!ema_ctg_alt(ix, a_j.rid) || ema_ctg_alt(ix, a_i.rid))) {     // a kept ALT chain does not shadow a primary one
 						const int li = end_i - beg_i, lj = end_j - beg_j;
 						const int min_l = li < lj ? li : lj;
 						if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
@@ -1000,7 +1001,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		ema_wave_sync();
 		EMA_PHASE(9);      // 9: results out
 		DevReg *dst = regs + (size_t)read * opt.reg_cap;
-		for (int i = lane; i < n_out; i += EMA_WAVE) dst[i] = sl.av[i];
+		for (int i = lane; i < n_out; i += EMA_WAVE) { DevReg r = sl.av[i]; r.is_alt = ema_ctg_alt(ix, r.rid); dst[i] = r; }      // mem_align1_core's last loop
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
 		EMA_DBG(9, n_out);
 		EMA_PHASE(0);

@@ -263,7 +263,7 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 	int phase = 0;
 #define EMA_PHASE(idx) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc[phase] += t_now - t_prev; t_prev = t_now; phase = (idx); } } while (0)
 	const int lane = (int)(threadIdx.x & 63);
-	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)ema_uni((int)(threadIdx.x >> 6));
 	const LaneScratch s = lane_carve(scratch + wave * EMA_LANE_WAVE_BYTES, lane);
 	const int n_total = ema_work_count(n_reads, n_pairs_dev, 2);
 	const int64_t l_pac = ix.l_pac;
@@ -343,7 +343,7 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 					const int beg_j = a_j.f_qbeg, end_j = a_j.l_qbeg + a_j.l_len;
 					const int b_max = beg_j > beg_i ? beg_j : beg_i;
 					const int e_min = end_j < end_i ? end_j : end_i;
-					if (e_min > b_max) {     // is_alt is always 0: no .alt support
+					if (e_min > b_max && (!ema_ctg_alt(ix, a_j.rid) || ema_ctg_alt(ix, a_i.rid))) {     // a kept ALT chain does not shadow a primary one
 						const int li = end_i - beg_i, lj = end_j - beg_j;
 						const int min_l = li < lj ? li : lj;
 						if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
@@ -481,7 +481,7 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 		}
 		if (n_out > opt.reg_cap) { st |= EMA_ST_REG_OVERFLOW; n_out = opt.reg_cap; }
 		DevReg *dst = regs + (size_t)read * opt.reg_cap;
-		for (int i = 0; i < n_out; ++i) dst[i] = s.av[i];
+		for (int i = 0; i < n_out; ++i) { DevReg r = s.av[i]; r.is_alt = ema_ctg_alt(ix, r.rid); dst[i] = r; }      // mem_align1_core's last loop
 		n_regs[read] = n_out;
 		if (st) atomicOr(status + read, st);
 		EMA_PHASE(0);

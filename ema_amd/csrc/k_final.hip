@@ -143,7 +143,7 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
 	const int lane = (int)ema_lane();
-	const int wib = (int)(threadIdx.x >> 6);
+	const int wib = ema_uni((int)(threadIdx.x >> 6));      // scalar: slab and LDS pointers derived from it stay in SGPRs
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
 	uint8_t *z = slabs + (size_t)slot * EMA_FINAL_SLAB_BYTES;
 	uint32_t *ctmp = (uint32_t *)(z + EMA_Z_BYTES);

@@ -174,7 +174,7 @@ ema_k_pair(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_lo
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
 	__shared__ int lds_stack[4][3 * 70];
 	const int lane = (int)ema_lane();
-	const int wib = (int)(threadIdx.x >> 6);
+	const int wib = ema_uni((int)(threadIdx.x >> 6));      // scalar: slab and LDS pointers derived from it stay in SGPRs
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
 	uint8_t *slab = slabs + (size_t)slot * EMA_PAIR_SLAB_BYTES;
 	DevReg *av[2] = {(DevReg *)slab, (DevReg *)slab + EMA_AV_CAP};

@@ -23,8 +23,16 @@
 //   next row / end of search -> start of the next search -> the one place that looks up the next base and posts
 //   the extend request,
 // so that almost every tick is one pass over this sequence whatever mix of states the 64 lanes are in.
-// The read sits in LDS as 2-bit codes + N mask (packed by the host); the working lists (bwa's prev/curr vectors)
-// live in a lane-interleaved slab of HBM scratch, written fire-and-forget and read back one tick ahead of use.
+// The read sits in LDS as 2-bit codes + N mask (packed by the host).
+// Working lists (bwa's prev/curr vectors).  The forward phase of a search pushes its intervals onto list F, in a
+// lane-interleaved slab of HBM scratch, written fire-and-forget; the first backward row walks F from its end, one entry
+// prefetched per tick.  Every backward row writes the intervals that survive it onto list B -- and B is ONE list, compacted in
+// place: row r reads B[j] for j = 0, 1, ... and pushes at most one entry per entry read, so the push index never passes the
+// read index and the next row's list grows over the current one (bwa swaps two vectors).  B is where the traffic is (a
+// search's backward phase reads and writes ~100 entries, its forward phase ~17), and B's first EMA_SEED_LDS_LIST entries live in
+// LDS as 16-byte entries {k: 40 bit, end: 8, size: 40, aux: 40 = the string's code in table mode, k' otherwise}: no memory
+// request, no tick of latency.  Entries beyond that (rows of more than 14 intervals: a few per cent) go to the slab as before.
+// (Round 2 kept both lists in the slab: 0.3 G of K1's 1.3 G requests per series and 10.8 GB of writes)
 // (Earlier forms: one read per 8-lane group sharing each block load -- the 8 lanes replayed the whole control
 // program, ~10 M reads/s; one read per lane with per-state code that stored/pushed at a dozen inlined sites --
 // every tick walked ~1500 vector instructions, 189 VGPRs.)
@@ -49,9 +57,13 @@ enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, 
 
 // A machine taken off its lane (see "re-packing" below): everything phase B and the next step need.  The working
 // lists stay where they are -- `wl` is the address of the lane's list slab -- and the read is re-staged from qpack.
+#ifndef EMA_SEED_LDS_LIST
+#define EMA_SEED_LDS_LIST 14      // 64 B of read codes + 32 B of N mask + 14 x 16 B per lane = 80 KB per 256 lanes: two blocks per CU
+#endif
 struct SeedPark {
 	uint64_t last_curr_size, c0, c1, c2, f0, f1, f2, ld_at, wl;
-	int32_t pc, pass, len, read, x, sm_x, min_intv, i, j, n_prev, n_curr, rev, prev_is_a, n_mem_call, last_mem_start;
+	uint64_t b_lds[EMA_SEED_LDS_LIST][2];      // list B's LDS entries
+	int32_t pc, pass, len, read, x, sm_x, min_intv, i, j, n_prev, n_curr, rev, pad_, n_mem_call, last_mem_start;
 	int32_t n_out, old_n, k2, st, req_c, ld_kind, has_req, n_ext;
 	uint32_t c_end, f_end;
 	uint32_t c_code, f_code, req_code, req_len;      // k-mer table mode (DevIndex.kmer_k > 0)
@@ -62,8 +74,8 @@ struct SeedPark {
 // reads: qpack[r * 24 ..]: 16 words of 2-bit codes (base i at bits 2(i%16) of word i/16, N stored as 0) followed by
 //        8 words of N flags (bit i%32 of word i/32); read lengths from off[]
 // intv : n_reads x opt.intv_cap (in discovery order, see the header), n_intv / status : n_reads
-// lists: (gridDim.x * blockDim.x) x 2 x EMA_LIST_CAP scratch entries (one pair of working lists per lane, interleaved
-//        over the 64 lanes of a wave so that lanes at the same list index touch one contiguous 2 KB run)
+// lists: (gridDim.x * blockDim.x) x 2 x EMA_LIST_CAP scratch entries (per lane list F, then the part of list B that is not in
+//        LDS; interleaved over the 64 lanes of a wave so that lanes at the same list index touch one contiguous 2 KB run)
 // counter: zero on entry; reads are handed out one by one
 // Re-packing.  A read costs anything from a hundred to ten thousand ticks, so once the queue is empty a wave keeps
 // ticking -- at full instruction cost -- for its last few long reads.  Instead, a wave that is down to park_max
@@ -85,17 +97,19 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
 	__shared__ uint32_t lds_n[4][8 * 64];       // N mask, 8 words per lane
-	const int lane = (int)(threadIdx.x & 63), wib = (int)(threadIdx.x >> 6);
+	__shared__ uint4 lds_b[4][EMA_SEED_LDS_LIST * 64];      // list B's first entries, entry e of a lane at [(e << 6) + lane]
+	const int lane = (int)(threadIdx.x & 63), wib = ema_uni((int)(threadIdx.x >> 6));
 	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wib;
 	const uint32_t *qw = lds_q[wib] + lane, *nm = lds_n[wib] + lane;
-	// this wave's working lists: list A then list B, entry e of this lane at [(e << 6) + lane]
+	// this wave's slab: list F then list B (entries from EMA_SEED_LDS_LIST on), entry e of this lane at [(e << 6) + lane]
 	Intv *wl = lists + wave * (2 * EMA_LIST_CAP * 64) + lane;
+	uint4 *bl = lds_b[wib] + lane;
 	const int n_tasks = park_in ? *n_park_in : ema_work_count(n_reads, n_pairs_dev, 2);
 
 	// ---- per-lane machine state
 	int pc = PC_DONE, pass = 1, len = 0, read = -1;
 	int x = 0, sm_x = 0, min_intv = 1, i = 0, j = 0;
-	int n_prev = 0, n_curr = 0, rev = 0, prev_is_a = 1;
+	int n_prev = 0, n_curr = 0, rev = 0;      // rev: the row being walked is list F from its end (the first backward row)
 	int n_mem_call = 0, last_mem_start = 0, n_out = 0, old_n = 0, k2 = 0, st = 0, n_ext = 0;
 	uint64_t last_curr_size = 0;
 	uint64_t c0 = 0, c1 = 0, c2 = 0; uint32_t c_end = 0;      // interval being extended: bwa's ik (forward) / *p (backward)
@@ -146,10 +160,18 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 						if ((int)c_end - (i + 1) >= opt.min_seed_len) { ev = 2; v0 = c0; v1 = c1; v2 = c2; v_start = (uint32_t)(i + 1); v_end = c_end; }
 					}
 				} else if (n_curr == 0 || r2 != last_curr_size) {
-					ev = 1; v0 = r0; v1 = kk ? r_code : r1; v2 = r2; v_end = c_end;
+					ev = 3; v0 = r0; v1 = kk ? r_code : r1; v2 = r2; v_end = c_end;
 					last_curr_size = r2;
 				}
-				if (j + 1 < n_prev) { c0 = ent.x0; c1 = ent.x1; c2 = ent.x2; c_end = (uint32_t)ent.info; c_code = (uint32_t)ent.x1; }      // prefetched with the extend
+				if (j + 1 < n_prev) {      // the row's next entry
+					if (rev || j + 1 >= EMA_SEED_LDS_LIST) { c0 = ent.x0; c1 = ent.x1; c2 = ent.x2; c_end = (uint32_t)ent.info; c_code = (uint32_t)ent.x1; }      // prefetched with the extend
+					else {
+						const uint4 w = bl[(j + 1) << 6];      // {k: 40, end: 8, aux low: 16} {size: 40, aux high: 24}
+						c0 = ((uint64_t)w.y << 32 | w.x) & 0xFFFFFFFFFFULL; c_end = (w.y >> 8) & 0xff;
+						c2 = ((uint64_t)w.w << 32 | w.z) & 0xFFFFFFFFFFULL;
+						c1 = (uint64_t)(w.y >> 16) | (uint64_t)(w.w >> 8) << 16; c_code = (uint32_t)c1;
+					}
+				}
 				nxt = true;
 				pc = PC_BWD;
 				break;
@@ -183,11 +205,16 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			if (ev) {
 				Intv e; e.x0 = v0; e.x1 = v1; e.x2 = v2;
 				Intv *dst = nullptr;
-				if (ev == 1) {
+				if (ev != 2) {
 					if (n_curr >= EMA_LIST_CAP) st |= EMA_ST_LIST_OVERFLOW;
 					else {
 						e.info = v_end;
-						dst = wl + ((size_t)((prev_is_a ? EMA_LIST_CAP : 0) + n_curr) << 6);
+						if (ev == 3 && n_curr < EMA_SEED_LDS_LIST) {
+							uint4 w;
+							w.x = (uint32_t)v0; w.y = ((uint32_t)(v0 >> 32) & 0xff) | (v_end & 0xff) << 8 | (uint32_t)(v1 & 0xffff) << 16;
+							w.z = (uint32_t)v2; w.w = ((uint32_t)(v2 >> 32) & 0xff) | (uint32_t)(v1 >> 16) << 8;
+							bl[n_curr << 6] = w;
+						} else dst = wl + ((size_t)((ev == 3 ? EMA_LIST_CAP : 0) + n_curr) << 6);
 						if (n_curr == 0) { f0 = v0; f1 = v1; f2 = v2; f_end = v_end; f_code = (uint32_t)v1; }
 						++n_curr;
 					}
@@ -200,7 +227,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			// (3) forward phase over: its list (longest match = the interval just pushed = c) becomes prev, walked in reverse
 			if (aft) {
 				if (pass == 1) x = (int)c_end;      // bwt_smem1's return value: where the forward extension stopped
-				prev_is_a ^= 1;
 				n_prev = n_curr; n_curr = 0; rev = 1;
 				i = sm_x - 1; j = 0;
 				pc = PC_BWD;
@@ -209,7 +235,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			if (nxt && ++j == n_prev) {
 				if (n_curr == 0) pc = pass == 1 ? PC_P1_NEXT : PC_P2_NEXT;
 				else {
-					prev_is_a ^= 1; n_prev = n_curr; n_curr = 0; rev = 0; j = 0; --i;
+					n_prev = n_curr; n_curr = 0; rev = 0; j = 0; --i;
 					c0 = f0; c1 = f1; c2 = f2; c_end = f_end; c_code = f_code;
 				}
 			}
@@ -224,7 +250,12 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 					last_curr_size = k.last_curr_size; c0 = k.c0; c1 = k.c1; c2 = k.c2; f0 = k.f0; f1 = k.f1; f2 = k.f2;
 					ld_at = (size_t)k.ld_at; wl = reinterpret_cast<Intv *>(k.wl);
 					pc = k.pc; pass = k.pass; x = k.x; sm_x = k.sm_x; min_intv = k.min_intv; i = k.i; j = k.j;
-					n_prev = k.n_prev; n_curr = k.n_curr; rev = k.rev; prev_is_a = k.prev_is_a; n_mem_call = k.n_mem_call;
+					n_prev = k.n_prev; n_curr = k.n_curr; rev = k.rev; n_mem_call = k.n_mem_call;
+#pragma unroll
+					for (int t = 0; t < EMA_SEED_LDS_LIST; ++t) {
+						uint4 w; w.x = (uint32_t)k.b_lds[t][0]; w.y = (uint32_t)(k.b_lds[t][0] >> 32); w.z = (uint32_t)k.b_lds[t][1]; w.w = (uint32_t)(k.b_lds[t][1] >> 32);
+						bl[t << 6] = w;
+					}
 					last_mem_start = k.last_mem_start; n_out = k.n_out; old_n = k.old_n; k2 = k.k2; st = k.st;
 					req_c = k.req_c; ld_kind = k.ld_kind; has_req = k.has_req; n_ext = k.n_ext; c_end = k.c_end; f_end = k.f_end;
 					c_code = k.c_code; f_code = k.f_code; req_code = k.req_code; req_len = k.req_len;
@@ -246,7 +277,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				}
 				out_base = (size_t)read * opt.intv_cap;
 				if (park_in) break;
-				st = 0; n_out = 0; pass = 1; x = 0; prev_is_a = 1; n_curr = 0; n_ext = 0;
+				st = 0; n_out = 0; pass = 1; x = 0; n_curr = 0; n_ext = 0;
 				if (len >= opt.min_seed_len) pc = PC_P1_NEXT;      // mem_chain: no seeds for a read shorter than min_seed_len
 				break;
 			case PC_P1_NEXT:      // pass 1: SMEMs from left to right
@@ -288,7 +319,10 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 					has_req = 1;
 					if (pc == PC_BWD) {
 						req_c = b;
-						if (j + 1 < n_prev) { ld_at = (size_t)((prev_is_a ? 0 : EMA_LIST_CAP) + (rev ? n_prev - 2 - j : j + 1)) << 6; ld_kind = 1; }
+						if (j + 1 < n_prev) {      // the row's next entry comes from the slab: list F walked from its end, or list B beyond its LDS part
+							if (rev) { ld_at = (size_t)(n_prev - 2 - j) << 6; ld_kind = 1; }
+							else if (j + 1 >= EMA_SEED_LDS_LIST) { ld_at = (size_t)(EMA_LIST_CAP + j + 1) << 6; ld_kind = 1; }
+						}
 						// the extended string is q[i .. c_end): short enough for the table?
 						const int rl = (int)c_end - i;
 						if (rl <= kk) { has_req = 2; req_len = (uint32_t)rl; req_code = ((uint32_t)b << (2 * (rl - 1))) | c_code; }
@@ -314,7 +348,12 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				k.last_curr_size = last_curr_size; k.c0 = c0; k.c1 = c1; k.c2 = c2; k.f0 = f0; k.f1 = f1; k.f2 = f2;
 				k.ld_at = ld_at; k.wl = reinterpret_cast<uint64_t>(wl);
 				k.pc = pc; k.pass = pass; k.len = len; k.read = read; k.x = x; k.sm_x = sm_x; k.min_intv = min_intv; k.i = i; k.j = j;
-				k.n_prev = n_prev; k.n_curr = n_curr; k.rev = rev; k.prev_is_a = prev_is_a; k.n_mem_call = n_mem_call;
+				k.n_prev = n_prev; k.n_curr = n_curr; k.rev = rev; k.pad_ = 0; k.n_mem_call = n_mem_call;
+#pragma unroll
+				for (int t = 0; t < EMA_SEED_LDS_LIST; ++t) {
+					const uint4 w = bl[t << 6];
+					k.b_lds[t][0] = (uint64_t)w.y << 32 | w.x; k.b_lds[t][1] = (uint64_t)w.w << 32 | w.z;
+				}
 				k.last_mem_start = last_mem_start; k.n_out = n_out; k.old_n = old_n; k.k2 = k2; k.st = st;
 				k.req_c = req_c; k.ld_kind = ld_kind; k.has_req = has_req; k.n_ext = n_ext; k.c_end = c_end; k.f_end = f_end;
 				k.c_code = c_code; k.f_code = f_code; k.req_code = req_code; k.req_len = req_len;

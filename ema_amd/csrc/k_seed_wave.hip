@@ -197,7 +197,7 @@ ema_k_seed_wave(const DevIndex *__restrict__ ixp, const DevOpts *__restrict__ op
 	__shared__ uint32_t lds_q[2][24];
 	__shared__ Intv lds_lists[2][2][EMA_LIST_CAP];
 	__shared__ uint64_t lds_tmp[2][EMA_WAVE];
-	const int lane = (int)ema_lane(), wib = (int)(threadIdx.x >> 6);
+	const int lane = (int)ema_lane(), wib = ema_uni((int)(threadIdx.x >> 6));
 	const int n_total = ema_work_count(n_reads, n_pairs_dev, 2);
 	const DevIndex &ix = *ixp;
 	const DevOpts &opt = *optp;

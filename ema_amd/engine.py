@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("EMA_ENGINE_LIB", "libema_engine.s
 
 SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
-    "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_l_pac",
+    "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_contig_is_alt", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
     "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free", "ema_engine_open_shared", "ema_engine_index_info", "ema_engine_stage_slot", "ema_engine_run_slot", "ema_engine_peer",
     "ema_engine_seed_launches", "ema_engine_get_opts",

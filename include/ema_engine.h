@@ -79,6 +79,10 @@ int ema_engine_n_contigs(const ema_engine_t *e);
 const char *ema_engine_contig_name(const ema_engine_t *e, int rid);
 int64_t ema_engine_contig_len(const ema_engine_t *e, int rid);
 int64_t ema_engine_contig_offset(const ema_engine_t *e, int rid);
+/* 1 if <index_prefix>.alt names the contig (bwa's bntann1_t.is_alt; every non-'@' line's first field is a contig name):
+ * a kept chain on such a contig does not shadow chains on primary contigs in the chain filter, and ema_cand_t.is_alt
+ * carries the flag the reference reads at src/bwabridge.c:371 */
+int ema_engine_contig_is_alt(const ema_engine_t *e, int rid);
 int64_t ema_engine_l_pac(const ema_engine_t *e);
 /* layout of the index in HBM: info[0] = rank superblocks, info[1] = log2 symbols per superblock, info[2] = bytes per
  * suffix-array row (4, or 8 beyond 2^32 rows), info[3] = k of the k-mer interval table (0 = none) */

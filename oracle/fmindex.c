@@ -156,6 +156,23 @@ orc_idx_t *orc_idx_load(const char *prefix)
 	}
 	fclose(f);
 
+	/* .alt (optional; bwa_idx_load_from_disk): every line that does not start with '@' names an ALT contig by its first
+	 * tab- or space-delimited field (the file is SAM-formatted in bwa.kit; a plain list of names works the same way) */
+	snprintf(path, sizeof(path), "%s.alt", prefix);
+	f = fopen(path, "r");
+	if (f) {
+		while (fgets(line, sizeof(line), f)) {
+			char *e = line;
+			if (line[0] == '@') continue;
+			while (*e && *e != '\t' && *e != ' ' && *e != '\n' && *e != '\r') ++e;
+			*e = 0;
+			if (!line[0]) continue;
+			for (i = 0; i < (size_t)idx->n_seqs; ++i)
+				if (strcmp(idx->anns[i].name, line) == 0) { idx->anns[i].is_alt = 1; break; }
+		}
+		fclose(f);
+	}
+
 	/* .pac: forward strand, 4 bases/byte, first base in the high bits */
 	idx->pac = slurp(prefix, ".pac", &sz);
 	if (!idx->pac) goto fail;

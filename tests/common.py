@@ -16,6 +16,7 @@ def small_ref(kind="two_contigs"):
     if kind in _CACHE:
         return _CACHE[kind]
     d = tempfile.mkdtemp(prefix="ema_ref_")
+    names = None
     if kind == "two_contigs":
         ctg = synth.make_genome([200000, 100000], seed=1)
     elif kind == "repeats":      # repeat-rich: exercises max_occ, chain filter, rescue
@@ -46,13 +47,38 @@ def small_ref(kind="two_contigs"):
                 e = (3 - e)[::-1]
             at = 3000 + 800 * k
             g[at:at + 500] = e
+    elif kind == "tiny_family":   # 118 Kbp (four 2^16-symbol superblocks in the ss16 build) holding 440 diverged copies of a 200 bp element:
+        ctg = synth.make_genome([118000], seed=31, short_rep=0.0, long_rep=0.0, segdup=0.0)      # reads from a copy have several hundred chains
+        rng = np.random.default_rng(31)
+        g = ctg[0]
+        elem = rng.integers(0, 4, 200).astype(np.uint8)
+        for k in range(440):
+            e = elem.copy()
+            hit = rng.random(200) < 0.015
+            e[hit] = (e[hit] + rng.integers(1, 4, int(hit.sum()))) % 4
+            if k & 1:
+                e = (3 - e)[::-1]
+            at = 2000 + 260 * k
+            g[at:at + 200] = e
+    elif kind == "with_alt":      # two primary contigs + two ALT contigs (diverged copies of primary segments), named in <prefix>.alt
+        ctg = synth.make_genome([200000, 100000], seed=29)
+        rng = np.random.default_rng(29)
+        for src, lo, n, div in ((0, 40000, 24000, 0.012), (1, 30000, 12000, 0.03)):
+            a = ctg[src][lo:lo + n].copy()
+            hit = rng.random(n) < div
+            a[hit] = (a[hit] + rng.integers(1, 4, int(hit.sum()))) % 4
+            ctg.append(a)
+        names = ["chr1", "chr2", "chr1_alt1", "chr2_alt1"]
     elif kind == "mid":          # a few Mbp for GPU throughput smoke tests
         ctg = synth.make_genome([3000000, 1000000], seed=11)
     else:
         raise KeyError(kind)
     prefix = os.path.join(d, "ref.fa")
-    synth.write_fasta(prefix, ctg)
+    synth.write_fasta(prefix, ctg, names=names)
     build_index(prefix)
+    if kind == "with_alt":      # bwa.kit's .alt is SAM-formatted: a header, then one line per ALT contig starting with its name
+        with open(prefix + ".alt", "w") as f:
+            f.write("@SQ\tSN:chr1\tLN:200000\nchr1_alt1\t0\tchr1\t40001\t60\t24000M\t*\t0\t0\t*\t*\nchr2_alt1\t0\tchr2\t30001\t60\t12000M\t*\t0\t0\t*\t*\n")
     _CACHE[kind] = (prefix, ctg)
     return _CACHE[kind]
 

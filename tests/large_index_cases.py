@@ -50,3 +50,20 @@ def test_pipeline():
 
 def test_pipeline_noisy():
     TP._check(KIND, 500, 65, sub_rate=0.06, indel_rate=0.003)
+
+
+def test_chain_rich_reads_on_the_large_index_paths():
+    """Reads with more than EMA_MED_CHAINS = 256 chains (K2b's medium layout outgrown, the slab layout, K2c / K2d) in the same run
+    as the several-superblock and 8-byte-row branches: a 118 Kbp reference with 440 copies of a 200 bp element."""
+    import oracle_lib as O
+    from ema_amd import synth
+    prefix, ctg = small_ref("tiny_family")
+    pairs = synth.make_pairs([ctg[0][2000:2000 + 260 * 440]], 160, seed=66, sub_rate=0.01)
+    idx, opt = O.Index(prefix), O.default_opt()
+    rich = sum(O.n_chains(idx, opt, pairs.read(r)) > 256 for r in range(0, 2 * pairs.n, 7))
+    assert rich >= 5, rich
+    eng = Engine(prefix)
+    batch = eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()
+    assert batch.status.max() == 0
+    assert not TP.compare(prefix, pairs, batch)

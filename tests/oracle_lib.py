@@ -347,3 +347,17 @@ def sam_header(contigs, rg_line, version: bytes, argv) -> bytes:
     libc.free.argtypes = [C.c_void_p]
     libc.free(text)
     return out
+
+
+class _ChainV(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+def n_chains(idx: Index, opt, read_ascii: bytes) -> int:
+    """Chains mem_chain builds for a read, before the filter (orc_chain): how chain-rich a test read is."""
+    L = lib()
+    L.orc_chain.restype = _ChainV
+    L.orc_chain.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int, C.c_char_p]
+    nt4 = bytes({65: 0, 67: 1, 71: 2, 84: 3}.get(c, 4) for c in read_ascii)
+    v = L.orc_chain(C.byref(opt), idx.h, len(nt4), nt4)
+    return int(v.n)      # (the few KB of seeds are left to the process: a test helper)

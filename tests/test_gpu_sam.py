@@ -52,13 +52,13 @@ def oracle_sam(prefix, path, names, so, haplotag=False):
     return oracle_text(arr, n, so), next_id, keep
 
 
-def _run(tmp_path, kind, sizes, haplotag, continue_ids):
+def _run(tmp_path, kind, sizes, haplotag, continue_ids, **kw):
     prefix, ctg = small_ref(kind)
     paths = []
     for k, n in enumerate(sizes):
         d = tmp_path / f"b{k}"
         d.mkdir()
-        _p, _c, _bucket = make_bucket(d, kind, n, 900 + k, 40, haplotag, sub_rate=0.015, chimeric=0.04)
+        _p, _c, _bucket = make_bucket(d, kind, n, 900 + k, 40, haplotag, sub_rate=0.015, chimeric=0.04, **kw)
         paths.append(str(d / "bucket"))
     _check(tmp_path, prefix, ctg, paths, sum(sizes), haplotag, continue_ids)
 
@@ -107,6 +107,12 @@ def test_x_mode_cloud_numbers_run_on(tmp_path):
 
 def test_haplotag_bucket_to_sam(tmp_path):
     _run(tmp_path, "two_contigs", [320], True, False)
+
+
+def test_haplotag_250bp_bucket_to_sam(tmp_path):
+    """BASELINE configs[4] as written: 2 x 250 bp haplotag reads (the documented MAX_READ_LEN deviation, SURVEY 0.4: the reference
+    stops at 200 bases, the engine and the oracle take 255), bucket file -> SAM text."""
+    _run(tmp_path, "two_contigs", [260], True, False, len1=250, len2=250, indel_rate=0.002)
 
 
 def test_raw_fastq_through_count_and_preproc_to_sam(tmp_path):

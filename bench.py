@@ -50,6 +50,60 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def cpus_granted():
+    """CPUs this job may really use: the affinity mask cut by the cgroup's CPU quota (the GPU boxes show a 64-core socket and
+    grant a job 16-19 CPUs' worth of run time through cpu.max, r02b)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if t[0] != "max":
+                    n = min(n, max(1, int(float(t[0]) / float(t[1]) + 0.5)))
+            else:
+                q = int(t[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return n
+
+
+def host_threads_for_rank(cpus, world):
+    """Every rank stages, fetches and runs its append / cloud / formatter stages on host threads (default: up to 32 per rank);
+    N ranks share the node's CPUs, so each takes its share and no more -- never more threads in total than CPUs granted
+    (round 2 had a floor of 4 per rank: 8 ranks on 19 CPUs oversubscribed)."""
+    return max(1, min(32, cpus // max(1, world)))
+
+
+def pin_to_gpu_numa_node(local):
+    """The rank's host threads on the NUMA node its GPU hangs off (sysfs: the GPU's PCI device -> numa_node -> cpulist), within
+    the affinity mask the job already has.  Best effort: returns the node or None.  Must run before the engine starts threads."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus |= set(range(int(a), int(b or a) + 1))
+        mine = cpus & os.sched_getaffinity(0)
+        if mine:
+            os.sched_setaffinity(0, mine)
+            return node
+    except Exception:      # noqa: BLE001 -- no sysfs entry, no permission: stay where we are
+        pass
+    return None
+
+
 def spawn_ranks(n):
     """--gpus N > 1 outside torch.distributed.run: start the N ranks as child processes (nothing has touched the GPU in
     this process) and leave with their exit code."""
@@ -292,14 +346,9 @@ def main(argv=None):
     if world != max(1, args.gpus):
         log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
         raise SystemExit(2)
+    node_cpus = cpus_granted()
     if world > 1 and "EMA_HOST_THREADS" not in os.environ:
-        # every rank stages, fetches and runs its append stage on host threads (default: up to 32 per rank): N ranks share the
-        # node's CPUs, so each takes its share -- 8 x 32 threads on a socket that grants a job 16-64 CPUs only thrash
-        try:
-            cpus = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cpus = os.cpu_count() or 8
-        os.environ["EMA_HOST_THREADS"] = str(max(4, min(32, cpus // world)))
+        os.environ["EMA_HOST_THREADS"] = str(host_threads_for_rank(node_cpus, world))
     dist = None
     # RCCL ("nccl") on the GPU box; EMA_BENCH_BACKEND=gloo runs the same control flow on CPU tensors (the world-size-2 test)
     backend = os.environ.get("EMA_BENCH_BACKEND", "nccl")
@@ -312,6 +361,9 @@ def main(argv=None):
         if backend == "nccl":
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(local)
+            numa = pin_to_gpu_numa_node(local)
+            log(f"[rank {rank}] host threads: {os.environ.get('EMA_HOST_THREADS')} of {node_cpus} CPUs granted to the node's {world} ranks"
+                + (f", pinned to NUMA node {numa} (the GPU's)" if numa is not None else ""))
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
         else:
             dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=30))
@@ -390,7 +442,8 @@ def main(argv=None):
     o.lean_seed_extends = args.lean_seed_extends
     t = time.time()
     eng = Engine(prefix, device=local, opts=o)
-    log(f"[rank {rank}] engine open (index in HBM) {time.time() - t:.1f}s")
+    open_s = time.time() - t
+    log(f"[rank {rank}] engine open (index in HBM) {open_s:.1f}s")
     so = stream.default_opts()
     so.n_engines = 2 if args.two_sets else 1
     peer = eng.peer() if args.two_sets else None
@@ -455,12 +508,17 @@ def main(argv=None):
     sync_all()
     # ---- timed region: K steps = K batches (distinct up to n_batches), inputs resident, results + records on the host
     sink = make_sink(True)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     st_timed = stream.stream_resident(eng, offs[:args.steps], slots, opts=so, raw_sink=sink)
     sync_all()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)      # this rank's host threads over the timed region
     if world > 1:
         elapsed = agree(elapsed, "max")
+        host_cpu_s = agree(host_cpu_s, "max")
     for s in st_timed:
         tallies["flags"] |= s["capacity_flags"]
     any_flag = int(agree(float(tallies["flags"] != 0), "max"))
@@ -478,19 +536,6 @@ def main(argv=None):
     boundary = resident = None
     kernel_ms_isolated = None
     if not args.no_extras:
-        # ---- the same K batches from host buffers: stage (nt4 + packing + H2D) inside the timed region too
-        hb = [(batches[k % n_batches].bases, batches[k % n_batches].off) for k in range(args.steps)]
-        sync_all()
-        t1 = time.perf_counter()
-        st_b = stream.stream_batches(eng, hb, opts=so, raw_sink=make_sink(False))
-        sync_all()
-        el_b = agree(time.perf_counter() - t1, "max") if world > 1 else time.perf_counter() - t1
-        boundary = {"value": round(args.pairs * args.steps * world / el_b, 1), "unit": "pairs/s", "ms_per_step": round(el_b / args.steps * 1e3, 3),
-                    "what": "host buffers in (ASCII reads) -> candidates + append_alignments records in host memory, "
-                            "ema_stream_batches over the same batches: nt4 conversion, 2-bit packing, H2D, K1-K4, pack, D2H, append stage, "
-                            f"pipelined: " + ("two sets of batch buffers, one pass each" if n_sets == 2 else "one set, passes queued up to three deep (ema_engine_run_async), staging / kernels / fetch + append of consecutive batches overlapping"),
-                    "host_s_per_step": {"align_call": round(float(np.mean([s["align_s"] for s in st_b])), 4),
-                                        "append": round(float(np.mean([s["append_s"] for s in st_b])), 4)}}
         # ---- kernels only, queued back to back on one set (nothing fetched): round 1's figure, for continuity
         for _ in range(args.warmup):
             eng.run_slot(0)
@@ -516,6 +561,20 @@ def main(argv=None):
         tm = eng.timing()
         kernel_ms_isolated = {k: tm[k] for k in kernel_ms}
         log(f"[rank {rank}] full-capacity tier K1..K4 ms (isolated pass): {tm['full_ms']}")
+        # ---- the same K batches from host buffers: stage (nt4 + packing + H2D) inside the timed region too.  LAST of the extras: it
+        # stages into input slots that hold resident batches (the legs above run the batches the labels say)
+        hb = [(batches[k % n_batches].bases, batches[k % n_batches].off) for k in range(args.steps)]
+        sync_all()
+        t1 = time.perf_counter()
+        st_b = stream.stream_batches(eng, hb, opts=so, raw_sink=make_sink(False))
+        sync_all()
+        el_b = agree(time.perf_counter() - t1, "max") if world > 1 else time.perf_counter() - t1
+        boundary = {"value": round(args.pairs * args.steps * world / el_b, 1), "unit": "pairs/s", "ms_per_step": round(el_b / args.steps * 1e3, 3),
+                    "what": "host buffers in (ASCII reads) -> candidates + append_alignments records in host memory, "
+                            "ema_stream_batches over the same batches: nt4 conversion, 2-bit packing, H2D, K1-K4, pack, D2H, append stage, "
+                            f"pipelined: " + ("two sets of batch buffers, one pass each" if n_sets == 2 else "one set, passes queued up to three deep (ema_engine_run_async), staging / kernels / fetch + append of consecutive batches overlapping"),
+                    "host_s_per_step": {"align_call": round(float(np.mean([s["align_s"] for s in st_b])), 4),
+                                        "append": round(float(np.mean([s["append_s"] for s in st_b])), 4)}}
     n_slices = eng.n_streams
 
     from ema_amd import shard
@@ -650,6 +709,21 @@ def main(argv=None):
             "bucket_stats": {f: int(gathered[:, i].sum()) for i, f in enumerate(shard.STAT_FIELDS)},
         }
         out["bucket_stats"].update(capacity_flags=int(any_flag), oracle_spot_check_pairs=len(kept), oracle_spot_check_mismatches=int(bad))
+        # What the host costs, and what that predicts for N ranks on this node's CPU grant: every rank needs its own host threads for
+        # fetch assembly and the append stage, and the node grants the job a fixed number of CPUs whatever N is.
+        cpu_s_per_pair = host_cpu_s / float(args.pairs * args.steps)
+        per_gpu = value / world
+        out["host"] = {"cpu_seconds_per_million_pairs": round(cpu_s_per_pair * 1e6, 3), "what": "CPU seconds (user + system) of one rank's process over the "
+                       "timed region: result assembly of fetched passes and the append_alignments stage on the host's threads",
+                       "cpus_granted_to_the_node": node_cpus, "host_threads_per_rank": int(os.environ.get("EMA_HOST_THREADS", "0")) or min(32, node_cpus),
+                       "engine_open_s": round(open_s, 2), "d2h_bytes_per_pair": 350}
+        out["scaling_prediction"] = {
+            "status": "PREDICTED from this run's per-GPU rate and host CPU cost; no multi-GPU run has been measured on hardware",
+            "per_n_gpus": {str(n): {"gpu_bound_pairs_per_s": round(n * per_gpu, 1),
+                                    "host_bound_pairs_per_s": round(node_cpus / cpu_s_per_pair, 1) if cpu_s_per_pair > 0 else None,
+                                    "predicted_pairs_per_s": round(min(n * per_gpu, node_cpus / cpu_s_per_pair if cpu_s_per_pair > 0 else n * per_gpu), 1)}
+                           for n in (1, 2, 4, 8)},
+            "pcie": "0.35 KB of results per pair: 1.6 GB/s per rank at 4.5 M pairs/s; the index replica (59 GB) is uploaded once per rank in engine_open_s"}
         out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not args.no_extras else None
         print(json.dumps(out), flush=True)
     eng.close()

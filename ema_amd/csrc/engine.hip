@@ -23,6 +23,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -206,6 +207,23 @@ struct Slice {
 
 }  // namespace
 
+// The engine's error text.  ema_stream_* call into one engine from two threads (the stager: ema_engine_stage_async; the engine thread:
+// run / fetch) and both may fail at once, so assignment and reading are serialised, and a reader gets its own thread's copy.
+struct ErrText {
+	mutable std::mutex mu;
+	std::string s;
+	ErrText &operator=(const std::string &v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
+	ErrText &operator=(const char *v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
+	bool empty() const { std::lock_guard<std::mutex> lk(mu); return s.empty(); }
+	const char *c_str() const
+	{
+		static thread_local std::string mine;
+		std::lock_guard<std::mutex> lk(mu);
+		mine = s;
+		return mine.c_str();
+	}
+};
+
 struct ema_engine {
 	ema_engine_opts opts;
 	DevOpts dopts;
@@ -214,7 +232,7 @@ struct ema_engine {
 	int64_t l_pac = 0;
 	int device = 0;
 	int n_cu = 256;
-	std::string err;
+	ErrText err;
 	// index in HBM
 	DevBuf<OccBlock> d_occ;
 	DevBuf<uint8_t> d_sa, d_pac;
@@ -998,6 +1016,12 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 	const int j = ticket < 0 ? 0 : ticket % EMA_MAX_INFLIGHT;
 	ema_engine::Ticket &t = e->tickets[j];
 	if (ticket < 0 || t.seq != ticket) { e->err = "ema_engine_fetch_ticket: no such run in flight"; return EMA_ESTATE; }
+	// the ticket is released on EVERY way out of this call from here on (a failed wait would otherwise leave n_inflight stuck)
+	struct Release {
+		ema_engine::Ticket &t; ema_engine *e; bool done;
+		void now() { if (!done) { t.seq = -1; --e->n_inflight; done = true; } }
+		~Release() { now(); }
+	} release{t, e, false};
 	HIPCHK(e, hipSetDevice(e->device));
 	if (!e->copy_stream) HIPCHK(e, hipStreamCreate(&e->copy_stream));
 	hipStream_t cs = e->copy_stream;
@@ -1014,7 +1038,7 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 	HIPCHK(e, hipMemcpyAsync(&tot[2 * n_sl], f.out[j].d_tot.p, 16, hipMemcpyDeviceToHost, cs));
 	HIPCHK(e, hipMemcpyAsync(&n_listed, f.out[j].d_redo.p, 4, hipMemcpyDeviceToHost, cs));
 	HIPCHK(e, hipStreamSynchronize(cs));
-	t.seq = -1; --e->n_inflight;      // whatever happens below, the output set is free again once this call returns
+	release.now();      // whatever happens below, the output set is free again
 	{   // kernel launch durations of this pass (as ema_engine_sync records them for a synchronous one)
 		float sum[4] = {0, 0, 0, 0};
 		for (auto &s : e->sl)
@@ -1572,7 +1596,7 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 	for (size_t k = 0; k < n_parts; ++k) {
 		if (rcs[k] == EMA_ELIMIT && parts[k]) { worst = EMA_ELIMIT; continue; }      // flagged reads: report at the end
 		if (rcs[k] != EMA_OK || !parts[k]) {
-			if ((k & 1) && e->shadow && rcs[k] != EMA_OK) e->err = e->shadow->err;
+			if ((k & 1) && e->shadow && rcs[k] != EMA_OK) e->err = std::string(e->shadow->err.c_str());
 			const int rc = rcs[k] != EMA_OK ? rcs[k] : EMA_ESTATE;
 			for (auto *q : parts) if (q) ema_batch_free(q);
 			return rc;

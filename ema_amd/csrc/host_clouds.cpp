@@ -425,101 +425,128 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 		run();
 		for (auto &t : th) t.join();
 	}
-	// assembly: cloud numbers of a single-threaded run, the selected records as formatter input, statistics
+	// assembly: cloud numbers of a single-threaded run, the selected records as formatter input, statistics -- on the host's threads
+	// as well (round 2 did this part on one: more than half of the stage's wall time, r03): the offsets of every group's records
+	// and lines follow from the per-group counts, so groups are laid out independently
 	ema_clouds_out *o = (ema_clouds_out *)calloc(1, sizeof(ema_clouds_out));
 	if (!o) return EMA_EARG;
 	std::vector<int32_t> cloud_base(n_groups + 1);
+	std::vector<size_t> rec_base(n_groups + 1), line_base(n_groups + 1);
 	int32_t next_id = S.o.first_cloud_id;
-	size_t n_sel = 0;
+	size_t n_sel = 0, n_recs = 0;
 	for (size_t g = 0; g < n_groups; ++g) {
 		cloud_base[g] = next_id;
 		next_id += (int32_t)S.n_clouds[g];
+		rec_base[g] = n_recs; line_base[g] = 2 * n_sel;
+		const uint64_t r0 = a->pair_off[bk->group_off[g]];
+		for (uint32_t k = 0; k < S.n_sel[g]; ++k) n_recs += S.sel[r0 + k].mate != ~(uint64_t)0 ? 2 : 1;
 		n_sel += S.n_sel[g];
 		if (S.n_clouds[g]) ++o->stats.groups;
 		o->stats.clouds += S.n_clouds[g]; o->stats.bad_clouds += S.n_bad[g];
 	}
+	rec_base[n_groups] = n_recs; line_base[n_groups] = 2 * n_sel;
 	o->next_cloud_id = next_id;
 	o->n_lines = 2 * n_sel;
+	o->n_recs = n_recs;
 	o->lines = (ema_sam_line *)malloc((2 * n_sel + 1) * sizeof(ema_sam_line));
 	o->recs = (ema_sam_rec *)malloc((2 * n_sel + 1) * sizeof(ema_sam_rec));
 	o->alts = (ema_sam_alt *)malloc((2 * n_sel + 1) * sizeof(ema_sam_alt));
+	std::vector<size_t> ident_at(bk->n_pairs + 1);
 	size_t id_bytes = 0;
-	for (size_t p = 0; p < bk->n_pairs; ++p) id_bytes += (size_t)(bk->id_off[p + 1] - bk->id_off[p]) + 1;
+	for (size_t p = 0; p < bk->n_pairs; ++p) {      // names without the first character ('@'), NUL-terminated
+		const uint32_t ib = bk->id_off[p], ie = bk->id_off[p + 1];
+		ident_at[p] = id_bytes;
+		id_bytes += (size_t)(ie > ib ? ie - ib - 1 : 0) + 1;
+	}
 	o->idents = (char *)malloc(id_bytes + 1);
 	if (!o->lines || !o->recs || !o->alts || !o->idents) { ema_clouds_free(o); return EMA_EARG; }
-	std::vector<size_t> ident_at(bk->n_pairs + 1);
-	{
-		size_t at = 0;
-		for (size_t p = 0; p < bk->n_pairs; ++p) {
+	std::atomic<int> rc_all{EMA_OK};
+	const int nt_asm = (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 64 + 1);
+	std::vector<ema_sam_stats> part((size_t)nt_asm);
+	for (auto &ps : part) memset(&ps, 0, sizeof(ps));
+	auto assemble = [&](int tid) {
+		// this thread's stretch of pairs (names) and of groups (records, lines, statistics)
+		const size_t pa = bk->n_pairs * (size_t)tid / (size_t)nt_asm, pb = bk->n_pairs * (size_t)(tid + 1) / (size_t)nt_asm;
+		for (size_t p = pa; p < pb; ++p) {
 			const uint32_t ib = bk->id_off[p], ie = bk->id_off[p + 1];
-			ident_at[p] = at;
-			const uint32_t len = ie > ib ? ie - ib - 1 : 0;      // without the first character ('@')
-			memcpy(o->idents + at, bk->ids + ib + (ie > ib ? 1 : 0), len);
-			o->idents[at + len] = '\0';
-			at += (size_t)len + 1;
+			const uint32_t len = ie > ib ? ie - ib - 1 : 0;
+			memcpy(o->idents + ident_at[p], bk->ids + ib + (ie > ib ? 1 : 0), len);
+			o->idents[ident_at[p] + len] = '\0';
 		}
-	}
-	int rc = EMA_OK;
-	size_t n_recs = 0, n_lines = 0;
-	auto fill = [&](uint64_t gi, size_t g, uint64_t r0) -> ema_sam_rec * {
-		const ema_aln_rec &ar = a->rec[gi];
-		const ema_cand_t &c = b->cand[ar.cand];
-		const size_t p = ar.pair;
-		ema_sam_rec &r = o->recs[n_recs];
-		memset(&r, 0, sizeof(r));
-		r.ident = o->idents + ident_at[p];
-		r.chrom = contig_names[c.rid]; r.chrom_id = (uint32_t)c.rid; r.pos = (uint32_t)(c.pos + 1);
-		r.mapq = ar.mapq; r.score_mapq = ar.score_mapq; r.gamma = S.gamma[gi];
-		r.mate = ar.mate; r.rev = (uint8_t)(c.is_rev != 0); r.duplicate = S.flags[gi] & 1;
-		r.cloud_id = cloud_base[g] + S.cloud[gi]; r.cloud_bad = (S.flags[gi] >> 1) & 1;
-		r.bc = bk->bc[p];
-		const size_t rd = 2 * p + ar.mate, md = 2 * p + (1 - ar.mate);
-		r.read = bk->bases + bk->off[rd]; r.qual = bk->quals + bk->off[rd]; r.read_len = (int32_t)(bk->off[rd + 1] - bk->off[rd]);
-		r.mate_read = bk->bases + bk->off[md]; r.mate_qual = bk->quals + bk->off[md]; r.mate_read_len = (int32_t)(bk->off[md + 1] - bk->off[md]);
-		r.aln_pos = c.pos; r.aln_rev = c.is_rev; r.edit_dist = c.NM; r.n_cigar = c.n_cigar; r.cigar = b->cigar + c.cigar_off;
-		r.alts = nullptr; r.n_alts = 0;
-		if (S.alt_of[gi] >= 0) {
-			const ema_aln_rec &xr = a->rec[r0 + (uint64_t)S.alt_of[gi]];
-			const ema_cand_t &x = b->cand[xr.cand];
-			if (x.n_cigar >= 64) rc = EMA_EFORMAT;      // the reference asserts (struct xa holds 64 operations)
-			ema_sam_alt &al = o->alts[n_recs];
-			al.chrom = contig_names[x.rid]; al.pos = (uint32_t)(x.pos + 1); al.edit_dist = x.NM; al.rev = x.is_rev != 0;
-			al.n_cigar = x.n_cigar; al.cigar = b->cigar + x.cigar_off;
-			r.alts = &al; r.n_alts = 1;
+		ema_sam_stats &st = part[(size_t)tid];
+		const size_t ga = n_groups * (size_t)tid / (size_t)nt_asm, gb = n_groups * (size_t)(tid + 1) / (size_t)nt_asm;
+		for (size_t g = ga; g < gb; ++g) {
+			const uint64_t r0 = a->pair_off[bk->group_off[g]];
+			size_t at = rec_base[g], ln = line_base[g];
+			auto fill = [&](uint64_t gi) -> ema_sam_rec * {
+				const ema_aln_rec &ar = a->rec[gi];
+				const ema_cand_t &c = b->cand[ar.cand];
+				const size_t p = ar.pair;
+				ema_sam_rec &r = o->recs[at];
+				memset(&r, 0, sizeof(r));
+				r.ident = o->idents + ident_at[p];
+				r.chrom = contig_names[c.rid]; r.chrom_id = (uint32_t)c.rid; r.pos = (uint32_t)(c.pos + 1);
+				r.mapq = ar.mapq; r.score_mapq = ar.score_mapq; r.gamma = S.gamma[gi];
+				r.mate = ar.mate; r.rev = (uint8_t)(c.is_rev != 0); r.duplicate = S.flags[gi] & 1;
+				r.cloud_id = cloud_base[g] + S.cloud[gi]; r.cloud_bad = (S.flags[gi] >> 1) & 1;
+				r.bc = bk->bc[p];
+				const size_t rd = 2 * p + ar.mate, md = 2 * p + (1 - ar.mate);
+				r.read = bk->bases + bk->off[rd]; r.qual = bk->quals + bk->off[rd]; r.read_len = (int32_t)(bk->off[rd + 1] - bk->off[rd]);
+				r.mate_read = bk->bases + bk->off[md]; r.mate_qual = bk->quals + bk->off[md]; r.mate_read_len = (int32_t)(bk->off[md + 1] - bk->off[md]);
+				r.aln_pos = c.pos; r.aln_rev = c.is_rev; r.edit_dist = c.NM; r.n_cigar = c.n_cigar; r.cigar = b->cigar + c.cigar_off;
+				r.alts = nullptr; r.n_alts = 0;
+				if (S.alt_of[gi] >= 0) {
+					const ema_aln_rec &xr = a->rec[r0 + (uint64_t)S.alt_of[gi]];
+					const ema_cand_t &x = b->cand[xr.cand];
+					if (x.n_cigar >= 64) rc_all.store(EMA_EFORMAT);      // the reference asserts (struct xa holds 64 operations)
+					ema_sam_alt &al = o->alts[at];
+					al.chrom = contig_names[x.rid]; al.pos = (uint32_t)(x.pos + 1); al.edit_dist = x.NM; al.rev = x.is_rev != 0;
+					al.n_cigar = x.n_cigar; al.cigar = b->cigar + x.cigar_off;
+					r.alts = &al; r.n_alts = 1;
+				}
+				return &o->recs[at++];
+			};
+			for (uint32_t k = 0; k < S.n_sel[g]; ++k) {
+				const Sel sl = S.sel[r0 + k];
+				const ema_sam_rec *rec = fill(sl.rec);
+				const ema_sam_rec *mate = sl.mate != ~(uint64_t)0 ? fill(sl.mate) : nullptr;
+				o->lines[ln++] = ema_sam_line{rec, mate};
+				o->lines[ln++] = ema_sam_line{mate, rec};
+			}
+			// statistics of the lines as print_sam_record will flag them (src/samrecord.c:104-175)
+			for (size_t i = line_base[g]; i < ln; ++i) {
+				const ema_sam_rec *rec = o->lines[i].rec, *mate = o->lines[i].mate;
+				++st.lines;
+				if (!rec) { ++st.unmapped_mates; continue; }
+				++st.mapped;
+				if (rec->duplicate) ++st.duplicates;
+				if (rec->n_alts) ++st.with_xa;
+				if (mate && rec->rev != mate->rev && rec->chrom_id == mate->chrom_id) {      // is_pair, src/align.c:27-40
+					const ema_sam_rec *r1 = rec, *r2 = mate;
+					if (r2->rev) { r1 = mate; r2 = rec; }
+					const int64_t d = (int64_t)(uint32_t)(r1->pos - r2->pos);      // two uint32_t: the difference wraps
+					if (kInsertMin <= d && d <= kInsertMax) ++st.proper;
+				}
+				const int gamma_mapq = rec->gamma <= 0.999999 ? (int)(-10 * std::log10(1 - rec->gamma)) : 60;
+				int q = gamma_mapq < rec->score_mapq ? gamma_mapq : rec->score_mapq;
+				q = q < rec->mapq ? q : rec->mapq;
+				q = q > 0 ? q : 0; q = q < 60 ? q : 60;
+				++st.mapq_hist[q == 0 ? 0 : q < 10 ? 1 : q < 20 ? 2 : q < 30 ? 3 : q < 40 ? 4 : q < 60 ? 5 : 6];
+			}
 		}
-		return &o->recs[n_recs++];
 	};
-	for (size_t g = 0; g < n_groups; ++g) {
-		const uint64_t r0 = a->pair_off[bk->group_off[g]];
-		for (uint32_t k = 0; k < S.n_sel[g]; ++k) {
-			const Sel s = S.sel[r0 + k];
-			const ema_sam_rec *rec = fill(s.rec, g, r0);
-			const ema_sam_rec *mate = s.mate != ~(uint64_t)0 ? fill(s.mate, g, r0) : nullptr;
-			o->lines[n_lines++] = ema_sam_line{rec, mate};
-			o->lines[n_lines++] = ema_sam_line{mate, rec};
-		}
+	{
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt_asm; ++t) th.emplace_back(assemble, t);
+		assemble(0);
+		for (auto &t : th) t.join();
 	}
-	o->n_recs = n_recs;
-	// statistics of the lines as print_sam_record will flag them (src/samrecord.c:104-175)
-	for (size_t i = 0; i < n_lines; ++i) {
-		const ema_sam_rec *rec = o->lines[i].rec, *mate = o->lines[i].mate;
-		++o->stats.lines;
-		if (!rec) { ++o->stats.unmapped_mates; continue; }
-		++o->stats.mapped;
-		if (rec->duplicate) ++o->stats.duplicates;
-		if (rec->n_alts) ++o->stats.with_xa;
-		if (mate && rec->rev != mate->rev && rec->chrom_id == mate->chrom_id) {      // is_pair, src/align.c:27-40
-			const ema_sam_rec *r1 = rec, *r2 = mate;
-			if (r2->rev) { r1 = mate; r2 = rec; }
-			const int64_t d = (int64_t)(uint32_t)(r1->pos - r2->pos);      // two uint32_t: the difference wraps
-			if (kInsertMin <= d && d <= kInsertMax) ++o->stats.proper;
-		}
-		const int gamma_mapq = rec->gamma <= 0.999999 ? (int)(-10 * std::log10(1 - rec->gamma)) : 60;
-		int q = gamma_mapq < rec->score_mapq ? gamma_mapq : rec->score_mapq;
-		q = q < rec->mapq ? q : rec->mapq;
-		q = q > 0 ? q : 0; q = q < 60 ? q : 60;
-		++o->stats.mapq_hist[q == 0 ? 0 : q < 10 ? 1 : q < 20 ? 2 : q < 30 ? 3 : q < 40 ? 4 : q < 60 ? 5 : 6];
+	for (const auto &ps : part) {
+		o->stats.lines += ps.lines; o->stats.mapped += ps.mapped; o->stats.unmapped_mates += ps.unmapped_mates; o->stats.proper += ps.proper;
+		o->stats.duplicates += ps.duplicates; o->stats.with_xa += ps.with_xa;
+		for (int i = 0; i < 7; ++i) o->stats.mapq_hist[i] += ps.mapq_hist[i];
 	}
+	const int rc = rc_all.load();
 	o->stats.select_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 	*out = o;
 	return rc;

@@ -247,17 +247,20 @@ int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opt
 	const int rc = format_parts(lines, n, opt, parts);
 	if (rc) return rc;
 	// an interrupted or momentarily refused write is retried; on a real failure *n_bytes says how much text is on the fd
+	// (a descriptor that stays unwritable for 120 polls of one second in a row is a failure too: EMA_EIO, not a hang)
 	size_t total = 0;
+	int refused = 0;
 	for (const Out &o : parts) {
 		size_t at = 0;
 		while (at < o.n) {
 			const ssize_t w = write(fd, o.buf.data() + at, o.n - at);
 			if (w < 0 && errno == EINTR) continue;
-			if (w < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {
+			if (w < 0 && (errno == EAGAIN || errno == EWOULDBLOCK) && ++refused <= 120) {
 				struct pollfd pf; pf.fd = fd; pf.events = POLLOUT; pf.revents = 0;
 				(void)poll(&pf, 1, 1000);
 				continue;
 			}
+			if (w > 0) refused = 0;
 			if (w <= 0) { if (n_bytes) *n_bytes = total + at; return EMA_EIO; }
 			at += (size_t)w;
 		}

@@ -524,9 +524,12 @@ int ema_stream_batches(ema_engine_t *e, const char *const *bases, const uint32_t
 }
 
 namespace {
-// ema_stream_sam's sink: clouds / EM / duplicates on the calling thread, the formatter + write of the bucket before on a
-// writer thread (the lines point into the bucket, the batch and the selection, so the sink takes those over from the stream
-// and the writer frees them).
+// ema_stream_sam's sink hands every bucket to a three-stage host pipeline of its own, so that the engine thread goes straight back to
+// fetching the next pass: clouds / EM / duplicates on a cloud thread (one bucket at a time, in order: the cloud counter of an -x run
+// runs on from bucket to bucket; barcode groups on the host's threads inside), then the formatter + write on a writer thread.  The
+// lines point into the bucket, the batch and the selection, so the sink takes those over from the stream and the writer frees them.
+// (Round 2 ran the cloud stage inside the sink, on the engine thread: 78 of the ~130 ms a 262 K-pair bucket spent there.)
+struct CloudJob { size_t k; ema_bucket *bk; ema_batch_out *b; ema_aln_out *a; };
 struct WriteJob { size_t k; ema_clouds_out *sel; ema_bucket *bk; ema_batch_out *b; ema_aln_out *a; };
 struct SamSink {
 	ema_engine_t *e;
@@ -539,10 +542,19 @@ struct SamSink {
 	Stream *stream = nullptr;
 	std::mutex mu;
 	std::condition_variable cv;
+	std::deque<CloudJob> cloud_jobs;
 	std::deque<WriteJob> jobs;
-	bool closing = false;
-	int write_rc = EMA_OK;
+	bool closing = false, clouds_done = false;
+	int write_rc = EMA_OK, cloud_rc = EMA_OK;
 };
+
+void free_job(ema_clouds_out *sel, ema_bucket *bk, ema_batch_out *b, ema_aln_out *a)
+{
+	if (sel) ema_clouds_free(sel);
+	if (a) ema_aln_free(a);
+	if (b) ema_batch_free(b);
+	if (bk) ema_bucket_free(bk);
+}
 
 void sam_writer(SamSink &S)
 {
@@ -550,7 +562,7 @@ void sam_writer(SamSink &S)
 		WriteJob j;
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
-			S.cv.wait(lk, [&] { return S.closing || !S.jobs.empty(); });
+			S.cv.wait(lk, [&] { return S.clouds_done || !S.jobs.empty(); });
 			if (S.jobs.empty()) return;
 			j = S.jobs.front();
 		}
@@ -559,10 +571,7 @@ void sam_writer(SamSink &S)
 		int rc = EMA_OK;
 		if (S.write_rc == EMA_OK) rc = ema_sam_write(S.fd, j.sel->lines, j.sel->n_lines, &S.o.sam, &n_bytes);
 		if (S.sstats) S.sstats[j.k].write_s = now_s() - t0;
-		ema_clouds_free(j.sel);
-		if (j.a) ema_aln_free(j.a);
-		if (j.b) ema_batch_free(j.b);
-		if (j.bk) ema_bucket_free(j.bk);
+		free_job(j.sel, j.bk, j.b, j.a);
 		{
 			std::lock_guard<std::mutex> lk(S.mu);
 			if (rc != EMA_OK && S.write_rc == EMA_OK) S.write_rc = rc;
@@ -572,24 +581,55 @@ void sam_writer(SamSink &S)
 	}
 }
 
+void sam_clouds(SamSink &S)
+{
+	for (;;) {
+		CloudJob c;
+		{
+			std::unique_lock<std::mutex> lk(S.mu);
+			S.cv.wait(lk, [&] { return S.closing || !S.cloud_jobs.empty(); });
+			if (S.cloud_jobs.empty()) { S.clouds_done = true; lk.unlock(); S.cv.notify_all(); return; }
+			c = S.cloud_jobs.front();
+		}
+		ema_clouds_out *sel = nullptr;
+		int rc = S.cloud_rc != EMA_OK || S.write_rc != EMA_OK ? EMA_ESTATE : EMA_OK;      // after a failure: drain, freeing what arrives
+		if (rc == EMA_OK) {
+			ema_cloud_opts co = S.o.clouds;
+			if (S.o.continue_cloud_ids) co.first_cloud_id = S.next_cloud_id;
+			rc = ema_clouds_select(c.bk, c.b, c.a, S.names.data(), (int32_t)S.names.size(), &co, &sel);
+			if (rc == EMA_OK) {
+				S.next_cloud_id = sel->next_cloud_id;
+				if (S.sstats) S.sstats[c.k] = sel->stats;
+			}
+		}
+		std::unique_lock<std::mutex> lk(S.mu);
+		if (rc != EMA_OK) {
+			if (S.cloud_rc == EMA_OK && S.write_rc == EMA_OK) { S.cloud_rc = rc; S.err = "ema_clouds_select failed"; }
+			S.cloud_jobs.pop_front();
+			lk.unlock();
+			free_job(sel, c.bk, c.b, c.a);
+			S.cv.notify_all();
+			continue;
+		}
+		S.cv.wait(lk, [&] { return S.jobs.size() < 2; });      // at most two buckets' worth of objects wait for the writer
+		S.jobs.push_back(WriteJob{c.k, sel, c.bk, c.b, c.a});
+		S.cloud_jobs.pop_front();
+		lk.unlock();
+		S.cv.notify_all();
+	}
+}
+
 int sam_sink(void *user, size_t k, const ema_bucket *bk, const ema_batch_out *b, const ema_aln_out *a)
 {
 	SamSink &S = *(SamSink *)user;
-	ema_cloud_opts co = S.o.clouds;
-	if (S.o.continue_cloud_ids) co.first_cloud_id = S.next_cloud_id;
-	ema_clouds_out *sel = nullptr;
-	int rc = ema_clouds_select(bk, b, a, S.names.data(), (int32_t)S.names.size(), &co, &sel);
-	if (rc != EMA_OK) { S.err = "ema_clouds_select failed"; if (sel) ema_clouds_free(sel); return rc; }
-	S.next_cloud_id = sel->next_cloud_id;
-	if (S.sstats) S.sstats[k] = sel->stats;
-	{
-		std::unique_lock<std::mutex> lk(S.mu);
-		S.cv.wait(lk, [&] { return S.jobs.size() < 2; });      // at most two buckets' worth of objects wait for the writer
-		if (S.write_rc != EMA_OK) { lk.unlock(); ema_clouds_free(sel); S.err = "ema_sam_write failed"; return S.write_rc; }
-		S.jobs.push_back(WriteJob{k, sel, const_cast<ema_bucket *>(bk), const_cast<ema_batch_out *>(b), const_cast<ema_aln_out *>(a)});
-	}
+	std::unique_lock<std::mutex> lk(S.mu);
+	S.cv.wait(lk, [&] { return S.cloud_jobs.size() < 2; });      // at most two buckets wait for the cloud stage
+	if (S.cloud_rc != EMA_OK) return S.cloud_rc;
+	if (S.write_rc != EMA_OK) { S.err = "ema_sam_write failed"; return S.write_rc; }
+	S.cloud_jobs.push_back(CloudJob{k, const_cast<ema_bucket *>(bk), const_cast<ema_batch_out *>(b), const_cast<ema_aln_out *>(a)});
+	lk.unlock();
 	S.cv.notify_all();
-	S.stream->sink_kept = true;      // the writer frees them
+	S.stream->sink_kept = true;      // the pipeline frees them
 	return 0;
 }
 }  // namespace
@@ -640,13 +680,16 @@ int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const em
 	for (auto &it : T.items) memset(&it.st, 0, sizeof(it.st));
 	S.stream = &T;
 	std::thread writer(sam_writer, std::ref(S));
+	std::thread clouder(sam_clouds, std::ref(S));
 	int rc = run_stream(e, T, sam_sink, &S, bstats);
 	{
 		std::lock_guard<std::mutex> lk(S.mu);
 		S.closing = true;
 	}
 	S.cv.notify_all();
+	clouder.join();
 	writer.join();
+	if (rc == EMA_OK && S.cloud_rc != EMA_OK) rc = S.cloud_rc;
 	if (rc == EMA_OK && S.write_rc != EMA_OK) { rc = S.write_rc; S.err = "ema_sam_write failed"; }
 	if (rc != EMA_OK && !S.err.empty()) g_err = S.err;
 	return rc;

@@ -73,3 +73,16 @@ def test_gpus_flag_without_a_launcher_spawns_the_ranks(tmp_path):
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and "launching" in p.stderr
+
+
+def test_host_threads_are_partitioned_over_the_ranks_of_a_node():
+    """N ranks share the CPUs the node grants the job: never more host threads in total than CPUs (round 2's floor of 4 per rank
+    put 32 threads on 19 CPUs at 8 ranks), at least one each."""
+    import bench
+    for cpus in (8, 16, 19, 64, 192):
+        for world in (1, 2, 4, 8):
+            t = bench.host_threads_for_rank(cpus, world)
+            assert 1 <= t <= 32
+            assert t * world <= max(cpus, world)
+    assert bench.host_threads_for_rank(19, 8) == 2 and bench.host_threads_for_rank(19, 1) == 19 and bench.host_threads_for_rank(256, 2) == 32
+    assert 1 <= bench.cpus_granted() <= (os.cpu_count() or 1)

@@ -60,11 +60,32 @@ __device__ __forceinline__ int ema_clamp_window(const DevIndex &ix, int64_t &beg
 	end = end < far_end ? end : far_end;
 	return rid;
 }
-// wave-cooperative copy of reference [beg, end) (one strand, already clamped) into dst as nt4 bytes
+// wave-cooperative copy of reference [beg, end) (one strand, already clamped) into dst as nt4 bytes.
+// Every lane takes whole 4-byte words of the packed reference (16 bases each): ONE round trip to memory per 1024 bases of window.
+// (Until round 3 every lane fetched its bases one byte-load at a time, l = lane, lane + 64, ...: a 450-base extension window was
+// seven dependent round trips, a 700-base rescue window eleven -- at loaded-memory latency that was the largest single wait of
+// K2's per-chain set-up and of K3.)
 __device__ __forceinline__ void ema_wave_fetch(const DevIndex &ix, int64_t beg, int64_t end, uint8_t *dst)
 {
 	const int n = (int)(end - beg);
-	for (int l = (int)ema_lane(); l < n; l += EMA_WAVE) dst[l] = (uint8_t)ema_ref_base(ix, beg + l);
+	if (n > 0) {
+		const bool rev = beg >= ix.l_pac;
+		const int64_t f_lo = rev ? (ix.l_pac << 1) - end : beg;      // the window on the forward strand: [f_lo, f_lo + n)
+		const int64_t w0 = (f_lo >> 2) & ~(int64_t)3;                // its first byte, rounded down to a word
+		const int shift = (int)(f_lo - (w0 << 2));                   // 0..15: where f_lo sits in that word
+		const int n_dw = (shift + n + 15) >> 4;
+		for (int d = (int)ema_lane(); d < n_dw; d += EMA_WAVE) {
+			const uint32_t w = *reinterpret_cast<const uint32_t *>(ix.pac + w0 + 4 * (int64_t)d);      // (the packed array is padded by 8 bytes)
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int o = 16 * d + i - shift;       // index along the forward strand
+				if (o >= 0 && o < n) {
+					const int code = (int)(w >> (8 * (i >> 2) + ((~i & 3) << 1))) & 3;      // byte i / 4 of the word, first base in the high bits
+					dst[rev ? n - 1 - o : o] = (uint8_t)(rev ? 3 - code : code);
+				}
+			}
+		}
+	}
 	ema_wave_sync();
 }
 

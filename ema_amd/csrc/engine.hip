@@ -71,7 +71,8 @@ extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int scor
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *qpack, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
                                  DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, int *kdone, int *todo, int *n_todo,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg);
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
+                                 const HeavyCtl *heavy, int *heavy_counters, unsigned long long *arena_used, int min_regions);
 extern "C" void ema_launch_collect(int n_pairs, int first_pair, int *status, int *count, int *map, int cap, hipStream_t stream);
 extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *status, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
@@ -271,6 +272,7 @@ struct ema_engine {
 	bool split_handed = true;            // EMA_SPLIT_HANDED=0: one K2b launch for everything on K2a's list
 	int align_wps = 4;                   // EMA_ALIGN_WPS=3: K2b built for three blocks per CU (measurement)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
+	int heavy_regions = 8;               // K4b sets a read with at least this many regions left aside for K4t / K4r (0: never)
 	int heavy_chains = 32;               // EMA_HEAVY_CHAINS: K2b sets a read with at least this many chains to extend aside for K2c / K2d (0: never)
 	int align_mid_blocks = 0;
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
@@ -317,8 +319,9 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
 	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
-	HIPCHK(e, s.d_counters.alloc(32));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts
+	HIPCHK(e, s.d_counters.alloc(48));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts
 	                                        // [26] reads set aside, [27] their chain tasks, [28..29] work queues of K2c, K2d, [30..31] arena bytes used (u64)
+	                                        // [32..35] K4: reads set aside, their region tasks, work queues of K4t, K4r; [36..37] CIGAR operations taken from the arena (u64)
 	if (e->heavy_chains > 0) {
 		// room: a record is ~0.2 KB per chain; a lean slice sets ~2 % of its reads aside (~100 chains each), the full-capacity
 		// tier possibly all of its reads.  Whatever does not fit is extended by K2b itself.
@@ -766,7 +769,7 @@ static Work work_of(ema_engine *e, const Slice &s, bool listed)
 static int run_seed(ema_engine *e, Slice &s, const Work &w)
 {
 	HIPCHK(e, hipMemsetAsync(s.d_status.p, 0, (size_t)w.n_pairs * 2 * 4, s.stream));
-	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 32 * 4, s.stream));
+	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 48 * 4, s.stream));
 	if (&s == &e->full && e->wave_seed) {      // the long reads: one wavefront each (k_seed_wave.hip)
 		ema_launch_seed_wave((const DevIndex *)e->d_k1w_args.p, (const DevOpts *)(e->d_k1w_args.p + ((sizeof(DevIndex) + 15) & ~(size_t)15)), w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
 		                     s.d_counters.p + 3, e->seed_wave_blocks, s.stream);
@@ -851,9 +854,17 @@ static int run_pair(ema_engine *e, Slice &s, const Work &w)
 
 static int run_final(ema_engine *e, Slice &s, const Work &w)
 {
+	// reads with many regions left for K4b are set aside into per-region tasks (k_final.hip: K4t / K4r), on K2's lists and arena
+	HeavyCtl hv;
+	memset(&hv, 0, sizeof(hv));
+	if (s.d_heavy.p) {
+		hv.arena = s.d_heavy.p; hv.arena_bytes = s.d_heavy.n; hv.reads = s.d_heavy_reads.p; hv.tasks = s.d_heavy_tasks.p;
+		hv.reads_cap = (int)s.d_heavy_reads.n; hv.tasks_cap = (int)s.d_heavy_tasks.n;
+	}
 	ema_launch_final(&e->dix, &s.dopts, e->cur_bases, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_alns.p,
 	                 s.d_cigars.p, s.d_cig_n.p, s.dopts.cig_cap, s.d_status.p, s.d_kdone.p, s.d_todo.p, s.d_counters.p + 20, s.d_slabs.p,
-	                 s.d_counters.p + 2, e->final_blocks, s.stream, s.dbg);
+	                 s.d_counters.p + 2, e->final_blocks, s.stream, s.dbg, s.d_heavy.p ? &hv : nullptr, s.d_counters.p + 32,
+	                 reinterpret_cast<unsigned long long *>(s.d_counters.p + 36), e->heavy_regions);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_final");
 	return EMA_OK;
@@ -1255,7 +1266,7 @@ int ema_engine_debug_final(ema_engine_t *e, const char *read, int l_read, const 
 	const Work w = work_of(e, f, false);
 	const int n2[2] = {n_regs, 0};
 	HIPCHK(e, hipMemsetAsync(f.d_status.p, 0, 2 * 4, f.stream));
-	HIPCHK(e, hipMemsetAsync(f.d_counters.p, 0, 32 * 4, f.stream));
+	HIPCHK(e, hipMemsetAsync(f.d_counters.p, 0, 48 * 4, f.stream));
 	HIPCHK(e, hipMemcpyAsync(f.d_n_regs.p, n2, 8, hipMemcpyHostToDevice, f.stream));
 	HIPCHK(e, hipMemcpyAsync(f.d_regs.p, regs, (size_t)n_regs * sizeof(DevReg), hipMemcpyHostToDevice, f.stream));
 	if ((rc = run_final(e, f, w))) return rc;

@@ -341,18 +341,23 @@ void async_engine_thread(Stream &S, AsyncState &A)
 			have_tm = ema_engine_last_timing(g, &tm) == EMA_OK;
 		}
 		const double t_f1 = now_s();
-		size_t p0 = 0;
-		for (size_t j = 0; j < ps.len; ++j) {
+		// the buckets of a shared pass are cut out of the fetched batch and run through the append stage side by side, one thread
+		// each (round 2 did them one after another on this thread: 0.35 us a pair, most of it first-touch page faults of the
+		// buckets' own arrays -- the engine thread spent more time here than waiting for the GPU, r03e)
+		std::vector<size_t> first_pair(ps.len + 1, 0);
+		for (size_t j = 0; j < ps.len; ++j) first_pair[j + 1] = first_pair[j] + S.items[ps.first + j].n_pairs;
+		const bool fetched = ticket[p_fetch] >= 0;
+		const double t_q = t_queued[p_fetch];
+		auto one = [&](size_t j) {
 			Item &it = S.items[ps.first + j];
-			if (ticket[p_fetch] >= 0) {
+			if (fetched) {
 				it.rc = rc; it.err = err;
 				if (have_tm) {
 					it.st.seed_ms = tm.seed_ms; it.st.extend_ms = tm.extend_ms; it.st.rescue_ms = tm.rescue_ms; it.st.final_ms = tm.final_ms;
 					it.st.full_tier_ms = tm.full_tier_ms;
 				}
-				if (b && ps.len == 1) { it.b = b; b = nullptr; }
-				else if (b) {
-					it.b = slice_batch(b, p0, it.n_pairs);
+				if (b && ps.len > 1) {
+					it.b = slice_batch(b, first_pair[j], it.n_pairs);
 					if (!it.b) { it.rc = EMA_EDEVICE; it.err = "out of host memory cutting a batch into its buckets"; }
 					else if (rc == EMA_ELIMIT) {      // the capacity flag is the batch's: does this bucket hold a flagged read?
 						int32_t flags = 0;
@@ -361,9 +366,15 @@ void async_engine_thread(Stream &S, AsyncState &A)
 					}
 				}
 			}
-			p0 += it.n_pairs;
-			finish_item(S, it, t_queued[p_fetch]);
-		}
+			finish_item(S, it, t_q);
+		};
+		if (fetched && b && ps.len == 1) { S.items[ps.first].b = b; b = nullptr; }
+		if (ps.len > 1 && fetched && b) {
+			std::vector<std::thread> cutters;
+			for (size_t j = 1; j < ps.len; ++j) cutters.emplace_back(one, j);
+			one(0);
+			for (auto &t : cutters) t.join();
+		} else for (size_t j = 0; j < ps.len; ++j) one(j);
 		if (b) ema_batch_free(b);
 		(void)head;
 		if (S.trace) fprintf(stderr, "[stream] engine thread: pass %zu queued at %.3f, fetch %.3f..%.3f, cut + append stage done by %.3f\n", p_fetch,

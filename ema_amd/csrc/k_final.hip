@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include "dev_regions.hpp"
 #include "ema_engine.h"
+#include <algorithm>
+#include <cstring>
 
 #define EMA_Z_BYTES ((size_t)256 * (EMA_RSEQ_CAP + 8))
 #define EMA_FINAL_SLAB_BYTES (EMA_Z_BYTES + 4096 * 4 + 1024)
@@ -129,15 +131,37 @@ ema_k_final_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 	if (k < nr) todo[atomicAdd(n_todo, 1)] = read;
 }
 
-// K4b: the regions K4a left (one wavefront per read of its todo list).
+// Reads with many regions left for K4b (a read inside a repeat family in the full-capacity tier: hundreds of global alignments)
+// are one long serial job for the wavefront that owns them and set the length of the launch (full tier, r02: K4 43 of 105 ms).
+// Their regions are independent up to WHERE in the read's CIGAR pool each one's operations go, so K4b sets such a read aside:
+//   K4t (ema_k_final_t<1>): one wavefront per (read, region) task runs the region's alignment and leaves position, strand, NM and
+//        the finished CIGAR (squeezed, clipped) in a result record + operations taken from an arena;
+//   K4r (ema_k_final_t<2>): one wavefront per read lays the results into the pool in region order -- the same pool offsets, the
+//        same capacity flags as the in-order loop.
+// The lists and the arena are K2's (dev_types.h, HeavyCtl: idle while K4 runs); whatever does not fit is done in place.
+struct FinalHeavy {
+	uint8_t *arena;                    // null: nothing is set aside.  [0, tasks_cap x 48): result records; then CIGAR operations
+	unsigned long long arena_bytes;
+	unsigned long long *arena_used;    // bump allocator of the operations (zero on entry), relative to ops_base
+	unsigned long long ops_base;       // = tasks_cap x 48
+	unsigned long long *reads;         // read | first task << 32
+	unsigned long long *tasks;         // read << 32 | region
+	int *n_reads, *n_tasks;
+	int reads_cap, tasks_cap;
+	int min_regions;                   // a read with at least this many regions left is set aside
+};
+struct FinalRes { DevAln aln; int32_t st, n_final; unsigned long long ops_at; int64_t pad_; };      // 48 bytes
+
+// K4b: the regions K4a left (one wavefront per read of its todo list).  MODE 0: that; 1: K4t; 2: K4r (above).
 // alns: n_reads x opt.reg_cap; cigars: n_reads x cig_cap ops (pool per read, regions in order)
+template <int MODE>
 __global__ void __launch_bounds__(256)
-ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
+ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
             uint32_t *__restrict__ cigars, int *__restrict__ cig_n, int cig_cap, int *__restrict__ status,
             const int *__restrict__ k_done, const int *__restrict__ todo, const int *__restrict__ n_todo,
-            uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg)
+            uint8_t *__restrict__ slabs, int *__restrict__ counter, int *dbg, FinalHeavy fh)
 {
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][256];
@@ -149,24 +173,83 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 	uint32_t *ctmp = (uint32_t *)(z + EMA_Z_BYTES);
 	uint8_t *query = lds_q[wib], *rseq = lds_r[wib];
 	const int64_t l_pac = ix.l_pac;
+	FinalRes *res = reinterpret_cast<FinalRes *>(fh.arena);
 
 	for (;;) {
 		int read = 0;
 		if (lane == 0) read = atomicAdd(counter, 1);
 		read = ema_uni(__shfl(read, 0));
-		if (read >= *n_todo) break;
-		read = ema_uni(todo[read]);
+		int task = -1, task_k = 0, first_task = 0;
+		if (MODE == 1) {
+			if (read >= ema_uni(*fh.n_tasks) || read >= fh.tasks_cap) break;
+			task = read;
+			const unsigned long long t = ema_uni((uint64_t)fh.tasks[task]);
+			if (t == ~0ULL) continue;      // a claim K4b gave back
+			read = (int)(t >> 32); task_k = (int)(uint32_t)t;
+		} else if (MODE == 2) {
+			if (read >= ema_uni(*fh.n_reads) || read >= fh.reads_cap) break;
+			const unsigned long long t = ema_uni((uint64_t)fh.reads[read]);
+			if (t == ~0ULL) continue;
+			read = (int)(uint32_t)t; first_task = (int)(t >> 32);
+		} else {
+			if (read >= *n_todo) break;
+			read = ema_uni(todo[read]);
+		}
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		const int in_read = ema_uni(ema_in_read(map, read));
 		const int l_query = (int)(off[in_read + 1] - off[in_read]);
 		const int nr = ema_uni(n_regs[read]);
-		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
-		ema_wave_sync();
+		const int k0 = ema_uni(k_done[read]);
+		if (MODE == 0 && fh.arena && nr - k0 >= fh.min_regions) {      // set aside: a place on the read list, tasks for its regions -- or done here after all
+			long long ri = -1, tb = -1;
+			if (lane == 0) {
+				ri = atomicAdd(fh.n_reads, 1);
+				if (ri >= fh.reads_cap) ri = -1;
+				if (ri >= 0) {
+					tb = atomicAdd(fh.n_tasks, nr - k0);
+					if (tb + (nr - k0) > fh.tasks_cap) {
+						for (long long j = tb; j < fh.tasks_cap && j < tb + (nr - k0); ++j) fh.tasks[j] = ~0ULL;
+						tb = -1;
+					}
+					fh.reads[ri] = tb >= 0 ? ((unsigned long long)(uint32_t)read | (unsigned long long)tb << 32) : ~0ULL;
+				}
+			}
+			tb = (long long)ema_uni((int64_t)__shfl(tb, 0));
+			if (tb >= 0) {
+				for (int k = k0 + lane; k < nr; k += EMA_WAVE) fh.tasks[tb + (k - k0)] = (unsigned long long)(uint32_t)read << 32 | (uint32_t)k;
+				EMA_DBG(9, -(nr - k0));
+				continue;
+			}
+		}
+		if (MODE != 2) {
+			for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
+			ema_wave_sync();
+		}
 		uint32_t *pool = cigars + (size_t)read * cig_cap;
-		int pool_n = ema_uni(cig_n[read]), st = 0;
-		for (int k = ema_uni(k_done[read]); k < nr; ++k) {
+		int pool_n = MODE == 1 ? 0 : ema_uni(cig_n[read]), st = 0;
+		for (int k = MODE == 1 ? task_k : k0; k < (MODE == 1 ? task_k + 1 : nr); ++k) {
 			EMA_DBG(2, k);
+			if (MODE == 2) {      // K4r: the region's result as K4t left it, placed at the pool's fill
+				const FinalRes *rp = res + (first_task + (k - k0));
+				DevAln out = rp->aln;
+				out.pos = ema_uni(out.pos); out.is_rev = ema_uni(out.is_rev); out.NM = ema_uni(out.NM);
+				const int n_final = ema_uni(rp->n_final);
+				const unsigned long long at = ema_uni((uint64_t)rp->ops_at);
+				st |= ema_uni(rp->st);
+				out.n_cigar = 0; out.cigar_off = (uint32_t)pool_n;
+				if (n_final > 0) {
+					if (pool_n + n_final > cig_cap) st |= EMA_ST_CIGAR_OVERFLOW;
+					else {
+						const uint32_t *src = reinterpret_cast<const uint32_t *>(fh.arena + at);
+						for (int i = lane; i < n_final; i += EMA_WAVE) pool[pool_n + i] = src[i];
+						out.n_cigar = n_final;
+						pool_n += n_final;
+					}
+				}
+				if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out;
+				continue;
+			}
 			const DevReg ar = ema_uni(regs[(size_t)read * opt.reg_cap + k]);
 			DevAln out;
 			out.pos = -1; out.is_rev = 0; out.NM = -1; out.n_cigar = 0; out.cigar_off = (uint32_t)pool_n;
@@ -175,7 +258,12 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			const bool rev = rb >= l_pac;
 			const int rlen = (int)(re - rb);
 			const bool ok = lq > 0 && rb < re && !(rb < l_pac && re > l_pac) && rb >= 0 && re <= l_pac << 1 && rlen <= EMA_RSEQ_CAP;
-			if (!ok) { if (rlen > EMA_RSEQ_CAP) st |= EMA_ST_RSEQ_OVERFLOW; if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out; continue; }
+			if (!ok) {
+				if (rlen > EMA_RSEQ_CAP) st |= EMA_ST_RSEQ_OVERFLOW;
+				if (MODE == 1) { if (lane == 0) { FinalRes r; r.aln = out; r.st = st; r.n_final = 0; r.ops_at = 0; r.pad_ = 0; res[task] = r; } }
+				else if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out;
+				continue;
+			}
 			ema_wave_fetch(ix, rb, re, rseq);
 			// reversed views so that indels are left-aligned on the forward strand (bwa_gen_cigar2)
 			const EmaSeq qs{rev ? query + qe - 1 : query + qb, rev ? -1 : 1};
@@ -244,23 +332,34 @@ ema_k_final(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const u
 			}
 			const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
 			const int n_final = (clip5 ? 1 : 0) + (hi - lo) + (clip3 ? 1 : 0);
-			if (pool_n + n_final > cig_cap) { st |= EMA_ST_CIGAR_OVERFLOW; }
-			else {
+			uint32_t *dst = nullptr;
+			unsigned long long ops_at = 0;
+			if (MODE == 1) {      // K4t: room for the operations from the arena; K4r applies the pool's capacity
+				long long at = -1;
+				if (lane == 0) {
+					at = (long long)(fh.ops_base + atomicAdd(fh.arena_used, (unsigned long long)n_final * 4));
+					if ((unsigned long long)at + (unsigned long long)n_final * 4 > fh.arena_bytes) at = -1;
+				}
+				at = (long long)ema_uni((int64_t)__shfl(at, 0));
+				if (at < 0) st |= EMA_ST_CIGAR_OVERFLOW;
+				else { dst = reinterpret_cast<uint32_t *>(fh.arena + at); ops_at = (unsigned long long)at; }
+			} else if (pool_n + n_final > cig_cap) { st |= EMA_ST_CIGAR_OVERFLOW; }
+			else dst = pool + pool_n;
+			if (dst) {
 				ema_wave_sync();
-				uint32_t *dst = pool + pool_n;
 				if (lane == 0 && clip5) dst[0] = (uint32_t)clip5 << 4 | 3;
 				const int o5 = clip5 ? 1 : 0;
 				for (int i = lane; i < hi - lo; i += EMA_WAVE) dst[o5 + i] = ctmp[lo + i];
 				if (lane == 0 && clip3) dst[o5 + hi - lo] = (uint32_t)clip3 << 4 | 3;
-				out.n_cigar = n_final;
-				pool_n += n_final;
+				if (MODE != 1) { out.n_cigar = n_final; pool_n += n_final; }
 			}
 			const int rid = ema_pos2rid(ix, pos);
 			out.pos = rid >= 0 ? pos - ix.ctg_off[rid] : pos;
-			if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out;
+			if (MODE == 1) { if (lane == 0) { FinalRes r; r.aln = out; r.st = st; r.n_final = dst ? n_final : 0; r.ops_at = ops_at; r.pad_ = 0; res[task] = r; } }
+			else if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out;
 			ema_wave_sync();
 		}
-		if (lane == 0) { cig_n[read] = pool_n; if (st) atomicOr(status + read, st); }
+		if (MODE != 1 && lane == 0) { cig_n[read] = pool_n; if (st) atomicOr(status + read, st); }
 		EMA_DBG(9, 0);
 	}
 #undef EMA_DBG
@@ -325,16 +424,36 @@ extern "C" size_t ema_final_slab_bytes() { return EMA_FINAL_SLAB_BYTES; }
 
 // K4 = K4a (gap-free regions, one lane per read) then K4b (the rest, one wavefront per read).  kdone / todo: n_reads ints
 // each; n_todo: one int, zero on entry.
+// heavy (may be null: nothing is set aside): K2's lists and arena (dev_types.h, HeavyCtl), idle while K4 runs; heavy_counters: five
+// ints, zero on entry {reads set aside, their tasks, work queues of K4t and K4r} and arena_used: the operations' cursor (u64, zero on entry)
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *qpack, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
                                  DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, int *kdone, int *todo, int *n_todo,
-                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg)
+                                 uint8_t *slabs, int *counter, int n_blocks, hipStream_t stream, int *dbg,
+                                 const HeavyCtl *heavy, int *heavy_counters, unsigned long long *arena_used, int min_regions)
 {
 	if (n_reads <= 0) return;
+	FinalHeavy fh;
+	memset(&fh, 0, sizeof(fh));
+	fh.min_regions = 1 << 30;
+	if (heavy && heavy->arena && min_regions > 0) {
+		fh.arena = heavy->arena; fh.arena_bytes = heavy->arena_bytes; fh.arena_used = arena_used;
+		fh.reads = heavy->reads; fh.tasks = heavy->tasks; fh.reads_cap = heavy->reads_cap;
+		fh.tasks_cap = (int)std::min<unsigned long long>((unsigned long long)heavy->tasks_cap, heavy->arena_bytes / 2 / sizeof(FinalRes));
+		fh.n_reads = heavy_counters; fh.n_tasks = heavy_counters + 1;
+		fh.min_regions = min_regions;
+		fh.ops_base = (unsigned long long)fh.tasks_cap * sizeof(FinalRes);      // the operations follow the result records
+	}
 	hipLaunchKernelGGL(ema_k_final_simple, dim3((n_reads + 255) / 256), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map,
 	                   regs, n_regs, alns, cigars, cig_n, cig_cap, status, kdone, todo, n_todo);
-	hipLaunchKernelGGL(ema_k_final, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, regs, n_regs, alns,
-	                   cigars, cig_n, cig_cap, status, kdone, todo, n_todo, slabs, counter, dbg);
+	hipLaunchKernelGGL(ema_k_final_t<0>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, regs, n_regs, alns,
+	                   cigars, cig_n, cig_cap, status, kdone, todo, n_todo, slabs, counter, dbg, fh);
+	if (fh.arena) {
+		hipLaunchKernelGGL(ema_k_final_t<1>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, regs, n_regs, alns,
+		                   cigars, cig_n, cig_cap, status, kdone, todo, n_todo, slabs, heavy_counters + 2, dbg, fh);
+		hipLaunchKernelGGL(ema_k_final_t<2>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, regs, n_regs, alns,
+		                   cigars, cig_n, cig_cap, status, kdone, todo, n_todo, slabs, heavy_counters + 3, dbg, fh);
+	}
 }
 
 extern "C" size_t ema_sizeof_aln() { return sizeof(DevAln); }
@@ -351,6 +470,6 @@ extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *
 extern "C" int ema_final_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_final, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_final_t<0>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

@@ -31,8 +31,8 @@
 // read index and the next row's list grows over the current one (bwa swaps two vectors).  B is where the traffic is (a
 // search's backward phase reads and writes ~100 entries, its forward phase ~17), and B's first EMA_SEED_LDS_LIST entries live in
 // LDS as 16-byte entries {k: 40 bit, end: 8, size: 40, aux: 40 = the string's code in table mode, k' otherwise}: no memory
-// request, no tick of latency.  Entries beyond that (rows of more than 14 intervals: a few per cent) go to the slab as before.
-// (Round 2 kept both lists in the slab: 0.3 G of K1's 1.3 G requests per series and 10.8 GB of writes)
+// request, no tick of latency; entries beyond that go to the slab.  EMA_SEED_LDS_LIST = 0 (the product build, see below why) keeps
+// all of B in the slab.
 // (Earlier forms: one read per 8-lane group sharing each block load -- the 8 lanes replayed the whole control
 // program, ~10 M reads/s; one read per lane with per-state code that stored/pushed at a dozen inlined sites --
 // every tick walked ~1500 vector instructions, 189 VGPRs.)
@@ -57,12 +57,20 @@ enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, 
 
 // A machine taken off its lane (see "re-packing" below): everything phase B and the next step need.  The working
 // lists stay where they are -- `wl` is the address of the lane's list slab -- and the read is re-staged from qpack.
+// Entries of list B kept in LDS.  MEASURED (r03c, default workload): with 14 (80 KB of LDS per block, two blocks per CU) K1 on its own
+// takes 48.2 ms per slice against 48.3 ms with every entry in the slab -- the list requests were never what the memory system was
+// short of (they are lane-interleaved runs that hit the caches; the bound is the random 32-byte gathers from the 6 GB rank
+// structure + table) -- while beside the other slices' kernels it takes 131 ms instead of 90: two such blocks own a CU's whole LDS,
+// no K2-K4 block can share the CU, and the timed steps lose 10 %.  So the product keeps list B in the slab (0) and only the
+// in-place compaction (one list where bwa swaps two: half the footprint); the LDS path stays compiled and is exercised through the
+// host interpreter with 3 and 14 (tools/emu_seed.py).
 #ifndef EMA_SEED_LDS_LIST
-#define EMA_SEED_LDS_LIST 14      // 64 B of read codes + 32 B of N mask + 14 x 16 B per lane = 80 KB per 256 lanes: two blocks per CU
+#define EMA_SEED_LDS_LIST 0
 #endif
+#define EMA_SEED_LDS_ROOM (EMA_SEED_LDS_LIST > 0 ? EMA_SEED_LDS_LIST : 1)
 struct SeedPark {
 	uint64_t last_curr_size, c0, c1, c2, f0, f1, f2, ld_at, wl;
-	uint64_t b_lds[EMA_SEED_LDS_LIST][2];      // list B's LDS entries
+	uint64_t b_lds[EMA_SEED_LDS_ROOM][2];      // list B's LDS entries
 	int32_t pc, pass, len, read, x, sm_x, min_intv, i, j, n_prev, n_curr, rev, pad_, n_mem_call, last_mem_start;
 	int32_t n_out, old_n, k2, st, req_c, ld_kind, has_req, n_ext;
 	uint32_t c_end, f_end;
@@ -97,7 +105,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
 	__shared__ uint32_t lds_n[4][8 * 64];       // N mask, 8 words per lane
-	__shared__ uint4 lds_b[4][EMA_SEED_LDS_LIST * 64];      // list B's first entries, entry e of a lane at [(e << 6) + lane]
+	__shared__ uint4 lds_b[4][EMA_SEED_LDS_ROOM * 64];      // list B's first entries, entry e of a lane at [(e << 6) + lane]
 	const int lane = (int)(threadIdx.x & 63), wib = ema_uni((int)(threadIdx.x >> 6));
 	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wib;
 	const uint32_t *qw = lds_q[wib] + lane, *nm = lds_n[wib] + lane;

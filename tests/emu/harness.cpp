@@ -217,6 +217,25 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 int emu_sizeof_reg() { return (int)sizeof(DevReg); }
 
 // the whole pipeline K1..K4 on host memory (n_reads even: pairs)
+// K4's set-aside path (k_final.hip: K4t / K4r) on host memory: lists, arena and counters; EMU_K4_HEAVY = regions a read must have left
+// for K4b to be set aside (default 2 here, so that the path runs on ordinary test reads; 0: never)
+struct EmuFinalHeavy {
+	std::vector<uint8_t> arena;
+	std::vector<unsigned long long> reads, tasks;
+	int counters[4] = {0, 0, 0, 0};
+	unsigned long long used = 0;
+	HeavyCtl hv;
+	int min_regions;
+	EmuFinalHeavy() : arena((size_t)8 << 20), reads(4096), tasks(65536)
+	{
+		memset(&hv, 0, sizeof(hv));
+		hv.arena = arena.data(); hv.arena_bytes = arena.size(); hv.reads = reads.data(); hv.tasks = tasks.data();
+		hv.reads_cap = (int)reads.size(); hv.tasks_cap = (int)tasks.size();
+		const char *v = getenv("EMU_K4_HEAVY");
+		min_regions = v ? atoi(v) : 2;
+	}
+};
+
 int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, void *regs, int *n_regs, void *alns,
                  uint32_t *cigars, int *cig_n, int *status, int upto)
 {
@@ -247,8 +266,10 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	if (upto >= 4)
 	{
 		std::vector<int> kdone(n_reads), todo(n_reads); int n_todo = 0;
+		EmuFinalHeavy fhv;
 		ema_launch_final(&di, &d, bases, qp.data(), off, n_reads, nullptr, nullptr, (DevReg *)regs, n_regs, (DevAln *)alns, cigars, cig_n, EMU_CIG_CAP, status,
-		                 kdone.data(), todo.data(), &n_todo, slabs.data(), &counter[2], 1, nullptr, nullptr);
+		                 kdone.data(), todo.data(), &n_todo, slabs.data(), &counter[2], 1, nullptr, nullptr, &fhv.hv, fhv.counters, &fhv.used, fhv.min_regions);
+		fprintf(stderr, "emu K4: %d reads set aside, %d region tasks\n", fhv.counters[0], fhv.counters[1]);
 	}
 	return EMU_CIG_CAP;
 }
@@ -281,8 +302,10 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_pairs, n_dev, map, t.regs.data(),
 	                t.n_regs.data(), t.status.data(), ptodo.data(), &n_ptodo, slabs.data(), &counter[1], 1, nullptr, nullptr);
 	std::vector<int> kdone(2 * n_pairs), todo(2 * n_pairs); int n_todo = 0;
+	EmuFinalHeavy fhv;
 	ema_launch_final(&di, &d, bases, qp, off, 2 * n_pairs, n_dev, map, t.regs.data(), t.n_regs.data(), t.alns.data(), t.cigars.data(),
-	                 t.cig_n.data(), d.cig_cap, t.status.data(), kdone.data(), todo.data(), &n_todo, slabs.data(), &counter[2], 1, nullptr, nullptr);
+	                 t.cig_n.data(), d.cig_cap, t.status.data(), kdone.data(), todo.data(), &n_todo, slabs.data(), &counter[2], 1, nullptr, nullptr,
+	                 &fhv.hv, fhv.counters, &fhv.used, fhv.min_regions);
 }
 
 // The engine's two capacity tiers on host memory: lean tier with the given capacities, ema_k_collect, full tier over the

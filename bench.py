@@ -285,7 +285,7 @@ def sam_leg(args, eng, batches, workdir, world):
         return None
     from ema_amd import stream, synth
     try:
-        n_files, per, rep = 4, min(262144, args.pairs), 4
+        n_files, per, rep = 4, min(262144, args.pairs), 12      # 48 buckets: a dozen passes, so that the pipeline's fill and drain do not set the rate
         t = time.time()
         paths = []
         for k in range(n_files):
@@ -297,9 +297,13 @@ def sam_leg(args, eng, batches, workdir, world):
         t_write = time.time() - t
         fd = os.open("/dev/null", os.O_WRONLY)
         stream.stream_sam(eng, paths[:1], fd, rg_id=b"rg1")      # warm-up: page cache, buffers
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         bst, sst = stream.stream_sam(eng, paths * rep, fd, rg_id=b"rg1", continue_cloud_ids=True)
         dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
         os.close(fd)
         for path in paths:
             os.remove(path)
@@ -311,6 +315,7 @@ def sam_leg(args, eng, batches, workdir, world):
                         "the CPUs the box grants",
                 "stage_seconds": {"reader": round(sum(s["read_s"] for s in bst), 3), "append": round(sum(s["append_s"] for s in bst), 3),
                                   "clouds_em_duplicates": round(sum(s["select_s"] for s in sst), 3), "formatter_and_write": round(sum(s["write_s"] for s in sst), 3)},
+                "host_cpu_seconds_per_million_pairs": round(cpu_s / tot * 1e6, 3), "host_cpus_busy": round(cpu_s / dt, 1),
                 "sam_lines": int(sum(s["lines"] for s in sst))}
     except Exception as e:      # an extra: never at the cost of the line
         log(f"[rank 0] bucket files -> SAM text leg failed: {e}")

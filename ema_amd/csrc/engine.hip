@@ -67,7 +67,8 @@ extern "C" size_t ema_sizeof_aln();
 extern "C" void ema_launch_pair(const DevIndex *ix, const DevOpts *opt, int score_delta, int max_rescue, int pes_low,
                                 int pes_high, const uint8_t *bases, const uint32_t *off, int n_pairs, const int *n_pairs_dev,
                                 const int *map, DevReg *regs, int *n_regs, int *status, int *todo, int *n_todo, uint8_t *slabs,
-                                int *counter, int n_blocks, hipStream_t stream, int *dbg);
+                                int *counter, int n_blocks, hipStream_t stream, int *dbg,
+                                const HeavyCtl *heavy, int *heavy_counters, unsigned long long *arena_used, int min_attempts);
 extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *qpack, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const DevReg *regs, const int *n_regs,
                                  DevAln *alns, uint32_t *cigars, int *cig_n, int cig_cap, int *status, int *kdone, int *todo, int *n_todo,
@@ -272,6 +273,7 @@ struct ema_engine {
 	bool split_handed = true;            // EMA_SPLIT_HANDED=0: one K2b launch for everything on K2a's list
 	int align_wps = 4;                   // EMA_ALIGN_WPS=3: K2b built for three blocks per CU (measurement)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
+	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)
 	int heavy_regions = 8;               // K4b sets a read with at least this many regions left aside for K4t / K4r (0: never)
 	int heavy_chains = 32;               // EMA_HEAVY_CHAINS: K2b sets a read with at least this many chains to extend aside for K2c / K2d (0: never)
 	int align_mid_blocks = 0;
@@ -321,6 +323,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
 	HIPCHK(e, s.d_counters.alloc(48));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts
 	                                        // [26] reads set aside, [27] their chain tasks, [28..29] work queues of K2c, K2d, [30..31] arena bytes used (u64)
+	                                        // [38..44] K3: pairs set aside, attempts per direction, work queues of K3t / K3r x 2; [46..47] arena bytes (u64)
 	                                        // [32..35] K4: reads set aside, their region tasks, work queues of K4t, K4r; [36..37] CIGAR operations taken from the arena (u64)
 	if (e->heavy_chains > 0) {
 		// room: a record is ~0.2 KB per chain; a lean slice sets ~2 % of its reads aside (~100 chains each), the full-capacity
@@ -528,6 +531,8 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = getenv("EMA_MID_ALIGN")) e->mid_align = atoi(v);
 	if (const char *v = getenv("EMA_AV_LDS")) e->av_lds = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
+	if (const char *v = getenv("EMA_HEAVY_ATTEMPTS")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
+	if (const char *v = getenv("EMA_HEAVY_REGIONS")) e->heavy_regions = std::max(0, atoi(v));        //  pair / read takes the set-aside route)
 	if (const char *v = getenv("EMA_SMALL_ONE_SLICE")) e->small_one_slice = atoi(v) != 0;
 	if (const char *v = getenv("EMA_ALIGN_WPS")) e->align_wps = atoi(v);
 	if (const char *v = getenv("EMA_SPLIT_HANDED")) e->split_handed = atoi(v) != 0;
@@ -844,9 +849,17 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 
 static int run_pair(ema_engine *e, Slice &s, const Work &w)
 {
+	// pairs with many rescue attempts are set aside into per-attempt tasks (k_pair.hip: K3t / K3r), on K2's lists and arena
+	HeavyCtl hv;
+	memset(&hv, 0, sizeof(hv));
+	if (s.d_heavy.p) {
+		hv.arena = s.d_heavy.p; hv.arena_bytes = s.d_heavy.n; hv.reads = s.d_heavy_reads.p; hv.tasks = s.d_heavy_tasks.p;
+		hv.reads_cap = (int)s.d_heavy_reads.n; hv.tasks_cap = (int)s.d_heavy_tasks.n;
+	}
 	ema_launch_pair(&e->dix, &s.dopts, e->opts.score_delta, e->opts.max_rescue, e->opts.pes_low, e->opts.pes_high, e->cur_bases,
 	                w.off, w.n_pairs, w.n_dev, w.map, s.d_regs.p, s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr,
-	                s.d_counters.p + 23, s.d_slabs.p, s.d_counters.p + 1, e->pair_blocks, s.stream, s.dbg);
+	                s.d_counters.p + 23, s.d_slabs.p, s.d_counters.p + 1, e->pair_blocks, s.stream, s.dbg, s.d_heavy.p ? &hv : nullptr,
+	                s.d_counters.p + 38, reinterpret_cast<unsigned long long *>(s.d_counters.p + 46), e->heavy_attempts);
 	HIPCHK(e, hipGetLastError());
 	watchdog(e, s, "ema_k_pair");
 	return EMA_OK;
@@ -1671,9 +1684,51 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 	return worst;
 }
 
+// A view (ema_batch_view, host_stream.cpp: one bucket of a shared pass) owns its offsets and its list of redone pairs only; the batch
+// it looks into goes when its last view does.
+struct BatchShare { ema_batch_out *whole; std::atomic<int> refs; };
+
+ema_batch_out *ema_batch_view(void **share, ema_batch_out *whole, size_t p0, size_t n)
+{
+	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+	if (!o) return nullptr;
+	const size_t r0 = 2 * p0, nr = 2 * n;
+	const uint64_t c0 = whole->cand_off[r0];
+	size_t n_red = 0;
+	for (size_t i = 0; i < whole->n_redone; ++i) n_red += whole->redone[i] >= p0 && whole->redone[i] < p0 + n;
+	o->n_pairs = n; o->n_cigar = whole->n_cigar; o->n_redone = n_red;
+	o->cand_off = (uint64_t *)malloc((nr + 1) * sizeof(uint64_t));
+	o->redone = (uint32_t *)malloc((n_red + 1) * sizeof(uint32_t));
+	if (!o->cand_off || !o->redone) { free(o->cand_off); free(o->redone); free(o); return nullptr; }
+	for (size_t r = 0; r <= nr; ++r) o->cand_off[r] = whole->cand_off[r0 + r] - c0;
+	o->cand = whole->cand + c0;          // cigar_off of the candidates stays an offset into the pass's CIGAR array
+	o->cigar = whole->cigar;
+	o->status = whole->status + r0;
+	n_red = 0;
+	for (size_t i = 0; i < whole->n_redone; ++i) if (whole->redone[i] >= p0 && whole->redone[i] < p0 + n) o->redone[n_red++] = whole->redone[i] - (uint32_t)p0;
+	BatchShare *sh = (BatchShare *)*share;
+	if (!sh) { sh = new BatchShare(); sh->whole = whole; sh->refs.store(1); *share = sh; }      // (one reference is the caller's: ema_batch_share_release)
+	sh->refs.fetch_add(1);
+	o->view_of = sh;
+	return o;
+}
+
+void ema_batch_share_release(void *share)
+{
+	BatchShare *sh = (BatchShare *)share;
+	if (sh && sh->refs.fetch_sub(1) == 1) { ema_batch_out *w = sh->whole; delete sh; ema_batch_free(w); }
+}
+
 void ema_batch_free(ema_batch_out *out)
 {
 	if (!out) return;
+	if (out->view_of) {
+		free(out->cand_off); free(out->redone);
+		void *sh = out->view_of;
+		free(out);
+		ema_batch_share_release(sh);
+		return;
+	}
 	free(out->cand_off); free(out->cand); free(out->cigar); free(out->status); free(out->redone);
 	free(out);
 }

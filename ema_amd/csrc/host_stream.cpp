@@ -190,39 +190,10 @@ struct AsyncState {
 	size_t n_run = 0;             // passes queued so far (the stager may fill slot p % kInSlots once pass p - kInSlots has been queued)
 };
 
-// pairs [p0, p0 + n) of a batch as a batch of their own (offsets rebased); nullptr when memory runs out
-ema_batch_out *slice_batch(const ema_batch_out *b, size_t p0, size_t n)
-{
-	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
-	if (!o) return nullptr;
-	const size_t r0 = 2 * p0, nr = 2 * n;
-	const uint64_t c0 = b->cand_off[r0], c1 = b->cand_off[r0 + nr];
-	uint64_t g0 = ~(uint64_t)0, g1 = 0;
-	for (uint64_t c = c0; c < c1; ++c) {
-		const ema_cand_t &x = b->cand[c];
-		if (x.n_cigar <= 0) continue;
-		if (x.cigar_off < g0) g0 = x.cigar_off;
-		if ((uint64_t)x.cigar_off + (uint64_t)x.n_cigar > g1) g1 = (uint64_t)x.cigar_off + (uint64_t)x.n_cigar;
-	}
-	if (g1 <= g0) g0 = g1 = 0;
-	size_t n_red = 0;
-	for (size_t i = 0; i < b->n_redone; ++i) n_red += b->redone[i] >= p0 && b->redone[i] < p0 + n;
-	o->n_pairs = n; o->n_cigar = (size_t)(g1 - g0); o->n_redone = n_red;
-	o->cand_off = (uint64_t *)malloc((nr + 1) * sizeof(uint64_t));
-	o->cand = (ema_cand_t *)malloc((size_t)(c1 - c0 + 1) * sizeof(ema_cand_t));
-	o->cigar = (uint32_t *)malloc((size_t)(g1 - g0 + 1) * sizeof(uint32_t));
-	o->status = (int32_t *)malloc((nr + 1) * sizeof(int32_t));
-	o->redone = (uint32_t *)malloc((n_red + 1) * sizeof(uint32_t));
-	if (!o->cand_off || !o->cand || !o->cigar || !o->status || !o->redone) { ema_batch_free(o); return nullptr; }
-	for (size_t r = 0; r <= nr; ++r) o->cand_off[r] = b->cand_off[r0 + r] - c0;
-	memcpy(o->status, b->status + r0, nr * sizeof(int32_t));
-	memcpy(o->cand, b->cand + c0, (size_t)(c1 - c0) * sizeof(ema_cand_t));
-	for (uint64_t c = 0; c < c1 - c0; ++c) if (o->cand[c].n_cigar > 0) o->cand[c].cigar_off -= (uint32_t)g0;
-	memcpy(o->cigar, b->cigar + g0, (size_t)(g1 - g0) * sizeof(uint32_t));
-	n_red = 0;
-	for (size_t i = 0; i < b->n_redone; ++i) if (b->redone[i] >= p0 && b->redone[i] < p0 + n) o->redone[n_red++] = b->redone[i] - (uint32_t)p0;
-	return o;
-}
+// pairs [p0, p0 + n) of a fetched pass as a batch: a VIEW into the pass's arrays (engine.hip: no candidate or CIGAR is copied;
+// round 2 copied them, 0.4 KB a pair through freshly faulted pages); the pass is freed with its last view
+extern "C" ema_batch_out *ema_batch_view(void **share, ema_batch_out *whole, size_t p0, size_t n);
+extern "C" void ema_batch_share_release(void *share);
 
 void stager(Stream &S, AsyncState &A)
 {
@@ -348,6 +319,13 @@ void async_engine_thread(Stream &S, AsyncState &A)
 		for (size_t j = 0; j < ps.len; ++j) first_pair[j + 1] = first_pair[j] + S.items[ps.first + j].n_pairs;
 		const bool fetched = ticket[p_fetch] >= 0;
 		const double t_q = t_queued[p_fetch];
+		std::vector<ema_batch_out *> views(ps.len, nullptr);
+		void *share = nullptr;
+		const bool shared_pass = fetched && b && ps.len > 1;
+		if (shared_pass) {
+			for (size_t j = 0; j < ps.len; ++j) views[j] = ema_batch_view(&share, b, first_pair[j], S.items[ps.first + j].n_pairs);
+			if (share) b = nullptr;      // the views own the pass now (this thread's reference is released below)
+		}
 		auto one = [&](size_t j) {
 			Item &it = S.items[ps.first + j];
 			if (fetched) {
@@ -356,8 +334,8 @@ void async_engine_thread(Stream &S, AsyncState &A)
 					it.st.seed_ms = tm.seed_ms; it.st.extend_ms = tm.extend_ms; it.st.rescue_ms = tm.rescue_ms; it.st.final_ms = tm.final_ms;
 					it.st.full_tier_ms = tm.full_tier_ms;
 				}
-				if (b && ps.len > 1) {
-					it.b = slice_batch(b, first_pair[j], it.n_pairs);
+				if (shared_pass) {
+					it.b = views[j];
 					if (!it.b) { it.rc = EMA_EDEVICE; it.err = "out of host memory cutting a batch into its buckets"; }
 					else if (rc == EMA_ELIMIT) {      // the capacity flag is the batch's: does this bucket hold a flagged read?
 						int32_t flags = 0;
@@ -369,12 +347,14 @@ void async_engine_thread(Stream &S, AsyncState &A)
 			finish_item(S, it, t_q);
 		};
 		if (fetched && b && ps.len == 1) { S.items[ps.first].b = b; b = nullptr; }
-		if (ps.len > 1 && fetched && b) {
+
+		if (shared_pass) {
 			std::vector<std::thread> cutters;
 			for (size_t j = 1; j < ps.len; ++j) cutters.emplace_back(one, j);
 			one(0);
 			for (auto &t : cutters) t.join();
 		} else for (size_t j = 0; j < ps.len; ++j) one(j);
+		if (share) ema_batch_share_release(share);
 		if (b) ema_batch_free(b);
 		(void)head;
 		if (S.trace) fprintf(stderr, "[stream] engine thread: pass %zu queued at %.3f, fetch %.3f..%.3f, cut + append stage done by %.3f\n", p_fetch,

@@ -56,7 +56,7 @@ REG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] +
 class BatchOut(C.Structure):
     _fields_ = [("n_pairs", C.c_size_t), ("cand_off", C.POINTER(C.c_uint64)), ("cand", C.POINTER(Cand)),
                 ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_size_t), ("n_redone", C.c_size_t), ("status", C.POINTER(C.c_int32)),
-                ("redone", C.POINTER(C.c_uint32))]
+                ("redone", C.POINTER(C.c_uint32)), ("view_of", C.c_void_p)]
 
 
 class AlnRec(C.Structure):

@@ -116,6 +116,8 @@ typedef struct {
 	int32_t *status;        /* per read (2*n_pairs): 0, or capacity bits (1 intervals, 2 lists, 4 seeds, 8 chains, 16 regions,
 	                         * 32 reference window, 64 CIGAR ops, 128 not redone: full-capacity tier was full, 256 seeding budget); a flagged read has no candidates */
 	uint32_t *redone;       /* n_redone pair indices: the pairs whose results come from the full-capacity tier */
+	void *view_of;          /* private to the library (NULL in a batch of its own): a bucket cut out of a shared pass by ema_stream_* is a
+	                         * VIEW -- cand, cigar and status point into the pass's batch, which lives until its last view is freed */
 } ema_batch_out;
 
 /* Whole hot path for a batch: reads are ASCII, read r at bases[off[r] .. off[r+1]);

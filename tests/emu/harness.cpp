@@ -222,10 +222,10 @@ int emu_sizeof_reg() { return (int)sizeof(DevReg); }
 struct EmuFinalHeavy {
 	std::vector<uint8_t> arena;
 	std::vector<unsigned long long> reads, tasks;
-	int counters[4] = {0, 0, 0, 0};
+	int counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long used = 0;
 	HeavyCtl hv;
-	int min_regions;
+	int min_regions, min_attempts;
 	EmuFinalHeavy() : arena((size_t)8 << 20), reads(4096), tasks(65536)
 	{
 		memset(&hv, 0, sizeof(hv));
@@ -233,6 +233,8 @@ struct EmuFinalHeavy {
 		hv.reads_cap = (int)reads.size(); hv.tasks_cap = (int)tasks.size();
 		const char *v = getenv("EMU_K4_HEAVY");
 		min_regions = v ? atoi(v) : 2;
+		const char *u = getenv("EMU_K3_HEAVY");      // candidate rescue anchors for K3b to set a pair aside (default 2 here; 0: never)
+		min_attempts = u ? atoi(u) : 2;
 	}
 };
 
@@ -259,8 +261,11 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	if (upto >= 3)
 	{
 		std::vector<int> todo(n_reads); int n_todo = 0;
+		EmuFinalHeavy phv;
 		ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_reads / 2, nullptr, nullptr, (DevReg *)regs,
-		                n_regs, status, getenv("EMU_NO_K3A") ? nullptr : todo.data(), &n_todo, slabs.data(), &counter[1], 1, nullptr, nullptr);
+		                n_regs, status, getenv("EMU_NO_K3A") ? nullptr : todo.data(), &n_todo, slabs.data(), &counter[1], 1, nullptr, nullptr,
+		                &phv.hv, phv.counters, &phv.used, phv.min_attempts);
+		fprintf(stderr, "emu K3: %d pairs set aside, %d + %d attempt tasks\n", phv.counters[0], phv.counters[1], phv.counters[2]);
 		fprintf(stderr, "emu K3a: %d of %d pairs need a rescue alignment\n", n_todo, n_reads / 2);
 	}
 	if (upto >= 4)
@@ -299,8 +304,10 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	emu_run_align(di, d, bases, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(), t.status.data(),
 	              slabs.data(), 1);
 	std::vector<int> ptodo(n_pairs + 1); int n_ptodo = 0;
+	EmuFinalHeavy phv;
 	ema_launch_pair(&di, &d, eo.score_delta, eo.max_rescue, eo.pes_low, eo.pes_high, bases, off, n_pairs, n_dev, map, t.regs.data(),
-	                t.n_regs.data(), t.status.data(), ptodo.data(), &n_ptodo, slabs.data(), &counter[1], 1, nullptr, nullptr);
+	                t.n_regs.data(), t.status.data(), ptodo.data(), &n_ptodo, slabs.data(), &counter[1], 1, nullptr, nullptr,
+	                &phv.hv, phv.counters, &phv.used, phv.min_attempts);
 	std::vector<int> kdone(2 * n_pairs), todo(2 * n_pairs); int n_todo = 0;
 	EmuFinalHeavy fhv;
 	ema_launch_final(&di, &d, bases, qp, off, 2 * n_pairs, n_dev, map, t.regs.data(), t.n_regs.data(), t.alns.data(), t.cigars.data(),

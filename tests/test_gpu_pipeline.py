@@ -87,6 +87,18 @@ def test_pipeline_250bp():
     _check("repeats", 300, 52, len1=250, len2=250, sub_rate=0.01, indel_rate=0.002)
 
 
+@pytest.mark.parametrize("attempts,regions", [(1, 1), (3, 2), (0, 0)])
+def test_set_aside_routes_of_rescue_and_final_alignment(attempts, regions, monkeypatch):
+    """K3t / K3r (one rescue attempt per wavefront, replayed in order) and K4t / K4r (one region per wavefront, laid into the CIGAR pool
+    in order) normally take only pairs with >= 8 candidate anchors / reads with >= 8 regions left; with the thresholds at 1 every
+    rescued pair and every read with a gapped region goes that way, at 0 none does.  Noisy reads (rescues in both directions,
+    several regions per read) and a repeat-rich reference."""
+    monkeypatch.setenv("EMA_HEAVY_ATTEMPTS", str(attempts))
+    monkeypatch.setenv("EMA_HEAVY_REGIONS", str(regions))
+    _check("two_contigs", 700, 46, sub_rate=0.08, indel_rate=0.004)
+    _check("repeats", 500, 47, sub_rate=0.03, indel_rate=0.003, chimeric=0.1)
+
+
 def test_pipeline_chimeric_and_n():
     _check("two_contigs", 600, 43, chimeric=0.3, n_rate=0.004)
 

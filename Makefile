@@ -13,7 +13,7 @@ all: ema_amd/libema_index.so ema_amd/libema_engine.so $(BWAABI) oracle
 test-libs: all ema_amd/libema_engine_ss16.so
 
 ema_amd/libema_index.so: $(CSRC)/index_build.cpp
-	$(CXX) $(HOSTFLAGS) -fopenmp -shared -o $@ $<
+	$(CXX) $(HOSTFLAGS) -fopenmp -shared -o $@ $< -ldl
 
 HIP_SRCS = $(wildcard $(CSRC)/*.hip)
 HOST_SRCS = $(wildcard $(CSRC)/host_*.cpp)

@@ -30,6 +30,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <dlfcn.h>
 
 namespace {
 
@@ -198,8 +199,27 @@ void build_sa(const Packed &T, I *sa)
 
 void fput64(FILE *f, uint64_t v) { fwrite(&v, 8, 1, f); }
 
+// The suffix array on the GPU (k_sa.hip in libema_engine.so, next to this library): same rows as build_sa, plus the base before every
+// row's suffix.  This library is plain host code (it also runs where there is no GPU), so the entry point is looked up at run time;
+// without the engine library, without a device, with EMA_INDEX_GPU=0 or on any failure there the host's cores sort as before.
+typedef int (*gpu_sa_fn)(const uint64_t *text, uint64_t n, int width, void *rows, uint8_t *prev, int verbose);
+gpu_sa_fn find_gpu_sa()
+{
+	const char *v = getenv("EMA_INDEX_GPU");
+	if (v && atoi(v) == 0) return nullptr;
+	Dl_info me;
+	if (!dladdr((void *)&find_gpu_sa, &me) || !me.dli_fname) return nullptr;
+	std::string dir(me.dli_fname);
+	const size_t slash = dir.rfind('/');
+	dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+	const char *lib = getenv("EMA_ENGINE_LIB");
+	void *h = dlopen((dir + "/" + (lib ? lib : "libema_engine.so")).c_str(), RTLD_NOW | RTLD_LOCAL);
+	if (!h) return nullptr;
+	return (gpu_sa_fn)dlsym(h, "ema_gpu_suffix_array");
+}
+
 template <typename I>
-int write_index(const std::string &prefix, const Packed &T, const I *sa)
+int write_index(const std::string &prefix, const Packed &T, const I *sa, const uint8_t *prev = nullptr)      // prev: the GPU builder's BWT symbols per row
 {
 	const uint64_t n = T.n;
 	// BWT without the sentinel row
@@ -216,7 +236,7 @@ int write_index(const std::string &prefix, const Packed &T, const I *sa)
 #pragma omp parallel for schedule(static) reduction(+ : c0, c1, c2, c3)
 		for (int64_t r = 0; r <= (int64_t)n; ++r) {
 			if ((uint64_t)r == primary) continue;
-			const uint8_t c = (uint8_t)T.get((uint64_t)sa[(size_t)r] - 1);
+			const uint8_t c = prev ? prev[(size_t)r] : (uint8_t)T.get((uint64_t)sa[(size_t)r] - 1);
 			B[(size_t)r - ((uint64_t)r > primary ? 1 : 0)] = c;
 			c0 += c == 0; c1 += c == 1; c2 += c == 2; c3 += c == 3;
 		}
@@ -436,15 +456,22 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 	// EMA_INDEX_SA64=1 (tests): 8-byte suffix-array rows whatever the size, so that a small reference drives the row width
 	// that only references beyond 2^32 symbols get otherwise
 	const char *force64 = getenv("EMA_INDEX_SA64");
+	const gpu_sa_fn gpu_sa = find_gpu_sa();
+	Raw<uint8_t> prev(gpu_sa ? T.n + 1 : 1);
+	const bool verbose = getenv("EMA_INDEX_PROF") != nullptr || getenv("EMA_VERBOSE") != nullptr;
 	if (T.n < 0xffffff00ULL && !(force64 && atoi(force64) != 0)) {
 		Raw<uint32_t> sa(T.n + 1);
 		if (!sa.p) return -3;
-		build_sa(T, sa.p);
-		return write_index(prefix, T, sa.p);
+		const bool on_gpu = gpu_sa && prev.p && gpu_sa(T.w.data(), T.n, 4, sa.p, prev.p, verbose) == 0;
+		if (!on_gpu) build_sa(T, sa.p);
+		lap(on_gpu ? "sa (gpu)" : "sa (host)");
+		return write_index(prefix, T, sa.p, on_gpu ? prev.p : nullptr);
 	} else {
 		Raw<uint64_t> sa(T.n + 1);
 		if (!sa.p) return -3;
-		build_sa(T, sa.p);
-		return write_index(prefix, T, sa.p);
+		const bool on_gpu = gpu_sa && prev.p && gpu_sa(T.w.data(), T.n, 8, sa.p, prev.p, verbose) == 0;
+		if (!on_gpu) build_sa(T, sa.p);
+		lap(on_gpu ? "sa (gpu)" : "sa (host)");
+		return write_index(prefix, T, sa.p, on_gpu ? prev.p : nullptr);
 	}
 }

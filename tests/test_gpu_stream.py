@@ -133,9 +133,11 @@ def test_stream_batches_from_memory_equals_align_pairs():
     for k, p in enumerate(batches):
         one = eng.align_pairs(p.bases, p.off)
         b = got[k][0]
-        assert (one.cand_off == b.cand_off).all() and (one.cigar == b.cigar).all()
-        for f in one.cand.dtype.names:      # field by field: the records' padding bytes are not part of the result
-            assert (one.cand[f] == b.cand[f]).all(), (k, f)
+        assert (one.cand_off == b.cand_off).all() and len(one.cand) == len(b.cand)
+        for f in one.cand.dtype.names:      # field by field: the records' padding bytes are not part of the result; cigar_off is an offset
+            if f != "cigar_off":            # into the batch's own CIGAR array -- a bucket cut out of a shared pass is a view into the pass's
+                assert (one.cand[f] == b.cand[f]).all(), (k, f)
+        assert all(one.cigar_of(x).tolist() == b.cigar_of(y).tolist() for x, y in zip(one.cand, b.cand))
     eng.close()
 
 

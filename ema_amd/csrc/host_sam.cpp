@@ -152,7 +152,9 @@ bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema
 	decode_bc(bc, opt, bc_str);
 	if (rec) {
 		char g[48];
-		snprintf(g, sizeof g, "%.5g", rec->gamma);
+		if (rec->gamma == 1.0) { g[0] = '1'; g[1] = 0; }      // "%.5g" of the two values most records carry, without the library call
+		else if (rec->gamma == 0.0) { g[0] = '0'; g[1] = 0; }
+		else snprintf(g, sizeof g, "%.5g", rec->gamma);
 		o.str("\tNM:i:"); o.i64(rec->edit_dist); o.str("\tBX:Z:"); o.str(bc_str);
 		if (!opt.is_haplotag) { o.ch('-'); o.str(opt.bx_index); }
 		o.str("\tXG:f:"); o.str(g); o.str("\tMI:i:"); o.i64(rec->cloud_id); o.str("\tXF:i:"); o.i64(rec->cloud_bad);
@@ -201,11 +203,14 @@ static int format_parts(const ema_sam_line *lines, size_t n, const ema_sam_opts 
 		return t < 1 ? 1 : t > 32 ? 32 : t;
 	}();
 	const size_t t = n < 4096 ? 1 : (size_t)n_thr_max, per = (n + t - 1) / t;
-	parts.assign(t, Out());
+	// the threads' buffers are the caller's thread's from call to call (grown, never handed back: a fresh 30 MB vector per call is
+	// zero-filled and page-faulted before the first byte is formatted)
+	if (parts.size() < t) parts.resize(t);
+	for (auto &pt : parts) { pt.n = 0; pt.p = nullptr; }
 	std::vector<int> bad(t, 0);
 	auto work = [&](size_t k) {
 		const size_t lo = std::min(n, k * per), hi = std::min(n, lo + per);
-		parts[k].buf.resize((hi - lo) * 400 + (1 << 16));
+		if (parts[k].buf.size() < (hi - lo) * 400 + (1 << 16)) parts[k].buf.resize((hi - lo) * 400 + (1 << 16));
 		for (size_t i = lo; i < hi; ++i) if (!put_line(parts[k], lines[i].rec, lines[i].mate, *opt)) { bad[k] = 1; return; }
 	};
 	std::vector<std::thread> th;
@@ -220,7 +225,8 @@ int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt,
 {
 	if (!text || !n_bytes) return EMA_EARG;
 	*text = nullptr; *n_bytes = 0;
-	std::vector<Out> parts;
+	static thread_local std::vector<Out> parts_tls;      // kept from call to call (see format_parts)
+	std::vector<Out> &parts = parts_tls;                  // (a lambda run by another thread would name ITS instance of a thread_local)
 	const int rc = format_parts(lines, n, opt, parts);
 	if (rc) return rc;
 	const size_t t = parts.size();
@@ -243,7 +249,8 @@ int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt,
 int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, size_t *n_bytes)
 {
 	if (n_bytes) *n_bytes = 0;
-	std::vector<Out> parts;
+	static thread_local std::vector<Out> parts_tls;      // kept from call to call (see format_parts)
+	std::vector<Out> &parts = parts_tls;                  // (a lambda run by another thread would name ITS instance of a thread_local)
 	const int rc = format_parts(lines, n, opt, parts);
 	if (rc) return rc;
 	// an interrupted or momentarily refused write is retried; on a real failure *n_bytes says how much text is on the fd

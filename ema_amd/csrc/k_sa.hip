@@ -132,7 +132,7 @@ inline unsigned grid_for(size_t m) { return (unsigned)((m + 255) / 256); }
 }  // namespace
 
 // text: the 2-bit text as index_build.cpp packs it ((n >> 5) + 3 words, zero past n); rows: (n + 1) x width bytes, row 0 = n;
-// prev: n + 1 bytes, the base before each row's suffix (4 for row 0 and for the row of suffix 0).  0 on success; 1 = no device, no
+// prev: n + 1 bytes, the base before each row's suffix (4 for the row of suffix 0, which has none).  0 on success; 1 = no device, no
 // memory or a runtime error (the caller then sorts on the host).
 extern "C" int ema_gpu_suffix_array(const uint64_t *text, uint64_t n, int width, void *rows, uint8_t *prev, int verbose)
 {
@@ -192,7 +192,7 @@ extern "C" int ema_gpu_suffix_array(const uint64_t *text, uint64_t n, int width,
 	int rc = 0;
 	size_t row0 = 1, total_rounds = 0, total_tied = 0;
 	if (width == 4) reinterpret_cast<uint32_t *>(rows)[0] = (uint32_t)n; else reinterpret_cast<uint64_t *>(rows)[0] = n;
-	prev[0] = 4;
+	prev[0] = (uint8_t)(text[(n - 1) >> 5] >> (62 - (((n - 1) & 31) << 1)) & 3);      // row 0 is the empty suffix: the base before it is the text's last
 	auto run_chunk = [&](unsigned c) -> int {
 		const size_t m = (size_t)cnt[c];
 		if (!m) return 0;

@@ -13,7 +13,8 @@ from . import sam as _sam
 
 
 class CloudOpts(C.Structure):
-    _fields_ = [("dist_thresh", C.c_uint32), ("many_clouds", C.c_int32), ("n_threads", C.c_int32), ("first_cloud_id", C.c_int32)]
+    _fields_ = [("dist_thresh", C.c_uint32), ("many_clouds", C.c_int32), ("n_threads", C.c_int32), ("first_cloud_id", C.c_int32),
+                ("density_opt", C.c_int32), ("n_density_probs", C.c_int32), ("density_probs", C.c_double * 16)]
 
 
 class SamStats(C.Structure):
@@ -41,6 +42,13 @@ def _lib():
         L.ema_clouds_free.argtypes = [C.POINTER(CloudsOut)]
         L._clouds_bound = True
     return L
+
+
+def reseed(seed: int) -> None:
+    """ema_clouds_reseed: srand(seed) for -d, as the reference does once per process with time()."""
+    L = _lib()
+    L.ema_clouds_reseed.argtypes = [C.c_uint]
+    L.ema_clouds_reseed(seed)
 
 
 def default_opts() -> CloudOpts:

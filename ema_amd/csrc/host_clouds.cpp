@@ -16,6 +16,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "ema_clouds.h"
@@ -34,6 +36,8 @@ struct Rec {
 	int32_t rank;                 // rank of the read name among the group's names (strcmp order)
 	double score, gamma;
 	uint8_t mate, rev, duplicate, visited;
+	uint8_t active;               // cleared by the density optimiser (-d) only
+	int32_t clip_edit_dist;       // edit distance including clipping (src/align.c:936), for -d
 	int32_t cloud, alt, sel_mate; // local cloud; record the XA entry is copied from; selected mate (record index) or -1
 	uint64_t gi;                  // index in ema_aln_out.rec
 };
@@ -149,13 +153,13 @@ void sam_dict_del(Work &w, int32_t k)      // src/samdict.c:150-157
 	if (ei >= 0 && !w.ents[(size_t)ei].c.empty()) w.ents[(size_t)ei].c.pop_back();
 }
 
-int32_t find_best_record(Work &w, Entry &e)      // src/samdict.c:177-243 (every record is active: no -d)
+int32_t find_best_record(Work &w, Entry &e)      // src/samdict.c:177-243 (records the density optimiser switched off are passed over)
 {
 	size_t best = 0;
 	double best_gamma = -1.0;
 	const size_t n = e.c.size();
 	for (size_t i = 0; i < n; i++)
-		if (e.c[i].gamma > best_gamma) { best = i; best_gamma = e.c[i].gamma; }
+		if (w.recs[(size_t)e.c[i].rec].active && e.c[i].gamma > best_gamma) { best = i; best_gamma = e.c[i].gamma; }
 	Rec &chosen = w.recs[(size_t)e.c[best].rec];
 	chosen.alt = -1;
 	chosen.gamma = best_gamma;
@@ -164,7 +168,7 @@ int32_t find_best_record(Work &w, Entry &e)      // src/samdict.c:177-243 (every
 		size_t second = 0;
 		double second_gamma = -1.0;
 		for (size_t i = 0; i < n; i++)
-			if (i != best && e.c[i].gamma > second_gamma) { second = i; second_gamma = e.c[i].gamma; }
+			if (w.recs[(size_t)e.c[i].rec].active && i != best && e.c[i].gamma > second_gamma) { second = i; second_gamma = e.c[i].gamma; }
 		if (second_gamma > 0) chosen.alt = e.c[second].rec;
 	}
 	return e.c[best].rec;
@@ -178,6 +182,164 @@ void normalize_cloud_probabilities(std::vector<Cloud> &cl, size_t nc)      // sr
 		for (int32_t c = (int32_t)i; c >= 0; c = cl[(size_t)c].child) total += cl[(size_t)c].weight;
 		for (int32_t c = (int32_t)i; c >= 0; c = cl[(size_t)c].child) cl[(size_t)c].weight /= total;
 	}
+}
+
+// ---- `ema align -d`: mark_optimal_alignments_in_cloud (src/split.c:38-338) on the name-sorted records of a bad cloud.
+// Same decisions, same order, same draws from libc's rand() as the reference, same floating-point expressions in the same order
+// (-ffp-contract=off); the arrays are sized by need instead of 50,000-entry stack buffers.
+std::once_flag g_rand_once;
+std::atomic<bool> g_rand_seeded{false};
+
+double log_density_prob(const Shared &S, unsigned int density)      // src/split.c:15-35
+{
+	const size_t size = (size_t)S.o.n_density_probs;
+	if (density < size) return std::log(S.o.density_probs[density]);
+	return std::log(S.o.density_probs[size - 1]) - (density - size + 1) * std::log(2.0);      // (unsigned arithmetic, as there)
+}
+
+bool split_is_pair(const Rec *r1, const Rec *r2)      // is_pair, src/align.c:27-41: two uint32_t positions, the difference wraps
+{
+	if (r1->rev == r2->rev || r1->chrom != r2->chrom) return false;
+	if (r2->rev) { const Rec *t = r2; r2 = r1; r1 = t; }
+	const int64_t d = (int64_t)(uint32_t)(r1->pos - r2->pos);
+	return kInsertMin <= d && d <= kInsertMax;
+}
+
+void mark_optimal_alignments_in_cloud(Work &w, const Shared &S, const std::vector<int32_t> &sorted)
+{
+	const int kMaxNoMove = 500, kBinSize = 1000, kMaxBins = 1000000 / 1000, kScoreScale = 20, kSplitExtraDepth = 5, kIters = 50000;
+	const size_t kBuf = 50000;
+	if (!g_rand_seeded.load()) std::call_once(g_rand_once, [] { if (!g_rand_seeded.load()) { srand((unsigned)time(nullptr)); g_rand_seeded.store(true); } });
+	size_t n_records = sorted.size();
+	if (n_records >= kBuf || n_records <= 5) return;
+	auto R = [&](int32_t i) -> Rec & { return w.recs[(size_t)i]; };
+	auto rec_eq = [&](int32_t a, int32_t b) { return R(a).rank == R(b).rank && R(a).mate == R(b).mate; };
+	auto rec_eq_mate = [&](int32_t a, int32_t b) { return R(a).rank == R(b).rank && R(a).mate != R(b).mate; };
+	// records too far from their read's lowest edit distance go
+	std::vector<int32_t> records;
+	records.reserve(n_records);
+	for (size_t i = 0; i < n_records;) {
+		size_t j = i + 1;
+		while (j < n_records && rec_eq(sorted[j], sorted[i])) ++j;
+		const size_t n = j - i;
+		if (n > 1) {
+			size_t min_edit = 0;
+			for (size_t k = 0; k < n; k++) if (R(sorted[i + k]).clip_edit_dist < R(sorted[i + min_edit]).clip_edit_dist) min_edit = k;
+			const int cutoff = R(sorted[i + min_edit]).clip_edit_dist + kSplitExtraDepth;
+			for (size_t k = 0; k < n; k++) {
+				if (R(sorted[i + k]).clip_edit_dist <= cutoff) records.push_back(sorted[i + k]);
+				else R(sorted[i + k]).active = 0;
+			}
+		} else records.push_back(sorted[i]);
+		i = j;
+	}
+	n_records = records.size();
+	struct MMap { size_t idx; int n, mate_umap, mate_mmap, active; };
+	std::vector<size_t> umaps;
+	std::vector<MMap> mmaps;
+	double log_config_prob = 0;
+	uint32_t cloud_lo = 0xffffffffu, cloud_hi = 0;
+	auto bounds = [&](const Rec &r) { if (r.pos < cloud_lo) cloud_lo = r.pos; if (r.pos > cloud_hi) cloud_hi = r.pos; };
+	for (size_t i = 0; i < n_records;) {
+		bounds(R(records[i]));
+		size_t j = i + 1;
+		while (j < n_records && rec_eq(records[j], records[i])) { bounds(R(records[j])); ++j; }
+		const size_t n = j - i;
+		if (n > 1) {
+			size_t max_score = 0;
+			for (size_t k = 0; k < n; k++) if (R(records[i + k]).score > R(records[i + max_score]).score) max_score = k;
+			int mate_umap = -1, mate_mmap = -1;
+			for (size_t k = 0; k < umaps.size(); k++) if (rec_eq_mate(records[i], records[umaps[k]])) { mate_umap = (int)k; break; }
+			if (mate_umap < 0)
+				for (size_t k = 0; k < mmaps.size(); k++)
+					if (rec_eq_mate(records[i], records[mmaps[k].idx])) { mate_mmap = (int)k; mmaps[k].mate_mmap = (int)mmaps.size(); break; }
+			mmaps.push_back(MMap{i, (int)n, mate_umap, mate_mmap, (int)max_score});
+			log_config_prob += R(records[i + max_score]).score / kScoreScale;
+		} else {
+			for (size_t k = 0; k < mmaps.size(); k++)
+				if (rec_eq_mate(records[i], records[mmaps[k].idx])) { mmaps[k].mate_umap = (int)umaps.size(); break; }
+			umaps.push_back(i);
+			log_config_prob += R(records[i]).score / kScoreScale;
+		}
+		i = j;
+	}
+	const size_t n_umaps = umaps.size(), n_mmaps = mmaps.size();
+	const size_t n_bins = (size_t)(cloud_hi - cloud_lo) / (size_t)kBinSize + 1;
+	if (n_bins >= (size_t)kMaxBins || n_records <= 5 || n_mmaps == 0) return;
+	std::vector<unsigned short> bins((size_t)kMaxBins, 0);
+	auto bin_of = [&](uint32_t pos) { return (size_t)((pos - cloud_lo) / (uint32_t)kBinSize); };
+	for (size_t i = 0; i < n_records; i++) R(records[i]).active = 0;      // the active ones are set again below
+	for (size_t i = 0; i < n_umaps; i++) ++bins[bin_of(R(records[umaps[i]]).pos)];
+	for (size_t i = 0; i < n_mmaps; i++) ++bins[bin_of(R(records[mmaps[i].idx + (size_t)mmaps[i].active]).pos)];
+	for (size_t i = 0; i < n_bins; i++) log_config_prob += log_density_prob(S, bins[i]);
+	int no_move_count = 0;
+	for (size_t k = 0; k < (size_t)kIters; k++) {
+		const double t = std::pow(10.0, 0.0 - ((0.0 - (-12.0)) * k) / kIters);
+		const size_t r = (size_t)rand() % n_mmaps;
+		const size_t r_old = (size_t)mmaps[r].active;
+		size_t r_new = (size_t)(rand() % (mmaps[r].n - 1));
+		if (r_new >= r_old) ++r_new;
+		const Rec *active_mate = nullptr;
+		size_t mate_r = 0;
+		int mate_is_mmap = 0;
+		if (mmaps[r].mate_umap >= 0) { mate_r = (size_t)mmaps[r].mate_umap; active_mate = &R(records[umaps[mate_r]]); }
+		else if (mmaps[r].mate_mmap >= 0) { mate_r = (size_t)mmaps[r].mate_mmap; active_mate = &R(records[mmaps[mate_r].idx + (size_t)mmaps[mate_r].active]); mate_is_mmap = 1; }
+		const Rec *rec_old = &R(records[mmaps[r].idx + r_old]), *rec_new = &R(records[mmaps[r].idx + r_new]);
+		double density_prob_change = 0.0, score_prob_change = 0.0;
+		int force_move = 0, mate_new_active = -1;
+		size_t mate_old_bin = 0, mate_new_bin = 0;
+		const int old_paired = active_mate != nullptr && split_is_pair(rec_old, active_mate);
+		const int new_paired = active_mate != nullptr && split_is_pair(rec_new, active_mate);
+		if (!old_paired && new_paired) force_move = 1;
+		else if (old_paired && !new_paired && mate_is_mmap) {      // try to move the mate along
+			for (int i = 0; i < mmaps[mate_r].n; i++) {
+				const Rec *mate_rec_new = &R(records[mmaps[mate_r].idx + (size_t)i]);
+				if (split_is_pair(rec_new, mate_rec_new)) {
+					const Rec *mate_rec_old = active_mate;
+					mate_new_active = i;
+					mate_old_bin = bin_of(mate_rec_old->pos);
+					mate_new_bin = bin_of(mate_rec_new->pos);
+					score_prob_change += (mate_rec_new->score - mate_rec_old->score) / kScoreScale;
+					break;
+				}
+			}
+		}
+		const size_t old_bin = bin_of(rec_old->pos), new_bin = bin_of(rec_new->pos);
+		const int p1 = (mate_new_active >= 0 && old_bin == mate_old_bin) ? 2 : 1;
+		const int p2 = (mate_new_active >= 0 && new_bin == mate_new_bin) ? 2 : 1;
+		{
+			const double old_bin_prob_old = log_density_prob(S, bins[old_bin]);
+			const double old_bin_prob_new = log_density_prob(S, (unsigned int)(bins[old_bin] - p1));
+			const double new_bin_prob_old = log_density_prob(S, bins[new_bin]);
+			const double new_bin_prob_new = log_density_prob(S, (unsigned int)(bins[new_bin] + p2));
+			density_prob_change += (old_bin_prob_new - old_bin_prob_old) + (new_bin_prob_new - new_bin_prob_old);
+		}
+		if (p1 == 1 && mate_new_active >= 0) {
+			const double a = log_density_prob(S, bins[mate_old_bin]), b = log_density_prob(S, (unsigned int)(bins[mate_old_bin] - 1));
+			density_prob_change += (b - a);
+		}
+		if (p2 == 1 && mate_new_active >= 0) {
+			const double a = log_density_prob(S, bins[mate_new_bin]), b = log_density_prob(S, (unsigned int)(bins[mate_new_bin] + 1));
+			density_prob_change += (b - a);
+		}
+		score_prob_change += (rec_new->score - rec_old->score) / kScoreScale;
+		const double prob_change = density_prob_change + score_prob_change;
+		if (force_move || prob_change > 0 || std::exp(prob_change / t) >= ((double)rand()) / RAND_MAX) {
+			log_config_prob += prob_change;
+			mmaps[r].active = (int)r_new;
+			bins[old_bin] -= 1;
+			bins[new_bin] += 1;
+			if (mate_new_active >= 0) {
+				mmaps[mate_r].active = mate_new_active;
+				bins[mate_old_bin] -= 1;
+				bins[mate_new_bin] += 1;
+			}
+		} else ++no_move_count;
+		if (no_move_count >= kMaxNoMove) break;
+	}
+	(void)log_config_prob;
+	for (size_t i = 0; i < n_umaps; i++) R(records[umaps[i]]).active = 1;
+	for (size_t i = 0; i < n_mmaps; i++) R(records[mmaps[i].idx + (size_t)mmaps[i].active]).active = 1;
 }
 
 // one barcode group: pairs [p0, p1), records [r0, r1) of ema_aln_out
@@ -213,6 +375,7 @@ void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 		r.rank = w.rank_of_pair[ar.pair - p0];
 		r.score = ar.score; r.gamma = 0;
 		r.mate = ar.mate; r.rev = (uint8_t)(c.is_rev != 0); r.duplicate = 0; r.visited = 0;
+		r.active = 1; r.clip_edit_dist = ar.clip_edit_dist;
 		r.cloud = -1; r.alt = -1; r.sel_mate = -1;
 		r.gi = r0 + i;
 	}
@@ -254,6 +417,7 @@ void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 				if (a.rank != b.rank) return a.rank < b.rank;
 				return a.mate < b.mate;
 			});
+			if (S.o.density_opt) mark_optimal_alignments_in_cloud(w, S, w.split);      // -d, src/align.c:396-397
 			for (size_t i = 0; i < cov; i++) sam_dict_add(w, S, w.split[i], ci, true);
 		}
 		at = r + 1;
@@ -302,7 +466,7 @@ void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 			normalize_log_probs(e.c);
 		}
 		for (size_t k = w.n_ents; k-- > 0;)
-			for (const Cand &c : w.ents[k].c) cl[(size_t)c.cloud].exp_cov += c.gamma;      // every record active, none duplicate yet
+			for (const Cand &c : w.ents[k].c) if (w.recs[(size_t)c.rec].active) cl[(size_t)c.cloud].exp_cov += c.gamma;      // src/align.c:530 (none is a duplicate yet)
 		for (size_t i = 0; i < nc; i++) cl[i].weight = cl[i].exp_cov;
 		if (!S.o.many_clouds) normalize_cloud_probabilities(cl, nc);
 	}
@@ -378,6 +542,15 @@ void ema_cloud_opts_default(ema_cloud_opts *o)
 {
 	if (!o) return;
 	o->dist_thresh = 50000; o->many_clouds = 0; o->n_threads = 0; o->first_cloud_id = 0;
+	o->density_opt = 0; o->n_density_probs = 4;
+	for (double &p : o->density_probs) p = 0;
+	o->density_probs[0] = 0.6; o->density_probs[1] = 0.05; o->density_probs[2] = 0.2; o->density_probs[3] = 0.01;      // src/techs.c: every platform but cpt
+}
+
+void ema_clouds_reseed(unsigned seed)
+{
+	srand(seed);
+	g_rand_seeded.store(true);
 }
 
 void ema_clouds_free(ema_clouds_out *out)
@@ -419,7 +592,8 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 				}
 			}
 		};
-		const int nt = (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 16 + 1);
+		// -d draws from libc's rand(): one thread, groups in order, so that the draws fall as in a `-t 1` run of the reference
+		const int nt = S.o.density_opt ? 1 : (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 16 + 1);
 		std::vector<std::thread> th;
 		for (int t = 1; t < nt; ++t) th.emplace_back(run);
 		run();

@@ -645,6 +645,11 @@ int ema_sam_run_opts_platform(const char *name, ema_sam_run_opts *o)
 		ema_sam_run_opts_default(o);
 		o->stream.bc_len = t.bc_len; o->stream.is_haplotag = t.haplotag; o->stream.error_rate = t.error_rate;
 		o->clouds.dist_thresh = t.dist_thresh; o->clouds.many_clouds = t.many_clouds;
+		if (strcmp(name, "cpt") == 0) {      // its own density model for -d (src/techs.c:107-109); every other platform has the default one
+			static const double cpt[9] = {0.6, 0.01, 0.15, 0.001, 0.05, 0.001, 0.02, 0.001, 0.01};
+			o->clouds.n_density_probs = 9;
+			for (int i = 0; i < 9; ++i) o->clouds.density_probs[i] = cpt[i];
+		}
 		o->sam.bc_len = t.bc_len; o->sam.is_haplotag = t.haplotag;
 		return EMA_OK;
 	}

@@ -173,7 +173,7 @@ def platform_opts(name: str) -> dict:
 
 
 def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None, is_haplotag: bool = False, bc_len: int = 16,
-               continue_cloud_ids: bool = False, n_engines: int = 0, bx_index: bytes | None = None):
+               continue_cloud_ids: bool = False, n_engines: int = 0, bx_index: bytes | None = None, density_opt: bool = False):
     """ema_stream_sam: bucket files -> SAM text on fd.  Returns (per-bucket stream stats, per-bucket SAM stats)."""
     from . import clouds as _clouds
     from . import sam as _sam
@@ -190,6 +190,7 @@ def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None
     if bx_index is not None:
         o.sam.bx_index = bx_index
     o.continue_cloud_ids = int(continue_cloud_ids)
+    o.clouds.density_opt = int(density_opt)
     arr = (C.c_char_p * max(1, len(paths)))(*[p.encode() for p in paths])
     bst = (BucketStats * max(len(paths), 1))()
     sst = (_clouds.SamStats * max(len(paths), 1))()

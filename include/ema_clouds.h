@@ -39,8 +39,19 @@ typedef struct {
 	int32_t many_clouds;      /* tech->many_clouds (tru, cpt): per-read cloud weights, no cloud sets, no duplicate marking */
 	int32_t n_threads;        /* host threads over barcode groups (0 = default: min(32, hardware threads)) */
 	int32_t first_cloud_id;   /* the reference's cloud counter when this bucket starts: 0 for `ema align -s bucket` */
+	/* `ema align -d` (src/split.c:38-338, hook at src/align.c:396-397): in a cloud with a read-name collision, simulated annealing over
+	 * the multi-mapped reads' alignments against the platform's read-density model decides which alignments stay `active`.  The
+	 * reference draws its moves from libc's rand(), seeded ONCE per process from time(); this library draws from the same rand(), so the
+	 * result equals the reference's for the same seed (ema_clouds_reseed) and the same order of work -- with density_opt the barcode
+	 * groups therefore run on ONE thread, in order (the reference's own -d under -t N is not reproducible either: SURVEY 0.5-1) */
+	int32_t density_opt;      /* -d */
+	int32_t n_density_probs;  /* tech->n_density_probs, tech->density_probs (src/techs.c:74-127): 4 x {0.6, 0.05, 0.2, 0.01} for 10x */
+	double density_probs[16];
 } ema_cloud_opts;
-void ema_cloud_opts_default(ema_cloud_opts *o);   /* 50000, 0, 0, 0 */
+void ema_cloud_opts_default(ema_cloud_opts *o);   /* 50000, 0, 0, 0; no -d, the 10x density model */
+/* srand(seed) for -d, as the reference's first bad cloud does with time(NULL) (src/split.c:54-59); without a call the library seeds
+ * from the clock at its first use, like the reference */
+void ema_clouds_reseed(unsigned seed);
 
 /* per-bucket SAM statistics (the record the ranks gather) */
 typedef struct {

@@ -93,6 +93,9 @@ CASES = [
     ("haplotag", "plain", [dict(n_pairs=120, seed=504, per_bc=40, haplotag=True, sub_rate=0.01)], ["-p", "haplotag"]),
     ("x_two_buckets", "plain", [dict(n_pairs=80, seed=505, per_bc=40), dict(n_pairs=70, seed=506, per_bc=35, chimeric=0.1)], []),
     ("10x_150bp_mates", "dups", [dict(n_pairs=100, seed=507, per_bc=34, len1=150, len2=150, sub_rate=0.01, indel_rate=0.004)], []),
+    # -d: the density optimiser on bad clouds; the reference seeds rand() from time(), which ema_refhost sees as 1500000000 (oracle/bwaface.c)
+    ("density_opt_exact_dups", "dups", [dict(n_pairs=320, seed=508, per_bc=80, sub_rate=0.003, dup_frac=0.0, junk_frac=0.0)], ["-d"]),
+    ("density_opt_x_two_buckets", "dups", [dict(n_pairs=200, seed=509, per_bc=100, sub_rate=0.004, dup_frac=0.05), dict(n_pairs=180, seed=510, per_bc=60, sub_rate=0.004)], ["-d"]),
 ]
 
 

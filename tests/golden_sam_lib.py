@@ -50,6 +50,8 @@ class Run:
         self.haplotag = "-p" in argv and argv[argv.index("-p") + 1] == "haplotag"
         self.bc_len = 12 if self.haplotag else 16
         self.x_mode = "-x" in argv
+        self.density_opt = "-d" in argv      # the reference seeds rand() from time(): 1500000000 as ema_refhost saw it (oracle/bwaface.c)
+        self.density_seed = 1500000000
         self.rg_line = b"@RG\tID:rg1\tSM:sample1"      # the reference's default, src/main.c:25: never NULL
         if "-R" in argv:      # main.c:282 escape(): backslash-t etc. become the characters
             s = argv[argv.index("-R") + 1]

@@ -32,8 +32,11 @@ def test_stream_sam_equals_the_reference_host_code(case, tmp_path):
     fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     head = run.header(contigs)
     assert os.write(fd, head) == len(head)
+    if run.density_opt:
+        from ema_amd import clouds
+        clouds.reseed(run.density_seed)
     bst, sst = stream.stream_sam(eng, run.paths, fd, rg_id=run.rg_id, is_haplotag=run.haplotag, bc_len=run.bc_len,
-                                 continue_cloud_ids=run.x_mode, bx_index=run.bx_index)
+                                 continue_cloud_ids=run.x_mode, bx_index=run.bx_index, density_opt=run.density_opt)
     os.close(fd)
     eng.close()
     got = open(out, "rb").read()

@@ -430,4 +430,162 @@ int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_
 	return rc;
 }
 
+// ---- `ema align -1 a.fq [-2 b.fq]`: barcode-sorted FASTQ (include/ema_ingest.h; reference src/align.c:637-744, src/techs.c:5-69)
+namespace {
+struct FqRec { const char *id; uint32_t id_l; const char *rd; const char *ql; uint32_t rl; uint64_t bc; };
+
+bool slurp_file(const char *path, std::vector<char> &buf, std::string &err)
+{
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) { err = std::string(path) + ": " + strerror(errno); return false; }
+	struct stat st;
+	if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+		buf.resize((size_t)st.st_size);
+		std::atomic<int> bad{0};
+		parallel_ranges(buf.size(), (size_t)4 << 20, [&](size_t, size_t lo, size_t hi) {
+			size_t at = lo;
+			while (at < hi) {
+				const ssize_t got = pread(fd, buf.data() + at, hi - at, (off_t)at);
+				if (got < 0 && errno == EINTR) continue;
+				if (got <= 0) { bad.store(got < 0 ? errno : EIO); return; }
+				at += (size_t)got;
+			}
+		});
+		if (bad.load()) { err = std::string(path) + ": read: " + strerror(bad.load()); close(fd); return false; }
+	} else {
+		char tmp[1 << 16];
+		ssize_t got;
+		while ((got = read(fd, tmp, sizeof tmp)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+		if (got < 0) { err = std::string(path) + ": " + strerror(errno); close(fd); return false; }
+	}
+	close(fd);
+	return true;
+}
+
+// the records of one FASTQ text; false + message on a malformed one
+bool parse_fastq(const char *what, const std::vector<char> &buf, int name_style, int bc_len, int is_haplotag, int max_read_len,
+                 std::vector<FqRec> &out, std::string &err)
+{
+	const char *p = buf.data(), *end = p + buf.size();
+	size_t n_rec = 0;
+	auto line = [&](const char *&b, uint32_t &l) -> bool {      // next line without its newline (and without a '\r' before it)
+		if (p >= end) return false;
+		const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+		b = p;
+		const char *e = q ? q : end;
+		p = q ? q + 1 : end;
+		if (e > b && e[-1] == '\r') --e;
+		l = (uint32_t)(e - b);
+		return true;
+	};
+	auto bad = [&](const char *m) { err = std::string(what) + ": record " + std::to_string(n_rec + 1) + ": " + m; return false; };
+	for (;;) {
+		const char *id, *rd, *sp, *ql;
+		uint32_t id_l, rl, sl, qlen;
+		if (!line(id, id_l)) break;
+		if (id_l == 0 && p >= end) break;      // a trailing empty line
+		if (!line(rd, rl) || !line(sp, sl) || !line(ql, qlen)) return bad("truncated (the reference asserts, src/align.c:644-646)");
+		if (id_l < 2 || id[0] != '@') return bad("the name line does not start with '@'");
+		if (id_l > kMaxId) return bad("name of 150 bytes or more (id[150], include/samrecord.h:12)");
+		if (rl > (uint32_t)max_read_len) return bad("read longer than the limit");
+		if (qlen != rl) return bad("quality string and read differ in length");
+		FqRec r;
+		r.rd = rd; r.ql = ql; r.rl = rl;
+		// barcode and identifier, as the platform's extract_bc leaves them (src/techs.c:5-54)
+		const char *name_end = id + id_l;                 // the identifier ends here ...
+		const char *bc = nullptr;
+		const char *space = (const char *)memchr(id, ' ', id_l);
+		if (name_style == 1 && space && (size_t)(id + id_l - space) >= 6 && memcmp(space, " BX:Z:", 6) == 0) {      // tellseq, Long Ranger basic format
+			const char *colon = nullptr;
+			for (const char *c = id + id_l; c-- > space;) if (*c == ':') { colon = c; break; }
+			bc = colon + 1;
+			name_end = space;
+		} else {
+			const char *lim = id + id_l;
+			if (name_style == 1 && space) lim = space;      // tellseq: text after the first blank is dropped first
+			const char *colon = nullptr;
+			for (const char *c = lim; c-- > id;) if (*c == ':') { colon = c; break; }
+			if (!colon) return bad("no ':' before the barcode in the name (the reference asserts, src/techs.c:8,21)");
+			bc = colon + 1;
+			name_end = colon;
+			if (space && space < name_end) name_end = space;
+		}
+		if ((size_t)(id + id_l - bc) < (size_t)bc_len) return bad("barcode shorter than the platform's");
+		if (is_haplotag) r.bc = encode_haplotag(bc);
+		else if (encode_default(bc, bc_len, &r.bc)) return bad("barcode with a character outside ACGT (the reference asserts, src/util.c:54)");
+		r.id = id; r.id_l = (uint32_t)(name_end - id);
+		if (r.id_l < 2) return bad("empty identifier");
+		out.push_back(r);
+		++n_rec;
+	}
+	return true;
+}
+}  // namespace
+
+int ema_fastq_read(const char *path1, const char *path2, int name_style, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out)
+{
+	if (!out) return EMA_EARG;
+	*out = nullptr;
+	g_err.clear();
+	if (!path1 || bc_len < 1 || bc_len > 32 || max_read_len < 1 || max_read_len > 4096 || (is_haplotag && bc_len != 12) || name_style < 0 || name_style > 1)
+		return fail(EMA_EARG, "bad argument");
+	std::vector<char> t1, t2;
+	std::string err;
+	if (!slurp_file(path1, t1, err) || (path2 && !slurp_file(path2, t2, err))) return fail(EMA_EIO, err);
+	std::vector<FqRec> r1, r2;
+	if (!parse_fastq(path1, t1, name_style, bc_len, is_haplotag, max_read_len, r1, err)) return fail(EMA_EFORMAT, err);
+	if (path2 && !parse_fastq(path2, t2, name_style, bc_len, is_haplotag, max_read_len, r2, err)) return fail(EMA_EFORMAT, err);
+	size_t n;
+	std::vector<FqRec> m1, m2;
+	const std::vector<FqRec> *a = &r1, *b = &r2;
+	if (!path2) {      // interleaved: mate 1, mate 2, mate 1, ...
+		if (r1.size() & 1) return fail(EMA_EFORMAT, std::string(path1) + ": an odd number of records in an interleaved file");
+		for (size_t i = 0; i < r1.size(); i += 2) { m1.push_back(r1[i]); m2.push_back(r1[i + 1]); }
+		a = &m1; b = &m2;
+	}
+	n = a->size();
+	if (b->size() != n) return fail(EMA_EFORMAT, "the two files hold different numbers of records (the reference asserts, src/align.c:341)");
+	for (size_t i = 0; i < n; ++i) {
+		const FqRec &x = (*a)[i], &y = (*b)[i];
+		if (x.bc != y.bc) return fail(EMA_EFORMAT, "pair " + std::to_string(i + 1) + ": the mates carry different barcodes (the reference asserts, src/align.c:708,733)");
+		if (x.id_l != y.id_l || memcmp(x.id, y.id, x.id_l) != 0) return fail(EMA_EFORMAT, "pair " + std::to_string(i + 1) + ": the mates' identifiers differ");
+	}
+	ema_bucket *o = (ema_bucket *)calloc(1, sizeof(ema_bucket));
+	if (!o) { g_err = "out of memory"; return EMA_EIO; }
+	o->n_pairs = n;
+	o->bc = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+	o->off = (uint32_t *)malloc((2 * n + 1) * sizeof(uint32_t));
+	o->id_off = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+	if (!o->bc || !o->off || !o->id_off) { ema_bucket_free(o); g_err = "out of memory"; return EMA_EIO; }
+	uint64_t nb = 0, ni = 0;
+	for (size_t i = 0; i < n; ++i) {
+		o->bc[i] = (*a)[i].bc;
+		o->off[2 * i] = (uint32_t)nb; nb += (*a)[i].rl;
+		o->off[2 * i + 1] = (uint32_t)nb; nb += (*b)[i].rl;
+		o->id_off[i] = (uint32_t)ni; ni += (*a)[i].id_l;
+		if (nb > UINT32_MAX || ni > UINT32_MAX) { ema_bucket_free(o); return fail(EMA_EARG, "more than 4 GiB of bases or identifiers in one input; split it"); }
+	}
+	o->off[2 * n] = (uint32_t)nb; o->id_off[n] = (uint32_t)ni;
+	o->bases = (char *)malloc(nb + 1); o->quals = (char *)malloc(nb + 1); o->ids = (char *)malloc(ni + 1);
+	if (!o->bases || !o->quals || !o->ids) { ema_bucket_free(o); g_err = "out of memory"; return EMA_EIO; }
+	parallel_ranges(n, 1 << 12, [&](size_t, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			const FqRec &x = (*a)[i], &y = (*b)[i];
+			memcpy(o->bases + o->off[2 * i], x.rd, x.rl); memcpy(o->quals + o->off[2 * i], x.ql, x.rl);
+			memcpy(o->bases + o->off[2 * i + 1], y.rd, y.rl); memcpy(o->quals + o->off[2 * i + 1], y.ql, y.rl);
+			memcpy(o->ids + o->id_off[i], x.id, x.id_l);
+		}
+	});
+	size_t n_groups = 0;
+	for (size_t i = 0; i < n; ++i) n_groups += (i == 0 || o->bc[i] != o->bc[i - 1]);      // runs in FILE order: the input is trusted to be sorted
+	o->n_groups = n_groups;
+	o->group_off = (uint64_t *)malloc((n_groups + 1) * sizeof(uint64_t));
+	if (!o->group_off) { ema_bucket_free(o); g_err = "out of memory"; return EMA_EIO; }
+	size_t g = 0;
+	for (size_t i = 0; i < n; ++i) if (i == 0 || o->bc[i] != o->bc[i - 1]) o->group_off[g++] = i;
+	o->group_off[n_groups] = n;
+	*out = o;
+	return 0;
+}
+
 }  // extern "C"

@@ -160,7 +160,9 @@ void reader(Stream &S)
 		}
 		Item &it = S.items[k];
 		const double t0 = now_s();
-		const int rc = ema_bucket_read(S.paths[k], S.o.bc_len, S.o.is_haplotag, S.o.max_read_len, &it.bk);
+		const int rc = S.o.fastq_input
+			? ema_fastq_read(S.paths[k], S.o.paths2 ? S.o.paths2[k] : nullptr, S.o.fastq_name_style, S.o.bc_len, S.o.is_haplotag, S.o.max_read_len, &it.bk)
+			: ema_bucket_read(S.paths[k], S.o.bc_len, S.o.is_haplotag, S.o.max_read_len, &it.bk);
 		it.st.read_s = now_s() - t0;
 		if (rc != EMA_OK) { it.rc = rc; it.err = ema_bucket_last_error(); it.st.rc = rc; }
 		else { it.bases = it.bk->bases; it.off = it.bk->off; it.n_pairs = it.bk->n_pairs; }
@@ -480,6 +482,7 @@ void ema_stream_opts_default(ema_stream_opts *o)
 {
 	if (!o) return;
 	o->bc_len = 16; o->is_haplotag = 0; o->max_read_len = 255; o->error_rate = 0.001; o->n_engines = 0; o->read_ahead = 0;
+	o->fastq_input = 0; o->fastq_name_style = 0; o->paths2 = nullptr;
 }
 
 const char *ema_stream_last_error(void) { return g_err.c_str(); }

@@ -89,6 +89,18 @@ def read_bucket(path: str, bc_len: int = 16, is_haplotag: bool = False, max_read
     return _take(L, p)
 
 
+def read_fastq(path1: str, path2: str | None = None, bc_len: int = 16, is_haplotag: bool = False, max_read_len: int = 255,
+               name_style: int = 0) -> Bucket:
+    """ema_fastq_read: barcode-sorted FASTQ as `ema align -1 [-2]` takes it (path2 None: interleaved)."""
+    L = _lib()
+    L.ema_fastq_read.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(_Bucket))]
+    p = C.POINTER(_Bucket)()
+    rc = L.ema_fastq_read(path1.encode(), path2.encode() if path2 else None, name_style, bc_len, int(is_haplotag), max_read_len, C.byref(p))
+    if rc != 0:
+        raise BucketError(rc, L.ema_bucket_last_error().decode())
+    return _take(L, p)
+
+
 def parse_bucket(text: bytes, bc_len: int = 16, is_haplotag: bool = False, max_read_len: int = 255) -> Bucket:
     L = _lib()
     p = C.POINTER(_Bucket)()

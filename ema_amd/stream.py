@@ -14,7 +14,8 @@ STAT_FIELDS = ("pairs", "candidates", "reads_with_candidates", "records", "uniqu
 
 class StreamOpts(C.Structure):
     _fields_ = [("bc_len", C.c_int), ("is_haplotag", C.c_int), ("max_read_len", C.c_int), ("error_rate", C.c_double),
-                ("n_engines", C.c_int), ("read_ahead", C.c_int)]
+                ("n_engines", C.c_int), ("read_ahead", C.c_int), ("fastq_input", C.c_int), ("fastq_name_style", C.c_int),
+                ("paths2", C.POINTER(C.c_char_p))]
 
 
 class BucketStats(C.Structure):
@@ -173,7 +174,8 @@ def platform_opts(name: str) -> dict:
 
 
 def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None, is_haplotag: bool = False, bc_len: int = 16,
-               continue_cloud_ids: bool = False, n_engines: int = 0, bx_index: bytes | None = None, density_opt: bool = False):
+               continue_cloud_ids: bool = False, n_engines: int = 0, bx_index: bytes | None = None, density_opt: bool = False,
+               fastq_mates: list | None = None):
     """ema_stream_sam: bucket files -> SAM text on fd.  Returns (per-bucket stream stats, per-bucket SAM stats)."""
     from . import clouds as _clouds
     from . import sam as _sam
@@ -191,6 +193,12 @@ def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None
         o.sam.bx_index = bx_index
     o.continue_cloud_ids = int(continue_cloud_ids)
     o.clouds.density_opt = int(density_opt)
+    keep2 = None
+    if fastq_mates is not None:      # `ema align -1 [-2]`: paths are FASTQ files; fastq_mates[k] = the mate-2 file of paths[k] or None (interleaved)
+        o.stream.fastq_input = 1
+        if any(m is not None for m in fastq_mates):
+            keep2 = (C.c_char_p * len(paths))(*[m.encode() if m else None for m in fastq_mates])
+            o.stream.paths2 = keep2
     arr = (C.c_char_p * max(1, len(paths)))(*[p.encode() for p in paths])
     bst = (BucketStats * max(len(paths), 1))()
     sst = (_clouds.SamStats * max(len(paths), 1))()

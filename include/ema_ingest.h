@@ -54,6 +54,17 @@ int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_
 /* The same on a bucket already in memory (text[0 .. len)); text is not modified and need not end in a newline or NUL. */
 int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out);
 
+/* `ema align -1 a.fq [-2 b.fq]` (reference src/align.c:637-744, src/techs.c:5-69): barcode-sorted FASTQ, the barcode in the read
+ * name.  path2 == NULL: one file with the mates interleaved (read_fastq_rec_bc_group_interleaved), else mate 1 in path1 and mate 2
+ * in path2 (read_fastq_rec_bc_group on each).  Per record, as extract_bc_10x / _haplotag do: the barcode is the bc_len characters
+ * after the LAST ':' of the name line, the identifier is the name without its '@', cut at that ':' and at the first blank
+ * (Long Ranger style names); name_style 1 = tellseq (src/techs.c:31-54: a " BX:Z:" comment carries the barcode).  Barcode groups are
+ * the runs of equal barcode IN FILE ORDER -- the reference trusts the input to be sorted and so does this reader -- and both
+ * mates of a pair must carry the same barcode and the same identifier (the reference asserts the former, src/align.c:708,733).
+ * The result is laid out as ema_bucket_read's.  EMA_EFORMAT names the record where the reference would assert or read past a
+ * buffer (truncated record, name of 150 bytes or more, read beyond max_read_len, quality string of another length, bad barcode). */
+int ema_fastq_read(const char *path1, const char *path2, int name_style, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out);
+
 void ema_bucket_free(ema_bucket *b);
 
 /* Message of the last failed call on this thread ("" if none). */

@@ -37,6 +37,10 @@ typedef struct {
 	                                          * buckets on the engine and its ema_engine_peer(), one pass each */
 	int read_ahead;                          /* buckets parsed ahead of the engine (0 = default 2) -- or, with small buckets, as many as make up
 	                                          * that many full batches */
+	int fastq_input;                         /* 0: paths are bucket files (-s / -x); 1: barcode-sorted FASTQ as `ema align -1 [-2]` takes it
+	                                          * (ema_fastq_read, include/ema_ingest.h): paths[k] and, unless NULL, paths2[k] */
+	int fastq_name_style;                    /* ema_fastq_read's name_style */
+	const char *const *paths2;               /* fastq_input: mate-2 files, or NULL for interleaved input */
 } ema_stream_opts;
 void ema_stream_opts_default(ema_stream_opts *o);   /* 16, 0, 255, 0.001, 0, 0 */
 

@@ -84,6 +84,39 @@ def write_bucket(path, ctg, n_pairs, seed, per_bc, haplotag=False, dup_frac=0.1,
     return len(lines)
 
 
+def write_fastq(d, ctg, n_pairs, seed, per_bc, style, haplotag=False, interleaved=False, **kw):
+    """Barcode-sorted FASTQ as `ema align -1 [-2]` takes it: the barcode after the last ':' of the read name."""
+    pairs = synth.make_pairs(ctg, n_pairs, seed=seed, pairs_per_barcode=per_bc, **kw)
+    rng = random.Random(seed)
+    nrng = np.random.default_rng(seed)
+    codes = {}
+    recs = []
+    for i in range(pairs.n):
+        key = pairs.barcodes[i].tobytes()
+        if haplotag:
+            if key not in codes:
+                a, c, b, dd = (int(x) for x in nrng.integers(1, 97, 4))
+                codes[key] = ("A%02dC%02dB%02dD%02d" % (a, c, b, dd)).encode()
+            bc = codes[key]
+        else:
+            bc = key
+        r1, r2 = pairs.read(2 * i), pairs.read(2 * i + 1)
+        q1 = bytes(rng.choice(b"#,5:AFF") for _ in r1)
+        q2 = bytes(rng.choice(b"#,5:AFF") for _ in r2)
+        names = (b"@s%d 1:N:0:" % i + bc, b"@s%d 2:N:0:" % i + bc) if style == "longranger" else (b"@s%d:" % i + bc, b"@s%d:" % i + bc)
+        recs.append((bc, names, r1, q1, r2, q2))
+    recs.sort(key=lambda r: r[0])      # equal barcodes side by side, as the reference expects
+    m1 = b"".join(n[0] + b"\n" + r1 + b"\n+\n" + q1 + b"\n" for _bc, n, r1, q1, _r2, _q2 in recs)
+    m2 = b"".join(n[1] + b"\n" + r2 + b"\n+\n" + q2 + b"\n" for _bc, n, _r1, _q1, r2, q2 in recs)
+    if interleaved:
+        both = b"".join(n[0] + b"\n" + r1 + b"\n+\n" + q1 + b"\n" + n[1] + b"\n" + r2 + b"\n+\n" + q2 + b"\n" for _bc, n, r1, q1, r2, q2 in recs)
+        open(os.path.join(d, "reads.fq"), "wb").write(both)
+        return ["reads.fq"]
+    open(os.path.join(d, "r1.fq"), "wb").write(m1)
+    open(os.path.join(d, "r2.fq"), "wb").write(m2)
+    return ["r1.fq", "r2.fq"]
+
+
 CASES = [
     # name, reference, [bucket specs], extra argv
     ("10x_full_em", "plain", [dict(n_pairs=150, seed=501, per_bc=50, sub_rate=0.015, indel_rate=0.002, chimeric=0.05)], []),
@@ -95,6 +128,10 @@ CASES = [
     ("10x_150bp_mates", "dups", [dict(n_pairs=100, seed=507, per_bc=34, len1=150, len2=150, sub_rate=0.01, indel_rate=0.004)], []),
     # -d: the density optimiser on bad clouds; the reference seeds rand() from time(), which ema_refhost sees as 1500000000 (oracle/bwaface.c)
     ("density_opt_exact_dups", "dups", [dict(n_pairs=320, seed=508, per_bc=80, sub_rate=0.003, dup_frac=0.0, junk_frac=0.0)], ["-d"]),
+    # -1 / -2: barcode-sorted FASTQ, the barcode in the read name (src/align.c:637-744, src/techs.c:5-69)
+    ("fastq_two_files", "plain", [dict(fastq=True, n_pairs=110, seed=511, per_bc=37, style="plain", sub_rate=0.01, chimeric=0.05)], []),
+    ("fastq_interleaved_longranger_names", "plain", [dict(fastq=True, n_pairs=90, seed=512, per_bc=45, style="longranger", interleaved=True)], []),
+    ("fastq_interleaved_haplotag", "plain", [dict(fastq=True, n_pairs=80, seed=513, per_bc=40, style="plain", haplotag=True, interleaved=True)], ["-p", "haplotag"]),
     ("density_opt_x_two_buckets", "dups", [dict(n_pairs=200, seed=509, per_bc=100, sub_rate=0.004, dup_frac=0.05), dict(n_pairs=180, seed=510, per_bc=60, sub_rate=0.004)], ["-d"]),
 ]
 
@@ -117,7 +154,12 @@ def main():
         d = os.path.join(OUT, name)
         os.makedirs(d)
         buckets = []
+        fastq = bool(specs[0].get("fastq"))
         for k, spec in enumerate(specs):
+            if fastq:
+                spec = {x: y for x, y in spec.items() if x != "fastq"}
+                buckets = write_fastq(d, refs[ref], **spec)
+                break
             b = f"bucket{k}"
             write_bucket(os.path.join(d, b), refs[ref], **spec)
             buckets.append(b)
@@ -127,7 +169,9 @@ def main():
             os.symlink(os.path.join(work, f"{ref}.fa{ext}"), os.path.join(run, f"ref.fa{ext}"))
         for b in buckets:
             shutil.copy(os.path.join(d, b), os.path.join(run, b))
-        if len(buckets) == 1:
+        if fastq:
+            argv = ["ema", "align", "-1", buckets[0]] + (["-2", buckets[1]] if len(buckets) == 2 else []) + ["-r", "ref.fa", "-t", "1", "-o", "out.sam"] + extra
+        elif len(buckets) == 1:
             argv = ["ema", "align", "-s", buckets[0], "-r", "ref.fa", "-t", "1", "-o", "out.sam"] + extra
         else:
             argv = ["ema", "align", "-r", "ref.fa", "-t", "1", "-o", "out.sam"] + extra + ["-x"] + buckets

@@ -59,7 +59,17 @@ class Run:
         self.rg_id = None if self.rg_line is None else self.rg_line[self.rg_line.index(b"ID:") + 3:]      # src/align.c:255 -> samrecord.c:260-264
         self.bx_index = argv[argv.index("-i") + 1].encode() if "-i" in argv else b"1"
         self.paths = [os.path.join(GOLD, case["name"], b) for b in case["buckets"]]
+        self.fastq = "-1" in argv      # `-1 a.fq [-2 b.fq]`: ONE input, of one or two files
+        if self.fastq:
+            self.fastq_mate = self.paths[1] if "-2" in argv else None
+            self.paths = self.paths[:1]
         self.expected = open(os.path.join(GOLD, case["name"], "expected.sam"), "rb").read()
+
+    def read(self, path):
+        """The input as the product's reader lays it out (bucket file, or FASTQ as -1 / -2 take it)."""
+        if self.fastq:
+            return ingest.read_fastq(path, self.fastq_mate, bc_len=self.bc_len, is_haplotag=self.haplotag)
+        return ingest.read_bucket(path, bc_len=self.bc_len, is_haplotag=self.haplotag)
 
     def sam_opts(self):
         so = sam.default_opts()

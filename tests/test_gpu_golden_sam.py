@@ -36,7 +36,8 @@ def test_stream_sam_equals_the_reference_host_code(case, tmp_path):
         from ema_amd import clouds
         clouds.reseed(run.density_seed)
     bst, sst = stream.stream_sam(eng, run.paths, fd, rg_id=run.rg_id, is_haplotag=run.haplotag, bc_len=run.bc_len,
-                                 continue_cloud_ids=run.x_mode, bx_index=run.bx_index, density_opt=run.density_opt)
+                                 continue_cloud_ids=run.x_mode, bx_index=run.bx_index, density_opt=run.density_opt,
+                                 fastq_mates=[run.fastq_mate] if run.fastq else None)
     os.close(fd)
     eng.close()
     got = open(out, "rb").read()
@@ -47,7 +48,7 @@ def test_stream_sam_equals_the_reference_host_code(case, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_GPU), reason="oracle/_ref/ema_ref_gpu (reference objects + libema_bwaabi.so) did not travel")
-@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("10x_small_barcodes_rg", "x_two_buckets", "haplotag")],
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("10x_small_barcodes_rg", "x_two_buckets", "haplotag", "fastq_two_files")],
                          ids=lambda c: c["name"])
 def test_the_reference_binary_on_the_gpu_face_writes_the_same_sam(case, tmp_path):
     run = Run(case)
@@ -55,8 +56,8 @@ def test_the_reference_binary_on_the_gpu_face_writes_the_same_sam(case, tmp_path
     for ext in ("", ".fai", ".bwt", ".fsa", ".sa", ".pac", ".ann", ".amb"):
         if os.path.exists(prefix + ext):
             os.symlink(prefix + ext, str(tmp_path / ("ref.fa" + ext)))
-    for p in run.paths:
-        os.symlink(p, str(tmp_path / os.path.basename(p)))
+    for b in case["buckets"]:
+        os.symlink(os.path.join(os.path.dirname(run.paths[0]), b), str(tmp_path / b))
     p = subprocess.run(case["argv"], executable=REF_GPU, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert open(str(tmp_path / "out.sam"), "rb").read() == run.expected

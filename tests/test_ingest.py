@@ -221,3 +221,47 @@ def test_fixed_width_bucket_writer_reads_back_like_the_per_pair_writer(tmp_path)
     # equal barcodes keep file order, and both files list the pairs in the same order: the payloads line up
     assert bytes(ba.bases) == bytes(bb.bases) and bytes(ba.quals) == bytes(bb.quals)
     assert [int(ba.ident(i)[2:]) for i in range(700)] == [int(bb.ident(i)[2:]) for i in range(700)]
+
+
+def _fq(name, read, qual=None):
+    return b"@" + name + b"\n" + read + b"\n+\n" + (qual if qual is not None else b"F" * len(read)) + b"\n"
+
+
+def test_fastq_reader_of_align_1_2(tmp_path):
+    """ema_fastq_read (`ema align -1 [-2]`, reference src/align.c:637-744, src/techs.c:5-69): barcode after the last ':' of the name,
+    identifier cut at that ':' and at the first blank, groups = runs of equal barcode in FILE order, both mates agreeing.  (The
+    whole path on such input is held to the reference's own output in tests/test_golden_sam.py.)"""
+    bc1, bc2 = b"ACGTACGTACGTACGT", b"TTTTCCCCGGGGAAAA"
+    recs = [(b"s1", bc1, b"ACGTACGTAC", b"GGGGTTTTAA"), (b"s2", bc1, b"AAAACCCC", b"CCCCAAAATT"), (b"s3", bc2, b"ACGT", b"TTGA"), (b"s4", bc1, b"GGGG", b"CCCC")]
+    f1 = b"".join(_fq(n + b" 1:N:0:" + bc, r1) for n, bc, r1, _r2 in recs)
+    f2 = b"".join(_fq(n + b" 2:N:0:" + bc, r2) for n, bc, _r1, r2 in recs)
+    p1, p2 = tmp_path / "a.fq", tmp_path / "b.fq"
+    p1.write_bytes(f1); p2.write_bytes(f2)
+    b = ingest.read_fastq(str(p1), str(p2))
+    assert b.n_pairs == 4 and b.group_off.tolist() == [0, 2, 3, 4]      # the third barcode run is bc1 again: file order, not sorted
+    assert [b.ident(i) for i in range(4)] == [b"@s1", b"@s2", b"@s3", b"@s4"]
+    assert b.read(0) == b"ACGTACGTAC" and b.read(1) == b"GGGGTTTTAA" and b.read(6) == b"GGGG"
+    assert b.bc[0] == ingest.encode_barcode(bc1) and b.bc[2] == ingest.encode_barcode(bc2)
+    # the same pairs interleaved, names in the plain form name:BARCODE, CRLF line ends, no final newline
+    inter = b"".join(_fq(n + b":" + bc, r1) + _fq(n + b":" + bc, r2) for n, bc, r1, r2 in recs).replace(b"\n", b"\r\n")[:-2]
+    p3 = tmp_path / "ab.fq"
+    p3.write_bytes(inter)
+    c = ingest.read_fastq(str(p3))
+    assert c.n_pairs == 4 and c.bases.tobytes() == b.bases.tobytes() and c.ids.tobytes() == b.ids.tobytes() and c.bc.tolist() == b.bc.tolist()
+    # where the reference asserts or overruns a buffer, the reader names the record
+    for bad, what in ((f1[:-3], "differ in length"), (f1[:-6], "truncated"), (f1.replace(b"@s3", b"s3"), "does not start"), (f1 + b"@x:ACGT\nAC\n+\nFF\n", "shorter"),
+                      (f1.replace(bc2, b"TTTTCCCCGGGGAAAN"), "outside ACGT")):
+        p1.write_bytes(bad)
+        with pytest.raises(ingest.BucketError) as e:
+            ingest.read_fastq(str(p1), str(p2))
+        assert what in str(e.value), str(e.value)
+    p1.write_bytes(f1)
+    p2.write_bytes(f2.replace(b"s2 2:N:0:" + bc1, b"s2 2:N:0:" + bc2))
+    with pytest.raises(ingest.BucketError, match="different barcodes"):
+        ingest.read_fastq(str(p1), str(p2))
+    p2.write_bytes(f2[:len(f2) // 2 + 3])
+    with pytest.raises(ingest.BucketError):
+        ingest.read_fastq(str(p1), str(p2))
+    p3.write_bytes(_fq(b"s1:" + bc1, b"ACGT") * 3)
+    with pytest.raises(ingest.BucketError, match="odd number"):
+        ingest.read_fastq(str(p3))

@@ -178,6 +178,7 @@ extern "C" int ema_count_fastq(const char *known_barcodes_path, int in_fd, const
 	std::vector<Parsed> parsed;
 	size_t have = 0;
 	bool eof = false;
+	std::string prev_q1;      // line 4 (mate 1's qualities) of the last pair seen: what the reference's `q` still holds when a getline fails
 	while (!eof || have > 0) {
 		while (!eof && have < blk.size()) {
 			const ssize_t got = read(in_fd, blk.data() + have, blk.size() - have);
@@ -196,8 +197,14 @@ extern "C" int ema_count_fastq(const char *known_barcodes_path, int in_fd, const
 		const size_t tail_at = n_lines ? nl.back() + 1 : 0;
 		if (eof && tail_at < have) ++n_lines;      // a last line without its line end: std::getline returns it all the same
 		size_t n_rec = n_lines / 8;
-		const size_t missing = (eof && n_lines % 8) ? 8 - n_lines % 8 : 0;      // the stream ends inside a pair: its missing lines read as empty
+		const size_t missing = (eof && n_lines % 8) ? 8 - n_lines % 8 : 0;      // the stream ends inside a pair
 		if (missing) ++n_rec;
+		// What the reference reads for the missing lines (cpp/count.cc:86-108): a getline that fails BEFORE the stream has hit its end
+		// erases its string and then sets the end flag -- the line reads as empty -- but once the flag is set (the last line present had
+		// no line end, so reading it hit the end) every further getline leaves its string untouched: the read then takes the NAME
+		// line for its bases (one line present) and the PREVIOUS pair's mate-1 qualities for its own (one or two lines present).
+		const bool open_tail = eof && tail_at < have;
+		const size_t stale_lines = (missing && open_tail) ? n_lines % 8 : 0;      // 1 or 2: the stale strings matter; 3 and up: they do not
 		if (n_rec == 0) {
 			if (eof) break;
 			blk.resize(blk.size() * 2);
@@ -214,7 +221,14 @@ extern "C" int ema_count_fastq(const char *known_barcodes_path, int in_fd, const
 		auto work = [&](int t) {
 			const size_t lo = std::min(n_rec, (size_t)t * per), hi = std::min(n_rec, (size_t)(t + 1) * per);
 			for (size_t rec = lo; rec < hi; ++rec) {
-				const LineRef name = line(8 * rec), seq = line(8 * rec + 1), q = line(8 * rec + 3);
+				const LineRef name = line(8 * rec);
+				LineRef seq = line(8 * rec + 1), q = line(8 * rec + 3);
+				if (stale_lines && rec + 1 == n_rec) {      // the cut-short last pair of a stream without a final line end
+					if (stale_lines == 1) seq = name;
+					if (stale_lines <= 2) {
+						if (rec > 0) q = line(8 * rec - 5); else q = LineRef{prev_q1.data(), prev_q1.size()};
+					}
+				}
 				Parsed &o = parsed[rec];
 				bool bx = false;
 				uint32_t barcode = 0;
@@ -275,6 +289,7 @@ extern "C" int ema_count_fastq(const char *known_barcodes_path, int in_fd, const
 			}
 			++s.total_reads;
 		}
+		if (n_rec) { const LineRef l4 = line(8 * (n_rec - 1) + 3); if (8 * (n_rec - 1) + 3 < n_lines) prev_q1.assign(l4.p, l4.len); }
 		const size_t used = 8 * n_rec <= nl.size() ? nl[8 * n_rec - 1] + 1 : have;
 		s.bytes += (int64_t)used + (int64_t)missing + ((eof && tail_at < have) ? 1 : 0);      // the reference's `sz`: every line's length + 1, failed getlines included
 		memmove(blk.data(), blk.data() + used, have - used);

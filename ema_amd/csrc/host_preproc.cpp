@@ -312,6 +312,7 @@ extern "C" int ema_preproc_fastq(const char *known_barcodes_path, const char *co
 	size_t have = 0;
 	bool eof = false;
 	size_t prev_last_len = 0;      // the length of `s` when a name line is examined: the previous pair's last line (cpp/correct.cc:446)
+	std::string prev_r, prev_q, prev_s;      // the previous pair's lines 2, 4 and 8: what the reference's `r`, `q`, `s` still hold when a getline fails
 	std::vector<size_t> nl;
 	std::vector<std::vector<std::string>> tbuf((size_t)n_threads, std::vector<std::string>((size_t)n_buckets + 1));
 	std::vector<std::string> terr((size_t)n_threads);
@@ -335,7 +336,12 @@ extern "C" int ema_preproc_fastq(const char *known_barcodes_path, const char *co
 		const bool open_tail = eof && tail_at < have;      // a last line without its line end: std::getline returns it all the same
 		if (open_tail) ++n_lines;
 		size_t n_rec = n_lines / 8;
-		if (eof && n_lines % 8) ++n_rec;      // the stream ends inside a pair: its missing lines read as empty, as failed getlines leave them
+		if (eof && n_lines % 8) ++n_rec;      // the stream ends inside a pair
+		// What the reference reads for the missing lines (cpp/correct.cc:427-430,573,596,607-608): the first getline that fails erases
+		// its string and sets the end flag, so the line reads as empty -- unless the flag is up already, because the last line present
+		// had no line end: then every further getline leaves its string as it was, and the cut-short pair is written with the
+		// previous pair's (or its own earlier) lines in the missing places.
+		const size_t stale_lines = (eof && n_lines % 8 && open_tail) ? n_lines % 8 : 0;
 		if (n_rec == 0) {
 			if (eof) break;
 			blk.resize(blk.size() * 2);      // a pair longer than the block
@@ -355,8 +361,21 @@ extern "C" int ema_preproc_fastq(const char *known_barcodes_path, const char *co
 			char bcd[kBcLen + 1]; bcd[kBcLen] = 0;
 			char hbc[12];
 			for (size_t rec = lo; rec < hi; ++rec) {
-				const LineRef n = line(8 * rec), r = line(8 * rec + 1), q = line(8 * rec + 3);
-				const LineRef m_name = line(8 * rec + 4), m_read = line(8 * rec + 5), m_qual = line(8 * rec + 7);
+				const LineRef n = line(8 * rec);
+				LineRef r = line(8 * rec + 1), q = line(8 * rec + 3);
+				LineRef m_name = line(8 * rec + 4), m_read = line(8 * rec + 5), m_qual = line(8 * rec + 7);
+				if (stale_lines && rec + 1 == n_rec) {      // the cut-short last pair of a stream without a final line end (see above)
+					const LineRef pr = rec ? line(8 * rec - 7) : LineRef{prev_r.data(), prev_r.size()};
+					const LineRef pq = rec ? line(8 * rec - 5) : LineRef{prev_q.data(), prev_q.size()};
+					const LineRef ps = rec ? line(8 * rec - 1) : LineRef{prev_s.data(), prev_s.size()};
+					if (stale_lines == 1) r = pr;
+					if (stale_lines <= 2) q = pq;
+					if (stale_lines == 3) q = line(8 * rec + 2);                 // the '+' line is what `q` holds
+					if (stale_lines <= 4) m_name = m_read = m_qual = ps;
+					if (stale_lines == 5) m_read = m_qual = m_name;
+					if (stale_lines == 6) m_qual = m_read;
+					if (stale_lines == 7) m_qual = line(8 * rec + 6);            // the mate's '+' line
+				}
 				const size_t last_len = rec ? line(8 * rec - 1).len : prev_last_len;
 				bool process = r.len >= (size_t)kMinRead;
 				uint32_t barcode = 0;
@@ -388,7 +407,11 @@ extern "C" int ema_preproc_fastq(const char *known_barcodes_path, const char *co
 					b.b[i] = (unsigned char)(code2n(base) * kQualBase + qv);
 				}
 				if (!process) { ++t_skipped[(size_t)t]; continue; }
-				if (r.len != q.len) { terr[(size_t)t] = "a quality line whose length differs from its read's (the reference's output is undefined there): " + std::string(n.p, n.len); return; }
+				// The reference copies q.size() - 23 quality characters and then advances by r.size() - 23 (cpp/correct.cc:558-565): a LONGER
+				// quality line is cut to the read's length by whatever is written next -- reproduced; a SHORTER one leaves a gap of
+				// whatever the bucket's buffer held -- undefined output, refused.
+				if (q.len > r.len) q.len = r.len;
+				if (r.len != q.len) { terr[(size_t)t] = "a quality line shorter than its read (the reference's output is undefined there): " + std::string(n.p, n.len); return; }
 				if (!is_haplotag) {
 					auto cit = corrected.find(b);
 					if (cit != corrected.end()) { barcode = cit->second; has_n = false; }
@@ -439,7 +462,7 @@ extern "C" int ema_preproc_fastq(const char *known_barcodes_path, const char *co
 			for (auto &x : th) x.join();
 		}
 		for (int t = 0; t < n_threads && rc == EMA_OK; ++t) if (!terr[(size_t)t].empty()) { rc = EMA_EFORMAT; g_err = terr[(size_t)t]; }
-		// (on an error the pairs of this block before the offending one are still written, as the reference would have written them)
+		// (on an error nothing of this block is written: EMA_EFORMAT ends the run where the reference's output turns undefined)
 		for (size_t f = 0; f < files.size(); ++f) for (int t = 0; t < n_threads; ++t) {
 			std::string &o = tbuf[(size_t)t][f];
 			if (o.empty()) continue;
@@ -449,6 +472,10 @@ extern "C" int ema_preproc_fastq(const char *known_barcodes_path, const char *co
 		for (int t = 0; t < n_threads; ++t) { S.pairs_written += t_written[(size_t)t]; S.pairs_nobc += t_nobc[(size_t)t]; S.pairs_skipped += t_skipped[(size_t)t]; t_written[(size_t)t] = t_nobc[(size_t)t] = t_skipped[(size_t)t] = 0; }
 		if (rc != EMA_OK) break;
 		prev_last_len = line(8 * n_rec - 1).len;
+		if (8 * n_rec <= n_lines) {      // (a complete last pair: what the strings hold when the next block's first pair is read)
+			const LineRef l2 = line(8 * n_rec - 7), l4 = line(8 * n_rec - 5), l8 = line(8 * n_rec - 1);
+			prev_r.assign(l2.p, l2.len); prev_q.assign(l4.p, l4.len); prev_s.assign(l8.p, l8.len);
+		}
 		const size_t used = 8 * n_rec <= nl.size() ? nl[8 * n_rec - 1] + 1 : have;
 		memmove(blk.data(), blk.data() + used, have - used);
 		have -= used;

@@ -20,9 +20,12 @@
  * containers whose iteration order decides floating-point sums and the deal are the reference's own kinds filled in the same
  * order, and every double-precision expression is the reference's, in its order (same libm).  Reproduced on purpose: in
  * haplotag mode the reference tests the BX tag's position against the length of the PREVIOUS pair's last line (cpp/correct.cc:446
- * uses `s`, not `n`), so the first pair of a haplotag stream is always dropped.  Not reproduced: for a quality line whose length
- * differs from its read's the reference copies one length and advances by the other (:545-553, uninitialised bytes or a
- * truncated record); that is EMA_EFORMAT here.  Host code; links into libema_engine.so.
+ * uses `s`, not `n`), so the first pair of a haplotag stream is always dropped; a quality line LONGER than
+ * its read is cut to the read's length (the reference copies one length and advances by the other, :558-565: its next write
+ * overwrites the surplus); a stream that ends inside a pair without a final line end is written from the strings the reference's
+ * failed getlines leave untouched (the previous pair's lines, :427-430,573,596,607-608; golden vectors cut_short_*).  Not
+ * reproduced: a quality line SHORTER than its read leaves a gap of whatever the reference's buffer held; that is EMA_EFORMAT
+ * here.  Host code; links into libema_engine.so.
  */
 #ifndef EMA_PREPROC_H
 #define EMA_PREPROC_H

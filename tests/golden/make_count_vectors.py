@@ -33,6 +33,15 @@ def main():
             wl_text += wl[0] + "\n" + wl[1][:16] + "TTTT\n"      # a duplicate line and a line longer than a barcode
         fq = K.tenx_fastq(seed, wl, n, nl)
         cases.append({"name": f"10x_{seed}", "whitelist": wl_text, "fastq": fq, "max_map_size": max_map, "haplotag": 0, "expect": run_ref(wl_text, fq, max_map, False)})
+    # a stream cut short inside its last pair WITHOUT a final line end: the reference's later getlines leave their strings as they were
+    # (the read takes the previous pair's qualities, or the name line for its bases: cpp/count.cc:86-108)
+    wl = K.whitelist(rng, 20)
+    wl_text = "\n".join(wl) + "\n"
+    lines = K.tenx_fastq(11, wl, 40).split("\n")
+    for k in (1, 2, 3, 5):
+        fq = "\n".join(lines[:8 * 39 + k])
+        cases.append({"name": f"cut_short_after_{k}_lines_no_final_newline", "whitelist": wl_text, "fastq": fq, "max_map_size": 1 << 20, "haplotag": 0,
+                      "expect": run_ref(wl_text, fq, 1 << 20, False)})
     json.dump({"made_by": "tests/golden/make_count_vectors.py with oracle/_ref/ref_count (reference cpp/count.cc)", "cases": cases},
               open(os.path.join(R, "tests", "golden", "count_vectors.json"), "w"), indent=0)
     print(len(cases), "cases")

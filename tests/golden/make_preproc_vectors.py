@@ -21,6 +21,16 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             want = T.run_reference(pathlib.Path(d) / "r", wl_text, fq, False, **dict(args))
         cases.append({"name": f"10x_{seed}", "whitelist": wl_text, "fastq": fq, "haplotag": 0, "args": args, "expect": T.digest(want)})
+    # a stream cut short inside its last pair without a final line end: the missing lines read as what the reference's strings still
+    # hold (cpp/correct.cc:427-430,573,596,607-608); 4..7 lines present: the mate is written from stale strings
+    wl = K.whitelist(rng, 20)
+    wl_text = "\n".join(wl) + "\n"
+    lines = T.well_formed(K.tenx_fastq(11, wl, 40)).split("\n")
+    for k in (1, 4, 5, 6, 7):
+        fq = "\n".join(lines[:8 * 39 + k])
+        with tempfile.TemporaryDirectory() as d:
+            want = T.run_reference(pathlib.Path(d) / "r", wl_text, fq, False, n_buckets=3)
+        cases.append({"name": f"cut_short_after_{k}_lines_no_final_newline", "whitelist": wl_text, "fastq": fq, "haplotag": 0, "args": dict(n_buckets=3), "expect": T.digest(want)})
     json.dump({"made_by": "tests/golden/make_preproc_vectors.py with oracle/_ref/ref_count + ref_preproc (reference cpp/count.cc, cpp/correct.cc)",
                "cases": cases}, open(os.path.join(R, "tests", "golden", "preproc_vectors.json"), "w"), indent=0)
     print(len(cases), "cases")

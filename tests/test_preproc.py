@@ -79,9 +79,14 @@ def test_statistics_threads_and_errors(tmp_path):
     line = next(l for f in sorted(a) if f != "ema-nobc" for l in a[f].decode().split("\n") if l)
     bc, name, r1, q1, r2, q2 = line.split(" ")
     assert len(bc) == 16 and len(r1) == len(q1) and len(r2) == len(q2) and name.startswith("@r")
-    bad = K.record("x 1", wl[0] + "ACGT" * 8, "F" * 49) + fq      # a quality line longer than its read: undefined in the reference, an error here
+    bad = K.record("x 1", wl[0] + "ACGT" * 8, "F" * 40) + fq      # a quality line SHORTER than its read: the reference writes whatever its buffer held, an error here
     with pytest.raises(RuntimeError, match="quality line"):
         run_product(tmp_path / "bad", wl_text, bad, False, n_buckets=3)
+    longer = K.record("x 1", wl[0] + "ACGT" * 8, "F" * 47 + "#,") + fq      # a LONGER one is cut to the read's length by the reference's next write: reproduced
+    got, _ = run_product(tmp_path / "longer", wl_text, longer, False, n_buckets=3)
+    assert any(b" @x " in v and b"#," not in v.split(b" @x ")[1].split(b"\n")[0] for v in got.values())
+    if os.path.exists(REF):
+        assert got == run_reference(tmp_path / "longer_ref", wl_text, longer, False, n_buckets=3)
     with pytest.raises(RuntimeError, match="not an ema-ncnt"):
         ema_preproc.preproc_fastq(str(tmp_path / "t1" / "wl.txt"), [str(tmp_path / "t1" / "wl.txt")], str(tmp_path / "o"), str(tmp_path / "t1" / "in.fastq"))
 

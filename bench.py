@@ -628,7 +628,7 @@ def main(argv=None):
         knobs = [k for k in ENGINE_KNOBS if k in os.environ]
         default_run = (args.pairs == 1048576 and n_slices == 3 and args.lean_seed_extends == 0 and not knobs)
         traffic, traffic_source = None, None
-        pmc_name = {0.0: "r02_pmc_chr20.csv", 3100.0: "r02_pmc_grch38scale.csv"}.get(float(args.genome_mbp))
+        pmc_name = {0.0: "r03_pmc_chr20.csv", 3100.0: "r03_pmc_grch38scale.csv"}.get(float(args.genome_mbp))
         tab = pmc_table(pmc_name) if (pmc_name and default_run) else None
         k1_name = next((k for k in ("ema_k_seed_t<false>", "ema_k_seed") if tab and (k, "FETCH_SIZE") in tab and (k, "WRITE_SIZE") in tab), None)
         if k1_name:      # (the product build of the template, or the plain kernel of older profiles)

@@ -17,7 +17,7 @@ if [[ $what == *tests* ]]; then
 fi
 if [[ $what == *bench* ]]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/gather_mb "$root/tools/gather_microbench.hip" 2> /dev/null && timeout 300 /tmp/gather_mb > "$out/gather_mb.txt" 2>&1; echo "gather: rc=$?"
-  timeout 1500 python3 "$root/bench.py" > "$out/bench.json" 2> "$out/bench.err"; echo "bench: rc=$?"; cut -c1-600 "$out/bench.json"; tail -25 "$out/bench.err"
+  EMA_INDEX_PROF=1 timeout 1500 python3 "$root/bench.py" > "$out/bench.json" 2> "$out/bench.err"; echo "bench: rc=$?"; cut -c1-600 "$out/bench.json"; tail -25 "$out/bench.err"
   timeout 300 python3 "$root/tools/cpu_seed_profile.py" > "$out/seed_profile.txt" 2>&1; echo "seedprof: rc=$?"
   EMA_PHASE_PROFILE=2 timeout 600 python3 "$root/tools/gpu_readlog.py" "$tag" > "$out/readlog.txt" 2>&1; echo "readlog: rc=$?"; tail -40 "$out/readlog.txt"
 fi

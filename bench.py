@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 VALU_PEAK_GINST = 256 * 4 * 0.5 * 2.4
 CHR20_LEN = 64_444_167
 ENGINE_KNOBS = ("EMA_SEED_ROUNDS", "EMA_SEED_PARK", "EMA_SEED_BLOCKS_PER_CU", "EMA_FULL_SEED_LANE", "EMA_LANE_ALIGN", "EMA_FULL_OWN_STREAM",
-                "EMA_KMER_K", "EMA_MID_ALIGN", "EMA_AV_LDS", "EMA_HEAVY_CHAINS")
+                "EMA_KMER_K", "EMA_HEAVY_CHAINS")
 
 
 def log(*a):

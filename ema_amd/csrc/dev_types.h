@@ -95,7 +95,6 @@ struct ChainRec {
 // {n_chn, n_seed}, the filter's sorted keys (weight << 32 | chain), the chains, the seed pool.  A todo-list entry with
 // bit 31 set says the record is there.
 #define EMA_HAND_SEEDS 32
-#define EMA_MID_SEEDS 192      // seed occurrences up to which K2b keeps a read's chaining tables in LDS (its one-block-per-CU build)
 #define EMA_HAND_BYTES ((size_t)16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)))
 #define EMA_HAND_FLAG 0x80000000u
 

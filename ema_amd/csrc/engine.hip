@@ -47,15 +47,14 @@ extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
                                  DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs,
-                                 int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof, int variant,
+                                 int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof,
                                  const HeavyCtl *heavy, int mode);
-extern "C" int ema_align_mid_blocks_per_cu(int variant);
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
-                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int *todo_mid,
-                                        int *n_todo_mid, int mid_seeds, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof);
+                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo,
+                                        uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" int ema_align_blocks_per_cu();
 extern "C" int ema_pair_blocks_per_cu();
@@ -163,7 +162,7 @@ struct Slice {
 	size_t cap_pairs = 0, n_pairs = 0, first_pair = 0;
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
 	DevBuf<Intv> d_intv, d_lists;
-	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo, d_todo_mid;
+	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo;
 	DevBuf<DevReg> d_regs;
 	DevBuf<uint8_t> d_heavy;                      // chain-rich reads set aside by K2b: records (dev_types.h, HeavyCtl)
 	DevBuf<unsigned long long> d_heavy_reads, d_heavy_tasks;
@@ -195,7 +194,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_todo_mid.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
+		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -268,15 +267,11 @@ struct ema_engine {
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
-	int mid_align = 0;                   // EMA_MID_ALIGN=1: LDS build of K2b for reads with 33..192 seed occurrences (one block per CU); 2: for 33..80 (two blocks); 0: none
-	bool av_lds = true;                  // EMA_AV_LDS=0: region lists in the HBM slab
 	bool split_handed = true;            // EMA_SPLIT_HANDED=0: one K2b launch for everything on K2a's list
-	int align_wps = 4;                   // EMA_ALIGN_WPS=3: K2b built for three blocks per CU (measurement)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)
 	int heavy_regions = 8;               // K4b sets a read with at least this many regions left aside for K4t / K4r (0: never)
 	int heavy_chains = 32;               // EMA_HEAVY_CHAINS: K2b sets a read with at least this many chains to extend aside for K2c / K2d (0: never)
-	int align_mid_blocks = 0;
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
@@ -346,7 +341,6 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_kdone.alloc(n_reads));
 	HIPCHK(e, s.d_hand.alloc(n_reads * EMA_HAND_BYTES));
 	HIPCHK(e, s.d_todo.alloc(n_reads));
-	HIPCHK(e, s.d_todo_mid.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
 	if (e->watchdog_s > 0 && !getenv("EMA_WATCHDOG_NOMARK")) {
@@ -528,15 +522,11 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
-	if (const char *v = getenv("EMA_MID_ALIGN")) e->mid_align = atoi(v);
-	if (const char *v = getenv("EMA_AV_LDS")) e->av_lds = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
 	if (const char *v = getenv("EMA_HEAVY_ATTEMPTS")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
 	if (const char *v = getenv("EMA_HEAVY_REGIONS")) e->heavy_regions = std::max(0, atoi(v));        //  pair / read takes the set-aside route)
 	if (const char *v = getenv("EMA_SMALL_ONE_SLICE")) e->small_one_slice = atoi(v) != 0;
-	if (const char *v = getenv("EMA_ALIGN_WPS")) e->align_wps = atoi(v);
 	if (const char *v = getenv("EMA_SPLIT_HANDED")) e->split_handed = atoi(v) != 0;
-	e->align_mid_blocks = e->n_cu * ema_align_mid_blocks_per_cu(e->mid_align == 2 ? 3 : 1);
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
 	if (n_streams > 16) n_streams = 16;
@@ -801,14 +791,13 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 static int run_align(ema_engine *e, Slice &s, const Work &w)
 {
 	// K2a: small reads, one lane each; the others land on the todo list that K2b (one wavefront per read) works through
-	const bool mid = e->lane_align && e->mid_align > 0;
 	if (e->lane_align) {
 		ema_launch_align_simple(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21,
-		                        mid ? s.d_todo_mid.p : nullptr, s.d_counters.p + 24, e->mid_align == 2 ? 80 : EMA_MID_SEEDS, s.d_hand.p, e->lane_blocks, s.stream, e->d_prof.p);
+		                        s.d_hand.p, e->lane_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
-	// K2b, bulk build: K2a's hand-overs and the repeat-rich reads; then the LDS build for the reads in between
+	// K2b: K2a's hand-overs on their own build (mode 3), then the reads with many seed occurrences (mode 0)
 	HeavyCtl hv;
 	const bool heavy = s.d_heavy.p != nullptr;
 	const bool split = e->lane_align && e->split_handed;      // K2a's hand-overs on their own build of K2b, ahead of the rest
@@ -817,7 +806,7 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	if (split) {
 		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                 s.d_n_regs.p, s.d_status.p, s.d_todo.p, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 22,
-		                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, 0, &hv, 3);
+		                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, &hv, 3);
 		HIPCHK(e, hipGetLastError());
 	}
 	if (heavy) {
@@ -827,19 +816,13 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	}
 	ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 	                 s.d_n_regs.p, s.d_status.p, e->lane_align ? s.d_todo.p : nullptr, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 0,
-	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, e->align_wps == 3 ? 4 : e->av_lds ? 0 : 2, &hv, 0);
+	                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, &hv, 0);
 	HIPCHK(e, hipGetLastError());
-	if (mid) {
-		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
-		                 s.d_n_regs.p, s.d_status.p, s.d_todo_mid.p, s.d_counters.p + 24, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 25,
-		                 e->align_mid_blocks, s.stream, s.dbg, e->d_prof.p, e->mid_align == 2 ? 3 : 1, nullptr, 0);
-		HIPCHK(e, hipGetLastError());
-	}
 	if (heavy) {      // K2c: the chains of the reads set aside, one per wavefront; K2d: their replay, dedup and output
 		for (int mode = 1; mode <= 2; ++mode) {
 			ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 			                 s.d_n_regs.p, s.d_status.p, nullptr, nullptr, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 27 + mode,
-			                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, 0, &hv, mode);
+			                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, &hv, mode);
 			HIPCHK(e, hipGetLastError());
 		}
 	}

@@ -39,15 +39,9 @@ struct AlignSlab {           // per resident wave
 // Most reads have a few dozen seed occurrences at most.  Their chaining tables then sit in LDS instead of the HBM slab:
 // chaining is a sequence of dependent small look-ups and edits (find the neighbouring chain, test, link the seed), and
 // each one costs a memory round trip when the tables are in HBM.
-// Two builds of the kernel differ in how much of that fits (template parameters SMALL = seed occurrences whose tables sit in
-// LDS, AVL = regions before de-duplication kept in LDS):
-//   ema_k_align_t<32, 8, 4>    the bulk: reads K2a hands over with their chains ready (<= EMA_HAND_SEEDS seeds) and the
-//                              repeat-rich ones (> EMA_MID_SEEDS occurrences: tables in the HBM slab); 16 waves per CU
-//   ema_k_align_t<192, 24, 1>  reads with 33..192 seed occurrences -- 12 % of the reads and 60 % of this stage's wave clocks
-//                              at the default scale while their tables were in HBM (every chaining step a handful of dependent
-//                              round trips at loaded-memory latency); one block per CU, everything in LDS.
-// K2a sorts the reads into the two work lists.
-// In between (more occurrences than SMALL, at most EMA_MED_CHAINS chains -- a tenth of the reads and, while everything of
+// The build is ema_k_align_t<32, 8, 4> (template parameters SMALL = seed occurrences whose tables sit in LDS, AVL = regions before
+// de-duplication kept in LDS, blocks per SIMD): 16 waves per CU.
+// Above SMALL occurrences ( at most EMA_MED_CHAINS chains -- a tenth of the reads and, while everything of
 // theirs sat in the slab, two fifths of this kernel's wave clocks): the chain and seed RECORDS stay in the slab, but the
 // structures every step searches or walks sit in LDS that is idle in that phase --
 //   chaining:  the sorted chain positions and their ids (cpos in the reference-window buffer, cord in the small-table area):
@@ -1024,14 +1018,14 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
-// variant 0: the bulk build (K2a's hand-overs and the repeat-rich reads), 16 waves per CU; 1: the LDS build for the reads with up
-// to EMA_MID_SEEDS seed occurrences, one block per CU; 2: the bulk build without the LDS region list; 3: LDS build for up to 80
-// occurrences, two blocks per CU  (2 and 3: measurement variants, EMA_AV_LDS=0 / EMA_MID_ALIGN=2)
+// mode 0: K2b (reads K2a could not finish and has no chains for: chaining, filter, extension or setting aside); 1: K2c; 2: K2d;
+// 3: the reads K2a handed over with their chains ready.  (Round 2's measurement builds -- everything in LDS at one or two blocks per
+// CU, the region list in the slab, three blocks per CU -- were measured, lost (profiles/r02c_k2b_variants.txt) and are gone.)
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs, int *n_regs, int *status,
                                  const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs, int *counter, int n_blocks,
                                  hipStream_t stream, int *dbg,
-                                 unsigned long long *prof, int variant, const HeavyCtl *heavy, int mode)
+                                 unsigned long long *prof, const HeavyCtl *heavy, int mode)
 {
 	HeavyCtl hv;
 	if (heavy) hv = *heavy;
@@ -1042,10 +1036,6 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 	if (mode == 1) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 1, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 1, false); }      // K2c: one chain of a read set aside per wavefront
 	else if (mode == 2) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 2, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 2, false); } // K2d: the replay of a read set aside
 	else if (mode == 3) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 3, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 3, false); } // the reads handed over by K2a
-	else if (variant == 1) EMA_ALIGN_LAUNCH(EMA_MID_SEEDS, 24, 1, 0, false);
-	else if (variant == 2) EMA_ALIGN_LAUNCH(32, 0, 4, 0, false);
-	else if (variant == 3) EMA_ALIGN_LAUNCH(80, 16, 2, 0, false);
-	else if (variant == 4 && !diag) EMA_ALIGN_LAUNCH(32, 8, 3, 0, false);      // measurement: three blocks per CU, 168 registers
 	else if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 0, true);
 	else EMA_ALIGN_LAUNCH(32, 8, 4, 0, false);
 #undef EMA_ALIGN_LAUNCH
@@ -1056,13 +1046,5 @@ extern "C" int ema_align_blocks_per_cu()
 {
 	int n = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4, 0, false>, 256, 0) != hipSuccess || n < 1) n = 1;
-	return n > 8 ? 8 : n;
-}
-extern "C" int ema_align_mid_blocks_per_cu(int variant)
-{
-	int n = 0;
-	hipError_t rc = variant == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<80, 16, 2, 0, false>, 256, 0)
-	                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<EMA_MID_SEEDS, 24, 1, 0, false>, 256, 0);
-	if (rc != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

@@ -255,7 +255,7 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,
                    uint8_t *__restrict__ scratch, int *__restrict__ counter, int *__restrict__ todo, int *__restrict__ n_todo,
-                   int *__restrict__ todo_mid, int *__restrict__ n_todo_mid, int mid_seeds, uint8_t *__restrict__ hand, unsigned long long *prof_arg)
+                   uint8_t *__restrict__ hand, unsigned long long *prof_arg)
 {
 	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	// diagnostic phase timing (prof != null): shader clocks per phase of this wave (all lanes move together)
@@ -290,12 +290,7 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 			small = tot <= EMA_LANE_SEEDS;      // which also means: no interval above max_occ, frac_rep = 0
 		}
 		if (!small) {
-			// K2b's work lists: its LDS build takes the reads whose chaining tables fit there (at most EMA_MID_SEEDS seed
-			// occurrences, counted as mem_chain will look them up: an interval above max_occ contributes max_occ)
-			int64_t occ = 0;
-			for (int i = 0; i < n_iv; ++i) { const uint64_t x2 = raw[i].x2; occ += x2 > (uint64_t)opt.max_occ ? (int64_t)opt.max_occ : (int64_t)x2; }
-			if (todo_mid && occ <= mid_seeds) todo_mid[atomicAdd(n_todo_mid, 1)] = read;
-			else todo[atomicAdd(n_todo, 1)] = read;
+			todo[atomicAdd(n_todo, 1)] = read;      // K2b's: too many seed occurrences for a lane
 			continue;
 		}
 		// intervals in mem_collect_intv's final order: by (start, end); equal keys are identical entries
@@ -501,13 +496,13 @@ extern "C" int ema_align_simple_blocks_per_cu()
 
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
-                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo, int *todo_mid,
-                                        int *n_todo_mid, int mid_seeds, uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof)
+                                        int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo,
+                                        uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
 	if (prof)
 		hipLaunchKernelGGL(ema_k_align_simple_t<true>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
-		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, todo_mid, n_todo_mid, mid_seeds, hand, prof);
+		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, prof);
 	else
 		hipLaunchKernelGGL(ema_k_align_simple_t<false>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
-		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, todo_mid, n_todo_mid, mid_seeds, hand, prof);
+		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, prof);
 }

@@ -47,16 +47,14 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 {
 	const char *v = getenv("EMU_LANE_ALIGN");
 	const bool lane = !v || atoi(v) != 0;
-	const char *vm = getenv("EMU_MID_ALIGN");
-	const bool mid = lane && (!vm || atoi(vm) != 0);
-	std::vector<int> todo(n_reads + 1), todo_mid(n_reads + 1);
+	std::vector<int> todo(n_reads + 1);
 	std::vector<uint8_t> hand((size_t)n_reads * EMA_HAND_BYTES);
-	int n_todo = 0, n_todo_mid = 0, c0 = 0, c1 = 0, c2 = 0;
+	int n_todo = 0, c0 = 0, c1 = 0;
 	if (lane) {
 		std::vector<uint8_t> scratch((size_t)n_blocks * 4 * ema_align_lane_wave_bytes());
 		ema_launch_align_simple(&di, &d, qp, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, scratch.data(), &c0, todo.data(),
-		                        &n_todo, mid ? todo_mid.data() : nullptr, &n_todo_mid, EMA_MID_SEEDS, hand.data(), n_blocks, nullptr, nullptr);
-		fprintf(stderr, "emu K2a: %d + %d (LDS build) of %d reads left for K2b\n", n_todo, n_todo_mid, n_reads);
+		                        &n_todo, hand.data(), n_blocks, nullptr, nullptr);
+		fprintf(stderr, "emu K2a: %d of %d reads left for K2b\n", n_todo, n_reads);
 	}
 	// EMU_HEAVY_CHAINS=n: K2b sets reads with at least n chains to extend aside for K2c / K2d (EMU_HEAVY_ARENA: arena bytes, to run it full)
 	const char *vh = getenv("EMU_HEAVY_CHAINS");
@@ -79,17 +77,14 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 	int c3 = 0;
 	if (split)
 		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, todo.data(), &n_todo, hand.data(), slabs,
-		                 &c3, n_blocks, nullptr, nullptr, nullptr, 0, &hv, 3);
+		                 &c3, n_blocks, nullptr, nullptr, nullptr, &hv, 3);
 	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,
-	                 &c1, n_blocks, nullptr, nullptr, nullptr, 0, &hv, 0);
-	if (mid)
-		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, todo_mid.data(), &n_todo_mid, hand.data(), slabs,
-		                 &c2, n_blocks, nullptr, nullptr, nullptr, 1, nullptr, 0);
+	                 &c1, n_blocks, nullptr, nullptr, nullptr, &hv, 0);
 	if (heavy_chains > 0) {
 		fprintf(stderr, "emu K2b: %d reads set aside, %d chain tasks, %llu arena bytes\n", hn[0], hn[1], used[0]);
 		for (int mode = 1; mode <= 2; ++mode)
 			ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, nullptr, nullptr, hand.data(), slabs,
-			                 &hn[1 + mode], n_blocks, nullptr, nullptr, nullptr, 0, &hv, mode);
+			                 &hn[1 + mode], n_blocks, nullptr, nullptr, nullptr, &hv, mode);
 	}
 }
 

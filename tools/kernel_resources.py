@@ -27,6 +27,8 @@ for f in files:
             cur[k] = v
         if k.startswith("LDS Size"):
             name = subprocess.run(["c++filt", cur["name"]], stdout=subprocess.PIPE, text=True).stdout.strip()
-            name = re.sub(r"\(.*", "", name).replace("void ", "")
+            name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "")
+            if "rocprim" in name or "hipcub" in name:          # the library's sort / scan kernels under k_sa.hip: not ours to tune
+                continue
             print(f"{os.path.basename(f) + ': ' + name:<58} {cur.get('VGPRs', '?'):>5} {cur.get('AGPRs', '?'):>5} {cur.get('TotalSGPRs', '?'):>5} "
                   f"{cur.get('ScratchSize [bytes/lane]', '?'):>15} {v:>7} {cur.get('Occupancy [waves/SIMD]', '?'):>11} {cur.get('VGPRs Spill', '?'):>12}")

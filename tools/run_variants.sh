@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev aid: A/B of engine knobs on one bench batch at the default scale (one GPU-box call): builds genome, index and two batches
 # through bench.py once, then runs tools/gpu_readlog.py (isolated K1..K4 times of one pass + K2b's per-read log) per variant.
-#   gpurun --timeout 2400 -- 'bash tools/run_variants.sh r02c "EMA_MID_ALIGN=0 EMA_AV_LDS=1" "EMA_MID_ALIGN=0 EMA_AV_LDS=0" ...'
+#   gpurun --timeout 2400 -- 'bash tools/run_variants.sh r02c "EMA_SEED_BLOCKS=2" "EMA_STREAMS=4" ...'
 tag=${1:-var}; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag

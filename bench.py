@@ -298,12 +298,14 @@ def sam_leg(args, eng, batches, workdir, world):
         fd = os.open("/dev/null", os.O_WRONLY)
         stream.stream_sam(eng, paths[:1], fd, rg_id=b"rg1")      # warm-up: page cache, buffers
         import resource
+        stream.host_cpu_seconds(reset=True)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         bst, sst = stream.stream_sam(eng, paths * rep, fd, rg_id=b"rg1", continue_cloud_ids=True)
         dt = time.perf_counter() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
+        by_stage = stream.host_cpu_seconds()
         os.close(fd)
         for path in paths:
             os.remove(path)
@@ -316,6 +318,7 @@ def sam_leg(args, eng, batches, workdir, world):
                 "stage_seconds": {"reader": round(sum(s["read_s"] for s in bst), 3), "append": round(sum(s["append_s"] for s in bst), 3),
                                   "clouds_em_duplicates": round(sum(s["select_s"] for s in sst), 3), "formatter_and_write": round(sum(s["write_s"] for s in sst), 3)},
                 "host_cpu_seconds_per_million_pairs": round(cpu_s / tot * 1e6, 3), "host_cpus_busy": round(cpu_s / dt, 1),
+                "host_cpu_seconds_per_million_pairs_by_stage": {k: round(v / tot * 1e6, 3) for k, v in by_stage.items()},
                 "sam_lines": int(sum(s["lines"] for s in sst))}
     except Exception as e:      # an extra: never at the cost of the line
         log(f"[rank 0] bucket files -> SAM text leg failed: {e}")
@@ -339,6 +342,7 @@ def main(argv=None):
                                                             "(default: one set, passes queued up to three deep with the layout and packing on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / engine_resident / isolated passes (profiling runs)")
+    ap.add_argument("--no-sam-leg", action="store_true", help="skip the bucket files -> SAM text leg (A/B runs of engine knobs)")
     ap.add_argument("--allow-capacity-flags", action="store_true", help="print the (invalid) line even if reads overflowed an engine capacity")
     ap.add_argument("--engine-module", default="ema_amd", help=argparse.SUPPRESS)      # tests/test_bench_control_flow.py: a stand-in engine
     args = ap.parse_args(argv)
@@ -729,7 +733,7 @@ def main(argv=None):
                                     "predicted_pairs_per_s": round(min(n * per_gpu, node_cpus / cpu_s_per_pair if cpu_s_per_pair > 0 else n * per_gpu), 1)}
                            for n in (1, 2, 4, 8)},
             "pcie": "0.35 KB of results per pair: 1.6 GB/s per rank at 4.5 M pairs/s; the index replica (59 GB) is uploaded once per rank in engine_open_s"}
-        out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not args.no_extras else None
+        out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not (args.no_extras or args.no_sam_leg) else None
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

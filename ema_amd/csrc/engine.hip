@@ -31,6 +31,7 @@
 #include "dev_types.h"
 #include "host_index.h"
 #include "opts.h"
+#include "host_cpuacct.h"
 
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
@@ -118,9 +119,10 @@ template <typename F> void host_parallel(size_t n, F fn)
 	if (t == 1) { fn((size_t)0, n); return; }
 	std::vector<std::thread> th;
 	const size_t per = (n + t - 1) / t;
+	const int stage = ema_cpu_current;      // the caller's stage (host_cpuacct.h)
 	for (size_t k = 0; k < t; ++k) {
 		const size_t b = k * per, e = b + per < n ? b + per : n;
-		if (b < e) th.emplace_back([=] { fn(b, e); });
+		if (b < e) th.emplace_back([=] { EMA_CPU(stage); fn(b, e); });
 	}
 	for (auto &x : th) x.join();
 }
@@ -650,6 +652,7 @@ int ema_engine_stage_async(ema_engine_t *e, int slot, const char *bases, const u
 static int stage_slot_impl(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs, bool async)
 {
 	if (!e || !bases || !off) return EMA_EARG;
+	EMA_CPU(EMA_CPU_STAGE);
 	if (slot < 0 || slot >= EMA_MAX_SLOTS) { e->err = "input slot out of range (EMA_MAX_SLOTS)"; return EMA_EARG; }
 	if (n_pairs > e->cap_pairs) { e->err = "batch larger than ema_engine_batch_capacity()"; return EMA_EARG; }
 	HIPCHK(e, hipSetDevice(e->device));
@@ -1019,6 +1022,7 @@ int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
 int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 {
 	if (!e || !out) return EMA_EARG;
+	EMA_CPU(EMA_CPU_FETCH);
 	*out = nullptr;
 	const int j = ticket < 0 ? 0 : ticket % EMA_MAX_INFLIGHT;
 	ema_engine::Ticket &t = e->tickets[j];
@@ -1457,6 +1461,7 @@ static int pack_slice(ema_engine *e, Slice &s, size_t nr, const uint64_t *loc_ca
 int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out)
 {
 	if (!e || !out) return EMA_EARG;
+	EMA_CPU(EMA_CPU_FETCH);
 	*out = nullptr;
 	if (!e->ran) { e->err = "ema_engine_fetch before ema_engine_run"; return EMA_ESTATE; }
 	HIPCHK(e, hipSetDevice(e->device));
@@ -1673,6 +1678,7 @@ struct BatchShare { ema_batch_out *whole; std::atomic<int> refs; };
 
 ema_batch_out *ema_batch_view(void **share, ema_batch_out *whole, size_t p0, size_t n)
 {
+	EMA_CPU(EMA_CPU_FETCH);
 	ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
 	if (!o) return nullptr;
 	const size_t r0 = 2 * p0, nr = 2 * n;

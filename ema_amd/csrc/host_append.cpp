@@ -11,6 +11,7 @@
 #include <thread>
 #include <vector>
 #include "ema_engine.h"
+#include "host_cpuacct.h"
 
 extern "C" void ema_aln_free(ema_aln_out *o);
 namespace {
@@ -51,6 +52,7 @@ extern "C" int ema_batch_append_alignments(const ema_batch_out *b, const uint32_
                                            double error_rate, ema_aln_out **out)
 {
 	if (!b || !off || !opts || !out || !(error_rate > 0. && error_rate < 1.)) return EMA_EARG;
+	EMA_CPU(EMA_CPU_APPEND);
 	*out = nullptr;
 	const double ln_match = std::log(1. - error_rate), ln_mis = std::log(error_rate), ln_indel = std::log(kIndelRate),
 	             ln_clip = std::log(kClipRate);
@@ -73,6 +75,7 @@ extern "C" int ema_batch_append_alignments(const ema_batch_out *b, const uint32_
 	std::vector<int> bad(n_thr, 0);
 	const size_t per = (b->n_pairs + n_thr - 1) / n_thr;
 	auto work = [&](int t) {
+		EMA_CPU(EMA_CPU_APPEND);
 		std::vector<ema_aln_rec> &recs = part[t];
 		const size_t p0 = (size_t)t * per, p1 = p0 + per < b->n_pairs ? p0 + per : b->n_pairs;
 		recs.reserve((p1 > p0 ? p1 - p0 : 0) * 2 + 16);

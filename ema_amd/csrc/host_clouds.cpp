@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 #include "ema_clouds.h"
+#include "host_cpuacct.h"
 
 namespace {
 
@@ -564,6 +565,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
                       int32_t n_contigs, const ema_cloud_opts *opts, ema_clouds_out **out)
 {
 	if (!out) return EMA_EARG;
+	EMA_CPU(EMA_CPU_CLOUDS);
 	*out = nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
 	if (!bk || !b || !a || (n_contigs > 0 && !contig_names)) return EMA_EARG;
@@ -582,6 +584,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 	{   // barcode groups over the host's threads, a few at a time from a shared counter
 		std::atomic<size_t> next{0};
 		auto run = [&] {
+			EMA_CPU(EMA_CPU_CLOUDS);
 			Work w;
 			for (;;) {
 				const size_t g0 = next.fetch_add(8);
@@ -639,6 +642,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 	std::vector<ema_sam_stats> part((size_t)nt_asm);
 	for (auto &ps : part) memset(&ps, 0, sizeof(ps));
 	auto assemble = [&](int tid) {
+		EMA_CPU(EMA_CPU_CLOUDS);
 		// this thread's stretch of pairs (names) and of groups (records, lines, statistics)
 		const size_t pa = bk->n_pairs * (size_t)tid / (size_t)nt_asm, pb = bk->n_pairs * (size_t)(tid + 1) / (size_t)nt_asm;
 		for (size_t p = pa; p < pb; ++p) {

@@ -31,6 +31,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include "ema_ingest.h"
+#include "host_cpuacct.h"
 
 namespace {
 
@@ -58,7 +59,7 @@ template <typename F> void parallel_ranges(size_t n, size_t min_per_thread, F fn
 	std::vector<std::thread> th;
 	for (size_t k = 0; k < t; ++k) {
 		const size_t b = k * per, e = std::min(n, b + per);
-		if (b < e) th.emplace_back([=] { fn(k, b, e); });
+		if (b < e) th.emplace_back([=] { EMA_CPU(EMA_CPU_READER); fn(k, b, e); });
 	}
 	for (auto &x : th) x.join();
 }
@@ -104,7 +105,7 @@ template <int W> void sorted_lines(const char *text, const std::vector<Line> &li
 	auto lo_of = [&](size_t k) { return std::min(n, k * per); };
 	{
 		std::vector<std::thread> th;
-		for (size_t k = 1; k < t; ++k) th.emplace_back([&, k] { std::sort(a.begin() + lo_of(k), a.begin() + lo_of(k + 1)); });
+		for (size_t k = 1; k < t; ++k) th.emplace_back([&, k] { EMA_CPU(EMA_CPU_READER); std::sort(a.begin() + lo_of(k), a.begin() + lo_of(k + 1)); });
 		std::sort(a.begin() + lo_of(0), a.begin() + lo_of(1));
 		for (auto &x : th) x.join();
 	}
@@ -114,7 +115,7 @@ template <int W> void sorted_lines(const char *text, const std::vector<Line> &li
 		std::vector<std::thread> th;
 		for (size_t k = 0; k < t; k += 2 * width) {
 			const size_t l = lo_of(k), m = lo_of(std::min(t, k + width)), r = lo_of(std::min(t, k + 2 * width));
-			th.emplace_back([=] { std::merge(src->begin() + l, src->begin() + m, src->begin() + m, src->begin() + r, dst->begin() + l); });
+			th.emplace_back([=] { EMA_CPU(EMA_CPU_READER); std::merge(src->begin() + l, src->begin() + m, src->begin() + m, src->begin() + r, dst->begin() + l); });
 		}
 		for (auto &x : th) x.join();
 		std::swap(src, dst);
@@ -233,6 +234,7 @@ void ema_bucket_free(ema_bucket *b)
 int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out)
 {
 	if (!out) return EMA_EARG;
+	EMA_CPU(EMA_CPU_READER);
 	*out = nullptr;
 	g_err.clear();
 	if ((!text && len) || bc_len < 1 || bc_len > 32 || max_read_len < 1 || max_read_len > 4096 || (is_haplotag && bc_len != 12))
@@ -247,6 +249,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	struct Part { std::vector<Line> lines; std::vector<Fields> fields; size_t bad_line = (size_t)-1; Bad bad = kOk; };
 	std::vector<Part> parts(t_scan);
 	auto scan = [&](size_t k) {
+		EMA_CPU(EMA_CPU_READER);
 		Part &pt = parts[k];
 		const size_t b = std::min(len, k * per), e = std::min(len, b + per);
 		size_t at = b;
@@ -301,6 +304,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	{
 		std::vector<std::thread> th;
 		auto gather = [&](size_t k) {
+			EMA_CPU(EMA_CPU_READER);
 			std::copy(parts[k].lines.begin(), parts[k].lines.end(), lines.begin() + first[k]);
 			std::copy(parts[k].fields.begin(), parts[k].fields.end(), fields.begin() + first[k]);
 			std::vector<Line>().swap(parts[k].lines); std::vector<Fields>().swap(parts[k].fields);
@@ -388,6 +392,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out)
 {
 	if (!out) return EMA_EARG;
+	EMA_CPU(EMA_CPU_READER);
 	*out = nullptr;
 	g_err.clear();
 	if (!path) return fail(EMA_EARG, "bad argument");
@@ -525,6 +530,7 @@ bool parse_fastq(const char *what, const std::vector<char> &buf, int name_style,
 int ema_fastq_read(const char *path1, const char *path2, int name_style, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out)
 {
 	if (!out) return EMA_EARG;
+	EMA_CPU(EMA_CPU_READER);
 	*out = nullptr;
 	g_err.clear();
 	if (!path1 || bc_len < 1 || bc_len > 32 || max_read_len < 1 || max_read_len > 4096 || (is_haplotag && bc_len != 12) || name_style < 0 || name_style > 1)

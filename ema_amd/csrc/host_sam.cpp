@@ -17,6 +17,7 @@
 #include <poll.h>
 #include <cerrno>
 #include "ema_sam.h"
+#include "host_cpuacct.h"
 
 namespace {
 
@@ -209,6 +210,7 @@ static int format_parts(const ema_sam_line *lines, size_t n, const ema_sam_opts 
 	for (auto &pt : parts) { pt.n = 0; pt.p = nullptr; }
 	std::vector<int> bad(t, 0);
 	auto work = [&](size_t k) {
+		EMA_CPU(EMA_CPU_FORMAT);
 		const size_t lo = std::min(n, k * per), hi = std::min(n, lo + per);
 		if (parts[k].buf.size() < (hi - lo) * 400 + (1 << 16)) parts[k].buf.resize((hi - lo) * 400 + (1 << 16));
 		for (size_t i = lo; i < hi; ++i) if (!put_line(parts[k], lines[i].rec, lines[i].mate, *opt)) { bad[k] = 1; return; }
@@ -224,6 +226,7 @@ static int format_parts(const ema_sam_line *lines, size_t n, const ema_sam_opts 
 int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, char **text, size_t *n_bytes)
 {
 	if (!text || !n_bytes) return EMA_EARG;
+	EMA_CPU(EMA_CPU_FORMAT);
 	*text = nullptr; *n_bytes = 0;
 	static thread_local std::vector<Out> parts_tls;      // kept from call to call (see format_parts)
 	std::vector<Out> &parts = parts_tls;                  // (a lambda run by another thread would name ITS instance of a thread_local)
@@ -237,7 +240,7 @@ int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt,
 	if (!buf) return EMA_EARG;
 	{
 		std::vector<std::thread> th;
-		auto copy = [&](size_t k) { memcpy(buf + at[k], parts[k].buf.data(), parts[k].n); };
+		auto copy = [&](size_t k) { EMA_CPU(EMA_CPU_FORMAT); memcpy(buf + at[k], parts[k].buf.data(), parts[k].n); };
 		for (size_t k = 1; k < t; ++k) th.emplace_back(copy, k);
 		copy(0);
 		for (auto &x : th) x.join();
@@ -248,6 +251,7 @@ int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt,
 
 int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, size_t *n_bytes)
 {
+	EMA_CPU(EMA_CPU_FORMAT);
 	if (n_bytes) *n_bytes = 0;
 	static thread_local std::vector<Out> parts_tls;      // kept from call to call (see format_parts)
 	std::vector<Out> &parts = parts_tls;                  // (a lambda run by another thread would name ITS instance of a thread_local)

@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 #include "ema_stream.h"
+#include "host_cpuacct.h"
 
 namespace {
 
@@ -486,6 +487,14 @@ void ema_stream_opts_default(ema_stream_opts *o)
 }
 
 const char *ema_stream_last_error(void) { return g_err.c_str(); }
+
+void ema_host_cpu_seconds(double out[6], int reset)
+{
+	for (int i = 0; i < 6; ++i) {
+		const uint64_t ns = reset ? ema_cpu_ns[i].exchange(0) : ema_cpu_ns[i].load();
+		if (out) out[i] = (double)ns * 1e-9;
+	}
+}
 
 int ema_stream_buckets(ema_engine_t *e, const char *const *paths, size_t n, const ema_stream_opts *o, ema_stream_sink sink,
                        void *user, ema_bucket_stats *stats)

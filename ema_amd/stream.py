@@ -45,8 +45,20 @@ def _lib():
         L.ema_stream_resident.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
                                           C.POINTER(StreamOpts), SINK, C.c_void_p, C.POINTER(BucketStats)]
         L.ema_stream_last_error.restype = C.c_char_p
+        L.ema_host_cpu_seconds.argtypes = [C.POINTER(C.c_double), C.c_int]
+        L.ema_host_cpu_seconds.restype = None
         L._stream_bound = True
     return L
+
+
+HOST_STAGES = ("reader", "staging", "fetch", "append", "clouds_em_duplicates", "formatter_and_write")
+
+
+def host_cpu_seconds(reset: bool = False) -> dict:
+    """ema_host_cpu_seconds: CPU seconds per host stage, summed over the stage's threads, since load or the last reset."""
+    out = (C.c_double * 6)()
+    _lib().ema_host_cpu_seconds(out, 1 if reset else 0)
+    return dict(zip(HOST_STAGES, (float(x) for x in out)))
 
 
 def default_opts() -> StreamOpts:

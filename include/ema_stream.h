@@ -102,6 +102,13 @@ int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const em
 
 const char *ema_stream_last_error(void);   /* of the last failed call on this thread */
 
+/* Diagnostics.  CPU seconds (user + system, summed over every thread that worked for the stage) the host stages of this library
+ * have used in this process since it was loaded or since the last call with reset != 0:  out[0] bucket / FASTQ reader,
+ * [1] staging (nt4 conversion, 2-bit packing, upload), [2] fetch (waiting for a pass, download, result assembly, cutting a shared
+ * pass into buckets), [3] the append_alignments stage, [4] clouds / EM / duplicate marking, [5] formatter and write.
+ * The stages of a stream overlap in time and spread over many short-lived threads: wall clocks cannot say where the cores went. */
+void ema_host_cpu_seconds(double out[6], int reset);
+
 #ifdef __cplusplus
 }
 #endif

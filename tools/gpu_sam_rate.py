@@ -38,6 +38,7 @@ eng = Engine(os.path.join(wd, "ref.fa"), opts=o)
 fd = os.open("/dev/null", os.O_WRONLY)
 stream.stream_sam(eng, paths[:1], fd, rg_id=b"rg1")      # warm-up: buffers, page cache
 import resource
+stream.host_cpu_seconds(reset=True)
 r0 = resource.getrusage(resource.RUSAGE_SELF)
 t0 = time.perf_counter()
 rep = int(os.environ.get("EMA_SAM_REPEAT", 1))      # the same files again and again: a longer stream without writing more of them
@@ -54,4 +55,7 @@ for name, key, src in (("reader", "read_s", bst), ("engine (stage+kernels+fetch)
                        ("clouds/EM/duplicates", "select_s", sst), ("formatter + write", "write_s", sst)):
     v = [s[key] for s in src]
     print(f"  {name:30s} {sum(v):7.2f}s in all, {n_p / (sum(v) / n_b):12.0f} pairs/s inside the stage")
+cpu = stream.host_cpu_seconds()
+print("  host CPU seconds per million pairs, by stage: " + ", ".join(f"{k} {v / (tot / 1e6):.3f}" for k, v in cpu.items()) +
+      f"; all stages {sum(cpu.values()) / (tot / 1e6):.3f}, the process {(r1.ru_utime + r1.ru_stime - r0.ru_utime - r0.ru_stime) / (tot / 1e6):.3f}")
 print("  SAM statistics of bucket 0:", {k: v for k, v in sst[0].items() if k not in ("select_s", "write_s")})

@@ -63,3 +63,5 @@ if not a.no_oracle:
     print(f"oracle (the reference's way: one thread, a line at a time): {t_orc * 1e3:.0f} ms = {n / t_orc / 1e6:.2f} M pairs/s, "
           f"{size / t_orc / 1e9:.2f} GB/s; ratio {t_orc / t_prod:.1f}x", flush=True)
 os.remove(path)
+from ema_amd import stream
+print("reader CPU seconds per million pairs (all runs above): %.3f" % (stream.host_cpu_seconds()["reader"] / (5 * n / 1e6)))

@@ -5,20 +5,20 @@
 
 #include "dev_common.hpp"
 
-// bns_pos2rid: contig holding forward position pos_f (binary search over the contig offsets)
+// bns_pos2rid: contig holding forward position pos_f -- the last contig that starts at or below it.  bwa searches the contig
+// offsets by bisection: five to twelve DEPENDENT loads per call, two calls per seed occurrence (ema_intv2rid), one per window.
+// The coarse table (dev_types.h, ctg_tab) names the contigs of the 2^ctg_shift-base block the position lies in; what is left to
+// bisect is the contigs that start inside that block -- none, for all but a few positions.
 __device__ __forceinline__ int ema_pos2rid(const DevIndex &ix, int64_t pos_f)
 {
 	if (pos_f >= ix.l_pac) return -1;
-	int left = 0, mid = 0, right = ix.n_seqs;
-	while (left < right) {
-		mid = (left + right) >> 1;
-		if (pos_f >= ix.ctg_off[mid]) {
-			if (mid == ix.n_seqs - 1) break;
-			if (pos_f < ix.ctg_off[mid + 1]) break;
-			left = mid + 1;
-		} else right = mid;
+	const int64_t b = pos_f >> ix.ctg_shift;
+	int lo = ix.ctg_tab[b], hi = ix.ctg_tab[b + 1];
+	while (lo < hi) {
+		const int mid = (lo + hi + 1) >> 1;
+		if (pos_f >= ix.ctg_off[mid]) lo = mid; else hi = mid - 1;
 	}
-	return mid;
+	return lo;
 }
 // bntann1_t.is_alt of contig rid (<prefix>.alt; reference src/bwabridge.c:371 reads the flag bwa carries through to mem_aln_t)
 __device__ __forceinline__ int ema_ctg_alt(const DevIndex &ix, int rid) { return ix.ctg_alt && rid >= 0 ? (int)ix.ctg_alt[rid] : 0; }
@@ -32,9 +32,13 @@ __device__ __forceinline__ int ema_intv2rid(const DevIndex &ix, int64_t rb, int6
 {
 	if (rb < ix.l_pac && re > ix.l_pac) return -2;
 	int r;
-	const int rid_b = ema_pos2rid(ix, ema_depos(ix, rb, r));
-	const int rid_e = rb < re ? ema_pos2rid(ix, ema_depos(ix, re - 1, r)) : rid_b;
-	return rid_b == rid_e ? rid_b : -1;
+	const int64_t fb = ema_depos(ix, rb, r);
+	const int rid_b = ema_pos2rid(ix, fb);
+	if (!(rb < re) || rid_b < 0) return rid_b;
+	// the other end lies in the same contig or the interval spans two (bwa looks its contig up as well and compares)
+	const int64_t fe = ema_depos(ix, re - 1, r);
+	if (fe >= ix.l_pac) return -1;
+	return fe >= ix.ctg_off[rid_b] && fe < ix.ctg_off[rid_b + 1] ? rid_b : -1;
 }
 // base at forward-reverse coordinate p (reverse strand = complement read from the far end)
 __device__ __forceinline__ int ema_ref_base(const DevIndex &ix, int64_t p)

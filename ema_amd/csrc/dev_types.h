@@ -34,6 +34,10 @@ struct DevIndex {
 	const uint8_t *pac;
 	const int64_t *ctg_off;   // n_seqs + 1
 	const uint8_t *ctg_alt;   // n_seqs flags: the contig is named in <prefix>.alt (bwa's bntann1_t.is_alt); null when none is
+	// bns_pos2rid without its binary search: ctg_tab[b] = the contig holding forward position b << ctg_shift (at most 2^16 + 1
+	// entries, the last one for l_pac - 1), so a position's contig lies in [ctg_tab[b], ctg_tab[b + 1]] -- nearly always one candidate
+	const int32_t *ctg_tab;
+	int32_t ctg_shift;
 	uint64_t primary, seq_len;
 	uint64_t L2[5];
 	uint64_t occ_super[EMA_OCC_MAX_SUPER - 1][4];   // absolute counts at the start of superblocks 1, 2, 3

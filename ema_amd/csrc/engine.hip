@@ -242,6 +242,7 @@ struct ema_engine {
 	DevBuf<uint64_t> d_kmer_wide, d_kmer_narrow;      // k-mer interval table (dev_types.h), built when the engine opens
 	DevBuf<int64_t> d_ctg;
 	DevBuf<uint8_t> d_ctg_alt;
+	DevBuf<int32_t> d_ctg_tab;
 	// batch input (whole batch; slices are sub-ranges, the full tier addresses it through its pair list)
 	// Batch inputs live in numbered slots, each a whole batch in HBM (nt4 bases, offsets, 2-bit packs: ~0.7 GB per Mi
 	// pairs): ema_engine_stage fills slot 0, ema_engine_stage_slot any of them, and a run reads the slot it names --
@@ -461,6 +462,9 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
 	e->dix.ctg_alt = nullptr;
+	HIPCHK(e, e->d_ctg_tab.alloc(hix.ctg_tab.size()));
+	HIPCHK(e, hipMemcpy(e->d_ctg_tab.p, hix.ctg_tab.data(), hix.ctg_tab.size() * 4, hipMemcpyHostToDevice));
+	e->dix.ctg_tab = e->d_ctg_tab.p; e->dix.ctg_shift = hix.ctg_shift;
 	if (!hix.ctg_alt.empty()) {      // <prefix>.alt names ALT contigs
 		HIPCHK(e, e->d_ctg_alt.alloc(hix.ctg_alt.size()));
 		HIPCHK(e, hipMemcpy(e->d_ctg_alt.p, hix.ctg_alt.data(), hix.ctg_alt.size(), hipMemcpyHostToDevice));
@@ -585,7 +589,7 @@ void ema_engine_close(ema_engine_t *e)
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
 	for (auto &fp : e->fetch_pin) { fp.c_off.release(); fp.g_off.release(); fp.status.release(); fp.cand.release(); fp.cig.release(); }
-	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_ctg_tab.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
 	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
 	e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();
@@ -1368,6 +1372,33 @@ int ema_engine_debug_regions(ema_engine_t *e, void **regs, int32_t **n_regs, int
 	HIPCHK(e, hipMemcpy(*status, f.d_status.p, n_reads * 4, hipMemcpyDeviceToHost));
 	*cap_per_read = EMA_REG_CAP;
 	*reg_bytes = (int32_t)sizeof(DevReg);
+	return EMA_OK;
+}
+
+extern "C" void ema_launch_test_contigs(const DevIndex *ix, const int64_t *rb, const int64_t *re, int n, int *out, hipStream_t s);
+
+int ema_engine_debug_contigs(ema_engine_t *e, const int64_t *ctg_off, int n_seqs, const int64_t *rb, const int64_t *re, int n, int32_t *out)
+{
+	if (!e || !ctg_off || n_seqs <= 0 || !rb || !re || n <= 0 || !out) return EMA_EARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	std::vector<int64_t> off(ctg_off, ctg_off + n_seqs + 1);
+	std::vector<int32_t> tab;
+	int shift = 0;
+	host_contig_table(off, tab, shift);
+	DevBuf<int64_t> d_off, d_rb, d_re;
+	DevBuf<int32_t> d_tab, d_out;
+	HIPCHK(e, d_off.alloc(off.size())); HIPCHK(e, d_rb.alloc(n)); HIPCHK(e, d_re.alloc(n)); HIPCHK(e, d_tab.alloc(tab.size())); HIPCHK(e, d_out.alloc(2 * (size_t)n));
+	HIPCHK(e, hipMemcpy(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(d_rb.p, rb, (size_t)n * 8, hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(d_re.p, re, (size_t)n * 8, hipMemcpyHostToDevice));
+	DevIndex ix = e->dix;
+	ix.ctg_off = d_off.p; ix.ctg_tab = d_tab.p; ix.ctg_shift = shift; ix.n_seqs = n_seqs; ix.l_pac = off.back(); ix.ctg_alt = nullptr;
+	ema_launch_test_contigs(&ix, d_rb.p, d_re.p, n, d_out.p, e->sl[0].stream);
+	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipStreamSynchronize(e->sl[0].stream));
+	HIPCHK(e, hipMemcpy(out, d_out.p, 2 * (size_t)n * 4, hipMemcpyDeviceToHost));
+	d_off.release(); d_rb.release(); d_re.release(); d_tab.release(); d_out.release();
 	return EMA_OK;
 }
 

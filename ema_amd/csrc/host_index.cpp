@@ -20,6 +20,24 @@ bool slurp(const std::string &path, std::vector<uint8_t> &buf)
 }
 }  // namespace
 
+// The coarse contig table (dev_types.h, DevIndex::ctg_tab) of contig offsets ctg_off[0..n] (ctg_off[n] = l_pac)
+void host_contig_table(const std::vector<int64_t> &ctg_off, std::vector<int32_t> &tab, int &shift)
+{
+	const int64_t l_pac = ctg_off.empty() ? 0 : ctg_off.back();
+	const int32_t last = (int32_t)ctg_off.size() - 2;
+	shift = 0;
+	while ((l_pac >> shift) >= (1 << 16)) ++shift;
+	const int64_t nb = (l_pac >> shift) + 1;
+	tab.assign((size_t)nb + 1, 0);
+	int32_t c = 0;
+	for (int64_t b = 0; b < nb; ++b) {
+		const int64_t pos = std::min<int64_t>(b << shift, l_pac - 1);
+		while (c < last && pos >= ctg_off[(size_t)c + 1]) ++c;
+		tab[(size_t)b] = c;
+	}
+	tab[(size_t)nb] = last < 0 ? 0 : last;
+}
+
 DevIndex HostIndex::view() const
 {
 	DevIndex d;
@@ -28,6 +46,7 @@ DevIndex HostIndex::view() const
 	d.pac = pac.data();
 	d.ctg_off = ctg_off.data();
 	d.ctg_alt = ctg_alt.empty() ? nullptr : ctg_alt.data();
+	d.ctg_tab = ctg_tab.data(); d.ctg_shift = ctg_shift;
 	d.primary = primary; d.seq_len = seq_len;
 	for (int i = 0; i < 5; ++i) d.L2[i] = L2[i];
 	d.l_pac = l_pac;
@@ -174,5 +193,6 @@ std::string host_index_load(const std::string &prefix, HostIndex &ix, bool with_
 	ix.ctg_off.clear();
 	for (auto &c : ix.contigs) ix.ctg_off.push_back(c.offset);
 	ix.ctg_off.push_back(ix.l_pac);
+	host_contig_table(ix.ctg_off, ix.ctg_tab, ix.ctg_shift);
 	return "";
 }

@@ -21,6 +21,8 @@ struct HostIndex {
 	std::vector<uint8_t> pac;
 	std::vector<int64_t> ctg_off;    // n+1
 	std::vector<uint8_t> ctg_alt;    // n flags from <prefix>.alt; empty when no contig is ALT
+	std::vector<int32_t> ctg_tab;    // dev_types.h, DevIndex::ctg_tab
+	int ctg_shift = 0;
 	std::vector<HostContig> contigs;
 	uint64_t primary = 0, seq_len = 0, L2[5] = {0, 0, 0, 0, 0};
 	int64_t l_pac = 0;
@@ -34,6 +36,8 @@ struct HostIndex {
 	// pointers with device addresses after upload).
 	DevIndex view() const;
 };
+
+void host_contig_table(const std::vector<int64_t> &ctg_off, std::vector<int32_t> &tab, int &shift);
 
 // Loads <prefix>.bwt/.pac/.ann and <prefix>.fsa.  Returns "" on success, else an error message.  with_sa == false
 // leaves the suffix array on disk (sa_path / sa_file_off / sa_size say where): the engine streams it to the device.

@@ -74,6 +74,21 @@ extern "C" void ema_launch_test_local(const DevOpts *opt, const uint8_t *qbuf, c
 	                   b_stride);
 }
 
+// bns_intv2rid and bns_pos2rid on the coarse contig table (dev_ref.hpp), one lane per query
+#include "dev_ref.hpp"
+__global__ void ema_k_test_contigs(DevIndex ix, const int64_t *rb, const int64_t *re, int n, int *out)
+{
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (i >= n) return;
+	int is_rev;
+	out[2 * i] = ema_intv2rid(ix, rb[i], re[i]);
+	out[2 * i + 1] = ema_pos2rid(ix, ema_depos(ix, rb[i], is_rev));
+}
+extern "C" void ema_launch_test_contigs(const DevIndex *ix, const int64_t *rb, const int64_t *re, int n, int *out, hipStream_t s)
+{
+	hipLaunchKernelGGL(ema_k_test_contigs, dim3((n + 255) / 256), dim3(256), 0, s, *ix, rb, re, n, out);
+}
+
 // mem_sort_dedup_patch without patching (the form mem_matesw uses), one task per wavefront:
 // task t owns regs[t*cap .. t*cap + n_in[t]); result in place, n_out[t] = surviving regions.
 #include "dev_regions.hpp"

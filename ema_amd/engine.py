@@ -18,7 +18,7 @@ SYMBOLS = [
     "ema_engine_opts_default", "ema_engine_open", "ema_engine_close", "ema_engine_strerror", "ema_engine_n_contigs",
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_contig_is_alt", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
-    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free", "ema_engine_open_shared", "ema_engine_index_info", "ema_engine_stage_slot", "ema_engine_run_slot", "ema_engine_peer",
+    "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_debug_contigs", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free", "ema_engine_open_shared", "ema_engine_index_info", "ema_engine_stage_slot", "ema_engine_run_slot", "ema_engine_peer",
     "ema_engine_seed_launches", "ema_engine_get_opts",
 ]
 
@@ -124,6 +124,7 @@ def load_library():
                                                C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32),
                                                C.POINTER(C.c_int32)]
         L.ema_engine_debug_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ema_engine_debug_contigs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ema_engine_debug_dp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -371,6 +372,17 @@ class Engine:
             libc.free(pn)
             libc.free(ps)
         return regs, n_regs, status
+
+    def debug_contigs(self, ctg_off, rb, re):
+        """bns_intv2rid of [rb, re) and bns_pos2rid of rb on the device, for a contig layout of the caller's (ctg_off: n + 1 offsets,
+        the last one l_pac).  Returns (intv2rid, pos2rid)."""
+        ctg_off = np.ascontiguousarray(ctg_off, dtype=np.int64)
+        rb = np.ascontiguousarray(rb, dtype=np.int64)
+        re = np.ascontiguousarray(re, dtype=np.int64)
+        out = np.zeros((len(rb), 2), dtype=np.int32)
+        self._check(self._L.ema_engine_debug_contigs(self._h, ctg_off.ctypes.data, len(ctg_off) - 1, rb.ctypes.data, re.ctypes.data,
+                                                     len(rb), out.ctypes.data), "debug_contigs")
+        return out[:, 0].copy(), out[:, 1].copy()
 
     def debug_dedup(self, regs, n_in):
         """mem_sort_dedup_patch (no patching) on regs[n_tasks, cap] (REG_DTYPE); returns (regs, n_out)."""

@@ -203,6 +203,11 @@ int ema_engine_debug_readlog(ema_engine_t *e, int32_t **log, size_t *n);
  * one task per wavefront: task t owns regs[t*cap .. t*cap + n_in[t]) (records laid out as in ema_engine_debug_regions);
  * sorted/compacted in place, n_out[t] = regions kept. */
 int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int32_t *n_out, int cap, int n_tasks);
+/* The device's contig look-ups (bwa's bns_intv2rid / bns_pos2rid, reached from mem_chain and bns_fetch_seq) on a contig layout of
+ * the caller's: ctg_off[0..n_seqs] = the contigs' first forward positions and, last, l_pac.  For query i -- the half-open
+ * interval [rb[i], re[i]) in bwa's forward-reverse coordinates -- out[2i] = bns_intv2rid, out[2i+1] = bns_pos2rid of rb[i]'s
+ * forward position.  (The engine answers them from a coarse table instead of bwa's bisection; tests/test_gpu_contigs.py.) */
+int ema_engine_debug_contigs(ema_engine_t *e, const int64_t *ctg_off, int n_seqs, const int64_t *rb, const int64_t *re, int n, int32_t *out);
 
 /* The host stage right behind the engine: what the reference's append_alignments() (src/align.c:986-1061) derives from a
  * pair's candidates before the records go on to the cloud stage -- clip filter (:1017,:1042), search-depth filter with

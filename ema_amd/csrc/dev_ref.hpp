@@ -48,6 +48,19 @@ __device__ __forceinline__ int ema_ref_base(const DevIndex &ix, int64_t p)
 	const int b = ix.pac[f >> 2] >> ((~f & 3) << 1) & 3;
 	return rev ? 3 - b : b;
 }
+// the same when the contig is known (a chain's rid IS the contig of its first seed): no search, two independent loads
+__device__ __forceinline__ void ema_clamp_window_rid(const DevIndex &ix, int64_t &beg, int rid, bool is_rev, int64_t &end)
+{
+	if (end < beg) { const int64_t t = beg; beg = end; end = t; }
+	int64_t far_beg = ix.ctg_off[rid], far_end = ix.ctg_off[rid + 1];
+	if (is_rev) {
+		const int64_t t = far_beg;
+		far_beg = (ix.l_pac << 1) - far_end;
+		far_end = (ix.l_pac << 1) - t;
+	}
+	beg = beg > far_beg ? beg : far_beg;
+	end = end < far_end ? end : far_end;
+}
 // bns_fetch_seq's clamping: [beg, end) cut to the contig (and strand) of `mid`; returns its rid
 __device__ __forceinline__ int ema_clamp_window(const DevIndex &ix, int64_t &beg, int64_t mid, int64_t &end)
 {
@@ -69,27 +82,36 @@ __device__ __forceinline__ int ema_clamp_window(const DevIndex &ix, int64_t &beg
 // (Until round 3 every lane fetched its bases one byte-load at a time, l = lane, lane + 64, ...: a 450-base extension window was
 // seven dependent round trips, a 700-base rescue window eleven -- at loaded-memory latency that was the largest single wait of
 // K2's per-chain set-up and of K3.)
-__device__ __forceinline__ void ema_wave_fetch(const DevIndex &ix, int64_t beg, int64_t end, uint8_t *dst)
+struct EmaWin { int64_t w0; int shift, n, n_dw; bool rev; };      // a window as words of the packed reference (wave-uniform)
+__device__ __forceinline__ EmaWin ema_win(const DevIndex &ix, int64_t beg, int64_t end)
 {
-	const int n = (int)(end - beg);
-	if (n > 0) {
-		const bool rev = beg >= ix.l_pac;
-		const int64_t f_lo = rev ? (ix.l_pac << 1) - end : beg;      // the window on the forward strand: [f_lo, f_lo + n)
-		const int64_t w0 = (f_lo >> 2) & ~(int64_t)3;                // its first byte, rounded down to a word
-		const int shift = (int)(f_lo - (w0 << 2));                   // 0..15: where f_lo sits in that word
-		const int n_dw = (shift + n + 15) >> 4;
-		for (int d = (int)ema_lane(); d < n_dw; d += EMA_WAVE) {
-			const uint32_t w = *reinterpret_cast<const uint32_t *>(ix.pac + w0 + 4 * (int64_t)d);      // (the packed array is padded by 8 bytes)
+	EmaWin w;
+	w.n = (int)(end - beg);
+	w.rev = beg >= ix.l_pac;
+	const int64_t f_lo = w.rev ? (ix.l_pac << 1) - end : beg;      // the window on the forward strand: [f_lo, f_lo + n)
+	w.w0 = (f_lo >> 2) & ~(int64_t)3;                              // its first byte, rounded down to a word
+	w.shift = (int)(f_lo - (w.w0 << 2));                           // 0..15: where f_lo sits in that word
+	w.n_dw = w.n > 0 ? (w.shift + w.n + 15) >> 4 : 0;
+	return w;
+}
+// word d of the window (d < n_dw); the packed array is padded by 8 bytes
+__device__ __forceinline__ uint32_t ema_win_load(const DevIndex &ix, const EmaWin &w, int d) { return *reinterpret_cast<const uint32_t *>(ix.pac + w.w0 + 4 * (int64_t)d); }
+// the 16 bases of word d into dst (nt4 bytes, window order)
+__device__ __forceinline__ void ema_win_unpack(const EmaWin &w, int d, uint32_t word, uint8_t *dst)
+{
 #pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				const int o = 16 * d + i - shift;       // index along the forward strand
-				if (o >= 0 && o < n) {
-					const int code = (int)(w >> (8 * (i >> 2) + ((~i & 3) << 1))) & 3;      // byte i / 4 of the word, first base in the high bits
-					dst[rev ? n - 1 - o : o] = (uint8_t)(rev ? 3 - code : code);
-				}
-			}
+	for (int i = 0; i < 16; ++i) {
+		const int o = 16 * d + i - w.shift;       // index along the forward strand
+		if (o >= 0 && o < w.n) {
+			const int code = (int)(word >> (8 * (i >> 2) + ((~i & 3) << 1))) & 3;      // byte i / 4 of the word, first base in the high bits
+			dst[w.rev ? w.n - 1 - o : o] = (uint8_t)(w.rev ? 3 - code : code);
 		}
 	}
+}
+__device__ __forceinline__ void ema_wave_fetch(const DevIndex &ix, int64_t beg, int64_t end, uint8_t *dst)
+{
+	const EmaWin w = ema_win(ix, beg, end);
+	for (int d = (int)ema_lane(); d < w.n_dw; d += EMA_WAVE) ema_win_unpack(w, d, ema_win_load(ix, w, d), dst);
 	ema_wave_sync();
 }
 

@@ -95,12 +95,14 @@ struct ChainRec {
 };
 
 // K2a -> K2b hand-over: when the lane-per-read kernel gives a read up only at the extension (or later), its chaining and
-// chain-filter results travel with the read, so the wave-per-read kernel starts at mem_chain2aln.  Per read:
-// {n_chn, n_seed}, the filter's sorted keys (weight << 32 | chain), the chains, the seed pool.  A todo-list entry with
-// bit 31 set says the record is there.
+// chain-filter results travel with the read, so the wave-per-read kernel (k_align.hip, mode 3) starts at mem_chain2aln.
+// Records are written densely, in the order K2a gives reads up (record i = the i-th read handed over; their number is a device
+// counter), and carry everything the consumer needs to start -- the read's number, its length and where its bases are -- so
+// that a wavefront goes from "item i" to its first extension in two round trips to memory: the header, then {bases, tables}.
+// Layout: HandHdr, the filter's sorted keys (weight << 32 | chain), the chains, the seed pool.
 #define EMA_HAND_SEEDS 32
-#define EMA_HAND_BYTES ((size_t)16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)))
-#define EMA_HAND_FLAG 0x80000000u
+struct HandHdr { int32_t read, n_chn, n_seed, l_query; uint32_t base_off; int32_t pad[3]; };
+#define EMA_HAND_BYTES (sizeof(HandHdr) + (size_t)EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)))
 
 // Chain-rich reads (hundreds of chains, nearly every one of them extended: a read from a young repeat family) are a long
 // serial job for the one wavefront that owns them -- two extension DPs per chain, one after the other -- and they set the
@@ -120,7 +122,6 @@ struct HeavyCtl {
 	int *n_reads, *n_tasks;
 	int reads_cap, tasks_cap;
 	int min_chains;                    // a read with at least this many chains to extend is set aside
-	int skip_handed;                   // K2b (mode 0): the reads K2a handed over with their chains ready are another launch's (mode 3)
 };
 struct HeavyHdr {                      // head of a record; the arrays follow at the offsets given (bytes from the record's start)
 	int32_t read, n_chn, n_chain, n_seed, status, n_ext;

@@ -55,7 +55,7 @@ extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo,
-                                        uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof);
+                                        uint8_t *hand, int *n_hand, int n_blocks, hipStream_t stream, unsigned long long *prof);
 struct DevAln { int64_t pos; int32_t is_rev, NM, n_cigar; uint32_t cigar_off; };
 extern "C" int ema_align_blocks_per_cu();
 extern "C" int ema_pair_blocks_per_cu();
@@ -270,7 +270,6 @@ struct ema_engine {
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
-	bool split_handed = true;            // EMA_SPLIT_HANDED=0: one K2b launch for everything on K2a's list
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)
 	int heavy_regions = 8;               // K4b sets a read with at least this many regions left aside for K4t / K4r (0: never)
@@ -532,7 +531,6 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = getenv("EMA_HEAVY_ATTEMPTS")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
 	if (const char *v = getenv("EMA_HEAVY_REGIONS")) e->heavy_regions = std::max(0, atoi(v));        //  pair / read takes the set-aside route)
 	if (const char *v = getenv("EMA_SMALL_ONE_SLICE")) e->small_one_slice = atoi(v) != 0;
-	if (const char *v = getenv("EMA_SPLIT_HANDED")) e->split_handed = atoi(v) != 0;
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
 	if (n_streams > 16) n_streams = 16;
@@ -801,18 +799,17 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	if (e->lane_align) {
 		ema_launch_align_simple(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                        s.d_n_regs.p, s.d_status.p, s.d_slabs.p, s.d_counters.p + 4, s.d_todo.p, s.d_counters.p + 21,
-		                        s.d_hand.p, e->lane_blocks, s.stream, e->d_prof.p);
+		                        s.d_hand.p, s.d_counters.p + 24, e->lane_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
 	// K2b: K2a's hand-overs on their own build (mode 3), then the reads with many seed occurrences (mode 0)
 	HeavyCtl hv;
 	const bool heavy = s.d_heavy.p != nullptr;
-	const bool split = e->lane_align && e->split_handed;      // K2a's hand-overs on their own build of K2b, ahead of the rest
 	hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr;
-	hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; hv.skip_handed = split ? 1 : 0;
-	if (split) {
+	hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30;
+	if (e->lane_align) {      // (mode 3 reads K2a's dense records: their number is counter 24)
 		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
-		                 s.d_n_regs.p, s.d_status.p, s.d_todo.p, s.d_counters.p + 21, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 22,
+		                 s.d_n_regs.p, s.d_status.p, nullptr, s.d_counters.p + 24, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 22,
 		                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, &hv, 3);
 		HIPCHK(e, hipGetLastError());
 	}

@@ -331,10 +331,14 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first, int
 
 // one wavefront = one read at a time, reads taken from a shared counter
 // intv/n_intv: K1's output (stride opt.intv_cap).  regs: n_reads x opt.reg_cap, n_regs: n_reads.  status is OR-ed.
-// MODE 0: the kernel described above (it sets chain-rich reads aside when hv.arena is given); 1: K2c, 2: K2d (dev_types.h, HeavyCtl);
-// 3: the reads K2a handed over with their chains ready, and nothing else -- five sixths of the reads on the list.  Without the
-// chaining, the filter and the setting-aside in the same function the register allocator has a far easier job (a third of
-// the spills of mode 0), and the bulk of the reads runs on that build.
+// MODE 0: the kernel described above, over K2a's todo list (or every read when todo is null); it sets chain-rich reads aside when
+// hv.arena is given; 1: K2c, 2: K2d (dev_types.h, HeavyCtl);
+// 3: the reads K2a handed over with their chains ready (dev_types.h, HandHdr: *n_todo dense records in `hand`) -- five sixths of
+// the reads that reach this kernel.  Without the chaining, the filter and the setting-aside in the same function the register
+// allocator has a far easier job, and the path is laid out for few DEPENDENT round trips to memory, which is what a read costs
+// here while K1 of another slice keeps the memory system saturated (a round trip then takes several microseconds): records are
+// claimed four at a time with their headers, a record's tables and the read's bases arrive together, the windows of all its
+// chains are planned at once (lane per chain) and fetched up to four at a time.
 // PROF: the diagnostic build (phase clocks, per-read log); the product build carries none of its registers
 template <int SMALL, int AVL, int WPS, int MODE, bool PROF>
 __global__ void __launch_bounds__(256, WPS)
@@ -382,15 +386,40 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	const AlignSlab &sl = cb.sl;
 	const int64_t l_pac = ix.l_pac;
 
+	// MODE 3: records claimed four at a time; lane k < 4 keeps record k's header until its turn
+	int cl_base = 0, cl_n = 0, cl_i = 0, win_end = 0;
+	HandHdr pf;
+	pf.read = pf.n_chn = pf.n_seed = pf.l_query = 0; pf.base_off = 0;
 	for (;;) {
 		int read = 0;
-		if (lane == 0) read = atomicAdd(counter, 1);
-		read = ema_uni(__shfl(read, 0));
-		if (read >= (MODE == 1 ? *hv.n_tasks : MODE == 2 ? *hv.n_reads : todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2))) {
-			if (MODE == 0 && prof && lane == 0 && opt.reg_cap <= EMA_REG_LEAN) atomicMin(prof + 27, (unsigned long long)__builtin_amdgcn_s_memtime());      // the queue ran dry (lean tier)
-			break;
+		constexpr bool handed = MODE == 3;      // K2a already chained and filtered this read (dev_types.h, HandHdr)
+		HandHdr hd;                             // MODE 3: this record's header, wave-uniform
+		hd.read = hd.n_chn = hd.n_seed = hd.l_query = 0; hd.base_off = 0;
+		const uint8_t *hrec = nullptr;
+		if (MODE == 3) {
+			if (cl_i == cl_n) {
+				int base = 0;
+				if (lane == 0) base = atomicAdd(counter, 4);
+				base = __builtin_amdgcn_readlane(base, 0);
+				const int total = *n_todo;
+				if (base >= total) break;
+				cl_base = base; cl_n = total - base < 4 ? total - base : 4; cl_i = 0;
+				if (lane < cl_n) pf = *reinterpret_cast<const HandHdr *>(hand + (size_t)(base + lane) * EMA_HAND_BYTES);
+			}
+			hd.read = __builtin_amdgcn_readlane(pf.read, cl_i); hd.n_chn = __builtin_amdgcn_readlane(pf.n_chn, cl_i);
+			hd.n_seed = __builtin_amdgcn_readlane(pf.n_seed, cl_i); hd.l_query = __builtin_amdgcn_readlane(pf.l_query, cl_i);
+			hd.base_off = (uint32_t)__builtin_amdgcn_readlane((int)pf.base_off, cl_i);
+			hrec = hand + (size_t)(cl_base + cl_i) * EMA_HAND_BYTES;
+			++cl_i;
+			read = hd.read;
+		} else {
+			if (lane == 0) read = atomicAdd(counter, 1);
+			read = __builtin_amdgcn_readlane(read, 0);
+			if (read >= (MODE == 1 ? *hv.n_tasks : MODE == 2 ? *hv.n_reads : todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2))) {
+				if (MODE == 0 && prof && lane == 0 && opt.reg_cap <= EMA_REG_LEAN) atomicMin(prof + 27, (unsigned long long)__builtin_amdgcn_s_memtime());      // the queue ran dry (lean tier)
+				break;
+			}
 		}
-		bool handed = false;      // K2a already chained and filtered this read (dev_types.h, EMA_HAND_*)
 		const uint8_t *rec = nullptr;      // MODE 1, 2: the record of the read set aside
 		int task_chain = -1;               // MODE 1: the chain of this task (index in filtered order)
 		if (MODE == 1) {
@@ -405,29 +434,32 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			if (t == ~0ULL) continue;
 			rec = hv.arena + (size_t)t;
 			read = ema_uni(reinterpret_cast<const HeavyHdr *>(rec)->read);
-		} else if (todo) {
-			const unsigned t = (unsigned)ema_uni(todo[read]);
-			handed = (t & EMA_HAND_FLAG) != 0;
-			read = (int)(t & ~EMA_HAND_FLAG);
-		}
-		if (MODE == 3 && !handed) continue;
-		if (MODE == 0 && handed && hv.skip_handed) continue;
+		} else if (MODE == 0 && todo) read = ema_uni(todo[read]);
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		const unsigned long long t_read = rlog ? __builtin_amdgcn_s_memtime() : 0;
 		int log_iv = -1, log_occ = 0;
 		n_dp = 0;
 		EMA_DBG(1, 0);
 		EMA_PHASE(6);      // 6: the read and (handed reads) K2a's record arrive
-		if ((MODE == 0 || MODE == 3) && ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
-			if (lane == 0) n_regs[read] = 0;
+		if (MODE == 0 && ema_uni(status[read])) {      // over a capacity in K1: the pair is redone by the full-capacity tier
+			if (lane == 0) n_regs[read] = 0;      // (K2a hands over only reads whose status is clear)
 			EMA_DBG(9, 0);
 			continue;
 		}
-		ema_phase_fence();      // the previous read's stores have landed
-		const int in_read = ema_uni(ema_in_read(map, read));
-		const int l_query = ema_uni((int)(off[in_read + 1] - off[in_read]));
-		for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
-		ema_wave_sync();
+		int l_query = 0;
+		uint8_t qv[4] = {0, 0, 0, 0};      // MODE 3: the read's bases on their way while the record's tables are
+		if (MODE == 3) {
+			l_query = hd.l_query;
+			const uint8_t *src = bases + hd.base_off;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const int i = lane + k * EMA_WAVE; if (i < l_query) qv[k] = src[i]; }
+		} else {
+			ema_phase_fence();      // the previous read's stores have landed
+			const int in_read = ema_uni(ema_in_read(map, read));
+			l_query = ema_uni((int)(off[in_read + 1] - off[in_read]));
+			for (int i = lane; i < l_query; i += EMA_WAVE) query[i] = bases[off[in_read] + i];
+			ema_wave_sync();
+		}
 		float frac_rep = 0.f;
 		int n_chn = 0, n_keep = 0;
 		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
@@ -449,23 +481,61 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			cb.n_chain = ema_uni(h->n_chain); cb.n_seed = ema_uni(h->n_seed);
 			cb.status = MODE == 2 ? ema_uni(h->status) : 0;
 			frac_rep = ema_uni(h->frac_rep);
-		} else if (handed) {
-			// small tables in LDS, filled from K2a's record
+		} else if (MODE == 3) {
+			// small tables in LDS, filled from K2a's record: one entry per lane (EMA_HAND_SEEDS <= 64), all loads in flight together
+			// with the read's bases; then the point where the previous read's stores must have landed; then LDS
 			cb.sl = slab;
 			ema_small_tables<SMALL>(cb.sl, lds_small[wib]);
-			const uint8_t *h = hand + (size_t)read * EMA_HAND_BYTES;
-			const int32_t *head = reinterpret_cast<const int32_t *>(h);
-			n_chn = ema_uni(head[0]);
-			const int n_sd = ema_uni(head[1]);
-			const uint64_t *hk = reinterpret_cast<const uint64_t *>(h + 16);
-			const ChainRec *hc = reinterpret_cast<const ChainRec *>(h + 16 + EMA_HAND_SEEDS * 8);
-			const SeedRec *hs = reinterpret_cast<const SeedRec *>(h + 16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
-			for (int i = lane; i < n_chn; i += EMA_WAVE) { sl.skey[i] = hk[i]; sl.chains[i] = hc[i]; }
-			for (int i = lane; i < n_sd; i += EMA_WAVE) sl.seeds[i] = hs[i];
+			n_chn = hd.n_chn;
+			const int n_sd = hd.n_seed;
+			const uint64_t *hk = reinterpret_cast<const uint64_t *>(hrec + sizeof(HandHdr));
+			const ChainRec *hc = reinterpret_cast<const ChainRec *>(hrec + sizeof(HandHdr) + EMA_HAND_SEEDS * 8);
+			const SeedRec *hs = reinterpret_cast<const SeedRec *>(hrec + sizeof(HandHdr) + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
+			uint64_t kv = 0;
+			ChainRec cv; SeedRec sv;
+			if (lane < n_chn) { kv = hk[lane]; cv = hc[lane]; }
+			if (lane < n_sd) sv = hs[lane];
+			ema_phase_fence();
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const int i = lane + k * EMA_WAVE; if (i < l_query) query[i] = qv[k]; }
+			if (lane < n_chn) { sl.skey[lane] = kv; sl.chains[lane] = cv; }
+			if (lane < n_sd) sl.seeds[lane] = sv;
 			cb.n_chain = n_chn; cb.n_seed = n_sd;
 			n_keep = n_chn;
 			ema_wave_sync();
-		} else if (MODE != 3) {
+			// The windows of ALL chains, planned at once, one lane per chain (filtered order): the bounds over the chain's seeds, the
+			// strand junction, the contig's ends (the chain's rid IS the contig bns_fetch_seq would look up from its first seed).
+			// Start, length and -- once fetched -- place in the window buffer sit in the tables chaining no longer needs.
+			if (lane < n_chn) {
+				const ChainRec c = sl.chains[(int)(uint32_t)kv];
+				int64_t r0 = 0;
+				int wl = 0;
+				if (c.kept != 0) {
+					int64_t rmax0 = l_pac << 1, rmax1 = 0;
+					int k = c.first_seed;
+					for (int t = 0; t < c.n; ++t) {
+						const SeedRec s = sl.seeds[k];
+						const int64_t b = s.rbeg - (s.qbeg + cal_max_gap(opt, s.qbeg));
+						const int tail = l_query - s.qbeg - s.len;
+						const int64_t e = s.rbeg + s.len + (tail + cal_max_gap(opt, tail));
+						rmax0 = rmax0 < b ? rmax0 : b;
+						rmax1 = rmax1 > e ? rmax1 : e;
+						k = s.next;
+					}
+					rmax0 = rmax0 > 0 ? rmax0 : 0;
+					rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+					if (rmax0 < l_pac && l_pac < rmax1) {
+						if (c.f_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+					}
+					ema_clamp_window_rid(ix, rmax0, c.rid, c.f_rbeg >= l_pac, rmax1);
+					const int64_t d = rmax1 - rmax0;
+					r0 = rmax0; wl = d > (1 << 20) ? 1 << 20 : d < -(1 << 20) ? -(1 << 20) : (int)d;
+				}
+				sl.cpos[lane] = r0; sl.cord[lane] = wl;
+			}
+			win_end = 0;
+			ema_wave_sync();
+		} else {
 		EMA_PHASE(10);      // 10: the intervals in order, the repetitive fraction
 		const int n_iv = ema_uni(n_intv[read]);
 		const Intv *iv = slab.ivs;
@@ -719,7 +789,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		}
 
 		// ---------------- a chain-rich read is set aside for K2c / K2d (dev_types.h, HeavyCtl) ----------------
-		if (MODE == 0 && hv.arena && !handed && n_keep >= hv.min_chains) {
+		if (MODE == 0 && hv.arena && n_keep >= hv.min_chains) {
 			int n_ext = 0, tot = 0;      // chains to extend, their seeds
 			for (int base = 0; base < n_keep; base += EMA_WAVE) {
 				const int i = base + lane;
@@ -834,30 +904,81 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				ema_wave_sync();
 			}
 			int64_t rmax0 = l_pac << 1, rmax1 = 0;
-			for (int t = lane; t < cn; t += EMA_WAVE) {
-				const SeedRec s = sl.cs[t];
-				const int64_t b = s.rbeg - (s.qbeg + cal_max_gap(opt, s.qbeg));
-				const int tail = l_query - s.qbeg - s.len;
-				const int64_t e = s.rbeg + s.len + (tail + cal_max_gap(opt, tail));
-				rmax0 = rmax0 < b ? rmax0 : b;
-				rmax1 = rmax1 > e ? rmax1 : e;
-				if (MODE != 2) sl.srt[t] = (uint64_t)(uint32_t)s.len << 32 | (uint32_t)t;      // score == len
+			uint8_t *rs = rseq;      // where this chain's window sits
+			if (MODE == 3) {         // planned with the record (above)
+				for (int t = lane; t < cn; t += EMA_WAVE) sl.srt[t] = (uint64_t)(uint32_t)sl.cs[t].len << 32 | (uint32_t)t;      // score == len
+				rmax0 = ema_uni((int64_t)sl.cpos[ci_sorted]);
+				rmax1 = rmax0 + ema_uni((int)sl.cord[ci_sorted]);
+			} else {
+				for (int t = lane; t < cn; t += EMA_WAVE) {
+					const SeedRec s = sl.cs[t];
+					const int64_t b = s.rbeg - (s.qbeg + cal_max_gap(opt, s.qbeg));
+					const int tail = l_query - s.qbeg - s.len;
+					const int64_t e = s.rbeg + s.len + (tail + cal_max_gap(opt, tail));
+					rmax0 = rmax0 < b ? rmax0 : b;
+					rmax1 = rmax1 > e ? rmax1 : e;
+					if (MODE != 2) sl.srt[t] = (uint64_t)(uint32_t)s.len << 32 | (uint32_t)t;      // score == len
+				}
+				for (int m = 1; m < EMA_WAVE; m <<= 1) {
+					const int64_t o0 = __shfl_xor(rmax0, m), o1 = __shfl_xor(rmax1, m);
+					rmax0 = rmax0 < o0 ? rmax0 : o0;
+					rmax1 = rmax1 > o1 ? rmax1 : o1;
+				}
+				rmax0 = ema_uni(rmax0); rmax1 = ema_uni(rmax1);
+				rmax0 = rmax0 > 0 ? rmax0 : 0;
+				rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+				if (rmax0 < l_pac && l_pac < rmax1) {
+					if (c.f_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+				}
+				ema_clamp_window(ix, rmax0, c.f_rbeg, rmax1);
 			}
-			for (int m = 1; m < EMA_WAVE; m <<= 1) {
-				const int64_t o0 = __shfl_xor(rmax0, m), o1 = __shfl_xor(rmax1, m);
-				rmax0 = rmax0 < o0 ? rmax0 : o0;
-				rmax1 = rmax1 > o1 ? rmax1 : o1;
-			}
-			rmax0 = ema_uni(rmax0); rmax1 = ema_uni(rmax1);
-			rmax0 = rmax0 > 0 ? rmax0 : 0;
-			rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
-			if (rmax0 < l_pac && l_pac < rmax1) {
-				if (c.f_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
-			}
-			ema_clamp_window(ix, rmax0, c.f_rbeg, rmax1);
 			if (rmax1 - rmax0 > EMA_RSEQ_CAP) { cb.status |= EMA_ST_RSEQ_OVERFLOW; continue; }
 			bool have_win = MODE != 2;      // K2d fetches the window only if it has to run a DP itself
-			if (MODE != 2) {
+			if (MODE == 3) {
+				if (ci_sorted >= win_end) {
+					// The windows of this chain and of the next ones, as many as fit the buffer (at most four, each of at most 63 words +
+					// the odd bases: a longer one travels alone), in ONE round trip: every lane takes a word of each.
+					const int b = ci_sorted;
+					const int my_len = lane < n_keep ? (int)sl.cord[lane] : 0;
+					const int64_t my_r0 = lane < n_keep ? (int64_t)sl.cpos[lane] : 0;
+					if (rmax1 - rmax0 > 1008) {
+						ema_wave_fetch(ix, rmax0, rmax1, rseq);
+						if (lane == 0) sl.kept[b] = 0;
+						win_end = b + 1;
+					} else {
+						const unsigned long long big = __ballot(lane > b && my_len > 1008);
+						const int limit = big ? __ffsll((long long)big) - 1 : n_keep;
+						const int wl = (lane >= b && lane < limit && my_len > 0) ? my_len : 0;
+						const int incl = ema_wave_incl_scan_add(wl);
+						const unsigned long long nz = __ballot(wl > 0);
+						unsigned long long take = nz & __ballot(incl <= EMA_RSEQ_CAP), first4 = 0;
+						int ct[4] = {-1, -1, -1, -1};
+#pragma unroll
+						for (int t = 0; t < 4; ++t) if (take) { ct[t] = __ffsll((long long)take) - 1; first4 |= 1ULL << ct[t]; take &= take - 1; }
+						const unsigned long long blocked = nz & ~first4;
+						win_end = blocked ? __ffsll((long long)blocked) - 1 : limit;
+						if ((first4 >> lane) & 1) sl.kept[lane] = incl - wl;
+						EmaWin wn[4];
+						uint32_t word[4] = {0, 0, 0, 0};
+						int at[4] = {0, 0, 0, 0};
+#pragma unroll
+						for (int t = 0; t < 4; ++t) if (ct[t] >= 0) {
+							const int64_t r0 = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)my_r0, ct[t]) |
+							                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_r0 >> 32), ct[t]) << 32);
+							wn[t] = ema_win(ix, r0, r0 + __builtin_amdgcn_readlane(wl, ct[t]));
+							at[t] = __builtin_amdgcn_readlane(incl - wl, ct[t]);
+							if (lane < wn[t].n_dw) word[t] = ema_win_load(ix, wn[t], lane);
+						}
+#pragma unroll
+						for (int t = 0; t < 4; ++t) if (ct[t] >= 0 && lane < wn[t].n_dw) ema_win_unpack(wn[t], lane, word[t], rseq + at[t]);
+					}
+					ema_wave_sync();
+				}
+				rs = rseq + ema_uni((int)sl.kept[ci_sorted]);
+				// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
+				if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
+				ema_wave_sync();
+			} else if (MODE != 2) {
 				ema_wave_fetch(ix, rmax0, rmax1, rseq);
 				// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
 				ema_wave_sync();
@@ -935,7 +1056,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						const int prev = a.score;
 						aw0 = opt.w << i;
 						++n_dp;
-						r = ema_wave_extend(opt, s.qbeg, EmaSeq{query + s.qbeg - 1, -1}, tlen, EmaSeq{rseq + tlen - 1, -1}, aw0,
+						r = ema_wave_extend(opt, s.qbeg, EmaSeq{query + s.qbeg - 1, -1}, tlen, EmaSeq{rs + tlen - 1, -1}, aw0,
 						                    opt.pen_clip5, opt.zdrop, s.len * opt.a);
 						a.score = r.score;
 						if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -953,7 +1074,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						const int prev = a.score;
 						aw1 = opt.w << i;
 						++n_dp;
-						r = ema_wave_extend(opt, l_query - qe, EmaSeq{query + qe, 1}, (int)(rmax1 - rmax0 - re), EmaSeq{rseq + re, 1},
+						r = ema_wave_extend(opt, l_query - qe, EmaSeq{query + qe, 1}, (int)(rmax1 - rmax0 - re), EmaSeq{rs + re, 1},
 						                    aw1, opt.pen_clip3, opt.zdrop, sc0);
 						a.score = r.score;
 						if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
@@ -1029,7 +1150,7 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 {
 	HeavyCtl hv;
 	if (heavy) hv = *heavy;
-	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; hv.skip_handed = 0; }
+	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
 #define EMA_ALIGN_LAUNCH(...) hipLaunchKernelGGL((ema_k_align_t<__VA_ARGS__>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs, \
 	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof, hv)
 	const bool diag = prof != nullptr;

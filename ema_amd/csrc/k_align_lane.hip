@@ -248,14 +248,15 @@ __device__ inline int lane_sort_dedup(const DevIndex &ix, const DevOpts &o, int 
 }  // namespace
 
 // One lane = one read; a wave takes 64 consecutive reads at a time from the shared counter.
-// todo / n_todo: reads left for K2b (n_todo zero on entry).  scratch: EMA_LANE_WAVE_BYTES per resident wave.
+// todo / n_todo: reads left for K2b's full path (too many seed occurrences for a lane); hand / n_hand: the reads given up at the
+// extension, with their chains (both counters zero on entry).  scratch: EMA_LANE_WAVE_BYTES per resident wave.
 template <bool PROF>      // PROF: the diagnostic build (phase clocks); the product build carries none of its registers
 __global__ void __launch_bounds__(256)
 ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,
                    uint8_t *__restrict__ scratch, int *__restrict__ counter, int *__restrict__ todo, int *__restrict__ n_todo,
-                   uint8_t *__restrict__ hand, unsigned long long *prof_arg)
+                   uint8_t *__restrict__ hand, int *__restrict__ n_hand, unsigned long long *prof_arg)
 {
 	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	// diagnostic phase timing (prof != null): shader clocks per phase of this wave (all lanes move together)
@@ -462,16 +463,16 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 		EMA_PHASE(6);
 		int n_out = bail ? -1 : lane_sort_dedup(ix, opt, n_av, s, stack);
 		if (n_out < 0) {
-			// K2b redoes the read from mem_chain2aln on: hand it the chains, the filter's order and the seed pool
-			uint8_t *h = hand + (size_t)read * EMA_HAND_BYTES;
-			int32_t *head = reinterpret_cast<int32_t *>(h);
-			head[0] = n_chn; head[1] = n_seed;
-			uint64_t *hk = reinterpret_cast<uint64_t *>(h + 16);
-			ChainRec *hc = reinterpret_cast<ChainRec *>(h + 16 + EMA_HAND_SEEDS * 8);
-			SeedRec *hs = reinterpret_cast<SeedRec *>(h + 16 + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
+			// K2b redoes the read from mem_chain2aln on: hand it the chains, the filter's order and the seed pool (dev_types.h, HandHdr)
+			uint8_t *h = hand + (size_t)atomicAdd(n_hand, 1) * EMA_HAND_BYTES;
+			HandHdr hd;
+			hd.read = read; hd.n_chn = n_chn; hd.n_seed = n_seed; hd.l_query = l_query; hd.base_off = off[in_read]; hd.pad[0] = hd.pad[1] = hd.pad[2] = 0;
+			*reinterpret_cast<HandHdr *>(h) = hd;
+			uint64_t *hk = reinterpret_cast<uint64_t *>(h + sizeof(HandHdr));
+			ChainRec *hc = reinterpret_cast<ChainRec *>(h + sizeof(HandHdr) + EMA_HAND_SEEDS * 8);
+			SeedRec *hs = reinterpret_cast<SeedRec *>(h + sizeof(HandHdr) + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
 			for (int i = 0; i < n_chn; ++i) { hk[i] = s.skey[i]; hc[i] = s.chains[i]; }
 			for (int i = 0; i < n_seed; ++i) hs[i] = s.seeds[i];
-			todo[atomicAdd(n_todo, 1)] = (int)((unsigned)read | EMA_HAND_FLAG);
 			continue;
 		}
 		if (n_out > opt.reg_cap) { st |= EMA_ST_REG_OVERFLOW; n_out = opt.reg_cap; }
@@ -497,12 +498,12 @@ extern "C" int ema_align_simple_blocks_per_cu()
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
                                         int *n_regs, int *status, uint8_t *scratch, int *counter, int *todo, int *n_todo,
-                                        uint8_t *hand, int n_blocks, hipStream_t stream, unsigned long long *prof)
+                                        uint8_t *hand, int *n_hand, int n_blocks, hipStream_t stream, unsigned long long *prof)
 {
 	if (prof)
 		hipLaunchKernelGGL(ema_k_align_simple_t<true>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
-		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, prof);
+		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, n_hand, prof);
 	else
 		hipLaunchKernelGGL(ema_k_align_simple_t<false>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv,
-		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, prof);
+		                   n_intv, regs, n_regs, status, scratch, counter, todo, n_todo, hand, n_hand, prof);
 }

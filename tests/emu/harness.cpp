@@ -49,12 +49,12 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 	const bool lane = !v || atoi(v) != 0;
 	std::vector<int> todo(n_reads + 1);
 	std::vector<uint8_t> hand((size_t)n_reads * EMA_HAND_BYTES);
-	int n_todo = 0, c0 = 0, c1 = 0;
+	int n_todo = 0, n_hand = 0, c0 = 0, c1 = 0;
 	if (lane) {
 		std::vector<uint8_t> scratch((size_t)n_blocks * 4 * ema_align_lane_wave_bytes());
 		ema_launch_align_simple(&di, &d, qp, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, scratch.data(), &c0, todo.data(),
-		                        &n_todo, hand.data(), n_blocks, nullptr, nullptr);
-		fprintf(stderr, "emu K2a: %d of %d reads left for K2b\n", n_todo, n_reads);
+		                        &n_todo, hand.data(), &n_hand, n_blocks, nullptr, nullptr);
+		fprintf(stderr, "emu K2a: %d of %d reads handed over with their chains, %d left for K2b's full path\n", n_hand, n_reads, n_todo);
 	}
 	// EMU_HEAVY_CHAINS=n: K2b sets reads with at least n chains to extend aside for K2c / K2d (EMU_HEAVY_ARENA: arena bytes, to run it full)
 	const char *vh = getenv("EMU_HEAVY_CHAINS");
@@ -72,11 +72,9 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 		hv.n_reads = &hn[0]; hv.n_tasks = &hn[1]; hv.reads_cap = (int)hreads.size(); hv.tasks_cap = (int)htasks.size(); hv.min_chains = heavy_chains;
 	}
 	if (heavy_chains <= 0) { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
-	const bool split = lane && !(getenv("EMU_SPLIT_HANDED") && atoi(getenv("EMU_SPLIT_HANDED")) == 0);      // K2a's hand-overs on their own build, as the engine runs them
-	hv.skip_handed = split ? 1 : 0;
 	int c3 = 0;
-	if (split)
-		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, todo.data(), &n_todo, hand.data(), slabs,
+	if (lane)      // K2a's hand-overs on their own build
+		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, nullptr, &n_hand, hand.data(), slabs,
 		                 &c3, n_blocks, nullptr, nullptr, nullptr, &hv, 3);
 	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,
 	                 &c1, n_blocks, nullptr, nullptr, nullptr, &hv, 0);

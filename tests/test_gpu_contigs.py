@@ -80,4 +80,4 @@ def test_contig_lookups_equal_bwas(eng, layout):
     want_pos = np.array([bwa_pos2rid(offl, depos(int(b))) for b in rb], dtype=np.int32)
     assert np.array_equal(got_pos, want_pos), np.flatnonzero(got_pos != want_pos)[:10]
     assert np.array_equal(got_intv, want_intv), np.flatnonzero(got_intv != want_intv)[:10]
-    assert (want_intv == -1).sum() > 0 and (want_intv >= 0).sum() > 0
+    assert (want_intv >= 0).sum() > 0 and (len(lens) == 1 or (want_intv == -1).sum() > 0)

@@ -14,7 +14,7 @@ bases, off = z["bases"], z["off"]
 
 
 def run(env):
-    for k in ("EMA_LANE_ALIGN", "EMA_HEAVY_CHAINS", "EMA_KMER_K", "EMA_SPLIT_HANDED"):
+    for k in ("EMA_LANE_ALIGN", "EMA_HEAVY_CHAINS", "EMA_KMER_K"):
         os.environ.pop(k, None)
     os.environ.update(env)
     o = default_opts(); o.batch_pairs = (len(off) - 1) // 2
@@ -28,7 +28,7 @@ def run(env):
 
 
 a = run({})
-b = run({"EMA_LANE_ALIGN": "0", "EMA_HEAVY_CHAINS": "0", "EMA_KMER_K": "0", "EMA_SPLIT_HANDED": "0"})
+b = run({"EMA_LANE_ALIGN": "0", "EMA_HEAVY_CHAINS": "0", "EMA_KMER_K": "0"})
 assert np.array_equal(a.cand_off, b.cand_off), "candidate counts differ"
 fields = [f for f in a.cand.dtype.names if f != "cigar_off"]
 for f in fields:

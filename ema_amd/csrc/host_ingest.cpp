@@ -4,13 +4,15 @@
 // qsort of the line pointers by strncmp(.., BC_LEN), six copy_until_space calls into 568-byte FASTQRecords (reference
 // src/align.c:759-806, src/util.c:11-21,97-106) -- is here five data-parallel passes over the mapped file on the host's
 // cores, producing the engine's input layout directly:
-//   1. newline scan: per-chunk counts, prefix, line table (start, length);
-//   2. sort keys: the first bc_len bytes of each line, cut at the line's end and zero-padded (what strncmp sees: the
-//      buffer holds the line, its '\n', then NUL), as big-endian words + the line number, so that an ordinary sort is
-//      the stable order; chunk sorts and a merge tree;
-//   3. field extents of every line in sorted order, validation, lengths;
+//   1. newline scan: line table (start, length), field extents, validation, and -- the common case: barcodes of ACGT / acgt, at
+//      most 21 bases -- the barcode as a sort code of 3 bits per base in the order strncmp gives the bytes (A C G T a c g t);
+//   2. order: a stable radix sort of (code, line) -- or, for haplotag barcodes and longer ones, the first bc_len bytes of each
+//      line, cut at the line's end and zero-padded (what strncmp sees: the buffer holds the line, its '\n', then NUL), as
+//      big-endian words + the line number, chunk-sorted and merged;
+//   3. barcodes in sorted order (encode_bc, src/util.c:41-76): from the code, or from the text;
 //   4. prefix sums -> off[], id_off[];
-//   5. copies of bases / qualities / identifiers, barcode encoding (encode_bc, src/util.c:41-76), barcode groups
+//   5. copies of bases / qualities / identifiers: lines taken in FILE order (the source streams through the cache) and written
+//      to their sorted place -- a gather in sorted order waits for five cache misses per pair; barcode groups
 //      (seek_next_barcode_group's runs of equal bc, src/align.c:829-837).
 // No GPU work: parsing is byte-serial per line and the payload crosses PCIe once, as 2-bit packed reads, in
 // ema_engine_stage.
@@ -126,6 +128,37 @@ template <int W> void sorted_lines(const char *text, const std::vector<Line> &li
 }
 
 struct Fields { uint16_t id_b, id_l, r1_b, r1_l, q1_b, r2_b, r2_l, q2_b; };      // byte offsets within the line
+
+// Sort code of a barcode of ACGT / acgt: 3 bits per base, first base in the highest bits, in the order of the bytes' values
+// ('A' < 'C' < 'G' < 'T' < 'a' < 'c' < 'g' < 't'); the low two bits of a base's code are its encode_bc value.  -1: another byte.
+const struct BaseCode {
+	int8_t t[256];
+	BaseCode() { memset(t, -1, sizeof t); const char *b = "ACGTacgt"; for (int i = 0; i < 8; ++i) t[(unsigned char)b[i]] = (int8_t)i; }
+} kBaseCode;
+inline int base_code(unsigned char c) { return kBaseCode.t[c]; }
+
+// order[] = the lines by (code, line number): least-significant-digit radix sort, 8 bits a pass (stable, so equal codes keep
+// file order -- the order Key<W> + std::sort gives)
+void radix_order(const std::vector<uint64_t> &code, int bits, std::vector<uint32_t> &order)
+{
+	struct KV { uint64_t k; uint32_t i; };
+	const size_t n = code.size();
+	order.clear();
+	if (!n) return;
+	std::vector<KV> a(n), b(n);
+	for (size_t i = 0; i < n; ++i) { a[i].k = code[i]; a[i].i = (uint32_t)i; }
+	KV *src = a.data(), *dst = b.data();
+	for (int sh = 0; sh < bits; sh += 8) {
+		size_t cnt[257] = {0};
+		for (size_t i = 0; i < n; ++i) ++cnt[((src[i].k >> sh) & 255) + 1];
+		if (cnt[((src[0].k >> sh) & 255) + 1] == n) continue;      // every key has the same digit here
+		for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+		for (size_t i = 0; i < n; ++i) dst[cnt[(src[i].k >> sh) & 255]++] = src[i];
+		std::swap(src, dst);
+	}
+	order.resize(n);
+	for (size_t i = 0; i < n; ++i) order[i] = src[i].i;
+}
 
 enum Bad : uint8_t { kOk = 0, kLong, kFew, kBcLen, kBcBase, kIdEmpty, kIdLong, kReadLong, kQualLen };
 const char *const kBadText[] = {"", "line of 5000 bytes or more", "fewer than six fields", "barcode field is not bc_len bytes",
@@ -246,7 +279,8 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	// 1. lines and fields, in file order: each thread takes the lines that START in its stretch of the text
 	const size_t t_scan = std::max<size_t>(1, std::min<size_t>((size_t)n_threads(), len >> 20));
 	const size_t per = (len + t_scan - 1) / t_scan;
-	struct Part { std::vector<Line> lines; std::vector<Fields> fields; size_t bad_line = (size_t)-1; Bad bad = kOk; };
+	const bool coded = !is_haplotag && bc_len <= 21;      // barcodes travel as sort codes (base_code)
+	struct Part { std::vector<Line> lines; std::vector<Fields> fields; std::vector<uint64_t> codes; size_t bad_line = (size_t)-1; Bad bad = kOk; };
 	std::vector<Part> parts(t_scan);
 	auto scan = [&](size_t k) {
 		EMA_CPU(EMA_CPU_READER);
@@ -258,6 +292,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 			at = q ? (size_t)(q - text) + 1 : len;
 		}
 		pt.lines.reserve((e - b) / 256 + 16); pt.fields.reserve((e - b) / 256 + 16);
+		if (coded) pt.codes.reserve((e - b) / 256 + 16);
 		while (at < e && at < len) {
 			const char *s = text + at;
 			const size_t room = len - at;
@@ -271,11 +306,21 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 			if (ln > kMaxLine) bad = kLong;
 			else if (!six) bad = kFew;
 			else if (fl[0] != (size_t)bc_len) bad = kBcLen;
-			else if (!is_haplotag && !acgt_only(s, (size_t)bc_len)) bad = kBcBase;
+			else if (!is_haplotag && !coded && !acgt_only(s, (size_t)bc_len)) bad = kBcBase;
 			else if (fl[1] == 0) bad = kIdEmpty;
 			else if (fl[1] > kMaxId) bad = kIdLong;
 			else if (fl[2] > (size_t)max_read_len || fl[4] > (size_t)max_read_len) bad = kReadLong;
 			else if (fl[3] != fl[2] || fl[5] != fl[4]) bad = kQualLen;
+			uint64_t code = 0;
+			if (bad == kOk && coded) {
+				int any_bad = 0;
+				for (int j = 0; j < bc_len; ++j) {
+					const int c = base_code((unsigned char)s[j]);
+					any_bad |= c;
+					code = code << 3 | (uint64_t)(c & 7);
+				}
+				if (any_bad < 0) bad = kBcBase;
+			}
 			if (bad == kOk) {
 				f.id_b = (uint16_t)fb[1]; f.id_l = (uint16_t)fl[1];
 				f.r1_b = (uint16_t)fb[2]; f.r1_l = (uint16_t)fl[2]; f.q1_b = (uint16_t)fb[3];
@@ -283,6 +328,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 			} else if (pt.bad == kOk) { pt.bad = bad; pt.bad_line = pt.lines.size(); }
 			pt.lines.push_back(Line{(uint64_t)at, (uint32_t)std::min<size_t>(ln, UINT32_MAX)});
 			pt.fields.push_back(f);
+			if (coded) pt.codes.push_back(code);
 			at += ln;
 		}
 	};
@@ -301,13 +347,15 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 			return fail(EMA_EFORMAT, "line " + std::to_string(first[k] + parts[k].bad_line + 1) + ": " + kBadText[parts[k].bad]);
 	std::vector<Line> lines(n);
 	std::vector<Fields> fields(n);      // by line number
+	std::vector<uint64_t> codes(coded ? n : 0);
 	{
 		std::vector<std::thread> th;
 		auto gather = [&](size_t k) {
 			EMA_CPU(EMA_CPU_READER);
 			std::copy(parts[k].lines.begin(), parts[k].lines.end(), lines.begin() + first[k]);
 			std::copy(parts[k].fields.begin(), parts[k].fields.end(), fields.begin() + first[k]);
-			std::vector<Line>().swap(parts[k].lines); std::vector<Fields>().swap(parts[k].fields);
+			if (coded) std::copy(parts[k].codes.begin(), parts[k].codes.end(), codes.begin() + first[k]);
+			std::vector<Line>().swap(parts[k].lines); std::vector<Fields>().swap(parts[k].fields); std::vector<uint64_t>().swap(parts[k].codes);
 		};
 		for (size_t k = 1; k < t_scan; ++k) th.emplace_back(gather, k);
 		gather(0);
@@ -316,7 +364,8 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	lap("scan");
 	// 2. order
 	std::vector<uint32_t> order;
-	switch ((bc_len + 7) / 8) {
+	if (coded) radix_order(codes, 3 * bc_len, order);
+	else switch ((bc_len + 7) / 8) {
 	case 1: sorted_lines<1>(text, lines, bc_len, order); break;
 	case 2: sorted_lines<2>(text, lines, bc_len, order); break;
 	case 3: sorted_lines<3>(text, lines, bc_len, order); break;
@@ -334,6 +383,13 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	std::vector<size_t> bad_bc((size_t)n_threads() + 1, (size_t)-1);
 	parallel_ranges(n, 1 << 12, [&](size_t k, size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) {
+			if (coded) {      // two bits a base, first base lowest (encode_bc_default): the low bits of the sort code's digits
+				const uint64_t code = codes[order[i]];
+				uint64_t v = 0;
+				for (int t = 0; t < bc_len; ++t) v = v << 2 | ((code >> (3 * t)) & 3);
+				o->bc[i] = v;
+				continue;
+			}
 			const char *s = text + lines[order[i]].start;
 			if (is_haplotag) o->bc[i] = encode_haplotag(s);
 			else if (encode_default(s, bc_len, &o->bc[i])) { o->bc[i] = 0; bad_bc[k] = std::min<size_t>(bad_bc[k], order[i]); }
@@ -363,11 +419,14 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	o->ids = (char *)malloc(ni + 1);
 	if (!o->bases || !o->quals || !o->ids) { ema_bucket_free(o); g_err = "out of memory"; return EMA_EIO; }
 	lap("offsets");
-	// 5. payload
+	// 5. payload, lines in file order to their sorted places
+	std::vector<uint32_t> rank(n);
+	parallel_ranges(n, 1 << 14, [&](size_t, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) rank[order[i]] = (uint32_t)i; });
 	parallel_ranges(n, 1 << 12, [&](size_t, size_t lo, size_t hi) {
-		for (size_t i = lo; i < hi; ++i) {
-			const char *s = text + lines[order[i]].start;
-			const Fields &f = fields[order[i]];
+		for (size_t ln = lo; ln < hi; ++ln) {
+			const size_t i = rank[ln];
+			const char *s = text + lines[ln].start;
+			const Fields &f = fields[ln];
 			memcpy(o->bases + o->off[2 * i], s + f.r1_b, f.r1_l);
 			memcpy(o->quals + o->off[2 * i], s + f.q1_b, f.r1_l);
 			memcpy(o->bases + o->off[2 * i + 1], s + f.r2_b, f.r2_l);

@@ -32,6 +32,7 @@
 #include "host_index.h"
 #include "opts.h"
 #include "host_cpuacct.h"
+#include "host_pool.h"
 
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
@@ -78,6 +79,7 @@ extern "C" void ema_launch_collect(int n_pairs, int first_pair, int *status, int
 extern "C" void ema_launch_pack(int n_reads, const int *n_pairs_dev, const int *status, int reg_cap, const DevReg *regs, const int *n_regs, const DevAln *alns, const uint32_t *cigars,
                                 const int *cig_n, int cig_cap, const uint64_t *cand_off, const uint64_t *cig_off,
                                 uint64_t cig_base, ema_cand_t *cand, uint32_t *cigar_out, uint64_t cand_cap, uint64_t cigar_cap, int n_blocks, hipStream_t stream);
+extern "C" void ema_launch_stage_reads(const uint32_t *off, int n_reads, uint8_t *bases, uint32_t *qpack, hipStream_t stream);
 extern "C" void ema_launch_scan(int n_reads, const int *n_pairs_dev, const int *status, const int *n_regs, const int *cig_n, uint2 *block_tot,
                                 uint64_t *tot, uint64_t *cand_off, uint64_t *cig_off, hipStream_t stream);
 extern "C" void ema_launch_test_extend(const DevOpts *opt, const uint8_t *qbuf, const uint32_t *qoff, const uint8_t *tbuf,
@@ -110,21 +112,15 @@ const unsigned char kNt4[256] = {
 // result loops are memory-bound byte shuffles that one core does at ~1 GB/s
 template <typename F> void host_parallel(size_t n, F fn)
 {
-	static int n_thr = [] {
-		const char *v = getenv("EMA_HOST_THREADS");
-		int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
-		return t < 1 ? 1 : t > 32 ? 32 : t;
-	}();
-	const size_t t = n < 65536 ? 1 : (size_t)n_thr;
+	const size_t t = n < 65536 ? 1 : (size_t)EmaPool::get().size();      // host_pool.h
 	if (t == 1) { fn((size_t)0, n); return; }
-	std::vector<std::thread> th;
 	const size_t per = (n + t - 1) / t;
 	const int stage = ema_cpu_current;      // the caller's stage (host_cpuacct.h)
-	for (size_t k = 0; k < t; ++k) {
+	EmaPool::get().run(t, [&](size_t k) {
+		EMA_CPU(stage);
 		const size_t b = k * per, e = b + per < n ? b + per : n;
-		if (b < e) th.emplace_back([=] { EMA_CPU(stage); fn(b, e); });
-	}
-	for (auto &x : th) x.join();
+		if (b < e) fn(b, e);
+	});
 }
 
 // page-locked host staging buffer (asynchronous copies at full PCIe rate)
@@ -265,7 +261,7 @@ struct ema_engine {
 	size_t cap_pairs = 0, n_pairs = 0;
 	bool staged = false, ran = false, ever_ran = false;
 	PinBuf<uint8_t> h_nt4;
-	PinBuf<uint32_t> h_off, h_qpack;
+	PinBuf<uint32_t> h_off;
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
@@ -585,7 +581,7 @@ void ema_engine_close(ema_engine_t *e)
 	if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
 	for (auto &ev : e->slot_free) if (ev) (void)hipEventDestroy(ev);
 	e->d_k1w_args.release();
-	e->h_nt4.release(); e->h_off.release(); e->h_qpack.release();
+	e->h_nt4.release(); e->h_off.release();
 	for (auto &fp : e->fetch_pin) { fp.c_off.release(); fp.g_off.release(); fp.status.release(); fp.cand.release(); fp.cig.release(); }
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_ctg_tab.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
 	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
@@ -672,35 +668,23 @@ static int stage_slot_impl(ema_engine_t *e, int slot, const char *bases, const u
 	}
 	const size_t n_reads = 2 * n_pairs;
 	HIPCHK(e, e->h_off.reserve(2 * e->cap_pairs + 1));
-	HIPCHK(e, e->h_qpack.reserve(2 * e->cap_pairs * 24 + 8));
 	const uint32_t base0 = off[0];
 	for (size_t r = 0; r <= n_reads; ++r) e->h_off.p[r] = off[r] - base0;
 	for (size_t r = 0; r < n_reads; ++r)
 		if (off[r + 1] < off[r] || off[r + 1] - off[r] > EMA_MAX_READ) { e->err = "read longer than EMA_MAX_READ"; return EMA_ELIMIT; }
 	const size_t total = e->h_off.p[n_reads];
 	HIPCHK(e, e->h_nt4.reserve(2 * e->cap_pairs * (size_t)(EMA_MAX_READ + 1)));
+	// The caller's bytes go up as they are (through the page-locked buffer: asynchronous copies at full PCIe rate); the device
+	// turns them into nt4 codes and the packed form (ema_k_stage_reads, k_pack.hip: seq_convert, reference src/bwabridge.c:151-157).
 	const unsigned char *src = (const unsigned char *)bases + base0;
-	uint8_t *nt4 = e->h_nt4.p;
-	host_parallel(total, [=](size_t b0, size_t b1) { for (size_t i = b0; i < b1; ++i) nt4[i] = kNt4[src[i]]; });   // seq_convert, reference src/bwabridge.c:151-157
-	uint32_t *qpack = e->h_qpack.p;
-	const uint32_t *hoff = e->h_off.p;
-	memset(qpack + n_reads * 24, 0, 8 * 4);
-	host_parallel(n_reads, [=](size_t r0, size_t r1) {
-	for (size_t r = r0; r < r1; ++r) {
-		uint32_t *w = qpack + r * 24;
-		memset(w, 0, 24 * 4);
-		const uint8_t *b = nt4 + hoff[r];
-		const uint32_t len = hoff[r + 1] - hoff[r];
-		for (uint32_t i = 0; i < len; ++i) {
-			w[i >> 4] |= (uint32_t)(b[i] & 3) << ((i & 15) << 1);
-			if (b[i] > 3) w[16 + (i >> 5)] |= 1u << (i & 31);
-		}
-	}
-	});
+	uint8_t *raw = e->h_nt4.p;
+	host_parallel(total, [=](size_t b0, size_t b1) { memcpy(raw + b0, src + b0, b1 - b0); });
 	hipStream_t st = async ? e->h2d_stream : e->sl[0].stream;
-	HIPCHK(e, hipMemcpyAsync(in.d_qpack.p, e->h_qpack.p, (n_reads * 24 + 8) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(e, hipMemcpyAsync(in.d_bases.p, e->h_nt4.p, total, hipMemcpyHostToDevice, st));
 	HIPCHK(e, hipMemcpyAsync(in.d_off.p, e->h_off.p, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(e, hipMemsetAsync(in.d_qpack.p + n_reads * 24, 0, 8 * 4, st));
+	ema_launch_stage_reads(in.d_off.p, (int)n_reads, in.d_bases.p, in.d_qpack.p, st);
+	HIPCHK(e, hipGetLastError());
 	HIPCHK(e, hipStreamSynchronize(st));
 	in.n_pairs = n_pairs; in.staged = true;
 	return async ? EMA_OK : select_slot(e, slot);
@@ -1688,12 +1672,7 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 		ema_batch_free(q);
 	};
 	{
-		const size_t n_thr = std::min<size_t>(n_parts, 16);
-		auto lane = [&](size_t first) { for (size_t k = first; k < n_parts; k += n_thr) place(k); };
-		std::vector<std::thread> th;
-		for (size_t t = 1; t < n_thr; ++t) th.emplace_back(lane, t);
-		lane(0);
-		for (auto &t : th) t.join();
+		EmaPool::get().run(n_parts, [&](size_t k) { EMA_CPU(EMA_CPU_FETCH); place(k); });
 	}
 	o->cand_off[2 * n_pairs] = c_at[n_parts];
 	*out = o;

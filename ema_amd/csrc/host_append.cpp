@@ -12,6 +12,7 @@
 #include <vector>
 #include "ema_engine.h"
 #include "host_cpuacct.h"
+#include "host_pool.h"
 
 extern "C" void ema_aln_free(ema_aln_out *o);
 namespace {
@@ -66,9 +67,7 @@ extern "C" int ema_batch_append_alignments(const ema_batch_out *b, const uint32_
 	// each into its own list; the lists are then laid end to end
 	int n_thr = 1;
 	{
-		const char *v = getenv("EMA_HOST_THREADS");
-		n_thr = v ? atoi(v) : (int)std::thread::hardware_concurrency();
-		n_thr = n_thr < 1 ? 1 : n_thr > 32 ? 32 : n_thr;
+		n_thr = EmaPool::get().size();      // host_pool.h
 		if (b->n_pairs < 4096) n_thr = 1;
 	}
 	std::vector<std::vector<ema_aln_rec>> part(n_thr);
@@ -120,12 +119,7 @@ extern "C" int ema_batch_append_alignments(const ema_batch_out *b, const uint32_
 			}
 		}
 	};
-	if (n_thr == 1) work(0);
-	else {
-		std::vector<std::thread> th;
-		for (int t = 0; t < n_thr; ++t) th.emplace_back(work, t);
-		for (auto &x : th) x.join();
-	}
+	EmaPool::get().run((size_t)n_thr, [&](size_t t) { work((int)t); });
 	for (int t = 0; t < n_thr; ++t) if (bad[t]) { free(o->pair_off); free(o); return EMA_EARG; }
 	size_t total = 0;
 	for (int t = 0; t < n_thr; ++t) total += part[t].size();

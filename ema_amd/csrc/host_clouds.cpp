@@ -22,6 +22,7 @@
 #include <vector>
 #include "ema_clouds.h"
 #include "host_cpuacct.h"
+#include "host_pool.h"
 
 namespace {
 
@@ -529,10 +530,7 @@ void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 
 int n_host_threads(int want)
 {
-	if (want > 0) return want;
-	const char *v = getenv("EMA_HOST_THREADS");
-	int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
-	return t < 1 ? 1 : t > 32 ? 32 : t;
+	return want > 0 ? want : EmaPool::get().size();      // (pieces of a pass: the pool runs as many at a time as it has threads)
 }
 
 }  // namespace
@@ -597,10 +595,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 		};
 		// -d draws from libc's rand(): one thread, groups in order, so that the draws fall as in a `-t 1` run of the reference
 		const int nt = S.o.density_opt ? 1 : (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 16 + 1);
-		std::vector<std::thread> th;
-		for (int t = 1; t < nt; ++t) th.emplace_back(run);
-		run();
-		for (auto &t : th) t.join();
+		EmaPool::get().run((size_t)nt, [&](size_t) { run(); });
 	}
 	// assembly: cloud numbers of a single-threaded run, the selected records as formatter input, statistics -- on the host's threads
 	// as well (round 2 did this part on one: more than half of the stage's wall time, r03): the offsets of every group's records
@@ -713,12 +708,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 			}
 		}
 	};
-	{
-		std::vector<std::thread> th;
-		for (int t = 1; t < nt_asm; ++t) th.emplace_back(assemble, t);
-		assemble(0);
-		for (auto &t : th) t.join();
-	}
+	EmaPool::get().run((size_t)nt_asm, [&](size_t t) { assemble((int)t); });
 	for (const auto &ps : part) {
 		o->stats.lines += ps.lines; o->stats.mapped += ps.mapped; o->stats.unmapped_mates += ps.unmapped_mates; o->stats.proper += ps.proper;
 		o->stats.duplicates += ps.duplicates; o->stats.with_xa += ps.with_xa;

@@ -34,6 +34,7 @@
 #include <unistd.h>
 #include "ema_ingest.h"
 #include "host_cpuacct.h"
+#include "host_pool.h"
 
 namespace {
 
@@ -42,28 +43,19 @@ thread_local std::string g_err;
 const size_t kMaxLine = 4999;      // fgets(buf, 5000): at most 4999 bytes per call, '\n' included (src/align.c:762,768)
 const size_t kMaxId = 149;         // id[150] (include/samrecord.h:12)
 
-int n_threads()
-{
-	static int n = [] {
-		const char *v = getenv("EMA_HOST_THREADS");
-		int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
-		return t < 1 ? 1 : t > 32 ? 32 : t;
-	}();
-	return n;
-}
+int n_threads() { return EmaPool::get().size(); }      // host_pool.h
 
-// fn(k, b, e) on contiguous ranges of [0, n), one per thread
+// fn(k, b, e) on contiguous ranges of [0, n), one per thread of the pool
 template <typename F> void parallel_ranges(size_t n, size_t min_per_thread, F fn)
 {
 	size_t t = std::min<size_t>((size_t)n_threads(), n / std::max<size_t>(min_per_thread, 1));
 	if (t <= 1) { fn((size_t)0, (size_t)0, n); return; }
 	const size_t per = (n + t - 1) / t;
-	std::vector<std::thread> th;
-	for (size_t k = 0; k < t; ++k) {
+	EmaPool::get().run(t, [&](size_t k) {
+		EMA_CPU(EMA_CPU_READER);
 		const size_t b = k * per, e = std::min(n, b + per);
-		if (b < e) th.emplace_back([=] { EMA_CPU(EMA_CPU_READER); fn(k, b, e); });
-	}
-	for (auto &x : th) x.join();
+		if (b < e) fn(k, b, e);
+	});
 }
 
 // isspace() in the "C" locale, which is what the reference runs in (it never calls setlocale)
@@ -105,21 +97,16 @@ template <int W> void sorted_lines(const char *text, const std::vector<Line> &li
 	while (t * 2 <= (size_t)n_threads() && n / (t * 2) >= (1 << 14)) t *= 2;
 	const size_t per = (n + t - 1) / t;
 	auto lo_of = [&](size_t k) { return std::min(n, k * per); };
-	{
-		std::vector<std::thread> th;
-		for (size_t k = 1; k < t; ++k) th.emplace_back([&, k] { EMA_CPU(EMA_CPU_READER); std::sort(a.begin() + lo_of(k), a.begin() + lo_of(k + 1)); });
-		std::sort(a.begin() + lo_of(0), a.begin() + lo_of(1));
-		for (auto &x : th) x.join();
-	}
+	EmaPool::get().run(t, [&](size_t k) { EMA_CPU(EMA_CPU_READER); std::sort(a.begin() + lo_of(k), a.begin() + lo_of(k + 1)); });
 	if (t > 1) b.resize(n);
 	std::vector<Key<W>> *src = &a, *dst = &b;
 	for (size_t width = 1; width < t; width *= 2) {
-		std::vector<std::thread> th;
-		for (size_t k = 0; k < t; k += 2 * width) {
+		EmaPool::get().run((t + 2 * width - 1) / (2 * width), [&](size_t j) {
+			EMA_CPU(EMA_CPU_READER);
+			const size_t k = j * 2 * width;
 			const size_t l = lo_of(k), m = lo_of(std::min(t, k + width)), r = lo_of(std::min(t, k + 2 * width));
-			th.emplace_back([=] { EMA_CPU(EMA_CPU_READER); std::merge(src->begin() + l, src->begin() + m, src->begin() + m, src->begin() + r, dst->begin() + l); });
-		}
-		for (auto &x : th) x.join();
+			std::merge(src->begin() + l, src->begin() + m, src->begin() + m, src->begin() + r, dst->begin() + l);
+		});
 		std::swap(src, dst);
 	}
 	order.resize(n);
@@ -332,12 +319,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 			at += ln;
 		}
 	};
-	{
-		std::vector<std::thread> th;
-		for (size_t k = 1; k < t_scan; ++k) th.emplace_back(scan, k);
-		scan(0);
-		for (auto &x : th) x.join();
-	}
+	EmaPool::get().run(t_scan, scan);
 	std::vector<size_t> first(t_scan + 1, 0);
 	for (size_t k = 0; k < t_scan; ++k) first[k + 1] = first[k] + parts[k].lines.size();
 	const size_t n = first[t_scan];
@@ -349,7 +331,6 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 	std::vector<Fields> fields(n);      // by line number
 	std::vector<uint64_t> codes(coded ? n : 0);
 	{
-		std::vector<std::thread> th;
 		auto gather = [&](size_t k) {
 			EMA_CPU(EMA_CPU_READER);
 			std::copy(parts[k].lines.begin(), parts[k].lines.end(), lines.begin() + first[k]);
@@ -357,9 +338,7 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
 			if (coded) std::copy(parts[k].codes.begin(), parts[k].codes.end(), codes.begin() + first[k]);
 			std::vector<Line>().swap(parts[k].lines); std::vector<Fields>().swap(parts[k].fields); std::vector<uint64_t>().swap(parts[k].codes);
 		};
-		for (size_t k = 1; k < t_scan; ++k) th.emplace_back(gather, k);
-		gather(0);
-		for (auto &x : th) x.join();
+		EmaPool::get().run(t_scan, gather);
 	}
 	lap("scan");
 	// 2. order

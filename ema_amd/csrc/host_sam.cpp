@@ -16,8 +16,12 @@
 #include <unistd.h>
 #include <poll.h>
 #include <cerrno>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include "ema_sam.h"
 #include "host_cpuacct.h"
+#include "host_pool.h"
 
 namespace {
 
@@ -47,24 +51,78 @@ struct Out {
 	void i64(int64_t v) { if (v < 0) { *p++ = '-'; u64((uint64_t)0 - (uint64_t)v); } else u64((uint64_t)v); }
 };
 
-size_t line_bound(const ema_sam_rec *rec, const ema_sam_rec *mate, const ema_sam_opts &opt)
-{
-	const ema_sam_rec *r = rec ? rec : mate;
-	size_t b = 512 + strlen(r->ident) + (opt.rg_id ? strlen(opt.rg_id) : 0) + strlen(opt.bx_index);
-	b += 2 * (size_t)(rec ? rec->read_len : mate->mate_read_len);
-	if (rec) {
-		b += strlen(rec->chrom) + 12 * (size_t)rec->n_cigar;
-		for (size_t i = 0; i < rec->n_alts; ++i) b += strlen(rec->alts[i].chrom) + 12 * (size_t)rec->alts[i].n_cigar + 48;
-	}
-	if (mate) b += strlen(mate->chrom);
-	return b;
-}
+// what a call's lines share: lengths of the option strings (the RG identifier ends at its first whitespace, src/samrecord.c)
+struct Shared { size_t rg_len = 0, bx_len = 0; };
 
 const struct CompTable {
 	char t[256];
 	CompTable() { memset(t, 0, sizeof t); t['A'] = 'T'; t['C'] = 'G'; t['G'] = 'C'; t['T'] = 'A'; t['N'] = 'N'; }
 	char operator[](unsigned char c) const { return t[c]; }
 } kComp;
+
+size_t line_bound(const ema_sam_rec *rec, const ema_sam_rec *mate, const Shared &sh, size_t ident_len, size_t chrom_len, size_t mchrom_len)
+{
+	size_t b = 512 + ident_len + sh.rg_len + sh.bx_len + chrom_len + mchrom_len;
+	b += 2 * (size_t)(rec ? rec->read_len : mate->mate_read_len);
+	if (rec) {
+		b += 12 * (size_t)rec->n_cigar;
+		for (size_t i = 0; i < rec->n_alts; ++i) b += strlen(rec->alts[i].chrom) + 12 * (size_t)rec->alts[i].n_cigar + 48;
+	}
+	return b;
+}
+
+// A reversed read and its qualities, sixteen bytes at a time where the CPU has PSHUFB (every x86-64 of the last fifteen years;
+// checked at run time): the byte order through one shuffle, the complement through a second one on the low nibbles of
+// A C G T N (1 3 7 4 14: all different), and a third one that maps the result back, which only the five valid bytes survive.
+// rc(), src/samrecord.c:86-102; false = a byte outside ACGTN.
+bool revcomp_scalar(char *dst, const char *src, int n)
+{
+	for (int i = n - 1; i >= 0; --i) {
+		const char c = kComp[(unsigned char)src[i]];
+		if (!c) return false;
+		*dst++ = c;
+	}
+	return true;
+}
+void reverse_scalar(char *dst, const char *src, int n) { for (int i = n - 1; i >= 0; --i) *dst++ = src[i]; }
+
+#if defined(__x86_64__)
+__attribute__((target("ssse3"))) bool revcomp_ssse3(char *dst, const char *src, int n)
+{
+	const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+	const __m128i comp = _mm_setr_epi8(0, 'T', 0, 'G', 'A', 0, 0, 'C', 0, 0, 0, 0, 0, 0, 'N', 0);      // by low nibble: A=1 C=3 T=4 G=7 N=14
+	const __m128i low = _mm_set1_epi8(0x0f);
+	int i = n;
+	__m128i bad = _mm_setzero_si128();
+	while (i >= 16) {
+		i -= 16;
+		const __m128i x = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(src + i)), rev);
+		const __m128i y = _mm_shuffle_epi8(comp, _mm_and_si128(x, low));
+		const __m128i back = _mm_shuffle_epi8(comp, _mm_and_si128(y, low));      // the complement of the complement: x again, if x is valid
+		bad = _mm_or_si128(bad, _mm_xor_si128(back, x));
+		_mm_storeu_si128((__m128i *)dst, y);
+		dst += 16;
+	}
+	if (_mm_movemask_epi8(_mm_cmpeq_epi8(bad, _mm_setzero_si128())) != 0xffff) return false;
+	return revcomp_scalar(dst, src, i);
+}
+__attribute__((target("ssse3"))) void reverse_ssse3(char *dst, const char *src, int n)
+{
+	const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+	int i = n;
+	while (i >= 16) {
+		i -= 16;
+		_mm_storeu_si128((__m128i *)dst, _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(src + i)), rev));
+		dst += 16;
+	}
+	reverse_scalar(dst, src, i);
+}
+const bool kHaveSsse3 = __builtin_cpu_supports("ssse3");
+#else
+const bool kHaveSsse3 = false;
+bool revcomp_ssse3(char *dst, const char *src, int n) { return revcomp_scalar(dst, src, n); }
+void reverse_ssse3(char *dst, const char *src, int n) { reverse_scalar(dst, src, n); }
+#endif
 
 int ref_len(int n_cigar, const uint32_t *cigar)      // get_rlen, src/samrecord.c:75-84
 {
@@ -98,9 +156,10 @@ void decode_bc(uint64_t bc, const ema_sam_opts &opt, char *out)      // src/util
 }
 
 // one line; false: a base outside ACGTN in a reversed read
-bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema_sam_opts &opt)
+bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema_sam_opts &opt, const Shared &sh)
 {
-	o.room(line_bound(rec, mate, opt));
+	const size_t ident_len = strlen(rec ? rec->ident : mate->ident), chrom_len = rec ? strlen(rec->chrom) : 1, mchrom_len = mate ? strlen(mate->chrom) : 0;
+	o.room(line_bound(rec, mate, sh, ident_len, chrom_len, mchrom_len));
 	int flag = kPaired, mapq = 0, read_len;
 	const char *ident, *chrom = "*", *read, *qual;
 	uint32_t pos = 0;
@@ -124,11 +183,13 @@ bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema
 		if (rec && is_pair(rec, mate, opt)) flag |= kProper;
 		if (mate->rev) flag |= kMateReversed;
 	} else flag |= kMateUnmapped;
-	o.str(ident); o.ch('\t'); o.i64(flag); o.ch('\t'); o.str(chrom); o.ch('\t'); o.u64(pos); o.ch('\t'); o.i64(mapq); o.ch('\t');
+	o.mem(ident, ident_len); o.ch('\t'); o.i64(flag); o.ch('\t'); o.mem(chrom, chrom_len); o.ch('\t'); o.u64(pos); o.ch('\t'); o.i64(mapq); o.ch('\t');
 	if (rec) put_cigar(o, rec->cigar, rec->n_cigar); else o.ch('*');
 	if (mate) {
 		const bool same_chrom = rec && mate->chrom_id == rec->chrom_id;
-		o.ch('\t'); o.str(same_chrom ? "=" : mate->chrom); o.ch('\t'); o.i64((int)mate->pos);      // "%d" of a uint32_t
+		o.ch('\t');
+		if (same_chrom) o.ch('='); else o.mem(mate->chrom, mchrom_len);
+		o.ch('\t'); o.i64((int)mate->pos);      // "%d" of a uint32_t
 		if (same_chrom) {
 			const int64_t p0 = rec->aln_pos + (rec->aln_rev ? ref_len(rec->n_cigar, rec->cigar) - 1 : 0);
 			const int64_t p1 = mate->aln_pos + (mate->aln_rev ? ref_len(mate->n_cigar, mate->cigar) - 1 : 0);
@@ -139,13 +200,11 @@ bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema
 	} else o.str("\t*\t0\t0");
 	o.ch('\t');
 	if (rec && rec->rev) {
-		for (int i = read_len - 1; i >= 0; --i) {
-			const char c = kComp[(unsigned char)read[i]];      // rc(), src/samrecord.c:86-102
-			if (!c) return false;
-			o.ch(c);
-		}
+		if (!(kHaveSsse3 ? revcomp_ssse3(o.p, read, read_len) : revcomp_scalar(o.p, read, read_len))) return false;
+		o.p += read_len;
 		o.ch('\t');
-		for (int i = read_len - 1; i >= 0; --i) o.ch(qual[i]);
+		if (kHaveSsse3) reverse_ssse3(o.p, qual, read_len); else reverse_scalar(o.p, qual, read_len);
+		o.p += read_len;
 	} else {
 		o.mem(read, (size_t)read_len); o.ch('\t'); o.mem(qual, (size_t)read_len);
 	}
@@ -157,7 +216,7 @@ bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema
 		else if (rec->gamma == 0.0) { g[0] = '0'; g[1] = 0; }
 		else snprintf(g, sizeof g, "%.5g", rec->gamma);
 		o.str("\tNM:i:"); o.i64(rec->edit_dist); o.str("\tBX:Z:"); o.str(bc_str);
-		if (!opt.is_haplotag) { o.ch('-'); o.str(opt.bx_index); }
+		if (!opt.is_haplotag) { o.ch('-'); o.mem(opt.bx_index, sh.bx_len); }
 		o.str("\tXG:f:"); o.str(g); o.str("\tMI:i:"); o.i64(rec->cloud_id); o.str("\tXF:i:"); o.i64(rec->cloud_bad);
 	} else {
 		o.str("\tBX:Z:"); o.str(bc_str);
@@ -165,7 +224,7 @@ bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema
 	}
 	if (opt.rg_id) {
 		o.str("\tRG:Z:");
-		for (size_t i = 0; opt.rg_id[i] && !(opt.rg_id[i] == ' ' || (opt.rg_id[i] >= '\t' && opt.rg_id[i] <= '\r')); ++i) o.ch(opt.rg_id[i]);
+		o.mem(opt.rg_id, sh.rg_len);
 	}
 	if (rec && rec->n_alts > 0) {
 		o.str("\tXA:Z:");
@@ -198,27 +257,22 @@ static int format_parts(const ema_sam_line *lines, size_t n, const ema_sam_opts 
 {
 	if ((!lines && n) || !opt || !opt->bx_index || opt->bc_len < 1 || opt->bc_len > 32 || (opt->is_haplotag && opt->bc_len != 12)) return EMA_EARG;
 	for (size_t i = 0; i < n; ++i) if (!lines[i].rec && !lines[i].mate) return EMA_EARG;
-	static int n_thr_max = [] {
-		const char *v = getenv("EMA_HOST_THREADS");
-		int t = v ? atoi(v) : (int)std::thread::hardware_concurrency();
-		return t < 1 ? 1 : t > 32 ? 32 : t;
-	}();
-	const size_t t = n < 4096 ? 1 : (size_t)n_thr_max, per = (n + t - 1) / t;
+	const size_t t = n < 4096 ? 1 : (size_t)EmaPool::get().size(), per = (n + t - 1) / t;      // host_pool.h
 	// the threads' buffers are the caller's thread's from call to call (grown, never handed back: a fresh 30 MB vector per call is
 	// zero-filled and page-faulted before the first byte is formatted)
 	if (parts.size() < t) parts.resize(t);
 	for (auto &pt : parts) { pt.n = 0; pt.p = nullptr; }
 	std::vector<int> bad(t, 0);
+	Shared sh;
+	sh.bx_len = strlen(opt->bx_index);
+	if (opt->rg_id) for (size_t i = 0; opt->rg_id[i] && !(opt->rg_id[i] == ' ' || (opt->rg_id[i] >= '\t' && opt->rg_id[i] <= '\r')); ++i) sh.rg_len = i + 1;
 	auto work = [&](size_t k) {
 		EMA_CPU(EMA_CPU_FORMAT);
 		const size_t lo = std::min(n, k * per), hi = std::min(n, lo + per);
 		if (parts[k].buf.size() < (hi - lo) * 400 + (1 << 16)) parts[k].buf.resize((hi - lo) * 400 + (1 << 16));
-		for (size_t i = lo; i < hi; ++i) if (!put_line(parts[k], lines[i].rec, lines[i].mate, *opt)) { bad[k] = 1; return; }
+		for (size_t i = lo; i < hi; ++i) if (!put_line(parts[k], lines[i].rec, lines[i].mate, *opt, sh)) { bad[k] = 1; return; }
 	};
-	std::vector<std::thread> th;
-	for (size_t k = 1; k < t; ++k) th.emplace_back(work, k);
-	work(0);
-	for (auto &x : th) x.join();
+	EmaPool::get().run(t, work);
 	for (int b : bad) if (b) return EMA_EFORMAT;
 	return 0;
 }
@@ -239,11 +293,8 @@ int ema_sam_format(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt,
 	char *buf = (char *)malloc(total + 1);
 	if (!buf) return EMA_EARG;
 	{
-		std::vector<std::thread> th;
 		auto copy = [&](size_t k) { EMA_CPU(EMA_CPU_FORMAT); memcpy(buf + at[k], parts[k].buf.data(), parts[k].n); };
-		for (size_t k = 1; k < t; ++k) th.emplace_back(copy, k);
-		copy(0);
-		for (auto &x : th) x.join();
+		EmaPool::get().run(t, copy);
 	}
 	*text = buf; *n_bytes = total;
 	return 0;

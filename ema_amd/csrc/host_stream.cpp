@@ -20,6 +20,7 @@
 #include <vector>
 #include "ema_stream.h"
 #include "host_cpuacct.h"
+#include "host_pool.h"
 
 namespace {
 
@@ -352,10 +353,7 @@ void async_engine_thread(Stream &S, AsyncState &A)
 		if (fetched && b && ps.len == 1) { S.items[ps.first].b = b; b = nullptr; }
 
 		if (shared_pass) {
-			std::vector<std::thread> cutters;
-			for (size_t j = 1; j < ps.len; ++j) cutters.emplace_back(one, j);
-			one(0);
-			for (auto &t : cutters) t.join();
+			EmaPool::get().run(ps.len, one);
 		} else for (size_t j = 0; j < ps.len; ++j) one(j);
 		if (share) ema_batch_share_release(share);
 		if (b) ema_batch_free(b);

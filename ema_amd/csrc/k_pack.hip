@@ -95,3 +95,36 @@ extern "C" void ema_launch_scan(int n_reads, const int *n_pairs_dev, const int *
 	hipLaunchKernelGGL(ema_k_scan_tops, dim3(1), dim3(256), 0, stream, nb, block_tot, tot);
 	hipLaunchKernelGGL(ema_k_scan_write, dim3(nb), dim3(256), 0, stream, n_reads, n_pairs_dev, status, n_regs, cig_n, block_tot, cand_off, cig_off);
 }
+
+// Input staging on the device.  A batch arrives as the caller's ASCII bases; one thread per 32 bases of a read turns them into nt4
+// codes in place (seq_convert, reference src/bwabridge.c:151-157 with bwa's nst_nt4_table: ACGT / acgt -> 0..3, any other
+// byte 4) and writes its share of the read's packed form (24 words per read: 16 of 2-bit codes, first base lowest, and 8 of
+// "ambiguous base" flags) -- byte work that took 0.46 CPU-seconds per million pairs on the host (r03) and is nothing here.
+__global__ void __launch_bounds__(256)
+ema_k_stage_reads(const uint32_t *__restrict__ off, int n_reads, uint8_t *__restrict__ bases, uint32_t *__restrict__ qpack)
+{
+	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t r = t >> 3;
+	const int c = (int)(t & 7);
+	if (r >= (size_t)n_reads) return;
+	const uint32_t b0 = off[r], len = off[r + 1] - b0;
+	uint32_t w[2] = {0, 0}, amb = 0;
+#pragma unroll
+	for (int i = 0; i < 32; ++i) {
+		const uint32_t pos = (uint32_t)c * 32 + (uint32_t)i;
+		if (pos < len) {
+			const uint32_t x = bases[b0 + pos] | 0x20u;
+			const uint32_t code = x == 'a' ? 0u : x == 'c' ? 1u : x == 'g' ? 2u : x == 't' ? 3u : 4u;
+			bases[b0 + pos] = (uint8_t)code;
+			w[i >> 4] |= (code & 3u) << ((i & 15) << 1);
+			if (code > 3u) amb |= 1u << i;
+		}
+	}
+	uint32_t *q = qpack + r * 24;
+	q[2 * c] = w[0]; q[2 * c + 1] = w[1]; q[16 + c] = amb;
+}
+extern "C" void ema_launch_stage_reads(const uint32_t *off, int n_reads, uint8_t *bases, uint32_t *qpack, hipStream_t stream)
+{
+	if (n_reads <= 0) return;
+	hipLaunchKernelGGL(ema_k_stage_reads, dim3((unsigned)(((size_t)n_reads * 8 + 255) / 256)), dim3(256), 0, stream, off, n_reads, bases, qpack);
+}

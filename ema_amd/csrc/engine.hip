@@ -51,6 +51,7 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
                                  DevReg *regs, int *n_regs, int *status, const int *todo, const int *n_todo, const uint8_t *hand, uint8_t *slabs,
                                  int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof,
                                  const HeavyCtl *heavy, int mode);
+extern "C" void ema_align_set_light_profile(unsigned long long *buf);
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
@@ -273,6 +274,7 @@ struct ema_engine {
 	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
+	DevBuf<unsigned long long> d_lprof;  // EMA_PHASE_PROFILE=3: the product builds' few clocks (k_align.hip, PROF 2)
 	DevBuf<int> d_rlog;                  // EMA_PHASE_PROFILE=2: per-read records of K2b
 	int dbg_slots = 0;
 	double watchdog_s = 0;               // EMA_WATCHDOG_S=<seconds>: poll after every launch, report stuck waves
@@ -494,7 +496,10 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	}
 	}
 
-	if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
+	if (getenv("EMA_PHASE_PROFILE") && atoi(getenv("EMA_PHASE_PROFILE")) == 3) {
+		HIPCHK(e, e->d_lprof.alloc(32)); HIPCHK(e, hipMemset(e->d_lprof.p, 0, 256));
+		ema_align_set_light_profile(e->d_lprof.p);
+	} else if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
 		HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256));
 		{ const unsigned long long ones[2] = {~0ULL, ~0ULL}; HIPCHK(e, hipMemcpy(e->d_prof.p + 26, ones, 16, hipMemcpyHostToDevice)); }
 		if (atoi(pp) >= 2) {      // per-read log of K2b (k_align.hip): [0] entries, [1] capacity, records from word 16
@@ -583,7 +588,7 @@ void ema_engine_close(ema_engine_t *e)
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release();
 	for (auto &fp : e->fetch_pin) { fp.c_off.release(); fp.g_off.release(); fp.status.release(); fp.cand.release(); fp.cig.release(); }
-	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_ctg_tab.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release();
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_ctg_tab.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release(); if (e->d_lprof.p) { ema_align_set_light_profile(nullptr); e->d_lprof.release(); }
 	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
 	e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();
@@ -1155,6 +1160,20 @@ int ema_engine_seed_launches(const ema_engine_t *e) { return e ? e->seed_rounds 
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 {
 	if (!e || !t) return EMA_EARG;
+	if (e->d_lprof.p) {
+		unsigned long long h[32];
+		if (hipMemcpy(h, e->d_lprof.p, 256, hipMemcpyDeviceToHost) == hipSuccess) {
+			static const char *const name[4] = {"K2b (mode 0)", "K2c", "K2d", "hand-overs (mode 3)"};
+			for (int m = 0; m < 4; ++m) {
+				const unsigned long long *o = h + 8 * m;
+				if (!o[0]) continue;
+				fprintf(stderr, "%-20s wavefront lifetimes %.3f Gclk over %llu wavefronts: extension DPs %.3f (%llu calls), read / record / chaining %.3f, "
+				        "per-chain window set-up %.3f, dedup + output %.3f; %llu work items\n", name[m], (double)o[0] * 1e-9, o[7], (double)o[1] * 1e-9, o[5],
+				        (double)o[2] * 1e-9, (double)o[3] * 1e-9, (double)o[4] * 1e-9, o[6]);
+			}
+			(void)hipMemset(e->d_lprof.p, 0, 256);
+		}
+	}
 	if (e->d_prof.p) {
 		unsigned long long h[32];
 		if (hipMemcpy(h, e->d_prof.p, 256, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -339,8 +339,11 @@ __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first, int
 // here while K1 of another slice keeps the memory system saturated (a round trip then takes several microseconds): records are
 // claimed four at a time with their headers, a record's tables and the read's bases arrive together, the windows of all its
 // chains are planned at once (lane per chain) and fetched up to four at a time.
-// PROF: the diagnostic build (phase clocks, per-read log); the product build carries none of its registers
-template <int SMALL, int AVL, int WPS, int MODE, bool PROF>
+// PROF 1: the diagnostic build (phase clocks, per-read log); the product build (0) carries none of its registers.  PROF 2: the
+// product build with a handful of clocks kept in scalar registers (EMA_PHASE_PROFILE=3) -- per mode: the wavefronts' lifetimes
+// (= the slot-time the launch costs the chip), the clocks inside the extension DPs, record + window set-up, dedup + output --
+// because the diagnostic build spills eight times as much as the product and its split says little about the product's.
+template <int SMALL, int AVL, int WPS, int MODE, int PROF>
 __global__ void __launch_bounds__(256, WPS)
 ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
@@ -352,7 +355,12 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	// The phase clocks and the per-read log exist in the diagnostic build only.  (The watchdog's progress words stay a run-time
 	// pointer: with both folded away this kernel faulted on the device -- r02: every other combination passes the suite, the
 	// interpreter and AddressSanitizer find nothing -- and until that is understood the build that is tested is the one shipped.)
-	unsigned long long *const prof = PROF ? prof_arg : nullptr;
+	unsigned long long *const prof = PROF == 1 ? prof_arg : nullptr;
+	unsigned long long lp_dp = 0, lp_pro = 0, lp_win = 0, lp_out = 0, lp_mark = 0;      // PROF 2
+	int lp_n_dp = 0, lp_reads = 0;
+	const unsigned long long lp_t0 = PROF == 2 ? __builtin_amdgcn_s_memtime() : 0;
+#define EMA_LP_START() do { if (PROF == 2) lp_mark = __builtin_amdgcn_s_memtime(); } while (0)
+#define EMA_LP_STOP(acc) do { if (PROF == 2) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (acc) += t_ - lp_mark; lp_mark = t_; } } while (0)
 	int *const dbg = dbg_arg;
 	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
 	unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -420,6 +428,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				break;
 			}
 		}
+		EMA_LP_START();
+		if (PROF == 2) ++lp_reads;
 		const uint8_t *rec = nullptr;      // MODE 1, 2: the record of the read set aside
 		int task_chain = -1;               // MODE 1: the chain of this task (index in filtered order)
 		if (MODE == 1) {
@@ -877,6 +887,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			cb.sl.av = (DevReg *)b; cb.sl.av_tmp = (DevReg *)b + AVL; cb.sl.rkeys = (uint64_t *)((DevReg *)b + 2 * AVL);
 		}
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
+		EMA_LP_STOP(lp_pro);      // the read, its record or its chaining and filter
 		int n_av = 0;
 		EMA_DBG(5, n_keep);
 		EMA_PHASE(3);
@@ -903,6 +914,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				for (int t = 0; t < cn; ++t) { const SeedRec s = ema_uni(sl.seeds[k]); if (lane == 0) sl.cs[t] = s; k = s.next; }
 				ema_wave_sync();
 			}
+			EMA_LP_START();
 			int64_t rmax0 = l_pac << 1, rmax1 = 0;
 			uint8_t *rs = rseq;      // where this chain's window sits
 			if (MODE == 3) {         // planned with the record (above)
@@ -986,6 +998,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				ema_wave_sync();
 			}
 
+			EMA_LP_STOP(lp_win);      // bounds, window, seed order
 			EMA_PHASE(3);
 			for (int k = cn - 1; k >= 0; --k) {
 				EMA_DBG(7, k);
@@ -1056,8 +1069,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						const int prev = a.score;
 						aw0 = opt.w << i;
 						++n_dp;
+						EMA_LP_START(); if (PROF == 2) ++lp_n_dp;
 						r = ema_wave_extend(opt, s.qbeg, EmaSeq{query + s.qbeg - 1, -1}, tlen, EmaSeq{rs + tlen - 1, -1}, aw0,
 						                    opt.pen_clip5, opt.zdrop, s.len * opt.a);
+						EMA_LP_STOP(lp_dp);
 						a.score = r.score;
 						if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 					}
@@ -1074,8 +1089,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						const int prev = a.score;
 						aw1 = opt.w << i;
 						++n_dp;
+						EMA_LP_START(); if (PROF == 2) ++lp_n_dp;
 						r = ema_wave_extend(opt, l_query - qe, EmaSeq{query + qe, 1}, (int)(rmax1 - rmax0 - re), EmaSeq{rs + re, 1},
 						                    aw1, opt.pen_clip3, opt.zdrop, sc0);
+						EMA_LP_STOP(lp_dp);
 						a.score = r.score;
 						if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 					}
@@ -1109,6 +1126,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		if (MODE == 1) { EMA_PHASE(0); continue; }      // K2c: this chain's results are in the record
 		// ---------------- mem_sort_dedup_patch ----------------
 		EMA_DBG(8, n_av);
+		EMA_LP_START();
 		EMA_PHASE(5);
 		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq; wk.mark = dbg ? dbg + slot * 4 : nullptr;
 		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
@@ -1119,6 +1137,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		for (int i = lane; i < n_out; i += EMA_WAVE) { DevReg r = sl.av[i]; r.is_alt = ema_ctg_alt(ix, r.rid); dst[i] = r; }      // mem_align1_core's last loop
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
 		EMA_DBG(9, n_out);
+		EMA_LP_STOP(lp_out);      // dedup / patch, results out
 		EMA_PHASE(0);
 		if (rlog && lane == 0) {
 			const int at = atomicAdd(rlog, 1);
@@ -1133,11 +1152,23 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		atomicMin(prof + 26, t_launch); atomicMax(prof + 28, (unsigned long long)__builtin_amdgcn_s_memtime());
 	}
 	if (prof && lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(prof + (i < 8 ? i : i + 4), acc[i]);      // 8.. -> slots 12.. (8..11 are K1's)
+	if (PROF == 2 && lane == 0 && prof_arg) {      // eight slots per mode
+		unsigned long long *o = prof_arg + 8 * MODE;
+		atomicAdd(o + 0, __builtin_amdgcn_s_memtime() - lp_t0); atomicAdd(o + 1, lp_dp); atomicAdd(o + 2, lp_pro); atomicAdd(o + 3, lp_win);
+		atomicAdd(o + 4, lp_out); atomicAdd(o + 5, (unsigned long long)lp_n_dp); atomicAdd(o + 6, (unsigned long long)lp_reads); atomicAdd(o + 7, 1ULL);
+	}
+#undef EMA_LP_START
+#undef EMA_LP_STOP
 #undef EMA_DBG
 #undef EMA_PHASE
 }
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
+
+// EMA_PHASE_PROFILE=3 (engine.hip): 32 device words, eight per mode -- wavefront lifetimes, clocks in the extension DPs, in the
+// read / record / chaining set-up, in the per-chain window set-up, in dedup + output; DP calls, work items, wavefronts
+static unsigned long long *ema_align_light_prof = nullptr;
+extern "C" void ema_align_set_light_profile(unsigned long long *buf) { ema_align_light_prof = buf; }
 
 // mode 0: K2b (reads K2a could not finish and has no chains for: chaining, filter, extension or setting aside); 1: K2c; 2: K2d;
 // 3: the reads K2a handed over with their chains ready.  (Round 2's measurement builds -- everything in LDS at one or two blocks per
@@ -1153,12 +1184,14 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
 #define EMA_ALIGN_LAUNCH(...) hipLaunchKernelGGL((ema_k_align_t<__VA_ARGS__>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs, \
 	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof, hv)
-	const bool diag = prof != nullptr;
-	if (mode == 1) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 1, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 1, false); }      // K2c: one chain of a read set aside per wavefront
-	else if (mode == 2) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 2, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 2, false); } // K2d: the replay of a read set aside
-	else if (mode == 3) { if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 3, true); else EMA_ALIGN_LAUNCH(32, 8, 4, 3, false); } // the reads handed over by K2a
-	else if (diag) EMA_ALIGN_LAUNCH(32, 8, 4, 0, true);
-	else EMA_ALIGN_LAUNCH(32, 8, 4, 0, false);
+	const int level = ema_align_light_prof ? 2 : prof != nullptr ? 1 : 0;
+	if (level == 2) prof = ema_align_light_prof;
+#define EMA_ALIGN_MODE(M) do { if (level == 2) EMA_ALIGN_LAUNCH(32, 8, 4, M, 2); else if (level == 1) EMA_ALIGN_LAUNCH(32, 8, 4, M, 1); else EMA_ALIGN_LAUNCH(32, 8, 4, M, 0); } while (0)
+	if (mode == 1) EMA_ALIGN_MODE(1);            // K2c: one chain of a read set aside per wavefront
+	else if (mode == 2) EMA_ALIGN_MODE(2);       // K2d: the replay of a read set aside
+	else if (mode == 3) EMA_ALIGN_MODE(3);       // the reads handed over by K2a
+	else EMA_ALIGN_MODE(0);
+#undef EMA_ALIGN_MODE
 #undef EMA_ALIGN_LAUNCH
 }
 
@@ -1166,6 +1199,6 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 extern "C" int ema_align_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4, 0, false>, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_align_t<32, 8, 4, 0, 0>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

@@ -46,6 +46,15 @@ __device__ __forceinline__ int64_t ema_uni(int64_t v)
 	return (int64_t)((uint64_t)hi << 32 | lo);
 }
 __device__ __forceinline__ uint64_t ema_uni(uint64_t v) { return (uint64_t)ema_uni((int64_t)v); }
+// lane `l`'s value (l wave-uniform) as a scalar
+__device__ __forceinline__ int ema_lane_val(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int64_t ema_lane_val(int64_t v, int l)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, l);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+	return (int64_t)((uint64_t)hi << 32 | lo);
+}
+__device__ __forceinline__ uint64_t ema_lane_val(uint64_t v, int l) { return (uint64_t)ema_lane_val((int64_t)v, l); }
 __device__ __forceinline__ float ema_uni(float v) { return __int_as_float(ema_uni(__float_as_int(v))); }
 __device__ __forceinline__ Intv ema_uni(const Intv &v)
 {

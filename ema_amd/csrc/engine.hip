@@ -497,7 +497,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	}
 
 	if (getenv("EMA_PHASE_PROFILE") && atoi(getenv("EMA_PHASE_PROFILE")) == 3) {
-		HIPCHK(e, e->d_lprof.alloc(32)); HIPCHK(e, hipMemset(e->d_lprof.p, 0, 256));
+		HIPCHK(e, e->d_lprof.alloc(48)); HIPCHK(e, hipMemset(e->d_lprof.p, 0, 48 * 8));
 		ema_align_set_light_profile(e->d_lprof.p);
 	} else if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
 		HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256));
@@ -525,6 +525,12 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
 	e->lane_blocks = e->n_cu * ema_align_simple_blocks_per_cu();
+	{   // EMA_GRID="k2a,k2b,k3,k4": resident blocks per CU of those kernels, at most what the occupancy calculation allows (0 = leave)
+		int v[4] = {0, 0, 0, 0};
+		if (const char *g = getenv("EMA_GRID")) sscanf(g, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+		int *blk[4] = {&e->lane_blocks, &e->align_blocks, &e->pair_blocks, &e->final_blocks};
+		for (int k = 0; k < 4; ++k) if (v[k] > 0 && v[k] * e->n_cu < *blk[k]) *blk[k] = v[k] * e->n_cu;
+	}
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
@@ -1161,17 +1167,17 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 {
 	if (!e || !t) return EMA_EARG;
 	if (e->d_lprof.p) {
-		unsigned long long h[32];
-		if (hipMemcpy(h, e->d_lprof.p, 256, hipMemcpyDeviceToHost) == hipSuccess) {
+		unsigned long long h[48];
+		if (hipMemcpy(h, e->d_lprof.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
 			static const char *const name[4] = {"K2b (mode 0)", "K2c", "K2d", "hand-overs (mode 3)"};
 			for (int m = 0; m < 4; ++m) {
-				const unsigned long long *o = h + 8 * m;
-				if (!o[0]) continue;
-				fprintf(stderr, "%-20s wavefront lifetimes %.3f Gclk over %llu wavefronts: extension DPs %.3f (%llu calls), read / record / chaining %.3f, "
-				        "per-chain window set-up %.3f, dedup + output %.3f; %llu work items\n", name[m], (double)o[0] * 1e-9, o[7], (double)o[1] * 1e-9, o[5],
-				        (double)o[2] * 1e-9, (double)o[3] * 1e-9, (double)o[4] * 1e-9, o[6]);
+				const unsigned long long *o = h + 12 * m;
+				if (!o[7]) continue;
+				fprintf(stderr, "%-20s lifetimes %.2f Gclk, %llu wavefronts, %llu work items: claim %.2f, read / record / chaining %.2f, chain head + seeds %.2f, "
+				        "window %.2f, per-seed control %.2f, extension DPs %.2f (%llu calls), dedup + output %.2f\n", name[m], (double)o[7] * 1e-9, o[10], o[9],
+				        (double)o[0] * 1e-9, (double)o[1] * 1e-9, (double)o[2] * 1e-9, (double)o[3] * 1e-9, (double)o[4] * 1e-9, (double)o[5] * 1e-9, o[8], (double)o[6] * 1e-9);
 			}
-			(void)hipMemset(e->d_lprof.p, 0, 256);
+			(void)hipMemset(e->d_lprof.p, 0, sizeof h);
 		}
 	}
 	if (e->d_prof.p) {

@@ -356,11 +356,14 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	// pointer: with both folded away this kernel faulted on the device -- r02: every other combination passes the suite, the
 	// interpreter and AddressSanitizer find nothing -- and until that is understood the build that is tested is the one shipped.)
 	unsigned long long *const prof = PROF == 1 ? prof_arg : nullptr;
-	unsigned long long lp_dp = 0, lp_pro = 0, lp_win = 0, lp_out = 0, lp_mark = 0;      // PROF 2
+	// PROF 2: the clocks since the previous mark go to phase k -- 0 claiming a work item, 1 the read and its record (mode 0: the
+	// intervals, suffix-array rows, chaining, filter, setting aside), 2 a chain's head and seeds, 3 its window (bounds, fetch, seed
+	// order), 4 the per-seed control (cover tests, region records), 5 the extension DPs, 6 dedup / patch and output
+	unsigned long long lp[7] = {0, 0, 0, 0, 0, 0, 0};
 	int lp_n_dp = 0, lp_reads = 0;
 	const unsigned long long lp_t0 = PROF == 2 ? __builtin_amdgcn_s_memtime() : 0;
-#define EMA_LP_START() do { if (PROF == 2) lp_mark = __builtin_amdgcn_s_memtime(); } while (0)
-#define EMA_LP_STOP(acc) do { if (PROF == 2) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (acc) += t_ - lp_mark; lp_mark = t_; } } while (0)
+	unsigned long long lp_mark = lp_t0;
+#define EMA_LP(k) do { if (PROF == 2) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); lp[k] += t_ - lp_mark; lp_mark = t_; } } while (0)
 	int *const dbg = dbg_arg;
 	// diagnostic phase timing (prof != null): shader-clock ticks per phase, summed over all waves
 	unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -428,7 +431,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				break;
 			}
 		}
-		EMA_LP_START();
+		EMA_LP(0);
 		if (PROF == 2) ++lp_reads;
 		const uint8_t *rec = nullptr;      // MODE 1, 2: the record of the read set aside
 		int task_chain = -1;               // MODE 1: the chain of this task (index in filtered order)
@@ -591,27 +594,50 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			log_iv = n_iv; log_occ = (int)(tot_occ < (1 << 30) ? tot_occ : (1 << 30));
 		}
 		frac_rep = (float)l_rep / (float)l_query;
-		for (int i = 0; i < n_iv; ++i) {
-			EMA_DBG(2, i);
-			const Intv p = iv[i];
-			const int qbeg = (int)(p.info >> 32), slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
-			const int64_t step = p.x2 > (uint64_t)opt.max_occ ? (int64_t)(p.x2 / (uint64_t)opt.max_occ) : 1;
-			int64_t n_occ = ((int64_t)p.x2 + step - 1) / step;        // k = 0, step, ... < size
-			if (n_occ > opt.max_occ) n_occ = opt.max_occ;
-			for (int64_t base = 0; base < n_occ; base += EMA_WAVE) {
+		// The seed occurrences in mem_chain's order -- interval by interval, k = 0, step, ... within one -- taken SIXTY-FOUR AT A TIME
+		// ACROSS intervals: one round trip for the suffix-array rows of a whole batch and one for their contigs, where a read from a
+		// repeat family (dozens of intervals with a handful of occurrences each) paid those round trips per interval.  Lane L keeps
+		// interval L of the current chunk of 64 intervals in registers; a batch is assembled from them with scalar reads.
+		for (int iv_base = 0; iv_base < n_iv; iv_base += EMA_WAVE) {
+			const int chunk_n = n_iv - iv_base < EMA_WAVE ? n_iv - iv_base : EMA_WAVE;
+			uint64_t my_x0 = 0;
+			int64_t my_step = 1;
+			int my_nocc = 0, my_qbeg = 0, my_slen = 0;
+			if (lane < chunk_n) {
+				const Intv p = iv[iv_base + lane];
+				my_qbeg = (int)(p.info >> 32); my_slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
+				my_step = p.x2 > (uint64_t)opt.max_occ ? (int64_t)(p.x2 / (uint64_t)opt.max_occ) : 1;
+				int64_t n_occ = ((int64_t)p.x2 + my_step - 1) / my_step;        // k = 0, step, ... < size
+				if (n_occ > opt.max_occ) n_occ = opt.max_occ;
+				my_nocc = (int)n_occ; my_x0 = p.x0;
+			}
+			int ci = 0, ck = 0;      // next occurrence: number ck of interval ci of the chunk
+			while (ci < chunk_n) {
+				EMA_DBG(2, iv_base + ci);
 				EMA_PHASE(11);      // 11: suffix-array rows and contig ids of up to 64 occurrences
-				const int64_t idx = base + lane;
-				int64_t rbeg = 0; int rid = -1;
-				if (idx < n_occ) {      // consecutive suffix-array rows (step 1) -> coalesced loads
-					rbeg = (int64_t)ema_sa(ix, p.x0 + (uint64_t)(idx * step));
-					rid = ema_intv2rid(ix, rbeg, rbeg + slen);
+				int filled = 0, a_q = 0, a_l = 0;
+				uint64_t a_row = 0;
+				while (filled < EMA_WAVE && ci < chunk_n) {
+					const int n = ema_lane_val(my_nocc, ci);
+					const int take = n - ck < EMA_WAVE - filled ? n - ck : EMA_WAVE - filled;
+					const uint64_t x0 = ema_lane_val(my_x0, ci);
+					const int64_t step = ema_lane_val(my_step, ci);
+					const int q = ema_lane_val(my_qbeg, ci), l = ema_lane_val(my_slen, ci);
+					if (lane >= filled && lane < filled + take) { a_row = x0 + (uint64_t)((int64_t)(ck + lane - filled) * step); a_q = q; a_l = l; }
+					filled += take; ck += take;
+					if (ck >= n) { ++ci; ck = 0; }
 				}
-				const int cnt = (int)(n_occ - base < EMA_WAVE ? n_occ - base : EMA_WAVE);
+				int64_t rbeg = 0; int rid = -1;
+				if (lane < filled) {      // consecutive suffix-array rows within an interval (step 1) -> coalesced loads
+					rbeg = (int64_t)ema_sa(ix, a_row);
+					rid = ema_intv2rid(ix, rbeg, rbeg + a_l);
+				}
 				EMA_PHASE(1);      // 1: the insertions
-				for (int t = 0; t < cnt; ++t) {
-					const int64_t rb = ema_uni(__shfl(rbeg, t));
-					const int rd = ema_uni(__shfl(rid, t));
+				for (int t = 0; t < filled; ++t) {
+					const int64_t rb = ema_lane_val(rbeg, t);
+					const int rd = ema_lane_val(rid, t);
 					if (rd < 0) continue;
+					const int qbeg = ema_lane_val(a_q, t), slen = ema_lane_val(a_l, t);
 					if (MED && med) {
 						if (chain_insert_med(opt, l_pac, cb, mt, rb, qbeg, slen, rd)) continue;
 						// EMA_MED_CHAINS chains and one more to open: the chain records are brought up to date, the position table moves to
@@ -887,7 +913,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			cb.sl.av = (DevReg *)b; cb.sl.av_tmp = (DevReg *)b + AVL; cb.sl.rkeys = (uint64_t *)((DevReg *)b + 2 * AVL);
 		}
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
-		EMA_LP_STOP(lp_pro);      // the read, its record or its chaining and filter
+		EMA_LP(1);
 		int n_av = 0;
 		EMA_DBG(5, n_keep);
 		EMA_PHASE(3);
@@ -914,7 +940,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				for (int t = 0; t < cn; ++t) { const SeedRec s = ema_uni(sl.seeds[k]); if (lane == 0) sl.cs[t] = s; k = s.next; }
 				ema_wave_sync();
 			}
-			EMA_LP_START();
+			EMA_LP(2);
 			int64_t rmax0 = l_pac << 1, rmax1 = 0;
 			uint8_t *rs = rseq;      // where this chain's window sits
 			if (MODE == 3) {         // planned with the record (above)
@@ -975,10 +1001,9 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						int at[4] = {0, 0, 0, 0};
 #pragma unroll
 						for (int t = 0; t < 4; ++t) if (ct[t] >= 0) {
-							const int64_t r0 = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)my_r0, ct[t]) |
-							                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_r0 >> 32), ct[t]) << 32);
-							wn[t] = ema_win(ix, r0, r0 + __builtin_amdgcn_readlane(wl, ct[t]));
-							at[t] = __builtin_amdgcn_readlane(incl - wl, ct[t]);
+							const int64_t r0 = ema_lane_val(my_r0, ct[t]);
+							wn[t] = ema_win(ix, r0, r0 + ema_lane_val(wl, ct[t]));
+							at[t] = ema_lane_val(incl - wl, ct[t]);
 							if (lane < wn[t].n_dw) word[t] = ema_win_load(ix, wn[t], lane);
 						}
 #pragma unroll
@@ -998,7 +1023,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				ema_wave_sync();
 			}
 
-			EMA_LP_STOP(lp_win);      // bounds, window, seed order
+			EMA_LP(3);
 			EMA_PHASE(3);
 			for (int k = cn - 1; k >= 0; --k) {
 				EMA_DBG(7, k);
@@ -1069,10 +1094,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						const int prev = a.score;
 						aw0 = opt.w << i;
 						++n_dp;
-						EMA_LP_START(); if (PROF == 2) ++lp_n_dp;
+						EMA_LP(4); if (PROF == 2) ++lp_n_dp;
 						r = ema_wave_extend(opt, s.qbeg, EmaSeq{query + s.qbeg - 1, -1}, tlen, EmaSeq{rs + tlen - 1, -1}, aw0,
 						                    opt.pen_clip5, opt.zdrop, s.len * opt.a);
-						EMA_LP_STOP(lp_dp);
+						EMA_LP(5);
 						a.score = r.score;
 						if (a.score == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 					}
@@ -1089,10 +1114,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 						const int prev = a.score;
 						aw1 = opt.w << i;
 						++n_dp;
-						EMA_LP_START(); if (PROF == 2) ++lp_n_dp;
+						EMA_LP(4); if (PROF == 2) ++lp_n_dp;
 						r = ema_wave_extend(opt, l_query - qe, EmaSeq{query + qe, 1}, (int)(rmax1 - rmax0 - re), EmaSeq{rs + re, 1},
 						                    aw1, opt.pen_clip3, opt.zdrop, sc0);
-						EMA_LP_STOP(lp_dp);
+						EMA_LP(5);
 						a.score = r.score;
 						if (a.score == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 					}
@@ -1123,10 +1148,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			}
 		}
 
-		if (MODE == 1) { EMA_PHASE(0); continue; }      // K2c: this chain's results are in the record
+		if (MODE == 1) { EMA_PHASE(0); EMA_LP(4); continue; }      // K2c: this chain's results are in the record
 		// ---------------- mem_sort_dedup_patch ----------------
 		EMA_DBG(8, n_av);
-		EMA_LP_START();
+		EMA_LP(4);
 		EMA_PHASE(5);
 		EmaRegWork wk; wk.a = sl.av; wk.tmp = sl.av_tmp; wk.keys = sl.rkeys; wk.stack = lds_stack[wib]; wk.rseq = rseq; wk.mark = dbg ? dbg + slot * 4 : nullptr;
 		int n_out = ema_sort_dedup_patch(ix, opt, query, n_av, wk, cb.status);
@@ -1137,7 +1162,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		for (int i = lane; i < n_out; i += EMA_WAVE) { DevReg r = sl.av[i]; r.is_alt = ema_ctg_alt(ix, r.rid); dst[i] = r; }      // mem_align1_core's last loop
 		if (lane == 0) { n_regs[read] = n_out; if (cb.status) atomicOr(status + read, cb.status); }
 		EMA_DBG(9, n_out);
-		EMA_LP_STOP(lp_out);      // dedup / patch, results out
+		EMA_LP(6);
 		EMA_PHASE(0);
 		if (rlog && lane == 0) {
 			const int at = atomicAdd(rlog, 1);
@@ -1152,21 +1177,21 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		atomicMin(prof + 26, t_launch); atomicMax(prof + 28, (unsigned long long)__builtin_amdgcn_s_memtime());
 	}
 	if (prof && lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(prof + (i < 8 ? i : i + 4), acc[i]);      // 8.. -> slots 12.. (8..11 are K1's)
-	if (PROF == 2 && lane == 0 && prof_arg) {      // eight slots per mode
-		unsigned long long *o = prof_arg + 8 * MODE;
-		atomicAdd(o + 0, __builtin_amdgcn_s_memtime() - lp_t0); atomicAdd(o + 1, lp_dp); atomicAdd(o + 2, lp_pro); atomicAdd(o + 3, lp_win);
-		atomicAdd(o + 4, lp_out); atomicAdd(o + 5, (unsigned long long)lp_n_dp); atomicAdd(o + 6, (unsigned long long)lp_reads); atomicAdd(o + 7, 1ULL);
+	if (PROF == 2 && lane == 0 && prof_arg) {      // twelve slots per mode: the seven phases, lifetimes, DP calls, work items, wavefronts
+		unsigned long long *o = prof_arg + 12 * MODE;
+		for (int k = 0; k < 7; ++k) atomicAdd(o + k, lp[k]);
+		atomicAdd(o + 7, __builtin_amdgcn_s_memtime() - lp_t0); atomicAdd(o + 8, (unsigned long long)lp_n_dp); atomicAdd(o + 9, (unsigned long long)lp_reads);
+		atomicAdd(o + 10, 1ULL);
 	}
-#undef EMA_LP_START
-#undef EMA_LP_STOP
+#undef EMA_LP
 #undef EMA_DBG
 #undef EMA_PHASE
 }
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
-// EMA_PHASE_PROFILE=3 (engine.hip): 32 device words, eight per mode -- wavefront lifetimes, clocks in the extension DPs, in the
-// read / record / chaining set-up, in the per-chain window set-up, in dedup + output; DP calls, work items, wavefronts
+// EMA_PHASE_PROFILE=3 (engine.hip): 48 device words, twelve per mode -- the clocks of seven phases (see the kernel), wavefront
+// lifetimes, DP calls, work items, wavefronts
 static unsigned long long *ema_align_light_prof = nullptr;
 extern "C" void ema_align_set_light_profile(unsigned long long *buf) { ema_align_light_prof = buf; }
 

@@ -86,6 +86,32 @@ __device__ __forceinline__ DevReg ema_uni(const DevReg &g)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Work items of a launch, taken from its shared counter EMA_CLAIM at a time.  One atomic per item -- every wavefront of the chip
+// on one address, a dependent look-up of the item's list entry behind it -- cost the wave-per-read kernels 30-50 K clocks per
+// item (r03, product-build profile of K2b: the L2 serialises the updates of one address); a claim of four, with the four list
+// entries fetched together by four lanes, costs 2 K.
+#define EMA_CLAIM 4
+struct EmaClaim { int base = 0, n = 0, i = 0; unsigned long long mine = 0; };
+// The next item's index, or -1 when none is left.  total: items in all (final before the launch).  list (may be null): one entry
+// per item; `entry` receives this item's.
+template <typename T>
+__device__ __forceinline__ int ema_claim_next(EmaClaim &c, int *counter, int total, const T *list, T &entry)
+{
+	const int lane = (int)ema_lane();
+	if (c.i == c.n) {
+		int b = 0;
+		if (lane == 0) b = atomicAdd(counter, EMA_CLAIM);
+		b = __builtin_amdgcn_readlane(b, 0);
+		if (b >= total) return -1;
+		c.base = b; c.n = total - b < EMA_CLAIM ? total - b : EMA_CLAIM; c.i = 0;
+		if (list && lane < c.n) c.mine = (unsigned long long)list[b + lane];
+	}
+	const int k = c.i++;
+	if (list) entry = (T)ema_lane_val((uint64_t)c.mine, k);
+	return c.base + k;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wave-wide scans and reductions on DPP (data-parallel primitives: operands are read from a neighbouring lane by
 // the VALU itself -- a few cycles -- instead of going through the LDS crossbar like ds_bpermute/__shfl, which
 // costs >100 cycles per dependent step and dominated the row-parallel DPs).  gfx950 keeps the GFX9 controls

@@ -399,6 +399,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 	// MODE 3: records claimed four at a time; lane k < 4 keeps record k's header until its turn
 	int cl_base = 0, cl_n = 0, cl_i = 0, win_end = 0;
+	EmaClaim claim;                        // the other modes
+	unsigned long long list_entry = 0;     // this item's entry of the launch's list (todo / tasks / reads)
 	HandHdr pf;
 	pf.read = pf.n_chn = pf.n_seed = pf.l_query = 0; pf.base_off = 0;
 	for (;;) {
@@ -423,10 +425,15 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			hrec = hand + (size_t)(cl_base + cl_i) * EMA_HAND_BYTES;
 			++cl_i;
 			read = hd.read;
-		} else {
-			if (lane == 0) read = atomicAdd(counter, 1);
-			read = __builtin_amdgcn_readlane(read, 0);
-			if (read >= (MODE == 1 ? *hv.n_tasks : MODE == 2 ? *hv.n_reads : todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2))) {
+		} else {      // (dev_common.hpp, EmaClaim: four items and their list entries at a time)
+			if (MODE == 1) { const int cap = hv.tasks_cap, n = *hv.n_tasks; read = ema_claim_next(claim, counter, n < cap ? n : cap, hv.tasks, list_entry); }
+			else if (MODE == 2) { const int cap = hv.reads_cap, n = *hv.n_reads; read = ema_claim_next(claim, counter, n < cap ? n : cap, hv.reads, list_entry); }
+			else {
+				int t = 0;
+				read = ema_claim_next(claim, counter, todo ? *n_todo : ema_work_count(n_reads, n_pairs_dev, 2), todo, t);
+				if (todo) list_entry = (unsigned long long)(unsigned)t;
+			}
+			if (read < 0) {
 				if (MODE == 0 && prof && lane == 0 && opt.reg_cap <= EMA_REG_LEAN) atomicMin(prof + 27, (unsigned long long)__builtin_amdgcn_s_memtime());      // the queue ran dry (lean tier)
 				break;
 			}
@@ -436,18 +443,16 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		const uint8_t *rec = nullptr;      // MODE 1, 2: the record of the read set aside
 		int task_chain = -1;               // MODE 1: the chain of this task (index in filtered order)
 		if (MODE == 1) {
-			if (read >= hv.tasks_cap) break;
-			const unsigned long long t = ema_uni((uint64_t)hv.tasks[read]);
+			const unsigned long long t = list_entry;
 			if (t == ~0ULL) continue;      // a claim K2b gave back
 			rec = hv.arena + (size_t)(t >> 32) * 64; task_chain = (int)(uint32_t)t;
 			read = ema_uni(reinterpret_cast<const HeavyHdr *>(rec)->read);
 		} else if (MODE == 2) {
-			if (read >= hv.reads_cap) break;
-			const unsigned long long t = ema_uni((uint64_t)hv.reads[read]);
+			const unsigned long long t = list_entry;
 			if (t == ~0ULL) continue;
 			rec = hv.arena + (size_t)t;
 			read = ema_uni(reinterpret_cast<const HeavyHdr *>(rec)->read);
-		} else if (MODE == 0 && todo) read = ema_uni(todo[read]);
+		} else if (MODE == 0 && todo) read = (int)(unsigned)list_entry;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		const unsigned long long t_read = rlog ? __builtin_amdgcn_s_memtime() : 0;
 		int log_iv = -1, log_occ = 0;

@@ -175,26 +175,25 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	const int64_t l_pac = ix.l_pac;
 	FinalRes *res = reinterpret_cast<FinalRes *>(fh.arena);
 
+	EmaClaim claim;      // work items four at a time, with their list entries (dev_common.hpp)
 	for (;;) {
 		int read = 0;
-		if (lane == 0) read = atomicAdd(counter, 1);
-		read = ema_uni(__shfl(read, 0));
+		unsigned long long list_entry = 0;
+		if (MODE == 1) { const int n = *fh.n_tasks; read = ema_claim_next(claim, counter, n < fh.tasks_cap ? n : fh.tasks_cap, fh.tasks, list_entry); }
+		else if (MODE == 2) { const int n = *fh.n_reads; read = ema_claim_next(claim, counter, n < fh.reads_cap ? n : fh.reads_cap, fh.reads, list_entry); }
+		else { int t = 0; read = ema_claim_next(claim, counter, *n_todo, todo, t); list_entry = (unsigned long long)(unsigned)t; }
+		if (read < 0) break;
 		int task = -1, task_k = 0, first_task = 0;
 		if (MODE == 1) {
-			if (read >= ema_uni(*fh.n_tasks) || read >= fh.tasks_cap) break;
 			task = read;
-			const unsigned long long t = ema_uni((uint64_t)fh.tasks[task]);
+			const unsigned long long t = list_entry;
 			if (t == ~0ULL) continue;      // a claim K4b gave back
 			read = (int)(t >> 32); task_k = (int)(uint32_t)t;
 		} else if (MODE == 2) {
-			if (read >= ema_uni(*fh.n_reads) || read >= fh.reads_cap) break;
-			const unsigned long long t = ema_uni((uint64_t)fh.reads[read]);
+			const unsigned long long t = list_entry;
 			if (t == ~0ULL) continue;
 			read = (int)(uint32_t)t; first_task = (int)(t >> 32);
-		} else {
-			if (read >= *n_todo) break;
-			read = ema_uni(todo[read]);
-		}
+		} else read = (int)(unsigned)list_entry;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		const int in_read = ema_uni(ema_in_read(map, read));

@@ -244,13 +244,20 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 	cx.pes_low = pes_low; cx.pes_high = pes_high;
 	if (max_rescue > EMA_PAIR_MAX_RESCUE) ph.arena = nullptr;      // (more attempts than a record has slots for: everything in place)
 
+	EmaClaim claim;      // work items four at a time, with their list entries (dev_common.hpp)
 	for (;;) {
 		int pair = 0;
-		if (lane == 0) pair = atomicAdd(counter, 1);
-		pair = ema_uni(__shfl(pair, 0));
+		unsigned long long list_entry = 0;
+		if (MODE == 1) { const int n = ph.n_tasks[dirn_arg]; pair = ema_claim_next(claim, counter, n < ph.tasks_cap ? n : ph.tasks_cap, ph.tasks + (size_t)dirn_arg * ph.tasks_cap, list_entry); }
+		else if (MODE == 2) { const int n = *ph.n_pairs; pair = ema_claim_next(claim, counter, n < ph.pairs_cap ? n : ph.pairs_cap, ph.pairs, list_entry); }
+		else {
+			int t = 0;
+			pair = ema_claim_next(claim, counter, todo ? *n_todo : ema_work_count(n_pairs, n_pairs_dev, 1), todo, t);
+			if (todo) list_entry = (unsigned long long)(unsigned)t;
+		}
+		if (pair < 0) break;
 		if (MODE == 1) {      // K3t: one attempt
-			if (pair >= ema_uni(ph.n_tasks[dirn_arg]) || pair >= ph.tasks_cap) break;
-			const unsigned long long t = ema_uni((uint64_t)ph.tasks[(size_t)dirn_arg * ph.tasks_cap + pair]);
+			const unsigned long long t = list_entry;
 			if (t == ~0ULL) continue;
 			uint8_t *rec = ph.arena + (size_t)(t >> 32) * 64;
 			const PairHdr *h = reinterpret_cast<const PairHdr *>(rec);
@@ -273,8 +280,7 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 			continue;
 		}
 		if (MODE == 2) {      // K3r: the attempts of direction dirn_arg replayed in order
-			if (pair >= ema_uni(*ph.n_pairs) || pair >= ph.pairs_cap) break;
-			const unsigned long long t = ema_uni((uint64_t)ph.pairs[pair]);
+			const unsigned long long t = list_entry;
 			if (t == ~0ULL) continue;
 			uint8_t *rec = ph.arena + t;
 			PairHdr *h = reinterpret_cast<PairHdr *>(rec);
@@ -367,8 +373,7 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 			ema_wave_sync();
 			continue;
 		}
-		if (pair >= (todo ? *n_todo : ema_work_count(n_pairs, n_pairs_dev, 1))) break;
-		if (todo) pair = ema_uni(todo[pair]);
+		if (todo) pair = (int)(unsigned)list_entry;
 		if (dbg && lane == 0) __hip_atomic_store(dbg + slot * 4, pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		EMA_DBG(1, 0);
 		if (ema_uni(status[2 * pair] | status[2 * pair + 1])) { EMA_DBG(9, 0); continue; }      // redone by the full-capacity tier

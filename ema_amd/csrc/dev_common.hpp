@@ -89,9 +89,16 @@ __device__ __forceinline__ DevReg ema_uni(const DevReg &g)
 // Work items of a launch, taken from its shared counter EMA_CLAIM at a time.  One atomic per item -- every wavefront of the chip
 // on one address, a dependent look-up of the item's list entry behind it -- cost the wave-per-read kernels 30-50 K clocks per
 // item (r03, product-build profile of K2b: the L2 serialises the updates of one address); a claim of four, with the four list
-// entries fetched together by four lanes, costs 2 K.
+// entries fetched together by four lanes, costs 2 K.  Near the end of the queue -- fewer than two claims of four per resident
+// wavefront left, judged by this wave's previous claim -- items are taken singly again: their costs have long tails, and a
+// wavefront working through four heavy ones while the others have run out of work set the length of K3 (r03q: 5.2 -> 9.5 ms).
 #define EMA_CLAIM 4
 struct EmaClaim { int base = 0, n = 0, i = 0; unsigned long long mine = 0; };
+__device__ __forceinline__ int ema_claim_step(int last_base, int total)
+{
+	const int waves = (int)(gridDim.x * (blockDim.x >> 6));
+	return (long long)last_base + 2LL * EMA_CLAIM * waves < (long long)total ? EMA_CLAIM : 1;
+}
 // The next item's index, or -1 when none is left.  total: items in all (final before the launch).  list (may be null): one entry
 // per item; `entry` receives this item's.
 template <typename T>
@@ -99,11 +106,12 @@ __device__ __forceinline__ int ema_claim_next(EmaClaim &c, int *counter, int tot
 {
 	const int lane = (int)ema_lane();
 	if (c.i == c.n) {
+		const int step = ema_claim_step(c.base, total);
 		int b = 0;
-		if (lane == 0) b = atomicAdd(counter, EMA_CLAIM);
+		if (lane == 0) b = atomicAdd(counter, step);
 		b = __builtin_amdgcn_readlane(b, 0);
 		if (b >= total) return -1;
-		c.base = b; c.n = total - b < EMA_CLAIM ? total - b : EMA_CLAIM; c.i = 0;
+		c.base = b; c.n = total - b < step ? total - b : step; c.i = 0;
 		if (list && lane < c.n) c.mine = (unsigned long long)list[b + lane];
 	}
 	const int k = c.i++;

@@ -411,12 +411,13 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		const uint8_t *hrec = nullptr;
 		if (MODE == 3) {
 			if (cl_i == cl_n) {
-				int base = 0;
-				if (lane == 0) base = atomicAdd(counter, 4);
-				base = __builtin_amdgcn_readlane(base, 0);
 				const int total = *n_todo;
+				const int step = ema_claim_step(cl_base, total);      // (dev_common.hpp: singly near the end of the queue)
+				int base = 0;
+				if (lane == 0) base = atomicAdd(counter, step);
+				base = __builtin_amdgcn_readlane(base, 0);
 				if (base >= total) break;
-				cl_base = base; cl_n = total - base < 4 ? total - base : 4; cl_i = 0;
+				cl_base = base; cl_n = total - base < step ? total - base : step; cl_i = 0;
 				if (lane < cl_n) pf = *reinterpret_cast<const HandHdr *>(hand + (size_t)(base + lane) * EMA_HAND_BYTES);
 			}
 			hd.read = __builtin_amdgcn_readlane(pf.read, cl_i); hd.n_chn = __builtin_amdgcn_readlane(pf.n_chn, cl_i);

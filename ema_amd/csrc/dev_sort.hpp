@@ -107,4 +107,19 @@ __device__ inline void ema_introsort(A a, int n, LT lt, int *stack)
 	}
 }
 
+
+// Ascending sort of n <= 64 DISTINCT 64-bit keys by the whole wavefront: lane i ranks key i against the others (values read
+// lane to lane, no memory) and stores it at its rank.  With distinct keys every correct sort gives the same array, so this stands
+// in for ks_introsort where bwa's keys cannot tie (mem_chain2aln's seed order: score << 32 | index) -- the single-lane sort
+// on LDS costs a hundred-clock round trip per comparison.  The caller synchronises before (keys written) and after.
+__device__ __forceinline__ void ema_rank_sort_distinct(uint64_t *keys, int n)
+{
+	const int lane = (int)ema_lane();
+	const uint64_t mine = lane < n ? keys[lane] : ~0ULL;
+	int rank = 0;
+	for (int j = 0; j < n; ++j) rank += ema_lane_val(mine, j) < mine ? 1 : 0;
+	ema_wave_sync();
+	if (lane < n) keys[rank] = mine;
+}
+
 #endif

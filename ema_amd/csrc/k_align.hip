@@ -1019,13 +1019,16 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				}
 				rs = rseq + ema_uni((int)sl.kept[ci_sorted]);
 				// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
-				if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
+				ema_wave_sync();
+				if (cn > 1 && cn <= EMA_WAVE) ema_rank_sort_distinct(sl.srt, cn);      // (distinct keys: dev_sort.hpp)
+				else if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
 				ema_wave_sync();
 			} else if (MODE != 2) {
 				ema_wave_fetch(ix, rmax0, rmax1, rseq);
 				// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
 				ema_wave_sync();
-				if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
+				if (cn > 1 && cn <= EMA_WAVE) ema_rank_sort_distinct(sl.srt, cn);      // (distinct keys: dev_sort.hpp)
+				else if (cn > 1 && lane == 0) ema_introsort(sl.srt, cn, [](uint64_t x, uint64_t y) { return x < y; }, lds_stack[wib]);
 				ema_wave_sync();
 			}
 

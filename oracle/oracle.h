@@ -19,12 +19,15 @@
  *   src/bwabridge.c:313-339  interpret_align      -> (fields kept raw in orc_reg_t)
  *   src/align.c:180-186      bwa_init             -> orc_idx_load(), orc_opt_init()
  *   src/align.c:986-1061     append_alignments    -> orc_align_pair() (candidate part), orc_append_alignments() (filters, mapq, scores)
- * Two later parts restate code that IS in the reference tree: oracle/ingest.c (read_special_fastq and its helpers;
- * the helpers are pinned to the reference's own src/util.c, compiled into oracle/_ref by `make ref`) and oracle/sam.c
- * (print_sam_record; unpinned, samrecord.c cannot be compiled here).
- * Self-consistency is checked in tests/ against brute-force models (suffix
- * array search, exhaustive DP re-scoring); nothing here is checked against
- * real bwa output.
+ * The later parts restate code that IS in the reference tree -- oracle/ingest.c (read_special_fastq and its helpers),
+ * oracle/clouds.c (clouds, EM, duplicates), oracle/sam.c (print_sam_record) -- and since round 3 they are PINNED: every
+ * unmodified reference source (src/ *.c, cpp/ *.cc) compiles against include/bwa_compat/ and links over this oracle's nine libbwa
+ * symbols (oracle/bwaface.c -> oracle/_ref/ema_refhost, `make ref`, build container only); the SAM that binary writes is
+ * committed under tests/golden/sam/ with the script that made it, and these restatements reproduce it byte for byte
+ * (tests/test_golden_sam.py) -- except `-d`'s random draws and the `-1/-2` FASTQ reader, which only the product restates.
+ * The bwa half stays unpinned: self-consistency is checked in tests/ against brute-force models (suffix array search,
+ * exhaustive DP re-scoring); nothing here is checked against real bwa output (tools/diff_vs_bwa.sh is the way out for
+ * whoever has a bwa checkout).
  */
 #ifndef EMA_ORACLE_H
 #define EMA_ORACLE_H

@@ -20,6 +20,7 @@ if [[ $what == *bench* ]]; then
   EMA_INDEX_PROF=1 timeout 1500 python3 "$root/bench.py" > "$out/bench.json" 2> "$out/bench.err"; echo "bench: rc=$?"; cut -c1-600 "$out/bench.json"; tail -25 "$out/bench.err"
   timeout 300 python3 "$root/tools/cpu_seed_profile.py" > "$out/seed_profile.txt" 2>&1; echo "seedprof: rc=$?"
   EMA_PHASE_PROFILE=2 timeout 600 python3 "$root/tools/gpu_readlog.py" "$tag" > "$out/readlog.txt" 2>&1; echo "readlog: rc=$?"; tail -40 "$out/readlog.txt"
+  timeout 600 python3 "$root/tools/gpu_k2_profile.py" > "$out/k2_profile.txt" 2>&1; echo "k2 profile: rc=$?"; cat "$out/k2_profile.txt"
 fi
 if [[ $what == *sam* ]]; then
   EMA_SAM_REPEAT=4 timeout 900 python3 "$root/tools/gpu_sam_rate.py" 25 200000 > "$out/sam_rate.txt" 2>&1; echo "sam: rc=$?"; tail -12 "$out/sam_rate.txt"

@@ -127,8 +127,26 @@ __device__ __forceinline__ int ema_claim_next(EmaClaim &c, int *counter, int tot
 // row / next two rows) and wave_shr:1.  Lanes without a source receive `ident`.
 #define EMA_DPP(old, v, ctrl, row_mask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (row_mask), 0xf, false)
 
+// One instruction per step: v_max_i32_dpp / v_add_u32_dpp with the lane's own register as destination and both sources -- a
+// lane without a source, or in a row the step's row mask leaves out, is not written and keeps its value, which is what the
+// identity would have given it.  Through __builtin_amdgcn_update_dpp the compiler emits three instructions per step (reload the
+// identity, v_mov_b32_dpp, operate) and does not fold them (r03: the two scans of every DP row were a fifth of the row's
+// instructions).  The s_nop covers the two wait states a DPP read needs after a VALU write of the same register.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EMA_DPP_STEP(op, v, ctrl) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+#endif
 __device__ __forceinline__ int ema_wave_incl_scan_max(int v, int ident)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+	(void)ident;
+	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_max_i32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");      // into rows 1 and 3
+	EMA_DPP_STEP("v_max_i32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");      // into rows 2 and 3
+	return v;
+#else      // (the host interpreter of tests/emu)
 	int t;
 	t = EMA_DPP(ident, v, 0x111, 0xf); v = max(v, t);     // row_shr:1
 	t = EMA_DPP(ident, v, 0x112, 0xf); v = max(v, t);     // row_shr:2
@@ -137,9 +155,19 @@ __device__ __forceinline__ int ema_wave_incl_scan_max(int v, int ident)
 	t = EMA_DPP(ident, v, 0x142, 0xa); v = max(v, t);     // row_bcast:15 into rows 1 and 3
 	t = EMA_DPP(ident, v, 0x143, 0xc); v = max(v, t);     // row_bcast:31 into rows 2 and 3
 	return v;
+#endif
 }
 __device__ __forceinline__ int ema_wave_incl_scan_add(int v)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP("v_add_u32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+	EMA_DPP_STEP("v_add_u32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+	return v;
+#else
 	int t;
 	t = EMA_DPP(0, v, 0x111, 0xf); v += t;
 	t = EMA_DPP(0, v, 0x112, 0xf); v += t;
@@ -148,6 +176,7 @@ __device__ __forceinline__ int ema_wave_incl_scan_add(int v)
 	t = EMA_DPP(0, v, 0x142, 0xa); v += t;
 	t = EMA_DPP(0, v, 0x143, 0xc); v += t;
 	return v;
+#endif
 }
 // value of the lane below (lane 0 receives `ident`)
 __device__ __forceinline__ int ema_wave_shr1(int v, int ident) { return EMA_DPP(ident, v, 0x138, 0xf); }

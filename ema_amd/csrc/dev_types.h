@@ -99,10 +99,13 @@ struct ChainRec {
 // Records are written densely, in the order K2a gives reads up (record i = the i-th read handed over; their number is a device
 // counter), and carry everything the consumer needs to start -- the read's number, its length and where its bases are -- so
 // that a wavefront goes from "item i" to its first extension in two round trips to memory: the header, then {bases, tables}.
-// Layout: HandHdr, the filter's sorted keys (weight << 32 | chain), the chains, the seed pool.
+// K2a's finished work travels too: the chains it extended completely before the one it gave up in (chain_from: where the consumer
+// resumes, in filtered order) and the regions they produced (n_av of them: mem_chain2aln's list as it stood at that chain's start).
+// Layout: HandHdr, the filter's sorted keys (weight << 32 | chain), the chains, the seed pool, the regions.
 #define EMA_HAND_SEEDS 32
-struct HandHdr { int32_t read, n_chn, n_seed, l_query; uint32_t base_off; int32_t pad[3]; };
-#define EMA_HAND_BYTES (sizeof(HandHdr) + (size_t)EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)))
+#define EMA_HAND_REGS 12        // = K2a's EMA_LANE_REGS
+struct HandHdr { int32_t read, n_chn, n_seed, l_query; uint32_t base_off; int32_t chain_from, n_av, pad; };
+#define EMA_HAND_BYTES (sizeof(HandHdr) + (size_t)EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)) + (size_t)EMA_HAND_REGS * sizeof(DevReg))
 
 // Chain-rich reads (hundreds of chains, nearly every one of them extended: a read from a young repeat family) are a long
 // serial job for the one wavefront that owns them -- two extension DPs per chain, one after the other -- and they set the

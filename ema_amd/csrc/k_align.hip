@@ -402,12 +402,12 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	EmaClaim claim;                        // the other modes
 	unsigned long long list_entry = 0;     // this item's entry of the launch's list (todo / tasks / reads)
 	HandHdr pf;
-	pf.read = pf.n_chn = pf.n_seed = pf.l_query = 0; pf.base_off = 0;
+	pf.read = pf.n_chn = pf.n_seed = pf.l_query = pf.chain_from = pf.n_av = 0; pf.base_off = 0;
 	for (;;) {
 		int read = 0;
 		constexpr bool handed = MODE == 3;      // K2a already chained and filtered this read (dev_types.h, HandHdr)
 		HandHdr hd;                             // MODE 3: this record's header, wave-uniform
-		hd.read = hd.n_chn = hd.n_seed = hd.l_query = 0; hd.base_off = 0;
+		hd.read = hd.n_chn = hd.n_seed = hd.l_query = hd.chain_from = hd.n_av = 0; hd.base_off = 0;
 		const uint8_t *hrec = nullptr;
 		if (MODE == 3) {
 			if (cl_i == cl_n) {
@@ -423,6 +423,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			hd.read = __builtin_amdgcn_readlane(pf.read, cl_i); hd.n_chn = __builtin_amdgcn_readlane(pf.n_chn, cl_i);
 			hd.n_seed = __builtin_amdgcn_readlane(pf.n_seed, cl_i); hd.l_query = __builtin_amdgcn_readlane(pf.l_query, cl_i);
 			hd.base_off = (uint32_t)__builtin_amdgcn_readlane((int)pf.base_off, cl_i);
+			hd.chain_from = __builtin_amdgcn_readlane(pf.chain_from, cl_i); hd.n_av = __builtin_amdgcn_readlane(pf.n_av, cl_i);
 			hrec = hand + (size_t)(cl_base + cl_i) * EMA_HAND_BYTES;
 			++cl_i;
 			read = hd.read;
@@ -510,15 +511,18 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			const uint64_t *hk = reinterpret_cast<const uint64_t *>(hrec + sizeof(HandHdr));
 			const ChainRec *hc = reinterpret_cast<const ChainRec *>(hrec + sizeof(HandHdr) + EMA_HAND_SEEDS * 8);
 			const SeedRec *hs = reinterpret_cast<const SeedRec *>(hrec + sizeof(HandHdr) + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
+			const DevReg *hr = reinterpret_cast<const DevReg *>(hrec + sizeof(HandHdr) + EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)));
 			uint64_t kv = 0;
-			ChainRec cv; SeedRec sv;
+			ChainRec cv; SeedRec sv; DevReg rv;
 			if (lane < n_chn) { kv = hk[lane]; cv = hc[lane]; }
 			if (lane < n_sd) sv = hs[lane];
+			if (lane < hd.n_av) rv = hr[lane];      // the regions of the chains K2a finished (below: into the region list)
 			ema_phase_fence();
 #pragma unroll
 			for (int k = 0; k < 4; ++k) { const int i = lane + k * EMA_WAVE; if (i < l_query) query[i] = qv[k]; }
 			if (lane < n_chn) { sl.skey[lane] = kv; sl.chains[lane] = cv; }
 			if (lane < n_sd) sl.seeds[lane] = sv;
+			if (lane < hd.n_av) { if (AVL > 0 && hd.n_av <= AVL) reinterpret_cast<DevReg *>(lds_av[wib])[lane] = rv; else slab.av[lane] = rv; }
 			cb.n_chain = n_chn; cb.n_seed = n_sd;
 			n_keep = n_chn;
 			ema_wave_sync();
@@ -529,7 +533,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				const ChainRec c = sl.chains[(int)(uint32_t)kv];
 				int64_t r0 = 0;
 				int wl = 0;
-				if (c.kept != 0) {
+				if (c.kept != 0 && lane >= hd.chain_from) {      // (the chains before chain_from are K2a's: done)
 					int64_t rmax0 = l_pac << 1, rmax1 = 0;
 					int k = c.first_seed;
 					for (int t = 0; t < c.n; ++t) {
@@ -913,17 +917,17 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 		// regions start out in LDS (sorting and de-duplicating a handful of them in the HBM slab is dozens of dependent round
 		// trips); the list moves to the slab when it outgrows AVL
-		bool av_lds = AVL > 0;
-		if (AVL > 0) {
+		bool av_lds = AVL > 0 && !(MODE == 3 && hd.n_av > AVL);      // (mode 3 starts with the regions K2a handed over)
+		if (av_lds) {
 			uint8_t *b = lds_av[wib];
 			cb.sl.av = (DevReg *)b; cb.sl.av_tmp = (DevReg *)b + AVL; cb.sl.rkeys = (uint64_t *)((DevReg *)b + 2 * AVL);
 		}
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
 		EMA_LP(1);
-		int n_av = 0;
+		int n_av = MODE == 3 ? hd.n_av : 0;
 		EMA_DBG(5, n_keep);
 		EMA_PHASE(3);
-		for (int ci_sorted = MODE == 1 ? task_chain : 0; ci_sorted < (MODE == 1 ? task_chain + 1 : n_keep); ++ci_sorted) {
+		for (int ci_sorted = MODE == 1 ? task_chain : MODE == 3 ? hd.chain_from : 0; ci_sorted < (MODE == 1 ? task_chain + 1 : n_keep); ++ci_sorted) {
 			EMA_DBG(6, ci_sorted);
 			const int cid = ema_uni((int)(uint32_t)sl.skey[ci_sorted]);
 			const ChainRec c = ema_uni(sl.chains[cid]);

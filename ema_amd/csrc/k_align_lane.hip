@@ -19,7 +19,7 @@
 
 #define EMA_LANE_INTV 24        // seed intervals of a small read
 #define EMA_LANE_SEEDS 32       // seed occurrences (and therefore chains)
-#define EMA_LANE_REGS 12        // regions before de-duplication
+#define EMA_LANE_REGS EMA_HAND_REGS        // regions before de-duplication (12)
 
 namespace {
 
@@ -359,9 +359,11 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 		// ---------------- mem_chain2aln for every surviving chain, in filtered order ----------------
 		EMA_PHASE(4);
 		int n_av = 0, st = 0;
+		int chain_from = 0, n_av_from = 0;      // where K2b resumes if this lane gives the read up: the chain being extended, the list at its start
 		bool bail = false;
 		for (int cs_ = 0; cs_ < n_chn && !bail; ++cs_) {
 			const ChainRec c = s.chains[(int)(uint32_t)s.skey[cs_]];
+			chain_from = cs_; n_av_from = n_av;
 			if (c.kept == 0) continue;
 			const int cn = c.n;
 			int64_t rmax0 = l_pac << 1, rmax1 = 0;
@@ -461,18 +463,22 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 			}
 		}
 		EMA_PHASE(6);
+		if (!bail) { chain_from = 0; n_av_from = 0; }      // (given up in the dedup below, which edits the list in place: K2b starts over)
 		int n_out = bail ? -1 : lane_sort_dedup(ix, opt, n_av, s, stack);
 		if (n_out < 0) {
 			// K2b redoes the read from mem_chain2aln on: hand it the chains, the filter's order and the seed pool (dev_types.h, HandHdr)
 			uint8_t *h = hand + (size_t)atomicAdd(n_hand, 1) * EMA_HAND_BYTES;
 			HandHdr hd;
-			hd.read = read; hd.n_chn = n_chn; hd.n_seed = n_seed; hd.l_query = l_query; hd.base_off = off[in_read]; hd.pad[0] = hd.pad[1] = hd.pad[2] = 0;
+			hd.read = read; hd.n_chn = n_chn; hd.n_seed = n_seed; hd.l_query = l_query; hd.base_off = off[in_read];
+			hd.chain_from = chain_from; hd.n_av = n_av_from; hd.pad = 0;
 			*reinterpret_cast<HandHdr *>(h) = hd;
 			uint64_t *hk = reinterpret_cast<uint64_t *>(h + sizeof(HandHdr));
 			ChainRec *hc = reinterpret_cast<ChainRec *>(h + sizeof(HandHdr) + EMA_HAND_SEEDS * 8);
 			SeedRec *hs = reinterpret_cast<SeedRec *>(h + sizeof(HandHdr) + EMA_HAND_SEEDS * (8 + sizeof(ChainRec)));
 			for (int i = 0; i < n_chn; ++i) { hk[i] = s.skey[i]; hc[i] = s.chains[i]; }
 			for (int i = 0; i < n_seed; ++i) hs[i] = s.seeds[i];
+			DevReg *hr = reinterpret_cast<DevReg *>(h + sizeof(HandHdr) + EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)));
+			for (int i = 0; i < n_av_from; ++i) hr[i] = s.av[i];
 			continue;
 		}
 		if (n_out > opt.reg_cap) { st |= EMA_ST_REG_OVERFLOW; n_out = opt.reg_cap; }

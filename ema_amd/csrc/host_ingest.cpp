@@ -538,6 +538,32 @@ bool parse_fastq(const char *what, const std::vector<char> &buf, int name_style,
 		const char *name_end = id + id_l;                 // the identifier ends here ...
 		const char *bc = nullptr;
 		const char *space = (const char *)memchr(id, ' ', id_l);
+		if (name_style == 2 || name_style == 3) {
+			// TruSeq SLR / CPT-seq: integer barcodes.  extract_bc_truseq: atoi() of the name behind its '@', the name left whole;
+			// extract_bc_cptseq: the name cut at its last ':', atoi() of what follows that ':' and two more characters (src/techs.c:56-68)
+			const char *num = id + 1;
+			if (name_style == 3) {
+				const char *colon = nullptr;
+				for (const char *c = id + id_l; c-- > id;) if (*c == ':') { colon = c; break; }
+				if (!colon) return bad("no ':' before the barcode in the name (the reference asserts, src/techs.c:65)");
+				name_end = colon;
+				num = colon + 3 <= id + id_l ? colon + 3 : id + id_l;
+			}
+			// atoi: blanks, a sign, digits (the line's end stops it: the buffer the reference parses ends in '\n')
+			const char *c = num, *lim = id + id_l;
+			while (c < lim && is_space((unsigned char)*c)) ++c;
+			bool neg = false;
+			if (c < lim && (*c == '-' || *c == '+')) { neg = *c == '-'; ++c; }
+			long long v = 0;
+			while (c < lim && *c >= '0' && *c <= '9' && v < (1LL << 40)) { v = v * 10 + (*c - '0'); ++c; }
+			if (v > 2147483647LL) return bad("barcode number beyond int (the reference's atoi is undefined there)");
+			r.bc = (uint64_t)(int64_t)(int)(neg ? -v : v);      // bc_t = uint64_t of an int
+			r.id = id; r.id_l = (uint32_t)(name_end - id);
+			if (r.id_l < 2) return bad("empty identifier");
+			out.push_back(r);
+			++n_rec;
+			continue;
+		}
 		if (name_style == 1 && space && (size_t)(id + id_l - space) >= 6 && memcmp(space, " BX:Z:", 6) == 0) {      // tellseq, Long Ranger basic format
 			const char *colon = nullptr;
 			for (const char *c = id + id_l; c-- > space;) if (*c == ':') { colon = c; break; }
@@ -571,7 +597,8 @@ int ema_fastq_read(const char *path1, const char *path2, int name_style, int bc_
 	EMA_CPU(EMA_CPU_READER);
 	*out = nullptr;
 	g_err.clear();
-	if (!path1 || bc_len < 1 || bc_len > 32 || max_read_len < 1 || max_read_len > 4096 || (is_haplotag && bc_len != 12) || name_style < 0 || name_style > 1)
+	const bool numbered = name_style == 2 || name_style == 3;      // (integer barcodes: the platform's bc_len is 0)
+	if (!path1 || bc_len < (numbered ? 0 : 1) || bc_len > 32 || max_read_len < 1 || max_read_len > 4096 || (is_haplotag && bc_len != 12) || name_style < 0 || name_style > 3)
 		return fail(EMA_EARG, "bad argument");
 	std::vector<char> t1, t2;
 	std::string err;

@@ -255,7 +255,7 @@ void ema_sam_free(char *text) { free(text); }
 // lines[0..n) formatted by the host's threads into one buffer per thread, in order
 static int format_parts(const ema_sam_line *lines, size_t n, const ema_sam_opts *opt, std::vector<Out> &parts)
 {
-	if ((!lines && n) || !opt || !opt->bx_index || opt->bc_len < 1 || opt->bc_len > 32 || (opt->is_haplotag && opt->bc_len != 12)) return EMA_EARG;
+	if ((!lines && n) || !opt || !opt->bx_index || opt->bc_len < 0 || opt->bc_len > 32 || (opt->is_haplotag && opt->bc_len != 12)) return EMA_EARG;
 	for (size_t i = 0; i < n; ++i) if (!lines[i].rec && !lines[i].mate) return EMA_EARG;
 	const size_t t = n < 4096 ? 1 : (size_t)EmaPool::get().size(), per = (n + t - 1) / t;      // host_pool.h
 	// the threads' buffers are the caller's thread's from call to call (grown, never handed back: a fresh 30 MB vector per call is

@@ -661,6 +661,8 @@ int ema_sam_run_opts_platform(const char *name, ema_sam_run_opts *o)
 			for (int i = 0; i < 9; ++i) o->clouds.density_probs[i] = cpt[i];
 		}
 		o->sam.bc_len = t.bc_len; o->sam.is_haplotag = t.haplotag;
+		// how `-1 / -2` input names its barcodes (ema_fastq_read): after the last ':' | a " BX:Z:" comment | the name's leading number | ":xxNNN"
+		o->stream.fastq_name_style = strcmp(name, "tellseq") == 0 ? 1 : strcmp(name, "tru") == 0 ? 2 : strcmp(name, "cpt") == 0 ? 3 : 0;
 		return EMA_OK;
 	}
 	g_err = std::string("unknown platform ") + name;

@@ -182,13 +182,15 @@ def platform_opts(name: str) -> dict:
     if rc != 0:
         raise ValueError(f"unknown platform {name!r}")
     return {"bc_len": o.stream.bc_len, "is_haplotag": bool(o.stream.is_haplotag), "error_rate": o.stream.error_rate,
-            "dist_thresh": o.clouds.dist_thresh, "many_clouds": bool(o.clouds.many_clouds), "sam_bc_len": o.sam.bc_len, "sam_is_haplotag": bool(o.sam.is_haplotag)}
+            "dist_thresh": o.clouds.dist_thresh, "many_clouds": bool(o.clouds.many_clouds), "sam_bc_len": o.sam.bc_len, "sam_is_haplotag": bool(o.sam.is_haplotag),
+            "fastq_name_style": o.stream.fastq_name_style, "density_probs": [float(o.clouds.density_probs[i]) for i in range(o.clouds.n_density_probs)]}
 
 
 def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None, is_haplotag: bool = False, bc_len: int = 16,
                continue_cloud_ids: bool = False, n_engines: int = 0, bx_index: bytes | None = None, density_opt: bool = False,
-               fastq_mates: list | None = None):
-    """ema_stream_sam: bucket files -> SAM text on fd.  Returns (per-bucket stream stats, per-bucket SAM stats)."""
+               fastq_mates: list | None = None, platform: str | None = None):
+    """ema_stream_sam: bucket files -> SAM text on fd.  Returns (per-bucket stream stats, per-bucket SAM stats).
+    platform: `-p <name>` (ema_sam_run_opts_platform; is_haplotag / bc_len are then the platform's)."""
     from . import clouds as _clouds
     from . import sam as _sam
     if not SamRunOpts.__dict__.get("_fields_"):
@@ -198,8 +200,14 @@ def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None
     L.ema_stream_sam.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(SamRunOpts), C.c_int, C.POINTER(BucketStats),
                                  C.POINTER(_clouds.SamStats)]
     o = SamRunOpts()
-    L.ema_sam_run_opts_default(C.byref(o))
-    o.stream.is_haplotag, o.stream.bc_len, o.stream.n_engines = int(is_haplotag), bc_len, n_engines
+    if platform is not None:
+        L.ema_sam_run_opts_platform.argtypes = [C.c_char_p, C.POINTER(SamRunOpts)]
+        if L.ema_sam_run_opts_platform(platform.encode(), C.byref(o)) != 0:
+            raise ValueError(f"unknown platform {platform!r}")
+        o.stream.n_engines = n_engines
+    else:
+        L.ema_sam_run_opts_default(C.byref(o))
+        o.stream.is_haplotag, o.stream.bc_len, o.stream.n_engines = int(is_haplotag), bc_len, n_engines
     o.sam.rg_id = rg_id
     if bx_index is not None:
         o.sam.bx_index = bx_index

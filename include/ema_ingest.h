@@ -58,7 +58,10 @@ int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, 
  * name.  path2 == NULL: one file with the mates interleaved (read_fastq_rec_bc_group_interleaved), else mate 1 in path1 and mate 2
  * in path2 (read_fastq_rec_bc_group on each).  Per record, as extract_bc_10x / _haplotag do: the barcode is the bc_len characters
  * after the LAST ':' of the name line, the identifier is the name without its '@', cut at that ':' and at the first blank
- * (Long Ranger style names); name_style 1 = tellseq (src/techs.c:31-54: a " BX:Z:" comment carries the barcode).  Barcode groups are
+ * (Long Ranger style names); name_style 1 = tellseq (src/techs.c:31-54: a " BX:Z:" comment carries the barcode); name_style 2 =
+ * TruSeq SLR (extract_bc_truseq: the barcode is atoi() of the name behind its '@', the name stays whole) and 3 = CPT-seq
+ * (extract_bc_cptseq: the name is cut at its last ':' and the barcode is atoi() of what follows that ':' and two more
+ * characters) -- integer barcodes, bc_len 0 as in the reference's platform table.  Barcode groups are
  * the runs of equal barcode IN FILE ORDER -- the reference trusts the input to be sorted and so does this reader -- and both
  * mates of a pair must carry the same barcode and the same identifier (the reference asserts the former, src/align.c:708,733).
  * The result is laid out as ema_bucket_read's.  EMA_EFORMAT names the record where the reference would assert or read past a

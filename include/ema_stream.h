@@ -93,9 +93,9 @@ void ema_sam_run_opts_default(ema_sam_run_opts *o);
 /* The defaults, then what `ema align -p <platform>` takes from the reference's platform table (get_platform_profile_by_name,
  * src/techs.c:74-135): barcode length, whether barcodes are haplotag codes, the error rate of the append stage, the cloud
  * distance threshold and the many-clouds mode.  name: "10x", "haplotag", "dbs", "tellseq" (bucketed text with 16 / 12 / 20 / 18
- * base barcodes), "tru", "cpt" (many-clouds platforms: 15 kb / 3.5 kb clouds; their FASTQ identifiers carry the barcode, which
- * the bucket reader here does not parse -- the options are for ema_clouds_select on records of the caller's own).  EMA_EARG for
- * any other name. */
+ * base barcodes), "tru", "cpt" (many-clouds platforms: 15 kb / 3.5 kb clouds, integer barcodes in the FASTQ names: `-1 / -2`
+ * input only, bc_len 0; cpt also brings its own density model for -d).  stream.fastq_name_style is set to what
+ * ema_fastq_read needs for the platform's names.  EMA_EARG for any other name. */
 int ema_sam_run_opts_platform(const char *name, ema_sam_run_opts *o);
 int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const ema_sam_run_opts *o, int fd, ema_bucket_stats *bstats,
                    ema_sam_stats *sstats);

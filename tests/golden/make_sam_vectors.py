@@ -103,7 +103,13 @@ def write_fastq(d, ctg, n_pairs, seed, per_bc, style, haplotag=False, interleave
         r1, r2 = pairs.read(2 * i), pairs.read(2 * i + 1)
         q1 = bytes(rng.choice(b"#,5:AFF") for _ in r1)
         q2 = bytes(rng.choice(b"#,5:AFF") for _ in r2)
-        names = (b"@s%d 1:N:0:" % i + bc, b"@s%d 2:N:0:" % i + bc) if style == "longranger" else (b"@s%d:" % i + bc, b"@s%d:" % i + bc)
+        if style in ("tru", "cpt"):      # integer barcodes: extract_bc_truseq reads atoi() of the name, extract_bc_cptseq the digits after ":BC"
+            if key not in codes:
+                codes[key] = len(codes) + 1
+            bc = b"%06d" % codes[key]
+            names = (b"@%d_s%d" % (codes[key], i),) * 2 if style == "tru" else (b"@s%d:BC%d" % (i, codes[key]),) * 2
+        else:
+            names = (b"@s%d 1:N:0:" % i + bc, b"@s%d 2:N:0:" % i + bc) if style == "longranger" else (b"@s%d:" % i + bc, b"@s%d:" % i + bc)
         recs.append((bc, names, r1, q1, r2, q2))
     recs.sort(key=lambda r: r[0])      # equal barcodes side by side, as the reference expects
     m1 = b"".join(n[0] + b"\n" + r1 + b"\n+\n" + q1 + b"\n" for _bc, n, r1, q1, _r2, _q2 in recs)
@@ -132,6 +138,9 @@ CASES = [
     ("fastq_two_files", "plain", [dict(fastq=True, n_pairs=110, seed=511, per_bc=37, style="plain", sub_rate=0.01, chimeric=0.05)], []),
     ("fastq_interleaved_longranger_names", "plain", [dict(fastq=True, n_pairs=90, seed=512, per_bc=45, style="longranger", interleaved=True)], []),
     ("fastq_interleaved_haplotag", "plain", [dict(fastq=True, n_pairs=80, seed=513, per_bc=40, style="plain", haplotag=True, interleaved=True)], ["-p", "haplotag"]),
+    # -p tru / cpt: integer barcodes in the names, the many-clouds EM, other distance thresholds and error rates (src/techs.c:56-107)
+    ("tru_fastq_many_clouds", "dups", [dict(fastq=True, n_pairs=240, seed=514, per_bc=60, style="tru", sub_rate=0.004)], ["-p", "tru"]),
+    ("cpt_fastq_density_opt", "dups", [dict(fastq=True, n_pairs=260, seed=515, per_bc=65, style="cpt", sub_rate=0.004, interleaved=True)], ["-p", "cpt", "-d"]),
     ("density_opt_x_two_buckets", "dups", [dict(n_pairs=200, seed=509, per_bc=100, sub_rate=0.004, dup_frac=0.05), dict(n_pairs=180, seed=510, per_bc=60, sub_rate=0.004)], ["-d"]),
 ]
 

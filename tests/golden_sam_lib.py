@@ -12,7 +12,7 @@ import numpy as np
 import oracle_lib as O
 from ema_amd import build_index
 from ema_amd import engine as E
-from ema_amd import ingest, sam
+from ema_amd import clouds, ingest, sam, stream
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden", "sam")
@@ -47,8 +47,10 @@ class Run:
     def __init__(self, case):
         argv = case["argv"]
         self.argv = [a.encode() for a in argv]
-        self.haplotag = "-p" in argv and argv[argv.index("-p") + 1] == "haplotag"
-        self.bc_len = 12 if self.haplotag else 16
+        self.platform = argv[argv.index("-p") + 1] if "-p" in argv else "10x"
+        self.po = stream.platform_opts(self.platform)      # barcode length, thresholds, error rate, name style (src/techs.c:70-130)
+        self.haplotag = self.po["is_haplotag"]
+        self.bc_len = self.po["bc_len"]
         self.x_mode = "-x" in argv
         self.density_opt = "-d" in argv      # the reference seeds rand() from time(): 1500000000 as ema_refhost saw it (oracle/bwaface.c)
         self.density_seed = 1500000000
@@ -68,21 +70,28 @@ class Run:
     def read(self, path):
         """The input as the product's reader lays it out (bucket file, or FASTQ as -1 / -2 take it)."""
         if self.fastq:
-            return ingest.read_fastq(path, self.fastq_mate, bc_len=self.bc_len, is_haplotag=self.haplotag)
+            return ingest.read_fastq(path, self.fastq_mate, bc_len=self.bc_len, is_haplotag=self.haplotag, name_style=self.po["fastq_name_style"])
         return ingest.read_bucket(path, bc_len=self.bc_len, is_haplotag=self.haplotag)
 
     def sam_opts(self):
         so = sam.default_opts()
         so.rg_id, so.bx_index = self.rg_id, self.bx_index
-        if self.haplotag:
-            so.is_haplotag, so.bc_len = 1, 12
+        so.is_haplotag, so.bc_len = int(self.haplotag), self.bc_len
         return so
+
+    def cloud_opts(self):
+        co = clouds.default_opts()
+        co.dist_thresh, co.many_clouds, co.density_opt = self.po["dist_thresh"], int(self.po["many_clouds"]), int(self.density_opt)
+        co.n_density_probs = len(self.po["density_probs"])
+        for i, p in enumerate(self.po["density_probs"]):
+            co.density_probs[i] = p
+        return co
 
     def header(self, contigs):
         return sam.header(contigs, self.rg_line, b"0.6.2", self.argv)
 
 
-def oracle_batch(prefix, bucket):
+def oracle_batch(prefix, bucket, error_rate=0.001):
     """Candidates and append_alignments records of every pair of a bucket from the CPU oracle, in the engine's layout."""
     idx, opt = O.Index(prefix), O.default_opt()
     cand_off, cands, cigar, recs, pair_off = [0], [], [], [], [0]
@@ -101,7 +110,7 @@ def oracle_batch(prefix, bucket):
                 cands.append(c)
             cand_off.append(len(cands))
             base.append(len(cands))
-        for e in O.append_alignments(idx, opt, r1, r2):
+        for e in O.append_alignments(idx, opt, r1, r2, error_rate=error_rate):
             a = np.zeros((), dtype=E.ALN_REC_DTYPE)
             a["pair"], a["mate"], a["unique"], a["cand"] = p, e["mate"], e["unique"], base[e["mate"]] + e["cand"]
             a["clip"], a["clip_edit_dist"], a["mapq"], a["score_mapq"], a["score"] = e["clip"], e["clip_edit_dist"], e["mapq"], e["score_mapq"], e["score"]

@@ -46,8 +46,9 @@ def test_oracle_chain_equals_the_reference_host_code(case):
         if not run.fastq:      # (the oracle restates the bucket reader only; for FASTQ input the product's reader feeds its chain)
             want, _groups = O.read_special_fastq(path, run.bc_len, run.haplotag)
             assert [w[0] for w in want] == bucket.bc.tolist() and all(bucket.read(2 * i) == w[2] for i, w in enumerate(want))
-        batch, rec, pair_off = oracle_batch(prefix, bucket)
-        arr, n, _keep, _rows, next_id = oracle_selection(bucket, batch, rec, pair_off, names, first_cloud_id=first)
+        batch, rec, pair_off = oracle_batch(prefix, bucket, error_rate=run.po["error_rate"])
+        arr, n, _keep, _rows, next_id = oracle_selection(bucket, batch, rec, pair_off, names, dist_thresh=run.po["dist_thresh"],
+                                                         many_clouds=run.po["many_clouds"], first_cloud_id=first)
         body += oracle_text(arr, n, so)
         first = next_id      # src/align.c:19: the cloud counter is static, so it runs on across the files of an -x run
     assert body == want_body
@@ -68,9 +69,9 @@ def test_product_host_stages_equal_the_reference_host_code(case):
     for path in run.paths:
         bucket = run.read(path)
         batch, _orec, _opair_off = oracle_batch(prefix, bucket)
-        rec, pair_off = E.append_alignments(batch, bucket.off)      # the product's append stage on the oracle's candidates
-        co = clouds.default_opts()
-        co.first_cloud_id, co.n_threads, co.density_opt = first, 3, int(run.density_opt)
+        rec, pair_off = E.append_alignments(batch, bucket.off, error_rate=run.po["error_rate"])      # the product's append stage on the oracle's candidates
+        co = run.cloud_opts()
+        co.first_cloud_id, co.n_threads = first, 3
         sel = clouds.select(bucket, batch, rec, pair_off, names, co)
         body += sam.format_lines(sel.lines, sel.n_lines, so)
         first = sel.next_cloud_id

@@ -35,7 +35,7 @@ def test_stream_sam_equals_the_reference_host_code(case, tmp_path):
     if run.density_opt:
         from ema_amd import clouds
         clouds.reseed(run.density_seed)
-    bst, sst = stream.stream_sam(eng, run.paths, fd, rg_id=run.rg_id, is_haplotag=run.haplotag, bc_len=run.bc_len,
+    bst, sst = stream.stream_sam(eng, run.paths, fd, rg_id=run.rg_id, platform=run.platform,
                                  continue_cloud_ids=run.x_mode, bx_index=run.bx_index, density_opt=run.density_opt,
                                  fastq_mates=[run.fastq_mate] if run.fastq else None)
     os.close(fd)

@@ -265,3 +265,26 @@ def test_fastq_reader_of_align_1_2(tmp_path):
     p3.write_bytes(_fq(b"s1:" + bc1, b"ACGT") * 3)
     with pytest.raises(ingest.BucketError, match="odd number"):
         ingest.read_fastq(str(p3))
+
+
+def test_fastq_reader_integer_barcodes_of_tru_and_cpt(tmp_path):
+    """ema_fastq_read name styles 2 and 3 (`-p tru`, `-p cpt`; reference src/techs.c:56-68): extract_bc_truseq takes atoi() of the name
+    behind its '@' and leaves the name whole; extract_bc_cptseq cuts the name at its last ':' and takes atoi() of what follows that ':'
+    and two more characters.  (The whole path on such input: tests/golden/sam/tru_fastq_many_clouds, cpt_fastq_density_opt.)"""
+    recs = [(b"12_a", b"ACGTAC", b"GGTTAA"), (b"12_b", b"AAAACC", b"CCAATT"), (b"7x", b"ACGT", b"TTGA"), (b"+7y", b"GGGG", b"CCCC"), (b"x9", b"AC", b"GT"), (b"-3z", b"AC", b"GT")]
+    p = tmp_path / "t.fq"
+    p.write_bytes(b"".join(_fq(n, r1) + _fq(n, r2) for n, r1, r2 in recs))
+    b = ingest.read_fastq(str(p), bc_len=0, name_style=2)
+    assert b.n_pairs == 6 and b.group_off.tolist() == [0, 2, 4, 5, 6]      # 12 12 | 7 7 | 0 (no number) | -3
+    assert b.bc.tolist() == [12, 12, 7, 7, 0, (1 << 64) - 3]               # bc_t = uint64_t of atoi()'s int
+    assert [b.ident(i) for i in range(6)] == [b"@" + n for n, _r1, _r2 in recs]
+    recs = [(b"r1:BC41", b"ACGTAC", b"GGTTAA"), (b"r2:xy41tail", b"AAAACC", b"CCAATT"), (b"a:b:BC5", b"ACGT", b"TTGA"), (b"q:B", b"AC", b"GT")]
+    p.write_bytes(b"".join(_fq(n, r1) + _fq(n, r2) for n, r1, r2 in recs))
+    c = ingest.read_fastq(str(p), bc_len=0, name_style=3)
+    assert c.bc.tolist() == [41, 41, 5, 0] and c.group_off.tolist() == [0, 2, 3, 4]
+    assert [c.ident(i) for i in range(4)] == [b"@r1", b"@r2", b"@a:b", b"@q"]
+    p.write_bytes(_fq(b"nocolon", b"AC") * 2)
+    with pytest.raises(ingest.BucketError, match="no ':'"):
+        ingest.read_fastq(str(p), bc_len=0, name_style=3)
+    with pytest.raises(ingest.BucketError):
+        ingest.read_fastq(str(p), bc_len=0, name_style=0)      # the ACGT platforms need their barcode length

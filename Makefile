@@ -41,6 +41,18 @@ build/ss16/%.o: $(CSRC)/%.cpp $(ENGINE_HDRS)
 ema_amd/libema_engine_ss16.so: $(SS16_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(SS16_OBJS)
 
+# Development build with phase clocks in K3 / K4 (dev_prof.hpp; tools/gpu_k34_profile.py): `make prof-lib`
+PROF_OBJS = $(patsubst $(CSRC)/%.hip,build/prof/%.o,$(HIP_SRCS)) $(patsubst $(CSRC)/%.cpp,build/prof/%.o,$(HOST_SRCS))
+build/prof/%.o: $(CSRC)/%.hip $(ENGINE_HDRS)
+	@mkdir -p build/prof
+	$(HIPCC) $(HIPFLAGS) -DEMA_K34_PROF=1 -c -o $@ $<
+build/prof/%.o: $(CSRC)/%.cpp $(ENGINE_HDRS)
+	@mkdir -p build/prof
+	$(HIPCC) $(HOSTCLANG) -DEMA_K34_PROF=1 -c -o $@ $<
+ema_amd/libema_engine_prof.so: $(PROF_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(PROF_OBJS)
+prof-lib: ema_amd/libema_engine_prof.so
+
 # libbwa-shaped face (include/ema_bwaabi.h): the 9 symbols the reference links from -lbwa, on top of the engine
 ema_amd/libema_bwaabi.so: $(CSRC)/bwaabi.cpp include/ema_bwaabi.h include/ema_engine.h ema_amd/libema_engine.so
 	$(CXX) $(HOSTFLAGS) -Iinclude -shared -o $@ $(CSRC)/bwaabi.cpp -Lema_amd -lema_engine -Wl,-rpath,'$$ORIGIN'
@@ -55,4 +67,4 @@ oracle: $(BWAABI)
 clean:
 	rm -rf build; rm -f ema_amd/*.so; $(MAKE) -C oracle clean
 
-.PHONY: all test-libs oracle clean
+.PHONY: all test-libs prof-lib oracle clean

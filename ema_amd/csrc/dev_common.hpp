@@ -7,6 +7,13 @@
 #include "dev_types.h"
 
 #define EMA_WAVE 64
+// LDS addressed as LDS (ds_read / ds_write): through a generic pointer every access is a FLAT instruction, which takes the longer
+// way and waits for the global stores in flight
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EMA_LDS __attribute__((address_space(3)))
+#else
+#define EMA_LDS
+#endif
 
 __device__ __forceinline__ unsigned ema_lane() { return threadIdx.x & 63u; }
 

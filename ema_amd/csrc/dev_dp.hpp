@@ -390,30 +390,35 @@ __device__ EMA_DP_CALL int ema_wave_global(const DevOpts &o, int qlen, EmaSeq qu
 // Ops are produced from the alignment's end towards its start and written backwards into cig[0..cap),
 // so cig[first..cap) is the CIGAR in forward order (BAM packing len<<4|op, M=0 I=1 D=2).  Returns `first`,
 // or -1 if cap is too small.
-__device__ inline int ema_traceback(const uint8_t *z, int qlen, int tlen, int w, uint32_t *cig, int cap)
+// ZP: const uint8_t * (the matrix where the DP wrote it) or const EMA_LDS uint8_t * (staged: k_final.hip).
+// Run by the WHOLE wavefront with wave-uniform scalars (every lane reads the same byte; lane 0 alone stores the operations): as a
+// loop of one lane under an exec mask its ~30 dependent vector instructions per step cost more than the read they wait for.
+template <typename ZP>
+__device__ inline int ema_traceback(ZP z, int qlen, int tlen, int w, uint32_t *cig, int cap)
 {
+	const bool leader = ema_lane() == 0;
 	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
 	int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0, pos = cap, last_op = -1;
 	uint32_t cur = 0;
 	while (i >= 0 && k >= 0) {
-		which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+		which = ema_uni((int)z[(size_t)i * n_col + (k - (i > w ? i - w : 0))]) >> (which << 1) & 3;
 		const int op = which == 0 ? 0 : which == 1 ? 2 : 1;
 		if (op == last_op) cur += 1u << 4;
 		else {
-			if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; }
+			if (last_op >= 0) { if (pos == 0) return -1; --pos; if (leader) cig[pos] = cur; }
 			cur = 1u << 4 | (uint32_t)op; last_op = op;
 		}
 		if (which == 0) { --i; --k; } else if (which == 1) --i; else --k;
 	}
 	if (i >= 0) {
 		if (last_op == 2) cur += (uint32_t)(i + 1) << 4;
-		else { if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; } cur = (uint32_t)(i + 1) << 4 | 2u; last_op = 2; }
+		else { if (last_op >= 0) { if (pos == 0) return -1; --pos; if (leader) cig[pos] = cur; } cur = (uint32_t)(i + 1) << 4 | 2u; last_op = 2; }
 	}
 	if (k >= 0) {
 		if (last_op == 1) cur += (uint32_t)(k + 1) << 4;
-		else { if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; } cur = (uint32_t)(k + 1) << 4 | 1u; last_op = 1; }
+		else { if (last_op >= 0) { if (pos == 0) return -1; --pos; if (leader) cig[pos] = cur; } cur = (uint32_t)(k + 1) << 4 | 1u; last_op = 1; }
 	}
-	if (last_op >= 0) { if (pos == 0) return -1; cig[--pos] = cur; }
+	if (last_op >= 0) { if (pos == 0) return -1; --pos; if (leader) cig[pos] = cur; }
 	return pos;
 }
 

@@ -52,6 +52,10 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
                                  int *counter, int n_blocks, hipStream_t stream, int *dbg, unsigned long long *prof,
                                  const HeavyCtl *heavy, int mode);
 extern "C" void ema_align_set_light_profile(unsigned long long *buf);
+#ifdef EMA_K34_PROF
+extern "C" void ema_k3_prof_read(unsigned long long *out);
+extern "C" void ema_k4_prof_read(unsigned long long *out);
+#endif
 extern "C" size_t ema_align_lane_wave_bytes();
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
@@ -1166,6 +1170,23 @@ int ema_engine_seed_launches(const ema_engine_t *e) { return e ? e->seed_rounds 
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 {
 	if (!e || !t) return EMA_EARG;
+#ifdef EMA_K34_PROF
+	{   // `make prof-lib`: K3's and K4's phase clocks (dev_prof.hpp), reported and reset at every call
+		unsigned long long h[2][3][12];
+		ema_k3_prof_read(&h[0][0][0]); ema_k4_prof_read(&h[1][0][0]);
+		static const char *const name[2][3] = {{"K3b", "K3t", "K3r"}, {"K4b", "K4t", "K4r"}};
+		static const char *const ph[2] = {"claim %.2f, pair in %.2f, anchors / found %.2f, window %.2f, local DP forward %.2f, backward %.2f, insert + dedup %.2f, out %.2f",
+		                                  "claim %.2f, read in %.2f, region + window + band %.2f, global DP %.2f, traceback %.2f, NM / squeeze / out %.2f, place %.2f, totals %.2f"};
+		for (int k = 0; k < 2; ++k)
+			for (int m = 0; m < 3; ++m) {
+				const unsigned long long *o = h[k][m];
+				if (!o[8]) continue;
+				fprintf(stderr, "%-4s lifetimes %.2f Gclk, %llu wavefronts, %llu work items: ", name[k][m], (double)o[8] * 1e-9, o[10], o[9]);
+				fprintf(stderr, ph[k], (double)o[0] * 1e-9, (double)o[1] * 1e-9, (double)o[2] * 1e-9, (double)o[3] * 1e-9, (double)o[4] * 1e-9, (double)o[5] * 1e-9, (double)o[6] * 1e-9, (double)o[7] * 1e-9);
+				fprintf(stderr, "\n");
+			}
+	}
+#endif
 	if (e->d_lprof.p) {
 		unsigned long long h[48];
 		if (hipMemcpy(h, e->d_lprof.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {

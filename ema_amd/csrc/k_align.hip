@@ -203,11 +203,6 @@ __device__ inline void chain_insert(const DevOpts &o, int64_t l_pac, ChainBuild 
 // positions, ids and a 12-byte summary of each chain's mutable end -- and what goes to the slab are stores nobody waits for
 // (the seed, the link from the chain's last seed, a new chain's record).  LDS is addressed as LDS (ds_read / ds_write): a
 // generic-pointer access would be a FLAT instruction, which has to wait for every global store before it.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define EMA_LDS __attribute__((address_space(3)))
-#else
-#define EMA_LDS
-#endif
 // Summary of a chain, three words by chain id: what test_and_merge looks at, relative to the chain's position (= rbeg of its
 // first seed):  [0] rbeg of the last seed - position   [1] rid | last_seed << 16   [2] f_qbeg | l_qbeg << 8 | l_len << 16
 struct MedTables {

@@ -32,7 +32,9 @@ ema_k_test_global(DevOpts opt, const uint8_t *qbuf, const uint32_t *qoff, const 
 	uint8_t *z = zbuf + (size_t)t * z_stride;
 	const int score = ema_wave_global(opt, qlen, q, tlen, tg, prm[t], z);
 	uint32_t *c = cig + (size_t)t * cap;
-	const int first = ema_traceback(z, qlen, tlen, prm[t], c, cap);
+	ema_wave_sync();
+	const int first = ema_traceback((const uint8_t *)z, qlen, tlen, prm[t], c, cap);
+	ema_wave_sync();
 	const int n = first < 0 ? -1 : cap - first;
 	for (int k = 0; k < n; ++k) { const uint32_t v = c[first + k]; c[k] = v; }   // wave-uniform left-pack (first >= k)
 	if (ema_lane() == 0) { out[t * 2] = score; out[t * 2 + 1] = n; }

@@ -9,6 +9,11 @@
 // global DP lives in the wave's slab of HBM scratch.
 #include <hip/hip_runtime.h>
 #include "dev_regions.hpp"
+#include "dev_prof.hpp"
+#ifdef EMA_K34_PROF
+__device__ unsigned long long ema_k4_lp[3][12];
+extern "C" void ema_k4_prof_read(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ema_k4_lp), sizeof(ema_k4_lp)); static unsigned long long z[36]; (void)hipMemcpyToSymbol(HIP_SYMBOL(ema_k4_lp), z, sizeof(z)); }
+#endif
 #include "ema_engine.h"
 #include <algorithm>
 #include <cstring>
@@ -16,6 +21,8 @@
 #define EMA_Z_BYTES ((size_t)256 * (EMA_RSEQ_CAP + 8))
 #define EMA_FINAL_SLAB_BYTES (EMA_Z_BYTES + 4096 * 4 + 1024)
 #define EMA_CIG_TMP 4096
+#define EMA_FINAL_SLOT_OPS 32      // K4t: CIGAR operations of a region that go to the task's own slot of the arena
+#define EMA_Z_LDS 6144      // bytes of LDS per wavefront for a staged direction matrix (a band of 21 columns x 290 rows)
 
 struct DevAln {           // per candidate: what interpret_single_read_alignment reads (reference src/bwabridge.c:359-379)
 	int64_t pos;
@@ -142,7 +149,8 @@ ema_k_final_simple(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack,
 struct FinalHeavy {
 	uint8_t *arena;                    // null: nothing is set aside.  [0, tasks_cap x 48): result records; then CIGAR operations
 	unsigned long long arena_bytes;
-	unsigned long long *arena_used;    // bump allocator of the operations (zero on entry), relative to ops_base
+	unsigned long long *arena_used;    // bump allocator of the operations beyond a slot (zero on entry), relative to ovf_base
+	unsigned long long ovf_base;       // = ops_base + tasks_cap slots
 	unsigned long long ops_base;       // = tasks_cap x 48
 	unsigned long long *reads;         // read | first task << 32
 	unsigned long long *tasks;         // read << 32 | region
@@ -166,6 +174,8 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
+	constexpr int Z_LDS = MODE == 1 ? 2 * EMA_Z_LDS : EMA_Z_LDS;      // (K4t's regions are the gapped ones of repeat-rich reads: wider bands)
+	__shared__ __attribute__((aligned(16))) uint8_t lds_z[MODE == 2 ? 1 : 4][MODE == 2 ? 16 : Z_LDS];      // the direction matrix, staged for the traceback
 	const int lane = (int)ema_lane();
 	const int wib = ema_uni((int)(threadIdx.x >> 6));      // scalar: slab and LDS pointers derived from it stay in SGPRs
 	const int slot = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
@@ -176,13 +186,18 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	FinalRes *res = reinterpret_cast<FinalRes *>(fh.arena);
 
 	EmaClaim claim;      // work items four at a time, with their list entries (dev_common.hpp)
+	// (make prof-lib: phase clocks, dev_prof.hpp) 0 claim, 1 the read in / setting aside, 2 region record, window, band, 3 global DP, 4 traceback,
+	// 5 NM, squeeze, clips, operations out, 6 K4r: a result placed, 7 the read's totals out
+	EMA_LP_DECL(lp);
 	for (;;) {
+		EMA_LP_UPTO(lp, 7);
 		int read = 0;
 		unsigned long long list_entry = 0;
 		if (MODE == 1) { const int n = *fh.n_tasks; read = ema_claim_next(claim, counter, n < fh.tasks_cap ? n : fh.tasks_cap, fh.tasks, list_entry); }
 		else if (MODE == 2) { const int n = *fh.n_reads; read = ema_claim_next(claim, counter, n < fh.reads_cap ? n : fh.reads_cap, fh.reads, list_entry); }
 		else { int t = 0; read = ema_claim_next(claim, counter, *n_todo, todo, t); list_entry = (unsigned long long)(unsigned)t; }
 		if (read < 0) break;
+		EMA_LP_UPTO(lp, 0); EMA_LP_ITEM(lp);
 		int task = -1, task_k = 0, first_task = 0;
 		if (MODE == 1) {
 			task = read;
@@ -227,6 +242,7 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		}
 		uint32_t *pool = cigars + (size_t)read * cig_cap;
 		int pool_n = MODE == 1 ? 0 : ema_uni(cig_n[read]), st = 0;
+		EMA_LP_UPTO(lp, 1);
 		for (int k = MODE == 1 ? task_k : k0; k < (MODE == 1 ? task_k + 1 : nr); ++k) {
 			EMA_DBG(2, k);
 			if (MODE == 2) {      // K4r: the region's result as K4t left it, placed at the pool's fill
@@ -247,6 +263,7 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					}
 				}
 				if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out;
+				EMA_LP_UPTO(lp, 6);
 				continue;
 			}
 			const DevReg ar = ema_uni(regs[(size_t)read * opt.reg_cap + k]);
@@ -286,11 +303,25 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					ema_wave_sync();
 				} else {
 					const int w = ema_cigar_band(opt, lq, rlen, w2);
+					EMA_LP_UPTO(lp, 2);
 					score = ema_wave_global(opt, lq, qs, rlen, ts, w, z);
 					ema_wave_sync();
+					EMA_LP_UPTO(lp, 3);
+					// The traceback is ~lq + rlen DEPENDENT one-byte reads by one lane: from the slab each is a round trip to L2 -- a third
+					// of K4b's and three fifths of K4t's wavefront lifetimes (r03, make prof-lib) -- so a matrix that fits is first copied
+					// to LDS by the whole wavefront (one round trip).  Writing it to LDS in the first place makes the DP's rows wait for
+					// their byte stores (r02: measured, slower); to the slab they are fire-and-forget.
+					const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1, zb = n_col * rlen;
 					int f = 0;
-					if (lane == 0) f = ema_traceback(z, lq, rlen, w, ctmp, EMA_CIG_TMP);
-					f = ema_uni(__shfl(f, 0));
+					if (MODE != 2 && zb <= Z_LDS) {
+						const uint32_t *src = reinterpret_cast<const uint32_t *>(z);
+						uint32_t *dst = reinterpret_cast<uint32_t *>(lds_z[MODE == 2 ? 0 : wib]);
+						for (int i = lane; i < (zb + 3) >> 2; i += EMA_WAVE) dst[i] = src[i];
+						ema_wave_sync();
+						f = ema_traceback((const EMA_LDS uint8_t *)lds_z[MODE == 2 ? 0 : wib], lq, rlen, w, ctmp, EMA_CIG_TMP);
+					} else f = ema_traceback((const uint8_t *)z, lq, rlen, w, ctmp, EMA_CIG_TMP);
+					ema_wave_sync();
+					EMA_LP_UPTO(lp, 4);
 					if (f < 0) { st |= EMA_ST_CIGAR_OVERFLOW; first = EMA_CIG_TMP; n_cig = 0; }
 					else { first = f; n_cig = EMA_CIG_TMP - f; }
 				}
@@ -334,12 +365,17 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			uint32_t *dst = nullptr;
 			unsigned long long ops_at = 0;
 			if (MODE == 1) {      // K4t: room for the operations from the arena; K4r applies the pool's capacity
+				// a task's own slot when the operations fit it (nearly always), else from the arena's cursor: one atomic per region on one
+				// address, with every wavefront of the chip behind it, was a sixth of K4t's lifetimes (r03, make prof-lib)
 				long long at = -1;
-				if (lane == 0) {
-					at = (long long)(fh.ops_base + atomicAdd(fh.arena_used, (unsigned long long)n_final * 4));
-					if ((unsigned long long)at + (unsigned long long)n_final * 4 > fh.arena_bytes) at = -1;
+				if (n_final <= EMA_FINAL_SLOT_OPS) at = (long long)(fh.ops_base + (unsigned long long)task * (EMA_FINAL_SLOT_OPS * 4));
+				else {
+					if (lane == 0) {
+						at = (long long)(fh.ovf_base + atomicAdd(fh.arena_used, (unsigned long long)n_final * 4));
+						if ((unsigned long long)at + (unsigned long long)n_final * 4 > fh.arena_bytes) at = -1;
+					}
+					at = (long long)ema_lane_val((int64_t)at, 0);
 				}
-				at = (long long)ema_uni((int64_t)__shfl(at, 0));
 				if (at < 0) st |= EMA_ST_CIGAR_OVERFLOW;
 				else { dst = reinterpret_cast<uint32_t *>(fh.arena + at); ops_at = (unsigned long long)at; }
 			} else if (pool_n + n_final > cig_cap) { st |= EMA_ST_CIGAR_OVERFLOW; }
@@ -357,10 +393,14 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			if (MODE == 1) { if (lane == 0) { FinalRes r; r.aln = out; r.st = st; r.n_final = dst ? n_final : 0; r.ops_at = ops_at; r.pad_ = 0; res[task] = r; } }
 			else if (lane == 0) alns[(size_t)read * opt.reg_cap + k] = out;
 			ema_wave_sync();
+			EMA_LP_UPTO(lp, 5);
 		}
 		if (MODE != 1 && lane == 0) { cig_n[read] = pool_n; if (st) atomicOr(status + read, st); }
 		EMA_DBG(9, 0);
 	}
+#ifdef EMA_K34_PROF
+	EMA_LP_FLUSH(lp, &ema_k4_lp[MODE][0]);
+#endif
 #undef EMA_DBG
 }
 
@@ -438,10 +478,11 @@ extern "C" void ema_launch_final(const DevIndex *ix, const DevOpts *opt, const u
 	if (heavy && heavy->arena && min_regions > 0) {
 		fh.arena = heavy->arena; fh.arena_bytes = heavy->arena_bytes; fh.arena_used = arena_used;
 		fh.reads = heavy->reads; fh.tasks = heavy->tasks; fh.reads_cap = heavy->reads_cap;
-		fh.tasks_cap = (int)std::min<unsigned long long>((unsigned long long)heavy->tasks_cap, heavy->arena_bytes / 2 / sizeof(FinalRes));
+		fh.tasks_cap = (int)std::min<unsigned long long>((unsigned long long)heavy->tasks_cap, heavy->arena_bytes / 2 / (sizeof(FinalRes) + EMA_FINAL_SLOT_OPS * 4));
 		fh.n_reads = heavy_counters; fh.n_tasks = heavy_counters + 1;
 		fh.min_regions = min_regions;
-		fh.ops_base = (unsigned long long)fh.tasks_cap * sizeof(FinalRes);      // the operations follow the result records
+		fh.ops_base = (unsigned long long)fh.tasks_cap * sizeof(FinalRes);      // the operations follow the result records: a slot per task, then the cursor's room
+		fh.ovf_base = fh.ops_base + (unsigned long long)fh.tasks_cap * (EMA_FINAL_SLOT_OPS * 4);
 	}
 	hipLaunchKernelGGL(ema_k_final_simple, dim3((n_reads + 255) / 256), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map,
 	                   regs, n_regs, alns, cigars, cig_n, cig_cap, status, kdone, todo, n_todo);

@@ -14,6 +14,11 @@
 // written back in place.
 #include <hip/hip_runtime.h>
 #include "dev_regions.hpp"
+#include "dev_prof.hpp"
+#ifdef EMA_K34_PROF
+__device__ unsigned long long ema_k3_lp[3][12];
+extern "C" void ema_k3_prof_read(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ema_k3_lp), sizeof(ema_k3_lp)); static unsigned long long z[36]; (void)hipMemcpyToSymbol(HIP_SYMBOL(ema_k3_lp), z, sizeof(z)); }
+#endif
 #include <cstring>
 
 #define EMA_PAIR_SLAB_BYTES ((size_t)EMA_AV_CAP * (3 * sizeof(DevReg) + 8) + 2048 * 8 + 1024)
@@ -21,6 +26,7 @@
 namespace {
 
 struct PairCtx {
+	EmaLp lp;               // (make prof-lib: phase clocks, dev_prof.hpp) 0 claim, 1 the pair in, 2 anchors and "already there?", 3 window, 4 local DP forward, 5 backward, 6 insertion + dedup, 7 results out
 	const DevIndex *ix;
 	const DevOpts *opt;
 	uint8_t *rc, *rseq;     // LDS: reverse complement of the mate being rescued; reference window
@@ -82,17 +88,21 @@ __device__ inline int matesw_sw(PairCtx &cx, const DevReg &a, int l_ms, const ui
 	if (!(a.rid == rid && re - rb >= o.min_seed_len)) return SW_NONE;
 	if (re - rb > EMA_RSEQ_CAP) { st |= EMA_ST_RSEQ_OVERFLOW; return SW_NONE; }
 	const int tlen = (int)(re - rb);
+	EMA_LP_UPTO(cx.lp, 2);
 	ema_wave_fetch(ix, rb, re, cx.rseq);
+	EMA_LP_UPTO(cx.lp, 3);
 	// ksw_align2 with KSW_XSUBO | KSW_XSTART | (l_ms * a < 250 ? KSW_XBYTE : 0) | min_seed_len * a
 	const int p = l_ms * o.a < 250 ? 16 : 8;
 	const int minsc = o.min_seed_len * o.a;
 	const EmaLocalRes r1 = ema_wave_local(o, l_ms, p, EmaSeq{cx.rc, 1}, tlen, EmaSeq{cx.rseq, 1}, minsc, 0x10000, cx.bsc);
+	EMA_LP_UPTO(cx.lp, 4);
 	int qb = -1, tb = -1;
 	if (r1.score >= minsc) {      // start coordinates: the same DP on the reversed prefixes, stopping at the score
 		EmaSeq tq{cx.rc + r1.qe, -1};
 		EmaSeq tt{cx.rseq, 1, r1.te};
 		const EmaLocalRes r2 = ema_wave_local(o, r1.qe + 1, p, tq, tlen, tt, 0x10000, r1.score, cx.bsc);
 		if (r1.score == r2.score) { tb = r1.te - r2.te; qb = r1.qe - r2.qe; }
+		EMA_LP_UPTO(cx.lp, 5);
 	}
 	if (!(r1.score >= o.min_seed_len && qb >= 0)) return SW_RAN;
 	b.rid = a.rid; b.is_alt = a.is_alt;
@@ -107,6 +117,7 @@ __device__ inline int matesw_sw(PairCtx &cx, const DevReg &a, int l_ms, const ui
 __device__ inline int matesw_apply(PairCtx &cx, int what, const DevReg &b, int n_ma)
 {
 	const int lane = (int)ema_lane();
+	EMA_LP_UPTO(cx.lp, 2);
 	++cx.n_sw;
 	int n = n_ma;
 	if (what == SW_REGION) {
@@ -123,7 +134,9 @@ __device__ inline int matesw_apply(PairCtx &cx, int what, const DevReg &b, int n
 			n = n_ma + 1;
 		}
 	}
-	return ema_sort_dedup_patch(*cx.ix, *cx.opt, nullptr, n, cx.wk, cx.status);     // runs whenever the SW ran
+	const int n_out_ = ema_sort_dedup_patch(*cx.ix, *cx.opt, nullptr, n, cx.wk, cx.status);     // runs whenever the SW ran
+	EMA_LP_UPTO(cx.lp, 6);
+	return n_out_;
 }
 
 __device__ inline int matesw(PairCtx &cx, const DevReg &a, int l_ms, const uint8_t *ms, int n_ma)
@@ -245,7 +258,11 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 	if (max_rescue > EMA_PAIR_MAX_RESCUE) ph.arena = nullptr;      // (more attempts than a record has slots for: everything in place)
 
 	EmaClaim claim;      // work items four at a time, with their list entries (dev_common.hpp)
+#ifdef EMA_K34_PROF
+	cx.lp.start();
+#endif
 	for (;;) {
+		EMA_LP_UPTO(cx.lp, 7);
 		int pair = 0;
 		unsigned long long list_entry = 0;
 		if (MODE == 1) { const int n = ph.n_tasks[dirn_arg]; pair = ema_claim_next(claim, counter, n < ph.tasks_cap ? n : ph.tasks_cap, ph.tasks + (size_t)dirn_arg * ph.tasks_cap, list_entry); }
@@ -256,6 +273,7 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 			if (todo) list_entry = (unsigned long long)(unsigned)t;
 		}
 		if (pair < 0) break;
+		EMA_LP_UPTO(cx.lp, 0); EMA_LP_ITEM(cx.lp);
 		if (MODE == 1) {      // K3t: one attempt
 			const unsigned long long t = list_entry;
 			if (t == ~0ULL) continue;
@@ -268,6 +286,7 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 			for (int i = lane; i < l_ms; i += EMA_WAVE) lds_q[wib][0][i] = bases[off[in_r] + i];
 			ema_wave_sync();
 			const DevReg a = ema_uni(reinterpret_cast<const DevReg *>(rec + ema_uni(h->off_av[anchor]))[k]);
+			EMA_LP_UPTO(cx.lp, 1);
 			DevReg b;
 			memset(&b, 0, sizeof(b));
 			int st = 0;
@@ -297,6 +316,7 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 			if (!(dirn == 1 && ema_uni(h->done1))) {
 				for (int i = lane; i < n_t; i += EMA_WAVE) av[target][i] = r_target[i];
 				ema_wave_sync();
+				EMA_LP_UPTO(cx.lp, 1);
 				int num = 0;
 				for (int k = 0; k < n_anchor && num < max_rescue; ++k) {
 					const DevReg a = ema_uni(r_anchor[k]);
@@ -390,6 +410,7 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 			best[m] = ema_wave_max(b);
 		}
 		ema_wave_sync();
+		EMA_LP_UPTO(cx.lp, 1);
 		cx.status = 0;
 		if (ph.arena) {      // many attempts ahead?  then the pair is set aside (see above) -- if the lists and the arena have room
 			int cand[2];
@@ -476,6 +497,9 @@ ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_
 		ema_wave_sync();
 		EMA_DBG(9, 0);
 	}
+#ifdef EMA_K34_PROF
+	EMA_LP_FLUSH(cx.lp, &ema_k3_lp[MODE][0]);
+#endif
 #undef EMA_DBG
 }
 

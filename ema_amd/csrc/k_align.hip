@@ -575,15 +575,28 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		// ---------------- mem_chain: frac_rep, seed occurrences, chaining ----------------
 		int l_rep = 0;
 		{
+			// (64 intervals at a time, one per lane: the occurrence total is a wave sum, and the merge of the repetitive intervals'
+			// query spans -- the only part that is sequential -- walks the few lanes that hold one.  As a loop over the intervals every
+			// iteration waited for its own load from the slab.)
 			int b = 0, e = 0;
 			int64_t tot_occ = 0;      // seed occurrences the chaining loop below will look up
-			for (int i = 0; i < n_iv; ++i) {
-				const Intv p = iv[i];
-				const int sb = (int)(p.info >> 32), se = (int)(uint32_t)p.info;
-				tot_occ += p.x2 <= (uint64_t)opt.max_occ ? (int64_t)p.x2 : (int64_t)opt.max_occ;
-				if (p.x2 <= (uint64_t)opt.max_occ) continue;
-				if (sb > e) { l_rep += e - b; b = sb; e = se; }
-				else e = e > se ? e : se;
+			for (int base = 0; base < n_iv; base += EMA_WAVE) {
+				const int i = base + lane;
+				int occ = 0, sb_v = 0, se_v = 0;
+				bool rep = false;
+				if (i < n_iv) {
+					const Intv p = iv[i];
+					sb_v = (int)(p.info >> 32); se_v = (int)(uint32_t)p.info;
+					rep = p.x2 > (uint64_t)opt.max_occ;
+					occ = rep ? opt.max_occ : (int)p.x2;
+				}
+				tot_occ += ema_wave_sum(occ);
+				for (unsigned long long todo_ = __ballot(rep); todo_; todo_ &= todo_ - 1) {
+					const int l = __ffsll((long long)todo_) - 1;
+					const int sb = ema_lane_val(sb_v, l), se = ema_lane_val(se_v, l);
+					if (sb > e) { l_rep += e - b; b = sb; e = se; }
+					else e = e > se ? e : se;
+				}
 			}
 			l_rep += e - b;
 			cb.sl = slab;

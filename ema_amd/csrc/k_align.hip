@@ -236,14 +236,23 @@ __device__ inline bool chain_insert_med(const DevOpts &o, int64_t l_pac, ChainBu
 	const int lane = (int)ema_lane();
 	const bool leader = lane == 0;
 	int at = 0, lower = -1;
+	int64_t pos = 0;
 	if (cb.n_chain) {
+		// the two table entries around the insertion point in ONE LDS round trip (lane 0: entry lo, lane 1: entry lo - 1), not a
+		// dependent read for each of position, id, and position again
 		const int lo = med_lower_bound(mt.cpos, cb.n_chain, rbeg);
-		if (lo < cb.n_chain && ema_uni((int64_t)mt.cpos[lo]) == rbeg) { lower = ema_uni((int)mt.cord[lo]); at = lo + 1; }
-		else if (lo > 0) { lower = ema_uni((int)mt.cord[lo - 1]); at = lo; }
+		const int mine = lo - lane;      // lanes 0 and 1
+		int64_t p2 = 0; int id2 = -1;
+		if (lane < 2 && mine >= 0 && mine < cb.n_chain) { p2 = mt.cpos[mine]; id2 = mt.cord[mine]; }
+		const int64_t p_lo = ema_lane_val(p2, 0), p_lm = ema_lane_val(p2, 1);
+		const int id_lo = ema_lane_val(id2, 0), id_lm = ema_lane_val(id2, 1);
+		if (lo < cb.n_chain && p_lo == rbeg) { lower = id_lo; at = lo + 1; pos = p_lo; }
+		else if (lo > 0) { lower = id_lm; at = lo; pos = p_lm; }
 	}
 	if (lower >= 0) {   // test_and_merge
-		const int64_t pos = ema_uni((int64_t)mt.cpos[at - 1]);
-		const uint32_t m0 = (uint32_t)ema_uni((int)mt.csm[3 * lower]), m1 = (uint32_t)ema_uni((int)mt.csm[3 * lower + 1]), m2 = (uint32_t)ema_uni((int)mt.csm[3 * lower + 2]);
+		uint32_t mv = 0;      // the chain's three summary words, one per lane
+		if (lane < 3) mv = mt.csm[3 * lower + lane];
+		const uint32_t m0 = (uint32_t)ema_lane_val((int)mv, 0), m1 = (uint32_t)ema_lane_val((int)mv, 1), m2 = (uint32_t)ema_lane_val((int)mv, 2);
 		const int l_delta = (int)m0, c_rid = (int)(m1 & 0xffff), last_seed = (int)(m1 >> 16);
 		const int f_qbeg = (int)(m2 & 0xff), l_qbeg = (int)(m2 >> 8 & 0xff), l_len = (int)(m2 >> 16 & 0xff);
 		const int64_t f_rbeg = pos, l_rbeg = pos + l_delta;

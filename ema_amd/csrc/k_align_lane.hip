@@ -250,8 +250,11 @@ __device__ inline int lane_sort_dedup(const DevIndex &ix, const DevOpts &o, int 
 // One lane = one read; a wave takes 64 consecutive reads at a time from the shared counter.
 // todo / n_todo: reads left for K2b's full path (too many seed occurrences for a lane); hand / n_hand: the reads given up at the
 // extension, with their chains (both counters zero on entry).  scratch: EMA_LANE_WAVE_BYTES per resident wave.
+#ifndef EMA_K2A_MIN_BLOCKS
+#define EMA_K2A_MIN_BLOCKS 4      // resident 256-thread blocks per CU the register allocation must allow: 126 registers and 12 spilled instead of 162 -- beside K1 and K2b (128 each) a SIMD then holds four waves of any mix, not three (r03at: the steady state 178 -> 173 ms per step)
+#endif
 template <bool PROF>      // PROF: the diagnostic build (phase clocks); the product build carries none of its registers
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, EMA_K2A_MIN_BLOCKS)
 ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
                    const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const Intv *__restrict__ intv,
                    const int *__restrict__ n_intv, DevReg *__restrict__ regs, int *__restrict__ n_regs, int *__restrict__ status,

@@ -160,10 +160,13 @@ struct FinalHeavy {
 };
 struct FinalRes { DevAln aln; int32_t st, n_final; unsigned long long ops_at; int64_t pad_; };      // 48 bytes
 
+#ifndef EMA_K4_MIN_BLOCKS
+#define EMA_K4_MIN_BLOCKS 4      // K4b fits 128 registers without a spill (143 when left alone)
+#endif
 // K4b: the regions K4a left (one wavefront per read of its todo list).  MODE 0: that; 1: K4t; 2: K4r (above).
 // alns: n_reads x opt.reg_cap; cigars: n_reads x cig_cap ops (pool per read, regions in order)
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MODE == 1 ? 1 : EMA_K4_MIN_BLOCKS)      // (K4t's 64 KB of LDS allow two blocks per CU whatever its registers)
 ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,

@@ -226,10 +226,13 @@ struct PairHdr {                       // head of a record; arrays at the offset
 	uint64_t off_av[2], off_res, bytes;
 };
 
+#ifndef EMA_K3_MIN_BLOCKS
+#define EMA_K3_MIN_BLOCKS 1      // (4 costs K3b 40 spilled registers and changed nothing, r03at)
+#endif
 // K3b: the pairs K3a listed.  MODE 0: that; 1: K3t; 2: K3r (above), dirn_arg = the direction it handles.
 // regs/n_regs: K2's output, updated in place.  One wave per pair, pairs taken from a shared counter.
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, EMA_K3_MIN_BLOCKS)
 ema_k_pair_t(DevIndex ix, DevOpts opt, int score_delta, int max_rescue, int pes_low, int pes_high,
            const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_pairs,
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, DevReg *__restrict__ regs,

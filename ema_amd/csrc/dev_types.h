@@ -50,6 +50,11 @@ struct DevIndex {
 	// in the high bits).  Levels 1..EMA_KMER_WIDE: {u64 start, u64 size}; above: one u64, start in bits 0..39, size in 40..63.
 	const uint64_t *kmer_wide;    // levels 1..EMA_KMER_WIDE, level L at entry offset (4^L - 4) / 3
 	const uint64_t *kmer_narrow;  // levels EMA_KMER_WIDE+1..kmer_k, level L at offset (4^L - 4^(EMA_KMER_WIDE+1)) / 3
+	// The text the FM-index is built on -- forward strand, then its reverse complement: 2 * l_pac bases -- as 2-bit codes in the
+	// order K1 keeps its reads in (base j at bits 2(j%32) of word j/32), followed by at least 8 zero words.  K1 follows a match
+	// that has a single occurrence left along this text (one suffix-array row + one 64-byte load for up to 224 bases) instead
+	// of through two rank gathers per base (k_seed.hip, "tails").  Null: no tails (then K1 works on the rank structure alone).
+	const uint64_t *text2;
 };
 #define EMA_KMER_WIDE 9
 #define EMA_KMER_MAX 15

@@ -45,6 +45,8 @@ extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, con
                                      int n_blocks, hipStream_t stream);
 
 extern "C" void ema_launch_kmer_level(const DevIndex *ix, int L, uint64_t *wide, uint64_t *narrow, int *overflow, hipStream_t stream);
+extern "C" size_t ema_text2_words(int64_t l_pac);
+extern "C" void ema_launch_text2(const uint8_t *pac, int64_t l_pac, uint64_t *text2, hipStream_t stream);
 extern "C" size_t ema_align_slab_bytes();
 extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const uint32_t *off,
                                  int n_reads, const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv,
@@ -241,6 +243,7 @@ struct ema_engine {
 	DevBuf<OccBlock> d_occ;
 	DevBuf<uint8_t> d_sa, d_pac;
 	DevBuf<uint64_t> d_kmer_wide, d_kmer_narrow;      // k-mer interval table (dev_types.h), built when the engine opens
+	DevBuf<uint64_t> d_text2;                         // both strands as 2-bit codes for K1's tails (dev_types.h), built when the engine opens
 	DevBuf<int64_t> d_ctg;
 	DevBuf<uint8_t> d_ctg_alt;
 	DevBuf<int32_t> d_ctg_tab;
@@ -498,6 +501,17 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 			} else e->dix.kmer_k = k;
 		}
 	}
+	e->dix.text2 = nullptr;
+	{   // K1's tails read the text itself (DevIndex::text2; needs the table mode); EMA_SEED_TAIL=0: rank queries to the last base
+		const char *v = getenv("EMA_SEED_TAIL");
+		if (e->dix.kmer_k > 0 && (!v || atoi(v) != 0)) {
+			HIPCHK(e, e->d_text2.alloc(ema_text2_words(e->l_pac)));
+			ema_launch_text2(e->d_pac.p, e->l_pac, e->d_text2.p, nullptr);
+			HIPCHK(e, hipGetLastError());
+			HIPCHK(e, hipDeviceSynchronize());
+			e->dix.text2 = e->d_text2.p;
+		}
+	}
 	}
 
 	if (getenv("EMA_PHASE_PROFILE") && atoi(getenv("EMA_PHASE_PROFILE")) == 3) {
@@ -598,7 +612,7 @@ void ema_engine_close(ema_engine_t *e)
 	e->d_k1w_args.release();
 	e->h_nt4.release(); e->h_off.release();
 	for (auto &fp : e->fetch_pin) { fp.c_off.release(); fp.g_off.release(); fp.status.release(); fp.cand.release(); fp.cig.release(); }
-	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_ctg_tab.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_prof.release(); e->d_rlog.release(); if (e->d_lprof.p) { ema_align_set_light_profile(nullptr); e->d_lprof.release(); }
+	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_ctg_tab.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_text2.release(); e->d_prof.release(); e->d_rlog.release(); if (e->d_lprof.p) { ema_align_set_light_profile(nullptr); e->d_lprof.release(); }
 	for (auto &in : e->in) { in.d_bases.release(); in.d_off.release(); in.d_qpack.release(); }
 	e->d_redo.release(); e->d_redo_run.release();
 	e->full.release();

@@ -53,6 +53,7 @@ DevIndex HostIndex::view() const
 	d.n_seqs = (int32_t)contigs.size();
 	d.sa_width = sa_width;
 	d.n_super = n_super; d.kmer_k = kmer_k; d.kmer_wide = kmer_wide.empty() ? nullptr : kmer_wide.data(); d.kmer_narrow = kmer_narrow.empty() ? nullptr : kmer_narrow.data();
+	d.text2 = text2.empty() ? nullptr : text2.data();
 	memcpy(d.occ_super, occ_super, sizeof(occ_super));
 	return d;
 }

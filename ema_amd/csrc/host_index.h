@@ -31,6 +31,7 @@ struct HostIndex {
 	// own on the device)
 	std::vector<uint64_t> kmer_wide, kmer_narrow;
 	int kmer_k = 0;
+	std::vector<uint64_t> text2;     // DevIndex::text2, when a host copy exists (the SIMT harness)
 	// Fills a DevIndex whose pointers refer to THIS object's host buffers
 	// (used by the host-side SIMT harness in tests/; the engine overwrites the
 	// pointers with device addresses after upload).

@@ -39,3 +39,29 @@ extern "C" void ema_launch_kmer_level(const DevIndex *ix, int L, uint64_t *wide,
 	const size_t n_prev = L == 1 ? 1 : (size_t)1 << (2 * (L - 1));
 	hipLaunchKernelGGL(ema_k_kmer_level, dim3((unsigned)((n_prev + 255) / 256)), dim3(256), 0, stream, *ix, L, wide, narrow, overflow);
 }
+
+// DevIndex::text2: the indexed text (forward strand + reverse complement, 2 * l_pac bases) as 2-bit codes, 32 to a word, base j
+// at bits 2(j%32) of word j/32; words beyond the text are zero.  One lane per word.
+__global__ void __launch_bounds__(256)
+ema_k_text2(const uint8_t *__restrict__ pac, int64_t l_pac, uint64_t *__restrict__ text2, size_t n_words)
+{
+	const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_words) return;
+	uint64_t v = 0;
+	for (int t = 0; t < 32; ++t) {
+		const int64_t j = (int64_t)(w << 5) + t;
+		if (j >= 2 * l_pac) break;
+		const int64_t f = j < l_pac ? j : 2 * l_pac - 1 - j;
+		unsigned b = (pac[f >> 2] >> ((~f & 3) << 1)) & 3u;
+		if (j >= l_pac) b = 3u - b;
+		v |= (uint64_t)b << (t << 1);
+	}
+	text2[w] = v;
+}
+
+extern "C" size_t ema_text2_words(int64_t l_pac) { return (size_t)((2 * l_pac + 31) >> 5) + 8; }
+extern "C" void ema_launch_text2(const uint8_t *pac, int64_t l_pac, uint64_t *text2, hipStream_t stream)
+{
+	const size_t n = ema_text2_words(l_pac);
+	hipLaunchKernelGGL(ema_k_text2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pac, l_pac, text2, n);
+}

@@ -46,6 +46,19 @@
 // nothing downstream reads: mem_chain uses k, size, start, end); k' itself is fetched from the table once, when a forward
 // extension leaves the table's range and the next step needs it for its rank query.  Emitted intervals carry k' = 0 in this
 // mode (the exact-k' build of this kernel is kmer_k = 0).
+//
+// Tails (DevIndex.text2 != null; needs the table mode).  Once a forward extension of pass 1 is down to ONE occurrence and past the
+// table's range, every further base costs bwt_smem1 a rank query whose only possible outcomes are "still that occurrence" and
+// "none" -- a hundred dependent pairs of gathers for the usual read, whose first SMEM runs to the first mismatch or to the end.
+// The machine instead asks for the occurrence's suffix-array row (one tick), then for the text behind it (DevIndex.text2: both
+// strands as 2-bit codes in the read's own packing; one tick, 64 bytes = up to 224 bases), and compares 32 bases per step with
+// the read in LDS: the forward phase ends where the first difference, the read's end, an ambiguous base or the text's end is,
+// exactly where the rank queries would have ended it (a forward extension of a one-row interval keeps k; k' is never read
+// again: backward extensions pass it through, and in table mode it is not emitted).  15 % of all ticks, a quarter of the
+// gathers that miss the caches.
+// Pass 3 jumps (table mode): bwt_seed_strategy1 tests nothing before its match is min_seed_len + 1 bases long, so its first
+// min(kmer_k, min_seed_len) bases are ONE table look-up instead of that many dependent ones, a start too close to the read's
+// end for a seed to fit ends the pass, and an ambiguous base inside the first bases moves the start behind it without a look-up.
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
 
@@ -53,7 +66,8 @@ namespace {
 
 // states; the three that wait for an extend have their "result arrived" twin at +1
 enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, PC_BWD_N,
-       PC_FWD = 8, PC_FWD_RES, PC_BWD, PC_BWD_RES, PC_S3, PC_S3_RES };
+       PC_FWD = 8, PC_FWD_RES, PC_BWD, PC_BWD_RES, PC_S3, PC_S3_RES,
+       PC_TSA_RES, PC_TXT, PC_TXT_RES };      // a tail (below): suffix-array row requested / text to request / text requested
 
 // A machine taken off its lane (see "re-packing" below): everything phase B and the next step need.  The working
 // lists stay where they are -- `wl` is the address of the lane's list slab -- and the read is re-staged from qpack.
@@ -76,6 +90,17 @@ struct SeedPark {
 	uint32_t c_end, f_end;
 	uint32_t c_code, f_code, req_code, req_len;      // k-mer table mode (DevIndex.kmer_k > 0)
 };
+
+// bits [s, s + 64) of hi:lo, 0 <= s < 64
+__device__ __forceinline__ uint64_t seed_funnel(uint64_t lo, uint64_t hi, int s) { return s ? (lo >> s) | (hi << (64 - s)) : lo; }
+// the order of the 16 two-bit groups of v reversed
+__device__ __forceinline__ uint32_t seed_rev_groups(uint32_t v)
+{
+	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+	v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+	return (v >> 16) | (v << 16);
+}
 
 }  // namespace
 
@@ -130,6 +155,9 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	int req_c = 0, ld_kind = 0;      // ld_kind: 1 = next list entry of the backward row, 2 = out[k2 - 1] for pass 2
 	size_t ld_at = 0;
 	const int kk = ix.kmer_k;        // 0: no table
+	const bool tails = kk > 0 && ix.text2 != nullptr;
+	const int jump = kk > 0 && opt.max_mem_intv > 0 ? (kk < opt.min_seed_len ? kk : opt.min_seed_len) : 0;      // pass 3's first look-up
+	const uint64_t n_text = (uint64_t)ix.l_pac << 1;
 	uint32_t c_code = 0, f_code = 0, r_code = 0, req_code = 0, req_len = 0;      // 2-bit codes of the strings behind c, f, r
 
 	auto q = [&](int p_) -> int {
@@ -206,6 +234,14 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				else { sm_x = (s + e) >> 1; min_intv = (int)ent.x2 + 1; start = true; }
 				break;
 			}
+			case PC_TSA_RES:      // tail: the occurrence's place in the text is known (f0 = the text position of read base i)
+				pc = PC_TXT;
+				break;
+			case PC_TXT_RES:      // tail: r2 bases agreed; r0 != 0: and the match ends there -- then what PC_FWD_STOP does
+				i += (int)r2; f0 += r2;
+				if (r0) { c_end = (uint32_t)i; ev = 1; v0 = c0; v1 = c_code; v2 = c2; v_end = c_end; aft = true; }
+				else pc = PC_TXT;
+				break;
 			default:
 				break;
 			}
@@ -296,6 +332,20 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			case PC_P3_NEXT:      // pass 3: LAST-like seeds
 				while (x < len && q(x) > 3) ++x;
 				if (x >= len) { pc = PC_DONE; break; }
+				if (jump > 0) {      // the first `jump` bases in one look-up (see the header)
+					if (len - x <= opt.min_seed_len) { x = len; pc = PC_DONE; break; }      // no seed fits any more
+					const int wn = x >> 5, wq = x >> 4;
+					const uint64_t nn = (uint64_t)(wn < 7 ? nm[(wn + 1) << 6] : 0u) << 32 | nm[wn << 6];
+					const uint32_t nbits = (uint32_t)(nn >> (x & 31)) & ((1u << jump) - 1u);
+					if (nbits) { x += __ffs(nbits); break; }      // an ambiguous base ends the attempt; the next one starts behind it
+					if (++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; break; }
+					const uint64_t qq = (uint64_t)(wq < 15 ? qw[(wq + 1) << 6] : 0u) << 32 | qw[wq << 6];
+					req_code = seed_rev_groups((uint32_t)(qq >> ((x & 15) << 1))) >> (32 - 2 * jump);
+					req_len = (uint32_t)jump; req_c = 0; has_req = 2;
+					i = x + jump - 1;
+					pc = PC_S3_RES;
+					break;
+				}
 				{
 					const int b = q(x);
 					c0 = ix.L2[b] + 1; c2 = ix.L2[b + 1] - ix.L2[b]; c1 = ix.L2[3 - b] + 1; c_code = (uint32_t)b;
@@ -320,9 +370,11 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				pc = PC_FWD;
 			}
 			// (7) the one place that looks up the next base and posts the extend
-			if (pc == PC_FWD || pc == PC_BWD || pc == PC_S3) {
+			if (pc == PC_TXT) { has_req = 4; pc = PC_TXT_RES; }
+			else if (pc == PC_FWD || pc == PC_BWD || pc == PC_S3) {
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
 				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
+				else if (b < 4 && tails && pc == PC_FWD && c2 == 1 && i - sm_x > kk) { has_req = 3; pc = PC_TSA_RES; }      // a tail begins
 				else if (b < 4) {
 					has_req = 1;
 					if (pc == PC_BWD) {
@@ -388,25 +440,68 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			const uint64_t pk = x_nb - 1, pl = x_nb - 1 + c2;                    // rows whose occ4 the extend needs
 			const uint64_t qk = pk - (pk >= ix.primary ? 1 : 0), ql = pl - (pl >= ix.primary ? 1 : 0);      // '$' is not stored
 			const bool want_rc = tab && (int)req_len == kk && !back;
-			const uint4 *pa, *pb;
-			if (tab) {
+			const uint4 *p0, *p1, *p2, *p3;      // the tick's four 16-byte loads
+			if (has_req == 3) {      // tail: the suffix-array row of the one occurrence (the aligned 16 bytes that hold it)
+				p0 = reinterpret_cast<const uint4 *>((reinterpret_cast<uintptr_t>(ix.sa) + c0 * (uint64_t)ix.sa_width) & ~(uintptr_t)15);
+				p1 = p2 = p3 = p0;
+			} else if (has_req == 4) {      // tail: 8 words of text from the word that holds position f0
+				p0 = reinterpret_cast<const uint4 *>(ix.text2 + (f0 >> 5));
+				p1 = p0 + 1; p2 = p0 + 2; p3 = p0 + 3;
+			} else if (tab) {
 				const int L = (int)req_len;
 				const uint32_t rcode = want_rc ? ema_kmer_revcomp(req_code, kk) : req_code;
 				if (L <= EMA_KMER_WIDE) {
 					const size_t base = (((size_t)1 << (2 * L)) - 4) / 3;
-					pa = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + req_code));
-					pb = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + rcode));
+					p0 = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + req_code));
+					p2 = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + rcode));
 				} else {
 					const size_t base = (((size_t)1 << (2 * L)) - ((size_t)1 << (2 * (EMA_KMER_WIDE + 1)))) / 3;
-					pa = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + req_code);
-					pb = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + rcode);
+					p0 = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + req_code);
+					p2 = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + rcode);
 				}
+				p1 = p0; p3 = p2;      // an entry is 16 or 8 bytes: the second halves repeat the first (no second cache line touched)
 			} else {
-				pa = reinterpret_cast<const uint4 *>(ix.occ + (qk >> 6));
-				pb = reinterpret_cast<const uint4 *>(ix.occ + (ql >> 6));
+				p0 = reinterpret_cast<const uint4 *>(ix.occ + (qk >> 6));
+				p2 = reinterpret_cast<const uint4 *>(ix.occ + (ql >> 6));
+				p1 = p0 + 1; p3 = p2 + 1;
 			}
-			const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
-			if (tab) {
+			const uint4 a0 = *p0, a1 = *p1, b0 = *p2, b1 = *p3;
+			if (has_req == 3) {
+				const unsigned o = (unsigned)((reinterpret_cast<uintptr_t>(ix.sa) + c0 * (uint64_t)ix.sa_width) & 15);
+				uint64_t pos;
+				if (ix.sa_width == 4) pos = o == 0 ? a0.x : o == 4 ? a0.y : o == 8 ? a0.z : a0.w;
+				else pos = o == 0 ? ((uint64_t)a0.y << 32 | a0.x) : ((uint64_t)a0.w << 32 | a0.z);
+				f0 = pos + (uint64_t)(i - sm_x);
+			} else if (has_req == 4) {
+				// read base i stands against text position f0: count the bases that agree, 32 per step, up to the first difference,
+				// the read's end, its next ambiguous base (stored as code 0: cut by the mask) or the text's end
+				const uint64_t T[8] = {(uint64_t)a0.y << 32 | a0.x, (uint64_t)a0.w << 32 | a0.z, (uint64_t)a1.y << 32 | a1.x, (uint64_t)a1.w << 32 | a1.z,
+				                       (uint64_t)b0.y << 32 | b0.x, (uint64_t)b0.w << 32 | b0.z, (uint64_t)b1.y << 32 | b1.x, (uint64_t)b1.w << 32 | b1.z};
+				const int st_ = (int)(f0 & 31) << 1, sq = (i & 31) << 1, sn = i & 31, w0 = i >> 5;
+				int lim = len - i;
+				if (f0 >= n_text) lim = 0;
+				else if (n_text - f0 < (uint64_t)lim) lim = (int)(n_text - f0);
+				int total = 0;
+				bool stopped = false;
+#pragma unroll
+				for (int c = 0; c < 7; ++c) {
+					if (!stopped && total < lim) {
+						const int w = w0 + c;
+						const uint64_t q_lo = w < 8 ? ((uint64_t)qw[(2 * w + 1) << 6] << 32 | qw[(2 * w) << 6]) : 0;
+						const uint64_t q_hi = w < 7 ? ((uint64_t)qw[(2 * w + 3) << 6] << 32 | qw[(2 * w + 2) << 6]) : 0;
+						const uint64_t n_w = (uint64_t)(w < 7 ? nm[(w + 1) << 6] : 0u) << 32 | (w < 8 ? nm[w << 6] : 0u);
+						uint64_t d = seed_funnel(T[c], T[c + 1], st_) ^ seed_funnel(q_lo, q_hi, sq);
+						d = (d | d >> 1) & 0x5555555555555555ULL;
+						const uint32_t nb = (uint32_t)(n_w >> sn);
+						const int m_d = d ? (__ffsll((unsigned long long)d) - 1) >> 1 : 32, m_n = nb ? __ffs(nb) - 1 : 32;
+						const int m = m_d < m_n ? m_d : m_n;
+						total += m;
+						stopped = m < 32;
+					}
+				}
+				if (total >= lim) { total = lim; stopped = true; }
+				r2 = (uint64_t)total; r0 = stopped ? 1 : 0;
+			} else if (tab) {
 				uint64_t ea = (uint64_t)a0.y << 32 | a0.x, eb = (uint64_t)b0.y << 32 | b0.x;
 				if ((int)req_len <= EMA_KMER_WIDE) { r0 = ea; r2 = (uint64_t)a0.w << 32 | a0.z; r1 = want_rc ? eb : 0; }
 				else { r0 = ea & 0xFFFFFFFFFFULL; r2 = ea >> 40; r1 = want_rc ? (eb & 0xFFFFFFFFFFULL) : 0; }

@@ -103,3 +103,45 @@ def golden_workload():
         pairs = synth.Pairs(np.frombuffer(b"".join(reads), dtype=np.uint8), off)
         _CACHE["golden"] = (prefix, pairs, doc["intervals"], doc["candidates"])
     return _CACHE["golden"]
+
+
+def text_edge_pairs(ctg, seed=41):
+    """Reads whose long single-occurrence matches run into the places where K1's text tails (k_seed.hip) must stop as the rank
+    queries do: across the junction of the forward strand and its reverse complement, into the end of the text, into an
+    ambiguous base, past 224 bases (more than one load of text), at the read's end; and starting in every word phase.
+    Returns synth.Pairs (an even number of reads of assorted lengths, paired up arbitrarily)."""
+    rng = np.random.default_rng(seed)
+    g = np.concatenate(ctg)
+    g = np.where(g > 3, 0, g).astype(np.uint8)      # as the index stores ambiguous reference bases (any base will do here)
+    text = np.concatenate([g, (3 - g)[::-1]])
+    n_text = len(text)
+    reads = []
+
+    def take(at, n):
+        return text[at:at + n].copy()
+
+    for d in range(0, 40):      # across the strand junction, every phase
+        reads.append(take(len(g) - 100 - d, 180))
+    for d in range(0, 40):      # up to the text's end, then bases that cannot match
+        r = take(n_text - 90 - d, 90 + d)
+        reads.append(np.concatenate([r, rng.integers(0, 4, 40, dtype=np.uint8)]))
+    for d in range(0, 34):      # exact reads of every length class around one and two loads of text
+        reads.append(take(5000 + 37 * d, 200 + d))
+        reads.append(take(9000 + 41 * d, 255 - d))
+    for d in range(0, 34):      # an ambiguous base right behind / inside a long match
+        r = take(20000 + 53 * d, 150)
+        r[60 + d] = 4
+        reads.append(r)
+        r = take(30000 + 59 * d, 150)
+        r[149 - (d % 8)] = 4
+        reads.append(r)
+    for d in range(0, 34):      # one mismatch at every word phase
+        r = take(40000 + 61 * d, 150)
+        r[70 + d] = (r[70 + d] + 1) & 3
+        reads.append(r)
+    if len(reads) & 1:
+        reads.append(take(50000, 100))
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    off = np.zeros(len(reads) + 1, np.uint32)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    return synth.Pairs(lut[np.concatenate(reads)], off)

@@ -106,6 +106,11 @@ void *emu_index_load(const char *prefix, char *err, int errlen)
 			}
 			if (overflow) { snprintf(err, errlen, "k-mer table overflow"); delete ix; return nullptr; }
 			ix->kmer_k = k;
+			const char *t = getenv("EMU_SEED_TAIL");
+			if (!t || atoi(t) != 0) {      // the 2-bit text K1's tails read, by the device kernel under the interpreter
+				ix->text2.assign(ema_text2_words(ix->l_pac), 0);
+				ema_launch_text2(ix->pac.data(), ix->l_pac, ix->text2.data(), nullptr);
+			}
 		}
 	}
 	return ix;

@@ -12,10 +12,11 @@ from ema_amd.engine import Engine
 pytestmark = pytest.mark.gpu
 
 
-def _check(kind, n_pairs, seed, kernel, monkeypatch, **kw):
+def _check(kind, n_pairs, seed, kernel, monkeypatch, pairs=None, **kw):
     monkeypatch.setenv("EMA_FULL_SEED_LANE", "1" if kernel == "lane" else "0")
     prefix, ctg = small_ref(kind)
-    pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
+    if pairs is None:
+        pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
     eng = Engine(prefix)
     table = eng.index_info()["kmer_k"] > 0 and kernel == "lane"      # K1 with the k-mer interval table: k' is not produced (0)
     eng.stage(pairs.bases, pairs.off)
@@ -62,6 +63,29 @@ def test_seed_parity_kmer_table_depths(k, monkeypatch):
     part of the table although the test genome would get 8 by itself) and without parking rounds left out."""
     monkeypatch.setenv("EMA_KMER_K", str(k))
     _check("repeats", 500, 25, "lane", monkeypatch, sub_rate=0.02, n_rate=0.003)
+
+
+@pytest.mark.parametrize("tail", ["1", "0"])
+@pytest.mark.parametrize("k", ["", "5", "11"])
+@pytest.mark.parametrize("kind", ["two_contigs", "ngaps"])
+def test_seed_parity_text_tails_at_their_edges(kind, k, tail, monkeypatch):
+    """K1's text tails (a single-occurrence match followed along the 2-bit text instead of through rank queries) and pass 3's
+    jump, where they must stop exactly as the rank queries do: across the strand junction, at the text's end, at an ambiguous
+    base, at the read's end, beyond one load of text, in every word phase (tests/common.py, text_edge_pairs) -- with the tails
+    on and off (EMA_SEED_TAIL) and at several table depths."""
+    from common import text_edge_pairs
+    monkeypatch.setenv("EMA_SEED_TAIL", tail)
+    if k:
+        monkeypatch.setenv("EMA_KMER_K", k)
+    _prefix, ctg = small_ref(kind)
+    _check(kind, 0, 0, "lane", monkeypatch, pairs=text_edge_pairs(ctg))
+
+
+@pytest.mark.parametrize("tail", ["1", "0"])
+def test_seed_parity_tails_on_and_off(tail, monkeypatch):
+    monkeypatch.setenv("EMA_SEED_TAIL", tail)
+    _check("repeats", 600, 27, "lane", monkeypatch, sub_rate=0.01, n_rate=0.002)
+    _check("two_contigs", 300, 28, "lane", monkeypatch, len1=250, len2=250, sub_rate=0.002)
 
 
 def test_pipeline_with_and_without_the_table(monkeypatch):

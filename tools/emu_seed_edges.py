@@ -1,0 +1,29 @@
+"""Dev aid (no GPU): K1's text tails and pass-3 jumps at their edges (tests/common.py, text_edge_pairs) through the host SIMT
+interpreter vs the oracle's mem_collect_intv.   EMU_KMER_K=5 python tools/emu_seed_edges.py"""
+import os, sys
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import common, emu_lib, oracle_lib as O
+tot_bad = 0
+for kind in ("two_contigs", "ngaps"):
+    prefix, ctg = common.small_ref(kind)
+    pairs = common.text_edge_pairs(ctg)
+    nt4 = np.array([{65: 0, 67: 1, 71: 2, 84: 3}.get(c, 4) for c in pairs.bases], dtype=np.uint8)
+    off = pairs.off.astype(np.uint32)
+    h = emu_lib.index_load(prefix)
+    intv, n_intv, status = emu_lib.seed(h, nt4, off, n_blocks=1)
+    idx, opt = O.Index(prefix), O.default_opt()
+    bad = 0
+    for r in range(len(off) - 1):
+        ref = O.collect_intv(idx, opt, pairs.read(r))
+        got = [(int(a[3]) >> 32, int(a[3]) & 0xffffffff, int(a[0]), int(a[1]), int(a[2])) for a in intv[r, :n_intv[r]]]
+        exp = [tuple(int(t) for t in d) for d in ref]
+        if os.environ.get("EMU_KMER_K", "0") != "0":
+            exp = [(d[0], d[1], d[2], 0, d[4]) for d in exp]
+        if got != exp:
+            bad += 1
+            if bad < 4: print(kind, r, len(pairs.read(r)), got[:4], exp[:4])
+    print(kind, "reads", len(off) - 1, "mismatching", bad, "status", np.unique(status))
+    tot_bad += bad
+sys.exit(1 if tot_bad else 0)

@@ -340,6 +340,8 @@ def main(argv=None):
     ap.add_argument("--lean-seed-extends", type=int, default=0, help="engine option lean_seed_extends (0 = engine default)")
     ap.add_argument("--two-sets", action="store_true", help="the older schedule: alternate batches on two sets of batch buffers, one pass each "
                                                             "(default: one set, passes queued up to three deep with the layout and packing on the device)")
+    ap.add_argument("--spot-check", type=int, default=24000, help="regular pairs of the timed steps re-aligned by the oracle afterwards (besides "
+                                                                  "every pair the full-capacity tier redid in two of the steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / engine_resident / isolated passes (profiling runs)")
     ap.add_argument("--no-sam-leg", action="store_true", help="skip the bucket files -> SAM text leg (A/B runs of engine knobs)")
@@ -476,27 +478,26 @@ def main(argv=None):
             dist.barrier()
 
     # parity spot check inside the run: candidates of sampled pairs of EVERY timed step -- regular ones and pairs that went
-    # through the full-capacity tier -- are kept by the sink and compared with the oracle afterwards; a mismatch is fatal
+    # through the full-capacity tier -- are copied by the sink (vectorised: ema_amd.engine.gather_pairs) and compared with the
+    # oracle afterwards, digest against digest (oracle/pair.c, orc_digest_pairs, on all granted threads); a mismatch is fatal.
+    # Two of the timed steps are checked in depth: EVERY pair the full-capacity tier redid and thousands of regular ones.
     rng = np.random.default_rng(12345 + rank)
-    kept = {}
+    kept = []
+    deep_steps = {0, 1} if args.steps >= 2 else {0}
+    deep_regular = max(24, args.spot_check // (2 * len(deep_steps)))
 
     def keep_sample(k, pb, n_reg, n_full):
         ob = pb.contents
         n = int(ob.n_pairs)
-        ids = set(int(x) for x in rng.integers(0, n, n_reg))
         nr = int(ob.n_redone)
-        if nr:
-            ids |= set(int(ob.redone[int(i)]) for i in rng.integers(0, nr, min(n_full, nr)))
-        for p in ids:
-            per = []
-            for m in range(2):
-                lo, hi = int(ob.cand_off[2 * p + m]), int(ob.cand_off[2 * p + m + 1])
-                rows = []
-                for i in range(lo, hi):
-                    c = ob.cand[i]
-                    rows.append((c.rb, c.re, c.qb, c.qe, c.score, c.pos, c.NM, [int(ob.cigar[c.cigar_off + j]) for j in range(c.n_cigar)]))
-                per.append(rows)
-            kept[(k % n_batches, p)] = per
+        redone = np.ctypeslib.as_array(ob.redone, shape=(max(nr, 1),))[:nr].astype(np.int64)
+        if k in deep_steps:
+            n_reg, pick = deep_regular, redone
+        else:
+            pick = redone[rng.integers(0, nr, min(n_full, nr))] if nr else redone
+        ids = np.unique(np.concatenate([rng.integers(0, n, min(n_reg, n)), pick]))
+        cand, pool, read_off = engine_mod.gather_pairs(ob, ids)
+        kept.append((k % n_batches, ids, cand, pool, read_off, len(np.intersect1d(ids, redone))))
 
     tallies = {"flags": 0}
 
@@ -597,16 +598,21 @@ def main(argv=None):
         import oracle_lib as O
         idx, opt = O.Index(prefix), O.default_opt()
         t = time.time()
-        for (b, p), per in sorted(kept.items()):
-            pr = batches[b]
-            ref = O.align_pair(idx, opt, pr.read(2 * p), pr.read(2 * p + 1))
-            for m in range(2):
-                exp = [(d["rb"], d["re"], d["qb"], d["qe"], d["score"], d["pos"], d["NM"], d["cigar"]) for d in ref[m]]
-                if per[m] != exp:
-                    bad += 1
-                    if bad <= 3:
-                        log(f"MISMATCH batch {b} pair {p} mate {m + 1}: engine {per[m][:2]} oracle {exp[:2]}")
-        log(f"[rank 0] oracle spot check: {len(kept)} pairs of the timed steps ({bad} reads differ) {time.time() - t:.1f}s")
+        n_checked = n_checked_full = 0
+        for b, ids, cand, pool, read_off, n_full in kept:
+            sub = batches[b].take(ids)
+            want, _secs = O.digest_pairs(idx, opt, sub.bases, sub.off, node_cpus)
+            got = O.cand_digest(cand, pool, read_off)
+            n_checked += len(ids); n_checked_full += n_full
+            for r in np.nonzero(got != want)[0][:3 if bad < 3 else 0]:      # the first few in full
+                p = int(ids[r >> 1]); m = int(r & 1)
+                ref = O.align_pair(idx, opt, batches[b].read(2 * p), batches[b].read(2 * p + 1))[m]
+                mine = cand[int(read_off[r]):int(read_off[r + 1])]
+                log(f"MISMATCH batch {b} pair {p} mate {m + 1}: engine {[(int(c['rb']), int(c['re']), int(c['score']), int(c['pos']), int(c['NM'])) for c in mine[:3]]} "
+                    f"oracle {[(d['rb'], d['re'], d['score'], d['pos'], d['NM']) for d in ref[:3]]}")
+            bad += int((got != want).sum())
+        log(f"[rank 0] oracle spot check: {n_checked} pairs of the timed steps, {n_checked_full} of them through the full-capacity tier "
+            f"({bad} reads differ) {time.time() - t:.1f}s on {node_cpus} threads")
     bad = int(agree(float(bad), "max"))
     if bad:
         log(f"ERROR: {bad} reads of the spot check differ from the oracle: no bench line")
@@ -717,7 +723,8 @@ def main(argv=None):
             "roofline": roofline, "roofline_k2b": roofline_k2b, "cpu_baseline": cpu,
             "bucket_stats": {f: int(gathered[:, i].sum()) for i, f in enumerate(shard.STAT_FIELDS)},
         }
-        out["bucket_stats"].update(capacity_flags=int(any_flag), oracle_spot_check_pairs=len(kept), oracle_spot_check_mismatches=int(bad))
+        out["bucket_stats"].update(capacity_flags=int(any_flag), oracle_spot_check_pairs=int(n_checked), oracle_spot_check_full_tier_pairs=int(n_checked_full),
+                                   oracle_spot_check_mismatches=int(bad))
         # What the host costs, and what that predicts for N ranks on this node's CPU grant: every rank needs its own host threads for
         # fetch assembly and the append stage, and the node grants the job a fixed number of CPUs whatever N is.
         cpu_s_per_pair = host_cpu_s / float(args.pairs * args.steps)

@@ -152,6 +152,38 @@ class Batch:
         return self.cigar[int(c["cigar_off"]):int(c["cigar_off"]) + int(c["n_cigar"])]
 
 
+def gather_pairs(ob, pair_ids):
+    """Candidates of the given pairs out of an ema_batch_out (`ob`: the ctypes struct a stream sink receives, or a Batch): copies
+    of the candidate rows of reads 2p, 2p + 1 for every p in pair_ids, in that order, with cigar_off rebased into the returned
+    pool.  Returns (cand rows, CIGAR pool, read_off[2 * len(pair_ids) + 1]).  Vectorised: cheap enough for a sink callback."""
+    ids = np.asarray(pair_ids, dtype=np.int64)
+    if isinstance(ob, Batch):
+        cand_off, cand_all, cig_all = ob.cand_off, ob.cand, ob.cigar
+    else:
+        n = int(ob.n_pairs)
+        cand_off = np.ctypeslib.as_array(ob.cand_off, shape=(2 * n + 1,))
+        n_cand = int(cand_off[-1])
+        cand_all = np.frombuffer((C.c_char * (n_cand * C.sizeof(Cand))).from_address(C.addressof(ob.cand.contents)), dtype=CAND_DTYPE) \
+            if n_cand else np.zeros(0, dtype=CAND_DTYPE)
+        cig_all = np.ctypeslib.as_array(ob.cigar, shape=(max(int(ob.n_cigar), 1),))
+    reads = np.stack([2 * ids, 2 * ids + 1], axis=1).reshape(-1)
+    lo = cand_off[reads].astype(np.int64)
+    cnt = cand_off[reads + 1].astype(np.int64) - lo
+    read_off = np.zeros(len(reads) + 1, dtype=np.int64)
+    read_off[1:] = np.cumsum(cnt)
+    tot = int(read_off[-1])
+    rows = np.repeat(lo - read_off[:-1], cnt) + np.arange(tot)
+    cand = cand_all[rows].copy() if tot else np.zeros(0, dtype=CAND_DTYPE)
+    nc = cand["n_cigar"].astype(np.int64)
+    c_off = np.zeros(tot + 1, dtype=np.int64)
+    c_off[1:] = np.cumsum(nc)
+    n_ops = int(c_off[-1])
+    src = np.repeat(cand["cigar_off"].astype(np.int64) - c_off[:-1], nc) + np.arange(n_ops)
+    pool = cig_all[src].copy() if n_ops else np.zeros(0, dtype=np.uint32)
+    cand["cigar_off"] = c_off[:-1].astype(np.uint32)
+    return cand, pool, read_off
+
+
 def append_alignments(batch: "Batch", off: np.ndarray, opts: "Opts | None" = None, error_rate: float = 0.001):
     """The reference's append_alignments() on a batch (reference src/align.c:986-1061; host arithmetic, no GPU): returns
     (records as a structured array in the reference's order, pair_off[n_pairs + 1])."""

@@ -110,6 +110,17 @@ class Pairs:
     def read(self, r):
         return self.bases[self.off[r]:self.off[r + 1]].tobytes()
 
+    def take(self, ids):
+        """The pairs with the given numbers, in that order, as a batch of their own."""
+        ids = np.asarray(ids, dtype=np.int64)
+        reads = np.stack([2 * ids, 2 * ids + 1], axis=1).reshape(-1)
+        lo = self.off[reads].astype(np.int64)
+        n = self.off[reads + 1].astype(np.int64) - lo
+        off = np.zeros(len(reads) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(n)
+        src = np.repeat(lo - off[:-1], n) + np.arange(int(off[-1]))
+        return Pairs(np.asarray(self.bases)[src], off.astype(np.uint32), None if self.barcodes is None else self.barcodes[ids])
+
     def subset(self, lo, hi):
         o = self.off[2 * lo:2 * hi + 1]
         return Pairs(self.bases[o[0]:o[-1]].copy(), (o - o[0]).astype(np.uint32),

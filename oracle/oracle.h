@@ -213,6 +213,9 @@ typedef struct {
 void orc_align_pair(const orc_opt_t *opt, const orc_idx_t *idx, const char *read1, int len1,
                     const char *read2, int len2, orc_pair_out_t *out);
 void orc_pair_out_free(orc_pair_out_t *out);
+/* per-read digests of the candidate lists of a whole batch (2 * n_pairs words), n_threads OpenMP threads; returns seconds */
+double orc_digest_pairs(const orc_opt_t *opt, const orc_idx_t *idx, const char *bases, const uint32_t *off, size_t n_pairs,
+                        int n_threads, uint64_t *digest);
 
 /* the host stage behind the bridge calls (reference src/align.c:846-911, 959-1061): filters, mapq, likelihoods */
 int orc_append_alignments(const orc_opt_t *opt, const orc_pair_out_t *p, int len1, int len2, double error_rate, int *which,

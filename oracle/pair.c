@@ -362,6 +362,54 @@ double orc_bench_pairs(const orc_opt_t *opt, const orc_idx_t *idx, const char *b
 	return omp_get_wtime() - t0;
 }
 
+/* A 64-bit digest of each read's candidate list (regions, positions, NM, CIGARs, in order) for a whole batch on n_threads:
+ * the large spot checks of bench.py and the chr20-scale parity test compare these with the same digest of the engine's candidates
+ * (tests/oracle_lib.py, cand_digest) instead of walking 10^5 candidate lists in Python.  digest[2 * n_pairs]. */
+#define ORC_DG(k) ((uint64_t)(k))
+static uint64_t digest_cand(const orc_cand_t *c, const uint32_t *pool)
+{
+	uint64_t m = (uint64_t)c->reg.rb * ORC_DG(0x9E3779B97F4A7C15ULL) + (uint64_t)c->reg.re * ORC_DG(0xC2B2AE3D27D4EB4FULL)
+	           + (uint64_t)(int64_t)c->reg.qb * ORC_DG(0x165667B19E3779F9ULL) + (uint64_t)(int64_t)c->reg.qe * ORC_DG(0x85EBCA77C2B2AE63ULL)
+	           + (uint64_t)(int64_t)c->reg.score * ORC_DG(0x27D4EB2F165667C5ULL) + (uint64_t)c->pos * ORC_DG(0xD6E8FEB86659FD93ULL)
+	           + (uint64_t)(int64_t)c->NM * ORC_DG(0xFF51AFD7ED558CCDULL) + (uint64_t)(int64_t)c->n_cigar * ORC_DG(0xC4CEB9FE1A85EC53ULL)
+	           + (uint64_t)(int64_t)c->is_rev * ORC_DG(0x2545F4914F6CDD1DULL) + (uint64_t)(int64_t)c->reg.csub * ORC_DG(0x94D049BB133111EBULL)
+	           + (uint64_t)(int64_t)c->reg.seedcov * ORC_DG(0xBF58476D1CE4E5B9ULL);
+	int j;
+	for (j = 0; j < c->n_cigar; ++j) m += (uint64_t)pool[c->cigar_off + j] * (ORC_DG(0xA0761D6478BD642FULL) + (uint64_t)j * ORC_DG(0xE7037ED1A0B428DBULL));
+	m ^= m >> 29; m *= ORC_DG(0x8EBC6AF09C88C6E3ULL); m ^= m >> 32;
+	return m;
+}
+double orc_digest_pairs(const orc_opt_t *opt, const orc_idx_t *idx, const char *bases, const uint32_t *off, size_t n_pairs,
+                        int n_threads, uint64_t *digest)
+{
+	long i;
+	double t0;
+	if (n_threads < 1) n_threads = 1;
+	if (!getenv("ORC_BENCH_DEFAULT_MALLOC")) {
+		mallopt(M_TRIM_THRESHOLD, 1 << 30);
+		mallopt(M_MMAP_THRESHOLD, 1 << 30);
+		mallopt(M_TOP_PAD, 64 << 20);
+	}
+	t0 = omp_get_wtime();
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 4)
+	for (i = 0; i < (long)n_pairs; ++i) {
+		orc_pair_out_t o;
+		size_t k;
+		uint64_t d[2] = {0, 0};
+		orc_align_pair(opt, idx, bases + off[2 * i], (int)(off[2 * i + 1] - off[2 * i]), bases + off[2 * i + 1],
+		               (int)(off[2 * i + 2] - off[2 * i + 1]), &o);
+		for (k = 0; k < o.n1 + o.n2; ++k) {
+			const int m = k < o.n1 ? 0 : 1;
+			const uint64_t r = m ? k - o.n1 : k;
+			d[m] += digest_cand(&o.c[k], o.pool) * (2 * r + 1);
+		}
+		digest[2 * i] = d[0] + (uint64_t)o.n1 * ORC_DG(0x9FB21C651E98DF25ULL);
+		digest[2 * i + 1] = d[1] + (uint64_t)o.n2 * ORC_DG(0x9FB21C651E98DF25ULL);
+		orc_pair_out_free(&o);
+	}
+	return omp_get_wtime() - t0;
+}
+
 /* ------------------------------------------------------------------ */
 /* Host stage behind the bridge calls, reference src/align.c:
  *   :959-984   mem_approx_mapq_se_insist   -> approx_mapq()

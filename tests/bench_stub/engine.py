@@ -11,6 +11,9 @@ def default_opts():
     return E.default_opts()
 
 
+gather_pairs = E.gather_pairs
+
+
 class Engine:
     n_streams = 3
 

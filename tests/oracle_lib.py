@@ -209,6 +209,54 @@ def bench_pairs(idx: Index, opt, bases: np.ndarray, off: np.ndarray, n_threads: 
     return secs, n_cand.value
 
 
+def digest_pairs(idx: Index, opt, bases: np.ndarray, off: np.ndarray, n_threads: int):
+    """Per-read digests (uint64[2 * n_pairs]) of the oracle's candidate lists for a batch (oracle/pair.c, orc_digest_pairs), and the
+    seconds it took.  cand_digest() below computes the same digest from candidate arrays."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    n = (len(off) - 1) // 2
+    out = np.zeros(2 * n, dtype=np.uint64)
+    L = lib()
+    L.orc_digest_pairs.restype = C.c_double
+    L.orc_digest_pairs.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    secs = L.orc_digest_pairs(C.byref(opt), idx.h, bases.ctypes.data, off.ctypes.data, n, n_threads, out.ctypes.data)
+    return out, secs
+
+
+_DG = [np.uint64(x) for x in (0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0x85EBCA77C2B2AE63, 0x27D4EB2F165667C5,
+                              0xD6E8FEB86659FD93, 0xFF51AFD7ED558CCD, 0xC4CEB9FE1A85EC53, 0x2545F4914F6CDD1D, 0x94D049BB133111EB,
+                              0xBF58476D1CE4E5B9)]
+
+
+def cand_digest(cand: np.ndarray, cigar: np.ndarray, read_off: np.ndarray):
+    """orc_digest_pairs' digest from candidate arrays: cand = structured rows (rb, re, qb, qe, score, pos, NM, n_cigar, is_rev,
+    csub, seedcov, cigar_off) of consecutive reads, read_off[r] .. read_off[r + 1] = rows of read r (first row of read 0 is row 0),
+    cigar = the pool cigar_off points into.  Returns uint64[len(read_off) - 1]."""
+    with np.errstate(over="ignore"):
+        u = lambda a: np.asarray(a).astype(np.int64).astype(np.uint64)      # noqa: E731 -- sign-extended like the C casts
+        m = np.zeros(len(cand), dtype=np.uint64)
+        for f, k in zip(("rb", "re", "qb", "qe", "score", "pos", "NM", "n_cigar", "is_rev", "csub", "seedcov"), _DG):
+            m += u(cand[f]) * k
+        nc = np.asarray(cand["n_cigar"]).astype(np.int64)
+        tot = int(nc.sum())
+        if tot:
+            row = np.repeat(np.arange(len(cand)), nc)
+            start = np.cumsum(nc) - nc
+            j = np.arange(tot) - np.repeat(start, nc)
+            ops = cigar[np.asarray(cand["cigar_off"]).astype(np.int64)[row] + j].astype(np.uint64)
+            term = ops * (np.uint64(0xA0761D6478BD642F) + j.astype(np.uint64) * np.uint64(0xE7037ED1A0B428DB))
+            np.add.at(m, row, term)
+        m ^= m >> np.uint64(29); m *= np.uint64(0x8EBC6AF09C88C6E3); m ^= m >> np.uint64(32)
+        read_off = np.asarray(read_off).astype(np.int64)
+        n_per = np.diff(read_off)
+        r_in = np.arange(len(cand)) - np.repeat(read_off[:-1], n_per)
+        m *= (2 * r_in + 1).astype(np.uint64)
+        out = np.zeros(len(n_per), dtype=np.uint64)
+        np.add.at(out, np.repeat(np.arange(len(n_per)), n_per), m)
+        out += n_per.astype(np.uint64) * np.uint64(0x9FB21C651E98DF25)
+    return out
+
+
 # ---- bucket reader oracle (oracle/ingest.c) and the reference's own util.c (oracle/_ref/libref_util.so) ----
 ORC_MAX_READ_LEN = 255
 

@@ -226,3 +226,33 @@ def test_oracle_reproduces_the_committed_regression_vectors():
         res = O.align_pair(idx, opt, pairs.read(2 * p), pairs.read(2 * p + 1))
         got = [[{k: (float(np.float32(v)) if k == "frac_rep" else v) for k, v in c.items()} for c in mate] for mate in res]
         assert got == candidates[p]
+
+
+def test_candidate_digest_of_arrays_equals_the_oracles():
+    """oracle_lib.cand_digest (numpy, from candidate arrays: what bench.py's large spot check applies to the engine's output)
+    against orc_digest_pairs (C, from the oracle's own candidates)."""
+    import numpy as np
+    from common import small_ref
+    from ema_amd import synth
+    from ema_amd.engine import CAND_DTYPE
+    prefix, ctg = small_ref("repeats")
+    pairs = synth.make_pairs(ctg, 120, seed=77, sub_rate=0.02)
+    idx, opt = O.Index(prefix), O.default_opt()
+    want, _ = O.digest_pairs(idx, opt, pairs.bases, pairs.off, 4)
+    rows, pool, read_off = [], [], [0]
+    for p in range(pairs.n):
+        ref = O.align_pair(idx, opt, pairs.read(2 * p), pairs.read(2 * p + 1))
+        for m in range(2):
+            for d in ref[m]:
+                r = np.zeros(1, dtype=CAND_DTYPE)
+                for f in ("rb", "re", "qb", "qe", "score", "pos", "NM", "is_rev", "csub", "seedcov"):
+                    r[f] = d[f]
+                r["n_cigar"] = len(d["cigar"]); r["cigar_off"] = len(pool)
+                pool.extend(d["cigar"])
+                rows.append(r)
+            read_off.append(len(rows))
+    cand = np.concatenate(rows)
+    got = O.cand_digest(cand, np.array(pool, dtype=np.uint32), np.array(read_off))
+    assert got.tolist() == want.tolist()
+    cand["NM"][len(cand) // 2] += 1      # any field of any candidate moves its read's digest
+    assert (O.cand_digest(cand, np.array(pool, dtype=np.uint32), np.array(read_off)) != want).sum() == 1

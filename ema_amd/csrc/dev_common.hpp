@@ -140,13 +140,16 @@ __device__ __forceinline__ int ema_claim_next(EmaClaim &c, int *counter, int tot
 // identity, v_mov_b32_dpp, operate) and does not fold them (r03: the two scans of every DP row were a fifth of the row's
 // instructions).  The s_nop covers the two wait states a DPP read needs after a VALU write of the same register.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define EMA_DPP_STEP(op, v, ctrl) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+#define EMA_DPP_STEP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+// first step of a scan: 5 wait states, which also cover a VALU write of EXEC (v_cmpx, v_readlane-style) that the compiler may have
+// scheduled right before the block -- its hazard recognizer does not look inside the asm
+#define EMA_DPP_STEP0(op, v, ctrl) asm volatile("s_nop 4\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
 #endif
 __device__ __forceinline__ int ema_wave_incl_scan_max(int v, int ident)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	(void)ident;
-	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP0("v_max_i32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
 	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
 	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
 	EMA_DPP_STEP("v_max_i32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
@@ -167,7 +170,7 @@ __device__ __forceinline__ int ema_wave_incl_scan_max(int v, int ident)
 __device__ __forceinline__ int ema_wave_incl_scan_add(int v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+	EMA_DPP_STEP0("v_add_u32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
 	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
 	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
 	EMA_DPP_STEP("v_add_u32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");

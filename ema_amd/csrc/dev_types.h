@@ -85,6 +85,7 @@ struct Intv { uint64_t x0, x1, x2, info; };
 #define EMA_REG_LEAN 48
 #define EMA_CIG_LEAN 192
 #define EMA_SEED_BUDGET_LEAN 4096
+#define EMA_SEED_BUDGET_LANE 2048      // ... when the reads over it are seeded by K1w in place (engine.hip, run_seed) instead of going to the full tier
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
 
 // bwa's mem_seed_t plus the link to the next seed of the same chain

@@ -37,14 +37,16 @@
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
-                                int *n_park_out, int park_max, int n_blocks, hipStream_t stream, unsigned long long *prof);
+                                int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, int n_blocks, hipStream_t stream,
+                                unsigned long long *prof);
 extern "C" size_t ema_seed_park_bytes();
 extern "C" int ema_seed_wave_blocks_per_cu();
 extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
-                                     const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status, int *counter,
-                                     int n_blocks, hipStream_t stream);
+                                     const int *n_pairs_dev, const int *map, const int *read_list, Intv *intv, int *n_intv, int *status,
+                                     int *counter, int n_blocks, hipStream_t stream);
 
 extern "C" void ema_launch_kmer_level(const DevIndex *ix, int L, uint64_t *wide, uint64_t *narrow, int *overflow, hipStream_t stream);
+extern "C" void ema_launch_sa_expand(const DevIndex *ix, const uint64_t *sampled, int shift, void *sa_out, int width, uint64_t row0, uint64_t n, hipStream_t stream);
 extern "C" size_t ema_text2_words(int64_t l_pac);
 extern "C" void ema_launch_text2(const uint8_t *pac, int64_t l_pac, uint64_t *text2, hipStream_t stream);
 extern "C" size_t ema_align_slab_bytes();
@@ -168,6 +170,7 @@ struct Slice {
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo;
+	DevBuf<int> d_long;                           // lean slices: the reads K1 gave up over its extend budget, for K1w (run_seed); d_counters [18] counts them
 	DevBuf<DevReg> d_regs;
 	DevBuf<uint8_t> d_heavy;                      // chain-rich reads set aside by K2b: records (dev_types.h, HeavyCtl)
 	DevBuf<unsigned long long> d_heavy_reads, d_heavy_tasks;
@@ -199,7 +202,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
+		d_status.release(); d_long.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -273,6 +276,8 @@ struct ema_engine {
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
+	bool long_wave = true;               // lean slices: reads over K1's extend budget are seeded by K1w in place (EMA_SEED_LONG_WAVE=0: given to the full tier)
+	size_t long_cap = 0;                 // room of a lean slice's list of long reads
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)
@@ -323,7 +328,8 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
 	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
-	HIPCHK(e, s.d_counters.alloc(48));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts
+	if (&s != &e->full && e->long_wave) { e->long_cap = std::max<size_t>(1024, n_reads / 8); HIPCHK(e, s.d_long.alloc(e->long_cap)); }
+	HIPCHK(e, s.d_counters.alloc(48));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts; [18] long reads listed, [19] K1w's queue over them
 	                                        // [26] reads set aside, [27] their chain tasks, [28..29] work queues of K2c, K2d, [30..31] arena bytes used (u64)
 	                                        // [38..44] K3: pairs set aside, attempts per direction, work queues of K3t / K3r x 2; [46..47] arena bytes (u64)
 	                                        // [32..35] K4: reads set aside, their region tasks, work queues of K4t, K4r; [36..37] CIGAR operations taken from the arena (u64)
@@ -395,6 +401,9 @@ static bool stream_file_to_device(ema_engine *e, const std::string &path, uint64
 	return ok;
 }
 
+// K1w's argument records in device memory (k_seed_wave.hip): the index, the full tier's options, the lean tier's
+static const size_t K1W_OPTS_FULL = (sizeof(DevIndex) + 15) & ~(size_t)15, K1W_OPTS_LEAN = (K1W_OPTS_FULL + sizeof(DevOpts) + 15) & ~(size_t)15;
+
 static int engine_open(const char *index_prefix, const ema_engine *share, int device, const ema_engine_opts *opts, ema_engine_t **out);
 
 static int select_slot(ema_engine *e, int slot, int only = -1);
@@ -458,7 +467,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	HIPCHK(e, e->d_occ.alloc(hix.occ.size()));
 	HIPCHK(e, hipMemcpy(e->d_occ.p, hix.occ.data(), hix.occ.size() * sizeof(OccBlock), hipMemcpyHostToDevice));
 	HIPCHK(e, e->d_sa.alloc(hix.sa_size));
-	if (!stream_file_to_device(e, hix.sa_path, hix.sa_file_off, hix.sa_size, e->d_sa.p)) return e->err.empty() ? EMA_EINDEX : EMA_EDEVICE;
+	if (!hix.sa_path.empty() && !stream_file_to_device(e, hix.sa_path, hix.sa_file_off, hix.sa_size, e->d_sa.p)) return e->err.empty() ? EMA_EINDEX : EMA_EDEVICE;
 	HIPCHK(e, e->d_pac.alloc(hix.pac.size()));
 	HIPCHK(e, hipMemcpy(e->d_pac.p, hix.pac.data(), hix.pac.size(), hipMemcpyHostToDevice));
 	HIPCHK(e, e->d_ctg.alloc(hix.ctg_off.size()));
@@ -466,6 +475,21 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->dix = hix.view();
 	e->dix.occ = e->d_occ.p; e->dix.sa = e->d_sa.p; e->dix.pac = e->d_pac.p; e->dix.ctg_off = e->d_ctg.p;
 	e->dix.ctg_alt = nullptr;
+	if (hix.sa_path.empty()) {      // a stock bwa index: the flat suffix array from bwa's sampled one, on the device (k_kmer.hip)
+		DevBuf<uint64_t> d_samp;
+		HIPCHK(e, d_samp.alloc(hix.sa_sampled.size()));
+		HIPCHK(e, hipMemcpy(d_samp.p, hix.sa_sampled.data(), hix.sa_sampled.size() * 8, hipMemcpyHostToDevice));
+		int shift = 0;
+		while ((1 << shift) < hix.sa_intv) ++shift;
+		const uint64_t n_rows = hix.seq_len + 1, piece = (uint64_t)1 << 30;
+		for (uint64_t r0 = 0; r0 < n_rows; r0 += piece) {
+			ema_launch_sa_expand(&e->dix, d_samp.p, shift, e->d_sa.p, hix.sa_width, r0, std::min(piece, n_rows - r0), nullptr);
+			HIPCHK(e, hipGetLastError());
+		}
+		HIPCHK(e, hipDeviceSynchronize());
+		d_samp.release();
+		if (getenv("EMA_VERBOSE")) fprintf(stderr, "[ema] no %s.fsa: flat suffix array expanded on the device from bwa's sampled .sa (every %d rows)\n", index_prefix, hix.sa_intv);
+	}
 	HIPCHK(e, e->d_ctg_tab.alloc(hix.ctg_tab.size()));
 	HIPCHK(e, hipMemcpy(e->d_ctg_tab.p, hix.ctg_tab.data(), hix.ctg_tab.size() * 4, hipMemcpyHostToDevice));
 	e->dix.ctg_tab = e->d_ctg_tab.p; e->dix.ctg_shift = hix.ctg_shift;
@@ -551,6 +575,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	}
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
+	if (const char *v = getenv("EMA_SEED_LONG_WAVE")) e->long_wave = atoi(v) != 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
 	if (const char *v = getenv("EMA_HEAVY_ATTEMPTS")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
@@ -575,7 +600,8 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 		s.dopts.intv_cap = std::min(EMA_INTV_CAP, e->opts.lean_intervals > 0 ? e->opts.lean_intervals : EMA_INTV_LEAN);
 		s.dopts.reg_cap = std::min(EMA_REG_CAP, e->opts.lean_regions > 0 ? e->opts.lean_regions : EMA_REG_LEAN);
 		s.dopts.cig_cap = std::min(EMA_CIG_CAP, e->opts.lean_cigar_ops > 0 ? e->opts.lean_cigar_ops : EMA_CIG_LEAN);
-		s.dopts.seed_budget = e->opts.lean_seed_extends > 0 ? e->opts.lean_seed_extends : e->opts.lean_seed_extends < 0 ? 1 << 30 : EMA_SEED_BUDGET_LEAN;
+		s.dopts.seed_budget = e->opts.lean_seed_extends > 0 ? e->opts.lean_seed_extends : e->opts.lean_seed_extends < 0 ? 1 << 30
+		                      : e->long_wave ? EMA_SEED_BUDGET_LANE : EMA_SEED_BUDGET_LEAN;
 		int rc = slice_alloc(e, s, nullptr);
 		if (rc != EMA_OK) return rc;
 	}
@@ -594,9 +620,10 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	HIPCHK(e, e->d_redo_run.alloc(full_cap + 1));
 	HIPCHK(e, hipMemset(e->d_redo.p, 0, 4));
 	HIPCHK(e, hipMemset(e->d_redo_run.p, 0, 4));
-	HIPCHK(e, e->d_k1w_args.alloc(sizeof(DevIndex) + sizeof(DevOpts) + 64));
+	HIPCHK(e, e->d_k1w_args.alloc(K1W_OPTS_LEAN + sizeof(DevOpts) + 64));
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p, &e->dix, sizeof(DevIndex), hipMemcpyHostToDevice));
-	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + ((sizeof(DevIndex) + 15) & ~(size_t)15), &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_FULL, &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_LEAN, &e->sl[0].dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
 	return EMA_OK;
 }
 
@@ -784,7 +811,7 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 	HIPCHK(e, hipMemsetAsync(s.d_status.p, 0, (size_t)w.n_pairs * 2 * 4, s.stream));
 	HIPCHK(e, hipMemsetAsync(s.d_counters.p, 0, 48 * 4, s.stream));
 	if (&s == &e->full && e->wave_seed) {      // the long reads: one wavefront each (k_seed_wave.hip)
-		ema_launch_seed_wave((const DevIndex *)e->d_k1w_args.p, (const DevOpts *)(e->d_k1w_args.p + ((sizeof(DevIndex) + 15) & ~(size_t)15)), w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
+		ema_launch_seed_wave((const DevIndex *)e->d_k1w_args.p, (const DevOpts *)(e->d_k1w_args.p + K1W_OPTS_FULL), w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, nullptr, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
 		                     s.d_counters.p + 3, e->seed_wave_blocks, s.stream);
 		HIPCHK(e, hipGetLastError());
 		watchdog(e, s, "ema_k_seed_wave");
@@ -799,10 +826,20 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 		ema_launch_seed(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
 		                s.d_lists.p, r == 0 ? s.d_counters.p + 3 : s.d_counters.p + 8 + r, r == 0 ? nullptr : s.d_park[in].p,
 		                s.d_counters.p + 16 + in, last ? nullptr : s.d_park[out].p, s.d_counters.p + 16 + out,
-		                last ? 0 : e->seed_park_max, e->seed_blocks, s.stream, e->d_prof.p);
+		                last ? 0 : e->seed_park_max, s.d_long.p, s.d_counters.p + 18, (int)(s.d_long.p ? e->long_cap : 0), e->seed_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
 	watchdog(e, s, "ema_k_seed");
+	if (s.d_long.p) {
+		// The reads over K1's extend budget -- a few per cent, the ones from repeats whose backward rows are long -- are seeded again by
+		// K1w, one wavefront per read (a row per step instead of an entry per tick), into the same slots: a lane machine working
+		// through 4,000 dependent ticks set the length of K1's launch series, and the full-capacity tier, which used to take these
+		// reads, redid their pairs through K4.  A read beyond the list's room keeps EMA_ST_LONG and goes to the full tier as before.
+		ema_launch_seed_wave((const DevIndex *)e->d_k1w_args.p, (const DevOpts *)(e->d_k1w_args.p + K1W_OPTS_LEAN), w.qpack, w.off, (int)e->long_cap, s.d_counters.p + 18, nullptr,
+		                     s.d_long.p, s.d_intv.p, s.d_n_intv.p, s.d_status.p, s.d_counters.p + 19, e->seed_wave_blocks, s.stream);
+		HIPCHK(e, hipGetLastError());
+		watchdog(e, s, "ema_k_seed_wave (lean)");
+	}
 	return EMA_OK;
 }
 
@@ -1260,7 +1297,8 @@ int ema_engine_set_opts(ema_engine_t *e, const ema_engine_opts *o)
 	keep_caps(e->dopts);
 	for (auto &s : e->sl) keep_caps(s.dopts);
 	keep_caps(e->full.dopts);
-	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + ((sizeof(DevIndex) + 15) & ~(size_t)15), &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_FULL, &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
+	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_LEAN, &e->sl[0].dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
 	if (e->shadow) return ema_engine_set_opts(e->shadow, o);
 	return EMA_OK;
 }
@@ -1440,6 +1478,18 @@ int ema_engine_debug_contigs(ema_engine_t *e, const int64_t *ctg_off, int n_seqs
 	HIPCHK(e, hipStreamSynchronize(e->sl[0].stream));
 	HIPCHK(e, hipMemcpy(out, d_out.p, 2 * (size_t)n * 4, hipMemcpyDeviceToHost));
 	d_off.release(); d_rb.release(); d_re.release(); d_tab.release(); d_out.release();
+	return EMA_OK;
+}
+
+int ema_engine_debug_sa(ema_engine_t *e, uint64_t first, uint64_t n, uint64_t *out)
+{
+	if (!e || !out) return EMA_EARG;
+	if (first + n > e->dix.seq_len + 1) return EMA_EARG;
+	HIPCHK(e, hipSetDevice(e->device));
+	const size_t w = (size_t)e->dix.sa_width;
+	std::vector<uint8_t> raw((size_t)n * w);
+	HIPCHK(e, hipMemcpy(raw.data(), (const uint8_t *)e->dix.sa + first * w, raw.size(), hipMemcpyDeviceToHost));
+	for (uint64_t i = 0; i < n; ++i) out[i] = w == 4 ? (uint64_t)((const uint32_t *)raw.data())[i] : ((const uint64_t *)raw.data())[i];
 	return EMA_OK;
 }
 

@@ -1,6 +1,7 @@
 // ema_amd/csrc/host_index.cpp -- see host_index.h.
 #include "host_index.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <thread>
@@ -56,6 +57,46 @@ DevIndex HostIndex::view() const
 	d.text2 = text2.empty() ? nullptr : text2.data();
 	memcpy(d.occ_super, occ_super, sizeof(occ_super));
 	return d;
+}
+
+// bwa's bwt_sa() for every row: walk LF (bwt_invPsi) until a sampled row, count the steps.  Row 0 (the sentinel's suffix, which no
+// interval ever contains) gets seq_len, as ema_index_build writes it.
+void host_expand_sa(HostIndex &ix)
+{
+	const uint64_t n = ix.seq_len, mask = (uint64_t)ix.sa_intv - 1;
+	int shift = 0;
+	while (((uint64_t)1 << shift) < (uint64_t)ix.sa_intv) ++shift;
+	ix.sa_bytes.assign(ix.sa_size, 0);
+	auto inv_psi = [&](uint64_t k) -> uint64_t {
+		if (k == ix.primary) return 0;
+		const uint64_t p = k - (k > ix.primary ? 1 : 0);
+		const OccBlock &b = ix.occ[p >> 6];
+		const int r = (int)(p & 63);
+		const unsigned c = (unsigned)(b.bases[r >> 5] >> ((r & 31) << 1)) & 3u;
+		uint64_t cnt = b.cnt[c];
+		for (int t = 0; t <= r; ++t) cnt += ((b.bases[t >> 5] >> ((t & 31) << 1)) & 3u) == c;
+		const uint64_t sb = p >> EMA_OCC_SUPER_SHIFT;
+		if (sb > 0) cnt += ix.occ_super[sb - 1][c];
+		return ix.L2[c] + cnt;
+	};
+	unsigned n_thr = std::thread::hardware_concurrency();
+	n_thr = n_thr < 1 ? 1 : n_thr > 64 ? 64 : n_thr;
+	if (n < 65536) n_thr = 1;
+	auto work = [&](unsigned t) {
+		const uint64_t per = (n + 1 + n_thr - 1) / n_thr, lo = std::min(n + 1, t * per), hi = std::min(n + 1, lo + per);
+		for (uint64_t r = lo; r < hi; ++r) {
+			uint64_t k = r, steps = 0;
+			while (k & mask) { k = inv_psi(k); ++steps; }
+			uint64_t v = steps + ix.sa_sampled[k >> shift];
+			if (r == 0) v = n;
+			if (ix.sa_width == 4) ((uint32_t *)ix.sa_bytes.data())[r] = (uint32_t)v;
+			else ((uint64_t *)ix.sa_bytes.data())[r] = v;
+		}
+	};
+	std::vector<std::thread> th;
+	for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(work, t);
+	work(0);
+	for (auto &x : th) x.join();
 }
 
 std::string host_index_load(const std::string &prefix, HostIndex &ix, bool with_sa)
@@ -131,8 +172,31 @@ std::string host_index_load(const std::string &prefix, HostIndex &ix, bool with_
 	{
 		FILE *f = fopen((prefix + ".fsa").c_str(), "rb");
 		uint8_t head[24];
-		if (!f || fread(head, 1, 24, f) != 24 || memcmp(head, "EMAFSA01", 8) != 0) {
-			if (f) fclose(f);
+		if (!f) {
+			// a stock bwa index: bwa's sampled suffix array (bwt_dump_sa: primary, L2[1..4], sa_intv, seq_len, then SA[sa_intv],
+			// SA[2 sa_intv], ...), expanded to the flat one by LF-mapping -- here for with_sa, on the device by the engine
+			std::vector<uint8_t> sraw;
+			if (!slurp(prefix + ".sa", sraw) || sraw.size() < 56) return "cannot read " + prefix + ".fsa nor " + prefix + ".sa (suffix array)";
+			const uint64_t *h = (const uint64_t *)sraw.data();
+			if (h[0] != ix.primary || h[1] != ix.L2[1] || h[2] != ix.L2[2] || h[3] != ix.L2[3] || h[4] != ix.L2[4] || h[6] != ix.seq_len)
+				return prefix + ".sa does not belong to " + prefix + ".bwt";
+			const uint64_t intv = h[5];
+			if (intv == 0 || (intv & (intv - 1)) != 0 || intv > 1024) return "bad sampling interval in " + prefix + ".sa";
+			const uint64_t n_sa = (ix.seq_len + intv) / intv;
+			if (sraw.size() != 56 + (n_sa - 1) * 8) return "truncated " + prefix + ".sa";
+			ix.sa_intv = (int)intv;
+			ix.sa_sampled.resize(n_sa);
+			ix.sa_sampled[0] = ~(uint64_t)0;
+			memcpy(ix.sa_sampled.data() + 1, sraw.data() + 56, (n_sa - 1) * 8);
+			const char *force64 = getenv("EMA_INDEX_SA64");
+			ix.sa_width = (ix.seq_len < 0xffffff00ULL && !(force64 && atoi(force64) != 0)) ? 4 : 8;      // as ema_index_build chooses
+			ix.sa_path.clear();
+			ix.sa_file_off = 0;
+			ix.sa_size = (ix.seq_len + 1) * (uint64_t)ix.sa_width;
+			if (with_sa) host_expand_sa(ix);
+		} else {
+		if (fread(head, 1, 24, f) != 24 || memcmp(head, "EMAFSA01", 8) != 0) {
+			fclose(f);
 			return "cannot read " + prefix + ".fsa (flat suffix array; rebuild the index with ema_index_build)";
 		}
 		uint64_t n, width;
@@ -151,6 +215,7 @@ std::string host_index_load(const std::string &prefix, HostIndex &ix, bool with_
 			if (fread(ix.sa_bytes.data(), 1, ix.sa_size, f) != ix.sa_size) { fclose(f); return "cannot read " + prefix + ".fsa"; }
 		}
 		fclose(f);
+		}
 	}
 	// ---- .pac
 	if (!slurp(prefix + ".pac", ix.pac)) return "cannot read " + prefix + ".pac";

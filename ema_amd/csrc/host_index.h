@@ -18,6 +18,12 @@ struct HostIndex {
 	std::vector<uint8_t> sa_bytes;   // seq_len+1 rows of sa_width bytes (empty when loaded without the suffix array)
 	std::string sa_path;             // where those rows are on disk: sa_size bytes from sa_file_off
 	uint64_t sa_file_off = 0, sa_size = 0;
+	// A stock bwa index has no flat suffix array (<prefix>.fsa is this repo's builder's), only bwa's sampled one: <prefix>.sa holds
+	// SA[j * sa_intv] for j = 1 .. seq_len / sa_intv.  Then sa_path is empty, sa_sampled = those values with entry 0 = -1 (bwa's
+	// bwt_restore_sa leaves sa[0] = -1), and the rows in between follow by LF-mapping (bwt_sa): host_expand_sa below, or the
+	// engine's kernel on the device (k_kmer.hip, ema_k_sa_expand).
+	std::vector<uint64_t> sa_sampled;
+	int sa_intv = 0;
 	std::vector<uint8_t> pac;
 	std::vector<int64_t> ctg_off;    // n+1
 	std::vector<uint8_t> ctg_alt;    // n flags from <prefix>.alt; empty when no contig is ALT
@@ -40,8 +46,12 @@ struct HostIndex {
 
 void host_contig_table(const std::vector<int64_t> &ctg_off, std::vector<int32_t> &tab, int &shift);
 
-// Loads <prefix>.bwt/.pac/.ann and <prefix>.fsa.  Returns "" on success, else an error message.  with_sa == false
+// Loads <prefix>.bwt/.pac/.ann and <prefix>.fsa -- or, without an .fsa, bwa's own <prefix>.sa (a stock `bwa index`).  Returns "" on success, else an error message.  with_sa == false
 // leaves the suffix array on disk (sa_path / sa_file_off / sa_size say where): the engine streams it to the device.
 std::string host_index_load(const std::string &prefix, HostIndex &out, bool with_sa = true);
+
+// The flat suffix array (ix.sa_bytes: seq_len + 1 rows of ix.sa_width bytes) from bwa's sampled one and the rank structure, as
+// bwt_sa() computes single rows (reference path: src/bwabridge.c:79 bwa_idx_load -> bwt_restore_sa; rows located in mem_chain).
+void host_expand_sa(HostIndex &ix);
 
 #endif

@@ -445,22 +445,29 @@ int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_
 		// The file comes in through pread() on the host's threads, each taking a stretch, into a buffer that is kept from bucket to
 		// bucket.  (Round 2 mapped the file: every 4 KB of a bucket read once is a page fault, and the faults of all parsing threads
 		// queue on one lock -- 100-200 ms for a 120 MB bucket against 45 ms for the parse itself, r03.)
-		static std::mutex buf_mu;
-		static std::vector<char> buf;
-		std::lock_guard<std::mutex> hold(buf_mu);
-		if (buf.size() < len) { std::vector<char>().swap(buf); buf.resize(len + (len >> 3)); }
+		// One buffer per calling thread (a stream's reader thread; concurrent readers do not queue behind each other), malloc'd without
+		// a zero fill and grown geometrically; it lives as long as its thread.
+		struct KeptBuf { char *p = nullptr; size_t cap = 0; ~KeptBuf() { free(p); } };
+		static thread_local KeptBuf kept;
+		if (kept.cap < len) {
+			free(kept.p);
+			kept.cap = len + (len >> 3);
+			kept.p = (char *)malloc(kept.cap);
+			if (!kept.p) { kept.cap = 0; close(fd); return fail(EMA_EIO, std::string(path) + ": out of memory for the read buffer"); }
+		}
+		char *const buf = kept.p;
 		std::atomic<int> bad{0};
 		parallel_ranges(len, (size_t)4 << 20, [&](size_t, size_t lo, size_t hi) {
 			size_t at = lo;
 			while (at < hi) {
-				const ssize_t got = pread(fd, buf.data() + at, hi - at, (off_t)at);
+				const ssize_t got = pread(fd, buf + at, hi - at, (off_t)at);
 				if (got < 0 && errno == EINTR) continue;
 				if (got <= 0) { bad.store(got < 0 ? errno : EIO); return; }
 				at += (size_t)got;
 			}
 		});
 		if (bad.load()) { const int e = bad.load(); close(fd); return fail(EMA_EIO, std::string(path) + ": read: " + strerror(e)); }
-		rc = ema_bucket_parse(buf.data(), len, bc_len, is_haplotag, max_read_len, out);
+		rc = ema_bucket_parse(buf, len, bc_len, is_haplotag, max_read_len, out);
 	} else {      // a pipe or a device: read it whole
 		std::vector<char> buf;
 		char tmp[1 << 16];

@@ -100,6 +100,7 @@ __attribute__((target("ssse3"))) bool revcomp_ssse3(char *dst, const char *src, 
 		const __m128i y = _mm_shuffle_epi8(comp, _mm_and_si128(x, low));
 		const __m128i back = _mm_shuffle_epi8(comp, _mm_and_si128(y, low));      // the complement of the complement: x again, if x is valid
 		bad = _mm_or_si128(bad, _mm_xor_si128(back, x));
+		bad = _mm_or_si128(bad, _mm_cmpeq_epi8(y, _mm_setzero_si128()));      // no complement (a NUL among them: its round trip is 0 too)
 		_mm_storeu_si128((__m128i *)dst, y);
 		dst += 16;
 	}

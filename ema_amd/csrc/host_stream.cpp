@@ -586,14 +586,16 @@ void sam_clouds(SamSink &S)
 {
 	for (;;) {
 		CloudJob c;
+		bool failed;
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
 			S.cv.wait(lk, [&] { return S.closing || !S.cloud_jobs.empty(); });
 			if (S.cloud_jobs.empty()) { S.clouds_done = true; lk.unlock(); S.cv.notify_all(); return; }
 			c = S.cloud_jobs.front();
+			failed = S.cloud_rc != EMA_OK || S.write_rc != EMA_OK;      // read under the lock the writer stores write_rc under
 		}
 		ema_clouds_out *sel = nullptr;
-		int rc = S.cloud_rc != EMA_OK || S.write_rc != EMA_OK ? EMA_ESTATE : EMA_OK;      // after a failure: drain, freeing what arrives
+		int rc = failed ? EMA_ESTATE : EMA_OK;      // after a failure: drain, freeing what arrives
 		if (rc == EMA_OK) {
 			ema_cloud_opts co = S.o.clouds;
 			if (S.o.continue_cloud_ids) co.first_cloud_id = S.next_cloud_id;

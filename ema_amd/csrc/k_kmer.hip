@@ -65,3 +65,57 @@ extern "C" void ema_launch_text2(const uint8_t *pac, int64_t l_pac, uint64_t *te
 	const size_t n = ema_text2_words(l_pac);
 	hipLaunchKernelGGL(ema_k_text2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pac, l_pac, text2, n);
 }
+
+// The flat suffix array of a stock bwa index (no <prefix>.fsa): one lane per row walks bwa's bwt_sa() -- LF-mapping (bwt_invPsi: the
+// row's BWT symbol c and its rank, L2[c] + occ(c, row)) until a row of bwa's sample, counting the steps -- on the rank structure
+// already in HBM: at most sa_intv - 1 dependent 32-byte gathers per row, 6.2 G rows x 15.5 on average at the scale of a human genome.
+// sampled[j] = SA[j << shift], sampled[0] = -1 (bwa's bwt_restore_sa); row 0 (the sentinel's suffix) gets seq_len as ema_index_build
+// writes it.  Reference path: src/bwabridge.c:79 (bwa_idx_load) and every bwt_sa() behind mem_chain.
+__global__ void __launch_bounds__(256)
+ema_k_sa_expand(DevIndex ix, const uint64_t *__restrict__ sampled, int shift, void *__restrict__ sa_out, int width, uint64_t row0, uint64_t n_rows)
+{
+	const uint64_t r = row0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_rows) return;
+	const uint64_t mask = ((uint64_t)1 << shift) - 1;
+	uint64_t k = r, steps = 0;
+	while (k & mask) {
+		if (k == ix.primary) k = 0;
+		else {
+			const uint64_t p = k - (k > ix.primary ? 1 : 0);
+			const OccBlock *blk = ix.occ + (p >> 6);
+			const uint4 head = *reinterpret_cast<const uint4 *>(blk);
+			const ulong2 sym = *(reinterpret_cast<const ulong2 *>(blk) + 1);
+			const int q = (int)(p & 63);
+			const unsigned c = (unsigned)((q < 32 ? sym.x : sym.y) >> ((q & 31) << 1)) & 3u;
+			// positions 0..q of the block holding symbol c: the two bit planes matched against c, cut after position q
+			const uint64_t w[2] = {sym.x, sym.y};
+			unsigned cnt = 0;
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+				int nvalid = q + 1 - (j << 5);
+				nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
+				const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
+				const uint64_t lo = (c & 1 ? w[j] : ~w[j]) & m55, hi = ((c & 2 ? w[j] : ~w[j]) >> 1) & m55;
+				cnt += (unsigned)__popcll(lo & hi);
+			}
+			uint64_t total = (uint64_t)(c == 0 ? head.x : c == 1 ? head.y : c == 2 ? head.z : head.w) + cnt;
+			if (ix.n_super > 1) {
+				const int sb = (int)(p >> EMA_OCC_SUPER_SHIFT);
+				total += sb == 0 ? 0 : sb == 1 ? ix.occ_super[0][c] : sb == 2 ? ix.occ_super[1][c] : ix.occ_super[2][c];
+			}
+			k = ix.L2[c] + total;
+		}
+		++steps;
+	}
+	uint64_t v = steps + sampled[k >> shift];
+	if (r == 0) v = ix.seq_len;
+	if (width == 4) reinterpret_cast<uint32_t *>(sa_out)[r] = (uint32_t)v;
+	else reinterpret_cast<uint64_t *>(sa_out)[r] = v;
+}
+
+// rows [row0, row0 + n) of the flat suffix array (the engine launches it in pieces of at most 2^31 rows)
+extern "C" void ema_launch_sa_expand(const DevIndex *ix, const uint64_t *sampled, int shift, void *sa_out, int width, uint64_t row0, uint64_t n,
+                                     hipStream_t stream)
+{
+	hipLaunchKernelGGL(ema_k_sa_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *ix, sampled, shift, sa_out, width, row0, row0 + n);
+}

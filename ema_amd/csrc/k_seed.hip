@@ -125,7 +125,8 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv,
            int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
            int *__restrict__ counter, const SeedPark *__restrict__ park_in, const int *__restrict__ n_park_in,
-           SeedPark *__restrict__ park_out, int *__restrict__ n_park_out, int park_max, unsigned long long *prof_arg)
+           SeedPark *__restrict__ park_out, int *__restrict__ n_park_out, int park_max, int *__restrict__ long_list,
+           int *__restrict__ n_long, int long_cap, unsigned long long *prof_arg)
 {
 	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
@@ -286,7 +287,13 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			// (5) between searches
 			switch (pc) {
 			case PC_DONE:
-				if (read >= 0) { n_intv[read] = n_out; status[read] = st; }
+				if (read >= 0) {
+					n_intv[read] = n_out; status[read] = st;
+					if ((st & EMA_ST_LONG) && long_list) {      // over the extend budget: on the list K1w (one wavefront per read) works through next
+						const int at = atomicAdd(n_long, 1);
+						if (at < long_cap) long_list[at] = read;
+					}
+				}
 				read = atomicAdd(counter, 1);
 				if (read >= n_tasks) { read = -1; exhausted = true; break; }
 				if (park_in) {      // resume a parked machine: it waits for its extend / entry load
@@ -531,18 +538,22 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 extern "C" size_t ema_seed_park_bytes() { return sizeof(SeedPark); }
 
 // One launch of the series (see "re-packing"): park_in == null takes fresh reads, otherwise the machines parked by the
-// previous launch; park_max == 0 never parks.
+// previous launch; park_max == 0 never parks.  long_list (may be null): the reads given up with EMA_ST_LONG are appended there (*n_long counts
+// them all, long_cap is the list's room) for K1w to seed next (engine.hip, run_seed).
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
-                                int *n_park_out, int park_max, int n_blocks, hipStream_t stream, unsigned long long *prof)
+                                int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, int n_blocks, hipStream_t stream,
+                                unsigned long long *prof)
 {
 	if (prof)
 		hipLaunchKernelGGL(ema_k_seed_t<true>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
-		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, prof);
+		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, long_list, n_long,
+		                   long_cap, prof);
 	else
 		hipLaunchKernelGGL(ema_k_seed_t<false>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
-		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, prof);
+		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, long_list, n_long,
+		                   long_cap, prof);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

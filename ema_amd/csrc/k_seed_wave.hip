@@ -191,14 +191,17 @@ struct WaveSeed {
 // (two waves per block: a block's LDS is limited to 64 KB and each wave keeps 16 KB of lists there)
 __global__ void __launch_bounds__(128)
 ema_k_seed_wave(const DevIndex *__restrict__ ixp, const DevOpts *__restrict__ optp, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
-                const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv,
+                const int *__restrict__ n_pairs_dev, const int *__restrict__ map, const int *__restrict__ read_list, Intv *__restrict__ intv,
                 int *__restrict__ n_intv, int *__restrict__ status, int *__restrict__ counter)
 {
 	__shared__ uint32_t lds_q[2][24];
 	__shared__ Intv lds_lists[2][2][EMA_LIST_CAP];
 	__shared__ uint64_t lds_tmp[2][EMA_WAVE];
 	const int lane = (int)ema_lane(), wib = ema_uni((int)(threadIdx.x >> 6));
-	const int n_total = ema_work_count(n_reads, n_pairs_dev, 2);
+	// read_list (a lean slice's long reads, listed by K1): item i is read read_list[i] of the slice -- input and results at that
+	// number -- and *n_pairs_dev counts the reads K1 wanted to list, n_reads is the list's room.  Otherwise the full-capacity tier's
+	// pairs (dev_common.hpp, ema_work_count / ema_in_read).
+	const int n_total = read_list ? (*n_pairs_dev < n_reads ? *n_pairs_dev : n_reads) : ema_work_count(n_reads, n_pairs_dev, 2);
 	const DevIndex &ix = *ixp;
 	const DevOpts &opt = *optp;
 	WaveSeed w;
@@ -211,8 +214,9 @@ ema_k_seed_wave(const DevIndex *__restrict__ ixp, const DevOpts *__restrict__ op
 		if (lane == 0) r = atomicAdd(counter, 1);
 		return __builtin_amdgcn_readlane(r, 0);
 	};
-	for (int read = next_read(); read < n_total; read = next_read()) {
-		const int in_read = ema_uni(ema_in_read(map, read));
+	for (int item = next_read(); item < n_total; item = next_read()) {
+		const int read = read_list ? ema_uni(read_list[item]) : item;
+		const int in_read = read_list ? read : ema_uni(ema_in_read(map, read));
 		w.len = ema_uni((int)(off[in_read + 1] - off[in_read]));
 		ema_wave_sync();
 		if (lane < 24) lds_q[wib][lane] = qpack[(size_t)in_read * 24 + lane];
@@ -234,9 +238,9 @@ extern "C" int ema_seed_wave_blocks_per_cu()
 
 // ix / opt: DEVICE pointers
 extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
-                                     const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status, int *counter,
+                                     const int *n_pairs_dev, const int *map, const int *read_list, Intv *intv, int *n_intv, int *status, int *counter,
                                      int n_blocks, hipStream_t stream)
 {
-	hipLaunchKernelGGL(ema_k_seed_wave, dim3(n_blocks), dim3(128), 0, stream, ix, opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
+	hipLaunchKernelGGL(ema_k_seed_wave, dim3(n_blocks), dim3(128), 0, stream, ix, opt, qpack, off, n_reads, n_pairs_dev, map, read_list, intv, n_intv,
 	                   status, counter);
 }

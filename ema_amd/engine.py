@@ -19,7 +19,7 @@ SYMBOLS = [
     "ema_engine_contig_name", "ema_engine_contig_len", "ema_engine_contig_offset", "ema_engine_contig_is_alt", "ema_engine_l_pac",
     "ema_engine_align_pairs", "ema_batch_free", "ema_engine_batch_capacity", "ema_engine_stage", "ema_engine_run",
     "ema_engine_sync", "ema_engine_fetch", "ema_engine_debug_seeds", "ema_engine_last_timing", "ema_engine_debug_dp", "ema_engine_debug_regions", "ema_engine_debug_dedup", "ema_engine_debug_contigs", "ema_engine_n_streams", "ema_engine_full_tier_capacity", "ema_engine_run_serial", "ema_batch_append_alignments", "ema_aln_free", "ema_engine_open_shared", "ema_engine_index_info", "ema_engine_stage_slot", "ema_engine_run_slot", "ema_engine_peer",
-    "ema_engine_seed_launches", "ema_engine_get_opts",
+    "ema_engine_seed_launches", "ema_engine_get_opts", "ema_engine_debug_sa",
 ]
 
 
@@ -368,6 +368,13 @@ class Engine:
         self._L.ema_engine_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         self._check(self._L.ema_engine_index_info(self._h, a), "index_info")
         return {"n_super": a[0], "super_shift": a[1], "sa_width": a[2], "kmer_k": a[3]}
+
+    def debug_sa(self, first: int, n: int) -> np.ndarray:
+        """Rows [first, first + n) of the suffix array in HBM (ema_engine_debug_sa)."""
+        out = np.zeros(n, dtype=np.uint64)
+        self._L.ema_engine_debug_sa.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        self._check(self._L.ema_engine_debug_sa(self._h, first, n, out.ctypes.data), "debug_sa")
+        return out
 
     def debug_seeds(self):
         """Seed intervals of the staged batch: (intv[n_reads, cap, 4] u64 = k, k', size, start<<32|end; n_intv)."""

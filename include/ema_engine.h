@@ -208,6 +208,10 @@ int ema_engine_debug_dedup(ema_engine_t *e, void *regs, const int32_t *n_in, int
  * interval [rb[i], re[i]) in bwa's forward-reverse coordinates -- out[2i] = bns_intv2rid, out[2i+1] = bns_pos2rid of rb[i]'s
  * forward position.  (The engine answers them from a coarse table instead of bwa's bisection; tests/test_gpu_contigs.py.) */
 int ema_engine_debug_contigs(ema_engine_t *e, const int64_t *ctg_off, int n_seqs, const int64_t *rb, const int64_t *re, int n, int32_t *out);
+/* Rows [first, first + n) of the suffix array as it sits in HBM (text positions, widened to 64 bits): what bwa's bwt_sa() returns
+ * for those rows.  tests/test_gpu_bwa_index.py holds an engine opened on a stock bwa index (sampled .sa, expanded on the device)
+ * against one opened on this repo's flat .fsa. */
+int ema_engine_debug_sa(ema_engine_t *e, uint64_t first, uint64_t n, uint64_t *out);
 
 /* The host stage right behind the engine: what the reference's append_alignments() (src/align.c:986-1061) derives from a
  * pair's candidates before the records go on to the cloud stage -- clip filter (:1017,:1042), search-depth filter with

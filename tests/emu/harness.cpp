@@ -116,6 +116,13 @@ void *emu_index_load(const char *prefix, char *err, int errlen)
 	return ix;
 }
 void emu_index_free(void *h) { delete (HostIndex *)h; }
+// rows of the loaded suffix array, widened to 64 bits (tests/test_index_build.py: the flat array expanded from bwa's sampled .sa)
+void emu_index_sa(void *h, uint64_t *out, uint64_t n)
+{
+	const HostIndex *ix = (const HostIndex *)h;
+	for (uint64_t i = 0; i < n; ++i)
+		out[i] = ix->sa_width == 4 ? (uint64_t)((const uint32_t *)ix->sa_bytes.data())[i] : ((const uint64_t *)ix->sa_bytes.data())[i];
+}
 
 // bases: nt4 codes.  intv: n_reads*EMU_INTV_CAP*4 u64.  Returns the interval capacity per read.
 int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, uint64_t *intv, int *n_intv, int *status,
@@ -140,7 +147,7 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 			if (r >= 2) n_park[out] = 0;
 			ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, lists.data(), &ctr[r],
 			                r == 0 ? nullptr : park[in].data(), &n_park[in], last ? nullptr : park[out].data(), &n_park[out],
-			                last ? 0 : park_max, nb, nullptr, nullptr);
+			                last ? 0 : park_max, nullptr, nullptr, 0, nb, nullptr, nullptr);
 			fprintf(stderr, "emu_seed round %d: parked %d\n", r, last ? 0 : n_park[out]);
 		}
 	}
@@ -160,7 +167,7 @@ extern "C" int emu_seed_wave(void *h, const uint8_t *bases, const uint32_t *off,
 	DevIndex di = ix->view();
 	int counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed_wave(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, &counter, 1, nullptr);
+	ema_launch_seed_wave(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, nullptr, (Intv *)intv, n_intv, status, &counter, 1, nullptr);
 	for (int r = 0; r < n_reads; ++r) {
 		Intv *a = (Intv *)intv + (size_t)r * EMU_INTV_CAP;
 		std::stable_sort(a, a + n_intv[r], [](const Intv &x, const Intv &y) { return x.info < y.info; });
@@ -206,7 +213,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
 	emu_run_align(di, d, bases, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(), n_blocks);
@@ -249,7 +256,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
@@ -298,7 +305,7 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[4] = {0, 0, 0, 0};
-	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 1, nullptr, nullptr);
 	emu_run_align(di, d, bases, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(), t.status.data(),
 	              slabs.data(), 1);
 	std::vector<int> ptodo(n_pairs + 1); int n_ptodo = 0;

@@ -195,18 +195,42 @@ def test_full_tier_overflow_fails_loudly():
     assert all(b.cand_off[r + 1] == b.cand_off[r] for r in flagged)
 
 
-def test_lean_seeding_budget_sends_long_reads_to_the_full_tier():
-    """A read whose seeding needs more FM-index extends than the lean budget is given up there and redone by the
-    full-capacity tier (which has no budget): same candidates as the oracle."""
+def test_lean_seeding_budget_long_reads_by_wave_or_full_tier(monkeypatch):
+    """A read whose seeding needs more FM-index extends than K1's lean budget is given up there and seeded again in place by K1w
+    (one wavefront per read, no budget) -- or, with EMA_SEED_LONG_WAVE=0 and beyond the room of the list of such reads, redone by the
+    full-capacity tier: same candidates as the oracle on every route."""
     prefix, ctg = small_ref("repeats")
     pairs = synth.make_pairs(ctg, 500, seed=49)
+    redone = {}
+    for route in ("1", "0"):
+        monkeypatch.setenv("EMA_SEED_LONG_WAVE", route)
+        o = default_opts()
+        o.lean_seed_extends = 450          # about the median read
+        eng = Engine(prefix, opts=o)
+        batch = eng.align_pairs(pairs.bases, pairs.off)
+        eng.close()
+        assert batch.status.max() == 0
+        assert not compare(prefix, pairs, batch)
+        redone[route] = batch.n_redone
+    assert 50 < redone["0"] < pairs.n          # every long read's pair went through the full tier
+    assert redone["1"] < redone["0"] // 4      # seeded in place: what is left are the pairs over a lean capacity
+
+
+def test_long_reads_beyond_the_list_go_to_the_full_tier():
+    """The list of long reads holds an eighth of a slice's reads (at least 1024): with nearly every read over a tiny budget the rest
+    keep their flag and take the full tier's route, up to its capacity."""
+    prefix, ctg = small_ref("repeats")
+    pairs = synth.make_pairs(ctg, 4000, seed=50)
     o = default_opts()
-    o.lean_seed_extends = 450          # about the median read
+    o.lean_seed_extends = 60
+    o.batch_pairs = 4000
+    o.n_streams = 1
+    o.full_tier_pairs = 4000
     eng = Engine(prefix, opts=o)
     batch = eng.align_pairs(pairs.bases, pairs.off)
     eng.close()
     assert batch.status.max() == 0
-    assert 50 < batch.n_redone < pairs.n
+    assert batch.n_redone > 1000
     assert not compare(prefix, pairs, batch)
 
 

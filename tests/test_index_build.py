@@ -79,3 +79,30 @@ def test_threaded_phases_on_a_repeat_rich_reference():
     c2 = np.tile(rng.integers(0, 4, 5000).astype(np.uint8), 40)    # 200 kb of tandem copies
     prefix, T = build([c1, c2])
     assert (flat_sa(prefix) == doubling_sa(T)).all()
+
+
+def test_flat_suffix_array_from_bwas_sampled_one(tmp_path):
+    """host_expand_sa (host_index.cpp; the device kernel ema_k_sa_expand restates it): bwa's bwt_sa() walk over every row of a stock
+    index (sampled .sa, no .fsa) gives the builder's flat suffix array -- through the host SIMT harness's loader, which keeps the
+    rows in host memory."""
+    import os, shutil
+    import numpy as np
+    import emu_lib
+    from common import small_ref
+    prefix, ctg = small_ref("two_contigs")
+    dst = str(tmp_path / "stock.fa")
+    for ext in (".bwt", ".sa", ".pac", ".ann", ".amb"):
+        shutil.copy(prefix + ext, dst + ext)
+    L = emu_lib.lib()
+    L.emu_index_sa.restype = None
+    n_rows = 2 * sum(len(c) for c in ctg) + 1
+    got = np.zeros(n_rows, dtype=np.uint64)
+    want = np.zeros(n_rows, dtype=np.uint64)
+    for pfx, out in ((dst, got), (prefix, want)):
+        h = emu_lib.index_load(pfx)
+        L.emu_index_sa.argtypes = [emu_lib.C.c_void_p, emu_lib.C.c_void_p, emu_lib.C.c_uint64]
+        L.emu_index_sa(h, out.ctypes.data, n_rows)
+        L.emu_index_free(h)
+    assert (got == want).all()
+    fsa = np.fromfile(prefix + ".fsa", dtype=np.uint32, offset=24).astype(np.uint64)
+    assert (want == fsa).all()

@@ -15,7 +15,7 @@ HIPCC = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shut
 LEAN = {
     "k_align_lane.hip": ["ema_k_align_simple_t<false>"],
     "k_final.hip": ["ema_k_final_t<0>"],
-    "k_seed.hip": ["ema_k_seed_t<false>", "ema_k_seed_t<true>"],
+    "k_seed.hip": ["ema_k_seed_t<false>"],      # (the diagnostic build <true> carries its tick counters in registers: 132)
 }
 
 

@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 VALU_PEAK_GINST = 256 * 4 * 0.5 * 2.4
 CHR20_LEN = 64_444_167
 ENGINE_KNOBS = ("EMA_SEED_ROUNDS", "EMA_SEED_PARK", "EMA_SEED_BLOCKS_PER_CU", "EMA_FULL_SEED_LANE", "EMA_LANE_ALIGN", "EMA_FULL_OWN_STREAM",
-                "EMA_KMER_K", "EMA_HEAVY_CHAINS")
+                "EMA_KMER_K", "EMA_HEAVY_CHAINS", "EMA_SEED_TAIL", "EMA_SEED_LONG_WAVE", "EMA_LEAN_SEED_EXTENDS", "EMA_GRID")
 
 
 def log(*a):
@@ -337,7 +337,8 @@ def main(argv=None):
                          "0 = chr20-scale (64.4 Mbp, one contig: configs[0]'s reference)")
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="pairs of the same workload timed on the host CPU (one socket)")
     ap.add_argument("--streams", type=int, default=0, help="slices of a batch on their own HIP streams (0 = engine default)")
-    ap.add_argument("--lean-seed-extends", type=int, default=0, help="engine option lean_seed_extends (0 = engine default)")
+    ap.add_argument("--lean-seed-extends", type=int, default=int(os.environ.get("EMA_LEAN_SEED_EXTENDS", "0")),
+                    help="engine option lean_seed_extends (0 = engine default; EMA_LEAN_SEED_EXTENDS sets the default for A/B runs)")
     ap.add_argument("--two-sets", action="store_true", help="the older schedule: alternate batches on two sets of batch buffers, one pass each "
                                                             "(default: one set, passes queued up to three deep with the layout and packing on the device)")
     ap.add_argument("--spot-check", type=int, default=24000, help="regular pairs of the timed steps re-aligned by the oracle afterwards (besides "

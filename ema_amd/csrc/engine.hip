@@ -276,7 +276,7 @@ struct ema_engine {
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
-	bool long_wave = true;               // lean slices: reads over K1's extend budget are seeded by K1w in place (EMA_SEED_LONG_WAVE=0: given to the full tier)
+	bool long_wave = false;              // EMA_SEED_LONG_WAVE=1: lean slices' reads over K1's extend budget are seeded by K1w in place (default: given to the full tier)
 	size_t long_cap = 0;                 // room of a lean slice's list of long reads
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices

@@ -12,8 +12,8 @@ BWAABI = $(if $(wildcard $(CSRC)/bwaabi.cpp),ema_amd/libema_bwaabi.so)
 all: ema_amd/libema_index.so ema_amd/libema_engine.so $(BWAABI) oracle
 test-libs: all ema_amd/libema_engine_ss16.so
 
-ema_amd/libema_index.so: $(CSRC)/index_build.cpp
-	$(CXX) $(HOSTFLAGS) -fopenmp -shared -o $@ $< -ldl
+ema_amd/libema_index.so: $(CSRC)/index_build.cpp $(CSRC)/synth_genome.cpp
+	$(CXX) $(HOSTFLAGS) -fopenmp -shared -o $@ $(CSRC)/index_build.cpp $(CSRC)/synth_genome.cpp -ldl -pthread
 
 HIP_SRCS = $(wildcard $(CSRC)/*.hip)
 HOST_SRCS = $(wildcard $(CSRC)/host_*.cpp)

@@ -134,7 +134,7 @@ def build_reference(args, workdir):
     lens, gname = genome_spec(args)
     prefix = os.path.join(workdir, "ref.fa")
     gpath = os.path.join(workdir, "genome.npy")
-    stamp = json.dumps({"lens": lens, "seed": synth.GENOME_SEED, "builder": 2})
+    stamp = json.dumps({"lens": lens, "seed": synth.GENOME_SEED, "builder": 3})
     t = time.time()
     try:
         have_genome = open(prefix + ".gstamp").read() == stamp and os.path.exists(gpath)
@@ -151,7 +151,7 @@ def build_reference(args, workdir):
         for n in lens:
             ctg.append(np.asarray(flat[at:at + n])); at += n
     else:
-        ctg = synth.make_genome(lens, seed=synth.GENOME_SEED)
+        ctg = synth.make_genome_native(lens, seed=synth.GENOME_SEED)      # csrc/synth_genome.cpp: seconds, not the 45 s of numpy's generator
         for e in (".gstamp", ".stamp"):
             if os.path.exists(prefix + e):
                 os.remove(prefix + e)
@@ -405,7 +405,7 @@ def main(argv=None):
     if rank == 0 and args.genome_mbp > 0:
         from ema_amd import synth
         lens, _ = genome_spec(args)
-        want = json.dumps({"lens": lens, "seed": synth.GENOME_SEED, "builder": 2})
+        want = json.dumps({"lens": lens, "seed": synth.GENOME_SEED, "builder": 3})
         try:
             have = open(os.path.join(workdir, "ref.fa.stamp")).read() == want      # the index of THIS genome is already there
         except OSError:
@@ -638,9 +638,17 @@ def main(argv=None):
         achieved = k1_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         knobs = [k for k in ENGINE_KNOBS if k in os.environ]
         default_run = (args.pairs == 1048576 and n_slices == 3 and args.lean_seed_extends == 0 and not knobs)
-        traffic, traffic_source = None, None
-        pmc_name = {0.0: "r03_pmc_chr20.csv", 3100.0: "r03_pmc_grch38scale.csv"}.get(float(args.genome_mbp))
+        traffic, traffic_source, traffic_stale = None, None, None
+        pmc_name = next((n for n in ({0.0: ("r04_pmc_chr20.csv", "r03_pmc_chr20.csv"), 3100.0: ("r04_pmc_grch38scale.csv", "r03_pmc_grch38scale.csv")}
+                                     .get(float(args.genome_mbp), ())) if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         tab = pmc_table(pmc_name) if (pmc_name and default_run) else None
+        if tab:      # do the stored counters describe THESE kernels?  (tools/kernel_hash.py beside the table; none stored = unknown = stale)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_hash import kernel_sources_hash
+            try:
+                traffic_stale = open(os.path.join(ROOT, "profiles", pmc_name + ".srchash")).read().split()[0] != kernel_sources_hash()
+            except (OSError, IndexError):
+                traffic_stale = True
         k1_name = next((k for k in ("ema_k_seed_t<false>", "ema_k_seed") if tab and (k, "FETCH_SIZE") in tab and (k, "WRITE_SIZE") in tab), None)
         if k1_name:      # (the product build of the template, or the plain kernel of older profiles)
             series = eng.seed_launches_per_series()
@@ -648,7 +656,7 @@ def main(argv=None):
             traffic = int(kb * 1024)
             traffic_source = f"profiles/{pmc_name} (separate FETCH_SIZE and WRITE_SIZE passes of this command; stored, not measured in this run)"
         roofline = {"bound": "hbm", "kernel": "ema_k_seed", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "traffic_source_stale": traffic_stale,
                     "algorithmic_bytes_per_launch": int(k1_bytes), "kernel_ms": round(dom_ms, 3),
                     "note": f"one launch (series) = one of {n_slices} slices of a batch; mean over the {args.steps} timed steps, in which "
                             f"launches of different slices, kernels and batches run concurrently and share the chip -- 'isolated' is the "
@@ -667,7 +675,7 @@ def main(argv=None):
             a = k[k.index("<") + 1:k.rindex(">")].split(";") if "<" in k else []
             return a[3] if len(a) > 3 else "0"
         k2_main = [k for k in k2_names if k2_mode(k) == "0"]
-        if k2_names and k2_main and kernel_ms_isolated:
+        if k2_names and k2_main and kernel_ms_isolated and not traffic_stale:      # (a stale instruction count would describe other kernels)
             insts = sum(tab[(k, "SQ_INSTS_VALU")][0] for k in k2_names)
             launches = max(tab[(k, "SQ_INSTS_VALU")][1] for k in k2_main)
             per_launch = insts / launches
@@ -716,8 +724,9 @@ def main(argv=None):
                                    f"{n_batches} distinct batches of {args.pairs} pairs per GPU (one barcode bucket per GPU), inputs staged in HBM "
                                    f"before the timed region, candidates + append_alignments records delivered to host memory inside it "
                                    f"(passes queued up to three deep, result layout and packing on the device); "
-                                   f"{fallback}reference = {gname} with injected repeat families (default: GRCh38-scale, 3.1 Gbp; index built on "
-                                   f"the host cores before the timed region; --genome-mbp 0 = chr20-scale)",
+                                   f"{fallback}reference = {gname} with injected repeat families (default: GRCh38-scale, 3.1 Gbp; genome by "
+                                   f"csrc/synth_genome.cpp, index by ema_index_build with the suffix array sorted on the GPU, both before the timed "
+                                   f"region; --genome-mbp 0 = chr20-scale)",
                        "pairs_per_step_per_gpu": args.pairs, "distinct_batches": n_batches, "buffer_sets": n_sets, "max_occ": 3000,
                        "parallelism": f"buckets x{world}", "engine_knobs_in_env": knobs},
             "boundary": boundary, "engine_resident": resident,
@@ -733,14 +742,16 @@ def main(argv=None):
         out["host"] = {"cpu_seconds_per_million_pairs": round(cpu_s_per_pair * 1e6, 3), "what": "CPU seconds (user + system) of one rank's process over the "
                        "timed region: result assembly of fetched passes and the append_alignments stage on the host's threads",
                        "cpus_granted_to_the_node": node_cpus, "host_threads_per_rank": int(os.environ.get("EMA_HOST_THREADS", "0")) or min(32, node_cpus),
-                       "engine_open_s": round(open_s, 2), "d2h_bytes_per_pair": 350}
+                       "engine_open_s": round(open_s, 2),
+                       "d2h_candidate_bytes_per_pair": round(112 * out["bucket_stats"]["candidates"] / max(1, total_pairs) + 2 * (8 + 8 + 4), 1)}      # 112-byte candidates + per-read layout; CIGAR operations (4 bytes each) come on top
         out["scaling_prediction"] = {
             "status": "PREDICTED from this run's per-GPU rate and host CPU cost; no multi-GPU run has been measured on hardware",
             "per_n_gpus": {str(n): {"gpu_bound_pairs_per_s": round(n * per_gpu, 1),
                                     "host_bound_pairs_per_s": round(node_cpus / cpu_s_per_pair, 1) if cpu_s_per_pair > 0 else None,
                                     "predicted_pairs_per_s": round(min(n * per_gpu, node_cpus / cpu_s_per_pair if cpu_s_per_pair > 0 else n * per_gpu), 1)}
                            for n in (1, 2, 4, 8)},
-            "pcie": "0.35 KB of results per pair: 1.6 GB/s per rank at 4.5 M pairs/s; the index replica (59 GB) is uploaded once per rank in engine_open_s"}
+            "note": "host_bound divides the CPUs granted to the node by ONE rank's CPU seconds per pair over its timed region (all of the process's "
+                    "threads, the Python sink included): a rough bound"}
         out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not (args.no_extras or args.no_sam_leg) else None
         print(json.dumps(out), flush=True)
     eng.close()

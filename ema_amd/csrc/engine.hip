@@ -29,6 +29,7 @@
 #include <vector>
 #include "ema_engine.h"
 #include "dev_types.h"
+#include "dev_merge.h"
 #include "host_index.h"
 #include "opts.h"
 #include "host_cpuacct.h"
@@ -47,6 +48,9 @@ extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, con
 
 extern "C" void ema_launch_kmer_level(const DevIndex *ix, int L, uint64_t *wide, uint64_t *narrow, int *overflow, hipStream_t stream);
 extern "C" void ema_launch_sa_expand(const DevIndex *ix, const uint64_t *sampled, int shift, void *sa_out, int width, uint64_t row0, uint64_t n, hipStream_t stream);
+extern "C" void ema_launch_merge(const MergeParts *P, int n_reads, const int *redo, int redo_cap, int *redo_idx, uint32_t *src, int *m_c, int *m_g,
+                                 uint2 *block_tot, uint64_t *tot, int *status_out, uint64_t *cand_off, uint64_t *cig_off, ema_cand_t *cand,
+                                 uint32_t *cigar, uint64_t cand_cap, uint64_t cigar_cap, hipStream_t stream);
 extern "C" size_t ema_text2_words(int64_t l_pac);
 extern "C" void ema_launch_text2(const uint8_t *pac, int64_t l_pac, uint64_t *text2, hipStream_t stream);
 extern "C" size_t ema_align_slab_bytes();
@@ -216,6 +220,58 @@ struct Slice {
 
 }  // namespace
 
+// Page-locked landing buffers of ema_engine_fetch_ticket.  A fetched batch is not assembled in malloc'd memory any more: the five
+// arrays of the device-side layout are downloaded into one of these sets and the ema_batch_out handed to the caller POINTS INTO it;
+// ema_batch_free gives the set back (no allocation, no page faults, no copy per batch in the steady state).  The pool outlives its
+// engine while batches are outstanding (reference count), and sets returned after the engine closed are freed at once.
+struct PinSet {
+	int kind = 2;      // first member of whatever ema_batch_out.view_of points to: 1 = BatchShare (a view), 2 = PinSet (a pooled batch)
+	struct PinPool *pool = nullptr;
+	PinBuf<uint64_t> cand_off;
+	PinBuf<int> status;
+	PinBuf<uint32_t> redone, cigar;
+	PinBuf<ema_cand_t> cand;
+	void release() { cand_off.release(); status.release(); redone.release(); cigar.release(); cand.release(); }
+};
+struct PinPool {
+	std::mutex mu;
+	std::vector<PinSet *> idle;
+	int refs = 1;          // the engine's + one per set handed out
+	bool closed = false;
+	PinSet *take()
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		PinSet *s;
+		if (!idle.empty()) { s = idle.back(); idle.pop_back(); }
+		else { s = new PinSet(); s->pool = this; }
+		++refs;
+		return s;
+	}
+	static void give(PinSet *s)      // from ema_batch_free, any thread
+	{
+		PinPool *p = s->pool;
+		bool last;
+		{
+			std::lock_guard<std::mutex> lk(p->mu);
+			if (p->closed) { s->release(); delete s; } else p->idle.push_back(s);
+			last = --p->refs == 0;
+		}
+		if (last) delete p;
+	}
+	static void close(PinPool *p)    // from ema_engine_close
+	{
+		bool last;
+		{
+			std::lock_guard<std::mutex> lk(p->mu);
+			p->closed = true;
+			for (PinSet *s : p->idle) { s->release(); delete s; }
+			p->idle.clear();
+			last = --p->refs == 0;
+		}
+		if (last) delete p;
+	}
+};
+
 // The engine's error text.  ema_stream_* call into one engine from two threads (the stager: ema_engine_stage_async; the engine thread:
 // run / fetch) and both may fail at once, so assignment and reading are serialised, and a reader gets its own thread's copy.
 struct ErrText {
@@ -296,6 +352,22 @@ struct ema_engine {
 	struct Ticket { int seq = -1; size_t n_pairs = 0; std::vector<size_t> first, n; };
 	Ticket tickets[EMA_MAX_INFLIGHT];
 	int next_ticket = 0, n_inflight = 0;
+	// The batch's final layout, made on the device behind the last pack of a pass (k_pack.hip, ema_launch_merge): one set per pass in
+	// flight, and the scratch of the merge itself (one set: merges run one after another on the full tier's stream)
+	struct MergedSet {
+		DevBuf<ema_cand_t> d_cand;
+		DevBuf<uint32_t> d_cigar;
+		DevBuf<uint64_t> d_cand_off, d_cig_off, d_tot;
+		DevBuf<int> d_status;
+		size_t cand_cap = 0, cigar_cap = 0;
+		hipEvent_t done = nullptr;
+		void release() { d_cand.release(); d_cigar.release(); d_cand_off.release(); d_cig_off.release(); d_tot.release(); d_status.release(); if (done) (void)hipEventDestroy(done); done = nullptr; }
+	} merged[EMA_MAX_INFLIGHT];
+	DevBuf<int> d_m_c, d_m_g, d_redo_idx;
+	DevBuf<uint32_t> d_m_src;
+	DevBuf<uint2> d_m_block;
+	bool merged_ready = false, device_merge = true;      // EMA_DEVICE_MERGE=0: round 3's host-side assembly
+	struct PinPool *pin_pool = nullptr;                  // page-locked landing buffers that ARE the batches handed out (below)
 	struct FetchPin { PinBuf<uint64_t> c_off, g_off; PinBuf<int> status; PinBuf<ema_cand_t> cand; PinBuf<uint32_t> cig; };
 	std::vector<FetchPin> fetch_pin;     // page-locked landing buffers of ema_engine_fetch_ticket, per slice + full tier
 	hipStream_t copy_stream = nullptr, h2d_stream = nullptr;   // device -> host / host -> device copies of the async path (never behind a kernel)
@@ -576,6 +648,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_SEED_LONG_WAVE")) e->long_wave = atoi(v) != 0;
+	if (const char *v = getenv("EMA_DEVICE_MERGE")) e->device_merge = atoi(v) != 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
 	if (const char *v = getenv("EMA_HEAVY_ATTEMPTS")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
@@ -637,6 +710,9 @@ void ema_engine_close(ema_engine_t *e)
 	if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
 	for (auto &ev : e->slot_free) if (ev) (void)hipEventDestroy(ev);
 	e->d_k1w_args.release();
+	for (auto &m : e->merged) m.release();
+	e->d_m_c.release(); e->d_m_g.release(); e->d_redo_idx.release(); e->d_m_src.release(); e->d_m_block.release();
+	if (e->pin_pool) { PinPool::close(e->pin_pool); e->pin_pool = nullptr; }
 	e->h_nt4.release(); e->h_off.release();
 	for (auto &fp : e->fetch_pin) { fp.c_off.release(); fp.g_off.release(); fp.status.release(); fp.cand.release(); fp.cig.release(); }
 	e->d_occ.release(); e->d_sa.release(); e->d_pac.release(); e->d_ctg.release(); e->d_ctg_alt.release(); e->d_ctg_tab.release(); e->d_kmer_wide.release(); e->d_kmer_narrow.release(); e->d_text2.release(); e->d_prof.release(); e->d_rlog.release(); if (e->d_lprof.p) { ema_align_set_light_profile(nullptr); e->d_lprof.release(); }
@@ -1027,6 +1103,24 @@ static int pack_async(ema_engine *e, Slice &s, Slice::OutSet &o, int nr, const i
 	return EMA_OK;
 }
 
+// device buffers of the batch-layout merge: allocated on the first asynchronous pass
+static int merged_alloc(ema_engine *e)
+{
+	if (e->merged_ready) return EMA_OK;
+	const size_t nr = 2 * e->cap_pairs;
+	for (auto &m : e->merged) {
+		m.cand_cap = nr * 6 + 4096; m.cigar_cap = nr * 24 + 4096;      // a bucket averages 1.3 candidates and 3 operations per read
+		HIPCHK(e, m.d_cand.alloc(m.cand_cap)); HIPCHK(e, m.d_cigar.alloc(m.cigar_cap));
+		HIPCHK(e, m.d_cand_off.alloc(nr + 2)); HIPCHK(e, m.d_cig_off.alloc(nr + 2)); HIPCHK(e, m.d_tot.alloc(2)); HIPCHK(e, m.d_status.alloc(nr + 2));
+		HIPCHK(e, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+	}
+	HIPCHK(e, e->d_m_c.alloc(nr + 2)); HIPCHK(e, e->d_m_g.alloc(nr + 2)); HIPCHK(e, e->d_m_src.alloc(nr + 2)); HIPCHK(e, e->d_redo_idx.alloc(e->cap_pairs + 2));
+	HIPCHK(e, e->d_m_block.alloc(nr / 1024 + 2));
+	if (!e->pin_pool) e->pin_pool = new PinPool();
+	e->merged_ready = true;
+	return EMA_OK;
+}
+
 int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
 {
 	if (!e || !ticket) return EMA_EARG;
@@ -1063,6 +1157,24 @@ int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
 	HIPCHK(e, hipEventRecord(e->slot_free[slot], f.stream));
 	HIPCHK(e, hipMemcpyAsync(f.out[j].d_redo.p, e->d_redo_run.p, (f.cap_pairs + 1) * 4, hipMemcpyDeviceToDevice, f.stream));
 	if ((rc = pack_async(e, f, f.out[j], (int)(2 * f.cap_pairs), e->d_redo_run.p))) return rc;
+	if (e->device_merge && e->sl.size() <= 16) {
+		// the batch's final layout, behind every slice's pack and the full tier's, on the full tier's stream
+		if ((rc = merged_alloc(e))) return rc;
+		MergeParts P;
+		memset(&P, 0, sizeof P);
+		const size_t n_sl = e->sl.size();
+		for (size_t k = 0; k <= n_sl; ++k) {
+			const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
+			P.c_off[k] = o.d_cand_off.p; P.g_off[k] = o.d_cig_off.p; P.status[k] = o.d_status.p; P.cand[k] = o.d_cand.p; P.cig[k] = o.d_cigar.p;
+			if (k < n_sl) { P.first_read[k] = (int)(2 * e->sl[k].first_pair); P.n_reads[k] = (int)(2 * e->sl[k].n_pairs); HIPCHK(e, hipStreamWaitEvent(f.stream, o.done, 0)); }
+		}
+		P.n_parts = (int)n_sl + 1;
+		ema_engine::MergedSet &m = e->merged[j];
+		ema_launch_merge(&P, (int)(2 * e->n_pairs), f.out[j].d_redo.p, (int)f.cap_pairs, e->d_redo_idx.p, e->d_m_src.p, e->d_m_c.p, e->d_m_g.p, e->d_m_block.p,
+		                 m.d_tot.p, m.d_status.p, m.d_cand_off.p, m.d_cig_off.p, m.d_cand.p, m.d_cigar.p, m.cand_cap, m.cigar_cap, f.stream);
+		HIPCHK(e, hipGetLastError());
+		HIPCHK(e, hipEventRecord(m.done, f.stream));
+	}
 	e->ran = false; e->ever_ran = true;      // (ran: a synchronous pass whose results ema_engine_fetch may take)
 	++e->n_inflight;
 	*ticket = e->next_ticket++;
@@ -1089,6 +1201,67 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 	hipStream_t cs = e->copy_stream;
 	const size_t n_sl = e->sl.size(), n_reads = 2 * t.n_pairs;
 	Slice &f = e->full;
+	if (e->device_merge && e->merged_ready && n_sl <= 16) {
+		// The layout was made on the device (ema_launch_merge): totals, then five arrays straight into a page-locked set that becomes
+		// the batch.  No assembly on the host.
+		ema_engine::MergedSet &m = e->merged[j];
+		uint64_t tot[2] = {0, 0};
+		std::vector<uint64_t> part_tot(2 * (n_sl + 1), 0);
+		int n_listed = 0;
+		HIPCHK(e, hipStreamWaitEvent(cs, m.done, 0));
+		for (size_t k = 0; k <= n_sl; ++k)
+			HIPCHK(e, hipMemcpyAsync(&part_tot[2 * k], (k < n_sl ? e->sl[k].out[j] : f.out[j]).d_tot.p, 16, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(tot, m.d_tot.p, 16, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipMemcpyAsync(&n_listed, f.out[j].d_redo.p, 4, hipMemcpyDeviceToHost, cs));
+		HIPCHK(e, hipStreamSynchronize(cs));
+		{   // kernel launch durations of this pass (as ema_engine_sync records them for a synchronous one)
+			float sum[4] = {0, 0, 0, 0};
+			for (auto &s : e->sl)
+				for (int k = 0; k < 4; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, s.tev[j][k], s.tev[j][k + 1]) == hipSuccess) { s.ms[k] = ms; sum[k] += ms; } }
+			const float n = (float)e->sl.size();
+			e->timing.seed_ms = sum[0] / n; e->timing.chain_ms = 0; e->timing.extend_ms = sum[1] / n;
+			e->timing.rescue_ms = sum[2] / n; e->timing.final_ms = sum[3] / n;
+			e->timing.total_ms = (sum[0] + sum[1] + sum[2] + sum[3]) / n;
+			(void)hipEventElapsedTime(&e->timing.full_tier_ms, f.tev[j][0], f.tev[j][4]);
+			for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&e->timing.full_ms[k], f.tev[j][k], f.tev[j][k + 1]);
+		}
+		if (tot[0] > m.cand_cap || tot[1] > m.cigar_cap) { e->err = "the merged result buffers are too small for this batch; use ema_engine_run + ema_engine_fetch"; return EMA_ELIMIT; }
+		for (size_t k = 0; k <= n_sl; ++k) {      // a slice's own packed set must have held its results for the merge to have copied them
+			const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
+			if (part_tot[2 * k] > o.cand_cap || part_tot[2 * k + 1] > o.cigar_cap) { e->err = "the packed result buffers of a slice are too small for this batch; use ema_engine_run + ema_engine_fetch"; return EMA_ELIMIT; }
+		}
+		if (tot[1] >= ((uint64_t)1 << 32)) { e->err = "batch has more than 2^32 CIGAR operations; use smaller batches"; return EMA_ELIMIT; }
+		const size_t n_redo = std::min<size_t>((size_t)n_listed, f.cap_pairs);
+		PinSet *ps = e->pin_pool->take();
+		auto fail = [&](const char *msg, int code) { PinPool::give(ps); e->err = msg; return code; };
+		if (ps->cand_off.reserve(n_reads + 2) != hipSuccess || ps->status.reserve(n_reads + 2) != hipSuccess || ps->redone.reserve(f.cap_pairs + 2) != hipSuccess ||
+		    (tot[0] + 1 > ps->cand.n && ps->cand.reserve((tot[0] + 1) * 5 / 4 + 4096) != hipSuccess) ||
+		    (tot[1] + 1 > ps->cigar.n && ps->cigar.reserve((tot[1] + 1) * 5 / 4 + 4096) != hipSuccess))
+			return fail("out of page-locked host memory", EMA_EDEVICE);
+		bool ok = hipMemcpyAsync(ps->cand_off.p, m.d_cand_off.p, (n_reads + 1) * 8, hipMemcpyDeviceToHost, cs) == hipSuccess;
+		ok = ok && hipMemcpyAsync(ps->status.p, m.d_status.p, n_reads * 4, hipMemcpyDeviceToHost, cs) == hipSuccess;
+		if (tot[0]) ok = ok && hipMemcpyAsync(ps->cand.p, m.d_cand.p, tot[0] * sizeof(ema_cand_t), hipMemcpyDeviceToHost, cs) == hipSuccess;
+		if (tot[1]) ok = ok && hipMemcpyAsync(ps->cigar.p, m.d_cigar.p, tot[1] * 4, hipMemcpyDeviceToHost, cs) == hipSuccess;
+		if (n_redo) ok = ok && hipMemcpyAsync(ps->redone.p, f.out[j].d_redo.p + 1, n_redo * 4, hipMemcpyDeviceToHost, cs) == hipSuccess;
+		ok = ok && hipStreamSynchronize(cs) == hipSuccess;
+		if (!ok) return fail("download of a pass's results failed", EMA_EDEVICE);
+		release.now();
+		ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
+		if (!o) return fail("out of host memory", EMA_EDEVICE);
+		o->n_pairs = t.n_pairs; o->n_redone = n_redo; o->n_cigar = (size_t)tot[1];
+		o->cand_off = ps->cand_off.p; o->status = ps->status.p; o->redone = ps->redone.p; o->cand = ps->cand.p; o->cigar = ps->cigar.p;
+		o->view_of = ps;
+		*out = o;
+		if (o->cand_off[n_reads] != tot[0]) { e->err = "internal: merged layout disagrees with its totals"; return EMA_EDEVICE; }
+		if ((size_t)n_listed > f.cap_pairs) {
+			e->err = "more pairs over the lean capacities than the full-capacity tier holds (ema_engine_opts.full_tier_pairs)";
+			return EMA_ELIMIT;
+		}
+		int any = 0;
+		for (size_t r = 0; r < n_reads; ++r) any |= o->status[r];
+		if (any) { e->err = "a read exceeded an engine capacity; see ema_batch_out.status"; return EMA_ELIMIT; }
+		return EMA_OK;
+	}
 	// totals first
 	std::vector<uint64_t> tot(2 * (n_sl + 1), 0);
 	int n_listed = 0;
@@ -1791,7 +1964,7 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 
 // A view (ema_batch_view, host_stream.cpp: one bucket of a shared pass) owns its offsets and its list of redone pairs only; the batch
 // it looks into goes when its last view does.
-struct BatchShare { ema_batch_out *whole; std::atomic<int> refs; };
+struct BatchShare { int kind = 1; ema_batch_out *whole; std::atomic<int> refs; };      // (kind: see PinSet)
 
 ema_batch_out *ema_batch_view(void **share, ema_batch_out *whole, size_t p0, size_t n)
 {
@@ -1828,6 +2001,12 @@ void ema_batch_share_release(void *share)
 void ema_batch_free(ema_batch_out *out)
 {
 	if (!out) return;
+	if (out->view_of && *(const int *)out->view_of == 2) {      // a pooled batch: its arrays are the page-locked set's
+		PinSet *ps = (PinSet *)out->view_of;
+		free(out);
+		PinPool::give(ps);
+		return;
+	}
 	if (out->view_of) {
 		free(out->cand_off); free(out->redone);
 		void *sh = out->view_of;

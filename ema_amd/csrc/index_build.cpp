@@ -218,6 +218,16 @@ gpu_sa_fn find_gpu_sa()
 	return (gpu_sa_fn)dlsym(h, "ema_gpu_suffix_array");
 }
 
+// which suffix-array builder ran, on stderr -- never silently the slower one
+void say_builder(bool on_gpu, bool gpu_entry_found)
+{
+	const char *v = getenv("EMA_INDEX_GPU");
+	fprintf(stderr, "[ema_index_build] suffix array built %s\n", on_gpu ? "on the GPU (k_sa.hip)"
+	        : (v && atoi(v) == 0) ? "on the host's threads (EMA_INDEX_GPU=0)"
+	        : gpu_entry_found ? "on the host's threads: the GPU builder failed (no device, or not enough device memory)"
+	        : "on the host's threads: libema_engine.so was not found next to this library");
+}
+
 template <typename I>
 int write_index(const std::string &prefix, const Packed &T, const I *sa, const uint8_t *prev = nullptr)      // prev: the GPU builder's BWT symbols per row
 {
@@ -464,6 +474,7 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 		if (!sa.p) return -3;
 		const bool on_gpu = gpu_sa && prev.p && gpu_sa(T.w.data(), T.n, 4, sa.p, prev.p, verbose) == 0;
 		if (!on_gpu) build_sa(T, sa.p);
+		say_builder(on_gpu, gpu_sa != nullptr);
 		lap(on_gpu ? "sa (gpu)" : "sa (host)");
 		return write_index(prefix, T, sa.p, on_gpu ? prev.p : nullptr);
 	} else {
@@ -471,6 +482,7 @@ extern "C" int ema_index_build(const char *fasta, int n_threads)
 		if (!sa.p) return -3;
 		const bool on_gpu = gpu_sa && prev.p && gpu_sa(T.w.data(), T.n, 8, sa.p, prev.p, verbose) == 0;
 		if (!on_gpu) build_sa(T, sa.p);
+		say_builder(on_gpu, gpu_sa != nullptr);
 		lap(on_gpu ? "sa (gpu)" : "sa (host)");
 		return write_index(prefix, T, sa.p, on_gpu ? prev.p : nullptr);
 	}

@@ -6,13 +6,14 @@
 // Three small launches: per-block totals (1024 reads per block), one block turning them into block offsets, per-read offsets.
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
+#include "dev_merge.h"
 
 namespace {
 
 __device__ __forceinline__ void counts_of(int r, int n, const int *status, const int *n_regs, const int *cig_n, unsigned &c, unsigned &g)
 {
 	c = g = 0;
-	if (r < n && status[r] == 0) { c = (unsigned)n_regs[r]; g = (unsigned)cig_n[r]; }
+	if (r < n && (!status || status[r] == 0)) { c = (unsigned)n_regs[r]; g = (unsigned)cig_n[r]; }      // (status null: every read counts)
 }
 
 // exclusive prefix (within the block) of this thread's 4-read run; returns the block totals through LDS
@@ -94,6 +95,76 @@ extern "C" void ema_launch_scan(int n_reads, const int *n_pairs_dev, const int *
 	hipLaunchKernelGGL(ema_k_scan_blocks, dim3(nb), dim3(256), 0, stream, n_reads, n_pairs_dev, status, n_regs, cig_n, block_tot);
 	hipLaunchKernelGGL(ema_k_scan_tops, dim3(1), dim3(256), 0, stream, nb, block_tot, tot);
 	hipLaunchKernelGGL(ema_k_scan_write, dim3(nb), dim3(256), 0, stream, n_reads, n_pairs_dev, status, n_regs, cig_n, block_tot, cand_off, cig_off);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The batch's final layout on the device (ema_engine_fetch_ticket).  A pass leaves one packed result set per slice and one for the
+// full-capacity tier; the batch the caller gets is ONE set in read order, a pair on the full tier's list taking its results from
+// there.  Round 3 cut the sets apart on the host (0.6 CPU-seconds per million pairs: what an 8-GPU node with few CPUs is short
+// of); now three small launches behind the last pack do it -- where every read's results are and how many, the batch-wide
+// offsets (the scan above), the copy with CIGAR offsets rebased -- and the host downloads five arrays into a page-locked buffer
+// that IS the batch.
+// redo[0] = pairs listed, redo[1..] = their batch pair numbers; redo_idx[pair] = place on the list (filled with -1 before)
+__global__ void __launch_bounds__(256)
+ema_k_merge_redo(const int *__restrict__ redo, int cap, int *__restrict__ redo_idx)
+{
+	const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+	const int n = redo[0] < cap ? redo[0] : cap;
+	if (i < n) redo_idx[redo[1 + i]] = i;
+}
+
+__global__ void __launch_bounds__(256)
+ema_k_merge_src(MergeParts P, int n_reads, const int *__restrict__ redo_idx, uint32_t *__restrict__ src, int *__restrict__ m_c, int *__restrict__ m_g,
+                int *__restrict__ status_out)
+{
+	const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+	if (r >= n_reads) return;
+	int part = 0, idx = 0;
+	const int ri = redo_idx[r >> 1];
+	if (ri >= 0) { part = P.n_parts - 1; idx = 2 * ri + (r & 1); }
+	else {
+		for (int k = 0; k < P.n_parts - 1; ++k)
+			if (r >= P.first_read[k] && r < P.first_read[k] + P.n_reads[k]) { part = k; idx = r - P.first_read[k]; }
+	}
+	src[r] = (uint32_t)part << 27 | (uint32_t)idx;
+	m_c[r] = (int)(P.c_off[part][idx + 1] - P.c_off[part][idx]);
+	m_g[r] = (int)(P.g_off[part][idx + 1] - P.g_off[part][idx]);
+	status_out[r] = P.status[part][idx];
+}
+
+__global__ void __launch_bounds__(256)
+ema_k_merge_copy(MergeParts P, int n_reads, const uint32_t *__restrict__ src, const uint64_t *__restrict__ cand_off, const uint64_t *__restrict__ cig_off,
+                 ema_cand_t *__restrict__ cand, uint32_t *__restrict__ cigar, uint64_t cand_cap, uint64_t cigar_cap)
+{
+	const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+	if (r >= n_reads) return;
+	const int part = (int)(src[r] >> 27), idx = (int)(src[r] & 0x7ffffffu);
+	const uint64_t c0 = P.c_off[part][idx], nc = P.c_off[part][idx + 1] - c0, g0 = P.g_off[part][idx], ng = P.g_off[part][idx + 1] - g0;
+	const uint64_t co = cand_off[r], go = cig_off[r];
+	if (co + nc > cand_cap || go + ng > cigar_cap) return;      // (the host checks the totals against the same capacities and fails loudly)
+	const ema_cand_t *sc = P.cand[part] + c0;
+	for (uint64_t k = 0; k < nc; ++k) {
+		ema_cand_t c = sc[k];
+		c.cigar_off = (uint32_t)((uint64_t)c.cigar_off - g0 + go);
+		cand[co + k] = c;
+	}
+	const uint32_t *sg = P.cig[part] + g0;
+	for (uint64_t k = 0; k < ng; ++k) cigar[go + k] = sg[k];
+}
+
+// redo_idx: n_reads / 2 ints; src, m_c, m_g: n_reads words each; status_out, cand_off (n_reads + 1), cig_off (n_reads + 1), tot (2),
+// cand, cigar: the merged set.  block_tot as for ema_launch_scan.
+extern "C" void ema_launch_merge(const MergeParts *P, int n_reads, const int *redo, int redo_cap, int *redo_idx, uint32_t *src, int *m_c, int *m_g,
+                                 uint2 *block_tot, uint64_t *tot, int *status_out, uint64_t *cand_off, uint64_t *cig_off, ema_cand_t *cand,
+                                 uint32_t *cigar, uint64_t cand_cap, uint64_t cigar_cap, hipStream_t stream)
+{
+	if (n_reads <= 0) return;
+	(void)hipMemsetAsync(redo_idx, 0xff, (size_t)(n_reads / 2) * 4, stream);
+	hipLaunchKernelGGL(ema_k_merge_redo, dim3((unsigned)((redo_cap + 255) / 256)), dim3(256), 0, stream, redo, redo_cap, redo_idx);
+	hipLaunchKernelGGL(ema_k_merge_src, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, *P, n_reads, redo_idx, src, m_c, m_g, status_out);
+	ema_launch_scan(n_reads, nullptr, nullptr, m_c, m_g, block_tot, tot, cand_off, cig_off, stream);
+	hipLaunchKernelGGL(ema_k_merge_copy, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, *P, n_reads, src, cand_off, cig_off, cand, cigar,
+	                   cand_cap, cigar_cap);
 }
 
 // Input staging on the device.  A batch arrives as the caller's ASCII bases; one thread per 32 bases of a read turns them into nt4

@@ -76,6 +76,25 @@ def make_genome(contig_lens, seed=GENOME_SEED, short_rep=0.10, long_rep=0.05, se
     return out
 
 
+def make_genome_native(contig_lens, seed=GENOME_SEED, short_rep=0.10, long_rep=0.05, segdup=0.01):
+    """The same model through libema_index.so's ema_synth_genome (csrc/synth_genome.cpp: its own generator, all host threads): a
+    3.1 Gbp reference in a few seconds where make_genome takes 45.  bench.py's reference; the tests keep make_genome."""
+    import ctypes as C
+    import os
+    L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libema_index.so"))
+    L.ema_synth_genome.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_int]
+    total = int(sum(contig_lens))
+    g = np.empty(total, dtype=np.uint8)
+    rc = L.ema_synth_genome(g.ctypes.data, total, seed, short_rep, long_rep, segdup, 0)
+    if rc != 0:
+        raise RuntimeError(f"ema_synth_genome failed ({rc})")
+    out, off = [], 0
+    for n in contig_lens:
+        out.append(g[off:off + n])
+        off += n
+    return out
+
+
 def write_fasta(path, contigs, names=None, width=60):
     names = names or [f"chr{i + 1}" for i in range(len(contigs))]
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)

@@ -372,3 +372,40 @@ def test_bucket_file_to_candidates(tmp_path):
     assert batch.status.max() == 0
     ordered = synth.Pairs(bucket.bases, bucket.off)
     assert not compare(prefix, ordered, batch)
+
+
+def test_chr20_scale_reference_50k_pairs_against_the_oracle():
+    """Parity at the scale of BASELINE configs[0]'s reference: a 64.4 Mbp synthetic chromosome (suffix array built
+    on the GPU), 32,000 pairs of the 10x mix and 20,000 of a rescue-heavy mix (6 % substitutions, ten times the indels, 5 % chimeric:
+    mates that do not seed and are found by mem_matesw, long extensions, gapped final alignments) -- every read's candidate list
+    (regions, positions, NM, CIGARs) against the oracle's, digest against digest (oracle/pair.c, orc_digest_pairs, on every CPU the
+    box grants)."""
+    import os
+    import numpy as np
+    from common import _CACHE
+    import tempfile
+    from ema_amd import build_index
+    if "chr20" not in _CACHE:
+        ctg = synth.make_genome([64_444_167], seed=synth.GENOME_SEED)
+        prefix = os.path.join(tempfile.mkdtemp(prefix="ema_chr20_"), "chr20.fa")
+        synth.write_fasta(prefix, ctg, names=["chr20"])
+        build_index(prefix)
+        _CACHE["chr20"] = (prefix, ctg)
+    prefix, ctg = _CACHE["chr20"]
+    mixes = [synth.make_pairs(ctg, 32000, seed=71), synth.make_pairs(ctg, 20000, seed=72, sub_rate=0.06, indel_rate=0.005, chimeric=0.05)]
+    o = default_opts()
+    o.batch_pairs = 32768
+    eng = Engine(prefix, opts=o)
+    idx, opt = O.Index(prefix), O.default_opt()
+    n_threads = len(os.sched_getaffinity(0))
+    try:
+        for pairs in mixes:
+            batch = eng.align_pairs(pairs.bases, pairs.off)
+            assert batch.status.max() == 0
+            got = O.cand_digest(batch.cand, batch.cigar, batch.cand_off)
+            want, _ = O.digest_pairs(idx, opt, pairs.bases, pairs.off, n_threads)
+            bad = np.nonzero(got != want)[0]
+            assert len(bad) == 0, f"{len(bad)} of {2 * pairs.n} reads differ from the oracle, first: read {int(bad[0])}"
+            assert int(batch.cand_off[-1]) > pairs.n      # (the mixes do align)
+    finally:
+        eng.close()

@@ -151,3 +151,36 @@ def test_a_bad_bucket_stops_the_stream_with_its_name(tmp_path):
         stream.stream_buckets(eng, paths, lambda k, *_: seen.append(k))
     eng.close()
     assert seen == [0] and "ema-bin-001" in str(ei.value)
+
+
+@pytest.mark.parametrize("tiny_lean", [False, True])
+def test_device_side_batch_layout_equals_the_host_assembly(tiny_lean, monkeypatch):
+    """ema_engine_fetch_ticket with the batch laid out on the device (k_pack.hip, ema_launch_merge: slices + full tier -> one set in
+    read order, downloaded into a page-locked buffer that is the batch) against round 3's assembly on the host (EMA_DEVICE_MERGE=0):
+    the same arrays, entry for entry -- with the default lean capacities and with tiny ones, where a third of the pairs come from the
+    full tier's set; batches of assorted sizes so that passes share and split slices."""
+    prefix, ctg = small_ref("repeats")
+    batches = [synth.make_pairs(ctg, n, seed=790 + i, sub_rate=0.01) for i, n in enumerate((700, 64, 1024, 333, 1, 900))]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EMA_DEVICE_MERGE", mode)
+        o = default_opts()
+        o.batch_pairs = 1024
+        if tiny_lean:
+            o.lean_intervals, o.lean_regions, o.lean_cigar_ops, o.full_tier_pairs = 10, 2, 8, 1024
+        eng = Engine(prefix, opts=o)
+        got = {}
+        stream.stream_batches(eng, [(p.bases, p.off) for p in batches], lambda k, _b, batch, rec, po: got.__setitem__(k, (batch, rec, po)))
+        eng.close()
+        res[mode] = got
+    for k, p in enumerate(batches):
+        a, b = res["1"][k], res["0"][k]
+        assert (a[0].cand_off == b[0].cand_off).all() and (a[0].status == b[0].status).all() and (a[0].redone == b[0].redone).all()
+        for f in a[0].cand.dtype.names:
+            if f != "cigar_off":
+                assert (a[0].cand[f] == b[0].cand[f]).all(), (k, f)
+        assert all(a[0].cigar_of(x).tolist() == b[0].cigar_of(y).tolist() for x, y in zip(a[0].cand, b[0].cand))
+        assert (a[1] == b[1]).all() and (a[2] == b[2]).all()      # the append stage's records
+        if tiny_lean and p.n > 100:
+            assert a[0].n_redone > p.n // 10
+    assert not compare(prefix, batches[0], res["1"][0][0])

@@ -28,5 +28,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in rows[-12:]:
         print("  %-40s %8.3f ms  grid %s" % (r["Kernel_Name"][:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Grid_Size", "")))
 PY
+echo "=== lean capacity flags"
+for c in "" "64 64 256" "96 96 384" "48 96 384" "96 48 192"; do timeout 600 python3 "$root/tools/gpu_capdist.py" $c 2>&1 | tail -8; done
 echo "=== extends per read (oracle, CPU)"
 timeout 900 python3 "$root/tools/gpu_k1_profile.py" dist 20000

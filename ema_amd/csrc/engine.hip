@@ -670,8 +670,9 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	for (auto &s : e->sl) {
 		s.cap_pairs = per;
 		s.dopts = e->dopts;
-		s.dopts.intv_cap = std::min(EMA_INTV_CAP, e->opts.lean_intervals > 0 ? e->opts.lean_intervals : EMA_INTV_LEAN);
-		s.dopts.reg_cap = std::min(EMA_REG_CAP, e->opts.lean_regions > 0 ? e->opts.lean_regions : EMA_REG_LEAN);
+		const char *env_i = getenv("EMA_LEAN_INTERVALS"), *env_r = getenv("EMA_LEAN_REGIONS");      // (A/B runs; the options win)
+		s.dopts.intv_cap = std::min(EMA_INTV_CAP, e->opts.lean_intervals > 0 ? e->opts.lean_intervals : env_i && atoi(env_i) > 0 ? atoi(env_i) : EMA_INTV_LEAN);
+		s.dopts.reg_cap = std::min(EMA_REG_CAP, e->opts.lean_regions > 0 ? e->opts.lean_regions : env_r && atoi(env_r) > 0 ? atoi(env_r) : EMA_REG_LEAN);
 		s.dopts.cig_cap = std::min(EMA_CIG_CAP, e->opts.lean_cigar_ops > 0 ? e->opts.lean_cigar_ops : EMA_CIG_LEAN);
 		s.dopts.seed_budget = e->opts.lean_seed_extends > 0 ? e->opts.lean_seed_extends : e->opts.lean_seed_extends < 0 ? 1 << 30
 		                      : e->long_wave ? EMA_SEED_BUDGET_LANE : EMA_SEED_BUDGET_LEAN;

@@ -175,7 +175,8 @@ def test_device_side_batch_layout_equals_the_host_assembly(tiny_lean, monkeypatc
         res[mode] = got
     for k, p in enumerate(batches):
         a, b = res["1"][k], res["0"][k]
-        assert (a[0].cand_off == b[0].cand_off).all() and (a[0].status == b[0].status).all() and (a[0].redone == b[0].redone).all()
+        assert (a[0].cand_off == b[0].cand_off).all() and (a[0].status == b[0].status).all()
+        assert sorted(a[0].redone.tolist()) == sorted(b[0].redone.tolist())      # (the list's order is the order of the collecting atomics)
         for f in a[0].cand.dtype.names:
             if f != "cigar_off":
                 assert (a[0].cand[f] == b[0].cand[f]).all(), (k, f)

@@ -81,8 +81,8 @@ struct Intv { uint64_t x0, x1, x2, info; };
 // per-read capacities of the seeding stage
 #define EMA_INTV_CAP 512      // intervals kept per read
 #define EMA_LIST_CAP 256      // entries of a forward/backward working list (<= read length)
-#define EMA_INTV_LEAN 48      // lean tier (engine.hip): 0.01-0.03 % of reads of the benchmark mix exceed one of these
-#define EMA_REG_LEAN 48
+#define EMA_INTV_LEAN 96      // lean tier (engine.hip).  [r4] 96 / 96 / 192: at the GRCh38 scale 0.5 % of pairs had a read over 48 intervals and 0.2 % one
+#define EMA_REG_LEAN 96       // over 48 regions (tools/gpu_capdist.py); with 96 both are under 0.04 %, and the full tier's pass is a quarter shorter
 #define EMA_CIG_LEAN 192
 #define EMA_SEED_BUDGET_LEAN 4096
 #define EMA_SEED_BUDGET_LANE 2048      // ... when the reads over it are seeded by K1w in place (engine.hip, run_seed) instead of going to the full tier

@@ -408,7 +408,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	if (e->heavy_chains > 0) {
 		// room: a record is ~0.2 KB per chain; a lean slice sets ~2 % of its reads aside (~100 chains each), the full-capacity
 		// tier possibly all of its reads.  Whatever does not fit is extended by K2b itself.
-		const bool full = s.dopts.reg_cap > EMA_REG_LEAN;
+		const bool full = &s == &e->full;
 		const size_t n_hreads = full ? n_reads : std::max<size_t>(4096, n_reads / 8);
 		HIPCHK(e, s.d_heavy_reads.alloc(n_hreads));
 		HIPCHK(e, s.d_heavy_tasks.alloc(full ? (size_t)8 << 20 : (size_t)4 << 20));
@@ -1437,6 +1437,8 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 			fprintf(stderr, " ; %llu %llu %llu %llu ; intervals in order %llu, SA rows + contig ids %llu", h[6], h[7], h[12], h[13], h[14], h[15]);
 			fprintf(stderr, "\nK1: wave-ticks %llu, active lane-ticks %llu (%.1f lanes/tick), clocks per wave-tick %.0f, longest wave %llu ticks\n", h[8], h[9],
 			        h[8] ? (double)h[9] / h[8] : 0., h[8] ? (double)h[10] / h[8] : 0., h[11]);
+			fprintf(stderr, "K1: wave-ticks with a lane asking for rank blocks %llu, a table entry %llu, a tail's row or text %llu (text %llu); phase-A passes per active lane-tick %.3f\n",
+			        h[23], h[24], h[25], h[29], h[9] ? (double)h[30] / h[9] : 0.);
 			if (h[28] > h[26] && h[26] != ~0ULL)
 				fprintf(stderr, "K2b launches so far: first wave in .. work queue dry %.3f Mclk, .. last wave out %.3f Mclk (shader clocks; min / max over the launches since the last report)\n",
 				        (double)(h[27] - h[26]) * 1e-6, (double)(h[28] - h[26]) * 1e-6);

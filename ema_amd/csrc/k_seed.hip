@@ -168,9 +168,11 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	// diagnostic (prof != null): ticks, active lane-ticks and shader clocks of this wave
 	int peak = 0;
 	unsigned long long n_tick = 0, n_active = 0, t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
+	unsigned long long n_pass_lane = 0, n_pass_wave = 0, n_kind[4] = {0, 0, 0, 0};      // (PROF) phase-A passes by lane / by wave; ticks with a rank / table / tail / list-only lane
 	for (;;) {
 		// ---- phase A: control programs, registers and LDS only
 		while (!has_req && !ld_kind && !exhausted) {
+			if (prof) { n_pass_lane += 1; }
 			int ev = 0;                       // 1: push v onto the current list, 2: emit v as a seed interval
 			uint64_t v0 = 0, v1 = 0, v2 = 0;
 			uint32_t v_start = 0, v_end = 0;
@@ -428,7 +430,11 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			}
 			break;
 		}
-		if (prof) { ++n_tick; n_active += __popcll(__ballot(has_req != 0)); }
+		if (prof) {
+			++n_tick; n_active += __popcll(__ballot(has_req != 0));
+			n_kind[0] += __ballot(has_req == 1) != 0; n_kind[1] += __ballot(has_req == 2) != 0; n_kind[2] += __ballot(has_req >= 3) != 0;
+			n_kind[3] += __ballot(has_req == 4) != 0;
+		}
 		// ---- phase B: every global load of the tick, issued together
 		if (ld_kind) {
 			const ulong2 *src = reinterpret_cast<const ulong2 *>(ld_kind == 1 ? wl + ld_at : intv + ld_at);
@@ -529,9 +535,11 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			has_req = 0;
 		}
 	}
+	if (prof) atomicAdd(prof + 30, n_pass_lane);
 	if (prof && lane == 0) {
 		atomicAdd(prof + 8, n_tick); atomicAdd(prof + 9, n_active);
 		atomicAdd(prof + 10, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start)); atomicMax(prof + 11, n_tick);
+		atomicAdd(prof + 23, n_kind[0]); atomicAdd(prof + 24, n_kind[1]); atomicAdd(prof + 25, n_kind[2]); atomicAdd(prof + 29, n_kind[3]);
 	}
 }
 

@@ -116,8 +116,10 @@ typedef struct {
 	int32_t *status;        /* per read (2*n_pairs): 0, or capacity bits (1 intervals, 2 lists, 4 seeds, 8 chains, 16 regions,
 	                         * 32 reference window, 64 CIGAR ops, 128 not redone: full-capacity tier was full, 256 seeding budget); a flagged read has no candidates */
 	uint32_t *redone;       /* n_redone pair indices: the pairs whose results come from the full-capacity tier */
-	void *view_of;          /* private to the library (NULL in a batch of its own): a bucket cut out of a shared pass by ema_stream_* is a
-	                         * VIEW -- cand, cigar and status point into the pass's batch, which lives until its last view is freed */
+	void *view_of;          /* private to the library (NULL in a batch whose arrays are malloc'd): a bucket cut out of a shared pass by
+	                         * ema_stream_* is a VIEW -- cand, cigar and status point into the pass's batch, which lives until its last view
+	                         * is freed; a batch from ema_engine_fetch_ticket points into a pooled page-locked buffer.  Always release a
+	                         * batch with ema_batch_free, never with free() on its members. */
 } ema_batch_out;
 
 /* Whole hot path for a batch: reads are ASCII, read r at bases[off[r] .. off[r+1]);
@@ -147,7 +149,9 @@ int ema_engine_stage_slot(ema_engine_t *e, int slot, const char *bases, const ui
 int ema_engine_run_slot(ema_engine_t *e, int slot);
 /* Asynchronous passes: run_async queues one pass over the batch in `slot`, with the result layout and the packing done on the
  * device in the pass's own streams, and returns a ticket; the next pass may be queued at once (EMA_MAX_INFLIGHT in flight), and
- * fetch_ticket waits for one pass, downloads and assembles its batch while the following pass runs.  stage_async stages a
+ * fetch_ticket waits for one pass and downloads its batch while the following pass runs (the batch's layout -- slices and
+ * full-capacity tier merged in read order -- is made on the device behind the pass; the arrays of the ema_batch_out it returns
+ * lie in a page-locked buffer the engine recycles when ema_batch_free is called on it).  stage_async stages a
  * slot for this path: it waits only for the last pass that read that slot and leaves the passes in flight alone.  This is the
  * form ema_stream_* (include/ema_stream.h) drives: staging of batch k+1, kernels of batch k and fetching of batch k-1 overlap
  * on one set of batch buffers. */

@@ -38,8 +38,9 @@
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
-                                int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, int n_blocks, hipStream_t stream,
-                                unsigned long long *prof);
+                                int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, const int *order, int n_blocks,
+                                hipStream_t stream, unsigned long long *prof);
+extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, hipStream_t stream);
 extern "C" size_t ema_seed_park_bytes();
 extern "C" int ema_seed_wave_blocks_per_cu();
 extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
@@ -174,6 +175,7 @@ struct Slice {
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo;
+	DevBuf<int> d_order;                          // lean slices: the order in which K1 takes the reads, long ones first (k_seed.hip, ema_k_seed_order); counts in d_counters [5..6]
 	DevBuf<int> d_long;                           // lean slices: the reads K1 gave up over its extend budget, for K1w (run_seed); d_counters [18] counts them
 	DevBuf<DevReg> d_regs;
 	DevBuf<uint8_t> d_heavy;                      // chain-rich reads set aside by K2b: records (dev_types.h, HeavyCtl)
@@ -206,7 +208,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_long.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
+		d_status.release(); d_long.release(); d_order.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -332,6 +334,7 @@ struct ema_engine {
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
+	bool seed_order = true;              // lean slices: K1 takes the reads expected to be long first (EMA_SEED_ORDER=0: in input order)
 	bool long_wave = false;              // EMA_SEED_LONG_WAVE=1: lean slices' reads over K1's extend budget are seeded by K1w in place (default: given to the full tier)
 	size_t long_cap = 0;                 // room of a lean slice's list of long reads
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
@@ -400,6 +403,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
 	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
+	if (&s != &e->full && e->seed_order) HIPCHK(e, s.d_order.alloc(n_reads));
 	if (&s != &e->full && e->long_wave) { e->long_cap = std::max<size_t>(1024, n_reads / 8); HIPCHK(e, s.d_long.alloc(e->long_cap)); }
 	HIPCHK(e, s.d_counters.alloc(48));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts; [18] long reads listed, [19] K1w's queue over them
 	                                        // [26] reads set aside, [27] their chain tasks, [28..29] work queues of K2c, K2d, [30..31] arena bytes used (u64)
@@ -648,6 +652,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_SEED_LONG_WAVE")) e->long_wave = atoi(v) != 0;
+	if (const char *v = getenv("EMA_SEED_ORDER")) e->seed_order = atoi(v) != 0;
 	if (const char *v = getenv("EMA_DEVICE_MERGE")) e->device_merge = atoi(v) != 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
@@ -894,6 +899,11 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 		watchdog(e, s, "ema_k_seed_wave");
 		return EMA_OK;
 	}
+	const bool ordered = s.d_order.p && &s != &e->full && e->dix.kmer_k > 0;
+	if (ordered) {
+		ema_launch_seed_order(&e->dix, w.qpack, w.off, 2 * w.n_pairs, s.d_order.p, s.d_counters.p + 5, s.stream);
+		HIPCHK(e, hipGetLastError());
+	}
 	// a series of launches: fresh reads first, then the machines the retiring waves of the previous launch parked
 	const int rounds = e->seed_rounds;
 	for (int r = 0; r < rounds; ++r) {
@@ -903,7 +913,8 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 		ema_launch_seed(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
 		                s.d_lists.p, r == 0 ? s.d_counters.p + 3 : s.d_counters.p + 8 + r, r == 0 ? nullptr : s.d_park[in].p,
 		                s.d_counters.p + 16 + in, last ? nullptr : s.d_park[out].p, s.d_counters.p + 16 + out,
-		                last ? 0 : e->seed_park_max, s.d_long.p, s.d_counters.p + 18, (int)(s.d_long.p ? e->long_cap : 0), e->seed_blocks, s.stream, e->d_prof.p);
+		                last ? 0 : e->seed_park_max, s.d_long.p, s.d_counters.p + 18, (int)(s.d_long.p ? e->long_cap : 0), ordered ? s.d_order.p : nullptr,
+		                e->seed_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
 	watchdog(e, s, "ema_k_seed");

@@ -126,7 +126,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
            int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
            int *__restrict__ counter, const SeedPark *__restrict__ park_in, const int *__restrict__ n_park_in,
            SeedPark *__restrict__ park_out, int *__restrict__ n_park_out, int park_max, int *__restrict__ long_list,
-           int *__restrict__ n_long, int long_cap, unsigned long long *prof_arg)
+           int *__restrict__ n_long, int long_cap, const int *__restrict__ order, unsigned long long *prof_arg)
 {
 	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
@@ -298,6 +298,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				}
 				read = atomicAdd(counter, 1);
 				if (read >= n_tasks) { read = -1; exhausted = true; break; }
+				if (order && !park_in) read = order[read];      // the reads expected to be long first (ema_k_seed_order below)
 				if (park_in) {      // resume a parked machine: it waits for its extend / entry load
 					const SeedPark &k = park_in[read];
 					last_curr_size = k.last_curr_size; c0 = k.c0; c1 = k.c1; c2 = k.c2; f0 = k.f0; f1 = k.f1; f2 = k.f2;
@@ -551,17 +552,58 @@ extern "C" size_t ema_seed_park_bytes() { return sizeof(SeedPark); }
 extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off,
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
-                                int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, int n_blocks, hipStream_t stream,
-                                unsigned long long *prof)
+                                int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, const int *order, int n_blocks,
+                                hipStream_t stream, unsigned long long *prof)
 {
 	if (prof)
 		hipLaunchKernelGGL(ema_k_seed_t<true>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
 		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, long_list, n_long,
-		                   long_cap, prof);
+		                   long_cap, order, prof);
 	else
 		hipLaunchKernelGGL(ema_k_seed_t<false>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
 		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, long_list, n_long,
-		                   long_cap, prof);
+		                   long_cap, order, prof);
+}
+
+// The order in which K1 takes a slice's reads: the ones expected to be LONG first.  A launch series is as long as its bulk plus
+// the tail of the last long reads -- a read from a repeat family needs 2,000-4,000 dependent ticks, and one that comes up when the
+// queue is nearly empty finishes on an empty chip 20 ms after everybody else (half of K1's isolated time, r04).  What makes a read
+// long is repeats, and the k-mer table knows them: a read is taken first when one of six k-mers (k = min(kmer_k, 12): a level the
+// caches hold) spread over it occurs more than four times as often as a random one would (on the benchmark mix that is a tenth of
+// the reads holding more than nine tenths of those over 1,500 extends).  order[]: those reads from the front, the others from the
+// back; cnt[0], cnt[1] = how many of each (zero on entry).  Results do not depend on the order (every read's slots are its own).
+__global__ void __launch_bounds__(256)
+ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads, int *__restrict__ order, int *__restrict__ cnt)
+{
+	const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+	if (r >= n_reads) return;
+	const int K = ix.kmer_k < 12 ? ix.kmer_k : 12;
+	const int len = (int)(off[r + 1] - off[r]);
+	const uint32_t *q = qpack + (size_t)r * 24;
+	uint64_t worst = 0;
+	if (len >= K) {
+#pragma unroll
+		for (int j = 0; j < 6; ++j) {
+			const int p = j < 5 ? (int)((long)len * j / 5) : len - K;
+			if (p + K > len) continue;
+			const int wq = p >> 4, wn = p >> 5;
+			const uint64_t nn = (uint64_t)(wn < 7 ? q[16 + wn + 1] : 0u) << 32 | q[16 + wn];
+			if ((uint32_t)(nn >> (p & 31)) & ((1u << K) - 1u)) continue;      // an ambiguous base in the k-mer
+			const uint64_t qq = (uint64_t)(wq < 15 ? q[wq + 1] : 0u) << 32 | q[wq];
+			const uint32_t code = seed_rev_groups((uint32_t)(qq >> ((p & 15) << 1))) >> (32 - 2 * K);
+			uint64_t x0, x2;
+			ema_kmer_lookup(ix, K, code, x0, x2);
+			worst = x2 > worst ? x2 : worst;
+		}
+	}
+	const uint64_t expected = (ix.seq_len >> (2 * K)) + 1;
+	if (worst > 4 * expected) order[atomicAdd(cnt, 1)] = r;
+	else order[n_reads - 1 - atomicAdd(cnt + 1, 1)] = r;
+}
+extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, hipStream_t stream)
+{
+	if (n_reads <= 0) return;
+	hipLaunchKernelGGL(ema_k_seed_order, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, *ix, qpack, off, n_reads, order, cnt);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

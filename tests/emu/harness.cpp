@@ -135,6 +135,13 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	std::vector<Intv> lists((size_t)n_blocks * 256 * 2 * EMA_LIST_CAP);
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
+	std::vector<int> emu_order;      // the engine's heavy-first order of the reads (k_seed.hip, ema_k_seed_order), in table mode
+	if (di.kmer_k > 0 && !(getenv("EMU_SEED_ORDER") && atoi(getenv("EMU_SEED_ORDER")) == 0)) {
+		emu_order.assign((size_t)n_reads, -1);
+		int cnt[2] = {0, 0};
+		ema_launch_seed_order(&di, qp.data(), off, n_reads, emu_order.data(), cnt, nullptr);
+		fprintf(stderr, "emu_seed order: %d reads expected long first, %d after them\n", cnt[0], cnt[1]);
+	}
 	{   // the engine's series of launches: fresh reads, then the machines parked by retiring waves (n_blocks < 0: no parking)
 		const int nb = n_blocks < 0 ? -n_blocks : n_blocks, park_max = n_blocks < 0 ? 0 : 40, rounds = n_blocks < 0 ? 1 : 4;
 		lists.assign((size_t)nb * 256 * 2 * EMA_LIST_CAP, Intv());
@@ -147,7 +154,7 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 			if (r >= 2) n_park[out] = 0;
 			ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, lists.data(), &ctr[r],
 			                r == 0 ? nullptr : park[in].data(), &n_park[in], last ? nullptr : park[out].data(), &n_park[out],
-			                last ? 0 : park_max, nullptr, nullptr, 0, nb, nullptr, nullptr);
+			                last ? 0 : park_max, nullptr, nullptr, 0, emu_order.empty() ? nullptr : emu_order.data(), nb, nullptr, nullptr);
 			fprintf(stderr, "emu_seed round %d: parked %d\n", r, last ? 0 : n_park[out]);
 		}
 	}
@@ -213,7 +220,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
 	emu_run_align(di, d, bases, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(), n_blocks);
@@ -256,7 +263,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
@@ -305,7 +312,7 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[4] = {0, 0, 0, 0};
-	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 1, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
 	emu_run_align(di, d, bases, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(), t.status.data(),
 	              slabs.data(), 1);
 	std::vector<int> ptodo(n_pairs + 1); int n_ptodo = 0;

@@ -183,5 +183,5 @@ def test_device_side_batch_layout_equals_the_host_assembly(tiny_lean, monkeypatc
         assert all(a[0].cigar_of(x).tolist() == b[0].cigar_of(y).tolist() for x, y in zip(a[0].cand, b[0].cand))
         assert (a[1] == b[1]).all() and (a[2] == b[2]).all()      # the append stage's records
         if tiny_lean and p.n > 100:
-            assert a[0].n_redone > p.n // 10
+            assert a[0].n_redone > p.n // 20
     assert not compare(prefix, batches[0], res["1"][0][0])

@@ -40,7 +40,8 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
                                 int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, const int *order, int n_blocks,
                                 hipStream_t stream, unsigned long long *prof);
-extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, hipStream_t stream);
+extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, int n_samples,
+                                      int mult4, hipStream_t stream);
 extern "C" size_t ema_seed_park_bytes();
 extern "C" int ema_seed_wave_blocks_per_cu();
 extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
@@ -334,6 +335,7 @@ struct ema_engine {
 	int seed_blocks = 0, align_blocks = 0, pair_blocks = 0, final_blocks = 0, lane_blocks = 0;
 	int seed_wave_blocks = 0;
 	bool wave_seed = true;               // the full-capacity tier seeds with K1w (one wavefront per read); EMA_FULL_SEED_LANE=1: with K1
+	int order_samples = 6, order_mult4 = 16;      // ... by six k-mers per read, one of them over 4x the expected count (EMA_SEED_ORDER="mult4,samples" for sweeps)
 	bool seed_order = true;              // lean slices: K1 takes the reads expected to be long first (EMA_SEED_ORDER=0: in input order)
 	bool long_wave = false;              // EMA_SEED_LONG_WAVE=1: lean slices' reads over K1's extend budget are seeded by K1w in place (default: given to the full tier)
 	size_t long_cap = 0;                 // room of a lean slice's list of long reads
@@ -652,7 +654,13 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
 	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
 	if (const char *v = getenv("EMA_SEED_LONG_WAVE")) e->long_wave = atoi(v) != 0;
-	if (const char *v = getenv("EMA_SEED_ORDER")) e->seed_order = atoi(v) != 0;
+	if (const char *v = getenv("EMA_SEED_ORDER")) {
+		int m4 = 0, ns = 0;
+		const int got = sscanf(v, "%d,%d", &m4, &ns);
+		e->seed_order = got >= 1 && m4 != 0;
+		if (got >= 1 && m4 > 1) e->order_mult4 = m4;      // ("1" = on with the defaults)
+		if (got >= 2 && ns >= 1) e->order_samples = std::min(16, ns);
+	}
 	if (const char *v = getenv("EMA_DEVICE_MERGE")) e->device_merge = atoi(v) != 0;
 	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
 	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
@@ -901,7 +909,7 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 	}
 	const bool ordered = s.d_order.p && &s != &e->full && e->dix.kmer_k > 0;
 	if (ordered) {
-		ema_launch_seed_order(&e->dix, w.qpack, w.off, 2 * w.n_pairs, s.d_order.p, s.d_counters.p + 5, s.stream);
+		ema_launch_seed_order(&e->dix, w.qpack, w.off, 2 * w.n_pairs, s.d_order.p, s.d_counters.p + 5, e->order_samples, e->order_mult4, s.stream);
 		HIPCHK(e, hipGetLastError());
 	}
 	// a series of launches: fresh reads first, then the machines the retiring waves of the previous launch parked

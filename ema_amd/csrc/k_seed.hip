@@ -573,7 +573,8 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
 // the reads holding more than nine tenths of those over 1,500 extends).  order[]: those reads from the front, the others from the
 // back; cnt[0], cnt[1] = how many of each (zero on entry).  Results do not depend on the order (every read's slots are its own).
 __global__ void __launch_bounds__(256)
-ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads, int *__restrict__ order, int *__restrict__ cnt)
+ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads, int *__restrict__ order, int *__restrict__ cnt,
+                 int n_samples, int mult4)
 {
 	const int r = (int)(blockIdx.x * 256 + threadIdx.x);
 	if (r >= n_reads) return;
@@ -582,10 +583,8 @@ ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t
 	const uint32_t *q = qpack + (size_t)r * 24;
 	uint64_t worst = 0;
 	if (len >= K) {
-#pragma unroll
-		for (int j = 0; j < 6; ++j) {
-			const int p = j < 5 ? (int)((long)len * j / 5) : len - K;
-			if (p + K > len) continue;
+		for (int j = 0; j < n_samples; ++j) {
+			const int p = (int)((long)(len - K) * j / (n_samples > 1 ? n_samples - 1 : 1));      // spread over the read, the last one at its end
 			const int wq = p >> 4, wn = p >> 5;
 			const uint64_t nn = (uint64_t)(wn < 7 ? q[16 + wn + 1] : 0u) << 32 | q[16 + wn];
 			if ((uint32_t)(nn >> (p & 31)) & ((1u << K) - 1u)) continue;      // an ambiguous base in the k-mer
@@ -597,13 +596,15 @@ ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t
 		}
 	}
 	const uint64_t expected = (ix.seq_len >> (2 * K)) + 1;
-	if (worst > 4 * expected) order[atomicAdd(cnt, 1)] = r;
+	if (4 * worst > (uint64_t)mult4 * expected) order[atomicAdd(cnt, 1)] = r;
 	else order[n_reads - 1 - atomicAdd(cnt + 1, 1)] = r;
 }
-extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, hipStream_t stream)
+// n_samples k-mers per read (<= 16); a read goes first when one of them occurs more than mult4 / 4 times the expected count
+extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, int n_samples,
+                                      int mult4, hipStream_t stream)
 {
 	if (n_reads <= 0) return;
-	hipLaunchKernelGGL(ema_k_seed_order, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, *ix, qpack, off, n_reads, order, cnt);
+	hipLaunchKernelGGL(ema_k_seed_order, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, *ix, qpack, off, n_reads, order, cnt, n_samples, mult4);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

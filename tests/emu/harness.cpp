@@ -139,7 +139,7 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	if (di.kmer_k > 0 && !(getenv("EMU_SEED_ORDER") && atoi(getenv("EMU_SEED_ORDER")) == 0)) {
 		emu_order.assign((size_t)n_reads, -1);
 		int cnt[2] = {0, 0};
-		ema_launch_seed_order(&di, qp.data(), off, n_reads, emu_order.data(), cnt, nullptr);
+		ema_launch_seed_order(&di, qp.data(), off, n_reads, emu_order.data(), cnt, 6, 16, nullptr);
 		fprintf(stderr, "emu_seed order: %d reads expected long first, %d after them\n", cnt[0], cnt[1]);
 	}
 	{   // the engine's series of launches: fresh reads, then the machines parked by retiring waves (n_blocks < 0: no parking)

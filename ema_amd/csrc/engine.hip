@@ -40,8 +40,8 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
                                 int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, const int *order, int n_blocks,
                                 hipStream_t stream, unsigned long long *prof);
-extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, uint8_t *cls, int *cnt,
-                                      int n_samples, int mult4, hipStream_t stream);
+extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, int n_samples,
+                                      int mult4, hipStream_t stream);
 extern "C" size_t ema_seed_park_bytes();
 extern "C" int ema_seed_wave_blocks_per_cu();
 extern "C" void ema_launch_seed_wave(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
@@ -176,7 +176,6 @@ struct Slice {
 	DevOpts dopts;                    // the engine's options with this tier's per-read capacities
 	DevBuf<Intv> d_intv, d_lists;
 	DevBuf<int> d_n_intv, d_status, d_n_regs, d_counters, d_cig_n, d_kdone, d_todo;
-	DevBuf<int> d_order_cnt;                      // ... its class sizes and cursors
 	DevBuf<int> d_order;                          // lean slices: the order in which K1 takes the reads, long ones first (k_seed.hip, ema_k_seed_order); counts in d_counters [5..6]
 	DevBuf<int> d_long;                           // lean slices: the reads K1 gave up over its extend budget, for K1w (run_seed); d_counters [18] counts them
 	DevBuf<DevReg> d_regs;
@@ -210,7 +209,7 @@ struct Slice {
 	void release()
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
-		d_status.release(); d_long.release(); d_order.release(); d_order_cnt.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
+		d_status.release(); d_long.release(); d_order.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -406,7 +405,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
 	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
-	if (&s != &e->full && e->seed_order) { HIPCHK(e, s.d_order.alloc(n_reads + n_reads / 4 + 16)); HIPCHK(e, s.d_order_cnt.alloc(16)); }      // order[], then one class byte per read
+	if (&s != &e->full && e->seed_order) HIPCHK(e, s.d_order.alloc(n_reads));
 	if (&s != &e->full && e->long_wave) { e->long_cap = std::max<size_t>(1024, n_reads / 8); HIPCHK(e, s.d_long.alloc(e->long_cap)); }
 	HIPCHK(e, s.d_counters.alloc(48));      // [0..3] work queues of K2, K3, K4, K1; [8..15] K1 resume launches; [16..17] parked counts; [18] long reads listed, [19] K1w's queue over them
 	                                        // [26] reads set aside, [27] their chain tasks, [28..29] work queues of K2c, K2d, [30..31] arena bytes used (u64)
@@ -910,8 +909,7 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 	}
 	const bool ordered = s.d_order.p && &s != &e->full && e->dix.kmer_k > 0;
 	if (ordered) {
-		HIPCHK(e, hipMemsetAsync(s.d_order_cnt.p, 0, 16 * 4, s.stream));
-		ema_launch_seed_order(&e->dix, w.qpack, w.off, 2 * w.n_pairs, s.d_order.p, (uint8_t *)(s.d_order.p + 2 * w.n_pairs), s.d_order_cnt.p, e->order_samples, e->order_mult4, s.stream);
+		ema_launch_seed_order(&e->dix, w.qpack, w.off, 2 * w.n_pairs, s.d_order.p, s.d_counters.p + 5, e->order_samples, e->order_mult4, s.stream);
 		HIPCHK(e, hipGetLastError());
 	}
 	// a series of launches: fresh reads first, then the machines the retiring waves of the previous launch parked

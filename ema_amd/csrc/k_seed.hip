@@ -565,19 +565,19 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
 		                   long_cap, order, prof);
 }
 
-// The order in which K1 takes a slice's reads: the ones expected to be LONG first, the longest of them first of all.  A launch series
-// is as long as its bulk plus the tail of the last long reads -- a read from a repeat family needs 2,000-4,000 dependent ticks, and
-// one that comes up when the queue is nearly empty finishes on an empty chip 20 ms after everybody else (half of K1's isolated
-// time, r04).  What makes a read long is repeats, and the k-mer table knows them: a read's score is the largest occurrence count
-// among n_samples k-mers (k = min(kmer_k, 12): a level the caches hold) spread over it, relative to what a random k-mer would have;
-// reads go into EMA_ORDER_CLASSES classes by that ratio (>= mult4/4 x 16, x 8, x 4, x 2, x 1, below) and are taken class by
-// class.  (Measured, r04i/j: a SELECTIVE first class matters more than a complete one -- lowering the threshold so that a fifth
-// of the reads go "first" loses what the order gained.)  Two launches: classes and their sizes, then every read's place.
-// order[]: n_reads entries; cnt[]: 2 * EMA_ORDER_CLASSES ints, zero on entry (sizes, then cursors); cls[]: n_reads bytes.
-// Results do not depend on the order (every read's slots are its own).
-#define EMA_ORDER_CLASSES 6
+// The order in which K1 takes a slice's reads: the ones expected to be LONG first.  A launch series is as long as its bulk plus
+// the tail of the last long reads -- a read from a repeat family needs 2,000-4,000 dependent ticks, and one that comes up when the
+// queue is nearly empty finishes on an empty chip 20 ms after everybody else (half of K1's isolated time, r04).  What makes a read
+// long is repeats, and the k-mer table knows them: a read is taken first when one of six k-mers (k = min(kmer_k, 12): a level the
+// caches hold) spread over it occurs more than four times as often as a random one would (on the benchmark mix that is a tenth of
+// the reads holding more than nine tenths of those over 1,500 extends).  order[]: those reads from the front, the others from the
+// back; cnt[0], cnt[1] = how many of each (zero on entry).  Results do not depend on the order (every read's slots are its own).
+// (Measured, r04i-l: a SELECTIVE first class matters -- with the threshold at 2x or 1x the expected count a fifth to a third of the
+// reads go first and the gain is gone (47-52 ms per series against 42); and six classes by the size of the count, longest expected
+// first, do nothing for the launches (42.3 ms) while their per-lane atomics on one counter cost 12 ms: the two-class form stays,
+// whose atomics the compiler folds into one per wavefront.)
 __global__ void __launch_bounds__(256)
-ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads, uint8_t *__restrict__ cls, int *__restrict__ cnt,
+ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads, int *__restrict__ order, int *__restrict__ cnt,
                  int n_samples, int mult4)
 {
 	const int r = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -599,31 +599,16 @@ ema_k_seed_order(DevIndex ix, const uint32_t *__restrict__ qpack, const uint32_t
 			worst = x2 > worst ? x2 : worst;
 		}
 	}
-	const uint64_t expected = (ix.seq_len >> (2 * K)) + 1, unit = (uint64_t)mult4 * expected;      // 4 x the first threshold
-	int c = EMA_ORDER_CLASSES - 1;
-	for (int k = 0; k < EMA_ORDER_CLASSES - 1; ++k)
-		if (4 * worst > (unit << (EMA_ORDER_CLASSES - 2 - k))) { c = k; break; }
-	cls[r] = (uint8_t)c;
-	atomicAdd(cnt + c, 1);
+	const uint64_t expected = (ix.seq_len >> (2 * K)) + 1;
+	if (4 * worst > (uint64_t)mult4 * expected) order[atomicAdd(cnt, 1)] = r;
+	else order[n_reads - 1 - atomicAdd(cnt + 1, 1)] = r;
 }
-__global__ void __launch_bounds__(256)
-ema_k_seed_place(int n_reads, const uint8_t *__restrict__ cls, int *__restrict__ cnt, int *__restrict__ order)
-{
-	const int r = (int)(blockIdx.x * 256 + threadIdx.x);
-	if (r >= n_reads) return;
-	const int c = cls[r];
-	int base = 0;
-	for (int k = 0; k < c; ++k) base += cnt[k];
-	order[base + atomicAdd(cnt + EMA_ORDER_CLASSES + c, 1)] = r;
-}
-
-// n_samples k-mers per read (<= 16); the last class but one starts at mult4 / 4 times the expected count.  cnt: 2 * EMA_ORDER_CLASSES ints (zero on entry)
-extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, uint8_t *cls, int *cnt,
-                                      int n_samples, int mult4, hipStream_t stream)
+// n_samples k-mers per read (<= 16); a read goes first when one of them occurs more than mult4 / 4 times the expected count
+extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, int n_samples,
+                                      int mult4, hipStream_t stream)
 {
 	if (n_reads <= 0) return;
-	hipLaunchKernelGGL(ema_k_seed_order, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, *ix, qpack, off, n_reads, cls, cnt, n_samples, mult4);
-	hipLaunchKernelGGL(ema_k_seed_place, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, n_reads, cls, cnt, order);
+	hipLaunchKernelGGL(ema_k_seed_order, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, *ix, qpack, off, n_reads, order, cnt, n_samples, mult4);
 }
 
 // resident 256-thread blocks per CU for this kernel's register/LDS footprint (sizes the grid and the scratch slabs)

@@ -138,10 +138,9 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 	std::vector<int> emu_order;      // the engine's heavy-first order of the reads (k_seed.hip, ema_k_seed_order), in table mode
 	if (di.kmer_k > 0 && !(getenv("EMU_SEED_ORDER") && atoi(getenv("EMU_SEED_ORDER")) == 0)) {
 		emu_order.assign((size_t)n_reads, -1);
-		int cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-		std::vector<uint8_t> cls((size_t)n_reads);
-		ema_launch_seed_order(&di, qp.data(), off, n_reads, emu_order.data(), cls.data(), cnt, 6, 16, nullptr);
-		fprintf(stderr, "emu_seed order: classes of %d %d %d %d %d %d reads, longest expected first\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5]);
+		int cnt[2] = {0, 0};
+		ema_launch_seed_order(&di, qp.data(), off, n_reads, emu_order.data(), cnt, 6, 16, nullptr);
+		fprintf(stderr, "emu_seed order: %d reads expected long first, %d after them\n", cnt[0], cnt[1]);
 	}
 	{   // the engine's series of launches: fresh reads, then the machines parked by retiring waves (n_blocks < 0: no parking)
 		const int nb = n_blocks < 0 ? -n_blocks : n_blocks, park_max = n_blocks < 0 ? 0 : 40, rounds = n_blocks < 0 ? 1 : 4;

@@ -73,6 +73,8 @@ struct DevOpts {
 	// K1: a read that needs more extends than this is given up with EMA_ST_LONG (lean tier: keeps a launch's tail short;
 	// the full tier has no budget)
 	int seed_budget;
+	// K1: bit 0 = a pass-2 search is skipped when no min_seed_len-base window over its position can be frequent enough (k_seed.hip, "window test")
+	int seed_flags;
 };
 
 // SMEM / seed interval: bwa's bwtintv_t.  info = start<<32 | end.

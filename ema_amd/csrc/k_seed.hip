@@ -59,6 +59,17 @@
 // Pass 3 jumps (table mode): bwt_seed_strategy1 tests nothing before its match is min_seed_len + 1 bases long, so its first
 // min(kmer_k, min_seed_len) bases are ONE table look-up instead of that many dependent ones, a start too close to the read's
 // end for a seed to fit ends the pass, and an ambiguous base inside the first bases moves the start behind it without a look-up.
+//
+// The window test of pass 2 (table mode, DevOpts.seed_flags bit 0).  Re-seeding runs bwt_smem1 from the middle of every long, rare
+// SMEM with min_intv = its occurrences + 1 -- 300 of a read's 740 extends on the benchmark mix -- and nearly always reports
+// NOTHING: what it reports are matches of at least min_seed_len bases over the middle position x that occur min_intv times, and in
+// unique sequence no 19-mer occurs twice.  Any such match contains a window of exactly min_seed_len bases over x that is at least
+// as frequent, so: if no window [e - W, e), x < e <= x + W, W = min_seed_len, reaches min_intv occurrences, the search reports
+// nothing and is skipped -- exactly.  A window is tested from its right end: its last kmer_k bases in one table look-up, then one
+// base to the left per rank query, until the suffix is too rare (length L) or the window is whole (then the search runs as before).
+// A suffix of L bases that is too rare condemns every window that holds it -- right ends e .. e + W - L -- so the next window
+// tested ends at e + W - L + 1 (an ambiguous base condemns the windows that hold it likewise): about six windows of four
+// dependent steps for the usual search instead of 150 extends.  K1's lane-ticks per read 555 -> R4WT on the benchmark mix.
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
 
@@ -67,7 +78,8 @@ namespace {
 // states; the three that wait for an extend have their "result arrived" twin at +1
 enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, PC_BWD_N,
        PC_FWD = 8, PC_FWD_RES, PC_BWD, PC_BWD_RES, PC_S3, PC_S3_RES,
-       PC_TSA_RES, PC_TXT, PC_TXT_RES };      // a tail (below): suffix-array row requested / text to request / text requested
+       PC_TSA_RES, PC_TXT, PC_TXT_RES,        // a tail (below): suffix-array row requested / text to request / text requested
+       PC_WT_NEXT, PC_WT, PC_WT_RES };        // the window test of a pass-2 search (below): next window / one more base to the left / answer
 
 // A machine taken off its lane (see "re-packing" below): everything phase B and the next step need.  The working
 // lists stay where they are -- `wl` is the address of the lane's list slab -- and the read is re-staged from qpack.
@@ -159,6 +171,8 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	const bool tails = kk > 0 && ix.text2 != nullptr;
 	const int jump = kk > 0 && opt.max_mem_intv > 0 ? (kk < opt.min_seed_len ? kk : opt.min_seed_len) : 0;      // pass 3's first look-up
 	const uint64_t n_text = (uint64_t)ix.l_pac << 1;
+	const bool wtest = kk > 0 && (opt.seed_flags & 1) && opt.min_seed_len >= 2 && opt.min_seed_len <= 32;      // pass 2's window test
+	const int wlen = opt.min_seed_len;
 	uint32_t c_code = 0, f_code = 0, r_code = 0, req_code = 0, req_len = 0;      // 2-bit codes of the strings behind c, f, r
 
 	auto q = [&](int p_) -> int {
@@ -234,9 +248,17 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			case PC_P2_RES: {     // pass 2 (re-seeding): a pass-1 SMEM of length >= split_len with at most split_width occurrences
 				const int s = (int)(ent.info >> 32), e = (int)(uint32_t)ent.info;
 				if (e - s < opt.split_len || ent.x2 > (uint64_t)opt.split_width) pc = PC_P2_NEXT;
-				else { sm_x = (s + e) >> 1; min_intv = (int)ent.x2 + 1; start = true; }
+				else {
+					sm_x = (s + e) >> 1; min_intv = (int)ent.x2 + 1;
+					if (wtest) { i = sm_x + 1; pc = PC_WT_NEXT; } else start = true;
+				}
 				break;
 			}
+			case PC_WT_RES:       // window test: the suffix of j bases ending at i has r2 occurrences
+				if (r2 < (uint64_t)min_intv) { i += wlen + 1 - j; pc = PC_WT_NEXT; }      // too rare: so is every window that holds it
+				else if (j >= wlen) start = true;                                         // a whole window is frequent enough: the search runs
+				else { c0 = r0; c2 = r2; pc = PC_WT; }
+				break;
 			case PC_TSA_RES:      // tail: the occurrence's place in the text is known (f0 = the text position of read base i)
 				pc = PC_TXT;
 				break;
@@ -334,6 +356,23 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				st = 0; n_out = 0; pass = 1; x = 0; n_curr = 0; n_ext = 0;
 				if (len >= opt.min_seed_len) pc = PC_P1_NEXT;      // mem_chain: no seeds for a read shorter than min_seed_len
 				break;
+			case PC_WT_NEXT: {    // window test: the next window [i - wlen, i) over sm_x that is not condemned yet
+				if (i < wlen) i = wlen;
+				const int e_hi = sm_x + wlen < len ? sm_x + wlen : len;
+				if (i > e_hi) { pc = PC_P2_NEXT; break; }      // none can be frequent enough: the search would report nothing
+				const int p0 = i - wlen, wn = p0 >> 5;
+				const uint64_t nn = (uint64_t)(wn < 7 ? nm[(wn + 1) << 6] : 0u) << 32 | nm[wn << 6];
+				const uint32_t nbits = (uint32_t)(nn >> (p0 & 31)) & (wlen < 32 ? (1u << wlen) - 1u : ~0u);
+				if (nbits) { i = p0 + (31 - __clz(nbits)) + wlen + 1; break; }      // an ambiguous base: no window that holds it matches anywhere
+				if (++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; break; }
+				const int J = kk < wlen ? kk : wlen, pj = i - J, wq = pj >> 4;
+				const uint64_t qq = (uint64_t)(wq < 15 ? qw[(wq + 1) << 6] : 0u) << 32 | qw[wq << 6];
+				req_code = seed_rev_groups((uint32_t)(qq >> ((pj & 15) << 1))) >> (32 - 2 * J);
+				req_len = (uint32_t)J; req_c = 0; has_req = 2;
+				j = J;
+				pc = PC_WT_RES;
+				break;
+			}
 			case PC_P1_NEXT:      // pass 1: SMEMs from left to right
 				while (x < len && q(x) > 3) ++x;
 				if (x >= len) { pass = 2; old_n = n_out; k2 = 0; pc = PC_P2_NEXT; }
@@ -380,7 +419,11 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				pc = PC_FWD;
 			}
 			// (7) the one place that looks up the next base and posts the extend
-			if (pc == PC_TXT) { has_req = 4; pc = PC_TXT_RES; }
+			if (pc == PC_WT) {      // window test: one more base to the left (the window holds no ambiguous base)
+				if (++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }
+				else { req_c = q(i - j - 1); ++j; has_req = 1; pc = PC_WT_RES; }
+			}
+			else if (pc == PC_TXT) { has_req = 4; pc = PC_TXT_RES; }
 			else if (pc == PC_FWD || pc == PC_BWD || pc == PC_S3) {
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
 				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
@@ -449,7 +492,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			//   table look-up (has_req 2): the entry of the result string (its interval) and, when a forward extension reaches
 			//   the table's last level, the entry of its reverse complement (the reverse-strand coordinate the next rank query
 			//   needs) -- read as 32 bytes each like the blocks (the entries are 16 or 8 bytes; the tables are padded).
-			const bool tab = has_req == 2, back = pc == PC_BWD_RES;
+			const bool tab = has_req == 2, back = pc == PC_BWD_RES || pc == PC_WT_RES;
 			const uint64_t x_nb = back ? c0 : c1, x_b = back ? c1 : c0;
 			const uint64_t pk = x_nb - 1, pl = x_nb - 1 + c2;                    // rows whose occ4 the extend needs
 			const uint64_t qk = pk - (pk >= ix.primary ? 1 : 0), ql = pl - (pl >= ix.primary ? 1 : 0);      // '$' is not stored

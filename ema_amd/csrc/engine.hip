@@ -620,7 +620,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 		HIPCHK(e, e->d_lprof.alloc(48)); HIPCHK(e, hipMemset(e->d_lprof.p, 0, 48 * 8));
 		ema_align_set_light_profile(e->d_lprof.p);
 	} else if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
-		HIPCHK(e, e->d_prof.alloc(32)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 256));
+		HIPCHK(e, e->d_prof.alloc(48)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 384));
 		{ const unsigned long long ones[2] = {~0ULL, ~0ULL}; HIPCHK(e, hipMemcpy(e->d_prof.p + 26, ones, 16, hipMemcpyHostToDevice)); }
 		if (atoi(pp) >= 2) {      // per-read log of K2b (k_align.hip): [0] entries, [1] capacity, records from word 16
 			const int cap = 1 << 22;
@@ -1446,8 +1446,8 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 		}
 	}
 	if (e->d_prof.p) {
-		unsigned long long h[32];
-		if (hipMemcpy(h, e->d_prof.p, 256, hipMemcpyDeviceToHost) == hipSuccess) {
+		unsigned long long h[48];
+		if (hipMemcpy(h, e->d_prof.p, 384, hipMemcpyDeviceToHost) == hipSuccess) {
 			fprintf(stderr, "K2a phase ticks (idle, fetch/stage, chain, filter, chain2aln-ctl, extend-dp, dedup):");
 			for (int i = 0; i < 7; ++i) fprintf(stderr, " %llu", h[16 + i]);
 			fprintf(stderr, "\n");
@@ -1461,6 +1461,9 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 			if (h[28] > h[26] && h[26] != ~0ULL)
 				fprintf(stderr, "K2b launches so far: first wave in .. work queue dry %.3f Mclk, .. last wave out %.3f Mclk (shader clocks; min / max over the launches since the last report)\n",
 				        (double)(h[27] - h[26]) * 1e-6, (double)(h[28] - h[26]) * 1e-6);
+			fprintf(stderr, "K1: active lane-ticks in pass 1 %llu, pass 2 %llu (window tests %llu of them), pass 3 %llu; searches the window test skipped: pass 2 %llu of %llu, pass 1 (backward phases) %llu of %llu\n",
+			        h[32], h[33], h[35], h[34], h[36], h[36] + h[37], h[38], h[38] + h[39]);
+			(void)hipMemset(e->d_prof.p + 32, 0, 128);
 			(void)hipMemset(e->d_prof.p, 0, 248);
 			{ const unsigned long long ones[2] = {~0ULL, ~0ULL}; (void)hipMemcpy(e->d_prof.p + 26, ones, 16, hipMemcpyHostToDevice); }
 		}

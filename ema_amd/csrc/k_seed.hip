@@ -182,7 +182,8 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	// diagnostic (prof != null): ticks, active lane-ticks and shader clocks of this wave
 	int peak = 0;
 	unsigned long long n_tick = 0, n_active = 0, t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
-	unsigned long long n_pass_lane = 0, n_pass_wave = 0, n_kind[4] = {0, 0, 0, 0};      // (PROF) phase-A passes by lane / by wave; ticks with a rank / table / tail / list-only lane
+	unsigned long long n_pass_lane = 0, n_pass_wave = 0, n_kind[4] = {0, 0, 0, 0};
+	unsigned long long n_by_pass[4] = {0, 0, 0, 0}, n_wt[4] = {0, 0, 0, 0};      // (PROF) this lane's ticks by pass / in window tests; searches skipped / run: pass 2, pass 1      // (PROF) phase-A passes by lane / by wave; ticks with a rank / table / tail / list-only lane
 	for (;;) {
 		// ---- phase A: control programs, registers and LDS only
 		while (!has_req && !ld_kind && !exhausted) {
@@ -190,7 +191,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			int ev = 0;                       // 1: push v onto the current list, 2: emit v as a seed interval
 			uint64_t v0 = 0, v1 = 0, v2 = 0;
 			uint32_t v_start = 0, v_end = 0;
-			bool aft = false, nxt = false, start = false;
+			bool aft = false, nxt = false, start = false, wt_done = false;
 			// (1) handlers: the extend result / the loaded entry / a forward phase that cannot go on
 			switch (pc) {
 			case PC_FWD_RES:      // bwt_smem1, forward loop body after bwt_extend(ik, ok, 0)
@@ -256,8 +257,10 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			}
 			case PC_WT_RES:       // window test: the suffix of j bases ending at i has r2 occurrences
 				if (r2 < (uint64_t)min_intv) { i += wlen + 1 - j; pc = PC_WT_NEXT; }      // too rare: so is every window that holds it
-				else if (j >= wlen) start = true;                                         // a whole window is frequent enough: the search runs
-				else { c0 = r0; c2 = r2; pc = PC_WT; }
+				else if (j >= wlen) {      // a whole window is frequent enough: the search (pass 2) / its backward phase (pass 1) runs
+					if (prof) n_wt[pass == 2 ? 1 : 3] += 1;
+					if (pass == 2) start = true; else { aft = true; wt_done = true; }
+				} else { f1 = r0; f2 = r2; pc = PC_WT; }      // (the test's interval lives in f1 / f2, idle outside backward rows, and is parked with them)
 				break;
 			case PC_TSA_RES:      // tail: the occurrence's place in the text is known (f0 = the text position of read base i)
 				pc = PC_TXT;
@@ -296,9 +299,15 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			// (3) forward phase over: its list (longest match = the interval just pushed = c) becomes prev, walked in reverse
 			if (aft) {
 				if (pass == 1) x = (int)c_end;      // bwt_smem1's return value: where the forward extension stopped
-				n_prev = n_curr; n_curr = 0; rev = 1;
-				i = sm_x - 1; j = 0;
-				pc = PC_BWD;
+				if (wtest && pass == 1 && !wt_done && (int)c_end - sm_x < wlen) {
+					// a forward match shorter than a seed (the search that starts ON a mismatch): its backward phase reports something only
+					// if a window of min_seed_len bases over sm_x occurs at all -- the window test, right ends up to the match's end
+					i = sm_x + 1; pc = PC_WT_NEXT;
+				} else {
+					n_prev = n_curr; n_curr = 0; rev = 1;
+					i = sm_x - 1; j = 0;
+					pc = PC_BWD;
+				}
 			}
 			// (4) row entry done: next entry (already in c), next row, or end of the search
 			if (nxt && ++j == n_prev) {
@@ -358,8 +367,13 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				break;
 			case PC_WT_NEXT: {    // window test: the next window [i - wlen, i) over sm_x that is not condemned yet
 				if (i < wlen) i = wlen;
-				const int e_hi = sm_x + wlen < len ? sm_x + wlen : len;
-				if (i > e_hi) { pc = PC_P2_NEXT; break; }      // none can be frequent enough: the search would report nothing
+				const int e_lim = pass == 1 ? (int)c_end : len;      // (pass 1: a window that reaches beyond the forward match holds a string that does not occur)
+				const int e_hi = sm_x + wlen < e_lim ? sm_x + wlen : e_lim;
+				if (i > e_hi) {      // none can be frequent enough: the search (its backward phase) would report nothing
+					if (prof) n_wt[pass == 2 ? 0 : 2] += 1;
+					pc = pass == 1 ? PC_P1_NEXT : PC_P2_NEXT;
+					break;
+				}
 				const int p0 = i - wlen, wn = p0 >> 5;
 				const uint64_t nn = (uint64_t)(wn < 7 ? nm[(wn + 1) << 6] : 0u) << 32 | nm[wn << 6];
 				const uint32_t nbits = (uint32_t)(nn >> (p0 & 31)) & (wlen < 32 ? (1u << wlen) - 1u : ~0u);
@@ -478,6 +492,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			++n_tick; n_active += __popcll(__ballot(has_req != 0));
 			n_kind[0] += __ballot(has_req == 1) != 0; n_kind[1] += __ballot(has_req == 2) != 0; n_kind[2] += __ballot(has_req >= 3) != 0;
 			n_kind[3] += __ballot(has_req == 4) != 0;
+			if (has_req) { n_by_pass[pass == 1 ? 0 : pass == 2 ? 1 : 2] += 1; if (pc == PC_WT_RES) n_by_pass[3] += 1; }
 		}
 		// ---- phase B: every global load of the tick, issued together
 		if (ld_kind) {
@@ -493,8 +508,9 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			//   the table's last level, the entry of its reverse complement (the reverse-strand coordinate the next rank query
 			//   needs) -- read as 32 bytes each like the blocks (the entries are 16 or 8 bytes; the tables are padded).
 			const bool tab = has_req == 2, back = pc == PC_BWD_RES || pc == PC_WT_RES;
-			const uint64_t x_nb = back ? c0 : c1, x_b = back ? c1 : c0;
-			const uint64_t pk = x_nb - 1, pl = x_nb - 1 + c2;                    // rows whose occ4 the extend needs
+			const bool wt = pc == PC_WT_RES;      // (the window test keeps its interval apart, in f1 / f2: pass 1 still needs c)
+			const uint64_t x_nb = wt ? f1 : back ? c0 : c1, x_b = back ? c1 : c0, sz = wt ? f2 : c2;
+			const uint64_t pk = x_nb - 1, pl = x_nb - 1 + sz;                    // rows whose occ4 the extend needs
 			const uint64_t qk = pk - (pk >= ix.primary ? 1 : 0), ql = pl - (pl >= ix.primary ? 1 : 0);      // '$' is not stored
 			const bool want_rc = tab && (int)req_len == kk && !back;
 			const uint4 *p0, *p1, *p2, *p3;      // the tick's four 16-byte loads
@@ -568,7 +584,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				ema_occ4_decode(ix, qk, a0, a1, tk);
 				ema_occ4_decode(ix, ql, b0, b1, tl);
 				const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
-				const uint64_t b3 = x_b + ((x_nb <= ix.primary && x_nb + c2 - 1 >= ix.primary) ? 1 : 0);
+				const uint64_t b3 = x_b + ((x_nb <= ix.primary && x_nb + sz - 1 >= ix.primary) ? 1 : 0);
 				const uint64_t b2 = b3 + s3, b1_ = b2 + s2, b0_ = b1_ + s1;
 				const int cc = req_c & 3;
 				const uint64_t o_b = cc == 3 ? b3 : cc == 2 ? b2 : cc == 1 ? b1_ : b0_;
@@ -579,7 +595,11 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			has_req = 0;
 		}
 	}
-	if (prof) atomicAdd(prof + 30, n_pass_lane);
+	if (prof) {
+		atomicAdd(prof + 30, n_pass_lane);
+		atomicAdd(prof + 32, n_by_pass[0]); atomicAdd(prof + 33, n_by_pass[1]); atomicAdd(prof + 34, n_by_pass[2]); atomicAdd(prof + 35, n_by_pass[3]);
+		atomicAdd(prof + 36, n_wt[0]); atomicAdd(prof + 37, n_wt[1]); atomicAdd(prof + 38, n_wt[2]); atomicAdd(prof + 39, n_wt[3]);
+	}
 	if (prof && lane == 0) {
 		atomicAdd(prof + 8, n_tick); atomicAdd(prof + 9, n_active);
 		atomicAdd(prof + 10, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start)); atomicMax(prof + 11, n_tick);

@@ -73,12 +73,16 @@ struct DevOpts {
 	// K1: a read that needs more extends than this is given up with EMA_ST_LONG (lean tier: keeps a launch's tail short;
 	// the full tier has no budget)
 	int seed_budget;
-	// K1: bit 0 = a pass-2 search is skipped when no min_seed_len-base window over its position can be frequent enough (k_seed.hip, "window test")
+	// K1: bit 0 = a pass-2 search is skipped when no min_seed_len-base window over its position can be frequent enough (k_seed.hip, "window test");
+	// bit 1 = a pass-1 search whose forward match ended as a single occurrence finds its SMEM on the text ("anchors")
 	int seed_flags;
 };
 
 // SMEM / seed interval: bwa's bwtintv_t.  info = start<<32 | end.
 struct Intv { uint64_t x0, x1, x2, info; };
+// K1 may hand a single-occurrence interval over BY POSITION: x1 == EMA_INTV_BYPOS, x2 == 1 and x0 is the occurrence's place in
+// the text (what bwt_sa() would return for the row) instead of the row -- K2 then skips the suffix-array look-up (k_seed.hip, "anchors")
+#define EMA_INTV_BYPOS (1ULL << 63)
 
 // per-read capacities of the seeding stage
 #define EMA_INTV_CAP 512      // intervals kept per read

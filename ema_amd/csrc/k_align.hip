@@ -636,7 +636,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				my_step = p.x2 > (uint64_t)opt.max_occ ? (int64_t)(p.x2 / (uint64_t)opt.max_occ) : 1;
 				int64_t n_occ = ((int64_t)p.x2 + my_step - 1) / my_step;        // k = 0, step, ... < size
 				if (n_occ > opt.max_occ) n_occ = opt.max_occ;
-				my_nocc = (int)n_occ; my_x0 = p.x0;
+				my_nocc = (int)n_occ; my_x0 = p.x0 | (p.x1 == EMA_INTV_BYPOS ? EMA_INTV_BYPOS : 0);      // (an interval K1 hands over by position: its one occurrence's place, marked)
 			}
 			int ci = 0, ck = 0;      // next occurrence: number ck of interval ci of the chunk
 			while (ci < chunk_n) {
@@ -656,7 +656,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				}
 				int64_t rbeg = 0; int rid = -1;
 				if (lane < filled) {      // consecutive suffix-array rows within an interval (step 1) -> coalesced loads
-					rbeg = (int64_t)ema_sa(ix, a_row);
+					rbeg = (a_row & EMA_INTV_BYPOS) ? (int64_t)(a_row & ~EMA_INTV_BYPOS) : (int64_t)ema_sa(ix, a_row);
 					rid = ema_intv2rid(ix, rbeg, rbeg + a_l);
 				}
 				EMA_PHASE(1);      // 1: the insertions

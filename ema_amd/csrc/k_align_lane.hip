@@ -311,7 +311,7 @@ ema_k_align_simple_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpac
 			const Intv p = raw[s.ord[i]];
 			const int qbeg = (int)(p.info >> 32), slen = (int)((uint32_t)p.info - (uint32_t)(p.info >> 32));
 			for (int64_t k = 0; k < (int64_t)p.x2; ++k) {
-				const int64_t rbeg = (int64_t)ema_sa(ix, p.x0 + (uint64_t)k);
+				const int64_t rbeg = p.x1 == EMA_INTV_BYPOS ? (int64_t)p.x0 : (int64_t)ema_sa(ix, p.x0 + (uint64_t)k);      // (by position: k_seed.hip, "anchors")
 				const int rid = ema_intv2rid(ix, rbeg, rbeg + slen);
 				if (rid < 0) continue;
 				lane_chain_insert(opt, l_pac, s, n_chain, n_seed, rbeg, qbeg, slen, rid);

@@ -70,6 +70,16 @@
 // A suffix of L bases that is too rare condemns every window that holds it -- right ends e .. e + W - L -- so the next window
 // tested ends at e + W - L + 1 (an ambiguous base condemns the windows that hold it likewise): about six windows of four
 // dependent steps for the usual search instead of 150 extends.  K1's lane-ticks per read 555 -> R4WT on the benchmark mix.
+//
+// Anchors (tails + window test; DevOpts.seed_flags bit 1).  A pass-1 search whose forward match ended as ONE occurrence of at least
+// min_seed_len bases has the usual read's shape: the match is the read's true place, and bwt_smem1's backward phase walks ~17
+// shorter prefixes leftwards beside it, a triangle of ~150 extends, to report one thing -- the longest match, extended to the
+// left as far as the text agrees.  The machine knows where that occurrence is (the tail's suffix-array row), so it compares the
+// read leftwards against the text as well (DevIndex.text2 holds the reverse complement too: going left on one strand is going
+// right on the other), which gives the SMEM's start p + 1 and its place in the text; the interval goes out BY POSITION
+// (EMA_INTV_BYPOS: K2 wants the position, not the row).  The prefixes beside it can report something only after the anchor has
+// died, i.e. as matches that span position p -- the window test over p decides: none can (the usual case) -> the search is over;
+// one might -> the regular backward phase runs from its start, nothing having been reported.  Exact, like the test itself.
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
 
@@ -79,7 +89,8 @@ namespace {
 enum { PC_DONE = 0, PC_P1_NEXT, PC_P2_NEXT, PC_P2_RES, PC_P3_NEXT, PC_FWD_STOP, PC_BWD_N,
        PC_FWD = 8, PC_FWD_RES, PC_BWD, PC_BWD_RES, PC_S3, PC_S3_RES,
        PC_TSA_RES, PC_TXT, PC_TXT_RES,        // a tail (below): suffix-array row requested / text to request / text requested
-       PC_WT_NEXT, PC_WT, PC_WT_RES };        // the window test of a pass-2 search (below): next window / one more base to the left / answer
+       PC_WT_NEXT, PC_WT, PC_WT_RES,          // the window test of a pass-2 search (below): next window / one more base to the left / answer
+       PC_AB, PC_AB_RES, PC_AB_EMIT };        // an anchor (below): text to the left to request / requested / its SMEM to report
 
 // A machine taken off its lane (see "re-packing" below): everything phase B and the next step need.  The working
 // lists stay where they are -- `wl` is the address of the lane's list slab -- and the read is re-staged from qpack.
@@ -114,6 +125,13 @@ __device__ __forceinline__ uint32_t seed_rev_groups(uint32_t v)
 	return (v >> 16) | (v << 16);
 }
 
+// the 32 bits of v in reverse order
+__device__ __forceinline__ uint32_t seed_rev_bits(uint32_t v)
+{
+	v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+	return seed_rev_groups(v);
+}
+
 }  // namespace
 
 // reads: qpack[r * 24 ..]: 16 words of 2-bit codes (base i at bits 2(i%16) of word i/16, N stored as 0) followed by
@@ -129,10 +147,10 @@ __device__ __forceinline__ uint32_t seed_rev_groups(uint32_t v)
 // engine queues a fixed, short series of such launches, the last one with park_max = 0.  (Each launch shrinks the
 // parked population about 64 / park_max-fold; a wave that starts with no more than park_max machines keeps them.)
 #ifndef EMA_SEED_WPS
-#define EMA_SEED_WPS 1
+#define EMA_SEED_WPS 4      // [r4] the product build is held to four waves per SIMD (128 registers, nothing spilled); left alone it takes 135 since the anchors
 #endif
 template <bool PROF>      // PROF: the diagnostic build (tick statistics); the product build carries none of its registers
-__global__ void __launch_bounds__(256, EMA_SEED_WPS)
+__global__ void __launch_bounds__(256, PROF ? 1 : EMA_SEED_WPS)
 ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv,
            int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
@@ -173,6 +191,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	const uint64_t n_text = (uint64_t)ix.l_pac << 1;
 	const bool wtest = kk > 0 && (opt.seed_flags & 1) && opt.min_seed_len >= 2 && opt.min_seed_len <= 32;      // pass 2's window test
 	const int wlen = opt.min_seed_len;
+	const bool anchors = wtest && tails && (opt.seed_flags & 2);
 	uint32_t c_code = 0, f_code = 0, r_code = 0, req_code = 0, req_len = 0;      // 2-bit codes of the strings behind c, f, r
 
 	auto q = [&](int p_) -> int {
@@ -251,7 +270,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				if (e - s < opt.split_len || ent.x2 > (uint64_t)opt.split_width) pc = PC_P2_NEXT;
 				else {
 					sm_x = (s + e) >> 1; min_intv = (int)ent.x2 + 1;
-					if (wtest) { i = sm_x + 1; pc = PC_WT_NEXT; } else start = true;
+					if (wtest) { n_prev = sm_x; i = sm_x + 1; pc = PC_WT_NEXT; } else start = true;
 				}
 				break;
 			}
@@ -267,8 +286,28 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				break;
 			case PC_TXT_RES:      // tail: r2 bases agreed; r0 != 0: and the match ends there -- then what PC_FWD_STOP does
 				i += (int)r2; f0 += r2;
-				if (r0) { c_end = (uint32_t)i; ev = 1; v0 = c0; v1 = c_code; v2 = c2; v_end = c_end; aft = true; }
+				if (r0) {
+					c_end = (uint32_t)i; ev = 1; v0 = c0; v1 = c_code; v2 = c2; v_end = c_end;
+					if (anchors && pass == 1 && i - sm_x >= wlen) {      // an anchor: its SMEM from the text (f0 = the text position of read base i)
+						x = i;
+						f0 -= (uint64_t)(i - sm_x);                     // the match's place in the text
+						if (sm_x == 0) { n_prev = -1; pc = PC_AB_EMIT; }      // nothing to the left of it
+						else { f0 = n_text - f0; i = sm_x - 1; pc = PC_AB; }  // leftwards = rightwards on the other strand, from there
+					} else aft = true;
+				}
 				else pc = PC_TXT;
+				break;
+			case PC_AB_RES:       // anchor: r2 more bases agree to the left; r0 != 0: and that is where the match ends
+				i -= (int)r2; f0 += r2;
+				if (!r0) { pc = PC_AB; break; }
+				f0 = n_text - f0;      // the SMEM q[i + 1 .. c_end) begins here in the text
+				n_prev = i;
+				if (i < 0 || q(i) > 3) pc = PC_AB_EMIT;      // the read's start or an ambiguous base: every prefix beside the anchor dies there too
+				else { rev = 2; i = n_prev + 1; pc = PC_WT_NEXT; }      // can a match that spans position n_prev exist at all?
+				break;
+			case PC_AB_EMIT:      // anchor: the search's one SMEM, by position
+				ev = 2; v0 = f0; v1 = EMA_INTV_BYPOS; v2 = 1; v_start = (uint32_t)(n_prev + 1); v_end = c_end;
+				pc = PC_P1_NEXT;
 				break;
 			default:
 				break;
@@ -292,7 +331,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 					}
 				} else {
 					if (n_out >= opt.intv_cap) st |= EMA_ST_INTV_OVERFLOW;
-					else { e.info = (uint64_t)v_start << 32 | v_end; if (kk) e.x1 = 0; dst = intv + out_base + n_out; ++n_out; }
+					else { e.info = (uint64_t)v_start << 32 | v_end; if (kk && v1 != EMA_INTV_BYPOS) e.x1 = 0; dst = intv + out_base + n_out; ++n_out; }
 				}
 				if (dst) *dst = e;
 			}
@@ -302,7 +341,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				if (wtest && pass == 1 && !wt_done && (int)c_end - sm_x < wlen) {
 					// a forward match shorter than a seed (the search that starts ON a mismatch): its backward phase reports something only
 					// if a window of min_seed_len bases over sm_x occurs at all -- the window test, right ends up to the match's end
-					i = sm_x + 1; pc = PC_WT_NEXT;
+					n_prev = sm_x; rev = 0; i = sm_x + 1; pc = PC_WT_NEXT;
 				} else {
 					n_prev = n_curr; n_curr = 0; rev = 1;
 					i = sm_x - 1; j = 0;
@@ -368,10 +407,10 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			case PC_WT_NEXT: {    // window test: the next window [i - wlen, i) over sm_x that is not condemned yet
 				if (i < wlen) i = wlen;
 				const int e_lim = pass == 1 ? (int)c_end : len;      // (pass 1: a window that reaches beyond the forward match holds a string that does not occur)
-				const int e_hi = sm_x + wlen < e_lim ? sm_x + wlen : e_lim;
-				if (i > e_hi) {      // none can be frequent enough: the search (its backward phase) would report nothing
+				const int e_hi = n_prev + wlen < e_lim ? n_prev + wlen : e_lim;      // (n_prev: the position the windows span)
+				if (i > e_hi) {      // none can be frequent enough: the search (its backward phase; the prefixes beside an anchor) would report nothing
 					if (prof) n_wt[pass == 2 ? 0 : 2] += 1;
-					pc = pass == 1 ? PC_P1_NEXT : PC_P2_NEXT;
+					pc = pass == 2 ? PC_P2_NEXT : rev == 2 ? PC_AB_EMIT : PC_P1_NEXT;
 					break;
 				}
 				const int p0 = i - wlen, wn = p0 >> 5;
@@ -438,6 +477,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				else { req_c = q(i - j - 1); ++j; has_req = 1; pc = PC_WT_RES; }
 			}
 			else if (pc == PC_TXT) { has_req = 4; pc = PC_TXT_RES; }
+			else if (pc == PC_AB) { has_req = 5; pc = PC_AB_RES; }
 			else if (pc == PC_FWD || pc == PC_BWD || pc == PC_S3) {
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
 				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
@@ -491,7 +531,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 		if (prof) {
 			++n_tick; n_active += __popcll(__ballot(has_req != 0));
 			n_kind[0] += __ballot(has_req == 1) != 0; n_kind[1] += __ballot(has_req == 2) != 0; n_kind[2] += __ballot(has_req >= 3) != 0;
-			n_kind[3] += __ballot(has_req == 4) != 0;
+			n_kind[3] += __ballot(has_req >= 4) != 0;
 			if (has_req) { n_by_pass[pass == 1 ? 0 : pass == 2 ? 1 : 2] += 1; if (pc == PC_WT_RES) n_by_pass[3] += 1; }
 		}
 		// ---- phase B: every global load of the tick, issued together
@@ -517,7 +557,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			if (has_req == 3) {      // tail: the suffix-array row of the one occurrence (the aligned 16 bytes that hold it)
 				p0 = reinterpret_cast<const uint4 *>((reinterpret_cast<uintptr_t>(ix.sa) + c0 * (uint64_t)ix.sa_width) & ~(uintptr_t)15);
 				p1 = p2 = p3 = p0;
-			} else if (has_req == 4) {      // tail: 8 words of text from the word that holds position f0
+			} else if (has_req >= 4) {      // tail / anchor: 8 words of text from the word that holds position f0
 				p0 = reinterpret_cast<const uint4 *>(ix.text2 + (f0 >> 5));
 				p1 = p0 + 1; p2 = p0 + 2; p3 = p0 + 3;
 			} else if (tab) {
@@ -545,13 +585,15 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				if (ix.sa_width == 4) pos = o == 0 ? a0.x : o == 4 ? a0.y : o == 8 ? a0.z : a0.w;
 				else pos = o == 0 ? ((uint64_t)a0.y << 32 | a0.x) : ((uint64_t)a0.w << 32 | a0.z);
 				f0 = pos + (uint64_t)(i - sm_x);
-			} else if (has_req == 4) {
+			} else if (has_req >= 4) {
 				// read base i stands against text position f0: count the bases that agree, 32 per step, up to the first difference,
-				// the read's end, its next ambiguous base (stored as code 0: cut by the mask) or the text's end
+				// the read's end, its next ambiguous base (stored as code 0: cut by the mask) or the text's end.  An anchor (5) walks the
+				// read LEFTWARDS from i against the other strand's text rightwards: the read's bases reversed and complemented.
 				const uint64_t T[8] = {(uint64_t)a0.y << 32 | a0.x, (uint64_t)a0.w << 32 | a0.z, (uint64_t)a1.y << 32 | a1.x, (uint64_t)a1.w << 32 | a1.z,
 				                       (uint64_t)b0.y << 32 | b0.x, (uint64_t)b0.w << 32 | b0.z, (uint64_t)b1.y << 32 | b1.x, (uint64_t)b1.w << 32 | b1.z};
-				const int st_ = (int)(f0 & 31) << 1, sq = (i & 31) << 1, sn = i & 31, w0 = i >> 5;
-				int lim = len - i;
+				const bool left = has_req == 5;
+				const int st_ = (int)(f0 & 31) << 1;
+				int lim = left ? i + 1 : len - i;
 				if (f0 >= n_text) lim = 0;
 				else if (n_text - f0 < (uint64_t)lim) lim = (int)(n_text - f0);
 				int total = 0;
@@ -559,13 +601,21 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 #pragma unroll
 				for (int c = 0; c < 7; ++c) {
 					if (!stopped && total < lim) {
-						const int w = w0 + c;
+						// 32 read bases from position s up (and their ambiguity flags), s = i + 32 c, or i - 32 c - 31 for an anchor
+						const int s_ = left ? i - 32 * c - 31 : i + 32 * c;
+						const int sp = s_ < 0 ? 0 : s_, w = sp >> 5, sh = sp & 31;
 						const uint64_t q_lo = w < 8 ? ((uint64_t)qw[(2 * w + 1) << 6] << 32 | qw[(2 * w) << 6]) : 0;
 						const uint64_t q_hi = w < 7 ? ((uint64_t)qw[(2 * w + 3) << 6] << 32 | qw[(2 * w + 2) << 6]) : 0;
 						const uint64_t n_w = (uint64_t)(w < 7 ? nm[(w + 1) << 6] : 0u) << 32 | (w < 8 ? nm[w << 6] : 0u);
-						uint64_t d = seed_funnel(T[c], T[c + 1], st_) ^ seed_funnel(q_lo, q_hi, sq);
+						uint64_t rd = seed_funnel(q_lo, q_hi, sh << 1);
+						uint32_t nb = (uint32_t)(n_w >> sh);
+						if (left) {
+							if (s_ < 0) { rd <<= (-s_) << 1; nb <<= -s_; }      // (positions below 0: beyond the limit)
+							rd = ~((uint64_t)seed_rev_groups((uint32_t)rd) << 32 | seed_rev_groups((uint32_t)(rd >> 32)));
+							nb = seed_rev_bits(nb);
+						}
+						uint64_t d = seed_funnel(T[c], T[c + 1], st_) ^ rd;
 						d = (d | d >> 1) & 0x5555555555555555ULL;
-						const uint32_t nb = (uint32_t)(n_w >> sn);
 						const int m_d = d ? (__ffsll((unsigned long long)d) - 1) >> 1 : 32, m_n = nb ? __ffs(nb) - 1 : 32;
 						const int m = m_d < m_n ? m_d : m_n;
 						total += m;

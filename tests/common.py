@@ -145,3 +145,21 @@ def text_edge_pairs(ctg, seed=41):
     off = np.zeros(len(reads) + 1, np.uint32)
     off[1:] = np.cumsum([len(r) for r in reads])
     return synth.Pairs(lut[np.concatenate(reads)], off)
+
+
+BYPOS = 1 << 63
+
+
+def same_intervals(got, exp, idx, table_mode):
+    """K1's intervals of one read against the oracle's: lists of (start, end, k, k', size).  In table mode K1 does not produce k'
+    (0), and it may hand a single-occurrence interval over BY POSITION (k' = EMA_INTV_BYPOS, k = the occurrence's place in the
+    text: what bwt_sa() returns for the oracle's row)."""
+    if len(got) != len(exp):
+        return False
+    for g, e in zip(got, exp):
+        if g[3] == BYPOS:
+            if (g[0], g[1], g[4]) != (e[0], e[1], e[4]) or g[4] != 1 or g[2] != idx.sa(e[2]):
+                return False
+        elif (g[0], g[1], g[2], g[4]) != (e[0], e[1], e[2], e[4]) or g[3] != (0 if table_mode else e[3]):
+            return False
+    return True

@@ -344,7 +344,7 @@ struct ema_engine {
 	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)
 	int heavy_regions = 8;               // K4b sets a read with at least this many regions left aside for K4t / K4r (0: never)
 	int heavy_chains = 32;               // EMA_HEAVY_CHAINS: K2b sets a read with at least this many chains to extend aside for K2c / K2d (0: never)
-	int seed_rounds = 3, seed_park_max = 16;   // K1 re-packing: launches per series, machines a retiring wave may park
+	int seed_rounds = 2, seed_park_max = 24;   // K1 re-packing: launches per series, machines a retiring wave may park ([r4]: 3 / 16 before the long reads went first)
 	DevBuf<uint8_t> d_k1w_args;          // device copies of the index and option records for K1w (see k_seed_wave.hip)
 	DevBuf<unsigned long long> d_prof;   // EMA_PHASE_PROFILE=1: per-phase shader-clock totals of K2
 	DevBuf<unsigned long long> d_lprof;  // EMA_PHASE_PROFILE=3: the product builds' few clocks (k_align.hip, PROF 2)

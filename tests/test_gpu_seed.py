@@ -86,13 +86,15 @@ def test_seed_parity_tails_on_and_off(tail, monkeypatch):
     _check("two_contigs", 300, 28, "lane", monkeypatch, len1=250, len2=250, sub_rate=0.002)
 
 
-@pytest.mark.parametrize("wtest", ["1", "0"])
+@pytest.mark.parametrize("wtest", ["1", "0", "no-anchors"])
 @pytest.mark.parametrize("k", ["", "5", "11"])
 def test_seed_parity_window_test_of_pass_2(k, wtest, monkeypatch):
     """Pass 2's window test (k_seed.hip: a re-seeding search is skipped when no min_seed_len-base window over its position can be
     frequent enough) on and off (EMA_SEED_WTEST), at several table depths: repeat-rich reads (searches that DO report), clean ones,
-    ambiguous bases, 250 bp, and a small min_seed_len... the intervals equal the oracle's either way."""
-    monkeypatch.setenv("EMA_SEED_WTEST", wtest)
+    ambiguous bases, 250 bp; with and without the anchors that build on it (a pass-1 SMEM found on the text and reported by position) --
+    the intervals equal the oracle's either way."""
+    monkeypatch.setenv("EMA_SEED_WTEST", "0" if wtest == "0" else "1")
+    monkeypatch.setenv("EMA_SEED_ANCHOR", "0" if wtest == "no-anchors" else "1")      # (anchors: single-occurrence matches reported by position)
     if k:
         monkeypatch.setenv("EMA_KMER_K", k)
     _check("repeats", 500, 31, "lane", monkeypatch, sub_rate=0.01, n_rate=0.004)

@@ -457,6 +457,28 @@ def main(argv=None):
     eng = Engine(prefix, device=local, opts=o)
     open_s = time.time() - t
     log(f"[rank {rank}] engine open (index in HBM) {open_s:.1f}s")
+    stock = {}
+    if not args.no_extras and world == 1:
+        # the same index as `bwa index` leaves it (no flat suffix array file): a second engine (small batch geometry) whose suffix array is
+        # bwa's sampled .sa expanded on the device.  Here, before the batch buffers and the SAM leg's second set fill the HBM.
+        try:
+            sdir = os.path.join(workdir, "stock_index")
+            os.makedirs(sdir, exist_ok=True)
+            for ext in (".bwt", ".sa", ".pac", ".ann", ".amb"):
+                dst = os.path.join(sdir, "ref.fa" + ext)
+                if not os.path.lexists(dst):
+                    os.symlink(prefix + ext, dst)
+            o2 = default_opts()
+            o2.batch_pairs = 16384
+            t = time.time()
+            e2 = Engine(os.path.join(sdir, "ref.fa"), device=local, opts=o2)
+            stock["engine_open_stock_bwa_index_s"] = round(time.time() - t, 2)
+            stock["stock_bwa_index_rows_equal_the_flat_file"] = bool((e2.debug_sa(12345, 4096) == eng.debug_sa(12345, 4096)).all())
+            e2.close()
+            log(f"[rank 0] engine open on the index without its .fsa (sampled .sa expanded on the device): {stock['engine_open_stock_bwa_index_s']}s, "
+                f"rows equal: {stock['stock_bwa_index_rows_equal_the_flat_file']}")
+        except Exception as e:      # noqa: BLE001 -- an extra: never at the cost of the line
+            log(f"[rank 0] stock-index open failed: {e}")
     so = stream.default_opts()
     so.n_engines = 2 if args.two_sets else 1
     peer = eng.peer() if args.two_sets else None
@@ -749,7 +771,7 @@ def main(argv=None):
                        "timed region: download of the device-made batch layout and the append_alignments stage on the host's threads (the bench's own "
                        "spot-check sampling in the sink is measured and left out)",
                        "cpus_granted_to_the_node": node_cpus, "host_threads_per_rank": int(os.environ.get("EMA_HOST_THREADS", "0")) or min(32, node_cpus),
-                       "engine_open_s": round(open_s, 2), "spot_check_sampling_cpu_s_excluded": round(sink_cpu[0], 3),
+                       "engine_open_s": round(open_s, 2), **stock, "spot_check_sampling_cpu_s_excluded": round(sink_cpu[0], 3),
                        "d2h_candidate_bytes_per_pair": round(112 * out["bucket_stats"]["candidates"] / max(1, total_pairs) + 2 * (8 + 8 + 4), 1)}      # 112-byte candidates + per-read layout; CIGAR operations (4 bytes each) come on top
         out["scaling_prediction"] = {
             "status": "PREDICTED from this run's per-GPU rate and host CPU cost; no multi-GPU run has been measured on hardware",
@@ -760,26 +782,6 @@ def main(argv=None):
             "note": "host_bound divides the CPUs granted to the node by ONE rank's CPU seconds per pair over its timed region (all of the process's "
                     "threads, the Python sink included): a rough bound"}
         out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not (args.no_extras or args.no_sam_leg) else None
-        if not args.no_extras and world == 1:
-            # the same index as `bwa index` leaves it (no flat suffix array file): the engine expands bwa's sampled .sa on the device
-            try:
-                sdir = os.path.join(workdir, "stock_index")
-                os.makedirs(sdir, exist_ok=True)
-                for ext in (".bwt", ".sa", ".pac", ".ann", ".amb"):
-                    dst = os.path.join(sdir, "ref.fa" + ext)
-                    if not os.path.lexists(dst):
-                        os.symlink(prefix + ext, dst)
-                o2 = default_opts()
-                o2.batch_pairs = 16384      # a second index replica fits beside the first (59 GB each); a second set of 1 Mi-pair batch buffers would not
-                t = time.time()
-                e2 = Engine(os.path.join(sdir, "ref.fa"), device=local, opts=o2)
-                out["host"]["engine_open_stock_bwa_index_s"] = round(time.time() - t, 2)
-                same = bool((e2.debug_sa(12345, 4096) == eng.debug_sa(12345, 4096)).all())
-                e2.close()
-                out["host"]["stock_bwa_index_rows_equal_the_flat_file"] = same
-                log(f"[rank 0] engine open on the index without its .fsa (sampled .sa expanded on the device): {out['host']['engine_open_stock_bwa_index_s']}s, rows equal: {same}")
-            except Exception as e:      # noqa: BLE001 -- an extra: never at the cost of the line
-                log(f"[rank 0] stock-index open failed: {e}")
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -69,7 +69,8 @@
 // base to the left per rank query, until the suffix is too rare (length L) or the window is whole (then the search runs as before).
 // A suffix of L bases that is too rare condemns every window that holds it -- right ends e .. e + W - L -- so the next window
 // tested ends at e + W - L + 1 (an ambiguous base condemns the windows that hold it likewise): about six windows of four
-// dependent steps for the usual search instead of 150 extends.  K1's lane-ticks per read 555 -> R4WT on the benchmark mix.
+// dependent steps for the usual search instead of 150 extends.  K1's lane-ticks per read 555 -> 475 on the benchmark mix (442 with
+// the same test deciding about the backward phases of pass-1 searches that start on a mismatch, 413 with the anchors below).
 //
 // Anchors (tails + window test; DevOpts.seed_flags bit 1).  A pass-1 search whose forward match ended as ONE occurrence of at least
 // min_seed_len bases has the usual read's shape: the match is the read's true place, and bwt_smem1's backward phase walks ~17

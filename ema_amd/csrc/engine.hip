@@ -711,6 +711,12 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p, &e->dix, sizeof(DevIndex), hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_FULL, &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_LEAN, &e->sl[0].dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
+	if (getenv("EMA_VERBOSE")) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			fprintf(stderr, "[ema] engine open: %.1f GB of the device's %.1f GB in use (index, tables, slots of %zu pairs in %zu slices + the full tier; result sets and input slots come with the first pass)\n",
+			        (double)(total_b - free_b) / 1e9, (double)total_b / 1e9, e->cap_pairs, e->sl.size());
+	}
 	return EMA_OK;
 }
 

@@ -165,7 +165,9 @@ int ema_engine_fetch(ema_engine_t *e, ema_batch_out **out);
 
 /* Stage-level access used by the parity tests and the profiler (the staged batch must fit the full-capacity tier,
  * on which these run): seed intervals of the staged batch (what bwa's mem_collect_intv leaves in aux->mem).  Runs K1 only.
- * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free(). */
+ * intv: 4 x u64 per interval {k, k', size, start<<32|end}; n_intv per read; caller frees with free().  With the k-mer table
+ * (ema_engine_index_info: kmer_k > 0) K1 does not produce k' (0), and it may hand a single-occurrence interval over BY POSITION:
+ * k' == 1 << 63, size == 1 and k is the occurrence's place in the text -- what bwt_sa() returns for the row (k_seed.hip, "anchors"). */
 int ema_engine_debug_seeds(ema_engine_t *e, uint64_t **intv, int32_t **n_intv, int32_t *cap_per_read);
 
 /* Regions of every staged read after seeding, chaining, extension and dedup (bwa's mem_align1_core result,

@@ -69,7 +69,8 @@
 // base to the left per rank query, until the suffix is too rare (length L) or the window is whole (then the search runs as before).
 // A suffix of L bases that is too rare condemns every window that holds it -- right ends e .. e + W - L -- so the next window
 // tested ends at e + W - L + 1 (an ambiguous base condemns the windows that hold it likewise): about six windows of four
-// dependent steps for the usual search instead of 150 extends.  K1's lane-ticks per read 555 -> 475 on the benchmark mix (442 with
+// dependent steps for the usual search instead of 150 extends.  When a window CAN be frequent enough the search runs, without the
+// prefixes that end before that window's right end (every window ending there has been condemned: they can report nothing).  K1's lane-ticks per read 555 -> 475 on the benchmark mix (442 with
 // the same test deciding about the backward phases of pass-1 searches that start on a mismatch, 413 with the anchors below).
 //
 // Anchors (tails + window test; DevOpts.seed_flags bit 1).  A pass-1 search whose forward match ended as ONE occurrence of at least
@@ -212,12 +213,16 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			uint64_t v0 = 0, v1 = 0, v2 = 0;
 			uint32_t v_start = 0, v_end = 0;
 			bool aft = false, nxt = false, start = false, wt_done = false;
+			int prune = 0;      // pass 2, set with `start`: the right end of the first window that can be frequent enough
 			// (1) handlers: the extend result / the loaded entry / a forward phase that cannot go on
 			switch (pc) {
 			case PC_FWD_RES:      // bwt_smem1, forward loop body after bwt_extend(ik, ok, 0)
 				if (r2 != c2) {
-					ev = 1; v0 = c0; v1 = kk ? c_code : c1; v2 = c2; v_end = c_end;
-					if (r2 < (uint64_t)min_intv) { aft = true; break; }
+					const bool last = r2 < (uint64_t)min_intv;
+					// (rev == 3: a pass-2 search after its window test -- a prefix that ends before the first window that can be frequent
+					// enough, n_prev, can report nothing, and neither can anything else because of it: it is not put on the list)
+					if (last || !(rev == 3 && (int)c_end < n_prev)) { ev = 1; v0 = c0; v1 = kk ? c_code : c1; v2 = c2; v_end = c_end; }
+					if (last) { aft = true; break; }
 				}
 				c0 = r0; c1 = r1; c2 = r2; c_end = (uint32_t)(i + 1); c_code = r_code;
 				++i;
@@ -279,7 +284,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				if (r2 < (uint64_t)min_intv) { i += wlen + 1 - j; pc = PC_WT_NEXT; }      // too rare: so is every window that holds it
 				else if (j >= wlen) {      // a whole window is frequent enough: the search (pass 2) / its backward phase (pass 1) runs
 					if (prof) n_wt[pass == 2 ? 1 : 3] += 1;
-					if (pass == 2) start = true; else { aft = true; wt_done = true; }
+					if (pass == 2) { start = true; prune = i; } else { aft = true; wt_done = true; }
 				} else { f1 = r0; f2 = r2; pc = PC_WT; }      // (the test's interval lives in f1 / f2, idle outside backward rows, and is parked with them)
 				break;
 			case PC_TSA_RES:      // tail: the occurrence's place in the text is known (f0 = the text position of read base i)
@@ -470,6 +475,8 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				c_end = (uint32_t)(sm_x + 1);
 				n_curr = 0; n_mem_call = 0;
 				i = sm_x + 1;
+				rev = prune ? 3 : 0;
+				if (prune) n_prev = prune;
 				pc = PC_FWD;
 			}
 			// (7) the one place that looks up the next base and posts the extend

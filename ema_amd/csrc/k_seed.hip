@@ -284,7 +284,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				if (r2 < (uint64_t)min_intv) { i += wlen + 1 - j; pc = PC_WT_NEXT; }      // too rare: so is every window that holds it
 				else if (j >= wlen) {      // a whole window is frequent enough: the search (pass 2) / its backward phase (pass 1) runs
 					if (prof) n_wt[pass == 2 ? 1 : 3] += 1;
-					if (pass == 2) { start = true; prune = i; } else { aft = true; wt_done = true; }
+					if (pass == 2) { start = true; prune = i; } else { aft = true; wt_done = true; prune = i; }
 				} else { f1 = r0; f2 = r2; pc = PC_WT; }      // (the test's interval lives in f1 / f2, idle outside backward rows, and is parked with them)
 				break;
 			case PC_TSA_RES:      // tail: the occurrence's place in the text is known (f0 = the text position of read base i)
@@ -319,6 +319,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				break;
 			}
 			// (2) the one place that stores an interval
+			if (ev == 1 && (int)v_end - sm_x < 64) last_curr_size |= 1ULL << ((int)v_end - sm_x);
 			if (ev) {
 				Intv e; e.x0 = v0; e.x1 = v1; e.x2 = v2;
 				Intv *dst = nullptr;
@@ -349,7 +350,16 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 					// if a window of min_seed_len bases over sm_x occurs at all -- the window test, right ends up to the match's end
 					n_prev = sm_x; rev = 0; i = sm_x + 1; pc = PC_WT_NEXT;
 				} else {
-					n_prev = n_curr; n_curr = 0; rev = 1;
+					// (after a window test of pass 1 that found a window ending at `prune`: the prefixes on list F that end before it can
+					// report nothing -- they are the list's first entries, the last ones of the first backward row: left out)
+					int n_skip = 0;
+					if (wt_done && prune > sm_x) {
+						const int d = prune - sm_x;
+						n_skip = __popcll(last_curr_size & (d < 64 ? (1ULL << d) - 1 : ~0ULL));
+						if (n_skip >= n_curr) n_skip = n_curr - 1;
+					}
+					if (pass == 1) k2 = n_skip;      // (k2 is pass 2's cursor: idle in pass 1)
+					n_prev = n_curr - n_skip; n_curr = 0; rev = 1;
 					i = sm_x - 1; j = 0;
 					pc = PC_BWD;
 				}
@@ -477,6 +487,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				i = sm_x + 1;
 				rev = prune ? 3 : 0;
 				if (prune) n_prev = prune;
+				last_curr_size = 0;      // (forward phase: which prefix lengths are on list F, bit c_end - sm_x; a backward row's own use comes later)
 				pc = PC_FWD;
 			}
 			// (7) the one place that looks up the next base and posts the extend
@@ -495,7 +506,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 					if (pc == PC_BWD) {
 						req_c = b;
 						if (j + 1 < n_prev) {      // the row's next entry comes from the slab: list F walked from its end, or list B beyond its LDS part
-							if (rev) { ld_at = (size_t)(n_prev - 2 - j) << 6; ld_kind = 1; }
+							if (rev) { ld_at = (size_t)(n_prev - 2 - j + (pass == 1 ? k2 : 0)) << 6; ld_kind = 1; }      // (+ the entries left out at the list's start)
 							else if (j + 1 >= EMA_SEED_LDS_LIST) { ld_at = (size_t)(EMA_LIST_CAP + j + 1) << 6; ld_kind = 1; }
 						}
 						// the extended string is q[i .. c_end): short enough for the table?

@@ -20,8 +20,10 @@
 #define EMU_INTV_CAP 512
 #define EMU_REG_CAP 256
 #define EMU_CIG_CAP 1024
-static DevOpts emu_dev_opts(const ema_engine_opts &o)
+static DevOpts emu_dev_opts(const ema_engine_opts &o_in)
 {
+	ema_engine_opts o = o_in;
+	if (const char *v = getenv("EMU_MIN_SEED_LEN")) o.min_seed_len = atoi(v);      // (bwa's -k, for the seeding shortcuts that depend on it)
 	DevOpts d = ema_make_dev_opts(o);
 	d.intv_cap = EMU_INTV_CAP; d.reg_cap = EMU_REG_CAP; d.cig_cap = EMU_CIG_CAP;
 	return d;

@@ -12,16 +12,23 @@ from ema_amd.engine import Engine
 pytestmark = pytest.mark.gpu
 
 
-def _check(kind, n_pairs, seed, kernel, monkeypatch, pairs=None, **kw):
+def _check(kind, n_pairs, seed, kernel, monkeypatch, pairs=None, min_seed_len=None, **kw):
     monkeypatch.setenv("EMA_FULL_SEED_LANE", "1" if kernel == "lane" else "0")
     prefix, ctg = small_ref(kind)
     if pairs is None:
         pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
-    eng = Engine(prefix)
+    eo = None
+    if min_seed_len is not None:
+        from ema_amd.engine import default_opts
+        eo = default_opts()
+        eo.min_seed_len = min_seed_len
+    eng = Engine(prefix, opts=eo)
     table = eng.index_info()["kmer_k"] > 0 and kernel == "lane"      # K1 with the k-mer interval table: k' is not produced (0)
     eng.stage(pairs.bases, pairs.off)
     intv, n_intv = eng.debug_seeds()
     idx, opt = O.Index(prefix), O.default_opt()
+    if min_seed_len is not None:
+        opt.min_seed_len = min_seed_len
     bad = 0
     for r in range(2 * pairs.n):
         ref = O.collect_intv(idx, opt, pairs.read(r))
@@ -100,6 +107,14 @@ def test_seed_parity_window_test_of_pass_2(k, wtest, monkeypatch):
     _check("repeats", 500, 31, "lane", monkeypatch, sub_rate=0.01, n_rate=0.004)
     _check("two_contigs", 300, 32, "lane", monkeypatch, len1=250, len2=250, sub_rate=0.003)
     _check("ngaps", 300, 33, "lane", monkeypatch, n_rate=0.01)
+
+
+@pytest.mark.parametrize("msl", [12, 25, 31])
+def test_seed_parity_other_minimum_seed_lengths(msl, monkeypatch):
+    """bwa's -k: the window test, the anchors and pass 3's jump all take their lengths from min_seed_len (the windows are that
+    long; the jump is min(kmer_k, min_seed_len) bases; re-seeding starts at 1.5 x) -- below, above and far above the default 19."""
+    _check("repeats", 400, 34, "lane", monkeypatch, min_seed_len=msl, sub_rate=0.01, n_rate=0.002)
+    _check("two_contigs", 200, 35, "lane", monkeypatch, min_seed_len=msl)
 
 
 def test_pipeline_with_and_without_the_table(monkeypatch):

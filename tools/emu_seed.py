@@ -15,6 +15,8 @@ for kind, kw in (("repeats", {}), ("ngaps", dict(n_rate=0.01)), ("two_contigs", 
     h = emu_lib.index_load(prefix)
     intv, n_intv, status = emu_lib.seed(h, nt4, off, n_blocks=1, wave=os.environ.get("EMU_SEED_WAVE") == "1")
     idx, opt = O.Index(prefix), O.default_opt()
+    if os.environ.get("EMU_MIN_SEED_LEN"):
+        opt.min_seed_len = int(os.environ["EMU_MIN_SEED_LEN"])
     bad = 0
     for r in range(len(off) - 1):
         ref = O.collect_intv(idx, opt, pairs.read(r))

@@ -33,6 +33,36 @@ static inline orc_reg_t *reg_pushp(orc_reg_v *v)
 #define u64lt(a, b) ((a) < (b))
 ORC_SORT_INIT(srt64, uint64_t, u64lt)
 
+/* Dev aid (tools/cpu_extend_profile.py): would the engine's lane-per-read pass (k_align_lane.hip, lane_extend_diag) know this
+ * extension's outcome without the dynamic program?  It does when the first qlen target bases differ from the query in at most one
+ * position, nothing is ambiguous, tlen >= qlen and h0 > 0.  Per thread: [0] extensions, [1] decided, and why not: [2] target too short
+ * or h0 <= 0, [3] ambiguous base, [4] two or more mismatches, [5] one mismatch but its conditions fail; [6] reads (align1_core calls),
+ * [7] reads with at least one extension not decided, [8] of those: the first such extension was in the read's FIRST chain. */
+__thread uint64_t orc_extprof[16];
+static __thread int extprof_read_bad, extprof_chain_no;
+void orc_extprof_get(uint64_t *out) { memcpy(out, orc_extprof, sizeof(orc_extprof)); }
+void orc_extprof_reset(void) { memset(orc_extprof, 0, sizeof(orc_extprof)); }
+static void extprof_call(const orc_opt_t *opt, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int h0)
+{
+	int j, n_mm = 0, p_mm = -1, why = 1;
+	++orc_extprof[0];
+	if (!(tlen >= qlen && h0 > 0)) why = 2;
+	else {
+		for (j = 0; j < qlen; ++j) {
+			if (q[j] > 3 || t[j] > 3) { why = 3; break; }
+			if (q[j] != t[j]) { ++n_mm; p_mm = j; }
+		}
+		if (why == 1 && n_mm >= 2) why = 4;
+		if (why == 1 && n_mm == 1) {
+			const int oe_del = opt->o_del + opt->e_del, oe_ins = opt->o_ins + opt->e_ins;
+			const int gap_min = oe_del < oe_ins + opt->a ? oe_del : oe_ins + opt->a;
+			if (!(opt->a > 0 && gap_min > opt->a + opt->b && (opt->zdrop <= 0 || opt->a + opt->b <= opt->zdrop) && h0 + p_mm * opt->a - opt->b > 0)) why = 5;
+		}
+	}
+	++orc_extprof[why];
+	if (why != 1 && !extprof_read_bad) { extprof_read_bad = 1; ++orc_extprof[7]; if (extprof_chain_no == 0) ++orc_extprof[8]; }
+}
+
 void orc_chain2aln(const orc_opt_t *opt, const orc_idx_t *idx, int l_query, const uint8_t *query,
                    const orc_chain_t *c, orc_reg_v *av)
 {
@@ -118,6 +148,7 @@ void orc_chain2aln(const orc_opt_t *opt, const orc_idx_t *idx, int l_query, cons
 			for (i = 0; i < MAX_BAND_TRY; ++i) {
 				int prev = a->score;
 				aw[0] = opt->w << i;
+				if (i == 0) extprof_call(opt, s->qbeg, qs, (int)tmp, rs, s->len * opt->a);
 				a->score = orc_ksw_extend2(s->qbeg, qs, (int)tmp, rs, 5, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins,
 				                           aw[0], opt->pen_clip5, opt->zdrop, s->len * opt->a, &qle, &tle, &gtle, &gscore, &max_off[0]);
 				if (a->score == prev || max_off[0] < (aw[0] >> 1) + (aw[0] >> 2)) break;
@@ -140,6 +171,7 @@ void orc_chain2aln(const orc_opt_t *opt, const orc_idx_t *idx, int l_query, cons
 			for (i = 0; i < MAX_BAND_TRY; ++i) {
 				int prev = a->score;
 				aw[1] = opt->w << i;
+				if (i == 0) extprof_call(opt, l_query - qe, query + qe, (int)(rmax[1] - rmax[0] - re), rseq + re, sc0);
 				a->score = orc_ksw_extend2(l_query - qe, query + qe, (int)(rmax[1] - rmax[0] - re), rseq + re, 5, opt->mat,
 				                           opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, aw[1], opt->pen_clip3, opt->zdrop, sc0,
 				                           &qle, &tle, &gtle, &gscore, &max_off[1]);
@@ -265,7 +297,9 @@ orc_reg_v orc_align1_core(const orc_opt_t *opt, const orc_idx_t *idx, int l_seq,
 	chn.n = orc_chain_flt(opt, (int)chn.n, chn.a);
 	/* mem_flt_chained_seeds: returns at once while MEM_MINSC_COEF*ln(l) > MEM_SEEDSW_COEF*l, i.e. l < ~700 */
 	assert(5.5 * log(l_seq > 1 ? l_seq : 2) > 0.05 * l_seq);
+	++orc_extprof[6]; extprof_read_bad = 0;
 	for (i = 0; (size_t)i < chn.n; ++i) {
+		extprof_chain_no = i;
 		orc_chain2aln(opt, idx, l_seq, seq, &chn.a[i], &regs);
 		free(chn.a[i].seeds);
 	}

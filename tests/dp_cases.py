@@ -62,8 +62,8 @@ def extend_cases(rng, n, max_q=250):
     return qs, ts, np.array(prm, dtype=np.int32)
 
 
-def oracle_extend(q, t, prm):
-    L = O.lib(); opt = O.default_opt()
+def oracle_extend(q, t, prm, opt=None):
+    L = O.lib(); opt = opt or O.default_opt()
     vals = [C.c_int() for _ in range(5)]
     sc = L.orc_ksw_extend2(len(q), q.tobytes(), len(t), t.tobytes(), 5, opt.mat, opt.o_del, opt.e_del, opt.o_ins,
                            opt.e_ins, int(prm[0]), int(prm[1]), int(prm[2]), int(prm[3]), *[C.byref(v) for v in vals])
@@ -89,8 +89,8 @@ def global_cases(rng, n, max_q=250):
     return qs, ts, np.array(prm, dtype=np.int32)
 
 
-def oracle_global(q, t, w):
-    L = O.lib(); opt = O.default_opt()
+def oracle_global(q, t, w, opt=None):
+    L = O.lib(); opt = opt or O.default_opt()
     n = C.c_int(); cig = C.POINTER(C.c_uint32)()
     sc = L.orc_ksw_global2(len(q), q.tobytes(), len(t), t.tobytes(), 5, opt.mat, opt.o_del, opt.e_del, opt.o_ins,
                            opt.e_ins, int(w), C.byref(n), C.byref(cig))
@@ -121,9 +121,9 @@ def local_cases(rng, n, max_q=250):
     return qs, ts, np.array(prm, dtype=np.int32)
 
 
-def oracle_local_pass(q, t, p, minsc, endsc):
+def oracle_local_pass(q, t, p, minsc, endsc, opt=None):
     """One pass of the local kernel = orc_ksw_align2 without XSTART (XSUBO|minsc, optional XSTOP)."""
-    L = O.lib(); opt = O.default_opt()
+    L = O.lib(); opt = opt or O.default_opt()
     xtra = (0x10000 if p == 16 else 0)
     if minsc < 0x10000:
         xtra |= 0x40000 | minsc
@@ -132,3 +132,15 @@ def oracle_local_pass(q, t, p, minsc, endsc):
     r = L.orc_ksw_align2(len(q), q.tobytes(), len(t), t.tobytes(), 5, opt.mat, opt.o_del, opt.e_del, opt.o_ins,
                          opt.e_ins, xtra)
     return [r.score, r.te, r.qe, r.score2, r.te2]
+
+
+def scoring(a, b, o_del, e_del, o_ins, e_ins):
+    """(engine options, oracle options) with bwa's -A -B -O -E set (bwa_fill_scmat for the oracle's matrix)."""
+    from ema_amd.engine import default_opts
+    eo, oo = default_opts(), O.default_opt()
+    for o in (eo, oo):
+        o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins = a, b, o_del, e_del, o_ins, e_ins
+    for i in range(5):
+        for j in range(5):
+            oo.mat[i * 5 + j] = -1 if i == 4 or j == 4 else (a if i == j else -b)
+    return eo, oo

@@ -67,3 +67,38 @@ def test_local_stop_pass_parity(eng):
     bad = [i for i in range(len(qs))
            if D.oracle_local_pass(qs[i], ts[i], int(prm2[i, 0]), 0x10000, int(prm2[i, 2])) != out[i].tolist()]
     assert not bad, f"{len(bad)} local XSTOP tasks differ, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("sc", [(2, 3, 5, 2, 4, 2), (1, 7, 2, 1, 2, 1), (5, 4, 9, 3, 12, 2)])
+def test_dp_parity_other_scorings(sc):
+    """The three DPs under other -A -B -O -E: asymmetric gap costs; mismatches dearer than the known-outcome shortcuts' conditions
+    allow (a + b >= the cheapest gap: the row loops must run); and a match score of 5, where a 250-base query reaches 1250 + h0 --
+    far beyond a byte, the range bwa's own 8-bit kernel leaves to ksw_i16 (the local pass is asked for both widths).
+    Queries up to 250 bases (the widest column layout)."""
+    prefix, _ = small_ref("two_contigs")
+    eo, oo = D.scoring(*sc)
+    e = Engine(prefix, opts=eo)
+    try:
+        rng = np.random.default_rng(200 + sc[0] * 7 + sc[1])
+        qs, ts, prm = D.extend_cases(rng, 1200)
+        prm[:, 3] = rng.integers(1, 150 * sc[0], len(prm))      # h0 up to a whole read of matches
+        out, _ = e.debug_dp(0, *D.flat(qs), *D.flat(ts), prm)
+        bad = [i for i in range(len(qs)) if D.oracle_extend(qs[i], ts[i], prm[i], oo) != out[i].tolist()]
+        assert not bad, f"{len(bad)} extension tasks differ, first {bad[:5]}"
+        qs, ts, prm = D.global_cases(rng, 800)
+        out, cig = e.debug_dp(1, *D.flat(qs), *D.flat(ts), prm)
+        bad = []
+        for i in range(len(qs)):
+            s_, ops = D.oracle_global(qs[i], ts[i], prm[i], oo)
+            if s_ != out[i, 0] or ops != cig[i, :out[i, 1]].tolist():
+                bad.append(i)
+        assert not bad, f"{len(bad)} global tasks differ, first {bad[:5]}"
+        qs, ts, prm = D.local_cases(rng, 600)
+        if sc[0] * 250 >= 250:      # ksw_align2 picks the 16-bit kernel when qlen * max score >= 250 (oracle/dp.c)
+            prm[[len(q) * sc[0] >= 250 for q in qs], 0] = 8
+        out, _ = e.debug_dp(2, *D.flat(qs), *D.flat(ts), prm)
+        bad = [i for i in range(len(qs))
+               if D.oracle_local_pass(qs[i], ts[i], int(prm[i, 0]), int(prm[i, 1]), int(prm[i, 2]), oo) != out[i].tolist()]
+        assert not bad, f"{len(bad)} local tasks differ, first {bad[:5]}"
+    finally:
+        e.close()

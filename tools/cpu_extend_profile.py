@@ -9,8 +9,8 @@ import numpy as np
 import oracle_lib as O
 from ema_amd import synth
 wd = os.environ.get("EMA_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "ema_bench_%d" % os.getuid())
-prefix = sys.argv[1] if len(sys.argv) > 1 else os.path.join(wd, "ref.fa")
-reads = sys.argv[2] if len(sys.argv) > 2 else sorted(glob.glob(os.path.join(wd, "reads_*.npz")))[0]
+prefix = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else os.path.join(wd, "ref.fa")
+reads = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] else sorted(glob.glob(os.path.join(wd, "reads_*.npz")))[0]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
 z = np.load(reads)
 pairs = synth.Pairs(z["bases"], z["off"]).subset(0, n)

@@ -190,6 +190,8 @@ __device__ __forceinline__ int ema_wave_incl_scan_add(int v)
 }
 // value of the lane below (lane 0 receives `ident`)
 __device__ __forceinline__ int ema_wave_shr1(int v, int ident) { return EMA_DPP(ident, v, 0x138, 0xf); }
+// value of the lane above (lane 63 receives `ident`): wave_shl:1
+__device__ __forceinline__ int ema_wave_shl1(int v, int ident) { return EMA_DPP(ident, v, 0x130, 0xf); }
 // wave-uniform results in scalar registers
 __device__ __forceinline__ int ema_wave_sum(int v) { return __builtin_amdgcn_readlane(ema_wave_incl_scan_add(v), 63); }
 

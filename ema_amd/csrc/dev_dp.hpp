@@ -377,9 +377,79 @@ __device__ inline int ema_wave_global_nc(const DevOpts &o, int qlen, EmaSeq quer
 	return ema_col_get_nc<NC>(hh, qlen);
 }
 
+// ksw_global2 when the band fits the wavefront (2w + 1 <= 64) and reaches the last column in the last row (|tlen - qlen| <= w: always,
+// for the bands bwa_gen_cigar2 chooses): the lanes lie ACROSS THE BAND, lane b on the diagonal j - i = b - w, i.e. on column
+// j = i - w + b in row i.  The bands of the final alignments are a few cells wide (inferred from the score: a mismatch or two, one
+// short gap), so the column layout above computes two or three cells per lane for 64 lanes to fill a dozen; here a row is one cell per
+// lane whatever the read's length.  The cell's diagonal predecessor is the lane's own cell of the row before (no shift), E comes
+// from the lane above (one DPP shift per row), F from the lanes below (the same max-plus scan), the query slides down the lanes by
+// one base per row.  Same recurrences, initial values, tie rules and direction bytes as ema_wave_global_nc, cell for cell.
+__device__ inline int ema_wave_global_band(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
+{
+	const int lane = (int)ema_lane();
+	const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
+	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	// row 0: this lane's column is lane - w.  hd = H(i-1, j-1) of the cell the lane computes in row i; ein = E(i, j) as it enters row i.
+	int hd, ein = EMA_DP_MINUS_INF, qb;
+	{
+		const int j = lane - w;
+		hd = j == 0 ? 0 : (j >= 1 && j <= qlen && j <= w) ? -(o.o_ins + e_ins * j) : EMA_DP_MINUS_INF;
+		qb = (j >= 0 && j < qlen) ? query.at(j) : 4;
+	}
+	EmaRowBases rows, qrows;      // the query base that enters at lane 63 in row i is q[i + 64 - w]: taken from a pack like the target's
+	int q_chunk = -1;
+	int h_last = EMA_DP_MINUS_INF;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 255) == 0) rows.load(target, i, tlen);
+		const int tb = rows.get(i);
+		const int j = i - w + lane;
+		const int beg = i > w ? i - w : 0;
+		const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const bool in = j >= beg && j < end;
+		if (j == 0) hd = i == 0 ? 0 : -(o.o_del + e_del * i);      // H(i-1, -1): the boundary column (in the band while i <= w)
+		const int m = hd + ema_score(o, tb, qb);
+		const int g = in ? (m - oe_ins) + j * e_ins : EMA_NEG_BIG;
+		const int pre = ema_wave_exscan_max(g);
+		int f = EMA_DP_MINUS_INF - (j - beg) * e_ins;
+		if (pre != EMA_NEG_BIG) f = max(f, pre - (j - 1) * e_ins);
+		const int e = ein;
+		int d = m >= e ? 0 : 1;
+		int hv = m >= e ? m : e;
+		d = hv >= f ? d : 2;
+		hv = hv >= f ? hv : f;
+		int e_next = EMA_DP_MINUS_INF;
+		if (in) {
+			int t = m - oe_del;
+			const int e2 = e - e_del;
+			d |= e2 > t ? 1 << 2 : 0;
+			e_next = e2 > t ? e2 : t;
+			t = m - oe_ins;
+			d |= (f - e_ins) > t ? 2 << 4 : 0;
+			if (z) z[(size_t)i * n_col + (j - beg)] = (uint8_t)d;
+			hd = hv;      // the diagonal predecessor of this lane's next cell, (i + 1, j + 1)
+		}
+		if (i == tlen - 1) h_last = hv;
+		ein = ema_wave_shl1(e_next, EMA_DP_MINUS_INF);      // cell (i + 1, j + 1) has (i, j + 1) above it: the lane above's
+		// the query slides down by one lane; lane 63 takes q[i + 1 - w + 63]
+		{
+			const int jn = i + 1 - w + 63;
+			int nb = 4;
+			if (jn >= 0 && jn < qlen) {
+				if ((jn >> 8) != q_chunk) { q_chunk = jn >> 8; qrows.load(query, q_chunk << 8, qlen); }
+				nb = qrows.get(jn);
+			}
+			const int down = ema_wave_shl1(qb, 4);
+			qb = lane == 63 ? nb : down;
+		}
+	}
+	// eh[qlen].h after the last row = H(tlen - 1, qlen - 1): the lane on diagonal (qlen - 1) - (tlen - 1)
+	return __builtin_amdgcn_readlane(h_last, qlen - tlen + w);
+}
+
 // ksw_global2 with the narrowest column layout that holds the query (qlen + 1 <= 64 NC)
 __device__ EMA_DP_CALL int ema_wave_global(const DevOpts &o, int qlen, EmaSeq query, int tlen, EmaSeq target, int w, uint8_t *z)
 {
+	if (2 * w + 1 <= 64 && tlen >= 1 && qlen >= 1 && tlen - qlen <= w && qlen - tlen <= w) return ema_wave_global_band(o, qlen, query, tlen, target, w, z);
 	if (qlen < 64) return ema_wave_global_nc<1>(o, qlen, query, tlen, target, w, z);
 	if (qlen < 128) return ema_wave_global_nc<2>(o, qlen, query, tlen, target, w, z);
 	if (qlen < 192) return ema_wave_global_nc<3>(o, qlen, query, tlen, target, w, z);
@@ -391,8 +461,9 @@ __device__ EMA_DP_CALL int ema_wave_global(const DevOpts &o, int qlen, EmaSeq qu
 // so cig[first..cap) is the CIGAR in forward order (BAM packing len<<4|op, M=0 I=1 D=2).  Returns `first`,
 // or -1 if cap is too small.
 // ZP: const uint8_t * (the matrix where the DP wrote it) or const EMA_LDS uint8_t * (staged: k_final.hip).
-// Run by the WHOLE wavefront with wave-uniform scalars (every lane reads the same byte; lane 0 alone stores the operations): as a
-// loop of one lane under an exec mask its ~30 dependent vector instructions per step cost more than the read they wait for.
+// Run by the WHOLE wavefront with wave-uniform scalars (lane 0 alone stores the operations): as a loop of one lane under an exec
+// mask its ~30 dependent vector instructions per step cost more than the read they wait for.  Runs of matches are taken 64 cells at a
+// time (below); what stays one read per step are the cells in and around gaps.
 template <typename ZP>
 __device__ inline int ema_traceback(ZP z, int qlen, int tlen, int w, uint32_t *cig, int cap)
 {
@@ -400,7 +471,27 @@ __device__ inline int ema_traceback(ZP z, int qlen, int tlen, int w, uint32_t *c
 	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
 	int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0, pos = cap, last_op = -1;
 	uint32_t cur = 0;
+	const int lane = (int)ema_lane();
 	while (i >= 0 && k >= 0) {
+		if (which == 0) {
+			// In the match state the walk goes down the diagonal for as long as the cells say "from the diagonal": lane l looks at the
+			// cell l steps ahead (same offset inside its row's band), and the whole run -- usually everything up to the next gap or the
+			// alignment's start -- becomes one step instead of one dependent read per base.
+			const int ii = i - lane, kk = k - lane;
+			bool m = false;
+			if (ii >= 0 && kk >= 0) m = (z[(size_t)ii * n_col + (kk - (ii > w ? ii - w : 0))] & 3) == 0;
+			const unsigned long long run_mask = __ballot(m);
+			const int r = run_mask == ~0ULL ? 64 : __ffsll((long long)~run_mask) - 1;
+			if (r > 0) {
+				if (last_op == 0) cur += (uint32_t)r << 4;
+				else {
+					if (last_op >= 0) { if (pos == 0) return -1; --pos; if (leader) cig[pos] = cur; }
+					cur = (uint32_t)r << 4; last_op = 0;
+				}
+				i -= r; k -= r;
+				continue;
+			}
+		}
 		which = ema_uni((int)z[(size_t)i * n_col + (k - (i > w ? i - w : 0))]) >> (which << 1) & 3;
 		const int op = which == 0 ? 0 : which == 1 ? 2 : 1;
 		if (op == last_op) cur += 1u << 4;

@@ -75,6 +75,7 @@ struct DevOpts {
 	int seed_budget;
 	// K1: bit 0 = a pass-2 search is skipped when no min_seed_len-base window over its position can be frequent enough (k_seed.hip, "window test");
 	// bit 1 = a pass-1 search whose forward match ended as a single occurrence finds its SMEM on the text ("anchors")
+	// bit 2 = one control pass per tick ("one pass per tick")
 	int seed_flags;
 };
 

@@ -194,6 +194,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	const bool wtest = kk > 0 && (opt.seed_flags & 1) && opt.min_seed_len >= 2 && opt.min_seed_len <= 32;      // pass 2's window test
 	const int wlen = opt.min_seed_len;
 	const bool anchors = wtest && tails && (opt.seed_flags & 2);
+	const bool one_pass = (opt.seed_flags & 4) != 0;
 	uint32_t c_code = 0, f_code = 0, r_code = 0, req_code = 0, req_len = 0;      // 2-bit codes of the strings behind c, f, r
 
 	auto q = [&](int p_) -> int {
@@ -207,7 +208,11 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	unsigned long long n_by_pass[4] = {0, 0, 0, 0}, n_wt[4] = {0, 0, 0, 0};      // (PROF) this lane's ticks by pass / in window tests; searches skipped / run: pass 2, pass 1      // (PROF) phase-A passes by lane / by wave; ticks with a rank / table / tail / list-only lane
 	for (;;) {
 		// ---- phase A: control programs, registers and LDS only
-		while (!has_req && !ld_kind && !exhausted) {
+		// (one pass per tick: a machine whose pass ends between two states -- 2 % of the lane-ticks, but 61 % of the ticks have one -- waits
+		// for the next tick's pass instead of making the whole wave run the pass again for it; EMA_SEED_ONEPASS=0: as many as it takes)
+		bool again = true;
+		while (!has_req && !ld_kind && !exhausted && again) {
+			again = !one_pass;
 			if (prof) { n_pass_lane += 1; }
 			int ev = 0;                       // 1: push v onto the current list, 2: emit v as a seed interval
 			uint64_t v0 = 0, v1 = 0, v2 = 0;
@@ -523,13 +528,13 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				else { x = i + 1; pc = PC_P3_NEXT; }
 			}
 		}
-		const unsigned long long busy = __ballot(has_req || ld_kind);
+		const unsigned long long busy = __ballot(!exhausted);      // every machine with a request or an entry load, and those between two states
 		if (!busy) break;
 		const int n_busy = __popcll(busy);
 		peak = peak > n_busy ? peak : n_busy;
 		// the queue is empty and the wave, once fuller, nearly so (a wave that never held more runs its machines to the end)
 		if (park_max > 0 && n_busy <= park_max && peak > park_max && __ballot(exhausted)) {
-			if (has_req || ld_kind) {
+			if (!exhausted) {
 				SeedPark k;
 				k.last_curr_size = last_curr_size; k.c0 = c0; k.c1 = c1; k.c2 = c2; k.f0 = f0; k.f1 = f1; k.f2 = f2;
 				k.ld_at = ld_at; k.wl = reinterpret_cast<uint64_t>(wl);

@@ -165,7 +165,7 @@ __attribute__((noinline)) inline int __builtin_amdgcn_readfirstlane(int v, int l
 	if (r != v) { fprintf(stderr, "simt_emu: value marked wave-uniform at line %d differs between lanes (%d vs %d)\n", line_, v, r); abort(); }
 	return r;
 }
-// DPP move: row_shr:n (0x110+n), row_bcast:15 (0x142), row_bcast:31 (0x143), wave_shr:1 (0x138); bound_ctrl = false
+// DPP move: row_shr:n (0x110+n), row_bcast:15 (0x142), row_bcast:31 (0x143), wave_shr:1 (0x138), wave_shl:1 (0x130); bound_ctrl = false
 __attribute__((noinline)) inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int row_mask, int bank_mask, bool, int line_ = __builtin_LINE()) {
 	emu::Lane &L = emu::W->lane[emu::W->cur];
 	unsigned p = L.par & 1; ++L.par;
@@ -178,6 +178,7 @@ __attribute__((noinline)) inline int __builtin_amdgcn_update_dpp(int old, int v,
 	else if (ctrl == 0x142) { if (row >= 1) src = row * 16 - 1; }
 	else if (ctrl == 0x143) { if (row >= 2) src = 31; }
 	else if (ctrl == 0x138) { if (lane >= 1) src = lane - 1; }
+	else if (ctrl == 0x130) { if (lane < 63) src = lane + 1; }      // wave_shl:1
 	else { fprintf(stderr, "simt_emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
 	if (src < 0 || emu::W->lane[src].done) return old;
 	return (int)(uint32_t)emu::W->slot[p][src];

@@ -330,7 +330,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10, help="default: 10 steps x 1 Mi pairs = the 10 M pairs of BASELINE configs[1]")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3, help="untimed passes before the timed ones; three, so that the pipeline's pooled page-locked batches (one per pass in flight) exist before the clock starts")
     ap.add_argument("--pairs", type=int, default=1048576, help="pairs per step and per GPU (one batch)")
     ap.add_argument("--batches", type=int, default=0, help="distinct batches resident per GPU (default min(steps, 10); steps cycle through them)")
     ap.add_argument("--genome-mbp", type=float, default=3100.0,

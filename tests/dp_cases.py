@@ -144,3 +144,32 @@ def scoring(a, b, o_del, e_del, o_ins, e_ins):
         for j in range(5):
             oo.mat[i * 5 + j] = -1 if i == 4 or j == 4 else (a if i == j else -b)
     return eo, oo
+
+
+def band_cases(rng, n):
+    """Global-alignment tasks for the band layout of the global DP (dev_dp.hpp, ema_wave_global_band: 2w + 1 <= 64 and
+    |tlen - qlen| <= w) and the traceback's runs: bands from 0 (a single diagonal) to 31, queries from 1 base to 255 at the sizes
+    where the column layout changes shape, clean diagonals, gaps of 1-24 bases, ambiguous bases in either sequence."""
+    qs, ts, prm = [], [], []
+    for _ in range(n):
+        ql = int(rng.choice([1, 2, 3, 5, 17, 40, 63, 64, 65, 100, 127, 150, 200, 250, 255, int(rng.integers(1, 256))]))
+        q = rng.integers(0, 4, ql).astype(np.uint8)
+        t = mutate(rng, q, sub=rng.choice([0.0, 0.03, 0.1, 0.3]), indel=rng.choice([0.0, 0.01, 0.05]))
+        if rng.random() < 0.3:
+            cut = int(rng.integers(0, len(t) + 1))
+            t = np.concatenate([t[:cut], rng.integers(0, 4, int(rng.integers(1, 25))).astype(np.uint8), t[cut:]])
+        if rng.random() < 0.2 and len(t) > 8:
+            cut = int(rng.integers(0, len(t) - 6))
+            t = np.concatenate([t[:cut], t[cut + int(rng.integers(1, 6)):]])
+        if len(t) == 0:
+            t = np.array([2], np.uint8)
+        if rng.random() < 0.2:
+            q = q.copy(); q[rng.random(ql) < 0.05] = 4
+        if rng.random() < 0.1:
+            t = t.copy(); t[rng.random(len(t)) < 0.05] = 4
+        d = abs(len(t) - ql)
+        w = d + int(rng.choice([0, 0, 1, 3, 3, 5, 10, 20]))
+        if rng.random() < 0.9:
+            w = max(w, 1)
+        qs.append(q); ts.append(t); prm.append(w)
+    return qs, ts, np.array(prm, dtype=np.int32)

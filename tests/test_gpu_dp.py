@@ -102,3 +102,18 @@ def test_dp_parity_other_scorings(sc):
         assert not bad, f"{len(bad)} local tasks differ, first {bad[:5]}"
     finally:
         e.close()
+
+
+def test_global_band_layout_and_traceback_runs(eng):
+    """The global DP with its lanes across the band and the traceback that takes a run of matches as one step (dev_dp.hpp), at
+    their edges: bands 0-31, queries of 1-255 bases, long clean diagonals, gaps, ambiguous bases -- score and CIGAR against
+    ksw_global2's restatement."""
+    rng = np.random.default_rng(105)
+    qs, ts, prm = D.band_cases(rng, 3000)
+    out, cig = eng.debug_dp(1, *D.flat(qs), *D.flat(ts), prm, cigar_cap=640)
+    bad = []
+    for i in range(len(qs)):
+        sc, ops = D.oracle_global(qs[i], ts[i], prm[i])
+        if sc != out[i, 0] or ops != cig[i, :max(0, out[i, 1])].tolist():
+            bad.append(i)
+    assert not bad, f"{len(bad)} global tasks differ, first {[(len(qs[i]), len(ts[i]), int(prm[i])) for i in bad[:5]]}"

@@ -58,7 +58,7 @@ ema_amd/libema_bwaabi.so: $(CSRC)/bwaabi.cpp include/ema_bwaabi.h include/ema_en
 	$(CXX) $(HOSTFLAGS) -Iinclude -shared -o $@ $(CSRC)/bwaabi.cpp -Lema_amd -lema_engine -Wl,-rpath,'$$ORIGIN'
 
 # oracle: the CPU checker; `ref` (only where /root/reference exists): the reference's own sources compiled where they lie into
-# oracle/_ref/ -- util.c, count, preproc, the host half over the oracle's nine-symbol face (ema_refhost), and the same objects
+# a directory OUTSIDE the repository ($EMA_REF_OUT, else $TMPDIR/ema_ref, else /tmp/ema_ref) -- util.c, count, preproc, the host half over the oracle's nine-symbol face (ema_refhost), and the same objects
 # over the product's face (ema_ref_gpu, needs libema_bwaabi.so)
 oracle: $(BWAABI)
 	$(MAKE) -C oracle

@@ -1,5 +1,5 @@
 """Writes tests/golden/count_vectors.json: inputs (tests/count_cases.py) and the bytes the REFERENCE's `ema count` produced for them
--- oracle/_ref/ref_count, i.e. /root/reference/cpp/count.cc compiled where it lies (oracle/Makefile, target ref).  Run in the
+-- $TMPDIR/ema_ref/ref_count, i.e. /root/reference/cpp/count.cc compiled where it lies (oracle/Makefile, target ref).  Run in the
 build container (the reference tree is needed); the vectors are what pins the product on a machine without it.
   python tests/golden/make_count_vectors.py"""
 import base64, json, os, random, subprocess, sys, tempfile
@@ -7,7 +7,7 @@ R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "tests"))
 import count_cases as K
 
-REF = os.path.join(R, "oracle", "_ref", "ref_count")
+REF = os.path.join(os.environ.get("EMA_REF_OUT") or os.path.join(os.environ.get("TMPDIR") or "/tmp", "ema_ref"), "ref_count")
 
 
 def run_ref(wl_text, fastq_text, max_map, haplotag):
@@ -42,7 +42,7 @@ def main():
         fq = "\n".join(lines[:8 * 39 + k])
         cases.append({"name": f"cut_short_after_{k}_lines_no_final_newline", "whitelist": wl_text, "fastq": fq, "max_map_size": 1 << 20, "haplotag": 0,
                       "expect": run_ref(wl_text, fq, 1 << 20, False)})
-    json.dump({"made_by": "tests/golden/make_count_vectors.py with oracle/_ref/ref_count (reference cpp/count.cc)", "cases": cases},
+    json.dump({"made_by": "tests/golden/make_count_vectors.py with $TMPDIR/ema_ref/ref_count (reference cpp/count.cc)", "cases": cases},
               open(os.path.join(R, "tests", "golden", "count_vectors.json"), "w"), indent=0)
     print(len(cases), "cases")
 

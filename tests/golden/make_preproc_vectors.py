@@ -1,5 +1,5 @@
 """Writes tests/golden/preproc_vectors.json: inputs (tests/count_cases.py) and, per bucket file, length + SHA-256 of what the
-REFERENCE's `ema count` + `ema preproc` produced for them -- oracle/_ref/ref_count and oracle/_ref/ref_preproc, i.e.
+REFERENCE's `ema count` + `ema preproc` produced for them -- $TMPDIR/ema_ref/ref_count and ref_preproc, i.e.
 /root/reference/cpp/count.cc and cpp/correct.cc compiled where they lie (oracle/Makefile, target ref).  Run in the build container.
   python tests/golden/make_preproc_vectors.py"""
 import json, os, random, sys, tempfile, pathlib
@@ -31,7 +31,7 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             want = T.run_reference(pathlib.Path(d) / "r", wl_text, fq, False, n_buckets=3)
         cases.append({"name": f"cut_short_after_{k}_lines_no_final_newline", "whitelist": wl_text, "fastq": fq, "haplotag": 0, "args": dict(n_buckets=3), "expect": T.digest(want)})
-    json.dump({"made_by": "tests/golden/make_preproc_vectors.py with oracle/_ref/ref_count + ref_preproc (reference cpp/count.cc, cpp/correct.cc)",
+    json.dump({"made_by": "tests/golden/make_preproc_vectors.py with ref_count + ref_preproc built outside the repository by oracle/Makefile (reference cpp/count.cc, cpp/correct.cc)",
                "cases": cases}, open(os.path.join(R, "tests", "golden", "preproc_vectors.json"), "w"), indent=0)
     print(len(cases), "cases")
 

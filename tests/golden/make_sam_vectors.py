@@ -3,7 +3,7 @@
 
     python tests/golden/make_sam_vectors.py        (build container only: needs /root/reference)
 
-`oracle/_ref/ema_refhost` (oracle/Makefile, target `refhost`) is every unmodified reference source -- src/align.c, bwabridge.c,
+`$TMPDIR/ema_ref/ema_refhost` (oracle/Makefile, target `refhost`) is every unmodified reference source -- src/align.c, bwabridge.c,
 samdict.c, samrecord.c, split.c, techs.c, util.c, main.c, cpp/*.cc -- compiled where it lies against the B2 headers under
 include/bwa_compat/ and linked to the nine libbwa symbols over the CPU oracle (oracle/bwaface.c).  This script runs
 `ema align -s <bucket> -r <ref> -t 1` (and `-x`, `-p haplotag`, `-R`, `-i`) on a few tiny inputs and commits, per case,
@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 from ema_amd import synth, build_index      # noqa: E402
 
 OUT = os.path.join(HERE, "sam")
-REFHOST = os.path.join(ROOT, "oracle", "_ref", "ema_refhost")
+REFHOST = os.path.join(os.environ.get("EMA_REF_OUT") or os.path.join(os.environ.get("TMPDIR") or "/tmp", "ema_ref"), "ema_refhost")
 
 
 def ref_plain():
@@ -199,7 +199,7 @@ def main():
         print(info)
         shutil.rmtree(run)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
-        json.dump({"generator": "tests/golden/make_sam_vectors.py", "binary": "oracle/_ref/ema_refhost (reference src/*.c + cpp/*.cc, unmodified, over oracle/bwaface.c)",
+        json.dump({"generator": "tests/golden/make_sam_vectors.py", "binary": "ema_refhost, built outside the repository by oracle/Makefile (reference src/*.c + cpp/*.cc, unmodified, over oracle/bwaface.c)",
                    "cases": manifest}, f, indent=1)
     shutil.rmtree(work)
 

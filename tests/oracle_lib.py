@@ -257,7 +257,7 @@ def cand_digest(cand: np.ndarray, cigar: np.ndarray, read_off: np.ndarray):
     return out
 
 
-# ---- bucket reader oracle (oracle/ingest.c) and the reference's own util.c (oracle/_ref/libref_util.so) ----
+# ---- bucket reader oracle (oracle/ingest.c) and the reference's own util.c (libref_util.so, built outside the repository) ----
 ORC_MAX_READ_LEN = 255
 
 
@@ -326,7 +326,10 @@ def _fields_with(fn, line: bytes, n_fields: int):
     return out
 
 
-REF_UTIL = os.path.join(ROOT, "oracle", "_ref", "libref_util.so")
+# Where `make -C oracle ref` puts what it builds from the reference's own sources: OUTSIDE the repository, so that nothing built
+# from /root/reference can travel to a GPU box with the working tree (oracle/Makefile, REFOUT).
+REF_OUT = os.environ.get("EMA_REF_OUT") or os.path.join(os.environ.get("TMPDIR") or "/tmp", "ema_ref")
+REF_UTIL = os.path.join(REF_OUT, "libref_util.so")
 
 
 class RefUtil:

@@ -1,5 +1,5 @@
 """`ema count` behind include/ema_count.h against the REFERENCE's own implementation (cpp/count.cc:38-182): the committed golden
-vectors (tests/golden/count_vectors.json, written by the reference compiled into oracle/_ref/ref_count) everywhere, and fresh
+vectors (tests/golden/count_vectors.json, written by the reference compiled into $TMPDIR/ema_ref/ref_count) everywhere, and fresh
 random inputs through that binary where it exists (the build container).  Both output files byte for byte."""
 import base64
 import json
@@ -13,7 +13,8 @@ import count_cases as K
 from ema_amd import count as ema_count
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.path.join(ROOT, "oracle", "_ref", "ref_count")
+import oracle_lib as _O
+REF = os.path.join(_O.REF_OUT, "ref_count")
 
 
 def product(tmp_path, wl_text, fastq_text, max_map, haplotag):
@@ -72,7 +73,7 @@ def test_blocks_statistics_and_errors(tmp_path):
         ema_count.count_fastq(str(tmp_path / "no_such_whitelist"), str(tmp_path / "in.fastq"), str(tmp_path / "o2"))
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's count (oracle/_ref/ref_count) is built where /root/reference exists")
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's count ($TMPDIR/ema_ref/ref_count) is built where /root/reference exists")
 @pytest.mark.parametrize("seed", [21, 22, 23])
 def test_random_inputs_against_the_reference_binary(tmp_path, seed):
     rng = random.Random(seed)

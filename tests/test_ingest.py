@@ -1,6 +1,6 @@
 """Bucket reader (include/ema_ingest.h): the product's parallel reader against the oracle's
 line-by-line restatement of read_special_fastq (reference src/align.c:751-843) on the same files, the oracle's util.c
-restatements against the reference's own util.c where it was compiled (oracle/_ref), and the error behaviour where the
+restatements against the reference's own util.c where it was compiled (oracle/Makefile `ref`, built outside the repository), and the error behaviour where the
 reference has undefined behaviour.  CPU only: the reader is host code."""
 import os
 import random
@@ -139,7 +139,7 @@ def test_barcode_codes_round_trip():
     assert ingest.encode_barcode(b"A" * 16) == 0      # the all-A barcode is the reference's sentinel code (src/align.c:1060)
 
 
-@pytest.mark.skipif(not os.path.exists(O.REF_UTIL), reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.skipif(not os.path.exists(O.REF_UTIL), reason="$TMPDIR/ema_ref not built (needs /root/reference at build time)")
 def test_oracle_util_restatements_equal_the_reference_util_c():
     """Pins oracle/ingest.c's copy_until_space / encode_bc / decode_bc to the reference's own compiled src/util.c."""
     ref = O.RefUtil()

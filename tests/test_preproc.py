@@ -1,5 +1,5 @@
 """`ema preproc` behind include/ema_preproc.h against the REFERENCE's own implementation (cpp/correct.cc:271-633): the committed
-golden vectors (tests/golden/preproc_vectors.json, written by the reference compiled into oracle/_ref/ref_preproc) everywhere, and
+golden vectors (tests/golden/preproc_vectors.json, written by the reference compiled into $TMPDIR/ema_ref/ref_preproc) everywhere, and
 fresh random inputs through that binary where it exists (the build container).  Every bucket file byte for byte."""
 import base64
 import hashlib
@@ -14,7 +14,8 @@ import count_cases as K
 from ema_amd import count as ema_count, preproc as ema_preproc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.path.join(ROOT, "oracle", "_ref", "ref_preproc")
+import oracle_lib as _O
+REF = os.path.join(_O.REF_OUT, "ref_preproc")
 
 
 def well_formed(fq: str) -> str:
@@ -91,7 +92,7 @@ def test_statistics_threads_and_errors(tmp_path):
         ema_preproc.preproc_fastq(str(tmp_path / "t1" / "wl.txt"), [str(tmp_path / "t1" / "wl.txt")], str(tmp_path / "o"), str(tmp_path / "t1" / "in.fastq"))
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's preproc (oracle/_ref/ref_preproc) is built where /root/reference exists")
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's preproc ($TMPDIR/ema_ref/ref_preproc) is built where /root/reference exists")
 @pytest.mark.parametrize("seed,kw", [(41, dict(n_buckets=5)), (42, dict(n_buckets=11, do_h2=True, n_threads=3)), (43, dict(n_buckets=3, do_bx_format=True)),
                                      (44, dict(n_buckets=4, buffer_size=2000, max_map=72 * 30)), (45, dict(n_buckets=2, do_h2=True, do_bx_format=True))])
 def test_random_inputs_against_the_reference_binary(tmp_path, seed, kw):
@@ -106,7 +107,7 @@ def test_random_inputs_against_the_reference_binary(tmp_path, seed, kw):
         assert got[f] == want[f], f"{f} differs"
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's preproc (oracle/_ref/ref_preproc) is built where /root/reference exists")
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's preproc ($TMPDIR/ema_ref/ref_preproc) is built where /root/reference exists")
 def test_haplotag_against_the_reference_binary(tmp_path):
     """Haplotag mode (96^4 whitelisted codes: half a minute per program run), including the reference's test of the BX tag against the
     previous pair's last line: the first pair of the stream is dropped."""

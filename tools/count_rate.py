@@ -1,4 +1,4 @@
-"""Dev aid (CPU): rate of ema_count_fastq against the reference's own `ema count` (oracle/_ref/ref_count, where it exists) on a
+"""Dev aid (CPU): rate of ema_count_fastq against the reference's own `ema count` ($TMPDIR/ema_ref/ref_count, where it exists) on a
 synthetic interleaved FASTQ of N pairs (2x150 bp, 10x barcodes from a 100 K whitelist), and that the four files are equal.
   python tools/count_rate.py [N_PAIRS]"""
 import os, random, subprocess, sys, tempfile, time
@@ -36,7 +36,7 @@ t = time.perf_counter()
 st = ema_count.count_fastq(os.path.join(d, "wl.txt"), fq, os.path.join(d, "a"))
 dt = time.perf_counter() - t
 print(f"ema_count_fastq: {n / dt:,.0f} pairs/s, {size / dt / 1e6:,.0f} MB/s ({dt:.2f} s; {st})")
-ref = os.path.join(R, "oracle", "_ref", "ref_count")
+ref = os.path.join(os.environ.get("EMA_REF_OUT") or os.path.join(os.environ.get("TMPDIR") or "/tmp", "ema_ref"), "ref_count")
 if os.path.exists(ref):
     t = time.perf_counter()
     subprocess.run([ref, os.path.join(d, "wl.txt"), os.path.join(d, "b"), str(1 << 30), "0"], stdin=open(fq, "rb"), check=True, stderr=subprocess.DEVNULL)

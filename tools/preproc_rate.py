@@ -1,5 +1,5 @@
 """Dev aid (CPU): rate of ema_count_fastq + ema_preproc_fastq against the reference's own `ema count` + `ema preproc`
-(oracle/_ref/ref_count, ref_preproc, where they exist) on a synthetic interleaved FASTQ of N pairs (2x150 bp, 10x barcodes from a
+($TMPDIR/ema_ref/ref_count, ref_preproc, where they exist) on a synthetic interleaved FASTQ of N pairs (2x150 bp, 10x barcodes from a
 100 K whitelist, 10 % of the barcodes one base off, 3 % with an N), and that every bucket file is equal.
   python tools/preproc_rate.py [N_PAIRS] [N_BUCKETS]"""
 import hashlib, os, subprocess, sys, tempfile, time
@@ -48,7 +48,8 @@ t1 = time.perf_counter()
 st = ema_preproc.preproc_fastq(wlp, [os.path.join(d, "a.ema-ncnt")], os.path.join(d, "A"), fq, n_threads=8, n_buckets=nb)
 t2 = time.perf_counter()
 print(f"product: count {n / (t1 - t):,.0f} pairs/s, preproc {n / (t2 - t1):,.0f} pairs/s ({size / (t2 - t1) / 1e6:,.0f} MB/s in); {st}")
-rc, rp = (os.path.join(R, "oracle", "_ref", x) for x in ("ref_count", "ref_preproc"))
+_out = os.environ.get("EMA_REF_OUT") or os.path.join(os.environ.get("TMPDIR") or "/tmp", "ema_ref")
+rc, rp = (os.path.join(_out, x) for x in ("ref_count", "ref_preproc"))
 if os.path.exists(rc) and os.path.exists(rp):
     t = time.perf_counter()
     subprocess.run([rc, wlp, os.path.join(d, "b"), str(1 << 30), "0"], stdin=open(fq, "rb"), check=True, stderr=subprocess.DEVNULL)

@@ -44,7 +44,7 @@ VALU_PEAK_GINST = 256 * 4 * 0.5 * 2.4
 CHR20_LEN = 64_444_167
 ENGINE_KNOBS = ("EMA_SEED_ROUNDS", "EMA_SEED_PARK", "EMA_SEED_BLOCKS_PER_CU", "EMA_FULL_SEED_LANE", "EMA_LANE_ALIGN", "EMA_FULL_OWN_STREAM",
                 "EMA_KMER_K", "EMA_HEAVY_CHAINS", "EMA_SEED_TAIL", "EMA_SEED_LONG_WAVE", "EMA_LEAN_SEED_EXTENDS", "EMA_GRID", "EMA_LEAN_INTERVALS",
-                "EMA_LEAN_REGIONS", "EMA_DEVICE_MERGE")
+                "EMA_LEAN_REGIONS", "EMA_DEVICE_MERGE", "EMA_TUNING", "EMA_EXT_LANE")      # (ema_amd/engine.py hands the EMA_<KNOB> ones to ema_engine_set_tuning)
 
 
 def log(*a):
@@ -345,6 +345,8 @@ def main(argv=None):
     ap.add_argument("--spot-check", type=int, default=24000, help="regular pairs of the timed steps re-aligned by the oracle afterwards (besides "
                                                                   "every pair the full-capacity tier redid in two of the steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-at-world-1", action="store_true", help="run the distributed control flow (torch.distributed process group, barriers, "
+                                                                    "all-reduces, statistics all-gather) even at world size 1")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / engine_resident / isolated passes (profiling runs)")
     ap.add_argument("--no-sam-leg", action="store_true", help="skip the bucket files -> SAM text leg (A/B runs of engine knobs)")
     ap.add_argument("--allow-capacity-flags", action="store_true", help="print the (invalid) line even if reads overflowed an engine capacity")
@@ -360,13 +362,16 @@ def main(argv=None):
         log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
         raise SystemExit(2)
     node_cpus = cpus_granted()
+    # --dist-at-world-1: the distributed control flow (process group, barriers, agree() all-reduces, the statistics all-gather on the
+    # device) also at world size 1 -- what a one-GPU box can run of it on hardware (tests/test_gpu_bench_dist.py)
+    use_dist = world > 1 or args.dist_at_world_1
     if world > 1 and "EMA_HOST_THREADS" not in os.environ:
         os.environ["EMA_HOST_THREADS"] = str(host_threads_for_rank(node_cpus, world))
     dist = None
     # RCCL ("nccl") on the GPU box; EMA_BENCH_BACKEND=gloo runs the same control flow on CPU tensors (the world-size-2 test)
     backend = os.environ.get("EMA_BENCH_BACKEND", "nccl")
     tdev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         import datetime
@@ -378,12 +383,13 @@ def main(argv=None):
             log(f"[rank {rank}] host threads: {os.environ.get('EMA_HOST_THREADS')} of {node_cpus} CPUs granted to the node's {world} ranks"
                 + (f", pinned to NUMA node {numa} (the GPU's)" if numa is not None else ""))
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
+            log(f"[rank {rank}] process group: backend {dist.get_backend()} (RCCL), world size {dist.get_world_size()}, device cuda:{local}")
         else:
             dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=30))
 
     def agree(value, op="min"):
         """rank 0's float for everybody (a plain tensor collective, like the ones below)"""
-        if world == 1:
+        if not use_dist:
             return value
         g = torch.tensor([value], dtype=torch.float64, device=tdev)
         dist.all_reduce(g, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.MAX)
@@ -392,7 +398,7 @@ def main(argv=None):
     import __graft_entry__
     if rank == 0:
         __graft_entry__.ensure_built()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     import tempfile
@@ -435,7 +441,7 @@ def main(argv=None):
             log(f"[rank 0] building the reference failed: {e!r}")
             failed = 1.0
     if agree(failed, "max") > 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         raise SystemExit(3)
     lens, gname = genome_spec(args)
@@ -499,7 +505,7 @@ def main(argv=None):
         eng.sync()
         if peer is not None:
             peer.sync()
-        if world > 1:
+        if use_dist:
             if tdev == "cuda":
                 torch.cuda.synchronize()
             dist.barrier()
@@ -544,8 +550,16 @@ def main(argv=None):
         return stream.SINK(cb)
 
     offs = [batches[k % n_batches].off for k in range(max(args.steps, args.warmup))]
+    cold_first_pass_s = None
     if args.warmup:
-        stream.stream_resident(eng, offs[:args.warmup], slots, opts=so, raw_sink=make_sink(False))
+        # the first untimed pass alone, timed apart: it pays what no later pass pays (the pooled page-locked batches -- hipHostMalloc of
+        # the first set -- the result sets' device allocations, cold caches); reported as `cold_first_pass_s`, never part of `value`
+        t_c = time.perf_counter()
+        stream.stream_resident(eng, offs[:1], slots, opts=so, raw_sink=make_sink(False))
+        sync_all()
+        cold_first_pass_s = time.perf_counter() - t_c
+        if args.warmup > 1:
+            stream.stream_resident(eng, offs[1:args.warmup], slots, opts=so, raw_sink=make_sink(False))
     sync_all()
     # ---- timed region: K steps = K batches (distinct up to n_batches), inputs resident, results + records on the host
     sink = make_sink(True)
@@ -558,7 +572,7 @@ def main(argv=None):
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)      # this rank's host threads over the timed region
     host_cpu_s = max(0.0, host_cpu_s - sink_cpu[0])      # ... without the spot check's sampling in the sink (the checker, not the product)
-    if world > 1:
+    if use_dist:
         elapsed = agree(elapsed, "max")
         host_cpu_s = agree(host_cpu_s, "max")
     for s in st_timed:
@@ -569,7 +583,7 @@ def main(argv=None):
             f"so the timed steps skipped work and the number is not valid")
         if not args.allow_capacity_flags:
             eng.close()
-            if world > 1:
+            if use_dist:
                 dist.destroy_process_group()
             raise SystemExit(2)
     # mean launch durations over the timed region (HIP events on the launching streams, read after every step's sync)
@@ -586,7 +600,7 @@ def main(argv=None):
         for k in range(args.steps):
             eng.run_slot(k % slots)      # the batches staged on this set
         sync_all()
-        el_r = agree(time.perf_counter() - t2, "max") if world > 1 else time.perf_counter() - t2
+        el_r = agree(time.perf_counter() - t2, "max") if use_dist else time.perf_counter() - t2
         resident = {"value": round(args.pairs * args.steps * world / el_r, 1), "unit": "pairs/s", "ms_per_step": round(el_r / args.steps * 1e3, 3),
                     "what": "K1-K4 only, steps queued back to back on one set of batch buffers, inputs resident, nothing fetched"}
         # ---- one pass on its own, from queueing to records on the host (what --sync-each-step used to show: nothing overlaps)
@@ -594,7 +608,7 @@ def main(argv=None):
         t3 = time.perf_counter()
         stream.stream_resident(eng, offs[:1], slots, opts=so, raw_sink=make_sink(False))
         sync_all()
-        el_1 = agree(time.perf_counter() - t3, "max") if world > 1 else time.perf_counter() - t3
+        el_1 = agree(time.perf_counter() - t3, "max") if use_dist else time.perf_counter() - t3
         resident["single_pass"] = {"value": round(args.pairs * world / el_1, 1), "unit": "pairs/s", "ms": round(el_1 * 1e3, 3),
                                    "what": "one batch alone through the timed region's path: three lean slices, the full-capacity tier, pack, D2H, assembly, "
                                            "append stage with nothing to overlap; the timed region's per-step time approaches engine_resident's as steps grow"}
@@ -610,7 +624,7 @@ def main(argv=None):
         t1 = time.perf_counter()
         st_b = stream.stream_batches(eng, hb, opts=so, raw_sink=make_sink(False))
         sync_all()
-        el_b = agree(time.perf_counter() - t1, "max") if world > 1 else time.perf_counter() - t1
+        el_b = agree(time.perf_counter() - t1, "max") if use_dist else time.perf_counter() - t1
         boundary = {"value": round(args.pairs * args.steps * world / el_b, 1), "unit": "pairs/s", "ms_per_step": round(el_b / args.steps * 1e3, 3),
                     "what": "host buffers in (ASCII reads) -> candidates + append_alignments records in host memory, "
                             "ema_stream_batches over the same batches: nt4 conversion, 2-bit packing, H2D, K1-K4, pack, D2H, append stage, "
@@ -622,7 +636,7 @@ def main(argv=None):
     from ema_amd import shard
     local_stats = np.array([[s[f] for f in shard.STAT_FIELDS] for s in st_timed], dtype=np.int64).sum(axis=0)[None, :]
     # the "trivial RCCL gather of per-bucket statistics" of the north star: one record per rank, O(100 B) over xGMI
-    gathered = shard.gather_stats(local_stats, world, device=(tdev if world > 1 and tdev == "cuda" else None))
+    gathered = shard.gather_stats(local_stats, world, device=(tdev if use_dist and tdev == "cuda" else None))
 
     bad = 0
     out = None
@@ -649,7 +663,7 @@ def main(argv=None):
     if bad:
         log(f"ERROR: {bad} reads of the spot check differ from the oracle: no bench line")
         eng.close()
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         raise SystemExit(2)
 
@@ -759,7 +773,12 @@ def main(argv=None):
                                    f"csrc/synth_genome.cpp, index by ema_index_build with the suffix array sorted on the GPU, both before the timed "
                                    f"region; --genome-mbp 0 = chr20-scale)",
                        "pairs_per_step_per_gpu": args.pairs, "distinct_batches": n_batches, "buffer_sets": n_sets, "max_occ": 3000,
-                       "parallelism": f"buckets x{world}", "engine_knobs_in_env": knobs},
+                       "parallelism": f"buckets x{world}", "engine_knobs_in_env": knobs,
+                       "method": {"warmup_passes": args.warmup, "since": "r04: three warm-up passes by default (r01-r03: one), so that the three pooled "
+                                  "page-locked batch sets exist before the clock starts; host CPU figures leave out the bench's own spot-check "
+                                  "sampling (host.spot_check_sampling_cpu_s_excluded); the spot check covers rank 0's kept samples -- r04+ figures "
+                                  "are not directly comparable with BENCH_r01-r03",
+                                  "cold_first_pass_s": None if cold_first_pass_s is None else round(cold_first_pass_s, 3)}},
             "boundary": boundary, "engine_resident": resident,
             "roofline": roofline, "roofline_k2b": roofline_k2b, "cpu_baseline": cpu,
             "bucket_stats": {f: int(gathered[:, i].sum()) for i, f in enumerate(shard.STAT_FIELDS)},
@@ -787,7 +806,7 @@ def main(argv=None):
         out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not (args.no_extras or args.no_sam_leg) else None
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

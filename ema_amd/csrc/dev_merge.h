@@ -11,6 +11,7 @@ struct MergeParts {      // by value: the packed sets of up to 16 slices and, la
 	const uint32_t *cig[17];
 	int first_read[17], n_reads[17];      // batch reads [first_read, first_read + n_reads) belong to slice k (not used for the last part)
 	int n_parts;                          // slices + 1
+	uint64_t cand_cap[17], cig_cap[17];   // capacities of each part's own packed arrays: a part whose pack overflowed is not read past them
 };
 
 

@@ -31,7 +31,47 @@
 #include "dev_types.h"
 #include "dev_merge.h"
 #include "host_index.h"
+const char *ema_tuning_get(const char *key);
 #include "opts.h"
+
+// ---------------------------------------------------------------------------------------------
+// Development knobs.  Everything that used to be an environment variable of its own (A/B switches of four rounds, the parity
+// tests' forced routes, profiling levels) is one comma-separated "key=value" string: ema_engine_set_tuning() (include/ema_engine.h;
+// what tests and tools call), or, when that was never called, the single environment variable EMA_TUNING.  Read when an engine
+// is opened.  The library neither reads other EMA_* variables on this path nor changes its host process's environment.
+static std::mutex g_tuning_mu;
+static std::string g_tuning;
+static bool g_tuning_set = false;
+extern "C" int ema_engine_set_tuning(const char *kv)
+{
+	std::lock_guard<std::mutex> lk(g_tuning_mu);
+	g_tuning_set = kv != nullptr;
+	g_tuning = kv ? kv : "";
+	return EMA_OK;
+}
+// value of `key` (storage of this thread, valid for its next seven calls), or nullptr
+const char *ema_tuning_get(const char *key)
+{
+	static thread_local std::string ring[8];
+	static thread_local unsigned turn = 0;
+	std::string &val = ring[turn++ & 7];
+	std::string all;
+	{
+		std::lock_guard<std::mutex> lk(g_tuning_mu);
+		if (g_tuning_set) all = g_tuning;
+		else if (const char *v = getenv("EMA_TUNING")) all = v;
+	}
+	const size_t kl = strlen(key);
+	for (size_t at = 0; at < all.size();) {
+		size_t end = all.find(',', at);
+		if (end == std::string::npos) end = all.size();
+		while (at < end && all[at] == ' ') ++at;
+		if (end - at > kl && all.compare(at, kl, key) == 0 && all[at + kl] == '=') { val = all.substr(at + kl + 1, end - at - kl - 1); return val.c_str(); }
+		at = end + 1;
+	}
+	return nullptr;
+}
+static bool ema_verbose() { const char *v = ema_tuning_get("verbose"); return v && atoi(v) != 0; }
 #include "host_cpuacct.h"
 #include "host_pool.h"
 
@@ -371,7 +411,9 @@ struct ema_engine {
 	DevBuf<int> d_m_c, d_m_g, d_redo_idx;
 	DevBuf<uint32_t> d_m_src;
 	DevBuf<uint2> d_m_block;
-	bool merged_ready = false, device_merge = true;      // EMA_DEVICE_MERGE=0: round 3's host-side assembly
+	bool merged_ready = false, device_merge = true;      // tuning knob device_merge=0: round 3's host-side assembly
+	int merged_cand_per_read = 6, merged_cig_per_read = 24;      // size of the merged set (tuning knobs merged_cand / merged_cigar: the fallback's test)
+	int n_merge_fallbacks = 0;
 	struct PinPool *pin_pool = nullptr;                  // page-locked landing buffers that ARE the batches handed out (below)
 	struct FetchPin { PinBuf<uint64_t> c_off, g_off; PinBuf<int> status; PinBuf<ema_cand_t> cand; PinBuf<uint32_t> cig; };
 	std::vector<FetchPin> fetch_pin;     // page-locked landing buffers of ema_engine_fetch_ticket, per slice + full tier
@@ -434,7 +476,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_todo.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
-	if (e->watchdog_s > 0 && !getenv("EMA_WATCHDOG_NOMARK")) {
+	if (e->watchdog_s > 0 && !ema_tuning_get("watchdog_nomark")) {
 		HIPCHK(e, hipHostMalloc((void **)&s.dbg, (size_t)e->dbg_slots * 4 * sizeof(int), hipHostMallocDefault));
 		memset(s.dbg, 0xff, (size_t)e->dbg_slots * 4 * sizeof(int));
 	}
@@ -520,9 +562,9 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->device = device;
 	memset(&e->timing, 0, sizeof(e->timing));
 	// The slices and the full-capacity tier want a hardware queue each, plus the null stream's; the ROCm runtime gives a
-	// process 4 unless GPU_MAX_HW_QUEUES says otherwise, and reads it when it initialises -- so ask for 8 here, which
-	// takes effect if nothing in the process has touched the GPU yet (bench.py and the Python wrapper set it at import).
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	// process 4 unless GPU_MAX_HW_QUEUES says otherwise, and reads it when it initialises.  That is the EMBEDDING PROGRAM's
+	// setting to make (bench.py and the Python wrapper set 8 at import): the library does not touch its host's
+	// environment, it reads what it finds (below) and places the full tier's work accordingly.
 	int n_dev = 0;
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { e->err = "no HIP device available (the engine has no CPU fallback)"; return EMA_EDEVICE; }
 	if (device < 0 || device >= n_dev) { e->err = "device index out of range"; return EMA_EARG; }
@@ -566,7 +608,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 		}
 		HIPCHK(e, hipDeviceSynchronize());
 		d_samp.release();
-		if (getenv("EMA_VERBOSE")) fprintf(stderr, "[ema] no %s.fsa: flat suffix array expanded on the device from bwa's sampled .sa (every %d rows)\n", index_prefix, hix.sa_intv);
+		if (ema_verbose()) fprintf(stderr, "[ema] no %s.fsa: flat suffix array expanded on the device from bwa's sampled .sa (every %d rows)\n", index_prefix, hix.sa_intv);
 	}
 	HIPCHK(e, e->d_ctg_tab.alloc(hix.ctg_tab.size()));
 	HIPCHK(e, hipMemcpy(e->d_ctg_tab.p, hix.ctg_tab.data(), hix.ctg_tab.size() * 4, hipMemcpyHostToDevice));
@@ -581,7 +623,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 		// 14 (2.9 GB); EMA_KMER_K overrides (0: none)
 		int k = 0;
 		while (k < 14 && ((uint64_t)1 << (2 * (k + 1))) <= e->dix.seq_len / 2) ++k;
-		if (const char *v = getenv("EMA_KMER_K")) k = std::max(0, std::min(EMA_KMER_MAX, atoi(v)));
+		if (const char *v = ema_tuning_get("kmer_k")) k = std::max(0, std::min(EMA_KMER_MAX, atoi(v)));
 		if (k > 0) {
 			const int w = k < EMA_KMER_WIDE ? k : EMA_KMER_WIDE;
 			DevBuf<int> d_over;
@@ -605,7 +647,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	}
 	e->dix.text2 = nullptr;
 	{   // K1's tails read the text itself (DevIndex::text2; needs the table mode); EMA_SEED_TAIL=0: rank queries to the last base
-		const char *v = getenv("EMA_SEED_TAIL");
+		const char *v = ema_tuning_get("seed_tail");
 		if (e->dix.kmer_k > 0 && (!v || atoi(v) != 0)) {
 			HIPCHK(e, e->d_text2.alloc(ema_text2_words(e->l_pac)));
 			ema_launch_text2(e->d_pac.p, e->l_pac, e->d_text2.p, nullptr);
@@ -616,10 +658,10 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	}
 	}
 
-	if (getenv("EMA_PHASE_PROFILE") && atoi(getenv("EMA_PHASE_PROFILE")) == 3) {
+	if (const char *pp3 = ema_tuning_get("phase_profile"); pp3 && atoi(pp3) == 3) {
 		HIPCHK(e, e->d_lprof.alloc(48)); HIPCHK(e, hipMemset(e->d_lprof.p, 0, 48 * 8));
 		ema_align_set_light_profile(e->d_lprof.p);
-	} else if (const char *pp = getenv("EMA_PHASE_PROFILE")) {
+	} else if (const char *pp = ema_tuning_get("phase_profile")) {
 		HIPCHK(e, e->d_prof.alloc(48)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 384));
 		{ const unsigned long long ones[2] = {~0ULL, ~0ULL}; HIPCHK(e, hipMemcpy(e->d_prof.p + 26, ones, 16, hipMemcpyHostToDevice)); }
 		if (atoi(pp) >= 2) {      // per-read log of K2b (k_align.hip): [0] entries, [1] capacity, records from word 16
@@ -631,42 +673,44 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 			HIPCHK(e, hipMemcpy(e->d_prof.p + 31, &addr, 8, hipMemcpyHostToDevice));
 		}
 	}
-	if (const char *wd = getenv("EMA_WATCHDOG_S")) { e->watchdog_s = atof(wd); e->dbg_slots = e->n_cu * 8 * 4 + 64; }
-	if (const char *v = getenv("EMA_SEED_ROUNDS")) e->seed_rounds = std::max(1, std::min(8, atoi(v)));
-	if (const char *v = getenv("EMA_SEED_PARK")) e->seed_park_max = std::max(0, std::min(63, atoi(v)));
+	if (const char *wd = ema_tuning_get("watchdog_s")) { e->watchdog_s = atof(wd); e->dbg_slots = e->n_cu * 8 * 4 + 64; }
+	if (const char *v = ema_tuning_get("seed_rounds")) e->seed_rounds = std::max(1, std::min(8, atoi(v)));
+	if (const char *v = ema_tuning_get("seed_park")) e->seed_park_max = std::max(0, std::min(63, atoi(v)));
 	if (e->seed_park_max == 0) e->seed_rounds = 1;
 	// K1: every lane of its grid carries one read at a time.  Half the lanes the chip could hold (2 of 4 blocks per CU):
 	// each lane then works through twice as many reads, so the drain at the end of a launch -- partly filled waves at
 	// full instruction cost -- is a smaller share, and the other slices' kernels use the issue slots left free
 	// (+6 % end to end; EMA_SEED_BLOCKS_PER_CU overrides).
 	e->seed_blocks = e->n_cu * std::min(ema_seed_blocks_per_cu(), 2);
-	if (const char *v = getenv("EMA_SEED_BLOCKS_PER_CU")) e->seed_blocks = e->n_cu * std::max(1, std::min(ema_seed_blocks_per_cu(), atoi(v)));
+	if (const char *v = ema_tuning_get("seed_blocks_per_cu")) e->seed_blocks = e->n_cu * std::max(1, std::min(ema_seed_blocks_per_cu(), atoi(v)));
 	e->align_blocks = e->n_cu * ema_align_blocks_per_cu();    // one scratch slab per resident wave
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
 	e->lane_blocks = e->n_cu * ema_align_simple_blocks_per_cu();
 	{   // EMA_GRID="k2a,k2b,k3,k4": resident blocks per CU of those kernels, at most what the occupancy calculation allows (0 = leave)
 		int v[4] = {0, 0, 0, 0};
-		if (const char *g = getenv("EMA_GRID")) sscanf(g, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+		if (const char *g = ema_tuning_get("grid")) sscanf(g, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
 		int *blk[4] = {&e->lane_blocks, &e->align_blocks, &e->pair_blocks, &e->final_blocks};
 		for (int k = 0; k < 4; ++k) if (v[k] > 0 && v[k] * e->n_cu < *blk[k]) *blk[k] = v[k] * e->n_cu;
 	}
 	e->seed_wave_blocks = e->n_cu * ema_seed_wave_blocks_per_cu();
-	if (const char *v = getenv("EMA_FULL_SEED_LANE")) e->wave_seed = atoi(v) == 0;
-	if (const char *v = getenv("EMA_SEED_LONG_WAVE")) e->long_wave = atoi(v) != 0;
-	if (const char *v = getenv("EMA_SEED_ORDER")) {
+	if (const char *v = ema_tuning_get("full_seed_lane")) e->wave_seed = atoi(v) == 0;
+	if (const char *v = ema_tuning_get("seed_long_wave")) e->long_wave = atoi(v) != 0;
+	if (const char *v = ema_tuning_get("seed_order")) {
 		int m4 = 0, ns = 0;
 		const int got = sscanf(v, "%d,%d", &m4, &ns);
 		e->seed_order = got >= 1 && m4 != 0;
 		if (got >= 1 && m4 > 1) e->order_mult4 = m4;      // ("1" = on with the defaults)
 		if (got >= 2 && ns >= 1) e->order_samples = std::min(16, ns);
 	}
-	if (const char *v = getenv("EMA_DEVICE_MERGE")) e->device_merge = atoi(v) != 0;
-	if (const char *v = getenv("EMA_LANE_ALIGN")) e->lane_align = atoi(v) != 0;
-	if (const char *v = getenv("EMA_HEAVY_CHAINS")) e->heavy_chains = std::max(0, atoi(v));
-	if (const char *v = getenv("EMA_HEAVY_ATTEMPTS")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
-	if (const char *v = getenv("EMA_HEAVY_REGIONS")) e->heavy_regions = std::max(0, atoi(v));        //  pair / read takes the set-aside route)
-	if (const char *v = getenv("EMA_SMALL_ONE_SLICE")) e->small_one_slice = atoi(v) != 0;
+	if (const char *v = ema_tuning_get("device_merge")) e->device_merge = atoi(v) != 0;
+	if (const char *v = ema_tuning_get("merged_cand")) e->merged_cand_per_read = std::max(0, atoi(v));
+	if (const char *v = ema_tuning_get("merged_cigar")) e->merged_cig_per_read = std::max(0, atoi(v));
+	if (const char *v = ema_tuning_get("lane_align")) e->lane_align = atoi(v) != 0;
+	if (const char *v = ema_tuning_get("heavy_chains")) e->heavy_chains = std::max(0, atoi(v));
+	if (const char *v = ema_tuning_get("heavy_attempts")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
+	if (const char *v = ema_tuning_get("heavy_regions")) e->heavy_regions = std::max(0, atoi(v));        //  pair / read takes the set-aside route)
+	if (const char *v = ema_tuning_get("small_one_slice")) e->small_one_slice = atoi(v) != 0;
 
 	int n_streams = e->opts.n_streams > 0 ? e->opts.n_streams : 3;   // streams beyond the process's hardware queues only serialise
 	if (n_streams > 16) n_streams = 16;
@@ -683,7 +727,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	for (auto &s : e->sl) {
 		s.cap_pairs = per;
 		s.dopts = e->dopts;
-		const char *env_i = getenv("EMA_LEAN_INTERVALS"), *env_r = getenv("EMA_LEAN_REGIONS");      // (A/B runs; the options win)
+		const char *env_i = ema_tuning_get("lean_intervals"), *env_r = ema_tuning_get("lean_regions");      // (A/B runs; the options win)
 		s.dopts.intv_cap = std::min(EMA_INTV_CAP, e->opts.lean_intervals > 0 ? e->opts.lean_intervals : env_i && atoi(env_i) > 0 ? atoi(env_i) : EMA_INTV_LEAN);
 		s.dopts.reg_cap = std::min(EMA_REG_CAP, e->opts.lean_regions > 0 ? e->opts.lean_regions : env_r && atoi(env_r) > 0 ? atoi(env_r) : EMA_REG_LEAN);
 		s.dopts.cig_cap = std::min(EMA_CIG_CAP, e->opts.lean_cigar_ops > 0 ? e->opts.lean_cigar_ops : EMA_CIG_LEAN);
@@ -699,8 +743,9 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	// The full tier gets a stream of its own when there is a hardware queue to spare (its kernels are one long latency
 	// chain of a few heavy reads: on a slice's stream they would hold up that slice's next pass); otherwise its work
 	// follows the last slice's.  EMA_FULL_OWN_STREAM=0/1 overrides.
-	bool own = atoi(getenv("GPU_MAX_HW_QUEUES")) >= n_streams + 2;
-	if (const char *v = getenv("EMA_FULL_OWN_STREAM")) own = atoi(v) != 0;
+	const char *hwq = getenv("GPU_MAX_HW_QUEUES");      // (the runtime's default is 4)
+	bool own = (hwq ? atoi(hwq) : 4) >= n_streams + 2;
+	if (const char *v = ema_tuning_get("full_own_stream")) own = atoi(v) != 0;
 	int rc = slice_alloc(e, e->full, own ? nullptr : e->sl.back().stream);
 	if (rc != EMA_OK) return rc;
 	HIPCHK(e, e->d_redo.alloc(full_cap + 1));
@@ -711,7 +756,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p, &e->dix, sizeof(DevIndex), hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_FULL, &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_LEAN, &e->sl[0].dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
-	if (getenv("EMA_VERBOSE")) {
+	if (ema_verbose()) {
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 			fprintf(stderr, "[ema] engine open: %.1f GB of the device's %.1f GB in use (index, tables, slots of %zu pairs in %zu slices + the full tier; result sets and input slots come with the first pass)\n",
@@ -758,7 +803,7 @@ ema_engine_t *ema_engine_peer(ema_engine_t *e)
 			ema_engine_close(e->shadow);
 			e->shadow = nullptr;
 		}
-		if (getenv("EMA_VERBOSE")) fprintf(stderr, "ema_engine_peer: %s, %.1f GB of device memory free\n", e->shadow ? "second set of batch buffers created" : "no room for a second set", free_b / 1e9);
+		if (ema_verbose()) fprintf(stderr, "ema_engine_peer: %s, %.1f GB of device memory free\n", e->shadow ? "second set of batch buffers created" : "no room for a second set", free_b / 1e9);
 	}
 	return e->shadow;
 }
@@ -1135,7 +1180,7 @@ static int merged_alloc(ema_engine *e)
 	if (e->merged_ready) return EMA_OK;
 	const size_t nr = 2 * e->cap_pairs;
 	for (auto &m : e->merged) {
-		m.cand_cap = nr * 6 + 4096; m.cigar_cap = nr * 24 + 4096;      // a bucket averages 1.3 candidates and 3 operations per read
+		m.cand_cap = nr * (size_t)e->merged_cand_per_read + 4096; m.cigar_cap = nr * (size_t)e->merged_cig_per_read + 4096;      // a bucket averages 1.3 candidates and 3 operations per read
 		HIPCHK(e, m.d_cand.alloc(m.cand_cap)); HIPCHK(e, m.d_cigar.alloc(m.cigar_cap));
 		HIPCHK(e, m.d_cand_off.alloc(nr + 2)); HIPCHK(e, m.d_cig_off.alloc(nr + 2)); HIPCHK(e, m.d_tot.alloc(2)); HIPCHK(e, m.d_status.alloc(nr + 2));
 		HIPCHK(e, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
@@ -1192,6 +1237,7 @@ int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket)
 		for (size_t k = 0; k <= n_sl; ++k) {
 			const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
 			P.c_off[k] = o.d_cand_off.p; P.g_off[k] = o.d_cig_off.p; P.status[k] = o.d_status.p; P.cand[k] = o.d_cand.p; P.cig[k] = o.d_cigar.p;
+			P.cand_cap[k] = o.cand_cap; P.cig_cap[k] = o.cigar_cap;
 			if (k < n_sl) { P.first_read[k] = (int)(2 * e->sl[k].first_pair); P.n_reads[k] = (int)(2 * e->sl[k].n_pairs); HIPCHK(e, hipStreamWaitEvent(f.stream, o.done, 0)); }
 		}
 		P.n_parts = (int)n_sl + 1;
@@ -1251,7 +1297,11 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 			(void)hipEventElapsedTime(&e->timing.full_tier_ms, f.tev[j][0], f.tev[j][4]);
 			for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&e->timing.full_ms[k], f.tev[j][k], f.tev[j][k + 1]);
 		}
-		if (tot[0] > m.cand_cap || tot[1] > m.cigar_cap) { e->err = "the merged result buffers are too small for this batch; use ema_engine_run + ema_engine_fetch"; return EMA_ELIMIT; }
+		// The merged set is sized for a usual bucket (6 candidates and 24 CIGAR operations per read); the slices' own packed sets hold
+		// 12 / 48 per read (64 / 256 in the full tier).  A repeat-heavy batch that fits those but not the merged set is assembled on
+		// the host from the slices' sets, as before the device-side merge existed (below) -- not refused.
+		const bool merged_fits = tot[0] <= m.cand_cap && tot[1] <= m.cigar_cap;
+		if (merged_fits) {
 		for (size_t k = 0; k <= n_sl; ++k) {      // a slice's own packed set must have held its results for the merge to have copied them
 			const Slice::OutSet &o = k < n_sl ? e->sl[k].out[j] : f.out[j];
 			if (part_tot[2 * k] > o.cand_cap || part_tot[2 * k + 1] > o.cigar_cap) { e->err = "the packed result buffers of a slice are too small for this batch; use ema_engine_run + ema_engine_fetch"; return EMA_ELIMIT; }
@@ -1287,6 +1337,8 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 		for (size_t r = 0; r < n_reads; ++r) any |= o->status[r];
 		if (any) { e->err = "a read exceeded an engine capacity; see ema_batch_out.status"; return EMA_ELIMIT; }
 		return EMA_OK;
+		}
+		++e->n_merge_fallbacks;
 	}
 	// totals first
 	std::vector<uint64_t> tot(2 * (n_sl + 1), 0);
@@ -1750,7 +1802,7 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
 	HIPCHK(e, hipGetLastError());
 	HIPCHK(e, hipEventRecord(e->sl[0].ev[6], e->sl[0].stream));
 	HIPCHK(e, hipStreamSynchronize(e->sl[0].stream));
-	if (getenv("EMA_DP_TIMING")) {
+	if (ema_tuning_get("dp_timing")) {
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, e->sl[0].ev[5], e->sl[0].ev[6]);
 		fprintf(stderr, "debug_dp kind %d: %d tasks in %.3f ms\n", kind, n_tasks, ms);
@@ -1912,7 +1964,7 @@ int ema_engine_align_pairs(ema_engine_t *e, const char *bases, const uint32_t *o
 	const size_t n_parts = (n_pairs + e->cap_pairs - 1) / e->cap_pairs;
 	std::vector<ema_batch_out *> parts(n_parts, nullptr);
 	std::vector<int> rcs(n_parts, EMA_OK);
-	const char *pv = getenv("EMA_ALIGN_PIPELINE");
+	const char *pv = ema_tuning_get("align_pipeline");
 	if (!e->shadow && !(pv && atoi(pv) == 0)) {
 		ema_engine_t *sh = nullptr;
 		if (engine_open(nullptr, e, e->device, &e->opts, &sh) == EMA_OK) e->shadow = sh;

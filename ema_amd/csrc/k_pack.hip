@@ -141,7 +141,10 @@ ema_k_merge_copy(MergeParts P, int n_reads, const uint32_t *__restrict__ src, co
 	const int part = (int)(src[r] >> 27), idx = (int)(src[r] & 0x7ffffffu);
 	const uint64_t c0 = P.c_off[part][idx], nc = P.c_off[part][idx + 1] - c0, g0 = P.g_off[part][idx], ng = P.g_off[part][idx + 1] - g0;
 	const uint64_t co = cand_off[r], go = cig_off[r];
-	if (co + nc > cand_cap || go + ng > cigar_cap) return;      // (the host checks the totals against the same capacities and fails loudly)
+	if (co + nc > cand_cap || go + ng > cigar_cap) return;      // (the host checks the totals against the same capacities and falls back to its own assembly)
+	// a part whose own pack overflowed: its offsets count every candidate, its arrays end at their capacity -- the host
+	// sees the part's totals after this launch and reports EMA_ELIMIT; nothing is read past the allocation meanwhile
+	if (c0 + nc > P.cand_cap[part] || g0 + ng > P.cig_cap[part]) return;
 	const ema_cand_t *sc = P.cand[part] + c0;
 	for (uint64_t k = 0; k < nc; ++k) {
 		ema_cand_t c = sc[k];

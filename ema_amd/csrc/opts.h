@@ -17,7 +17,12 @@ inline DevOpts ema_make_dev_opts(const ema_engine_opts &o)
 	d.max_chain_gap = o.max_chain_gap; d.min_chain_weight = o.min_chain_weight; d.max_chain_extend = o.max_chain_extend;
 	d.mask_level = o.mask_level; d.drop_ratio = o.drop_ratio; d.mask_level_redun = o.mask_level_redun;
 	d.intv_cap = EMA_INTV_CAP; d.reg_cap = EMA_REG_CAP; d.cig_cap = EMA_CIG_CAP; d.seed_budget = 1 << 30;
-	{ const char *v = getenv("EMA_SEED_WTEST"), *w = getenv("EMA_SEED_ANCHOR"); const char *u = getenv("EMA_SEED_ONEPASS"); d.seed_flags = ((v && atoi(v) == 0) ? 0 : 1) | ((w && atoi(w) == 0) ? 0 : 2) | ((u && atoi(u) == 0) ? 0 : 4); }      // (the switch exists for A/B runs and for the parity tests of both routes)
+	{   // (ema_tuning_get: engine.hip; each call's result is consumed before the next)
+		const char *v = ema_tuning_get("seed_wtest"); const int f0 = (v && atoi(v) == 0) ? 0 : 1;
+		v = ema_tuning_get("seed_anchor"); const int f1 = (v && atoi(v) == 0) ? 0 : 2;
+		v = ema_tuning_get("seed_onepass"); const int f2 = (v && atoi(v) == 0) ? 0 : 4;
+		d.seed_flags = f0 | f1 | f2;
+	}      // (the switch exists for A/B runs and for the parity tests of both routes)
 	int k = 0;
 	for (int i = 0; i < 4; ++i) {
 		for (int j = 0; j < 4; ++j) d.mat[k++] = (int8_t)(i == j ? o.a : -o.b);

@@ -126,8 +126,45 @@ def load_library():
         L.ema_engine_debug_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ema_engine_debug_contigs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ema_engine_debug_dp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ema_engine_set_tuning.argtypes = [C.c_char_p]
         _lib = L
+        tuning_from_env(LEGACY_KNOB_VARS)      # (the A/B scripts under tools/ still say EMA_SEED_TAIL=0 python3 ...: translated here, once)
     return _lib
+
+
+# The knobs that were environment variables of the LIBRARY up to round 4; the library itself now reads only EMA_TUNING / set_tuning.
+LEGACY_KNOB_VARS = ("EMA_KMER_K", "EMA_SEED_TAIL", "EMA_SEED_WTEST", "EMA_SEED_ANCHOR", "EMA_SEED_ONEPASS", "EMA_SEED_ROUNDS", "EMA_SEED_PARK",
+                    "EMA_SEED_BLOCKS_PER_CU", "EMA_SEED_ORDER", "EMA_SEED_LONG_WAVE", "EMA_FULL_SEED_LANE", "EMA_FULL_OWN_STREAM", "EMA_GRID",
+                    "EMA_DEVICE_MERGE", "EMA_LANE_ALIGN", "EMA_HEAVY_CHAINS", "EMA_HEAVY_ATTEMPTS", "EMA_HEAVY_REGIONS", "EMA_SMALL_ONE_SLICE",
+                    "EMA_LEAN_INTERVALS", "EMA_LEAN_REGIONS", "EMA_PHASE_PROFILE", "EMA_WATCHDOG_S", "EMA_WATCHDOG_NOMARK", "EMA_DP_TIMING",
+                    "EMA_ALIGN_PIPELINE", "EMA_VERBOSE", "EMA_EXT_LANE")
+
+
+_tuning = {}
+
+
+def set_tuning(**knobs):
+    """Development knobs of the library (include/ema_engine.h, ema_engine_set_tuning): `set_tuning(seed_tail=0, kmer_k=12)`;
+    a value of None removes a knob; no arguments at all clears them (back to the EMA_TUNING environment variable, if any).
+    Read when an engine is opened.  This is what the tests and tools use instead of one environment variable per knob."""
+    L = _lib if _lib is not None else load_library()
+    if not knobs:
+        _tuning.clear()
+    for k, v in knobs.items():
+        if v is None:
+            _tuning.pop(k, None)
+        else:
+            _tuning[k] = str(v)
+    L.ema_engine_set_tuning(",".join(f"{k}={v}" for k, v in _tuning.items()).encode() if _tuning else None)
+
+
+def tuning_from_env(names, environ=None):
+    """For command-line tools that take A/B knobs from their environment (tools/*.sh): EMA_<KNOB> -> knob, for the names given."""
+    environ = os.environ if environ is None else environ
+    got = {n[4:].lower(): environ[n] for n in names if n in environ}
+    if got:
+        set_tuning(**got)
+    return got
 
 
 def default_opts() -> Opts:

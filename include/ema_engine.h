@@ -195,6 +195,12 @@ int ema_engine_debug_dp(ema_engine_t *e, int kind, const uint8_t *qbuf, const ui
  * debug_final: mem_reg2aln (src/bwabridge.c:304) for n_regs given regions of one read: out[i] (region fields + pos, is_rev,
  *   NM, n_cigar, cigar_off into `cigar`). */
 int ema_engine_set_opts(ema_engine_t *e, const ema_engine_opts *o);
+/* Development knobs (no reference counterpart: the reference has no such switches): one comma-separated "key=value" string, read
+ * when an engine is opened -- A/B switches, the parity tests' forced routes, profiling levels (keys: ema_amd/csrc/engine.hip,
+ * ema_tuning_get call sites).  NULL returns to the default, which is the environment variable EMA_TUNING if
+ * set and nothing otherwise.  Process-wide; the library reads no other EMA_* variable when it opens an engine and never changes
+ * its host's environment (GPU_MAX_HW_QUEUES is the embedding program's to set: INTEGRATION.md). */
+int ema_engine_set_tuning(const char *kv);
 int ema_engine_debug_matesw(ema_engine_t *e, const void *anchor, const char *mate, int l_mate, void *ma, int32_t *n_ma, int cap,
                             int pes_low, int pes_high, int32_t *n_sw);
 int ema_engine_debug_final(ema_engine_t *e, const char *read, int l_read, const void *regs, int n_regs, ema_cand_t *out, uint32_t *cigar,

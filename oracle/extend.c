@@ -42,6 +42,10 @@ __thread uint64_t orc_extprof[16];
 static __thread int extprof_read_bad, extprof_chain_no;
 void orc_extprof_get(uint64_t *out) { memcpy(out, orc_extprof, sizeof(orc_extprof)); }
 void orc_extprof_reset(void) { memset(orc_extprof, 0, sizeof(orc_extprof)); }
+/* Off unless tools/cpu_extend_profile.py switches it on (orc_extprof_enable): the timed oracle path -- bench.py's cpu_baseline and its
+ * spot check run orc_chain2aln -- pays one predictable branch per extension and nothing else. */
+static int extprof_on = 0;
+void orc_extprof_enable(int on) { extprof_on = on; }
 static void extprof_call(const orc_opt_t *opt, int qlen, const uint8_t *q, int tlen, const uint8_t *t, int h0)
 {
 	int j, n_mm = 0, p_mm = -1, why = 1;
@@ -148,7 +152,7 @@ void orc_chain2aln(const orc_opt_t *opt, const orc_idx_t *idx, int l_query, cons
 			for (i = 0; i < MAX_BAND_TRY; ++i) {
 				int prev = a->score;
 				aw[0] = opt->w << i;
-				if (i == 0) extprof_call(opt, s->qbeg, qs, (int)tmp, rs, s->len * opt->a);
+				if (i == 0 && extprof_on) extprof_call(opt, s->qbeg, qs, (int)tmp, rs, s->len * opt->a);
 				a->score = orc_ksw_extend2(s->qbeg, qs, (int)tmp, rs, 5, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins,
 				                           aw[0], opt->pen_clip5, opt->zdrop, s->len * opt->a, &qle, &tle, &gtle, &gscore, &max_off[0]);
 				if (a->score == prev || max_off[0] < (aw[0] >> 1) + (aw[0] >> 2)) break;
@@ -171,7 +175,7 @@ void orc_chain2aln(const orc_opt_t *opt, const orc_idx_t *idx, int l_query, cons
 			for (i = 0; i < MAX_BAND_TRY; ++i) {
 				int prev = a->score;
 				aw[1] = opt->w << i;
-				if (i == 0) extprof_call(opt, l_query - qe, query + qe, (int)(rmax[1] - rmax[0] - re), rseq + re, sc0);
+				if (i == 0 && extprof_on) extprof_call(opt, l_query - qe, query + qe, (int)(rmax[1] - rmax[0] - re), rseq + re, sc0);
 				a->score = orc_ksw_extend2(l_query - qe, query + qe, (int)(rmax[1] - rmax[0] - re), rseq + re, 5, opt->mat,
 				                           opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, aw[1], opt->pen_clip3, opt->zdrop, sc0,
 				                           &qle, &tle, &gtle, &gscore, &max_off[1]);
@@ -297,9 +301,9 @@ orc_reg_v orc_align1_core(const orc_opt_t *opt, const orc_idx_t *idx, int l_seq,
 	chn.n = orc_chain_flt(opt, (int)chn.n, chn.a);
 	/* mem_flt_chained_seeds: returns at once while MEM_MINSC_COEF*ln(l) > MEM_SEEDSW_COEF*l, i.e. l < ~700 */
 	assert(5.5 * log(l_seq > 1 ? l_seq : 2) > 0.05 * l_seq);
-	++orc_extprof[6]; extprof_read_bad = 0;
+	if (extprof_on) { ++orc_extprof[6]; extprof_read_bad = 0; }
 	for (i = 0; (size_t)i < chn.n; ++i) {
-		extprof_chain_no = i;
+		if (extprof_on) extprof_chain_no = i;
 		orc_chain2aln(opt, idx, l_seq, seq, &chn.a[i], &regs);
 		free(chn.a[i].seeds);
 	}

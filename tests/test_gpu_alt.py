@@ -55,16 +55,13 @@ def test_alt_contigs_whole_path_against_the_oracle():
     shutil.rmtree(d)
 
 
-def test_alt_contigs_lane_and_wave_routes_agree():
+def test_alt_contigs_lane_and_wave_routes_agree(tuning):
     """K2a's per-lane chain filter and K2b's wave-wide ones (slab and medium layout) all read the flag: the same batch with the
     lane kernels switched off."""
     prefix, ctg = small_ref("with_alt")
     pairs = _pairs(ctg)
-    os.environ["EMA_LANE_ALIGN"] = "0"
-    try:
-        eng = Engine(prefix)
-        batch = eng.align_pairs(pairs.bases, pairs.off)
-        eng.close()
-    finally:
-        del os.environ["EMA_LANE_ALIGN"]
+    tuning(lane_align=0)
+    eng = Engine(prefix)
+    batch = eng.align_pairs(pairs.bases, pairs.off)
+    eng.close()
     assert not compare(prefix, pairs, batch)

@@ -88,13 +88,12 @@ def test_pipeline_250bp():
 
 
 @pytest.mark.parametrize("attempts,regions", [(1, 1), (3, 2), (0, 0)])
-def test_set_aside_routes_of_rescue_and_final_alignment(attempts, regions, monkeypatch):
+def test_set_aside_routes_of_rescue_and_final_alignment(attempts, regions, tuning):
     """K3t / K3r (one rescue attempt per wavefront, replayed in order) and K4t / K4r (one region per wavefront, laid into the CIGAR pool
     in order) normally take only pairs with >= 8 candidate anchors / reads with >= 8 regions left; with the thresholds at 1 every
     rescued pair and every read with a gapped region goes that way, at 0 none does.  Noisy reads (rescues in both directions,
     several regions per read) and a repeat-rich reference."""
-    monkeypatch.setenv("EMA_HEAVY_ATTEMPTS", str(attempts))
-    monkeypatch.setenv("EMA_HEAVY_REGIONS", str(regions))
+    tuning(heavy_attempts=attempts, heavy_regions=regions)
     _check("two_contigs", 700, 46, sub_rate=0.08, indel_rate=0.004)
     _check("repeats", 500, 47, sub_rate=0.03, indel_rate=0.003, chimeric=0.1)
 
@@ -136,11 +135,11 @@ def test_pipeline_empty_and_ragged_batches():
 
 
 @pytest.mark.parametrize("pipeline", ["1", "0"])
-def test_more_pairs_than_the_batch_capacity(pipeline, monkeypatch):
+def test_more_pairs_than_the_batch_capacity(pipeline, tuning):
     """ema_engine_align_pairs takes a whole bucket: beyond the engine's batch capacity it works in pieces (alternating
-    over two sets of batch buffers, or over one with EMA_ALIGN_PIPELINE=0) and lays the results end to end; the split
+    over two sets of batch buffers, or over one with the tuning knob align_pipeline=0) and lays the results end to end; the split
     form (stage) still refuses what does not fit."""
-    monkeypatch.setenv("EMA_ALIGN_PIPELINE", pipeline)
+    tuning(align_pipeline=pipeline)
     prefix, ctg = small_ref("two_contigs")
     o = default_opts()
     o.batch_pairs = 96
@@ -195,15 +194,15 @@ def test_full_tier_overflow_fails_loudly():
     assert all(b.cand_off[r + 1] == b.cand_off[r] for r in flagged)
 
 
-def test_lean_seeding_budget_long_reads_by_wave_or_full_tier(monkeypatch):
+def test_lean_seeding_budget_long_reads_by_wave_or_full_tier(tuning):
     """A read whose seeding needs more FM-index extends than K1's lean budget is given up there and seeded again in place by K1w
-    (one wavefront per read, no budget) -- or, with EMA_SEED_LONG_WAVE=0 and beyond the room of the list of such reads, redone by the
+    (one wavefront per read, no budget) -- or, with the tuning knob seed_long_wave=0 and beyond the room of the list of such reads, redone by the
     full-capacity tier: same candidates as the oracle on every route."""
     prefix, ctg = small_ref("repeats")
     pairs = synth.make_pairs(ctg, 500, seed=49)
     redone = {}
     for route in ("1", "0"):
-        monkeypatch.setenv("EMA_SEED_LONG_WAVE", route)
+        tuning(seed_long_wave=route)
         o = default_opts()
         o.lean_seed_extends = 250          # about the median read (of K1's requests: tails, window tests and anchors count one each)
         eng = Engine(prefix, opts=o)

@@ -1,6 +1,6 @@
 """GPU parity of the seeding kernels (SMEM / seed-interval collection) against the CPU oracle, through the C ABI:
 K1 (one read per lane: the bulk) and K1w (one wavefront per read: the long reads of the full-capacity tier).  The debug
-entry point runs on the full-capacity tier, whose seeding kernel EMA_FULL_SEED_LANE selects."""
+entry point runs on the full-capacity tier, whose seeding kernel the tuning knob full_seed_lane selects."""
 import numpy as np
 import pytest
 
@@ -12,8 +12,8 @@ from ema_amd.engine import Engine
 pytestmark = pytest.mark.gpu
 
 
-def _check(kind, n_pairs, seed, kernel, monkeypatch, pairs=None, min_seed_len=None, **kw):
-    monkeypatch.setenv("EMA_FULL_SEED_LANE", "1" if kernel == "lane" else "0")
+def _check(kind, n_pairs, seed, kernel, tuning, pairs=None, min_seed_len=None, **kw):
+    tuning(full_seed_lane="1" if kernel == "lane" else "0")
     prefix, ctg = small_ref(kind)
     if pairs is None:
         pairs = synth.make_pairs(ctg, n_pairs, seed=seed, **kw)
@@ -42,83 +42,95 @@ KERNELS = pytest.mark.parametrize("kernel", ["lane", "wave"])
 
 
 @KERNELS
-def test_seed_parity_clean(kernel, monkeypatch):
-    _check("two_contigs", 600, 21, kernel, monkeypatch)
+def test_seed_parity_clean(kernel, tuning):
+    _check("two_contigs", 600, 21, kernel, tuning)
 
 
 @KERNELS
-def test_seed_parity_with_n_bases(kernel, monkeypatch):
-    _check("two_contigs", 300, 22, kernel, monkeypatch, n_rate=0.01)
+def test_seed_parity_with_n_bases(kernel, tuning):
+    _check("two_contigs", 300, 22, kernel, tuning, n_rate=0.01)
 
 
 @KERNELS
-def test_seed_parity_repeats(kernel, monkeypatch):
-    _check("repeats", 600, 23, kernel, monkeypatch)
+def test_seed_parity_repeats(kernel, tuning):
+    _check("repeats", 600, 23, kernel, tuning)
 
 
 @KERNELS
-def test_seed_parity_250bp(kernel, monkeypatch):
+def test_seed_parity_250bp(kernel, tuning):
     # config 5 of BASELINE.json (2x250 bp): beyond the reference's MAX_READ_LEN (include/align.h:61), supported here
-    _check("repeats", 200, 24, kernel, monkeypatch, len1=250, len2=250)
+    _check("repeats", 200, 24, kernel, tuning, len1=250, len2=250)
 
 
 @pytest.mark.parametrize("k", [0, 5, 11, 12])
-def test_seed_parity_kmer_table_depths(k, monkeypatch):
+def test_seed_parity_kmer_table_depths(k, tuning):
     """K1 with the k-mer interval table at several depths (0: none, the build that produces k' too; 11, 12: levels in the packed
     part of the table although the test genome would get 8 by itself) and without parking rounds left out."""
-    monkeypatch.setenv("EMA_KMER_K", str(k))
-    _check("repeats", 500, 25, "lane", monkeypatch, sub_rate=0.02, n_rate=0.003)
+    tuning(kmer_k=str(k))
+    _check("repeats", 500, 25, "lane", tuning, sub_rate=0.02, n_rate=0.003)
 
 
 @pytest.mark.parametrize("tail", ["1", "0"])
 @pytest.mark.parametrize("k", ["", "5", "11"])
 @pytest.mark.parametrize("kind", ["two_contigs", "ngaps"])
-def test_seed_parity_text_tails_at_their_edges(kind, k, tail, monkeypatch):
+def test_seed_parity_text_tails_at_their_edges(kind, k, tail, tuning):
     """K1's text tails (a single-occurrence match followed along the 2-bit text instead of through rank queries) and pass 3's
     jump, where they must stop exactly as the rank queries do: across the strand junction, at the text's end, at an ambiguous
     base, at the read's end, beyond one load of text, in every word phase (tests/common.py, text_edge_pairs) -- with the tails
-    on and off (EMA_SEED_TAIL) and at several table depths."""
+    on and off (tuning knob seed_tail) and at several table depths."""
     from common import text_edge_pairs
-    monkeypatch.setenv("EMA_SEED_TAIL", tail)
+    tuning(seed_tail=tail)
     if k:
-        monkeypatch.setenv("EMA_KMER_K", k)
+        tuning(kmer_k=k)
     _prefix, ctg = small_ref(kind)
-    _check(kind, 0, 0, "lane", monkeypatch, pairs=text_edge_pairs(ctg))
+    _check(kind, 0, 0, "lane", tuning, pairs=text_edge_pairs(ctg))
 
 
 @pytest.mark.parametrize("tail", ["1", "0"])
-def test_seed_parity_tails_on_and_off(tail, monkeypatch):
-    monkeypatch.setenv("EMA_SEED_TAIL", tail)
-    _check("repeats", 600, 27, "lane", monkeypatch, sub_rate=0.01, n_rate=0.002)
-    _check("two_contigs", 300, 28, "lane", monkeypatch, len1=250, len2=250, sub_rate=0.002)
+def test_seed_parity_tails_on_and_off(tail, tuning):
+    tuning(seed_tail=tail)
+    _check("repeats", 600, 27, "lane", tuning, sub_rate=0.01, n_rate=0.002)
+    _check("two_contigs", 300, 28, "lane", tuning, len1=250, len2=250, sub_rate=0.002)
 
 
 @pytest.mark.parametrize("wtest", ["1", "0", "no-anchors"])
 @pytest.mark.parametrize("k", ["", "5", "11"])
-def test_seed_parity_window_test_of_pass_2(k, wtest, monkeypatch):
+def test_seed_parity_window_test_of_pass_2(k, wtest, tuning):
     """Pass 2's window test (k_seed.hip: a re-seeding search is skipped when no min_seed_len-base window over its position can be
-    frequent enough) on and off (EMA_SEED_WTEST), at several table depths: repeat-rich reads (searches that DO report), clean ones,
+    frequent enough) on and off (seed_wtest), at several table depths: repeat-rich reads (searches that DO report), clean ones,
     ambiguous bases, 250 bp; with and without the anchors that build on it (a pass-1 SMEM found on the text and reported by position) --
     the intervals equal the oracle's either way."""
-    monkeypatch.setenv("EMA_SEED_WTEST", "0" if wtest == "0" else "1")
-    monkeypatch.setenv("EMA_SEED_ANCHOR", "0" if wtest == "no-anchors" else "1")      # (anchors: single-occurrence matches reported by position)
+    tuning(seed_wtest="0" if wtest == "0" else "1")
+    tuning(seed_anchor="0" if wtest == "no-anchors" else "1")      # (anchors: single-occurrence matches reported by position)
     if k:
-        monkeypatch.setenv("EMA_KMER_K", k)
-    _check("repeats", 500, 31, "lane", monkeypatch, sub_rate=0.01, n_rate=0.004)
-    _check("two_contigs", 300, 32, "lane", monkeypatch, len1=250, len2=250, sub_rate=0.003)
-    _check("ngaps", 300, 33, "lane", monkeypatch, n_rate=0.01)
+        tuning(kmer_k=k)
+    _check("repeats", 500, 31, "lane", tuning, sub_rate=0.01, n_rate=0.004)
+    _check("two_contigs", 300, 32, "lane", tuning, len1=250, len2=250, sub_rate=0.003)
+    _check("ngaps", 300, 33, "lane", tuning, n_rate=0.01)
 
 
 @pytest.mark.parametrize("msl", [12, 25, 31])
-def test_seed_parity_other_minimum_seed_lengths(msl, monkeypatch):
+def test_seed_parity_other_minimum_seed_lengths(msl, tuning):
     """bwa's -k: the window test, the anchors and pass 3's jump all take their lengths from min_seed_len (the windows are that
     long; the jump is min(kmer_k, min_seed_len) bases; re-seeding starts at 1.5 x) -- below, above and far above the default 19."""
-    _check("repeats", 400, 34, "lane", monkeypatch, min_seed_len=msl, sub_rate=0.01, n_rate=0.002)
-    _check("two_contigs", 200, 35, "lane", monkeypatch, min_seed_len=msl)
+    _check("repeats", 400, 34, "lane", tuning, min_seed_len=msl, sub_rate=0.01, n_rate=0.002)
+    _check("two_contigs", 200, 35, "lane", tuning, min_seed_len=msl)
 
 
-def test_pipeline_with_and_without_the_table(monkeypatch):
+def test_pipeline_with_and_without_the_table(tuning):
     import test_gpu_pipeline as TP
     for k in ("0", "11"):
-        monkeypatch.setenv("EMA_KMER_K", k)
+        tuning(kmer_k=k)
         TP._check("repeats", 600, 26, sub_rate=0.02)
+
+
+@pytest.mark.parametrize("onepass", ["1", "0"])
+@pytest.mark.parametrize("park,rounds", [(40, 4), (60, 8)])
+def test_seed_parity_one_control_pass_per_tick_and_parking(onepass, park, rounds, tuning):
+    """one control pass per tick (seed_flags bit 2, the default) leaves machines without a request on their lane, and a
+    parked wave carries them with has_req = 0.  Both settings of the knob, with parking thresholds high enough (a wave parks as soon
+    as it is down to `park` machines, up to `rounds` launches per series) that request-less machines ARE parked and resumed: repeat-rich
+    reads (long chains of ticks), ambiguous bases (passes that end between two states), 250 bp."""
+    tuning(seed_onepass=onepass, seed_park=park, seed_rounds=rounds)
+    _check("repeats", 700, 36, "lane", tuning, sub_rate=0.01, n_rate=0.004)
+    _check("two_contigs", 300, 37, "lane", tuning, len1=250, len2=250, n_rate=0.01)

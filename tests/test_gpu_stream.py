@@ -154,16 +154,18 @@ def test_a_bad_bucket_stops_the_stream_with_its_name(tmp_path):
 
 
 @pytest.mark.parametrize("tiny_lean", [False, True])
-def test_device_side_batch_layout_equals_the_host_assembly(tiny_lean, monkeypatch):
+def test_device_side_batch_layout_equals_the_host_assembly(tiny_lean, tuning):
     """ema_engine_fetch_ticket with the batch laid out on the device (k_pack.hip, ema_launch_merge: slices + full tier -> one set in
-    read order, downloaded into a page-locked buffer that is the batch) against round 3's assembly on the host (EMA_DEVICE_MERGE=0):
+    read order, downloaded into a page-locked buffer that is the batch) against round 3's assembly on the host (tuning knob device_merge=0):
     the same arrays, entry for entry -- with the default lean capacities and with tiny ones, where a third of the pairs come from the
     full tier's set; batches of assorted sizes so that passes share and split slices."""
     prefix, ctg = small_ref("repeats")
     batches = [synth.make_pairs(ctg, n, seed=790 + i, sub_rate=0.01) for i, n in enumerate((700, 64, 1024, 333, 1, 900))]
     res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("EMA_DEVICE_MERGE", mode)
+    for mode in ("1", "0", "small"):
+        # "small": a merged set too small for the batches (room for 4,096 candidates and operations in all) -- the fetch must fall
+        # back to the host assembly from the slices' own sets, not refuse the batch (ADVICE r04: a repeat-heavy bucket aborted the stream)
+        tuning(device_merge="0" if mode == "0" else "1", merged_cand=0 if mode == "small" else None, merged_cigar=0 if mode == "small" else None)
         o = default_opts()
         o.batch_pairs = 1024
         if tiny_lean:
@@ -173,8 +175,8 @@ def test_device_side_batch_layout_equals_the_host_assembly(tiny_lean, monkeypatc
         stream.stream_batches(eng, [(p.bases, p.off) for p in batches], lambda k, _b, batch, rec, po: got.__setitem__(k, (batch, rec, po)))
         eng.close()
         res[mode] = got
-    for k, p in enumerate(batches):
-        a, b = res["1"][k], res["0"][k]
+    for k, p, first in [(k, p, f) for k, p in enumerate(batches) for f in ("1", "small")]:
+        a, b = res[first][k], res["0"][k]
         assert (a[0].cand_off == b[0].cand_off).all() and (a[0].status == b[0].status).all()
         assert sorted(a[0].redone.tolist()) == sorted(b[0].redone.tolist())      # (the list's order is the order of the collecting atomics)
         for f in a[0].cand.dtype.names:

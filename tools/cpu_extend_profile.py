@@ -16,6 +16,7 @@ z = np.load(reads)
 pairs = synth.Pairs(z["bases"], z["off"]).subset(0, n)
 idx, opt = O.Index(prefix), O.default_opt()
 L = O.lib()
+L.orc_extprof_enable(1)
 L.orc_extprof_reset()
 O.bench_pairs(idx, opt, pairs.bases, pairs.off, 1)
 buf = (C.c_uint64 * 16)()

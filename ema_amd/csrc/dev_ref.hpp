@@ -5,6 +5,16 @@
 
 #include "dev_common.hpp"
 
+// bwa's cal_max_gap (bwamem.c): the longest gap an extension over qlen query bases can pay for, capped at twice the band
+__device__ __forceinline__ int ema_cal_max_gap(const DevOpts &o, int qlen)
+{
+	const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+	const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+	int l = l_del > l_ins ? l_del : l_ins;
+	l = l > 1 ? l : 1;
+	return l < o.w << 1 ? l : o.w << 1;
+}
+
 // bns_pos2rid: contig holding forward position pos_f -- the last contig that starts at or below it.  bwa searches the contig
 // offsets by bisection: five to twelve DEPENDENT loads per call, two calls per seed occurrence (ema_intv2rid), one per window.
 // The coarse table (dev_types.h, ctg_tab) names the contigs of the 2^ctg_shift-base block the position lies in; what is left to

@@ -120,6 +120,13 @@ struct ChainRec {
 struct HandHdr { int32_t read, n_chn, n_seed, l_query; uint32_t base_off; int32_t chain_from, n_av, pad; };
 #define EMA_HAND_BYTES (sizeof(HandHdr) + (size_t)EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)) + (size_t)EMA_HAND_REGS * sizeof(DevReg))
 
+// K2x (k_ext_lane.hip): the extension of a chain's first seed as a task of its own, one LANE per task.  A task names the seed, the
+// chain's window [rmax0, rmax1) as mem_chain2aln computes it, the read (its nt4 bytes at q_off of the batch's bases), and the slot
+// of its result: the region's ends and scores as mem_chain2aln derives them from ksw_extend2's two calls.  valid[slot] says whether
+// the result was computed (a task may be given up: band doubling, a window that does not fit); the consumer then runs the DP itself.
+struct ExtTask { int64_t rbeg, rmax0, rmax1; uint32_t q_off; int32_t l_query, qbeg, len, res, pad; };
+struct ExtRes { int64_t rb, re; int32_t qb, qe, score, truesc; };
+
 // Chain-rich reads (hundreds of chains, nearly every one of them extended: a read from a young repeat family) are a long
 // serial job for the one wavefront that owns them -- two extension DPs per chain, one after the other -- and they set the
 // length of a K2b launch once the work queue is empty.  K2b therefore sets such a read aside after the chain filter: its
@@ -138,6 +145,10 @@ struct HeavyCtl {
 	int *n_reads, *n_tasks;
 	int reads_cap, tasks_cap;
 	int min_chains;                    // a read with at least this many chains to extend is set aside
+	// K2x (k_ext_lane.hip) for K2a's hand-overs (mode 3): slot [record * EMA_HAND_SEEDS + chain in filtered order] holds the region of
+	// the chain's first seed when xvalid says so.  Null: every extension is run by the wave-per-read kernel.
+	const ExtRes *xres;
+	const uint8_t *xvalid;
 };
 struct HeavyHdr {                      // head of a record; the arrays follow at the offsets given (bytes from the record's start)
 	int32_t read, n_chn, n_chain, n_seed, status, n_ext;

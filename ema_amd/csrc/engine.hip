@@ -107,6 +107,12 @@ extern "C" void ema_k3_prof_read(unsigned long long *out);
 extern "C" void ema_k4_prof_read(unsigned long long *out);
 #endif
 extern "C" size_t ema_align_lane_wave_bytes();
+// K2x (k_ext_lane.hip): the first seed of every chain K2a hands over, extended one lane per seed
+extern "C" void ema_launch_ext_plan_hand(const DevIndex *ix, const DevOpts *opt, const uint8_t *hand, const int *n_hand, int max_records, ExtTask *tasks, int *n_tasks,
+                                         int tasks_cap, uint8_t *valid, hipStream_t stream);
+extern "C" void ema_launch_ext_lane(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const ExtTask *tasks, const int *n_tasks, int tasks_cap,
+                                    ExtRes *res, uint8_t *valid, int *counters, int n_cu, hipStream_t stream, unsigned long long *prof);
+extern "C" int ema_ext_lane_supported(const DevOpts *opt);
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
@@ -221,6 +227,10 @@ struct Slice {
 	DevBuf<DevReg> d_regs;
 	DevBuf<uint8_t> d_heavy;                      // chain-rich reads set aside by K2b: records (dev_types.h, HeavyCtl)
 	DevBuf<unsigned long long> d_heavy_reads, d_heavy_tasks;
+	DevBuf<ExtTask> d_xtasks;                     // K2x: seed tasks of this pass, their results by record and chain, the flags that say which were computed,
+	DevBuf<ExtRes> d_xres;                        //      and [0] the task count, [1..3] the claim counters of the three launches (k_ext_lane.hip)
+	DevBuf<uint8_t> d_xvalid;
+	DevBuf<int> d_xctr;
 	DevBuf<uint8_t> d_slabs, d_park[2], d_hand;   // d_hand: K2a -> K2b records (EMA_HAND_BYTES per read)   // d_park: K1's parked machines, ping-pong between the launches of a series
 	DevBuf<DevAln> d_alns;
 	DevBuf<uint32_t> d_cigars, d_cigar_out;
@@ -250,6 +260,7 @@ struct Slice {
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_long.release(); d_order.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
+		d_xtasks.release(); d_xres.release(); d_xvalid.release(); d_xctr.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -380,6 +391,8 @@ struct ema_engine {
 	bool long_wave = false;              // EMA_SEED_LONG_WAVE=1: lean slices' reads over K1's extend budget are seeded by K1w in place (default: given to the full tier)
 	size_t long_cap = 0;                 // room of a lean slice's list of long reads
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
+	bool ext_lane = true;                // tuning knob ext_lane=0: every extension DP by the wave-per-read kernels (round 4's route)
+	unsigned long long *d_xprof = nullptr;      // tuning knob ext_lane_prof=1: K2x's counters (24 words)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)
 	int heavy_regions = 8;               // K4b sets a read with at least this many regions left aside for K4t / K4r (0: never)
@@ -473,6 +486,10 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_cig_n.alloc(n_reads));
 	HIPCHK(e, s.d_kdone.alloc(n_reads));
 	HIPCHK(e, s.d_hand.alloc(n_reads * EMA_HAND_BYTES));
+	if (e->ext_lane) {
+		HIPCHK(e, s.d_xtasks.alloc(n_reads * 3 + 1024)); HIPCHK(e, s.d_xres.alloc(n_reads * EMA_HAND_SEEDS + 8));
+		HIPCHK(e, s.d_xvalid.alloc(n_reads * EMA_HAND_SEEDS + 64)); HIPCHK(e, s.d_xctr.alloc(8));
+	}
 	HIPCHK(e, s.d_todo.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
@@ -707,6 +724,9 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = ema_tuning_get("merged_cand")) e->merged_cand_per_read = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("merged_cigar")) e->merged_cig_per_read = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("lane_align")) e->lane_align = atoi(v) != 0;
+	if (const char *v = ema_tuning_get("ext_lane")) e->ext_lane = atoi(v) != 0;
+	if (!e->lane_align) e->ext_lane = false;
+	if (const char *v = ema_tuning_get("ext_lane_prof")) if (atoi(v) != 0 && !e->d_xprof) { HIPCHK(e, hipMalloc(&e->d_xprof, 24 * 8)); HIPCHK(e, hipMemset(e->d_xprof, 0, 24 * 8)); }
 	if (const char *v = ema_tuning_get("heavy_chains")) e->heavy_chains = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("heavy_attempts")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
 	if (const char *v = ema_tuning_get("heavy_regions")) e->heavy_regions = std::max(0, atoi(v));        //  pair / read takes the set-aside route)
@@ -765,12 +785,28 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	return EMA_OK;
 }
 
+// K2x's counters (tuning knob ext_lane_prof=1), summed over every launch since the engine opened or the last call: per class of
+// task (longer query < 64, < 128, < 256 bases) eight words -- wavefront lifetimes in shader clocks, wavefronts, row-steps,
+// lane-rows (lanes busy in a row-step), DP cells, tasks finished, DP sides run, unused
+int ema_engine_debug_xprof(ema_engine_t *e, uint64_t out[24])
+{
+	if (!e || !out) return EMA_EARG;
+	memset(out, 0, 24 * 8);
+	if (!e->d_xprof) return EMA_OK;
+	HIPCHK(e, hipSetDevice(e->device));
+	HIPCHK(e, hipDeviceSynchronize());
+	HIPCHK(e, hipMemcpy(out, e->d_xprof, 24 * 8, hipMemcpyDeviceToHost));
+	HIPCHK(e, hipMemset(e->d_xprof, 0, 24 * 8));
+	return EMA_OK;
+}
+
 void ema_engine_close(ema_engine_t *e)
 {
 	if (!e) return;
 	if (e->shadow) { ema_engine_close(e->shadow); e->shadow = nullptr; }
 	(void)hipSetDevice(e->device);
 	(void)hipDeviceSynchronize();
+	if (e->d_xprof) { (void)hipFree(e->d_xprof); e->d_xprof = nullptr; }
 	if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
 	if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
 	for (auto &ev : e->slot_free) if (ev) (void)hipEventDestroy(ev);
@@ -1004,12 +1040,24 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	const bool heavy = s.d_heavy.p != nullptr;
 	hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr;
 	hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30;
+	hv.xres = nullptr; hv.xvalid = nullptr;
+	if (e->lane_align && e->ext_lane && s.d_xres.p && ema_ext_lane_supported(&s.dopts)) {
+		// K2x: one task per chain of every record K2a handed over -- the chain's first seed, extended one lane per seed -- so that
+		// mode 3 below finds the regions ready and runs a wave DP only where no task was computed (k_ext_lane.hip)
+		HIPCHK(e, hipMemsetAsync(s.d_xctr.p, 0, 8 * 4, s.stream));
+		ema_launch_ext_plan_hand(&e->dix, &s.dopts, s.d_hand.p, s.d_counters.p + 24, (int)(2 * w.n_pairs), s.d_xtasks.p, s.d_xctr.p, (int)s.d_xtasks.n, s.d_xvalid.p, s.stream);
+		HIPCHK(e, hipGetLastError());
+		ema_launch_ext_lane(&e->dix, &s.dopts, e->cur_bases, s.d_xtasks.p, s.d_xctr.p, (int)s.d_xtasks.n, s.d_xres.p, s.d_xvalid.p, s.d_xctr.p + 1, e->n_cu, s.stream, e->d_xprof);
+		HIPCHK(e, hipGetLastError());
+		hv.xres = s.d_xres.p; hv.xvalid = s.d_xvalid.p;
+	}
 	if (e->lane_align) {      // (mode 3 reads K2a's dense records: their number is counter 24)
 		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                 s.d_n_regs.p, s.d_status.p, nullptr, s.d_counters.p + 24, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 22,
 		                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, &hv, 3);
 		HIPCHK(e, hipGetLastError());
 	}
+	hv.xres = nullptr; hv.xvalid = nullptr;
 	if (heavy) {
 		hv.arena = s.d_heavy.p; hv.arena_bytes = s.d_heavy.n; hv.arena_used = reinterpret_cast<unsigned long long *>(s.d_counters.p + 30);
 		hv.reads = s.d_heavy_reads.p; hv.tasks = s.d_heavy_tasks.p; hv.n_reads = s.d_counters.p + 26; hv.n_tasks = s.d_counters.p + 27;

@@ -210,6 +210,10 @@ int ema_engine_debug_final(ema_engine_t *e, const char *read, int l_read, const 
  * {read, intervals or -1, seed occurrences, chains, seeds, regions before dedup, extension DPs, shader clocks / 16};
  * this returns and resets the log (n records of 8 ints; caller frees). */
 int ema_engine_debug_readlog(ema_engine_t *e, int32_t **log, size_t *n);
+/* Profiling aid: the counters of the lane-per-seed extension kernel (k_ext_lane.hip) when the engine was opened with the tuning knob
+ * ext_lane_prof=1: three classes of task (longer query < 64, < 128, < 256 bases) x eight words -- wavefront lifetimes in shader clocks,
+ * wavefronts, row-steps, lane-rows, DP cells, tasks finished, DP sides run, unused.  Summed since the previous call. */
+int ema_engine_debug_xprof(ema_engine_t *e, uint64_t out[24]);
 
 /* Region de-duplication in isolation (bwa's mem_sort_dedup_patch as mem_matesw calls it, i.e. without patching),
  * one task per wavefront: task t owns regs[t*cap .. t*cap + n_in[t]) (records laid out as in ema_engine_debug_regions);

@@ -4,6 +4,13 @@
 #include <string>
 #include <vector>
 #include "host_index.h"
+// the library's development knobs (engine.hip: ema_engine_set_tuning / EMA_TUNING) as the interpreter sees them: EMU_<KNOB> in the environment
+const char *ema_tuning_get(const char *key)
+{
+	std::string name = "EMU_";
+	for (const char *p = key; *p; ++p) name += (char)toupper((unsigned char)*p);
+	return getenv(name.c_str());
+}
 #include "opts.h"
 
 // kernels + launchers, compiled as plain C++
@@ -13,6 +20,7 @@
 #include "k_dp_test.hip"
 #include "k_align.hip"
 #include "k_align_lane.hip"
+#include "k_ext_lane.hip"
 #include "k_pair.hip"
 #include "k_final.hip"
 
@@ -74,10 +82,26 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 		hv.n_reads = &hn[0]; hv.n_tasks = &hn[1]; hv.reads_cap = (int)hreads.size(); hv.tasks_cap = (int)htasks.size(); hv.min_chains = heavy_chains;
 	}
 	if (heavy_chains <= 0) { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
+	hv.xres = nullptr; hv.xvalid = nullptr;
 	int c3 = 0;
+	// K2x: the first seed of every chain K2a handed over, one lane per seed (k_ext_lane.hip); EMU_EXT_LANE=0: all extensions by the wave kernel
+	const char *vx = getenv("EMU_EXT_LANE");
+	std::vector<ExtTask> xtasks((size_t)n_reads * 4 + 64);
+	std::vector<ExtRes> xres((size_t)n_reads * EMA_HAND_SEEDS + 1);
+	std::vector<uint8_t> xvalid((size_t)n_reads * EMA_HAND_SEEDS + 8, 0);
+	if (lane && (!vx || atoi(vx) != 0) && ema_ext_lane_supported(&d)) {
+		int xn = 0, xc[4] = {0, 0, 0, 0};
+		ema_launch_ext_plan_hand(&di, &d, hand.data(), &n_hand, n_hand, xtasks.data(), &xn, (int)xtasks.size(), xvalid.data(), nullptr);
+		ema_launch_ext_lane(&di, &d, bases, xtasks.data(), &xn, (int)xtasks.size(), xres.data(), xvalid.data(), xc, 1, nullptr, nullptr);
+		size_t nv = 0;
+		for (size_t i = 0; i < (size_t)n_hand * EMA_HAND_SEEDS; ++i) nv += xvalid[i];
+		fprintf(stderr, "emu K2x: %d seed tasks planned for %d records, %zu results computed\n", xn, n_hand, nv);
+		hv.xres = xres.data(); hv.xvalid = xvalid.data();
+	}
 	if (lane)      // K2a's hand-overs on their own build
 		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, nullptr, &n_hand, hand.data(), slabs,
 		                 &c3, n_blocks, nullptr, nullptr, nullptr, &hv, 3);
+	hv.xres = nullptr; hv.xvalid = nullptr;
 	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,
 	                 &c1, n_blocks, nullptr, nullptr, nullptr, &hv, 0);
 	if (heavy_chains > 0) {

@@ -32,12 +32,12 @@ def test_configuration_is_what_the_parent_asked_for():
 
 
 @pytest.mark.parametrize("kernel", ["lane", "wave"])
-def test_seeds(kernel, monkeypatch):
-    TS._check(KIND, 500, 61, kernel, monkeypatch)
+def test_seeds(kernel, tuning):
+    TS._check(KIND, 500, 61, kernel, tuning)
 
 
-def test_seeds_with_n(monkeypatch):
-    TS._check(KIND, 300, 62, "lane", monkeypatch, n_rate=0.01)
+def test_seeds_with_n(tuning):
+    TS._check(KIND, 300, 62, "lane", tuning, n_rate=0.01)
 
 
 def test_regions():

@@ -391,7 +391,7 @@ struct ema_engine {
 	bool long_wave = false;              // EMA_SEED_LONG_WAVE=1: lean slices' reads over K1's extend budget are seeded by K1w in place (default: given to the full tier)
 	size_t long_cap = 0;                 // room of a lean slice's list of long reads
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
-	bool ext_lane = true;                // tuning knob ext_lane=0: every extension DP by the wave-per-read kernels (round 4's route)
+	bool ext_lane = false;               // tuning knob ext_lane=1: K2x (k_ext_lane.hip), the first seed of every handed-over chain extended one lane per seed.  Parity-green and OFF: measured slower (profiles/r05_k2x_profile.txt, DESIGN section 3 [r5])
 	unsigned long long *d_xprof = nullptr;      // tuning knob ext_lane_prof=1: K2x's counters (24 words)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)

@@ -408,3 +408,38 @@ def test_chr20_scale_reference_50k_pairs_against_the_oracle():
             assert int(batch.cand_off[-1]) > pairs.n      # (the mixes do align)
     finally:
         eng.close()
+
+
+def test_lane_per_seed_extension_route(tuning):
+    """K2x (k_ext_lane.hip; tuning knob ext_lane=1: off by default, measured slower than the wave DP in round 5): the first seed of every
+    chain K2a hands over extended ONE LANE PER SEED -- ksw_extend2 cell by cell with the H/E row in LDS, left then right, the
+    known-outcome shortcuts, the exact early exit -- and mode 3 of K2b taking the regions from the result table (wave DP only where no
+    result was computed).  Same candidates as the oracle: clean and noisy reads (indels: gapped paths, z-drop, dead extensions in
+    repeats), 250 bp reads (the widest class), ambiguous bases, other scorings (asymmetric gaps; mismatches cheaper than a gap, so the
+    shortcuts do not apply), a narrow band (w = 4: max_off >= 3/4 w gives the task up to the band-doubling wave route), and tiny lean
+    capacities (the full-capacity tier runs the same route)."""
+    tuning(ext_lane=1)
+    _check("two_contigs", 900, 141, sub_rate=0.03, indel_rate=0.004)
+    _check("repeats", 700, 142, sub_rate=0.02, indel_rate=0.002, chimeric=0.05)
+    _check("repeats", 300, 143, len1=250, len2=250, sub_rate=0.015, indel_rate=0.003)
+    _check("ngaps", 400, 144, n_rate=0.01, sub_rate=0.01)
+    eo, oo = default_opts(), O.default_opt()
+    for o in (eo, oo):
+        o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins = 2, 3, 5, 2, 4, 2
+    for i in range(5):
+        for j in range(5):
+            oo.mat[i * 5 + j] = -1 if i == 4 or j == 4 else (oo.a if i == j else -oo.b)
+    _check("two_contigs", 400, 145, eopts=eo, oopt=oo, sub_rate=0.02, indel_rate=0.003)
+    eo2, oo2 = default_opts(), O.default_opt()
+    for o in (eo2, oo2):
+        o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins = 1, 7, 2, 1, 2, 1
+    for i in range(5):
+        for j in range(5):
+            oo2.mat[i * 5 + j] = -1 if i == 4 or j == 4 else (oo2.a if i == j else -oo2.b)
+    _check("two_contigs", 300, 146, eopts=eo2, oopt=oo2, sub_rate=0.02, indel_rate=0.002)
+    eo3, oo3 = default_opts(), O.default_opt()
+    eo3.w = oo3.w = 4
+    _check("two_contigs", 400, 147, eopts=eo3, oopt=oo3, sub_rate=0.02, indel_rate=0.01)
+    eo4 = default_opts()
+    eo4.lean_intervals, eo4.lean_regions, eo4.lean_cigar_ops, eo4.full_tier_pairs = 10, 2, 8, 1024
+    _check("repeats", 600, 148, eopts=eo4, sub_rate=0.02, indel_rate=0.002)

@@ -53,6 +53,18 @@ ema_amd/libema_engine_prof.so: $(PROF_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(PROF_OBJS)
 prof-lib: ema_amd/libema_engine_prof.so
 
+# A/B builds of the engine with extra compile-time flags: `make variant V=chainlds VFLAGS="-DEMA_CHAIN_REGS=0"` -> ema_amd/libema_engine_chainlds.so
+# (EMA_ENGINE_LIB=libema_engine_chainlds.so selects it in the Python wrapper; tools/run_r05_ab.sh runs bench.py over a set of them)
+VOBJS = $(patsubst $(CSRC)/%.hip,build/v_$(V)/%.o,$(HIP_SRCS)) $(patsubst $(CSRC)/%.cpp,build/v_$(V)/%.o,$(HOST_SRCS))
+build/v_$(V)/%.o: $(CSRC)/%.hip $(ENGINE_HDRS)
+	@mkdir -p build/v_$(V)
+	$(HIPCC) $(HIPFLAGS) $(VFLAGS) -c -o $@ $<
+build/v_$(V)/%.o: $(CSRC)/%.cpp $(ENGINE_HDRS)
+	@mkdir -p build/v_$(V)
+	$(HIPCC) $(HOSTCLANG) $(VFLAGS) -c -o $@ $<
+variant: $(VOBJS)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o ema_amd/libema_engine_$(V).so $(VOBJS)
+
 # libbwa-shaped face (include/ema_bwaabi.h): the 9 symbols the reference links from -lbwa, on top of the engine
 ema_amd/libema_bwaabi.so: $(CSRC)/bwaabi.cpp include/ema_bwaabi.h include/ema_engine.h ema_amd/libema_engine.so
 	$(CXX) $(HOSTFLAGS) -Iinclude -shared -o $@ $(CSRC)/bwaabi.cpp -Lema_amd -lema_engine -Wl,-rpath,'$$ORIGIN'
@@ -67,4 +79,4 @@ oracle: $(BWAABI)
 clean:
 	rm -rf build; rm -f ema_amd/*.so; $(MAKE) -C oracle clean
 
-.PHONY: all test-libs prof-lib oracle clean
+.PHONY: all test-libs prof-lib oracle clean variant

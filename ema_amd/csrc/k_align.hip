@@ -54,6 +54,9 @@ struct AlignSlab {           // per resident wave
 //              of the small-table area when the chain has no more than SMALL seeds.
 // A read whose chain count outgrows EMA_MED_CHAINS moves its position table to the slab and carries on there.
 #define EMA_MED_CHAINS 256
+#ifndef EMA_CHAIN_REGS
+#define EMA_CHAIN_REGS 1      // [r5] the medium layout's tables in registers while a read has at most 64 chains (chain_insert_reg); 0: round 4's LDS tables from the start
+#endif
 #define EMA_SMALL_BYTES(SMALL) ((SMALL) * (2 * sizeof(SeedRec) + sizeof(ChainRec) + 3 * 8 + 2 * 4))
 #define EMA_AVL_BYTES(AVL) (((AVL) > 0 ? (AVL) : 1) * (2 * sizeof(DevReg) + 8))
 
@@ -306,6 +309,92 @@ __device__ inline bool chain_insert_med(const DevOpts &o, int64_t l_pac, ChainBu
 	return true;
 }
 
+// ---- [r5] the medium layout's chaining while the read has at most 64 chains: the tables in REGISTERS.  Slot t of the sorted
+// position table (position, chain id) lives in lane t, the summary of chain id c in lane c.  The look-up is one ballot, the two
+// entries around the insertion point and the chain's summary are lane reads, a merge rewrites one lane's summary, a new chain
+// shifts the upper lanes by one with a DPP move: no LDS round trip, no wave-level ordering point -- an insertion was four dependent
+// LDS round trips and three of those (profiles/r04_k2_profile.txt: mode 0 spends two fifths of its lifetimes chaining, ~1,500
+// clocks per seed occurrence).  Same decisions from the same values as chain_insert_med.  Returns false, having done nothing,
+// when a 65th chain is needed: the caller writes the tables to LDS (reg_chains_to_lds) and carries on with chain_insert_med.
+struct RegChains { int64_t pos; int32_t id; uint32_t m0, m1, m2; };
+
+__device__ inline bool chain_insert_reg(const DevOpts &o, int64_t l_pac, ChainBuild &cb, RegChains &rc, int64_t rbeg, int qbeg, int len, int rid)
+{
+	const int lane = (int)ema_lane();
+	const bool leader = lane == 0;
+	const int n = cb.n_chain;
+	int at = 0, lower = -1;
+	int64_t pos = 0;
+	if (n) {
+		const int lo = __popcll(__ballot(lane < n && rc.pos < rbeg));      // first slot with position >= rbeg
+		const int64_t p_lo = ema_lane_val(rc.pos, lo < n ? lo : 0), p_lm = ema_lane_val(rc.pos, lo > 0 ? lo - 1 : 0);
+		const int id_lo = ema_lane_val(rc.id, lo < n ? lo : 0), id_lm = ema_lane_val(rc.id, lo > 0 ? lo - 1 : 0);
+		if (lo < n && p_lo == rbeg) { lower = id_lo; at = lo + 1; pos = p_lo; }
+		else if (lo > 0) { lower = id_lm; at = lo; pos = p_lm; }
+	}
+	if (lower >= 0) {   // test_and_merge
+		const uint32_t m0 = (uint32_t)ema_lane_val((int)rc.m0, lower), m1 = (uint32_t)ema_lane_val((int)rc.m1, lower), m2 = (uint32_t)ema_lane_val((int)rc.m2, lower);
+		const int l_delta = (int)m0, c_rid = (int)(m1 & 0xffff), last_seed = (int)(m1 >> 16);
+		const int f_qbeg = (int)(m2 & 0xff), l_qbeg = (int)(m2 >> 8 & 0xff), l_len = (int)(m2 >> 16 & 0xff);
+		const int64_t f_rbeg = pos, l_rbeg = pos + l_delta;
+		const int64_t qend = l_qbeg + l_len, rend = l_rbeg + l_len;
+		if (rid != c_rid) { }
+		else if (qbeg >= f_qbeg && qbeg + len <= qend && rbeg >= f_rbeg && rbeg + len <= rend) return true;      // contained: absorbed
+		else if ((l_rbeg < l_pac || f_rbeg < l_pac) && rbeg >= l_pac) { }                                      // other strand
+		else {
+			const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
+			if (y >= 0 && x - y <= o.w && y - x <= o.w && x - l_len < o.max_chain_gap && y - l_len < o.max_chain_gap) {
+				if (cb.n_seed >= EMA_SEED_CAP) { cb.status |= EMA_ST_SEED_OVERFLOW; return true; }
+				const int id = cb.n_seed++;
+				if (leader) {
+					SeedRec s; s.rbeg = rbeg; s.qbeg = qbeg; s.len = len; s.next = -1; s.pad = 0;
+					cb.sl.seeds[id] = s;
+					cb.sl.seeds[last_seed].next = id;
+				}
+				if (lane == lower) {
+					rc.m0 = (uint32_t)(int32_t)(rbeg - pos);
+					rc.m1 = (uint32_t)c_rid | (uint32_t)id << 16;
+					rc.m2 = (uint32_t)f_qbeg | (uint32_t)qbeg << 8 | (uint32_t)len << 16;
+				}
+				return true;
+			}
+		}
+	}
+	// a new chain right after the element the look-up returned
+	if (n >= EMA_WAVE) return false;
+	if (cb.n_seed >= EMA_SEED_CAP) { cb.status |= EMA_ST_SEED_OVERFLOW; return true; }
+	{
+		const int lo32 = ema_wave_shr1((int)(uint32_t)(uint64_t)rc.pos, 0), hi32 = ema_wave_shr1((int)(uint32_t)((uint64_t)rc.pos >> 32), 0);
+		const int up_id = ema_wave_shr1(rc.id, 0);
+		const int64_t up_pos = (int64_t)((uint64_t)(uint32_t)hi32 << 32 | (uint32_t)lo32);
+		const int cid_new = cb.n_chain;
+		if (lane > at) { rc.pos = up_pos; rc.id = up_id; }
+		else if (lane == at) { rc.pos = rbeg; rc.id = cid_new; }
+	}
+	const int sid = cb.n_seed++, cid = cb.n_chain++;
+	if (leader) {
+		SeedRec s; s.rbeg = rbeg; s.qbeg = qbeg; s.len = len; s.next = -1; s.pad = 0;
+		cb.sl.seeds[sid] = s;
+		ChainRec c;
+		c.pos = rbeg; c.f_rbeg = c.l_rbeg = rbeg; c.f_qbeg = c.l_qbeg = qbeg; c.l_len = len;
+		c.rid = rid; c.n = 1; c.first_seed = c.last_seed = sid; c.w = 0; c.kept = 0; c.first = -1;
+		cb.sl.chains[cid] = c;      // l_rbeg, l_qbeg, l_len, last_seed and n are brought up to date from the summaries (as for chain_insert_med)
+	}
+	if (lane == cid) { rc.m0 = 0; rc.m1 = (uint32_t)rid | (uint32_t)sid << 16; rc.m2 = (uint32_t)qbeg | (uint32_t)qbeg << 8 | (uint32_t)len << 16; }
+	return true;
+}
+
+// the register tables written out as chain_insert_med's LDS tables (the filter, and chaining beyond 64 chains, read those)
+__device__ inline void reg_chains_to_lds(const ChainBuild &cb, const RegChains &rc, const MedTables &mt)
+{
+	const int lane = (int)ema_lane();
+	if (lane < cb.n_chain) {
+		mt.cpos[lane] = rc.pos; mt.cord[lane] = rc.id;
+		mt.csm[3 * lane] = rc.m0; mt.csm[3 * lane + 1] = rc.m1; mt.csm[3 * lane + 2] = rc.m2;
+	}
+	ema_wave_sync();
+}
+
 // mem_chain_weight for one chain (walks its seed list); run lane-parallel over chains
 __device__ __forceinline__ int chain_weight(const SeedRec *seeds, int first, int *n_seeds = nullptr)
 {
@@ -490,6 +579,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 		int n_chn = 0, n_keep = 0;
 		cb.n_chain = 0; cb.n_seed = 0; cb.status = 0;
 		bool med = false;         // the medium layout (see the head of the file) is in force
+		bool reg_mode = false;    // ... with its tables in registers: at most 64 chains so far (chain_insert_reg)
+		RegChains rc; rc.pos = 0; rc.id = 0; rc.m0 = rc.m1 = rc.m2 = 0;
 		const int32_t *hv_first = nullptr;      // MODE 1, 2: per chain (filtered order) the first slot of its seeds in the tables below
 		SeedRec *hv_cs = nullptr; DevReg *hv_res = nullptr; uint8_t *hv_valid = nullptr;
 		if (MODE == 1 || MODE == 2) {
@@ -614,6 +705,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			if (ema_uni(tot_occ <= SMALL)) ema_small_tables<SMALL>(cb.sl, lds_small[wib]);
 			else if (MED && ix.n_seqs <= 0xffff) {      // (the summaries keep a contig id in 16 bits)
 				med = true;
+				reg_mode = EMA_CHAIN_REGS != 0;      // the first 64 chains' tables in registers (chain_insert_reg)
 				// The medium tables are written with LDS instructions; the same bytes were last written -- by the previous read's
 				// extension phase: window buffer, seed copies, region list -- through generic pointers, i.e. FLAT instructions, which
 				// take the longer way to LDS.  An older FLAT store must not land on top of a younger LDS store: everything in flight
@@ -668,6 +760,11 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					if (rd < 0) continue;
 					const int qbeg = ema_lane_val(a_q, t), slen = ema_lane_val(a_l, t);
 					if (MED && med) {
+						if (reg_mode) {
+							if (chain_insert_reg(opt, l_pac, cb, rc, rb, qbeg, slen, rd)) continue;
+							reg_chains_to_lds(cb, rc, mt);      // a 65th chain: the tables move to LDS
+							reg_mode = false;
+						}
 						if (chain_insert_med(opt, l_pac, cb, mt, rb, qbeg, slen, rd)) continue;
 						// EMA_MED_CHAINS chains and one more to open: the chain records are brought up to date, the position table moves to
 						// the slab, and the read carries on in the slab layout
@@ -693,6 +790,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			}
 		}
 
+		if (MED && med && reg_mode) { reg_chains_to_lds(cb, rc, mt); reg_mode = false; }      // (the filter reads the LDS tables)
 		// ---------------- mem_chain_flt ----------------
 		n_chn = cb.n_chain; n_keep = 0;
 		EMA_DBG(3, n_chn);

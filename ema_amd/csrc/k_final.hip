@@ -160,13 +160,21 @@ struct FinalHeavy {
 };
 struct FinalRes { DevAln aln; int32_t st, n_final; unsigned long long ops_at; int64_t pad_; };      // 48 bytes
 
+// K4t: LDS per wavefront for its staged direction matrix, and the resident blocks per CU its registers must allow.  Round 4: 12 KB and
+// two blocks per CU (64 KB of LDS per block, 150 registers); [r5] A/B: 9 KB and three ("ema_k_final_t<1> >= 3 waves/SIMD")
+#ifndef EMA_K4T_ZLDS
+#define EMA_K4T_ZLDS (2 * EMA_Z_LDS)
+#endif
+#ifndef EMA_K4T_MIN_BLOCKS
+#define EMA_K4T_MIN_BLOCKS 1
+#endif
 #ifndef EMA_K4_MIN_BLOCKS
 #define EMA_K4_MIN_BLOCKS 4      // K4b fits 128 registers without a spill (143 when left alone)
 #endif
 // K4b: the regions K4a left (one wavefront per read of its todo list).  MODE 0: that; 1: K4t; 2: K4r (above).
 // alns: n_reads x opt.reg_cap; cigars: n_reads x cig_cap ops (pool per read, regions in order)
 template <int MODE>
-__global__ void __launch_bounds__(256, MODE == 1 ? 1 : EMA_K4_MIN_BLOCKS)      // (K4t's 64 KB of LDS allow two blocks per CU whatever its registers)
+__global__ void __launch_bounds__(256, MODE == 1 ? EMA_K4T_MIN_BLOCKS : EMA_K4_MIN_BLOCKS)
 ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const uint32_t *__restrict__ off, int n_reads,
             const int *__restrict__ n_pairs_dev, const int *__restrict__ map,
             const DevReg *__restrict__ regs, const int *__restrict__ n_regs, DevAln *__restrict__ alns,
@@ -177,7 +185,7 @@ ema_k_final_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 #define EMA_DBG(stage, val) do { if (dbg && lane == 0) { __hip_atomic_store(dbg + slot * 4 + 1, (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dbg + slot * 4 + 2, (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 	__shared__ uint8_t lds_q[4][256];
 	__shared__ uint8_t lds_r[4][EMA_RSEQ_CAP];
-	constexpr int Z_LDS = MODE == 1 ? 2 * EMA_Z_LDS : EMA_Z_LDS;      // (K4t's regions are the gapped ones of repeat-rich reads: wider bands)
+	constexpr int Z_LDS = MODE == 1 ? EMA_K4T_ZLDS : EMA_Z_LDS;      // (K4t's regions are the gapped ones of repeat-rich reads: wider bands)
 	__shared__ __attribute__((aligned(16))) uint8_t lds_z[MODE == 2 ? 1 : 4][MODE == 2 ? 16 : Z_LDS];      // the direction matrix, staged for the traceback
 	const int lane = (int)ema_lane();
 	const int wib = ema_uni((int)(threadIdx.x >> 6));      // scalar: slab and LDS pointers derived from it stay in SGPRs

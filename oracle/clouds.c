@@ -8,7 +8,9 @@
  * normalize_cloud_probabilities (src/align.c:124-143) and normalize_log_probs (src/util.c:130-163).  libc's qsort is called
  * where the reference calls it, on the same element sizes' worth of ordering (the records array is sorted through an index
  * array with the same comparator and a stable fallback: glibc's qsort is a merge sort for these sizes).
- * The -d density optimisation (mark_optimal_alignments_in_cloud, src/split.c) is out of scope: apply_opt = 0.
+ * [r5] The -d density optimisation (mark_optimal_alignments_in_cloud, src/split.c:15-339 with include/split.h's constants) is
+ * restated below as well, statement for statement -- the draws from libc's rand() and the order of the double-precision sums ARE
+ * its output; off unless orc_clouds_set_density switches it on (apply_opt, src/align.c:396).
  * These files ARE in the reference tree but include bwa's headers (through bwabridge.h), so they cannot be compiled here:
  * unpinned, like oracle/sam.c.
  */
@@ -237,6 +239,185 @@ static SAMRecord *find_best_record(SAMDictEnt *e)
 	return chosen;
 }
 
+/* ---- -d: src/split.c ---------------------------------------------------------------------------------------------------- */
+#define SPLIT_EXTRA_SEARCH_DEPTH 5       /* include/align.h:74 */
+#define TMAX_LOG 0.0                     /* include/split.h:8-17 */
+#define TMIN_LOG (-12.0)
+#define SIM_ANNEAL_ITERS 50000
+#define BIN_SIZE 1000
+#define MAX_BINS (1000000 / BIN_SIZE)    /* MAX_FRAG / BIN_SIZE */
+#define SCORE_SCALE 20
+#define MAX_NO_MOVE 500
+#define BUF_SIZE 50000
+static int g_apply_opt = 0, g_n_density = 4;
+static double g_density_probs[16] = {0.6, 0.05, 0.2, 0.01};      /* src/techs.c:76-79: every platform but cpt */
+void orc_clouds_set_density(int apply_opt, int n_probs, const double *probs)
+{
+	g_apply_opt = apply_opt;
+	if (probs && n_probs > 0 && n_probs <= 16) { g_n_density = n_probs; for (int i = 0; i < n_probs; i++) g_density_probs[i] = probs[i]; }
+}
+void orc_clouds_reseed(unsigned seed) { srand(seed); }
+
+static double log_density_prob(unsigned int density)      /* src/split.c:15-35 */
+{
+	const size_t size = (size_t)g_n_density;
+	if (density < size) return log(g_density_probs[density]);
+	return log(g_density_probs[size - 1]) - (density - size + 1) * log(2.0);
+}
+
+static int split_is_pair(SAMRecord *r1, SAMRecord *r2)      /* is_pair, src/align.c:27-40 (pos is uint32_t there: the difference wraps) */
+{
+	if (r1->rev == r2->rev || r1->chrom != r2->chrom) return 0;
+	if (r2->rev) { SAMRecord *rt = r2; r2 = r1; r1 = rt; }
+	const int64_t d = (int64_t)(uint32_t)(r1->pos - r2->pos);
+	return INSERT_MIN <= d && d <= INSERT_MAX;
+}
+
+#define BIN_IDX_FOR_POS(pos, lo) (((pos) - (lo)) / BIN_SIZE)
+/* caution: `records` should be name-sorted */
+static void mark_optimal_alignments_in_cloud(SAMRecord **records, size_t n_records)      /* src/split.c:38-339 */
+{
+	double log_config_prob = 0;
+	static __thread unsigned short bins[MAX_BINS];
+	struct uniquemapped_read { size_t idx; };
+	struct multimapped_read { size_t idx; int n, mate_umap, mate_mmap, active; };
+	size_t n_umaps = 0, n_mmaps = 0;
+	uint32_t cloud_lo = 0xffffffff, cloud_hi = 0x00000000;
+	if (n_records >= BUF_SIZE || n_records <= 5) return;
+	memset(bins, 0, sizeof(bins));
+	struct uniquemapped_read *umaps = malloc((n_records + 1) * sizeof(*umaps));
+	struct multimapped_read *mmaps = malloc((n_records + 1) * sizeof(*mmaps));
+	/* remove records that are too far from the lowest edit distance */
+	SAMRecord **records_clean = malloc(n_records * sizeof(*records_clean));
+	size_t n_records_clean = 0;
+	for (size_t i = 0; i < n_records;) {
+		size_t j = i + 1;
+		while (j < n_records && record_eq(records[j], records[i])) ++j;
+		const size_t n = j - i;
+		if (n > 1) {
+			size_t min_edit_dist = 0;
+			for (size_t k = 0; k < n; k++) if (records[i + k]->clip_edit_dist < records[i + min_edit_dist]->clip_edit_dist) min_edit_dist = k;
+			SAMRecord *best = records[i + min_edit_dist];
+			const int edit_dist_cutoff = best->clip_edit_dist + SPLIT_EXTRA_SEARCH_DEPTH;
+			for (size_t k = 0; k < n; k++) {
+				if (records[i + k]->clip_edit_dist <= edit_dist_cutoff) records_clean[n_records_clean++] = records[i + k];
+				else records[i + k]->active = 0;
+			}
+		} else records_clean[n_records_clean++] = records[i];
+		i = j;
+	}
+	records = records_clean;
+	n_records = n_records_clean;
+	/* find the multi-mapped reads, record highest */
+	for (size_t i = 0; i < n_records;) {
+		if (records[i]->pos < cloud_lo) cloud_lo = records[i]->pos;
+		if (records[i]->pos > cloud_hi) cloud_hi = records[i]->pos;
+		size_t j = i + 1;
+		while (j < n_records && record_eq(records[j], records[i])) {
+			if (records[j]->pos < cloud_lo) cloud_lo = records[j]->pos;
+			if (records[j]->pos > cloud_hi) cloud_hi = records[j]->pos;
+			++j;
+		}
+		const size_t n = j - i;
+		if (n > 1) {
+			size_t max_score = 0;
+			for (size_t k = 0; k < n; k++) if (records[i + k]->score > records[i + max_score]->score) max_score = k;
+			int mate_umap = -1, mate_mmap = -1;
+			for (size_t k = 0; k < n_umaps; k++) if (record_eq_mate(records[i], records[umaps[k].idx])) { mate_umap = (int)k; break; }
+			if (mate_umap < 0) {
+				for (size_t k = 0; k < n_mmaps; k++) {
+					if (record_eq_mate(records[i], records[mmaps[k].idx])) { mate_mmap = (int)k; mmaps[k].mate_mmap = (int)n_mmaps; break; }
+				}
+			}
+			mmaps[n_mmaps++] = (struct multimapped_read){.idx = i, .n = (int)n, .mate_umap = mate_umap, .mate_mmap = mate_mmap, .active = (int)max_score};
+			log_config_prob += records[i + max_score]->score / SCORE_SCALE;
+		} else {
+			for (size_t k = 0; k < n_mmaps; k++) if (record_eq_mate(records[i], records[mmaps[k].idx])) { mmaps[k].mate_umap = (int)n_umaps; break; }
+			umaps[n_umaps++] = (struct uniquemapped_read){.idx = i};
+			log_config_prob += records[i]->score / SCORE_SCALE;
+		}
+		i = j;
+	}
+	/* get initial configuration probability */
+	const size_t n_bins = (cloud_hi - cloud_lo) / BIN_SIZE + 1;
+	if (n_bins >= MAX_BINS || n_records <= 5 || n_mmaps == 0) { free(records); free(umaps); free(mmaps); return; }
+	for (size_t i = 0; i < n_records; i++) records[i]->active = 0;      /* we will re-set the active ones later */
+	for (size_t i = 0; i < n_umaps; i++) ++bins[BIN_IDX_FOR_POS(records[umaps[i].idx]->pos, cloud_lo)];
+	for (size_t i = 0; i < n_mmaps; i++) ++bins[BIN_IDX_FOR_POS(records[mmaps[i].idx + mmaps[i].active]->pos, cloud_lo)];
+	for (size_t i = 0; i < n_bins; i++) log_config_prob += log_density_prob(bins[i]);
+	/* simulated annealing to minimize distance variance */
+	int no_move_count = 0;
+	for (size_t k = 0; k < SIM_ANNEAL_ITERS; k++) {
+		const double t = pow(10.0, TMAX_LOG - ((TMAX_LOG - TMIN_LOG) * k) / SIM_ANNEAL_ITERS);
+		size_t r = rand() % n_mmaps;
+		size_t r_old = mmaps[r].active;
+		size_t r_new = rand() % (mmaps[r].n - 1);
+		if (r_new >= r_old) ++r_new;
+		SAMRecord *active_mate = NULL;
+		size_t mate_r = 0;
+		int mate_is_mmap = 0;
+		if (mmaps[r].mate_umap >= 0) { mate_r = mmaps[r].mate_umap; active_mate = records[umaps[mate_r].idx]; }
+		else if (mmaps[r].mate_mmap >= 0) { mate_r = mmaps[r].mate_mmap; active_mate = records[mmaps[mate_r].idx + mmaps[mate_r].active]; mate_is_mmap = 1; }
+		SAMRecord *rec_old = records[mmaps[r].idx + r_old];
+		SAMRecord *rec_new = records[mmaps[r].idx + r_new];
+		double density_prob_change = 0.0, score_prob_change = 0.0;
+		int force_move = 0, mate_new_active = -1;
+		size_t mate_old_bin = 0, mate_new_bin = 0;
+		const int old_paired = active_mate != NULL && split_is_pair(rec_old, active_mate);
+		const int new_paired = active_mate != NULL && split_is_pair(rec_new, active_mate);
+		if (!old_paired && new_paired) force_move = 1;
+		else if (old_paired && !new_paired && mate_is_mmap) {
+			for (int i = 0; i < mmaps[mate_r].n; i++) {
+				SAMRecord *mate_rec_new = records[mmaps[mate_r].idx + i];
+				if (split_is_pair(rec_new, mate_rec_new)) {
+					SAMRecord *mate_rec_old = active_mate;
+					mate_new_active = i;
+					mate_old_bin = BIN_IDX_FOR_POS(mate_rec_old->pos, cloud_lo);
+					mate_new_bin = BIN_IDX_FOR_POS(mate_rec_new->pos, cloud_lo);
+					score_prob_change += (mate_rec_new->score - mate_rec_old->score) / SCORE_SCALE;
+					break;
+				}
+			}
+		}
+		const size_t old_bin = BIN_IDX_FOR_POS(rec_old->pos, cloud_lo), new_bin = BIN_IDX_FOR_POS(rec_new->pos, cloud_lo);
+		const int p1 = (mate_new_active >= 0 && old_bin == mate_old_bin) ? 2 : 1;
+		const int p2 = (mate_new_active >= 0 && new_bin == mate_new_bin) ? 2 : 1;
+		{
+			const double old_bin_prob_old = log_density_prob(bins[old_bin]);
+			const double old_bin_prob_new = log_density_prob(bins[old_bin] - p1);
+			const double new_bin_prob_old = log_density_prob(bins[new_bin]);
+			const double new_bin_prob_new = log_density_prob(bins[new_bin] + p2);
+			density_prob_change += (old_bin_prob_new - old_bin_prob_old) + (new_bin_prob_new - new_bin_prob_old);
+		}
+		if (p1 == 1 && mate_new_active >= 0) {
+			const double a = log_density_prob(bins[mate_old_bin]), b = log_density_prob(bins[mate_old_bin] - 1);
+			density_prob_change += (b - a);
+		}
+		if (p2 == 1 && mate_new_active >= 0) {
+			const double a = log_density_prob(bins[mate_new_bin]), b = log_density_prob(bins[mate_new_bin] + 1);
+			density_prob_change += (b - a);
+		}
+		score_prob_change += (rec_new->score - rec_old->score) / SCORE_SCALE;
+		const double prob_change = density_prob_change + score_prob_change;
+		if (force_move || prob_change > 0 || exp(prob_change / t) >= ((double)rand()) / RAND_MAX) {
+			log_config_prob += prob_change;
+			mmaps[r].active = (int)r_new;
+			bins[old_bin] -= 1;
+			bins[new_bin] += 1;
+			if (mate_new_active >= 0) {
+				mmaps[mate_r].active = mate_new_active;
+				bins[mate_old_bin] -= 1;
+				bins[mate_new_bin] += 1;
+			}
+		} else ++no_move_count;
+		if (no_move_count >= MAX_NO_MOVE) break;
+	}
+	(void)log_config_prob;
+	for (size_t i = 0; i < n_umaps; i++) records[umaps[i].idx]->active = 1;
+	for (size_t i = 0; i < n_mmaps; i++) records[mmaps[i].idx + mmaps[i].active]->active = 1;
+	free(records); free(umaps); free(mmaps);
+}
+
 static double mate_dist_penalty(const int64_t mate1_pos, const int64_t mate2_pos)
 {
 	const int64_t d = mate1_pos - mate2_pos;
@@ -290,6 +471,7 @@ size_t orc_clouds_group(orc_crec_t *recs, size_t n, size_t n_pairs, uint32_t dis
 			SAMRecord **cloud_to_split = malloc(cov * sizeof(*cloud_to_split));
 			for (size_t i = 0; i < cov; i++) cloud_to_split[i] = sorted[at + i];
 			qsort(cloud_to_split, cov, sizeof(*cloud_to_split), name_cmp);
+			if (g_apply_opt) mark_optimal_alignments_in_cloud(cloud_to_split, cov);      /* src/align.c:396-397 */
 			for (size_t i = 0; i < cov; i++) sam_dict_add(sd, cloud_to_split[i], &clouds[nc], 1, many_clouds);
 			free(cloud_to_split);
 		}

@@ -282,8 +282,14 @@ typedef struct orc_crec {         /* the fields of SAMRecord (reference include/
 	/* results */
 	double gamma;
 	int32_t cloud_id, cloud_bad, alt;      /* alt: `orig` of the record the XA entry is copied from, or -1 */
+	int32_t clip_edit_dist;       /* input, read by -d only (SAMRecord.clip_edit_dist, src/align.c:938); sits in what was padding */
 	struct orc_crec *sel_mate;
 } orc_crec_t;
+/* -d (reference src/split.c, called at src/align.c:396-397): off by default.  probs: the platform's read-density model
+ * (src/techs.c: density_probs, n of them).  The optimiser draws from libc's rand(), which the reference seeds from time() once per
+ * process; orc_clouds_reseed(seed) is srand(seed). */
+void orc_clouds_set_density(int apply_opt, int n_probs, const double *probs);
+void orc_clouds_reseed(unsigned seed);
 size_t orc_clouds_group(orc_crec_t *recs, size_t n, size_t n_pairs, uint32_t dist_thresh, int many_clouds, int *cloud_id, int *order);
 
 #ifdef __cplusplus

@@ -361,7 +361,7 @@ class CRec(C.Structure):      # orc_crec_t (oracle/oracle.h)
                 ("mate", C.c_uint32), ("rev", C.c_uint32), ("orig", C.c_uint32), ("hash", C.c_uint32), ("mate_hash", C.c_uint32),
                 ("hashed", C.c_uint8), ("mate_hashed", C.c_uint8), ("active", C.c_uint8), ("duplicate", C.c_uint8), ("visited", C.c_uint8),
                 ("pad_", C.c_uint8 * 3), ("gamma", C.c_double), ("cloud_id", C.c_int32), ("cloud_bad", C.c_int32), ("alt", C.c_int32),
-                ("sel_mate", C.c_void_p)]
+                ("clip_edit_dist", C.c_int32), ("sel_mate", C.c_void_p)]
 
 
 def clouds_group(records, n_pairs, cloud_id, dist_thresh=50000, many_clouds=False):
@@ -372,15 +372,31 @@ def clouds_group(records, n_pairs, cloud_id, dist_thresh=50000, many_clouds=Fals
     L.orc_clouds_group.argtypes = [C.POINTER(CRec), C.c_size_t, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     n = len(records)
     arr = (CRec * max(n, 1))()
-    for i, (bc, chrom, pos, ident, score, mate, rev) in enumerate(records):
+    for i, rec_in in enumerate(records):
+        bc, chrom, pos, ident, score, mate, rev = rec_in[:7]
         r = arr[i]
         r.bc, r.chrom, r.pos, r.ident, r.score, r.mate, r.rev, r.orig, r.active, r.alt = bc, chrom, pos, ident, score, mate, rev, i, 1, -1
+        r.clip_edit_dist = rec_in[7] if len(rec_in) > 7 else 0      # (read by -d only: clouds_density)
     cid = C.c_int(cloud_id)
     order = (C.c_int * (2 * max(n, 1)))()
     k = L.orc_clouds_group(arr, n, n_pairs, dist_thresh, int(many_clouds), C.byref(cid), order)
     out = [(order[2 * i], order[2 * i + 1]) for i in range(k)]
     res = [(arr[i].gamma, arr[i].cloud_id, arr[i].cloud_bad, arr[i].duplicate, arr[i].alt) for i in range(n)]
     return out, res, cid.value
+
+
+def clouds_density(on: bool, probs=None, seed=None):
+    """-d of the oracle's cloud stage (oracle/clouds.c, mark_optimal_alignments_in_cloud): on / off, the platform's density model
+    (default: src/techs.c's 0.6, 0.05, 0.2, 0.01), and srand(seed) when a seed is given (the optimiser draws from libc's rand())."""
+    L = lib()
+    L.orc_clouds_set_density.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+    if probs is None:
+        L.orc_clouds_set_density(int(on), 0, None)
+    else:
+        L.orc_clouds_set_density(int(on), len(probs), (C.c_double * len(probs))(*probs))
+    if seed is not None:
+        L.orc_clouds_reseed.argtypes = [C.c_uint]
+        L.orc_clouds_reseed(seed)
 
 
 def sam_header(contigs, rg_line, version: bytes, argv) -> bytes:

@@ -61,7 +61,7 @@ def oracle_selection(bucket, batch, rec, pair_off, names, dist_thresh=50000, man
             c = batch.cand[int(a["cand"])]
             p = int(a["pair"])
             ident = bucket.ident(p)[1:]
-            recs.append((int(bucket.bc[p]), int(c["rid"]), int(c["pos"]) + 1, ident, float(a["score"]), int(a["mate"]), int(c["is_rev"] != 0)))
+            recs.append((int(bucket.bc[p]), int(c["rid"]), int(c["pos"]) + 1, ident, float(a["score"]), int(a["mate"]), int(c["is_rev"] != 0), int(a["clip_edit_dist"])))
         order, res, cloud_id = O.clouds_group(recs, p1 - p0, cloud_id, dist_thresh, many_clouds)
 
         def sam_rec(i):

@@ -139,3 +139,48 @@ def test_raw_fastq_through_count_and_preproc_to_sam(tmp_path):
     assert st["h1_corrected"] > 20 and st["pairs_written"] + st["pairs_nobc"] == pairs.n
     paths = [str(tmp_path / "b" / f"ema-bin-{k:03d}") for k in range(3)]
     _check(tmp_path, prefix, ctg, paths, st["pairs_written"], False, True)
+
+
+def test_hundred_buckets_streamed_with_the_density_optimiser(tmp_path):
+    """BASELINE configs[2]'s shape: a hundred-odd barcode buckets through ONE ema_stream_sam call with `-d` on
+    (ema_cloud_opts.density_opt; rand() seeded once, as the reference's first bad cloud does), the SAM text against the all-oracle
+    chain -- oracle/ingest.c, the oracle's candidates and append stage, oracle/clouds.c WITH its restatement of src/split.c (pinned
+    to the reference's own -d output by tests/test_golden_sam.py), oracle/sam.c -- byte for byte, bucket after bucket.  A repeat-rich
+    reference, so that clouds with a read in two places exist and the optimiser has moves to make; the test insists that -d changed
+    the output."""
+    from ema_amd import clouds
+    prefix, ctg = small_ref("repeats")
+    sizes = [90 + 17 * (k % 5) for k in range(104)]
+    paths = []
+    for k, n in enumerate(sizes):
+        d = tmp_path / f"b{k}"
+        d.mkdir()
+        make_bucket(d, "repeats", n, 2000 + k, 30, False, sub_rate=0.02, chimeric=0.04)
+        paths.append(str(d / "bucket"))
+    names = [f"chr{i + 1}".encode() for i in range(len(ctg))]
+    seed = 1500000000
+    eng = E.Engine(prefix)
+    out = str(tmp_path / "out.sam")
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    clouds.reseed(seed)
+    bst, sst = stream.stream_sam(eng, paths, fd, rg_id=b"rg1", density_opt=True)
+    os.close(fd)
+    eng.close()
+    got = open(out, "rb").read()
+    so = sam.default_opts()
+    so.rg_id = b"rg1"
+    texts = {}
+    for on in (True, False):
+        O.clouds_density(on, seed=seed if on else None)
+        try:
+            texts[on] = [oracle_sam(prefix, path, names, so)[0] for path in paths]
+        finally:
+            O.clouds_density(False)
+    want = b"".join(texts[True])
+    at = 0
+    for k, t in enumerate(texts[True]):      # bucket by bucket, so that a difference names its bucket
+        assert got[at:at + len(t)] == t, f"bucket {k} differs"
+        at += len(t)
+    assert got == want and got.count(b"\n") > 1.6 * sum(sizes)
+    assert want != b"".join(texts[False]), "-d changed nothing: the test has no teeth"
+    assert all(s["rc"] == 0 and s["capacity_flags"] == 0 for s in bst) and len(bst) == 104

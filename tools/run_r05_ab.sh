@@ -1,0 +1,24 @@
+#!/bin/bash
+# Dev aid: bench.py (20 steps, kernels + delivery only) over a set of engine builds on ONE GPU box, so that the numbers compare.
+#   gpurun --timeout 2400 -- 'bash tools/run_r05_ab.sh tag "" chainlds k4t3 ...'      ("" = the product build libema_engine.so)
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+for v in "$@"; do
+  name=${v:-product}
+  lib=libema_engine${v:+_$v}.so
+  EMA_ENGINE_LIB=$lib timeout 600 python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-sam-leg > "$out/bench_$name.json" 2> "$out/bench_$name.err"
+  echo "$name rc=$?"
+  python3 - "$out/bench_$name.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    er = d.get("engine_resident") or {}
+    iso = (d.get("roofline") or {}).get("isolated") or {}
+    print("   value %.0f  ms_per_step %.2f  engine_resident ms %.2f  isolated: %s" % (d["value"], d["ms_per_step"], er.get("ms_per_step", 0), (d.get("roofline") or {}).get("all_kernels_ms_isolated")))
+except Exception as e:
+    print("   no line:", e)
+PY
+done

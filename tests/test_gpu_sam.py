@@ -145,17 +145,17 @@ def test_hundred_buckets_streamed_with_the_density_optimiser(tmp_path):
     """BASELINE configs[2]'s shape: a hundred-odd barcode buckets through ONE ema_stream_sam call with `-d` on
     (ema_cloud_opts.density_opt; rand() seeded once, as the reference's first bad cloud does), the SAM text against the all-oracle
     chain -- oracle/ingest.c, the oracle's candidates and append stage, oracle/clouds.c WITH its restatement of src/split.c (pinned
-    to the reference's own -d output by tests/test_golden_sam.py), oracle/sam.c -- byte for byte, bucket after bucket.  A repeat-rich
-    reference, so that clouds with a read in two places exist and the optimiser has moves to make; the test insists that -d changed
-    the output."""
+    to the reference's own -d output by tests/test_golden_sam.py), oracle/sam.c -- byte for byte, bucket after bucket.  A reference
+    with exact 3 kb copies 15 kb apart and 80 pairs per barcode, so that clouds holding a read in two places exist and the optimiser
+    has moves to make (every bucket's text differs from its text without -d on this workload); the test insists that -d changed the output."""
     from ema_amd import clouds
-    prefix, ctg = small_ref("repeats")
-    sizes = [90 + 17 * (k % 5) for k in range(104)]
+    prefix, ctg = small_ref("exact_dups")
+    sizes = [160 + 16 * (k % 5) for k in range(104)]
     paths = []
     for k, n in enumerate(sizes):
         d = tmp_path / f"b{k}"
         d.mkdir()
-        make_bucket(d, "repeats", n, 2000 + k, 30, False, sub_rate=0.02, chimeric=0.04)
+        make_bucket(d, "exact_dups", n, 2000 + k, 80, False, sub_rate=0.003)
         paths.append(str(d / "bucket"))
     names = [f"chr{i + 1}".encode() for i in range(len(ctg))]
     seed = 1500000000

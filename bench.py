@@ -684,7 +684,7 @@ def main(argv=None):
         knobs = [k for k in ENGINE_KNOBS if k in os.environ]
         default_run = (args.pairs == 1048576 and n_slices == 3 and args.lean_seed_extends == 0 and not knobs)
         traffic, traffic_source, traffic_stale = None, None, None
-        pmc_name = next((n for n in ({0.0: ("r04_pmc_chr20.csv", "r03_pmc_chr20.csv"), 3100.0: ("r04_pmc_grch38scale.csv", "r03_pmc_grch38scale.csv")}
+        pmc_name = next((n for n in ({0.0: ("r04_pmc_chr20.csv", "r03_pmc_chr20.csv"), 3100.0: ("r05_pmc_grch38scale.csv", "r04_pmc_grch38scale.csv", "r03_pmc_grch38scale.csv")}
                                      .get(float(args.genome_mbp), ())) if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         tab = pmc_table(pmc_name) if (pmc_name and default_run) else None
         if tab:      # do the stored counters describe THESE kernels?  (tools/kernel_hash.py beside the table; none stored = unknown = stale)
@@ -804,6 +804,22 @@ def main(argv=None):
             "note": "host_bound divides the CPUs granted to the node by ONE rank's CPU seconds per pair over its timed region (all of the process's "
                     "threads, the Python sink included): a rough bound"}
         out["bucket_files_to_sam"] = sam_leg(args, eng, batches, workdir, world) if not (args.no_extras or args.no_sam_leg) else None
+        if out["bucket_files_to_sam"]:
+            # The same prediction for the end-to-end leg: N ranks run N such streams, every stream's host stages
+            # (reader, staging, fetch, append, clouds / EM / duplicates, formatter) drawing on the ONE CPU grant of the node.
+            leg = out["bucket_files_to_sam"]
+            cpu_per_pair = leg["host_cpu_seconds_per_million_pairs"] / 1e6
+            rate1 = leg["value"]
+            leg["scaling_prediction"] = {
+                "status": "PREDICTED from this run's 1-GPU rate and host CPU cost; no multi-GPU run has been measured on hardware",
+                "per_n_gpus": {str(n): {"gpu_bound_pairs_per_s": round(n * rate1, 1),
+                                        "host_bound_pairs_per_s": round(node_cpus / cpu_per_pair, 1) if cpu_per_pair > 0 else None,
+                                        "predicted_pairs_per_s": round(min(n * rate1, node_cpus / cpu_per_pair if cpu_per_pair > 0 else n * rate1), 1)}
+                               for n in (1, 2, 4, 8)},
+                "cpus_granted_to_the_node": node_cpus,
+                "cpus_for_6x_at_8_gpus": int(np.ceil(6.0 * rate1 * cpu_per_pair)) if cpu_per_pair > 0 else None,
+                "note": "north_star asks for >= 6x the 1-GPU rate at 8 GPUs: that takes cpus_for_6x_at_8_gpus CPUs' worth of host threads at this "
+                        "run's CPU cost per pair; on cpus_granted_to_the_node the stream is host-bound from the N where gpu_bound exceeds host_bound"}
         print(json.dumps(out), flush=True)
     eng.close()
     if use_dist:

@@ -676,7 +676,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	}
 
 	if (const char *pp3 = ema_tuning_get("phase_profile"); pp3 && atoi(pp3) == 3) {
-		HIPCHK(e, e->d_lprof.alloc(48)); HIPCHK(e, hipMemset(e->d_lprof.p, 0, 48 * 8));
+		HIPCHK(e, e->d_lprof.alloc(64)); HIPCHK(e, hipMemset(e->d_lprof.p, 0, 64 * 8));
 		ema_align_set_light_profile(e->d_lprof.p);
 	} else if (const char *pp = ema_tuning_get("phase_profile")) {
 		HIPCHK(e, e->d_prof.alloc(48)); HIPCHK(e, hipMemset(e->d_prof.p, 0, 384));
@@ -1538,15 +1538,19 @@ int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)
 	}
 #endif
 	if (e->d_lprof.p) {
-		unsigned long long h[48];
+		unsigned long long h[64];
 		if (hipMemcpy(h, e->d_lprof.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
 			static const char *const name[4] = {"K2b (mode 0)", "K2c", "K2d", "hand-overs (mode 3)"};
 			for (int m = 0; m < 4; ++m) {
-				const unsigned long long *o = h + 12 * m;
+				const unsigned long long *o = h + 16 * m;
 				if (!o[7]) continue;
 				fprintf(stderr, "%-20s lifetimes %.2f Gclk, %llu wavefronts, %llu work items: claim %.2f, read / record / chaining %.2f, chain head + seeds %.2f, "
 				        "window %.2f, per-seed control %.2f, extension DPs %.2f (%llu calls), dedup + output %.2f\n", name[m], (double)o[7] * 1e-9, o[10], o[9],
-				        (double)o[0] * 1e-9, (double)o[1] * 1e-9, (double)o[2] * 1e-9, (double)o[3] * 1e-9, (double)o[4] * 1e-9, (double)o[5] * 1e-9, o[8], (double)o[6] * 1e-9);
+				        (double)o[0] * 1e-9, (double)(o[1] + o[11] + o[12] + o[13] + o[14] + o[15]) * 1e-9, (double)o[2] * 1e-9, (double)o[3] * 1e-9, (double)o[4] * 1e-9, (double)o[5] * 1e-9, o[8], (double)o[6] * 1e-9);
+				if (m == 0)      // [r5] where mode 0's "read / record / chaining" goes
+					fprintf(stderr, "%-20s   of which: the read in + what is left %.2f, intervals in order + repetitive fraction %.2f, suffix-array rows + contig ids %.2f, "
+					        "insertions %.2f, chain filter %.2f, setting aside %.2f\n", "", (double)o[1] * 1e-9, (double)o[11] * 1e-9, (double)o[12] * 1e-9, (double)o[13] * 1e-9,
+					        (double)o[14] * 1e-9, (double)o[15] * 1e-9);
 			}
 			(void)hipMemset(e->d_lprof.p, 0, sizeof h);
 		}

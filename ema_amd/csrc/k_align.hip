@@ -452,7 +452,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	// PROF 2: the clocks since the previous mark go to phase k -- 0 claiming a work item, 1 the read and its record (mode 0: the
 	// intervals, suffix-array rows, chaining, filter, setting aside), 2 a chain's head and seeds, 3 its window (bounds, fetch, seed
 	// order), 4 the per-seed control (cover tests, region records), 5 the extension DPs, 6 dedup / patch and output
-	unsigned long long lp[7] = {0, 0, 0, 0, 0, 0, 0};
+	unsigned long long lp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [r5] 7..11: mode 0's phase 1 split -- intervals in order + repetitive fraction, suffix-array rows + contigs, insertions, chain filter, setting aside
 	int lp_n_dp = 0, lp_reads = 0;
 	const unsigned long long lp_t0 = PROF == 2 ? __builtin_amdgcn_s_memtime() : 0;
 	unsigned long long lp_mark = lp_t0;
@@ -715,6 +715,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 			log_iv = n_iv; log_occ = (int)(tot_occ < (1 << 30) ? tot_occ : (1 << 30));
 		}
 		frac_rep = (float)l_rep / (float)l_query;
+		EMA_LP(7);
 		// The seed occurrences in mem_chain's order -- interval by interval, k = 0, step, ... within one -- taken SIXTY-FOUR AT A TIME
 		// ACROSS intervals: one round trip for the suffix-array rows of a whole batch and one for their contigs, where a read from a
 		// repeat family (dozens of intervals with a handful of occurrences each) paid those round trips per interval.  Lane L keeps
@@ -754,6 +755,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					rid = ema_intv2rid(ix, rbeg, rbeg + a_l);
 				}
 				EMA_PHASE(1);      // 1: the insertions
+				EMA_LP(8);
 				for (int t = 0; t < filled; ++t) {
 					const int64_t rb = ema_lane_val(rbeg, t);
 					const int rd = ema_lane_val(rid, t);
@@ -787,6 +789,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					}
 					chain_insert(opt, l_pac, cb, rb, qbeg, slen, rd);
 				}
+				EMA_LP(9);
 			}
 		}
 
@@ -951,6 +954,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 		}
 
+		if (MODE == 0) EMA_LP(10);
 		// ---------------- a chain-rich read is set aside for K2c / K2d (dev_types.h, HeavyCtl) ----------------
 		if (MODE == 0 && hv.arena && n_keep >= hv.min_chains) {
 			int n_ext = 0, tot = 0;      // chains to extend, their seeds
@@ -1027,6 +1031,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					if (lane == 0) d_first[n_keep] = run;
 					EMA_DBG(9, -n_ext);
 					EMA_PHASE(0);
+					EMA_LP(11);
 					continue;
 				}
 			}
@@ -1324,8 +1329,9 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 	}
 	if (prof && lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(prof + (i < 8 ? i : i + 4), acc[i]);      // 8.. -> slots 12.. (8..11 are K1's)
 	if (PROF == 2 && lane == 0 && prof_arg) {      // twelve slots per mode: the seven phases, lifetimes, DP calls, work items, wavefronts
-		unsigned long long *o = prof_arg + 12 * MODE;
+		unsigned long long *o = prof_arg + 16 * MODE;
 		for (int k = 0; k < 7; ++k) atomicAdd(o + k, lp[k]);
+		for (int k = 7; k < 12; ++k) atomicAdd(o + 4 + k, lp[k]);      // slots 11..15
 		atomicAdd(o + 7, __builtin_amdgcn_s_memtime() - lp_t0); atomicAdd(o + 8, (unsigned long long)lp_n_dp); atomicAdd(o + 9, (unsigned long long)lp_reads);
 		atomicAdd(o + 10, 1ULL);
 	}
@@ -1336,7 +1342,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 
 extern "C" size_t ema_align_slab_bytes() { return EMA_ALIGN_SLAB_BYTES; }
 
-// EMA_PHASE_PROFILE=3 (engine.hip): 48 device words, twelve per mode -- the clocks of seven phases (see the kernel), wavefront
+// EMA_PHASE_PROFILE=3 (engine.hip): 64 device words, sixteen per mode -- the clocks of seven phases (see the kernel), wavefront
 // lifetimes, DP calls, work items, wavefronts
 static unsigned long long *ema_align_light_prof = nullptr;
 extern "C" void ema_align_set_light_profile(unsigned long long *buf) { ema_align_light_prof = buf; }

@@ -48,8 +48,8 @@ if [[ $what == *pmc* ]]; then
   python3 "$root/tools/pmc_summary.py" --csv "$out"/pmc* > "$out/pmc_summary.csv" 2> /dev/null
 fi
 if [[ $what == *rebench* ]]; then      # the bench line once more, now with K1's traffic and K2's instruction count from this call's PMC passes
-  cp "$out/pmc_summary.csv" "$root/profiles/r04_pmc_grch38scale.csv"
-  python3 "$root/tools/kernel_hash.py" > "$root/profiles/r04_pmc_grch38scale.csv.srchash"; cp "$root/profiles/r04_pmc_grch38scale.csv.srchash" "$out/"
+  cp "$out/pmc_summary.csv" "$root/profiles/r05_pmc_grch38scale.csv"
+  python3 "$root/tools/kernel_hash.py" > "$root/profiles/r05_pmc_grch38scale.csv.srchash"; cp "$root/profiles/r05_pmc_grch38scale.csv.srchash" "$out/"
   timeout 1500 python3 "$root/bench.py" > "$out/bench_with_pmc.json" 2> "$out/bench_with_pmc.err"; echo "rebench: rc=$?"; cut -c1-300 "$out/bench_with_pmc.json"
 fi
 # the per-dispatch traces are large; keep the statistics and the counter tables

@@ -54,6 +54,9 @@ struct AlignSlab {           // per resident wave
 //              of the small-table area when the chain has no more than SMALL seeds.
 // A read whose chain count outgrows EMA_MED_CHAINS moves its position table to the slab and carries on there.
 #define EMA_MED_CHAINS 256
+#ifndef EMA_SORT_WAVE
+#define EMA_SORT_WAVE 1      // [r5] the chain filter's ks_introsort (medium layout: up to 256 weights, ties the rule) by the whole wavefront (dev_sort.hpp, ema_introsort_wave); 0: by one lane
+#endif
 #ifndef EMA_CHAIN_REGS
 #define EMA_CHAIN_REGS 1      // [r5] the medium layout's tables in registers while a read has at most 64 chains (chain_insert_reg); 0: round 4's LDS tables from the start
 #endif
@@ -838,7 +841,10 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				}
 			}
 			ema_wave_sync();
-			if (lane == 0) ema_introsort(skey, n_chn, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, lds_stack[wib]);
+			// (ks_introsort by the whole wavefront, dev_sort.hpp: the same array, ties included; the stoppers' ranks go to the first
+			// kilobyte of the small-table area, whose summaries every lane took into registers above)
+			if (EMA_SORT_WAVE) ema_introsort_wave(skey, n_chn, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, lds_stack[wib], reinterpret_cast<uint16_t *>(lds_small[wib]));
+			else if (lane == 0) ema_introsort(skey, n_chn, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, lds_stack[wib]);
 			ema_wave_sync();
 			EMA_DBG(4, n_chn);
 			uint8_t *flag = reinterpret_cast<uint8_t *>(csum);      // byte 0 of a summary

@@ -113,3 +113,32 @@ extern "C" void ema_launch_test_dedup(const DevIndex *ix, const DevOpts *opt, De
 {
 	hipLaunchKernelGGL(ema_k_test_dedup, dim3(n_tasks), dim3(64), 0, s, *ix, *opt, regs, n_in, n_out, cap, n_tasks, tmp, keys);
 }
+
+// ema_introsort_wave against ema_introsort (dev_sort.hpp): task t sorts wave_io[t*cap .. +n[t]) with the wavefront's form and
+// seq_io[t*cap .. +n[t]) (the same keys) with the single-lane form; the comparison is the chain filter's (high words, descending)
+// when by_weight, else plain ascending.  The caller compares the two arrays.
+__global__ void __launch_bounds__(64)
+ema_k_test_sort(uint64_t *wave_io, uint64_t *seq_io, const int *n, int cap, int n_tasks, int by_weight)
+{
+	__shared__ int stack[3 * 70];
+	__shared__ uint16_t scratch[512];
+	__shared__ uint64_t keys[256];
+	const int t = blockIdx.x;
+	if (t >= n_tasks) return;
+	const int lane = (int)ema_lane(), m = n[t];
+	for (int i = lane; i < m; i += EMA_WAVE) keys[i] = wave_io[(size_t)t * cap + i];
+	ema_wave_sync();
+	if (by_weight) ema_introsort_wave(keys, m, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, stack, scratch);
+	else ema_introsort_wave(keys, m, [](uint64_t x, uint64_t y) { return x < y; }, stack, scratch);
+	ema_wave_sync();
+	for (int i = lane; i < m; i += EMA_WAVE) wave_io[(size_t)t * cap + i] = keys[i];
+	ema_wave_sync();
+	if (lane == 0) {
+		if (by_weight) ema_introsort(seq_io + (size_t)t * cap, m, [](uint64_t x, uint64_t y) { return (x >> 32) > (y >> 32); }, stack);
+		else ema_introsort(seq_io + (size_t)t * cap, m, [](uint64_t x, uint64_t y) { return x < y; }, stack);
+	}
+}
+extern "C" void ema_launch_test_sort(uint64_t *wave_io, uint64_t *seq_io, const int *n, int cap, int n_tasks, int by_weight, hipStream_t s)
+{
+	hipLaunchKernelGGL(ema_k_test_sort, dim3(n_tasks), dim3(64), 0, s, wave_io, seq_io, n, cap, n_tasks, by_weight);
+}

@@ -161,12 +161,14 @@ struct FinalHeavy {
 struct FinalRes { DevAln aln; int32_t st, n_final; unsigned long long ops_at; int64_t pad_; };      // 48 bytes
 
 // K4t: LDS per wavefront for its staged direction matrix, and the resident blocks per CU its registers must allow.  Round 4: 12 KB and
-// two blocks per CU (64 KB of LDS per block, 150 registers); [r5] A/B: 9 KB and three ("ema_k_final_t<1> >= 3 waves/SIMD")
+// two blocks per CU (64 KB of LDS per block, 150 registers).  [r5] 9 KB and three blocks per CU = three waves per SIMD:
+// K4 per slice with the chip to itself 5.37 -> 5.16 ms, the steady state unchanged (profiles/r05_ab.txt); a matrix over 9 KB -- a
+// band of 31 columns over 290 rows -- is walked in the slab as before.
 #ifndef EMA_K4T_ZLDS
-#define EMA_K4T_ZLDS (2 * EMA_Z_LDS)
+#define EMA_K4T_ZLDS 9216
 #endif
 #ifndef EMA_K4T_MIN_BLOCKS
-#define EMA_K4T_MIN_BLOCKS 1
+#define EMA_K4T_MIN_BLOCKS 3
 #endif
 #ifndef EMA_K4_MIN_BLOCKS
 #define EMA_K4_MIN_BLOCKS 4      // K4b fits 128 registers without a spill (143 when left alone)

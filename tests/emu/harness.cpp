@@ -253,6 +253,8 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	return EMU_REG_CAP;
 }
 int emu_sizeof_reg() { return (int)sizeof(DevReg); }
+// dev_sort.hpp: the wavefront's introsort and the single-lane one on copies of the same keys (tests/test_emu_dp.py)
+void emu_sort(uint64_t *wave_io, uint64_t *seq_io, const int *n, int cap, int n_tasks, int by_weight) { ema_launch_test_sort(wave_io, seq_io, n, cap, n_tasks, by_weight, nullptr); }
 
 // the whole pipeline K1..K4 on host memory (n_reads even: pairs)
 // K4's set-aside path (k_final.hip: K4t / K4r) on host memory: lists, arena and counters; EMU_K4_HEAVY = regions a read must have left

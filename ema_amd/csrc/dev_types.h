@@ -76,7 +76,10 @@ struct DevOpts {
 	// K1: bit 0 = a pass-2 search is skipped when no min_seed_len-base window over its position can be frequent enough (k_seed.hip, "window test");
 	// bit 1 = a pass-1 search whose forward match ended as a single occurrence finds its SMEM on the text ("anchors")
 	// bit 2 = one control pass per tick ("one pass per tick")
+	// bit 3 = pass 3 (the LAST-like seeds, bwt_seed_strategy1) runs as a kernel of its own behind K1 (k_seed_p3.hip); K1 then ends a
+	//         read after pass 2 and leaves the extends it has used in seed_ext[read] (the lean budget runs on across the passes)
 	int seed_flags;
+	int32_t *seed_ext;
 };
 
 // SMEM / seed interval: bwa's bwtintv_t.  info = start<<32 | end.

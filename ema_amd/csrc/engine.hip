@@ -106,6 +106,10 @@ extern "C" void ema_align_set_light_profile(unsigned long long *buf);
 extern "C" void ema_k3_prof_read(unsigned long long *out);
 extern "C" void ema_k4_prof_read(unsigned long long *out);
 #endif
+extern "C" void ema_launch_seed_p3(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads, const int *n_pairs_dev,
+                                   const int *map, Intv *intv, int *n_intv, int *status, const int32_t *ext, int *counter, int *long_list, int *n_long,
+                                   int long_cap, int n_blocks, hipStream_t stream);
+extern "C" int ema_seed_splits_pass3(const DevOpts *opt, const unsigned long long *prof);
 extern "C" size_t ema_align_lane_wave_bytes();
 // K2x (k_ext_lane.hip): the first seed of every chain K2a hands over, extended one lane per seed
 extern "C" void ema_launch_ext_plan_hand(const DevIndex *ix, const DevOpts *opt, const uint8_t *hand, const int *n_hand, int max_records, ExtTask *tasks, int *n_tasks,
@@ -227,6 +231,7 @@ struct Slice {
 	DevBuf<DevReg> d_regs;
 	DevBuf<uint8_t> d_heavy;                      // chain-rich reads set aside by K2b: records (dev_types.h, HeavyCtl)
 	DevBuf<unsigned long long> d_heavy_reads, d_heavy_tasks;
+	DevBuf<int32_t> d_sext;                       // K1 -> K1c: the extends a read's passes 1 and 2 used (k_seed_p3.hip)
 	DevBuf<ExtTask> d_xtasks;                     // K2x: seed tasks of this pass, their results by record and chain, the flags that say which were computed,
 	DevBuf<ExtRes> d_xres;                        //      and [0] the task count, [1..3] the claim counters of the three launches (k_ext_lane.hip)
 	DevBuf<uint8_t> d_xvalid;
@@ -260,7 +265,7 @@ struct Slice {
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_long.release(); d_order.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
-		d_xtasks.release(); d_xres.release(); d_xvalid.release(); d_xctr.release();
+		d_xtasks.release(); d_xres.release(); d_xvalid.release(); d_xctr.release(); d_sext.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -391,6 +396,7 @@ struct ema_engine {
 	bool long_wave = false;              // EMA_SEED_LONG_WAVE=1: lean slices' reads over K1's extend budget are seeded by K1w in place (default: given to the full tier)
 	size_t long_cap = 0;                 // room of a lean slice's list of long reads
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
+	bool seed_split3 = true;             // tuning knob seed_split3=0: pass 3 inside K1's machine (round 4); 1: its own kernel behind K1 (k_seed_p3.hip)
 	bool ext_lane = false;               // tuning knob ext_lane=1: K2x (k_ext_lane.hip), the first seed of every handed-over chain extended one lane per seed.  Parity-green and OFF: measured slower (profiles/r05_k2x_profile.txt, DESIGN section 3 [r5])
 	unsigned long long *d_xprof = nullptr;      // tuning knob ext_lane_prof=1: K2x's counters (24 words)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
@@ -486,6 +492,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_cig_n.alloc(n_reads));
 	HIPCHK(e, s.d_kdone.alloc(n_reads));
 	HIPCHK(e, s.d_hand.alloc(n_reads * EMA_HAND_BYTES));
+	if (e->seed_split3) { HIPCHK(e, s.d_sext.alloc(n_reads + 1)); s.dopts.seed_ext = s.d_sext.p; s.dopts.seed_flags |= 8; }
 	if (e->ext_lane) {
 		HIPCHK(e, s.d_xtasks.alloc(n_reads * 3 + 1024)); HIPCHK(e, s.d_xres.alloc(n_reads * EMA_HAND_SEEDS + 8));
 		HIPCHK(e, s.d_xvalid.alloc(n_reads * EMA_HAND_SEEDS + 64)); HIPCHK(e, s.d_xctr.alloc(8));
@@ -724,6 +731,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = ema_tuning_get("merged_cand")) e->merged_cand_per_read = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("merged_cigar")) e->merged_cig_per_read = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("lane_align")) e->lane_align = atoi(v) != 0;
+	if (const char *v = ema_tuning_get("seed_split3")) e->seed_split3 = atoi(v) != 0;
 	if (const char *v = ema_tuning_get("ext_lane")) e->ext_lane = atoi(v) != 0;
 	if (!e->lane_align) e->ext_lane = false;
 	if (const char *v = ema_tuning_get("ext_lane_prof")) if (atoi(v) != 0 && !e->d_xprof) { HIPCHK(e, hipMalloc(&e->d_xprof, 24 * 8)); HIPCHK(e, hipMemset(e->d_xprof, 0, 24 * 8)); }
@@ -1013,6 +1021,14 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 		HIPCHK(e, hipGetLastError());
 	}
 	watchdog(e, s, "ema_k_seed");
+	if (ema_seed_splits_pass3(&s.dopts, e->d_prof.p)) {
+		// K1c: pass 3 of every read K1 finished, as a three-state machine of its own (k_seed_p3.hip) -- before K1w takes the reads over
+		// the lean budget, which it seeds from scratch, all three passes
+		ema_launch_seed_p3(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p, s.d_sext.p,
+		                   s.d_counters.p + 7, s.d_long.p, s.d_counters.p + 18, (int)(s.d_long.p ? e->long_cap : 0), e->n_cu * 4, s.stream);
+		HIPCHK(e, hipGetLastError());
+		watchdog(e, s, "ema_k_seed_p3");
+	}
 	if (s.d_long.p) {
 		// The reads over K1's extend budget -- a few per cent, the ones from repeats whose backward rows are long -- are seeded again by
 		// K1w, one wavefront per read (a row per step instead of an entry per tick), into the same slots: a lane machine working
@@ -1600,7 +1616,9 @@ int ema_engine_set_opts(ema_engine_t *e, const ema_engine_opts *o)
 	const DevOpts d = ema_make_dev_opts(n);
 	auto keep_caps = [&](DevOpts &dst) {
 		const int ic = dst.intv_cap, rc = dst.reg_cap, cc = dst.cig_cap, sb = dst.seed_budget;
+		int32_t *const ext = dst.seed_ext;      // (the slice's own array of K1 -> K1c: stays)
 		dst = d; dst.intv_cap = ic; dst.reg_cap = rc; dst.cig_cap = cc; dst.seed_budget = sb;
+		dst.seed_ext = ext; if (ext) dst.seed_flags |= 8;
 	};
 	keep_caps(e->dopts);
 	for (auto &s : e->sl) keep_caps(s.dopts);

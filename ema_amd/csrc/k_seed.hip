@@ -151,7 +151,9 @@ __device__ __forceinline__ uint32_t seed_rev_bits(uint32_t v)
 #ifndef EMA_SEED_WPS
 #define EMA_SEED_WPS 4      // [r4] the product build is held to four waves per SIMD (128 registers, nothing spilled); left alone it takes 135 since the anchors
 #endif
-template <bool PROF>      // PROF: the diagnostic build (tick statistics); the product build carries none of its registers
+// P3: pass 3 (bwt_seed_strategy1) is part of this machine.  [r5] The product runs it as a kernel of its own (k_seed_p3.hip: a forward-only
+// machine of three states whose tick costs a fifth of this one's) and launches the <.., false> build, which carries none of its states.
+template <bool PROF, bool P3>      // PROF: the diagnostic build (tick statistics); the product build carries none of its registers
 __global__ void __launch_bounds__(256, PROF ? 1 : EMA_SEED_WPS)
 ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv,
@@ -189,7 +191,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	size_t ld_at = 0;
 	const int kk = ix.kmer_k;        // 0: no table
 	const bool tails = kk > 0 && ix.text2 != nullptr;
-	const int jump = kk > 0 && opt.max_mem_intv > 0 ? (kk < opt.min_seed_len ? kk : opt.min_seed_len) : 0;      // pass 3's first look-up
+	const int jump = P3 && kk > 0 && opt.max_mem_intv > 0 ? (kk < opt.min_seed_len ? kk : opt.min_seed_len) : 0;      // pass 3's first look-up
 	const uint64_t n_text = (uint64_t)ix.l_pac << 1;
 	const bool wtest = kk > 0 && (opt.seed_flags & 1) && opt.min_seed_len >= 2 && opt.min_seed_len <= 32;      // pass 2's window test
 	const int wlen = opt.min_seed_len;
@@ -268,6 +270,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				pc = pass == 1 ? PC_P1_NEXT : PC_P2_NEXT;
 				break;
 			case PC_S3_RES:       // bwt_seed_strategy1, loop body after the extend
+				if (!P3) break;
 				if (r2 < (uint64_t)opt.max_mem_intv && i - x >= opt.min_seed_len) {
 					if (r2 > 0) { ev = 2; v0 = r0; v1 = r1; v2 = r2; v_start = (uint32_t)x; v_end = (uint32_t)(i + 1); }
 					x = i + 1; pc = PC_P3_NEXT;
@@ -382,6 +385,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			case PC_DONE:
 				if (read >= 0) {
 					n_intv[read] = n_out; status[read] = st;
+					if (!P3 && opt.seed_ext) opt.seed_ext[read] = n_ext;      // pass 3 follows in its own kernel: the budget runs on
 					if ((st & EMA_ST_LONG) && long_list) {      // over the extend budget: on the list K1w (one wavefront per read) works through next
 						const int at = atomicAdd(n_long, 1);
 						if (at < long_cap) long_list[at] = read;
@@ -453,6 +457,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				else { sm_x = x; min_intv = 1; start = true; }
 				break;
 			case PC_P3_NEXT:      // pass 3: LAST-like seeds
+				if (!P3) break;
 				while (x < len && q(x) > 3) ++x;
 				if (x >= len) { pc = PC_DONE; break; }
 				if (jump > 0) {      // the first `jump` bases in one look-up (see the header)
@@ -480,7 +485,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				break;
 			}
 			if (pc == PC_P2_NEXT) {      // pass 2: fetch the next pass-1 SMEM; examined (PC_P2_RES) once loaded
-				if (k2 >= old_n) { pass = 3; x = 0; pc = opt.max_mem_intv > 0 ? PC_P3_NEXT : PC_DONE; }
+				if (k2 >= old_n) { pass = 3; x = 0; pc = (P3 && opt.max_mem_intv > 0) ? PC_P3_NEXT : PC_DONE; }
 				else { ld_at = out_base + k2; ld_kind = 2; ++k2; pc = PC_P2_RES; }
 			}
 			// (6) start of an SMEM search at sm_x (bwt_smem1 with min_intv)
@@ -502,7 +507,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			}
 			else if (pc == PC_TXT) { has_req = 4; pc = PC_TXT_RES; }
 			else if (pc == PC_AB) { has_req = 5; pc = PC_AB_RES; }
-			else if (pc == PC_FWD || pc == PC_BWD || pc == PC_S3) {
+			else if (pc == PC_FWD || pc == PC_BWD || (P3 && pc == PC_S3)) {
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
 				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
 				else if (b < 4 && tails && pc == PC_FWD && c2 == 1 && i - sm_x > kk) { has_req = 3; pc = PC_TSA_RES; }      // a tail begins
@@ -692,15 +697,25 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, const int *order, int n_blocks,
                                 hipStream_t stream, unsigned long long *prof)
 {
+	// (seed_flags bit 3 with a seed_ext array: pass 3 is k_seed_p3.hip's; the diagnostic build keeps it, and its statistics, in one machine)
+	const bool split3 = (opt->seed_flags & 8) && opt->seed_ext != nullptr && !prof;
+	DevOpts o = *opt;
+	if (!split3) o.seed_ext = nullptr;
 	if (prof)
-		hipLaunchKernelGGL(ema_k_seed_t<true>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
+		hipLaunchKernelGGL((ema_k_seed_t<true, true>), dim3(n_blocks), dim3(256), 0, stream, *ix, o, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
+		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, long_list, n_long,
+		                   long_cap, order, prof);
+	else if (split3)
+		hipLaunchKernelGGL((ema_k_seed_t<false, false>), dim3(n_blocks), dim3(256), 0, stream, *ix, o, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
 		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, long_list, n_long,
 		                   long_cap, order, prof);
 	else
-		hipLaunchKernelGGL(ema_k_seed_t<false>, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
+		hipLaunchKernelGGL((ema_k_seed_t<false, true>), dim3(n_blocks), dim3(256), 0, stream, *ix, o, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv,
 		                   status, lists, counter, (const SeedPark *)park_in, n_park_in, (SeedPark *)park_out, n_park_out, park_max, long_list, n_long,
 		                   long_cap, order, prof);
 }
+// does this launch of the series leave pass 3 to k_seed_p3.hip?  (the engine asks, so that both decide alike)
+extern "C" int ema_seed_splits_pass3(const DevOpts *opt, const unsigned long long *prof) { return (opt->seed_flags & 8) && opt->seed_ext != nullptr && !prof; }
 
 // The order in which K1 takes a slice's reads: the ones expected to be LONG first.  A launch series is as long as its bulk plus
 // the tail of the last long reads -- a read from a repeat family needs 2,000-4,000 dependent ticks, and one that comes up when the
@@ -752,6 +767,6 @@ extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack,
 extern "C" int ema_seed_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_seed_t<false>, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_seed_t<false, true>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

@@ -22,7 +22,8 @@ inline DevOpts ema_make_dev_opts(const ema_engine_opts &o)
 		v = ema_tuning_get("seed_anchor"); const int f1 = (v && atoi(v) == 0) ? 0 : 2;
 		v = ema_tuning_get("seed_onepass"); const int f2 = (v && atoi(v) == 0) ? 0 : 4;
 		d.seed_flags = f0 | f1 | f2;
-	}      // (the switch exists for A/B runs and for the parity tests of both routes)
+	}
+	d.seed_ext = nullptr;      // (bit 3 of seed_flags and this array: set per slice by the engine, engine.hip slice_alloc)      // (the switch exists for A/B runs and for the parity tests of both routes)
 	int k = 0;
 	for (int i = 0; i < 4; ++i) {
 		for (int j = 0; j < 4; ++j) d.mat[k++] = (int8_t)(i == j ? o.a : -o.b);

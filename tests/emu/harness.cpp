@@ -16,6 +16,7 @@ const char *ema_tuning_get(const char *key)
 // kernels + launchers, compiled as plain C++
 #include "k_kmer.hip"
 #include "k_seed.hip"
+#include "k_seed_p3.hip"
 #include "k_seed_wave.hip"
 #include "k_dp_test.hip"
 #include "k_align.hip"
@@ -34,7 +35,19 @@ static DevOpts emu_dev_opts(const ema_engine_opts &o_in)
 	if (const char *v = getenv("EMU_MIN_SEED_LEN")) o.min_seed_len = atoi(v);      // (bwa's -k, for the seeding shortcuts that depend on it)
 	DevOpts d = ema_make_dev_opts(o);
 	d.intv_cap = EMU_INTV_CAP; d.reg_cap = EMU_REG_CAP; d.cig_cap = EMU_CIG_CAP;
+	// pass 3 as its own kernel behind K1 (k_seed_p3.hip), as the product runs it; EMU_SEED_SPLIT3=0: inside K1's machine
+	static std::vector<int32_t> ext;
+	const char *sp = getenv("EMU_SEED_SPLIT3");
+	if (!sp || atoi(sp) != 0) { ext.assign(1 << 20, 0); d.seed_flags |= 8; d.seed_ext = ext.data(); }
 	return d;
+}
+// K1c behind a K1 launch (series) of the harness
+static void emu_seed_p3(const DevIndex &di, const DevOpts &d, const uint32_t *qp, const uint32_t *off, int n_reads, const int *n_dev, const int *map,
+                        Intv *intv, int *n_intv, int *status, int n_blocks)
+{
+	if (!ema_seed_splits_pass3(&d, nullptr)) return;
+	int ctr = 0;
+	ema_launch_seed_p3(&di, &d, qp, off, n_reads, n_dev, map, intv, n_intv, status, d.seed_ext, &ctr, nullptr, nullptr, 0, n_blocks, nullptr);
 }
 
 static std::vector<uint32_t> pack_reads(const uint8_t *bases, const uint32_t *off, int n_reads)
@@ -183,6 +196,7 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 			                last ? 0 : park_max, nullptr, nullptr, 0, emu_order.empty() ? nullptr : emu_order.data(), nb, nullptr, nullptr);
 			fprintf(stderr, "emu_seed round %d: parked %d\n", r, last ? 0 : n_park[out]);
 		}
+		emu_seed_p3(di, d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, nb);
 	}
 	for (int r = 0; r < n_reads; ++r) {
 		Intv *a = (Intv *)intv + (size_t)r * EMU_INTV_CAP;
@@ -247,6 +261,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
 	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
+	emu_seed_p3(di, d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, 1);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
 	emu_run_align(di, d, bases, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), (DevReg *)regs, n_regs, status, slabs.data(), n_blocks);
@@ -292,6 +307,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
 	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
+	emu_seed_p3(di, d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, 1);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
@@ -341,6 +357,7 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[4] = {0, 0, 0, 0};
 	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
+	emu_seed_p3(di, d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), 1);
 	emu_run_align(di, d, bases, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(), t.status.data(),
 	              slabs.data(), 1);
 	std::vector<int> ptodo(n_pairs + 1); int n_ptodo = 0;

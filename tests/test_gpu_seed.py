@@ -134,3 +134,36 @@ def test_seed_parity_one_control_pass_per_tick_and_parking(onepass, park, rounds
     tuning(seed_onepass=onepass, seed_park=park, seed_rounds=rounds)
     _check("repeats", 700, 36, "lane", tuning, sub_rate=0.01, n_rate=0.004)
     _check("two_contigs", 300, 37, "lane", tuning, len1=250, len2=250, n_rate=0.01)
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("k", ["", "0", "5", "11"])
+def test_seed_parity_pass_3_in_its_own_kernel_and_inside_k1(k, split, tuning):
+    """Pass 3 (bwt_seed_strategy1, the LAST-like seeds) runs as a kernel of its own behind K1 (k_seed_p3.hip, the default) or inside
+    K1's machine (tuning knob seed_split3=0, round 4's form): the same interval sets either way, with and without the k-mer table
+    (the jump over a seed's first bases, the reverse-complement entry at the table's last level), ambiguous bases (starts moved
+    behind them), repeat-rich reads (seeds that reach max_mem_intv late), 250 bp, other minimum seed lengths."""
+    tuning(seed_split3=split)
+    if k:
+        tuning(kmer_k=k)
+    _check("repeats", 500, 41, "lane", tuning, sub_rate=0.01, n_rate=0.004)
+    _check("ngaps", 300, 42, "lane", tuning, n_rate=0.02)
+    _check("two_contigs", 200, 43, "lane", tuning, len1=250, len2=250, sub_rate=0.003)
+    _check("repeats", 300, 44, "lane", tuning, min_seed_len=12, sub_rate=0.01)
+    _check("repeats", 300, 45, "lane", tuning, min_seed_len=25, sub_rate=0.01)
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_lean_budget_runs_on_across_the_passes(split, tuning):
+    """The lean tier's extend budget counts all three passes: with pass 3 in its own kernel the count K1 reached travels with the read
+    (DevOpts::seed_ext), so a read over the budget in pass 3 is given up there and redone by the full-capacity tier -- the whole
+    path against the oracle with a budget that about half the reads exceed, some of them only in pass 3."""
+    import test_gpu_pipeline as TP
+    from ema_amd.engine import default_opts
+    tuning(seed_split3=split)
+    o = default_opts()
+    o.lean_seed_extends = 300
+    TP._check("repeats", 500, 46, eopts=o, sub_rate=0.01)
+    o2 = default_opts()
+    o2.lean_seed_extends = 120
+    TP._check("two_contigs", 300, 47, eopts=o2)

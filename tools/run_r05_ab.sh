@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev aid: bench.py (20 steps, kernels + delivery only) over a set of engine builds on ONE GPU box, so that the numbers compare.
-#   gpurun --timeout 2400 -- 'bash tools/run_r05_ab.sh tag "" chainlds k4t3 ...'      ("" = the product build libema_engine.so)
+#   gpurun --timeout 2400 -- 'bash tools/run_r05_ab.sh tag "" chainlds tune:seed_split3=0 ...'      ("" = the product build libema_engine.so; tune:k=v = it with EMA_TUNING)
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
@@ -9,7 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   name=${v:-product}
   lib=libema_engine${v:+_$v}.so
-  EMA_ENGINE_LIB=$lib timeout 600 python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-sam-leg > "$out/bench_$name.json" 2> "$out/bench_$name.err"
+  tune=
+  if [[ $v == tune:* ]]; then tune=${v#tune:}; lib=libema_engine.so; name=${tune//[=,]/_}; fi      # "tune:seed_split3=0": the product build with a tuning string
+  EMA_TUNING=$tune EMA_ENGINE_LIB=$lib timeout 600 python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-sam-leg > "$out/bench_$name.json" 2> "$out/bench_$name.err"
   echo "$name rc=$?"
   python3 - "$out/bench_$name.json" <<'PY'
 import json, sys

@@ -15,7 +15,8 @@ HIPCC = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shut
 LEAN = {
     "k_align_lane.hip": ["ema_k_align_simple_t<false>"],
     "k_final.hip": ["ema_k_final_t<0>"],
-    "k_seed.hip": ["ema_k_seed_t<false>"],      # (the diagnostic build <true> carries its tick counters in registers: 132)
+    "k_seed.hip": ["ema_k_seed_t<false, false>", "ema_k_seed_t<false, true>"],      # (product: without pass 3 [r5] / with it; the diagnostic build <true, true> carries its tick counters in registers)
+    "k_seed_p3.hip": ["ema_k_seed_p3"],
 }
 
 

@@ -516,15 +516,20 @@ def main(argv=None):
     # Two of the timed steps are checked in depth: EVERY pair the full-capacity tier redid and thousands of regular ones.
     rng = np.random.default_rng(12345 + rank)
     kept = []
-    deep_steps = {0, 1} if args.steps >= 2 else {0}
-    deep_regular = max(24, args.spot_check // (2 * len(deep_steps)))
+    # [r5] The in-depth part of the check -- EVERY pair the full-capacity tier redid and thousands of regular ones, of two batches --
+    # is taken from two EXTRA passes over batches 0 and 1 right after the clock stops (same engine, same path, same input slots):
+    # inside the timed region it was ~0.1 s of the checker's copying in the stream's delivery thread, i.e. up to 5 ms per step at 20
+    # steps of measurement overhead in `value`.  Every TIMED step is still sampled (48 pairs: 24 regular + 24 of the full tier's).
+    deep = {"steps": set()}
+    n_deep = 2 if args.steps >= 2 else 1
+    deep_regular = max(24, args.spot_check // (2 * n_deep))
 
     def keep_sample(k, pb, n_reg, n_full):
         ob = pb.contents
         n = int(ob.n_pairs)
         nr = int(ob.n_redone)
         redone = np.ctypeslib.as_array(ob.redone, shape=(max(nr, 1),))[:nr].astype(np.int64)
-        if k in deep_steps:
+        if k in deep["steps"]:
             n_reg, pick = deep_regular, redone
         else:
             pick = redone[rng.integers(0, nr, min(n_full, nr))] if nr else redone
@@ -570,6 +575,11 @@ def main(argv=None):
     sync_all()
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    n_kept_timed = len(kept)
+    deep["steps"] = set(range(n_deep))      # (the two passes below are sampled in depth)
+    stream.stream_resident(eng, offs[:n_deep], slots, opts=so, raw_sink=make_sink(True))
+    sync_all()
+    deep["steps"] = set()
     host_cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)      # this rank's host threads over the timed region
     host_cpu_s = max(0.0, host_cpu_s - sink_cpu[0])      # ... without the spot check's sampling in the sink (the checker, not the product)
     if use_dist:
@@ -644,8 +654,10 @@ def main(argv=None):
         import oracle_lib as O
         idx, opt = O.Index(prefix), O.default_opt()
         t = time.time()
-        n_checked = n_checked_full = 0
-        for b, ids, cand, pool, read_off, n_full in kept:
+        n_checked = n_checked_full = n_checked_timed = 0
+        for i_kept, (b, ids, cand, pool, read_off, n_full) in enumerate(kept):
+            if i_kept < n_kept_timed:
+                n_checked_timed += len(ids)
             sub = batches[b].take(ids)
             want, _secs = O.digest_pairs(idx, opt, sub.bases, sub.off, node_cpus)
             got = O.cand_digest(cand, pool, read_off)
@@ -657,7 +669,7 @@ def main(argv=None):
                 log(f"MISMATCH batch {b} pair {p} mate {m + 1}: engine {[(int(c['rb']), int(c['re']), int(c['score']), int(c['pos']), int(c['NM'])) for c in mine[:3]]} "
                     f"oracle {[(d['rb'], d['re'], d['score'], d['pos'], d['NM']) for d in ref[:3]]}")
             bad += int((got != want).sum())
-        log(f"[rank 0] oracle spot check: {n_checked} pairs of the timed steps, {n_checked_full} of them through the full-capacity tier "
+        log(f"[rank 0] oracle spot check: {n_checked} pairs ({n_checked_timed} of the timed steps, the others of two passes over batches 0 and 1 right after them), {n_checked_full} of them through the full-capacity tier "
             f"({bad} reads differ) {time.time() - t:.1f}s on {node_cpus} threads")
     bad = int(agree(float(bad), "max"))
     if bad:
@@ -783,7 +795,7 @@ def main(argv=None):
             "roofline": roofline, "roofline_k2b": roofline_k2b, "cpu_baseline": cpu,
             "bucket_stats": {f: int(gathered[:, i].sum()) for i, f in enumerate(shard.STAT_FIELDS)},
         }
-        out["bucket_stats"].update(capacity_flags=int(any_flag), oracle_spot_check_pairs=int(n_checked), oracle_spot_check_full_tier_pairs=int(n_checked_full),
+        out["bucket_stats"].update(capacity_flags=int(any_flag), oracle_spot_check_pairs=int(n_checked), oracle_spot_check_pairs_of_timed_steps=int(n_checked_timed), oracle_spot_check_full_tier_pairs=int(n_checked_full),
                                    oracle_spot_check_mismatches=int(bad))
         # What the host costs, and what that predicts for N ranks on this node's CPU grant: every rank needs its own host threads for
         # fetch assembly and the append stage, and the node grants the job a fixed number of CPUs whatever N is.

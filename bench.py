@@ -365,6 +365,14 @@ def main(argv=None):
     # --dist-at-world-1: the distributed control flow (process group, barriers, agree() all-reduces, the statistics all-gather on the
     # device) also at world size 1 -- what a one-GPU box can run of it on hardware (tests/test_gpu_bench_dist.py)
     use_dist = world > 1 or args.dist_at_world_1
+    if args.dist_at_world_1 and "RANK" not in os.environ:      # (without a launcher: a rendezvous of one on this host)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            free_port = sk.getsockname()[1]
+        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port))
     if world > 1 and "EMA_HOST_THREADS" not in os.environ:
         os.environ["EMA_HOST_THREADS"] = str(host_threads_for_rank(node_cpus, world))
     dist = None

@@ -458,6 +458,14 @@ def main(argv=None):
     if args.two_sets:
         n_batches += n_batches & 1      # alternate batches on alternate sets of batch buffers: the same number on each
     batches = make_batches(args, rank, world, workdir, n_batches)
+    if rank == 0:
+        # The reference, its index (60 GB at the default scale) and the batches may just have been WRITTEN: let the kernel finish writing
+        # them back before anything is timed -- the timed region's host side (page-locked downloads, the append stage's threads) shares
+        # the box's memory system with that I/O, and the first run on a fresh box was the slow one in three of four calls of round 5
+        # (150-158 ms per step against 142-146 for the same kernels, `profiles/r05_ab.txt`).  Outside every timed region.
+        t_sync = time.time()
+        os.sync()
+        log(f"[rank 0] sync of the files written before the timed legs: {time.time() - t_sync:.1f}s")
 
     import importlib
     stream = importlib.import_module(args.engine_module + ".stream")
@@ -714,10 +722,12 @@ def main(argv=None):
                 traffic_stale = open(os.path.join(ROOT, "profiles", pmc_name + ".srchash")).read().split()[0] != kernel_sources_hash()
             except (OSError, IndexError):
                 traffic_stale = True
-        k1_name = next((k for k in ("ema_k_seed_t<false>", "ema_k_seed") if tab and (k, "FETCH_SIZE") in tab and (k, "WRITE_SIZE") in tab), None)
-        if k1_name:      # (the product build of the template, or the plain kernel of older profiles)
+        k1_name = next((k for k in ("ema_k_seed_t<false;false>", "ema_k_seed_t<false>", "ema_k_seed") if tab and (k, "FETCH_SIZE") in tab and (k, "WRITE_SIZE") in tab), None)
+        if k1_name:      # (the product build of the template -- [r5] without pass 3 -- or the plain kernel of older profiles)
             series = eng.seed_launches_per_series()
             kb = sum(tab[(k1_name, c)][0] / (tab[(k1_name, c)][1] / series) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+            if k1_name == "ema_k_seed_t<false;false>" and ("ema_k_seed_p3", "FETCH_SIZE") in tab:      # [r5] pass 3's own kernel, one launch behind every series: part of the same interval of HIP events
+                kb += sum(tab[("ema_k_seed_p3", c)][0] / tab[("ema_k_seed_p3", c)][1] for c in ("FETCH_SIZE", "WRITE_SIZE") if ("ema_k_seed_p3", c) in tab)
             traffic = int(kb * 1024)
             traffic_source = f"profiles/{pmc_name} (separate FETCH_SIZE and WRITE_SIZE passes of this command; stored, not measured in this run)"
         roofline = {"bound": "hbm", "kernel": "ema_k_seed", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

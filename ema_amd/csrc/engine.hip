@@ -396,6 +396,7 @@ struct ema_engine {
 	bool long_wave = false;              // EMA_SEED_LONG_WAVE=1: lean slices' reads over K1's extend budget are seeded by K1w in place (default: given to the full tier)
 	size_t long_cap = 0;                 // room of a lean slice's list of long reads
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
+	int seed_p3_blocks = 4;              // K1c's grid: 256-thread blocks per CU (tuning knob seed_p3_blocks_per_cu)
 	bool seed_split3 = true;             // tuning knob seed_split3=0: pass 3 inside K1's machine (round 4); 1: its own kernel behind K1 (k_seed_p3.hip)
 	bool ext_lane = false;               // tuning knob ext_lane=1: K2x (k_ext_lane.hip), the first seed of every handed-over chain extended one lane per seed.  Parity-green and OFF: measured slower (profiles/r05_k2x_profile.txt, DESIGN section 3 [r5])
 	unsigned long long *d_xprof = nullptr;      // tuning knob ext_lane_prof=1: K2x's counters (24 words)
@@ -732,6 +733,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = ema_tuning_get("merged_cigar")) e->merged_cig_per_read = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("lane_align")) e->lane_align = atoi(v) != 0;
 	if (const char *v = ema_tuning_get("seed_split3")) e->seed_split3 = atoi(v) != 0;
+	if (const char *v = ema_tuning_get("seed_p3_blocks_per_cu")) e->seed_p3_blocks = std::max(1, std::min(6, atoi(v)));
 	if (const char *v = ema_tuning_get("ext_lane")) e->ext_lane = atoi(v) != 0;
 	if (!e->lane_align) e->ext_lane = false;
 	if (const char *v = ema_tuning_get("ext_lane_prof")) if (atoi(v) != 0 && !e->d_xprof) { HIPCHK(e, hipMalloc(&e->d_xprof, 24 * 8)); HIPCHK(e, hipMemset(e->d_xprof, 0, 24 * 8)); }
@@ -1025,7 +1027,7 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 		// K1c: pass 3 of every read K1 finished, as a three-state machine of its own (k_seed_p3.hip) -- before K1w takes the reads over
 		// the lean budget, which it seeds from scratch, all three passes
 		ema_launch_seed_p3(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p, s.d_sext.p,
-		                   s.d_counters.p + 7, s.d_long.p, s.d_counters.p + 18, (int)(s.d_long.p ? e->long_cap : 0), e->n_cu * 4, s.stream);
+		                   s.d_counters.p + 7, s.d_long.p, s.d_counters.p + 18, (int)(s.d_long.p ? e->long_cap : 0), e->n_cu * e->seed_p3_blocks, s.stream);
 		HIPCHK(e, hipGetLastError());
 		watchdog(e, s, "ema_k_seed_p3");
 	}

@@ -557,9 +557,13 @@ def main(argv=None):
 
     sink_cpu = [0.0]      # CPU seconds of the checker's own sampling inside the sink (not the product's: reported apart)
 
+    step_done = []       # when the sink saw each step's results (timed region only): the spread shows a hiccup where it happened
+
     def make_sink(sample):
         def cb(_user, k, _pbk, pb, _pa):
             try:
+                if sample and not deep["steps"]:
+                    step_done.append(time.perf_counter())
                 if sample:
                     t_ = time.thread_time()
                     keep_sample(int(k), pb, 24, 24)
@@ -592,6 +596,9 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     n_kept_timed = len(kept)
+    gaps = np.diff(np.array([t0] + step_done[:args.steps])) * 1e3
+    step_gaps = None if len(gaps) < 2 else {"first": round(float(gaps[0]), 1), "median": round(float(np.median(gaps[1:])), 1),
+                                            "max": round(float(gaps[1:].max()), 1), "max_at_step": int(np.argmax(gaps[1:])) + 1}
     deep["steps"] = set(range(n_deep))      # (the two passes below are sampled in depth)
     stream.stream_resident(eng, offs[:n_deep], slots, opts=so, raw_sink=make_sink(True))
     sync_all()
@@ -808,7 +815,8 @@ def main(argv=None):
                                   "page-locked batch sets exist before the clock starts; host CPU figures leave out the bench's own spot-check "
                                   "sampling (host.spot_check_sampling_cpu_s_excluded); the spot check covers rank 0's kept samples -- r04+ figures "
                                   "are not directly comparable with BENCH_r01-r03",
-                                  "cold_first_pass_s": None if cold_first_pass_s is None else round(cold_first_pass_s, 3)}},
+                                  "cold_first_pass_s": None if cold_first_pass_s is None else round(cold_first_pass_s, 3),
+                                  "ms_between_steps_reaching_the_sink": step_gaps}},
             "boundary": boundary, "engine_resident": resident,
             "roofline": roofline, "roofline_k2b": roofline_k2b, "cpu_baseline": cpu,
             "bucket_stats": {f: int(gathered[:, i].sum()) for i, f in enumerate(shard.STAT_FIELDS)},

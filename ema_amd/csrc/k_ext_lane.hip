@@ -69,7 +69,7 @@ ema_k_ext_lane(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, cons
 	const int mxsc = opt.a > 0 ? opt.a : 0;
 	const int64_t l_pac = ix.l_pac;
 	const unsigned long long t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
-	unsigned long long n_rowsteps = 0, n_lanerows = 0, n_cells = 0, n_cellsteps = 0, n_done = 0, n_dp = 0;
+	unsigned long long n_rowsteps = 0, n_lanerows = 0, n_cells = 0, n_done = 0, n_dp = 0;
 
 	// per-lane task state
 	bool active = false;       // a DP side is running
@@ -339,10 +339,6 @@ ema_k_ext_lane(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, cons
 			}
 			if (stop) { active = false; pending = 4; }
 		}
-		if (prof) {
-			// (the widest band of the row-step: what it cost)
-			int width = active || pending == 4 ? 1 : 0; (void)width;
-		}
 	}
 	if (prof && lane == 0) {
 		atomicAdd(prof + 0, __builtin_amdgcn_s_memtime() - t_start); atomicAdd(prof + 1, 1ULL); atomicAdd(prof + 2, n_rowsteps); atomicAdd(prof + 3, n_lanerows);
@@ -352,7 +348,6 @@ ema_k_ext_lane(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, cons
 		for (int mm = 1; mm < 64; mm <<= 1) { c += __shfl_xor(c, mm); d += __shfl_xor(d, mm); p += __shfl_xor(p, mm); }
 		if (lane == 0) { atomicAdd(prof + 4, c); atomicAdd(prof + 5, d); atomicAdd(prof + 6, p); }
 	}
-	(void)n_cellsteps;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -381,8 +376,6 @@ ema_k_ext_plan_hand(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ hand, 
 #pragma unroll
 		for (int k = 0; k < EMA_HAND_SEEDS / 8; ++k) v[k] = 0;
 	}
-	const int n_round = __builtin_amdgcn_readlane(0, 0);      // (keeps the loop bound below wave-uniform for the interpreter)
-	(void)n_round;
 	int cmax = live ? hd.n_chn : 0;
 	for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(cmax, m); cmax = cmax > o ? cmax : o; }
 	for (int cs = 0; cs < cmax; ++cs) {

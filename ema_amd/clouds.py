@@ -14,7 +14,7 @@ from . import sam as _sam
 
 class CloudOpts(C.Structure):
     _fields_ = [("dist_thresh", C.c_uint32), ("many_clouds", C.c_int32), ("n_threads", C.c_int32), ("first_cloud_id", C.c_int32),
-                ("density_opt", C.c_int32), ("n_density_probs", C.c_int32), ("density_probs", C.c_double * 16)]
+                ("density_opt", C.c_int32), ("n_density_probs", C.c_int32), ("density_probs", C.c_double * 16), ("emit", C.c_int32), ("pad_", C.c_int32)]
 
 
 class SamStats(C.Structure):
@@ -30,7 +30,9 @@ class SamStats(C.Structure):
 
 class CloudsOut(C.Structure):
     _fields_ = [("n_lines", C.c_size_t), ("lines", C.POINTER(_sam.SamLine)), ("n_recs", C.c_size_t), ("recs", C.POINTER(_sam.SamRec)),
-                ("alts", C.POINTER(_sam.SamAlt)), ("idents", C.c_void_p), ("next_cloud_id", C.c_int32), ("stats", SamStats)]
+                ("alts", C.POINTER(_sam.SamAlt)), ("idents", C.c_void_p), ("next_cloud_id", C.c_int32), ("stats", SamStats),
+                ("n_descs", C.c_size_t), ("n_xas", C.c_size_t), ("n_sel", C.c_size_t), ("descs", C.c_void_p), ("xas", C.c_void_p), ("sel_at", C.c_void_p),
+                ("cigar_lo", C.c_uint64), ("cigar_hi", C.c_uint64)]
 
 
 def _lib():
@@ -64,6 +66,10 @@ class Selection:
         self._p, self._keep = ptr, keep
         o = ptr.contents
         self.lines, self.n_lines, self.n_recs = o.lines, int(o.n_lines), int(o.n_recs)
+        # the compact form (opts.emit 1 / 2): ema_sam_desc[], ema_sam_xa[], first descriptor of every selected pair, the CIGAR range
+        self.descs, self.xas, self.sel_at = o.descs, o.xas, o.sel_at
+        self.n_descs, self.n_xas, self.n_sel = int(o.n_descs), int(o.n_xas), int(o.n_sel)
+        self.cigar_lo, self.cigar_hi = int(o.cigar_lo), int(o.cigar_hi)
         self.next_cloud_id = int(o.next_cloud_id)
         self.stats = o.stats.as_dict()
 
@@ -137,4 +143,6 @@ def select(bucket, batch, rec, pair_off, contig_names, opts: CloudOpts | None = 
             L.ema_clouds_free(p)
         raise RuntimeError(f"ema_clouds_select failed ({rc})")
     keep += [bk, b, a]
-    return Selection(p, keep)
+    sel = Selection(p, keep)
+    sel.bk, sel.b = bk, b      # (the bucket and the batch as the C structs: the device formatter's other inputs)
+    return sel

@@ -1533,6 +1533,7 @@ int ema_engine_sync(ema_engine_t *e)
 }
 
 int ema_engine_n_streams(const ema_engine_t *e) { return e ? (int)e->sl.size() : 0; }
+int ema_engine_device(const ema_engine_t *e) { return e ? e->device : -1; }
 int ema_engine_seed_launches(const ema_engine_t *e) { return e ? e->seed_rounds : 0; }
 
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t)

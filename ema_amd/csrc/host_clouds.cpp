@@ -22,6 +22,7 @@
 #include <vector>
 #include "ema_clouds.h"
 #include "host_cpuacct.h"
+#include "host_fmt.h"
 #include "host_pool.h"
 
 namespace {
@@ -541,7 +542,7 @@ void ema_cloud_opts_default(ema_cloud_opts *o)
 {
 	if (!o) return;
 	o->dist_thresh = 50000; o->many_clouds = 0; o->n_threads = 0; o->first_cloud_id = 0;
-	o->density_opt = 0; o->n_density_probs = 4;
+	o->density_opt = 0; o->n_density_probs = 4; o->emit = 0; o->pad_ = 0;
 	for (double &p : o->density_probs) p = 0;
 	o->density_probs[0] = 0.6; o->density_probs[1] = 0.05; o->density_probs[2] = 0.2; o->density_probs[3] = 0.01;      // src/techs.c: every platform but cpt
 }
@@ -556,6 +557,7 @@ void ema_clouds_free(ema_clouds_out *out)
 {
 	if (!out) return;
 	free(out->lines); free(out->recs); free(out->alts); free(out->idents);
+	free(out->descs); free(out->xas); free(out->sel_at);
 	free(out);
 }
 
@@ -602,113 +604,179 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 	// and lines follow from the per-group counts, so groups are laid out independently
 	ema_clouds_out *o = (ema_clouds_out *)calloc(1, sizeof(ema_clouds_out));
 	if (!o) return EMA_EARG;
+	const bool want_lines = S.o.emit != 1, want_descs = S.o.emit >= 1;
 	std::vector<int32_t> cloud_base(n_groups + 1);
-	std::vector<size_t> rec_base(n_groups + 1), line_base(n_groups + 1);
+	std::vector<size_t> rec_base(n_groups + 1), line_base(n_groups + 1), xa_base(n_groups + 1);
 	int32_t next_id = S.o.first_cloud_id;
-	size_t n_sel = 0, n_recs = 0;
+	size_t n_sel = 0, n_recs = 0, n_xas = 0;
 	for (size_t g = 0; g < n_groups; ++g) {
 		cloud_base[g] = next_id;
 		next_id += (int32_t)S.n_clouds[g];
-		rec_base[g] = n_recs; line_base[g] = 2 * n_sel;
+		rec_base[g] = n_recs; line_base[g] = 2 * n_sel; xa_base[g] = n_xas;
 		const uint64_t r0 = a->pair_off[bk->group_off[g]];
-		for (uint32_t k = 0; k < S.n_sel[g]; ++k) n_recs += S.sel[r0 + k].mate != ~(uint64_t)0 ? 2 : 1;
+		for (uint32_t k = 0; k < S.n_sel[g]; ++k) {
+			const Sel &sl = S.sel[r0 + k];
+			n_recs += sl.mate != ~(uint64_t)0 ? 2 : 1;
+			if (want_descs) n_xas += (size_t)(S.alt_of[sl.rec] >= 0) + (size_t)(sl.mate != ~(uint64_t)0 && S.alt_of[sl.mate] >= 0);
+		}
 		n_sel += S.n_sel[g];
 		if (S.n_clouds[g]) ++o->stats.groups;
 		o->stats.clouds += S.n_clouds[g]; o->stats.bad_clouds += S.n_bad[g];
 	}
-	rec_base[n_groups] = n_recs; line_base[n_groups] = 2 * n_sel;
+	rec_base[n_groups] = n_recs; line_base[n_groups] = 2 * n_sel; xa_base[n_groups] = n_xas;
 	o->next_cloud_id = next_id;
-	o->n_lines = 2 * n_sel;
-	o->n_recs = n_recs;
-	o->lines = (ema_sam_line *)malloc((2 * n_sel + 1) * sizeof(ema_sam_line));
-	o->recs = (ema_sam_rec *)malloc((2 * n_sel + 1) * sizeof(ema_sam_rec));
-	o->alts = (ema_sam_alt *)malloc((2 * n_sel + 1) * sizeof(ema_sam_alt));
-	std::vector<size_t> ident_at(bk->n_pairs + 1);
-	size_t id_bytes = 0;
-	for (size_t p = 0; p < bk->n_pairs; ++p) {      // names without the first character ('@'), NUL-terminated
-		const uint32_t ib = bk->id_off[p], ie = bk->id_off[p + 1];
-		ident_at[p] = id_bytes;
-		id_bytes += (size_t)(ie > ib ? ie - ib - 1 : 0) + 1;
+	std::vector<size_t> ident_at;
+	if (want_lines) {
+		o->n_lines = 2 * n_sel;
+		o->n_recs = n_recs;
+		o->lines = (ema_sam_line *)malloc((2 * n_sel + 1) * sizeof(ema_sam_line));
+		o->recs = (ema_sam_rec *)malloc((2 * n_sel + 1) * sizeof(ema_sam_rec));
+		o->alts = (ema_sam_alt *)malloc((2 * n_sel + 1) * sizeof(ema_sam_alt));
+		ident_at.resize(bk->n_pairs + 1);
+		size_t id_bytes = 0;
+		for (size_t p = 0; p < bk->n_pairs; ++p) {      // names without the first character ('@'), NUL-terminated
+			const uint32_t ib = bk->id_off[p], ie = bk->id_off[p + 1];
+			ident_at[p] = id_bytes;
+			id_bytes += (size_t)(ie > ib ? ie - ib - 1 : 0) + 1;
+		}
+		o->idents = (char *)malloc(id_bytes + 1);
+		if (!o->lines || !o->recs || !o->alts || !o->idents) { ema_clouds_free(o); return EMA_EARG; }
 	}
-	o->idents = (char *)malloc(id_bytes + 1);
-	if (!o->lines || !o->recs || !o->alts || !o->idents) { ema_clouds_free(o); return EMA_EARG; }
+	if (want_descs) {      // the compact form (include/ema_sam.h): indices into the bucket and the batch instead of pointers
+		o->n_descs = n_recs; o->n_xas = n_xas; o->n_sel = n_sel;
+		o->descs = (ema_sam_desc *)malloc((n_recs + 1) * sizeof(ema_sam_desc));
+		o->xas = (ema_sam_xa *)malloc((n_xas + 1) * sizeof(ema_sam_xa));
+		o->sel_at = (uint32_t *)malloc((n_sel + 1) * sizeof(uint32_t));
+		if (!o->descs || !o->xas || !o->sel_at || n_recs >= 0xffffffffu) { ema_clouds_free(o); return EMA_EARG; }
+	}
 	std::atomic<int> rc_all{EMA_OK};
 	const int nt_asm = (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 64 + 1);
 	std::vector<ema_sam_stats> part((size_t)nt_asm);
+	std::vector<uint64_t> cig_lo((size_t)nt_asm, ~(uint64_t)0), cig_hi((size_t)nt_asm, 0);
 	for (auto &ps : part) memset(&ps, 0, sizeof(ps));
+	// one selected record as the statistics see it (what print_sam_record flags and prints of it, src/samrecord.c:104-175)
+	struct Brief { uint32_t rid, pos; int mapq; bool rev, dup, xa; };
 	auto assemble = [&](int tid) {
 		EMA_CPU(EMA_CPU_CLOUDS);
 		// this thread's stretch of pairs (names) and of groups (records, lines, statistics)
-		const size_t pa = bk->n_pairs * (size_t)tid / (size_t)nt_asm, pb = bk->n_pairs * (size_t)(tid + 1) / (size_t)nt_asm;
-		for (size_t p = pa; p < pb; ++p) {
-			const uint32_t ib = bk->id_off[p], ie = bk->id_off[p + 1];
-			const uint32_t len = ie > ib ? ie - ib - 1 : 0;
-			memcpy(o->idents + ident_at[p], bk->ids + ib + (ie > ib ? 1 : 0), len);
-			o->idents[ident_at[p] + len] = '\0';
+		if (want_lines) {
+			const size_t pa = bk->n_pairs * (size_t)tid / (size_t)nt_asm, pb = bk->n_pairs * (size_t)(tid + 1) / (size_t)nt_asm;
+			for (size_t p = pa; p < pb; ++p) {
+				const uint32_t ib = bk->id_off[p], ie = bk->id_off[p + 1];
+				const uint32_t len = ie > ib ? ie - ib - 1 : 0;
+				memcpy(o->idents + ident_at[p], bk->ids + ib + (ie > ib ? 1 : 0), len);
+				o->idents[ident_at[p] + len] = '\0';
+			}
 		}
-		ema_sam_stats &st = part[(size_t)tid];
+		ema_sam_stats st;      // (this thread's own: the threads' slots of part[] / cig_lo[] share cache lines)
+		memset(&st, 0, sizeof(st));
+		uint64_t clo = ~(uint64_t)0, chi = 0;
 		const size_t ga = n_groups * (size_t)tid / (size_t)nt_asm, gb = n_groups * (size_t)(tid + 1) / (size_t)nt_asm;
 		for (size_t g = ga; g < gb; ++g) {
 			const uint64_t r0 = a->pair_off[bk->group_off[g]];
-			size_t at = rec_base[g], ln = line_base[g];
-			auto fill = [&](uint64_t gi) -> ema_sam_rec * {
+			size_t at = rec_base[g], ln = line_base[g], xat = xa_base[g];
+			auto fill = [&](uint64_t gi, bool has_mate, Brief &bf) -> ema_sam_rec * {
 				const ema_aln_rec &ar = a->rec[gi];
 				const ema_cand_t &c = b->cand[ar.cand];
 				const size_t p = ar.pair;
-				ema_sam_rec &r = o->recs[at];
-				memset(&r, 0, sizeof(r));
-				r.ident = o->idents + ident_at[p];
-				r.chrom = contig_names[c.rid]; r.chrom_id = (uint32_t)c.rid; r.pos = (uint32_t)(c.pos + 1);
-				r.mapq = ar.mapq; r.score_mapq = ar.score_mapq; r.gamma = S.gamma[gi];
-				r.mate = ar.mate; r.rev = (uint8_t)(c.is_rev != 0); r.duplicate = S.flags[gi] & 1;
-				r.cloud_id = cloud_base[g] + S.cloud[gi]; r.cloud_bad = (S.flags[gi] >> 1) & 1;
-				r.bc = bk->bc[p];
-				const size_t rd = 2 * p + ar.mate, md = 2 * p + (1 - ar.mate);
-				r.read = bk->bases + bk->off[rd]; r.qual = bk->quals + bk->off[rd]; r.read_len = (int32_t)(bk->off[rd + 1] - bk->off[rd]);
-				r.mate_read = bk->bases + bk->off[md]; r.mate_qual = bk->quals + bk->off[md]; r.mate_read_len = (int32_t)(bk->off[md + 1] - bk->off[md]);
-				r.aln_pos = c.pos; r.aln_rev = c.is_rev; r.edit_dist = c.NM; r.n_cigar = c.n_cigar; r.cigar = b->cigar + c.cigar_off;
-				r.alts = nullptr; r.n_alts = 0;
+				const double gamma = S.gamma[gi];
+				const int gamma_mapq = gamma <= 0.999999 ? (int)(-10 * std::log10(1 - gamma)) : 60;
+				int q = gamma_mapq < ar.score_mapq ? gamma_mapq : ar.score_mapq;
+				q = q < ar.mapq ? q : ar.mapq;
+				q = q > 0 ? q : 0; q = q < 60 ? q : 60;
+				bf.rid = (uint32_t)c.rid; bf.pos = (uint32_t)(c.pos + 1); bf.mapq = q; bf.rev = c.is_rev != 0; bf.dup = S.flags[gi] & 1; bf.xa = S.alt_of[gi] >= 0;
+				const ema_cand_t *x = nullptr;
 				if (S.alt_of[gi] >= 0) {
-					const ema_aln_rec &xr = a->rec[r0 + (uint64_t)S.alt_of[gi]];
-					const ema_cand_t &x = b->cand[xr.cand];
-					if (x.n_cigar >= 64) rc_all.store(EMA_EFORMAT);      // the reference asserts (struct xa holds 64 operations)
-					ema_sam_alt &al = o->alts[at];
-					al.chrom = contig_names[x.rid]; al.pos = (uint32_t)(x.pos + 1); al.edit_dist = x.NM; al.rev = x.is_rev != 0;
-					al.n_cigar = x.n_cigar; al.cigar = b->cigar + x.cigar_off;
-					r.alts = &al; r.n_alts = 1;
+					x = &b->cand[a->rec[r0 + (uint64_t)S.alt_of[gi]].cand];
+					if (x->n_cigar >= 64) rc_all.store(EMA_EFORMAT);      // the reference asserts (struct xa holds 64 operations)
 				}
-				return &o->recs[at++];
+				if (want_descs) {
+					ema_sam_desc &d = o->descs[at];
+					memset(&d, 0, sizeof(d));
+					if (c.pos < 0 || c.pos >= 0xffffffffll || c.n_cigar < 0) rc_all.store(EMA_EARG);
+					d.pair = (uint32_t)p; d.rid = c.rid; d.pos = (uint32_t)(c.pos + 1); d.cigar_off = c.cigar_off; d.n_cigar = c.n_cigar; d.edit_dist = c.NM;
+					d.cloud_id = cloud_base[g] + S.cloud[gi]; d.xa = -1;
+					d.mate = ar.mate; d.rev = (uint8_t)(c.is_rev != 0); d.duplicate = S.flags[gi] & 1; d.cloud_bad = (S.flags[gi] >> 1) & 1;
+					d.mapq = (uint8_t)q; d.has_mate = has_mate;
+					if (gamma == 1.0) { d.gamma[0] = '1'; d.gamma_len = 1; }      // the two values most records carry, without the library call
+					else if (gamma == 0.0) { d.gamma[0] = '0'; d.gamma_len = 1; }
+					else if (const int k5 = ema_fmt_g5(gamma, d.gamma)) d.gamma_len = (uint8_t)k5;      // host_fmt.h: the same text, exactly
+					else {
+						char t[48];
+						const int k = snprintf(t, sizeof t, "%.5g", gamma);
+						if (k < 0 || k > (int)sizeof d.gamma) rc_all.store(EMA_EARG);      // (a gamma is in [0, 1]: at most 11 characters)
+						else { memcpy(d.gamma, t, (size_t)k); d.gamma_len = (uint8_t)k; }
+					}
+					if (c.n_cigar > 0) { clo = std::min<uint64_t>(clo, c.cigar_off); chi = std::max<uint64_t>(chi, (uint64_t)c.cigar_off + (uint64_t)c.n_cigar); }
+					if (x) {
+						ema_sam_xa &xa = o->xas[xat];
+						if (x->pos < 0 || x->pos >= 0xffffffffll || x->n_cigar < 0) rc_all.store(EMA_EARG);
+						xa.rid = x->rid; xa.pos = (uint32_t)(x->pos + 1); xa.cigar_off = x->cigar_off; xa.n_cigar = x->n_cigar; xa.edit_dist = x->NM; xa.rev = x->is_rev != 0;
+						if (x->n_cigar > 0) { clo = std::min<uint64_t>(clo, x->cigar_off); chi = std::max<uint64_t>(chi, (uint64_t)x->cigar_off + (uint64_t)x->n_cigar); }
+						d.xa = (int32_t)xat++;
+					}
+				}
+				ema_sam_rec *out_rec = nullptr;
+				if (want_lines) {
+					ema_sam_rec &r = o->recs[at];
+					memset(&r, 0, sizeof(r));
+					r.ident = o->idents + ident_at[p];
+					r.chrom = contig_names[c.rid]; r.chrom_id = (uint32_t)c.rid; r.pos = (uint32_t)(c.pos + 1);
+					r.mapq = ar.mapq; r.score_mapq = ar.score_mapq; r.gamma = gamma;
+					r.mate = ar.mate; r.rev = (uint8_t)(c.is_rev != 0); r.duplicate = S.flags[gi] & 1;
+					r.cloud_id = cloud_base[g] + S.cloud[gi]; r.cloud_bad = (S.flags[gi] >> 1) & 1;
+					r.bc = bk->bc[p];
+					const size_t rd = 2 * p + ar.mate, md = 2 * p + (1 - ar.mate);
+					r.read = bk->bases + bk->off[rd]; r.qual = bk->quals + bk->off[rd]; r.read_len = (int32_t)(bk->off[rd + 1] - bk->off[rd]);
+					r.mate_read = bk->bases + bk->off[md]; r.mate_qual = bk->quals + bk->off[md]; r.mate_read_len = (int32_t)(bk->off[md + 1] - bk->off[md]);
+					r.aln_pos = c.pos; r.aln_rev = c.is_rev; r.edit_dist = c.NM; r.n_cigar = c.n_cigar; r.cigar = b->cigar + c.cigar_off;
+					r.alts = nullptr; r.n_alts = 0;
+					if (x) {
+						ema_sam_alt &al = o->alts[at];
+						al.chrom = contig_names[x->rid]; al.pos = (uint32_t)(x->pos + 1); al.edit_dist = x->NM; al.rev = x->is_rev != 0;
+						al.n_cigar = x->n_cigar; al.cigar = b->cigar + x->cigar_off;
+						r.alts = &al; r.n_alts = 1;
+					}
+					out_rec = &r;
+				}
+				++at;
+				return out_rec;
 			};
-			for (uint32_t k = 0; k < S.n_sel[g]; ++k) {
-				const Sel sl = S.sel[r0 + k];
-				const ema_sam_rec *rec = fill(sl.rec);
-				const ema_sam_rec *mate = sl.mate != ~(uint64_t)0 ? fill(sl.mate) : nullptr;
-				o->lines[ln++] = ema_sam_line{rec, mate};
-				o->lines[ln++] = ema_sam_line{mate, rec};
-			}
 			// statistics of the lines as print_sam_record will flag them (src/samrecord.c:104-175)
-			for (size_t i = line_base[g]; i < ln; ++i) {
-				const ema_sam_rec *rec = o->lines[i].rec, *mate = o->lines[i].mate;
+			auto count_line = [&](const Brief *rec, const Brief *mate) {
 				++st.lines;
-				if (!rec) { ++st.unmapped_mates; continue; }
+				if (!rec) { ++st.unmapped_mates; return; }
 				++st.mapped;
-				if (rec->duplicate) ++st.duplicates;
-				if (rec->n_alts) ++st.with_xa;
-				if (mate && rec->rev != mate->rev && rec->chrom_id == mate->chrom_id) {      // is_pair, src/align.c:27-40
-					const ema_sam_rec *r1 = rec, *r2 = mate;
+				if (rec->dup) ++st.duplicates;
+				if (rec->xa) ++st.with_xa;
+				if (mate && rec->rev != mate->rev && rec->rid == mate->rid) {      // is_pair, src/align.c:27-40
+					const Brief *r1 = rec, *r2 = mate;
 					if (r2->rev) { r1 = mate; r2 = rec; }
 					const int64_t d = (int64_t)(uint32_t)(r1->pos - r2->pos);      // two uint32_t: the difference wraps
 					if (kInsertMin <= d && d <= kInsertMax) ++st.proper;
 				}
-				const int gamma_mapq = rec->gamma <= 0.999999 ? (int)(-10 * std::log10(1 - rec->gamma)) : 60;
-				int q = gamma_mapq < rec->score_mapq ? gamma_mapq : rec->score_mapq;
-				q = q < rec->mapq ? q : rec->mapq;
-				q = q > 0 ? q : 0; q = q < 60 ? q : 60;
+				const int q = rec->mapq;
 				++st.mapq_hist[q == 0 ? 0 : q < 10 ? 1 : q < 20 ? 2 : q < 30 ? 3 : q < 40 ? 4 : q < 60 ? 5 : 6];
+			};
+			for (uint32_t k = 0; k < S.n_sel[g]; ++k) {
+				const Sel sl = S.sel[r0 + k];
+				const bool has_mate = sl.mate != ~(uint64_t)0;
+				Brief b1, b2;
+				if (want_descs) o->sel_at[ln / 2] = (uint32_t)at;
+				const ema_sam_rec *rec = fill(sl.rec, has_mate, b1);
+				const ema_sam_rec *mate = has_mate ? fill(sl.mate, false, b2) : nullptr;
+				if (want_lines) { o->lines[ln] = ema_sam_line{rec, mate}; o->lines[ln + 1] = ema_sam_line{mate, rec}; }
+				ln += 2;
+				count_line(&b1, has_mate ? &b2 : nullptr);
+				count_line(has_mate ? &b2 : nullptr, &b1);
 			}
 		}
+		part[(size_t)tid] = st; cig_lo[(size_t)tid] = clo; cig_hi[(size_t)tid] = chi;
 	};
 	EmaPool::get().run((size_t)nt_asm, [&](size_t t) { assemble((int)t); });
+	o->cigar_lo = ~(uint64_t)0; o->cigar_hi = 0;
+	for (int t = 0; t < nt_asm; ++t) { o->cigar_lo = std::min(o->cigar_lo, cig_lo[(size_t)t]); o->cigar_hi = std::max(o->cigar_hi, cig_hi[(size_t)t]); }
+	if (o->cigar_lo > o->cigar_hi) o->cigar_lo = o->cigar_hi = 0;
 	for (const auto &ps : part) {
 		o->stats.lines += ps.lines; o->stats.mapped += ps.mapped; o->stats.unmapped_mates += ps.unmapped_mates; o->stats.proper += ps.proper;
 		o->stats.duplicates += ps.duplicates; o->stats.with_xa += ps.with_xa;

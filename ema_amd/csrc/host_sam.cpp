@@ -21,6 +21,7 @@
 #endif
 #include "ema_sam.h"
 #include "host_cpuacct.h"
+#include "host_fmt.h"
 #include "host_pool.h"
 
 namespace {
@@ -215,6 +216,7 @@ bool put_line(Out &o, const ema_sam_rec *rec, const ema_sam_rec *mate, const ema
 		char g[48];
 		if (rec->gamma == 1.0) { g[0] = '1'; g[1] = 0; }      // "%.5g" of the two values most records carry, without the library call
 		else if (rec->gamma == 0.0) { g[0] = '0'; g[1] = 0; }
+		else if (const int k5 = ema_fmt_g5(rec->gamma, g)) g[k5] = 0;      // host_fmt.h: exact, without the library call
 		else snprintf(g, sizeof g, "%.5g", rec->gamma);
 		o.str("\tNM:i:"); o.i64(rec->edit_dist); o.str("\tBX:Z:"); o.str(bc_str);
 		if (!opt.is_haplotag) { o.ch('-'); o.mem(opt.bx_index, sh.bx_len); }

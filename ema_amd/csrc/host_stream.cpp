@@ -22,6 +22,8 @@
 #include "host_cpuacct.h"
 #include "host_pool.h"
 
+const char *ema_tuning_get(const char *key);      // engine.hip: the library's tuning string (ema_engine_set_tuning / EMA_TUNING)
+
 namespace {
 
 thread_local std::string g_err;
@@ -541,6 +543,7 @@ struct SamSink {
 	int32_t next_cloud_id;
 	std::string err;
 	Stream *stream = nullptr;
+	ema_sam_dev_t *dev = nullptr;      // the formatter on the device (k_sam.hip); NULL: ema_sam_write on the host's threads
 	std::mutex mu;
 	std::condition_variable cv;
 	std::deque<CloudJob> cloud_jobs;
@@ -570,7 +573,14 @@ void sam_writer(SamSink &S)
 		size_t n_bytes = 0;
 		const double t0 = now_s();
 		int rc = EMA_OK;
-		if (S.write_rc == EMA_OK) rc = ema_sam_write(S.fd, j.sel->lines, j.sel->n_lines, &S.o.sam, &n_bytes);
+		if (S.write_rc == EMA_OK) {
+			if (S.dev) {
+				const ema_clouds_out *sl = j.sel;
+				rc = ema_sam_dev_write(S.dev, S.fd, j.bk, j.b->cigar ? j.b->cigar + sl->cigar_lo : nullptr, sl->cigar_lo, sl->cigar_hi, sl->descs, sl->n_descs,
+				                       sl->xas, sl->n_xas, sl->sel_at, sl->n_sel, &S.o.sam, &n_bytes);
+				if (rc == EMA_EIO && *ema_sam_dev_last_error()) { std::lock_guard<std::mutex> lk(S.mu); if (S.err.empty()) S.err = std::string("SAM formatter on the device: ") + ema_sam_dev_last_error(); }
+			} else rc = ema_sam_write(S.fd, j.sel->lines, j.sel->n_lines, &S.o.sam, &n_bytes);
+		}
 		if (S.sstats) S.sstats[j.k].write_s = now_s() - t0;
 		free_job(j.sel, j.bk, j.b, j.a);
 		{
@@ -599,6 +609,7 @@ void sam_clouds(SamSink &S)
 		if (rc == EMA_OK) {
 			ema_cloud_opts co = S.o.clouds;
 			if (S.o.continue_cloud_ids) co.first_cloud_id = S.next_cloud_id;
+			co.emit = S.dev ? 1 : 0;      // the compact records for the device's formatter, or the lines for the host's
 			rc = ema_clouds_select(c.bk, c.b, c.a, S.names.data(), (int32_t)S.names.size(), &co, &sel);
 			if (rc == EMA_OK) {
 				S.next_cloud_id = sel->next_cloud_id;
@@ -689,6 +700,13 @@ int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const em
 	T.items.resize(n);
 	for (auto &it : T.items) memset(&it.st, 0, sizeof(it.st));
 	S.stream = &T;
+	{   // SAM text from the device's kernels unless tuned off ("sam_device_format=0": the host formatter, ema_sam_write)
+		const char *v = ema_tuning_get("sam_device_format");
+		if (!(v && atoi(v) == 0)) {
+			const int drc = ema_sam_dev_open(ema_engine_device(e), S.names.data(), (int32_t)S.names.size(), &S.dev);
+			if (drc != EMA_OK) { g_err = std::string("SAM formatter on the device: ") + ema_sam_dev_last_error(); return drc; }
+		}
+	}
 	std::thread writer(sam_writer, std::ref(S));
 	std::thread clouder(sam_clouds, std::ref(S));
 	int rc = run_stream(e, T, sam_sink, &S, bstats);
@@ -699,6 +717,7 @@ int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const em
 	S.cv.notify_all();
 	clouder.join();
 	writer.join();
+	if (S.dev) ema_sam_dev_close(S.dev);
 	if (rc == EMA_OK && S.cloud_rc != EMA_OK) rc = S.cloud_rc;
 	if (rc == EMA_OK && S.write_rc != EMA_OK) { rc = S.write_rc; S.err = "ema_sam_write failed"; }
 	if (rc != EMA_OK && !S.err.empty()) g_err = S.err;

@@ -88,3 +88,59 @@ def header(contigs, rg_line, version: bytes, argv) -> bytes:
         return C.string_at(text, size.value)
     finally:
         L.ema_sam_free(text)
+
+
+# ---- the formatter on the device (ema_sam_dev_*, kernels in csrc/k_sam.hip): the same lines from the compact records ----
+import numpy as _np
+
+DESC_DTYPE = _np.dtype([("pair", "<u4"), ("rid", "<i4"), ("pos", "<u4"), ("cigar_off", "<u4"), ("n_cigar", "<i4"), ("edit_dist", "<i4"),
+                        ("cloud_id", "<i4"), ("xa", "<i4"), ("mate", "u1"), ("rev", "u1"), ("duplicate", "u1"), ("cloud_bad", "u1"),
+                        ("mapq", "u1"), ("gamma_len", "u1"), ("has_mate", "u1"), ("pad_", "u1"), ("gamma", "S12")])      # ema_sam_desc
+XA_DTYPE = _np.dtype([("rid", "<i4"), ("pos", "<u4"), ("cigar_off", "<u4"), ("n_cigar", "<i4"), ("edit_dist", "<i4"), ("rev", "<i4")])      # ema_sam_xa
+assert DESC_DTYPE.itemsize == 52 and XA_DTYPE.itemsize == 24
+
+
+class DevFormatter:
+    """ema_sam_dev_open / _format / _close: the formatter's kernels on `device`.  No fallback: without a GPU the open fails."""
+
+    def __init__(self, contig_names, device: int = 0):
+        L = _lib()
+        L.ema_sam_dev_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p)]
+        L.ema_sam_dev_close.argtypes = [C.c_void_p]
+        L.ema_sam_dev_format.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_size_t, C.POINTER(SamOpts), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.ema_sam_dev_last_error.restype = C.c_char_p
+        names = (C.c_char_p * max(1, len(contig_names)))(*[n if isinstance(n, bytes) else n.encode() for n in contig_names])
+        self._h = C.c_void_p()
+        rc = L.ema_sam_dev_open(device, names, len(contig_names), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"ema_sam_dev_open failed ({rc}): {L.ema_sam_dev_last_error().decode()}")
+
+    def format(self, bucket_struct, cigar_ptr, cigar_lo, cigar_hi, descs, n_descs, xas, n_xas, sel_at, n_sel, opts: SamOpts) -> bytes:
+        """bucket_struct: a ctypes ema_bucket; cigar_ptr: operation cigar_lo of the batch's array; the rest as ema_clouds_out carries it."""
+        L = _lib()
+        text, size = C.c_void_p(), C.c_size_t()
+        rc = L.ema_sam_dev_format(self._h, C.byref(bucket_struct), cigar_ptr, cigar_lo, cigar_hi, descs, n_descs, xas, n_xas, sel_at, n_sel,
+                                  C.byref(opts), C.byref(text), C.byref(size))
+        if rc != 0:
+            raise RuntimeError(f"ema_sam_dev_format failed (code {rc}): {L.ema_sam_dev_last_error().decode()}")
+        try:
+            return C.string_at(text, size.value)
+        finally:
+            L.ema_sam_free(text)
+
+    def format_selection(self, sel, opts: SamOpts) -> bytes:
+        """A clouds.Selection made with opts.emit >= 1."""
+        cig = C.cast(sel.b.cigar, C.c_void_p).value + 4 * sel.cigar_lo if sel.cigar_hi > sel.cigar_lo else None
+        return self.format(sel.bk, cig, sel.cigar_lo, sel.cigar_hi, sel.descs, sel.n_descs, sel.xas, sel.n_xas, sel.sel_at, sel.n_sel, opts)
+
+    def close(self):
+        if self._h:
+            _lib().ema_sam_dev_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

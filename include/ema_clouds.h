@@ -47,6 +47,9 @@ typedef struct {
 	int32_t density_opt;      /* -d */
 	int32_t n_density_probs;  /* tech->n_density_probs, tech->density_probs (src/techs.c:74-127): 4 x {0.6, 0.05, 0.2, 0.01} for 10x */
 	double density_probs[16];
+	int32_t emit;             /* what ema_clouds_out carries: 0 lines / recs / alts / idents (ema_sam_write's input); 1 the compact form only
+	                           * (descs / xas / sel_at: ema_sam_dev_write's input -- no per-record structs, no copies of the names); 2 both */
+	int32_t pad_;
 } ema_cloud_opts;
 void ema_cloud_opts_default(ema_cloud_opts *o);   /* 50000, 0, 0, 0; no -d, the 10x density model */
 /* srand(seed) for -d, as the reference's first bad cloud does with time(NULL) (src/split.c:54-59); without a call the library seeds
@@ -71,6 +74,12 @@ typedef struct ema_clouds_out {
 	char *idents;             /* NUL-terminated read names */
 	int32_t next_cloud_id;    /* the cloud counter after this bucket (first_cloud_id of the next one in an -x run) */
 	ema_sam_stats stats;
+	/* emit 1 / 2: the selected records by index (include/ema_sam.h), in the order of recs[] */
+	size_t n_descs, n_xas, n_sel;
+	ema_sam_desc *descs;
+	ema_sam_xa *xas;
+	uint32_t *sel_at;         /* n_sel: first descriptor of selected pair i (lines 2i and 2i+1) */
+	uint64_t cigar_lo, cigar_hi;      /* the CIGAR operations the descriptors and XA entries name lie in [cigar_lo, cigar_hi) of the batch's array */
 } ema_clouds_out;
 
 /* bk: the bucket as read (barcodes, groups, names, reads, qualities); b, a: its candidates and append_alignments records

@@ -262,6 +262,7 @@ typedef struct {
 } ema_engine_timing;
 int ema_engine_last_timing(ema_engine_t *e, ema_engine_timing *t);
 int ema_engine_n_streams(const ema_engine_t *e);
+int ema_engine_device(const ema_engine_t *e);          /* the HIP device the engine was opened on */
 int ema_engine_seed_launches(const ema_engine_t *e);   /* launches of the seeding kernel per slice and run (its re-packing series) */
 
 #ifdef __cplusplus

@@ -81,6 +81,48 @@ void ema_sam_free(char *text);
  * first); *n_bytes, if not NULL, receives the number of bytes written.  EMA_EIO if a write fails. */
 int ema_sam_write(int fd, const ema_sam_line *lines, size_t n, const ema_sam_opts *o, size_t *n_bytes);
 
+/* ---- the same lines in compact form, for the formatter on the device (ema_sam_dev_*, below) ----
+ * A selected record by index instead of by pointer: the device holds the bucket's text (names, bases, qualities, barcodes), the
+ * batch's CIGAR operations and the contig names, so a line needs 52 bytes from the host.  The host keeps what needs libm or libc:
+ * the printed MAPQ (min of the gamma-, score- and bwa-mapq clamped to [0, 60]: log10, reference src/samrecord.c:139-146) and the
+ * "%.5g" text of gamma (:247). */
+typedef struct ema_sam_desc {
+	uint32_t pair;                /* pair index in the bucket: name, reads, barcode */
+	int32_t rid;                  /* rec->chrom */
+	uint32_t pos;                 /* rec->pos (1-based); rec->aln.pos is pos - 1 */
+	uint32_t cigar_off;           /* first operation in the batch's CIGAR array */
+	int32_t n_cigar, edit_dist;
+	int32_t cloud_id;
+	int32_t xa;                   /* index of the XA entry, -1: none */
+	uint8_t mate, rev, duplicate, cloud_bad;
+	uint8_t mapq;                 /* as printed */
+	uint8_t gamma_len;            /* bytes of gamma[] */
+	uint8_t has_mate;             /* on the first record of a selected pair: the next descriptor is its mate's */
+	uint8_t pad_;
+	char gamma[12];               /* "%.5g" of rec->gamma */
+} ema_sam_desc;
+typedef struct ema_sam_xa { int32_t rid; uint32_t pos; uint32_t cigar_off; int32_t n_cigar, edit_dist, rev; } ema_sam_xa;
+
+/* The formatter as kernels (ema_amd/csrc/k_sam.hip): one lane renders one line -- a length pass, a prefix sum, a writing pass into
+ * one text buffer -- from the bucket's arrays uploaded as they are, the compact records above and the batch's CIGAR operations
+ * [cigar_lo, cigar_hi) (cigar points at operation cigar_lo).  sel_at[i] is the first descriptor of selected pair i, which prints two
+ * lines: (rec, mate) and (mate, rec), the second one standing in for an unaligned mate when there is no mate record.  The text
+ * comes back to a page-locked buffer and goes to fd with write(); byte for byte ema_sam_write()'s.  contig_names as for
+ * ema_clouds_select.  EMA_EFORMAT as ema_sam_write; EMA_EARG on inconsistent input; a HIP failure is EMA_EIO with the message in
+ * ema_sam_dev_last_error(). */
+struct ema_bucket;
+typedef struct ema_sam_dev ema_sam_dev_t;
+int ema_sam_dev_open(int device, const char *const *contig_names, int32_t n_contigs, ema_sam_dev_t **out);
+void ema_sam_dev_close(ema_sam_dev_t *d);
+int ema_sam_dev_write(ema_sam_dev_t *d, int fd, const struct ema_bucket *bk, const uint32_t *cigar, uint64_t cigar_lo, uint64_t cigar_hi,
+                      const ema_sam_desc *descs, size_t n_descs, const ema_sam_xa *xas, size_t n_xas, const uint32_t *sel_at, size_t n_sel,
+                      const ema_sam_opts *o, size_t *n_bytes);
+/* the same, the text returned instead of written (tests); free with ema_sam_free() */
+int ema_sam_dev_format(ema_sam_dev_t *d, const struct ema_bucket *bk, const uint32_t *cigar, uint64_t cigar_lo, uint64_t cigar_hi,
+                       const ema_sam_desc *descs, size_t n_descs, const ema_sam_xa *xas, size_t n_xas, const uint32_t *sel_at, size_t n_sel,
+                       const ema_sam_opts *o, char **text, size_t *n_bytes);
+const char *ema_sam_dev_last_error(void);
+
 /* The header write_sam_header() prints (reference src/align.c:192-211): @HD VN:1.3 SO:unsorted, one @SQ per contig,
  * the read-group line as given (NULL: none), and @PG ID:ema PN:ema VN:<version> CL:<argv joined by spaces>.  Contig
  * names and lengths are what ema_engine_contig_name / _contig_len return.  *text is freed with ema_sam_free(). */

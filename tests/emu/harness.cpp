@@ -24,6 +24,7 @@ const char *ema_tuning_get(const char *key)
 #include "k_ext_lane.hip"
 #include "k_pair.hip"
 #include "k_final.hip"
+#include "k_sam.hip"
 
 // per-read capacities of the emulated launches (the strides of the arrays tests/emu_lib.py allocates)
 #define EMU_INTV_CAP 512
@@ -270,6 +271,24 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 int emu_sizeof_reg() { return (int)sizeof(DevReg); }
 // dev_sort.hpp: the wavefront's introsort and the single-lane one on copies of the same keys (tests/test_emu_dp.py)
 void emu_sort(uint64_t *wave_io, uint64_t *seq_io, const int *n, int cap, int n_tasks, int by_weight) { ema_launch_test_sort(wave_io, seq_io, n, cap, n_tasks, by_weight, nullptr); }
+
+// k_sam.hip: the SAM formatter's three kernels on host memory (tests/test_sam_format.py, tests/test_golden_sam.py); the job's pointers
+// are the caller's arrays.  Returns the text's length (text may be NULL to ask for it), -7 where the kernel flags a bad base.
+long long emu_sam_format(const SamJob *job, char *text, long long cap)
+{
+	SamJob J = *job;
+	const uint32_t n_chunks = (J.n_lines + 63u) / 64u;
+	std::vector<uint32_t> local((size_t)J.n_lines + 64), ctot((size_t)n_chunks + 1);
+	std::vector<uint64_t> cbase((size_t)n_chunks + 1);
+	uint64_t total = 0;
+	int bad = 0;
+	ema_launch_sam_len(J, local.data(), ctot.data(), nullptr);
+	ema_launch_sam_tops(n_chunks, ctot.data(), cbase.data(), &total, nullptr);
+	if (!text || (long long)total > cap) return (long long)total;
+	ema_launch_sam_write(J, local.data(), cbase.data(), text, &bad, nullptr);
+	return bad ? -7 : (long long)total;
+}
+int emu_sizeof_sam_job() { return (int)sizeof(SamJob); }
 
 // the whole pipeline K1..K4 on host memory (n_reads even: pairs)
 // K4's set-aside path (k_final.hip: K4t / K4r) on host memory: lists, arena and counters; EMU_K4_HEAVY = regions a read must have left

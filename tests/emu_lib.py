@@ -116,3 +116,49 @@ def pipeline_tiers(h, nt4_bases, off, lean=(8, 2, 8), full_pairs=64, cap=256, ci
                              regs.ctypes.data, n_regs.ctypes.data, alns.ctypes.data, cigars.ctypes.data, cig_n.ctypes.data,
                              status.ctypes.data, tier.ctypes.data)
     return regs, n_regs, alns, cigars, cig_n, status, tier, n
+
+
+class _SamJob(C.Structure):      # csrc/dev_sam.h
+    _fields_ = [(n, C.c_void_p) for n in ("bases", "quals", "off", "ids", "id_off", "bc", "cigar", "desc", "xa", "sel_at", "names", "name_off", "rg", "bx")] + \
+               [("n_lines", C.c_uint32), ("cigar_lo", C.c_uint32)] + \
+               [(n, C.c_int32) for n in ("has_rg", "rg_len", "bx_len", "bc_len", "is_haplotag", "insert_min", "insert_max")]
+
+
+def sam_format(bk, cigar_ptr, cigar_lo, descs, xas, sel_at, n_sel, contig_names, opts) -> bytes:
+    """k_sam.hip's three kernels under the interpreter.  bk: a ctypes ema_bucket; cigar_ptr: address of operation cigar_lo of the
+    batch's CIGAR array; descs / xas / sel_at: addresses (ema_sam_desc[], ema_sam_xa[], uint32[]); opts: ema_amd.sam.SamOpts."""
+    L = lib()
+    L.emu_sam_format.restype = C.c_longlong
+    L.emu_sam_format.argtypes = [C.POINTER(_SamJob), C.c_void_p, C.c_longlong]
+    assert L.emu_sizeof_sam_job() == C.sizeof(_SamJob)
+    names = b"".join(contig_names) + b"\0" * 8
+    name_off = np.cumsum([0] + [len(n) for n in contig_names]).astype(np.uint32)
+    rg = opts.rg_id
+    rg_len = 0
+    if rg is not None:
+        for i, c in enumerate(rg):
+            if c == 0x20 or 9 <= c <= 13:
+                break
+            rg_len = i + 1
+    rg_buf, bx_buf, names_buf = C.create_string_buffer(rg or b"", max(8, len(rg or b"") + 8)), C.create_string_buffer(opts.bx_index, len(opts.bx_index) + 8), C.create_string_buffer(names, len(names))
+    J = _SamJob()
+    adr = lambda p: C.cast(p, C.c_void_p).value if p is not None and not isinstance(p, int) else p
+    J.bases, J.quals, J.off, J.ids, J.id_off, J.bc = adr(bk.bases), adr(bk.quals), adr(bk.off), adr(bk.ids), adr(bk.id_off), adr(bk.bc)
+    J.cigar, J.desc, J.xa, J.sel_at = adr(cigar_ptr), adr(descs), adr(xas), adr(sel_at)
+    J.names, J.name_off, J.rg, J.bx = adr(names_buf), name_off.ctypes.data, adr(rg_buf), adr(bx_buf)
+    J.n_lines, J.cigar_lo = 2 * n_sel, cigar_lo
+    J.has_rg, J.rg_len, J.bx_len, J.bc_len, J.is_haplotag = int(rg is not None), rg_len, len(opts.bx_index), opts.bc_len, opts.is_haplotag
+    J.insert_min, J.insert_max = opts.insert_min, opts.insert_max
+    n = L.emu_sam_format(C.byref(J), None, 0)
+    buf = C.create_string_buffer(max(1, n) + 8)
+    got = L.emu_sam_format(C.byref(J), buf, n)
+    if got < 0:
+        raise RuntimeError(f"emu_sam_format: code {got}")
+    assert got == n
+    return buf.raw[:n]
+
+
+def sam_format_selection(sel, contig_names, opts) -> bytes:
+    """A clouds.Selection made with opts.emit >= 1."""
+    cig = C.cast(sel.b.cigar, C.c_void_p).value + 4 * sel.cigar_lo if sel.cigar_hi > sel.cigar_lo else None
+    return sam_format(sel.bk, cig, sel.cigar_lo, sel.descs, sel.xas, sel.sel_at, sel.n_sel, contig_names, opts)

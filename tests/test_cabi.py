@@ -27,7 +27,7 @@ def test_header_symbols_are_exported():
 
 
 # which in-tree library implements each header of include/, and how many entry points it declares
-HEADERS = {"ema_engine.h": ("libema_engine.so", None), "ema_ingest.h": ("libema_engine.so", 7), "ema_sam.h": ("libema_engine.so", 5),
+HEADERS = {"ema_engine.h": ("libema_engine.so", None), "ema_ingest.h": ("libema_engine.so", 7), "ema_sam.h": ("libema_engine.so", 10),
            "ema_stream.h": ("libema_engine.so", None), "ema_clouds.h": ("libema_engine.so", None), "ema_bwaabi.h": ("libema_bwaabi.so", None),
            "ema_count.h": ("libema_engine.so", 2), "ema_preproc.h": ("libema_engine.so", 2)}
 
@@ -61,6 +61,15 @@ def test_default_options_match_the_reference():
     assert (o.w, o.zdrop, o.pen_clip5, o.pen_clip3, o.min_seed_len) == (100, 100, 5, 5, 19)
     assert o.max_occ == 3000 and o.max_mem_intv == 20 and o.split_width == 10
     assert (o.score_delta, o.max_rescue, o.pes_low, o.pes_high) == (25, 50, -35, 500)
+
+
+def test_device_formatter_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from ema_amd import sam
+    with pytest.raises(RuntimeError, match="ema_sam_dev_open failed"):
+        sam.DevFormatter([b"chr1"])
 
 
 def test_open_without_gpu_fails_loudly():

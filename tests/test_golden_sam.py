@@ -15,6 +15,8 @@ import ctypes as C
 
 import pytest
 
+import emu_lib
+
 import oracle_lib as O
 from golden_sam_lib import Run, cases, oracle_batch, reference
 from ema_amd import clouds, ingest, sam
@@ -72,7 +74,7 @@ def test_product_host_stages_equal_the_reference_host_code(case):
     want_head, want_body = split(run.expected)
     assert run.header(contigs) == want_head
     so = run.sam_opts()
-    body, first = b"", 0
+    body, dev_body, first = b"", b"", 0
     if run.density_opt:
         clouds.reseed(run.density_seed)      # once per run, as the reference's first bad cloud does
     for path in run.paths:
@@ -80,11 +82,13 @@ def test_product_host_stages_equal_the_reference_host_code(case):
         batch, _orec, _opair_off = oracle_batch(prefix, bucket)
         rec, pair_off = E.append_alignments(batch, bucket.off, error_rate=run.po["error_rate"])      # the product's append stage on the oracle's candidates
         co = run.cloud_opts()
-        co.first_cloud_id, co.n_threads = first, 3
+        co.first_cloud_id, co.n_threads, co.emit = first, 3, 2      # lines for the host formatter AND the compact records for the device's
         sel = clouds.select(bucket, batch, rec, pair_off, names, co)
         body += sam.format_lines(sel.lines, sel.n_lines, so)
+        dev_body += emu_lib.sam_format_selection(sel, names, so)      # k_sam.hip under the host interpreter (the GPU run: test_gpu_golden_sam.py)
         first = sel.next_cloud_id
     assert body == want_body
+    assert dev_body == want_body
 
 
 def test_the_vectors_cover_what_they_claim():

@@ -101,6 +101,13 @@ def test_three_10x_buckets_to_sam(tmp_path):
     _run(tmp_path, "repeats", [300, 260, 340], False, False)
 
 
+def test_host_formatter_route(tmp_path, tuning):
+    """ema_stream_sam's text comes from the device's formatter (csrc/k_sam.hip) by default -- every other test of this file; tuned off
+    ("sam_device_format=0") the cloud stage emits its per-record structs and ema_sam_write formats them on the host's threads."""
+    tuning(sam_device_format=0)
+    _run(tmp_path, "repeats", [300, 260], False, False)
+
+
 def test_x_mode_cloud_numbers_run_on(tmp_path):
     _run(tmp_path, "two_contigs", [200, 240], False, True)
 

@@ -33,6 +33,7 @@
 #include "host_index.h"
 const char *ema_tuning_get(const char *key);
 #include "opts.h"
+#include "dev_bucket.h"
 
 // ---------------------------------------------------------------------------------------------
 // Development knobs.  Everything that used to be an environment variable of its own (A/B switches of four rounds, the parity
@@ -880,6 +881,7 @@ int ema_engine_index_info(const ema_engine_t *e, int32_t info[4])
 	return EMA_OK;
 }
 size_t ema_engine_batch_capacity(const ema_engine_t *e) { return e ? e->cap_pairs : 0; }
+int ema_engine_max_read_len(void) { return EMA_MAX_READ; }
 size_t ema_engine_full_tier_capacity(const ema_engine_t *e) { return e ? e->full.cap_pairs : 0; }
 
 int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs) { return ema_engine_stage_slot(e, 0, bases, off, n_pairs); }
@@ -931,6 +933,50 @@ static int stage_slot_impl(ema_engine_t *e, int slot, const char *bases, const u
 	HIPCHK(e, hipStreamSynchronize(st));
 	in.n_pairs = n_pairs; in.staged = true;
 	return async ? EMA_OK : select_slot(e, slot);
+}
+
+// stage_async for buckets whose reads are already on this device (ema_bucket_read_device, ingest_dev.hip): the buckets are laid end to
+// end in the slot with device-to-device copies and a rebase of their offsets; the conversion to nt4 + packed form follows as usual.
+// The caller has checked the read lengths against EMA_MAX_READ on its host copy of the offsets.
+extern "C" void ema_launch_rebase_off(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t add, hipStream_t stream);
+int ema_engine_stage_async_dev(ema_engine_t *e, int slot, const ema_bucket *const *buckets, size_t n_buckets)
+{
+	if (!e || (!buckets && n_buckets)) return EMA_EARG;
+	EMA_CPU(EMA_CPU_STAGE);
+	if (slot < 0 || slot >= EMA_MAX_SLOTS) { e->err = "input slot out of range (EMA_MAX_SLOTS)"; return EMA_EARG; }
+	size_t n_pairs = 0, n_bases = 0;
+	for (size_t k = 0; k < n_buckets; ++k) {
+		const ema_bucket_dev *d = ema_bucket_dev_view(buckets[k]);
+		if (!d || d->device != e->device) { e->err = "ema_engine_stage_async_dev: a bucket is not on the engine's device"; return EMA_EARG; }
+		n_pairs += d->n_pairs; n_bases += d->n_bases;
+	}
+	if (n_pairs > e->cap_pairs) { e->err = "batch larger than ema_engine_batch_capacity()"; return EMA_EARG; }
+	if (n_bases > 0xfffffff0ull) { e->err = "more than 4 GB of bases in one batch"; return EMA_EARG; }
+	HIPCHK(e, hipSetDevice(e->device));
+	{
+		int rc = input_alloc(e, slot);
+		if (rc != EMA_OK) return rc;
+	}
+	ema_engine::InputSet &in = e->in[slot];
+	if (!e->h2d_stream) HIPCHK(e, hipStreamCreate(&e->h2d_stream));
+	if (e->slot_free[slot]) HIPCHK(e, hipEventSynchronize(e->slot_free[slot]));      // the last run queued on this slot has read it
+	hipStream_t st = e->h2d_stream;
+	const size_t n_reads = 2 * n_pairs;
+	size_t at_r = 0, at_b = 0;
+	HIPCHK(e, hipMemsetAsync(in.d_off.p, 0, 4, st));
+	for (size_t k = 0; k < n_buckets; ++k) {
+		const ema_bucket_dev *d = ema_bucket_dev_view(buckets[k]);
+		if (!d->n_pairs) continue;
+		HIPCHK(e, hipMemcpyAsync(in.d_bases.p + at_b, d->bases, d->n_bases, hipMemcpyDeviceToDevice, st));
+		ema_launch_rebase_off(in.d_off.p + at_r + 1, d->off + 1, (uint32_t)(2 * d->n_pairs), (uint32_t)at_b, st);
+		at_r += 2 * d->n_pairs; at_b += d->n_bases;
+	}
+	HIPCHK(e, hipMemsetAsync(in.d_qpack.p + n_reads * 24, 0, 8 * 4, st));
+	ema_launch_stage_reads(in.d_off.p, (int)n_reads, in.d_bases.p, in.d_qpack.p, st);
+	HIPCHK(e, hipGetLastError());
+	HIPCHK(e, hipStreamSynchronize(st));
+	in.n_pairs = n_pairs; in.staged = true;
+	return EMA_OK;
 }
 
 // makes `slot` the input of the next run: consecutive pairs go to consecutive slices, as evenly as the slice count allows

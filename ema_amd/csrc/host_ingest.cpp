@@ -36,6 +36,8 @@
 #include "host_cpuacct.h"
 #include "host_pool.h"
 
+extern "C" void ema_bucket_dev_release(void *dev);
+
 namespace {
 
 thread_local std::string g_err;
@@ -248,6 +250,7 @@ void ema_bucket_free(ema_bucket *b)
 {
 	if (!b) return;
 	free(b->group_off); free(b->bc); free(b->off); free(b->bases); free(b->quals); free(b->id_off); free(b->ids);
+	if (b->dev) ema_bucket_dev_release(b->dev);      // the arrays on the device (ingest_dev.hip)
 	free(b);
 }
 

@@ -21,6 +21,7 @@
 #include "ema_stream.h"
 #include "host_cpuacct.h"
 #include "host_pool.h"
+#include "dev_bucket.h"
 
 const char *ema_tuning_get(const char *key);      // engine.hip: the library's tuning string (ema_engine_set_tuning / EMA_TUNING)
 
@@ -60,6 +61,8 @@ struct Stream {
 	std::condition_variable cv;
 	size_t delivered = 0, pairs_read = 0, pairs_delivered = 0;
 	bool stop = false;
+	bool dev_reader = false;     // buckets are read by ema_bucket_read_device: reads and qualities stay on `device` (ema_stream_sam)
+	int device = 0;
 	bool sink_kept = false;      // set by a sink of this file that took the bucket's objects over (they are not freed on its return)
 	bool trace = getenv("EMA_STREAM_TRACE") != nullptr;      // when what happened, on stderr
 	double t_start = now_s();
@@ -150,6 +153,16 @@ void worker(Stream &S, int w)
 	}
 }
 
+// a device-resident bucket (ema_bucket_read_device) gets host copies of its reads and qualities as well
+int host_resident(ema_bucket *bk)
+{
+	if (!bk->dev || bk->bases) return EMA_OK;
+	const size_t nb = bk->off[2 * bk->n_pairs];
+	bk->bases = (char *)malloc(nb + 1); bk->quals = (char *)malloc(nb + 1);
+	if (!bk->bases || !bk->quals) return EMA_EIO;
+	return ema_bucket_dev_fetch(bk, bk->bases, bk->quals);
+}
+
 void reader(Stream &S)
 {
 	// How far ahead of the delivery: read_ahead buckets plus the ones inside the engine's pipeline -- or, with small buckets, as many
@@ -166,10 +179,16 @@ void reader(Stream &S)
 		const double t0 = now_s();
 		const int rc = S.o.fastq_input
 			? ema_fastq_read(S.paths[k], S.o.paths2 ? S.o.paths2[k] : nullptr, S.o.fastq_name_style, S.o.bc_len, S.o.is_haplotag, S.o.max_read_len, &it.bk)
+			: S.dev_reader ? ema_bucket_read_device(S.paths[k], S.o.bc_len, S.o.is_haplotag, S.o.max_read_len, S.device, &it.bk)
 			: ema_bucket_read(S.paths[k], S.o.bc_len, S.o.is_haplotag, S.o.max_read_len, &it.bk);
 		it.st.read_s = now_s() - t0;
-		if (rc != EMA_OK) { it.rc = rc; it.err = ema_bucket_last_error(); it.st.rc = rc; }
-		else { it.bases = it.bk->bases; it.off = it.bk->off; it.n_pairs = it.bk->n_pairs; }
+		if (rc != EMA_OK) { it.rc = rc; it.err = *ema_bucket_last_error() ? ema_bucket_last_error() : ema_bucket_dev_last_error(); it.st.rc = rc; }
+		else {
+			int hrc = EMA_OK;
+			if (it.bk->dev && it.bk->n_pairs > S.cap) hrc = host_resident(it.bk);      // beyond one batch: ema_engine_align_pairs takes host arrays
+			if (hrc != EMA_OK) { it.rc = hrc; it.err = "a bucket's reads could not be copied back from the device"; it.st.rc = hrc; }
+			else { it.bases = it.bk->bases; it.off = it.bk->off; it.n_pairs = it.bk->n_pairs; }
+		}
 		{
 			std::lock_guard<std::mutex> lk(S.mu);
 			it.state = ST_LOADED;
@@ -239,7 +258,28 @@ void stager(Stream &S, AsyncState &A)
 		}
 		Item &it = S.items[k];
 		int ok = 1;
-		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap) {
+		// buckets whose reads are on the device already go into the slot there (no host copy, no upload); a pass that mixes them with
+		// host-resident ones (a bucket the device reader handed to the host reader) takes the host path, with copies fetched back
+		size_t n_dev = 0, n_used = 0;
+		for (size_t j = 0; j < ps.len; ++j) { const Item &x = S.items[k + j]; if (x.rc == EMA_OK && x.n_pairs) { ++n_used; n_dev += x.bk && x.bk->dev && !x.bk->bases; } }
+		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap && n_dev && n_dev < n_used)
+			for (size_t j = 0; j < ps.len; ++j) { Item &x = S.items[k + j]; if (x.bk && x.bk->dev && host_resident(x.bk) == EMA_OK) x.bases = x.bk->bases; }
+		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap && n_dev && n_dev == n_used) {
+			std::vector<const ema_bucket *> bks;
+			size_t np = 0;
+			bool too_long = false;
+			for (size_t j = 0; j < ps.len; ++j) {
+				const Item &x = S.items[k + j];
+				if (!x.n_pairs) continue;
+				bks.push_back(x.bk); np += x.n_pairs;
+				for (size_t r = 0; r < 2 * x.n_pairs; ++r) too_long |= x.off[r + 1] - x.off[r] > (uint32_t)ema_engine_max_read_len();
+			}
+			std::lock_guard<std::mutex> hold(S.stage_mu);
+			const int rc = too_long ? EMA_ELIMIT : ema_engine_stage_async_dev(S.eng[0], 1 + (int)(A.passes.size() % (size_t)kInSlots), bks.data(), bks.size());
+			if (S.trace) fprintf(stderr, "[stream] stager: pass %zu = buckets %zu..%zu (%zu pairs): staged on the device by %.3f (s since start)\n",
+			                     A.passes.size(), k, k + ps.len - 1, np, now_s() - S.t_start);
+			if (rc != EMA_OK) { for (size_t j = 0; j < ps.len; ++j) { S.items[k + j].rc = rc; S.items[k + j].err = too_long ? "read longer than EMA_MAX_READ" : ema_engine_strerror(S.eng[0]); } ok = -1; }
+		} else if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap) {
 			const char *pb = it.bases; const uint32_t *po = it.off; size_t np = it.n_pairs;
 			if (ps.len > 1) {      // end to end in one batch
 				size_t tot_p = 0, tot_b = 0;
@@ -705,6 +745,11 @@ int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const em
 		if (!(v && atoi(v) == 0)) {
 			const int drc = ema_sam_dev_open(ema_engine_device(e), S.names.data(), (int32_t)S.names.size(), &S.dev);
 			if (drc != EMA_OK) { g_err = std::string("SAM formatter on the device: ") + ema_sam_dev_last_error(); return drc; }
+			// ... and then the reader's parse, sort and gather are kernels too, the reads staying where the formatter finds them
+			// ("sam_device_reader=0": the host reader; -1 / -2 FASTQ input and two-engine streams use the host reader as well)
+			v = ema_tuning_get("sam_device_reader");
+			T.dev_reader = !(v && atoi(v) == 0) && !T.o.fastq_input && T.o.n_engines != 2;
+			T.device = ema_engine_device(e);
 		}
 	}
 	std::thread writer(sam_writer, std::ref(S));

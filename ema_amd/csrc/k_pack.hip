@@ -202,3 +202,16 @@ extern "C" void ema_launch_stage_reads(const uint32_t *off, int n_reads, uint8_t
 	if (n_reads <= 0) return;
 	hipLaunchKernelGGL(ema_k_stage_reads, dim3((unsigned)(((size_t)n_reads * 8 + 255) / 256)), dim3(256), 0, stream, off, n_reads, bases, qpack);
 }
+
+// offsets of one bucket laid behind others in a shared input slot (ema_engine_stage_async_dev): dst[r] = src[r] + add
+__global__ void __launch_bounds__(256)
+ema_k_rebase_off(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t n, uint32_t add)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+	if (r < n) dst[r] = src[r] + add;
+}
+extern "C" void ema_launch_rebase_off(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t add, hipStream_t stream)
+{
+	if (!n) return;
+	hipLaunchKernelGGL(ema_k_rebase_off, dim3((n + 255u) / 256u), dim3(256), 0, stream, dst, src, n, add);
+}

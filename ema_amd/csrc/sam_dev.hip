@@ -18,6 +18,7 @@
 #include "ema_ingest.h"
 #include "ema_sam.h"
 #include "dev_sam.h"
+#include "dev_bucket.h"
 #include "host_cpuacct.h"
 
 const char *ema_tuning_get(const char *key);      // engine.hip
@@ -153,18 +154,27 @@ int run(ema_sam_dev *d, Sink &out, const ema_bucket *bk, const uint32_t *cigar, 
 	if (rg_len) memcpy(d->hsmall.p + rg_at, opt->rg_id, rg_len);
 	memcpy(d->hsmall.p + bx_at, opt->bx_index, bx_len);
 	SAMCHK(hipMemcpyAsync(d->small.p, d->hsmall.p, small_bytes, hipMemcpyHostToDevice, d->st));
+	// a bucket read by ema_bucket_read_device has its arrays on the device already: nothing of the bucket goes up
+	const ema_bucket_dev *twin = ema_bucket_dev_view(bk);
+	if (twin && twin->device != d->device) twin = nullptr;
+	if (!twin && (!bk->bases || !bk->quals)) return EMA_EARG;
 	struct Up { DBuf *b; const void *src; size_t bytes; };
 	const Up ups[] = {{&d->bases, bk->bases, n_bases}, {&d->quals, bk->quals, n_bases}, {&d->off, bk->off, (n_reads + 1) * 4}, {&d->ids, bk->ids, n_ids},
 	                  {&d->id_off, bk->id_off, (n_pairs + 1) * 4}, {&d->bc, bk->bc, n_pairs * 8}, {&d->cigar, cigar, n_cig * 4},
 	                  {&d->desc, descs, n_descs * sizeof(ema_sam_desc)}, {&d->xa, xas, n_xas * sizeof(ema_sam_xa)}, {&d->sel, sel_at, n_sel * 4}};
-	for (const Up &u : ups) {
+	for (size_t u_i = 0; u_i < sizeof ups / sizeof ups[0]; ++u_i) {
+		const Up &u = ups[u_i];
+		if (twin && u_i < 6) continue;
 		SAMCHK(u.b->need(u.bytes + 8));
 		if (u.bytes) SAMCHK(hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, d->st));
 	}
 	SamJob J;
 	memset(&J, 0, sizeof J);
-	J.bases = (const char *)d->bases.p; J.quals = (const char *)d->quals.p; J.off = (const uint32_t *)d->off.p;
-	J.ids = (const char *)d->ids.p; J.id_off = (const uint32_t *)d->id_off.p; J.bc = (const uint64_t *)d->bc.p;
+	if (twin) { J.bases = twin->bases; J.quals = twin->quals; J.off = twin->off; J.ids = twin->ids; J.id_off = twin->id_off; J.bc = twin->bc; }
+	else {
+		J.bases = (const char *)d->bases.p; J.quals = (const char *)d->quals.p; J.off = (const uint32_t *)d->off.p;
+		J.ids = (const char *)d->ids.p; J.id_off = (const uint32_t *)d->id_off.p; J.bc = (const uint64_t *)d->bc.p;
+	}
 	J.cigar = (const uint32_t *)d->cigar.p; J.desc = (const ema_sam_desc *)d->desc.p; J.xa = (const ema_sam_xa *)d->xa.p;
 	J.names = (const char *)d->names.p; J.name_off = (const uint32_t *)d->name_off.p;
 	J.rg = (const char *)d->small.p + rg_at; J.bx = (const char *)d->small.p + bx_at;

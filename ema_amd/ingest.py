@@ -16,7 +16,7 @@ EMA_EIO, EMA_EFORMAT = -6, -7
 class _Bucket(C.Structure):
     _fields_ = [("n_pairs", C.c_size_t), ("n_groups", C.c_size_t), ("group_off", C.POINTER(C.c_uint64)),
                 ("bc", C.POINTER(C.c_uint64)), ("off", C.POINTER(C.c_uint32)), ("bases", C.POINTER(C.c_char)),
-                ("quals", C.POINTER(C.c_char)), ("id_off", C.POINTER(C.c_uint32)), ("ids", C.POINTER(C.c_char))]
+                ("quals", C.POINTER(C.c_char)), ("id_off", C.POINTER(C.c_uint32)), ("ids", C.POINTER(C.c_char)), ("dev", C.c_void_p)]
 
 
 @dataclass
@@ -87,6 +87,47 @@ def read_bucket(path: str, bc_len: int = 16, is_haplotag: bool = False, max_read
     if rc != 0:
         raise BucketError(rc, L.ema_bucket_last_error().decode())
     return _take(L, p)
+
+
+def read_bucket_device(path: str, bc_len: int = 16, is_haplotag: bool = False, max_read_len: int = 255, device: int = 0):
+    """ema_bucket_read_device: the reader's parse, sort and gather as kernels (csrc/ingest_dev.hip).  Returns (Bucket, on_device): the
+    bucket with its reads and qualities copied back from the device (ema_bucket_dev_fetch) so that it compares with read_bucket's, and
+    whether the kernels took it (False: the library handed the file to the host reader -- haplotag, long barcodes, an irregular line)."""
+    L = _lib()
+    L.ema_bucket_read_device.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(_Bucket))]
+    L.ema_bucket_dev_fetch.argtypes = [C.POINTER(_Bucket), C.c_void_p, C.c_void_p]
+    L.ema_bucket_dev_last_error.restype = C.c_char_p
+    p = C.POINTER(_Bucket)()
+    rc = L.ema_bucket_read_device(path.encode(), bc_len, int(is_haplotag), max_read_len, device, C.byref(p))
+    if rc != 0:
+        raise BucketError(rc, (L.ema_bucket_last_error() or L.ema_bucket_dev_last_error()).decode())
+    b = p.contents
+    on_device = bool(b.dev)
+    if not on_device:
+        return _take(L, p), False
+    assert not b.bases and not b.quals
+    nb = int(b.off[2 * b.n_pairs])
+    bases, quals = np.zeros(nb + 1, np.uint8), np.zeros(nb + 1, np.uint8)
+    rc = L.ema_bucket_dev_fetch(p, bases.ctypes.data, quals.ctypes.data)
+    if rc != 0:
+        L.ema_bucket_free(p)
+        raise BucketError(rc, "ema_bucket_dev_fetch failed")
+    b.bases, b.quals = C.cast(bases.ctypes.data, C.POINTER(C.c_char)), C.cast(quals.ctypes.data, C.POINTER(C.c_char))
+    try:
+        n, g = b.n_pairs, b.n_groups
+
+        def arr(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dt).itemsize,)).view(dt).copy()
+        off = arr(b.off, 2 * n + 1, np.uint32)
+        id_off = arr(b.id_off, n + 1, np.uint32)
+        out = Bucket(arr(b.bc, n, np.uint64), arr(b.group_off, g + 1, np.uint64), off, bases[:nb].copy(), quals[:nb].copy(), id_off,
+                     arr(b.ids, int(id_off[-1]), np.uint8))
+    finally:
+        b.bases, b.quals = None, None      # (numpy's memory: not the library's to free)
+        L.ema_bucket_free(p)
+    return out, True
 
 
 def read_fastq(path1: str, path2: str | None = None, bc_len: int = 16, is_haplotag: bool = False, max_read_len: int = 255,

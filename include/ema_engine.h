@@ -137,6 +137,7 @@ void ema_batch_free(ema_batch_out *out);
  * Per-read result slots come in two tiers: every pair first runs with lean capacities; the few pairs with a read over
  * one of them are redone on the device with the full capacities (at most ema_engine_full_tier_capacity() per batch). */
 size_t ema_engine_batch_capacity(const ema_engine_t *e);
+int ema_engine_max_read_len(void);      /* longest read the engine takes (255; the reference's MAX_READ_LEN is 200) */
 size_t ema_engine_full_tier_capacity(const ema_engine_t *e);
 int ema_engine_stage(ema_engine_t *e, const char *bases, const uint32_t *off, size_t n_pairs);
 /* Several batches resident at once: stage_slot puts a batch into input slot 0 <= slot < EMA_MAX_SLOTS (its device buffers
@@ -156,6 +157,10 @@ int ema_engine_run_slot(ema_engine_t *e, int slot);
  * form ema_stream_* (include/ema_stream.h) drives: staging of batch k+1, kernels of batch k and fetching of batch k-1 overlap
  * on one set of batch buffers. */
 int ema_engine_stage_async(ema_engine_t *e, int slot, const char *bases, const uint32_t *off, size_t n_pairs);
+/* stage_async for buckets read by ema_bucket_read_device (include/ema_ingest.h) on the engine's device: they are laid end to end in
+ * the slot in device memory (bucket k's pairs follow bucket k-1's); no read crosses the host.  The caller checks the read lengths. */
+struct ema_bucket;
+int ema_engine_stage_async_dev(ema_engine_t *e, int slot, const struct ema_bucket *const *buckets, size_t n_buckets);
 int ema_engine_run_async(ema_engine_t *e, int slot, int *ticket);
 int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out);
 int ema_engine_run(ema_engine_t *e);

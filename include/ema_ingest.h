@@ -44,12 +44,26 @@ typedef struct ema_bucket {
 	char *quals;
 	uint32_t *id_off;       /* n_pairs + 1 */
 	char *ids;              /* identifiers back to back (both mates share one, src/align.c:790) */
+	void *dev;              /* private to the library.  NULL: every array above is in host memory.  Set by ema_bucket_read_device: bases and
+	                         * quals are NULL on the host and live in device memory (with copies of the other arrays), where the engine's
+	                         * staging and the SAM formatter read them; ema_bucket_dev_fetch copies them back */
 } ema_bucket;
 
 /* Reads a whole bucket file.  bc_len = the platform's barcode length (reference src/techs.c:74-119; 16 for 10x),
  * 1..32; is_haplotag selects encode_bc_haplotag (bc_len 12); max_read_len = longest read accepted (the reference's
  * MAX_READ_LEN is 200, include/align.h:61; the engine takes up to 255).  *out is freed with ema_bucket_free(). */
 int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out);
+
+/* The same with the parsing on the device (csrc/ingest_dev.hip): the file is read into page-locked memory and uploaded as it is;
+ * line table, field scan with the reader's checks, stable radix sort by barcode, prefix sums and the gather of bases / qualities /
+ * names into their sorted places are kernels.  The bucket that comes back is the one ema_bucket_read returns, except that bases and
+ * quals stay on the device (bucket->dev; NULL on the host): ema_stream_sam hands them to the engine and to the SAM formatter there.
+ * Whatever the kernels do not take -- haplotag or longer-than-21 barcodes, a line the checks refuse, a NUL byte, 4 GB of text -- is
+ * read by ema_bucket_read instead (then bases / quals are host arrays and dev is NULL): same result, same error texts. */
+int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int max_read_len, int device, ema_bucket **out);
+/* bases / quals of a device-resident bucket copied to the caller's arrays (off[2 * n_pairs] bytes each); EMA_EARG if dev is NULL */
+int ema_bucket_dev_fetch(const ema_bucket *b, char *bases, char *quals);
+const char *ema_bucket_dev_last_error(void);
 
 /* The same on a bucket already in memory (text[0 .. len)); text is not modified and need not end in a newline or NUL. */
 int ema_bucket_parse(const char *text, size_t len, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out);

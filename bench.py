@@ -286,7 +286,7 @@ def sam_leg(args, eng, batches, workdir, world):
         return None
     from ema_amd import stream, synth
     try:
-        n_files, per, rep = 4, min(262144, args.pairs), 12      # 48 buckets: a dozen passes, so that the pipeline's fill and drain do not set the rate
+        n_files, per, rep = 4, min(262144, args.pairs), 24      # 96 buckets: two dozen passes, so that the pipeline's fill and drain do not set the rate (r01-r05a: 48)
         t = time.time()
         paths = []
         for k in range(n_files):
@@ -313,9 +313,10 @@ def sam_leg(args, eng, batches, workdir, world):
         tot = n_files * rep * per
         log(f"[rank 0] bucket files -> SAM text: {tot / dt:.0f} pairs/s ({n_files * rep} buckets of {per} pairs in {dt:.2f}s; files written in {t_write:.1f}s)")
         return {"value": round(tot / dt, 1), "unit": "pairs/s", "buckets": n_files * rep, "pairs_per_bucket": per,
-                "what": "bucket files (preproc's one-pair-per-line form, page cache) -> SAM text on /dev/null through ONE ema_stream_sam call: reader, "
-                        "staging, K1-K4, fetch, append stage, clouds / EM / duplicate marking, formatter; small buckets share passes; host stages on "
-                        "the CPUs the box grants",
+                "what": "bucket files (preproc's one-pair-per-line form, page cache) -> SAM text on /dev/null through ONE ema_stream_sam call: reader "
+                        "(r05: parse, sort by barcode and gather on the device; the reads stay in HBM), staging, K1-K4, fetch, append stage, clouds / "
+                        "EM / duplicate marking on the host's threads, formatter (r05: on the device, from 52-byte records of the cloud stage); small "
+                        "buckets share passes; host stages on the CPUs the box grants",
                 "stage_seconds": {"reader": round(sum(s["read_s"] for s in bst), 3), "append": round(sum(s["append_s"] for s in bst), 3),
                                   "clouds_em_duplicates": round(sum(s["select_s"] for s in sst), 3), "formatter_and_write": round(sum(s["write_s"] for s in sst), 3)},
                 "host_cpu_seconds_per_million_pairs": round(cpu_s / tot * 1e6, 3), "host_cpus_busy": round(cpu_s / dt, 1),

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported():
 
 
 # which in-tree library implements each header of include/, and how many entry points it declares
-HEADERS = {"ema_engine.h": ("libema_engine.so", None), "ema_ingest.h": ("libema_engine.so", 7), "ema_sam.h": ("libema_engine.so", 10),
+HEADERS = {"ema_engine.h": ("libema_engine.so", None), "ema_ingest.h": ("libema_engine.so", 10), "ema_sam.h": ("libema_engine.so", 10),
            "ema_stream.h": ("libema_engine.so", None), "ema_clouds.h": ("libema_engine.so", None), "ema_bwaabi.h": ("libema_bwaabi.so", None),
            "ema_count.h": ("libema_engine.so", 2), "ema_preproc.h": ("libema_engine.so", 2)}
 
@@ -70,6 +70,19 @@ def test_device_formatter_without_gpu_fails_loudly():
     from ema_amd import sam
     with pytest.raises(RuntimeError, match="ema_sam_dev_open failed"):
         sam.DevFormatter([b"chr1"])
+
+
+def test_device_reader_without_gpu_fails_loudly(tmp_path):
+    """ema_bucket_read_device hands irregular FILES to the host reader; a missing GPU is not one of those cases."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from ema_amd import ingest
+    p = tmp_path / "b.fq"
+    p.write_bytes(b"ACGTACGTACGTACGA ok AC FF GT FF\n")
+    with pytest.raises(ingest.BucketError) as e:
+        ingest.read_bucket_device(str(p))
+    assert e.value.code == ingest.EMA_EIO
 
 
 def test_open_without_gpu_fails_loudly():

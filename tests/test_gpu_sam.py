@@ -108,6 +108,42 @@ def test_host_formatter_route(tmp_path, tuning):
     _run(tmp_path, "repeats", [300, 260], False, False)
 
 
+def test_a_bucket_the_device_reader_declines_shares_a_pass_with_ones_it_took(tmp_path, tuning):
+    """Three small buckets make one pass.  The middle one has a NUL byte in an ignored seventh field: the device's reader hands such a file
+    to the host reader (same bucket), so the pass mixes device-resident buckets with a host-resident one -- the stager fetches the
+    others' reads back and takes the host path.  The SAM text must be what the host reader + host formatter write for the UNCHANGED
+    files (a seventh field is never read; that route is the one the other tests of this file compare with the oracle)."""
+    prefix, ctg = small_ref("repeats")
+    paths = []
+    for k, n in enumerate((220, 180, 200)):
+        d = tmp_path / f"b{k}"
+        d.mkdir()
+        make_bucket(d, "repeats", n, 700 + k, 40, False, sub_rate=0.015, chimeric=0.04)
+        paths.append(str(d / "bucket"))
+
+    def run(ps, out):
+        eng = E.Engine(prefix)
+        fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        bst, _sst = stream.stream_sam(eng, ps, fd, rg_id=b"rg1")
+        os.close(fd)
+        eng.close()
+        assert all(s["rc"] == 0 and s["capacity_flags"] == 0 for s in bst)
+        return open(out, "rb").read()
+    tuning(sam_device_format=0)
+    want = run(paths, str(tmp_path / "host.sam"))
+    tuning()
+    assert run(paths, str(tmp_path / "dev.sam")) == want      # reader and formatter on the device
+    lines = open(paths[1], "rb").read().split(b"\n")
+    lines[3] += b" seventh\0field"
+    odd = str(tmp_path / "odd_bucket")
+    open(odd, "wb").write(b"\n".join(lines))
+    _b, on_device = ingest.read_bucket_device(odd)
+    assert not on_device
+    assert run([paths[0], odd, paths[2]], str(tmp_path / "mixed.sam")) == want
+    tuning(sam_device_reader=0)      # host reader, device formatter: the bucket's arrays go up with the records
+    assert run(paths, str(tmp_path / "up.sam")) == want
+
+
 def test_x_mode_cloud_numbers_run_on(tmp_path):
     _run(tmp_path, "two_contigs", [200, 240], False, True)
 

@@ -36,6 +36,9 @@
 #include "dev_bucket.h"
 #include "host_cpuacct.h"
 #include "host_pool.h"
+#include <chrono>
+
+const char *ema_tuning_get(const char *key);      // engine.hip
 
 namespace {
 
@@ -121,10 +124,12 @@ ema_k_ing_parse(const char *__restrict__ text, uint32_t text_len, const uint32_t
 			code = code << 3 | (uint64_t)c;
 		}
 	}
-	if (bad) { atomicOr(irregular, 2); return; }
-	f.id_b = (uint16_t)fb[1]; f.id_l = (uint16_t)fl[1];
-	f.r1_b = (uint16_t)fb[2]; f.r1_l = (uint16_t)fl[2]; f.q1_b = (uint16_t)fb[3];
-	f.r2_b = (uint16_t)fb[4]; f.r2_l = (uint16_t)fl[4]; f.q2_b = (uint16_t)fb[5];
+	if (bad) { atomicOr(irregular, 2); code = 0; }      // (the host reader takes the bucket; the line still gets its -- empty -- entries: the passes
+	else {                                               //  queued behind this one index by them before the flag is looked at)
+		f.id_b = (uint16_t)fb[1]; f.id_l = (uint16_t)fl[1];
+		f.r1_b = (uint16_t)fb[2]; f.r1_l = (uint16_t)fl[2]; f.q1_b = (uint16_t)fb[3];
+		f.r2_b = (uint16_t)fb[4]; f.r2_l = (uint16_t)fl[4]; f.q2_b = (uint16_t)fb[5];
+	}
 	fields[i] = f; codes[i] = code; idx[i] = i;
 }
 
@@ -262,6 +267,14 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		return ema_bucket_read(path, bc_len, is_haplotag, max_read_len, out);
 	}
 	const size_t len = (size_t)sb.st_size;
+	const bool prof = ema_tuning_get("ingest_prof") != nullptr;      // phase times on stderr (tools/ingest_rate.py --device)
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!prof) return;
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[ingest_dev] %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+		t_last = t;
+	};
 	Block pin, txt, work, keep;
 	ema_bucket *o = nullptr;
 	hipStream_t st = nullptr;
@@ -290,6 +303,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 			if (bad.load()) { rc = -1001; goto done; }      // (the host reader reports the I/O error)
 			memset(buf + len, 0, 64);
 		}
+		lap("pread (page-locked)");
 		ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 		ING(dev_pool().take(len + 64 + 512, txt));
 		char *d_text = (char *)txt.p;
@@ -301,6 +315,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		unsigned long long h_cnt[4] = {0, 0, 0, 0};
 		ING(hipMemcpyAsync(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost, st));
 		ING(hipStreamSynchronize(st));
+		lap("upload + count");
 		if (((int *)&h_cnt[2])[0]) { rc = -1001; goto done; }
 		const uint32_t n_nl = (uint32_t)h_cnt[0];
 		const uint32_t n = n_nl + (((const char *)pin.p)[len - 1] != '\n' ? 1u : 0u);
@@ -335,6 +350,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		ING(hipMemcpyAsync(&totals[1], d_id_off + n, 4, hipMemcpyDeviceToHost, st));
 		ING(hipMemcpyAsync(&irr, d_irr, 4, hipMemcpyDeviceToHost, st));
 		ING(hipStreamSynchronize(st));
+		lap("lines, parse, sort, sums");
 		if (irr) { rc = -1001; goto done; }
 		const size_t nb = totals[0], ni = totals[1];      // (each below the file's size: no 32-bit overflow)
 		// the bucket's arrays on the device, and their host copies (all but bases and qualities)
@@ -360,6 +376,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		ING(hipMemcpyAsync(o->id_off, k_id_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
 		if (ni) ING(hipMemcpyAsync(o->ids, k_ids, ni, hipMemcpyDeviceToHost, st));
 		ING(hipStreamSynchronize(st));
+		lap("gather + download");
 		size_t n_groups = 0;
 		for (size_t i = 0; i < n; ++i) n_groups += (i == 0 || o->bc[i] != o->bc[i - 1]);
 		o->n_groups = n_groups;
@@ -374,6 +391,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		d->block = keep; keep = Block();
 		o->dev = d;
 		rc = 0;
+		lap("groups");
 	}
 done:
 #undef ING

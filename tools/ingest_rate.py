@@ -11,6 +11,7 @@ import oracle_lib as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=1000000)
 ap.add_argument("--no-oracle", action="store_true")
+ap.add_argument("--device", action="store_true", help="ema_bucket_read_device (needs a GPU), with its phase times")
 a = ap.parse_args()
 rng = np.random.default_rng(3)
 n, l1, l2 = a.pairs, 127, 150
@@ -49,6 +50,20 @@ b = ingest.read_bucket(path)
 print(f"bucket of {n} pairs, {size / 1e6:.0f} MB, {len(b.group_off) - 1} barcode groups", flush=True)
 print(f"ema_bucket_read (median of 5): {t_prod * 1e3:.0f} ms = {n / t_prod / 1e6:.2f} M pairs/s, {size / t_prod / 1e9:.2f} GB/s "
       f"on {min(32, os.cpu_count())} host threads", flush=True)
+if a.device:
+    from ema_amd import engine as _E
+    L.ema_bucket_read_device.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(ingest._Bucket))]
+    ts = []
+    for k in range(6):
+        if k == 5:
+            _E.set_tuning(ingest_prof=1)
+        p = C.POINTER(ingest._Bucket)()
+        t = time.perf_counter(); rc = L.ema_bucket_read_device(path.encode(), 16, 0, 255, 0, C.byref(p)); ts.append(time.perf_counter() - t)
+        assert rc == 0 and p.contents.dev
+        L.ema_bucket_free(p)
+    _E.set_tuning()
+    t_dev = sorted(ts[1:])[2]
+    print(f"ema_bucket_read_device (median of 5 after the first): {t_dev * 1e3:.0f} ms = {n / t_dev / 1e6:.2f} M pairs/s, {size / t_dev / 1e9:.2f} GB/s", flush=True)
 if not a.no_oracle:
     L = O.lib()
     import ctypes as C

@@ -460,7 +460,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 {
 	const size_t n_reads = 2 * s.cap_pairs;
 	if (shared_stream) s.stream = shared_stream;
-	else { HIPCHK(e, hipStreamCreate(&s.stream)); s.own_stream = true; }
+	else { HIPCHK(e, hipStreamCreate(&s.stream)); s.own_stream = true; }      // (a high-priority queue for the full tier's stream: no effect, profiles/r05_ab.txt r05q)
 	for (auto &ev : s.ev) HIPCHK(e, hipEventCreate(&ev));
 	HIPCHK(e, s.d_intv.alloc(n_reads * (size_t)s.dopts.intv_cap));
 	HIPCHK(e, s.d_n_intv.alloc(n_reads));

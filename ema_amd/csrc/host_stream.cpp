@@ -163,7 +163,7 @@ int host_resident(ema_bucket *bk)
 	return ema_bucket_dev_fetch(bk, bk->bases, bk->quals);
 }
 
-void reader(Stream &S, size_t first, size_t step)      // buckets first, first + step, ...: the device reader runs as two of these, taking turns
+void reader(Stream &S, size_t first, size_t step)      // buckets first, first + step, ...
 {
 	// How far ahead of the delivery: read_ahead buckets plus the ones inside the engine's pipeline -- or, with small buckets, as many
 	// as make up that many full batches (the stream lays them end to end in one pass; a bound in buckets would starve it)
@@ -471,9 +471,9 @@ int run_stream(ema_engine_t *e, Stream &S, ema_stream_sink sink, void *user, ema
 		if (S.items[k].slot >= 0) S.items[k].slot = (int)((k / (size_t)S.n_eng) % (size_t)S.items[k].slot);
 	std::vector<std::thread> th;
 	AsyncState A;
-	// (a device reader's call is a chain of short kernels with the host waiting in between -- pread, upload, parse / sort, gather,
-	// download: two of them, on alternate buckets, keep both the host's threads and the copy engines busy)
-	const size_t n_readers = S.dev_reader ? 2 : 1;
+	// (two device readers taking turns were measured, r05p: 5.9-6.1 M pairs/s files -> SAM against 6.3 M with one -- the stream is bound
+	// by the GPU's passes, and two readers only contend for the copy engines)
+	const size_t n_readers = 1;
 	if (S.paths) for (size_t t = 0; t < n_readers; ++t) th.emplace_back(reader, std::ref(S), t, n_readers);
 	if (S.n_eng == 2) {
 		for (int w = 0; w < S.n_eng; ++w) th.emplace_back(worker, std::ref(S), w);

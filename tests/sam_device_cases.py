@@ -154,5 +154,10 @@ class Case:
     def host_text(self, so):
         return sam.format_lines(self.lines, len(self.lines), so)
 
+    def oracle_text(self, so):
+        """The same lines through the oracle's stdio restatement of print_sam_record (oracle/sam.c)."""
+        from test_sam_format import oracle_text
+        return oracle_text(self.lines, len(self.lines), so)
+
     def cigar_ptr(self):
         return self.cigar.ctypes.data + 4 * self.cigar_lo

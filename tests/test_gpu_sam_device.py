@@ -1,5 +1,5 @@
-"""The SAM formatter on the device (include/ema_sam.h: ema_sam_dev_*; csrc/k_sam.hip) on an MI355X against the host formatter on the
-same lines: the random cases of tests/sam_device_cases.py (every combination of aligned / unaligned record and mate, both strands, XA,
+"""The SAM formatter on the device (include/ema_sam.h: ema_sam_dev_*; csrc/k_sam.hip) on an MI355X against the oracle's restatement of
+print_sam_record (oracle/sam.c; and the host formatter) on the same lines: the random cases of tests/sam_device_cases.py (every combination of aligned / unaligned record and mate, both strands, XA,
 names from empty to 149 bytes, reads from 1 to 255 bases, 10x and haplotag barcodes, RG present / empty / absent), in one stretch and
 in many (the two text buffers taking turns), and the bad-base flag.  The golden SAM cases and the stream tests go through the same
 kernels by default (ema_stream_sam); tests/test_gpu_sam.py compares both formatters on a streamed run."""
@@ -22,7 +22,8 @@ def test_device_formatter_equals_the_host_formatter(haplotag, tuning):
     for seed, n_pairs, rg in ((3, 700, b"rg1\tSM:sample1"), (4, 64, None), (5, 33, b""), (6, 1, b"x")):
         case = Case(seed=seed, n_pairs=n_pairs, haplotag=haplotag)
         so = case.opts(rg=rg, bx=b"1" if seed != 4 else b"77")
-        want = case.host_text(so)
+        want = case.oracle_text(so)      # oracle/sam.c: print_sam_record restated call by call
+        assert case.host_text(so) == want
         assert dev_text(fmt, case, so) == want
         tuning(sam_stretch_lines=128)      # the same lines in stretches of 128: buffers reused, the text written piecewise
         assert dev_text(fmt, case, so) == want

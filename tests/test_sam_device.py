@@ -1,5 +1,5 @@
 """The SAM formatter's kernels (csrc/k_sam.hip: one lane per line, a length pass, a prefix sum, a writing pass) under the host SIMT
-interpreter against the host formatter on the same lines -- every combination of aligned / unaligned record and mate, both strands
+interpreter against the oracle's restatement of print_sam_record (and the host formatter) on the same lines -- every combination of aligned / unaligned record and mate, both strands
 (reversed reads of every length from 1 up: the word-at-a-time copies and their byte-wise heads and tails), XA entries, positions
 beyond 2^31, empty CIGARs, names from empty to 149 bytes, 10x and haplotag barcodes, RG present / empty / absent.  CPU only; the
 GPU runs the same cases in tests/test_gpu_sam_device.py.  The interpreter is test infrastructure, not parity evidence."""
@@ -14,7 +14,8 @@ from sam_device_cases import CHROMS, Case
 def test_interpreter_formats_what_the_host_formatter_does(haplotag, rg):
     case = Case(seed=11 + int(haplotag), n_pairs=150, haplotag=haplotag)
     so = case.opts(rg=rg, bx=b"1" if rg != b"" else b"42")
-    want = case.host_text(so)
+    want = case.oracle_text(so)      # oracle/sam.c: print_sam_record restated call by call
+    assert case.host_text(so) == want
     got = emu_lib.sam_format(case.bk, case.cigar_ptr(), case.cigar_lo, case.descs.ctypes.data, case.xas.ctypes.data, case.sel_at.ctypes.data,
                              case.n_sel, CHROMS, so)
     assert got == want

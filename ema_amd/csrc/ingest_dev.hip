@@ -36,158 +36,27 @@
 #include "dev_bucket.h"
 #include "host_cpuacct.h"
 #include "host_pool.h"
+#include "ingest_kernels.hpp"
 #include <chrono>
 
 const char *ema_tuning_get(const char *key);      // engine.hip
 
 namespace {
 
-const uint32_t kMaxLine = 4999;      // fgets(buf, 5000) (src/align.c:762,768)
-const uint32_t kMaxId = 149;         // id[150] (include/samrecord.h:12)
-
-struct Fields { uint16_t id_b, id_l, r1_b, r1_l, q1_b, r2_b, r2_l, q2_b; };      // byte offsets within the line (host_ingest.cpp's)
-
-__device__ __forceinline__ bool is_space(unsigned c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
-
-// line i of the text: [start, start + len), the '\n' counted (as in fgets' buffer)
-__device__ __forceinline__ void line_of(const uint32_t *nl, uint32_t n_nl, uint32_t text_len, uint32_t i, uint32_t &start, uint32_t &len)
-{
-	start = i ? nl[i - 1] + 1 : 0;
-	len = (i < n_nl ? nl[i] + 1 : text_len) - start;
-}
-
-__device__ __forceinline__ uint32_t field_end(const char *s, uint32_t at, uint32_t len)
-{
-	while (at + 8 <= len) {      // eight bytes at a time: a word with no byte below 0x21 holds no separator
-		uint64_t x;
-		__builtin_memcpy(&x, s + at, 8);
-		const uint64_t low = (x - 0x2121212121212121ULL) & ~x & 0x8080808080808080ULL;
-		if (!low) { at += 8; continue; }
-		at += (uint32_t)(__ffsll((long long)low) - 1) >> 3;
-		if (!s[at] || is_space((unsigned char)s[at])) return at;
-		++at;      // some other control byte: part of the field
-	}
-	while (at < len && s[at] && !is_space((unsigned char)s[at])) ++at;
-	return at;
-}
-__device__ __forceinline__ bool next_field(const char *s, uint32_t len, uint32_t &at, uint32_t &b, uint32_t &l)
-{
-	if (at > len) return false;
-	b = at;
-	at = field_end(s, at, len);
-	l = at - b;
-	at = (at < len && s[at]) ? at + 1 : len + 1;
-	return true;
-}
-
-__global__ void __launch_bounds__(256)
-ema_k_ing_count(const char *__restrict__ text, uint32_t len, unsigned long long *__restrict__ n_nl, int *__restrict__ irregular)
-{
-	const uint32_t at = (blockIdx.x * 256u + threadIdx.x) * 16u;
-	int c = 0, z = 0;
-	if (at < len) {
-		const uint32_t n = len - at < 16u ? len - at : 16u;
-		for (uint32_t k = 0; k < n; ++k) { c += text[at + k] == '\n'; z |= text[at + k] == 0; }
-	}
-	if (z) atomicOr(irregular, 1);      // a NUL ends the reference's C strings early: the host reader's business
-	if (c) atomicAdd(n_nl, (unsigned long long)c);
-}
-
-struct IsNewline {
-	const char *text;
-	__device__ bool operator()(uint32_t i) const { return text[i] == '\n'; }
-};
-
-__global__ void __launch_bounds__(256)
-ema_k_ing_parse(const char *__restrict__ text, uint32_t text_len, const uint32_t *__restrict__ nl, uint32_t n_nl, uint32_t n_lines, int bc_len,
-                uint32_t max_read_len, Fields *__restrict__ fields, uint64_t *__restrict__ codes, uint32_t *__restrict__ idx, int *__restrict__ irregular)
-{
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n_lines) return;
-	uint32_t start, ln;
-	line_of(nl, n_nl, text_len, i, start, ln);
-	const char *s = text + start;
-	Fields f;
-	memset(&f, 0, sizeof f);
-	uint32_t p = 0, fb[6] = {0, 0, 0, 0, 0, 0}, fl[6] = {0, 0, 0, 0, 0, 0};
-	bool six = ln <= kMaxLine;
-#pragma unroll
-	for (int x = 0; x < 6; ++x) if (six) six = next_field(s, ln, p, fb[x], fl[x]);
-	bool bad = !six || fl[0] != (uint32_t)bc_len || fl[1] == 0 || fl[1] > kMaxId || fl[2] > max_read_len || fl[4] > max_read_len ||
-	           fl[3] != fl[2] || fl[5] != fl[4];
-	uint64_t code = 0;
-	if (!bad) {
-		for (int j = 0; j < bc_len; ++j) {
-			const char ch = s[j];
-			int c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'a' ? 4 : ch == 'c' ? 5 : ch == 'g' ? 6 : ch == 't' ? 7 : -1;
-			if (c < 0) { bad = true; c = 0; }
-			code = code << 3 | (uint64_t)c;
-		}
-	}
-	if (bad) { atomicOr(irregular, 2); code = 0; }      // (the host reader takes the bucket; the line still gets its -- empty -- entries: the passes
-	else {                                               //  queued behind this one index by them before the flag is looked at)
-		f.id_b = (uint16_t)fb[1]; f.id_l = (uint16_t)fl[1];
-		f.r1_b = (uint16_t)fb[2]; f.r1_l = (uint16_t)fl[2]; f.q1_b = (uint16_t)fb[3];
-		f.r2_b = (uint16_t)fb[4]; f.r2_l = (uint16_t)fl[4]; f.q2_b = (uint16_t)fb[5];
-	}
-	fields[i] = f; codes[i] = code; idx[i] = i;
-}
-
-// lengths in sorted order, interleaved for one prefix sum each: rlen[2i], rlen[2i+1] (reads), ilen[i] (name); one zero past the end
-__global__ void __launch_bounds__(256)
-ema_k_ing_lens(const uint32_t *__restrict__ order, const Fields *__restrict__ fields, uint32_t n, uint32_t *__restrict__ rlen, uint32_t *__restrict__ ilen)
-{
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i > n) return;
-	if (i == n) { rlen[2 * n] = 0; ilen[n] = 0; return; }
-	const Fields f = fields[order[i]];
-	rlen[2 * i] = f.r1_l; rlen[2 * i + 1] = f.r2_l; ilen[i] = f.id_l;
-}
-
-__device__ __forceinline__ void copy_bytes(char *__restrict__ dst, const char *__restrict__ src, uint32_t n)
-{
-	uint32_t k = 0;
-	for (; k + 4 <= n; k += 4) { uint32_t v; __builtin_memcpy(&v, src + k, 4); __builtin_memcpy(dst + k, &v, 4); }      // (words at any alignment)
-	for (; k < n; ++k) dst[k] = src[k];
-}
-
-__global__ void __launch_bounds__(256)
-ema_k_ing_gather(const char *__restrict__ text, uint32_t text_len, const uint32_t *__restrict__ nl, uint32_t n_nl, const uint32_t *__restrict__ order,
-                 const Fields *__restrict__ fields, const uint64_t *__restrict__ codes_sorted, uint32_t n, int bc_len, const uint32_t *__restrict__ off,
-                 const uint32_t *__restrict__ id_off, char *__restrict__ bases, char *__restrict__ quals, char *__restrict__ ids, uint64_t *__restrict__ bc)
-{
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t line = order[i];
-	uint32_t start, ln;
-	line_of(nl, n_nl, text_len, line, start, ln);
-	const char *s = text + start;
-	const Fields f = fields[line];
-	copy_bytes(bases + off[2 * i], s + f.r1_b, f.r1_l);
-	copy_bytes(quals + off[2 * i], s + f.q1_b, f.r1_l);
-	copy_bytes(bases + off[2 * i + 1], s + f.r2_b, f.r2_l);
-	copy_bytes(quals + off[2 * i + 1], s + f.q2_b, f.r2_l);
-	copy_bytes(ids + id_off[i], s + f.id_b, f.id_l);
-	// two bits a base, first base lowest (encode_bc_default, src/util.c:41-61): the low bits of the sort code's digits
-	const uint64_t code = codes_sorted[i];
-	uint64_t v = 0;
-	for (int t = 0; t < bc_len; ++t) v = v << 2 | ((code >> (3 * t)) & 3u);
-	bc[i] = v;
-}
-
 // ---- memory kept from bucket to bucket: hipFree waits for the whole device (the engine's streams included), so blocks are reused -------------
-struct Block { void *p = nullptr; size_t cap = 0; };
+struct Block { void *p = nullptr; size_t cap = 0; int device = -1; };      // (device: where a device block lives; page-locked ones serve any)
 struct BlockPool {
 	std::mutex mu;
 	std::vector<Block> idle;
 	bool pinned;
 	explicit BlockPool(bool pin) : pinned(pin) {}
-	hipError_t take(size_t bytes, Block &out)
+	hipError_t take(size_t bytes, Block &out, int device)
 	{
 		{
 			std::lock_guard<std::mutex> lk(mu);
 			int best = -1;
-			for (size_t k = 0; k < idle.size(); ++k) if (idle[k].cap >= bytes && (best < 0 || idle[k].cap < idle[(size_t)best].cap)) best = (int)k;
+			for (size_t k = 0; k < idle.size(); ++k)
+				if (idle[k].cap >= bytes && (pinned || idle[k].device == device) && (best < 0 || idle[k].cap < idle[(size_t)best].cap)) best = (int)k;
 			if (best >= 0) { out = idle[(size_t)best]; idle.erase(idle.begin() + best); return hipSuccess; }
 			if (idle.size() >= 6) {      // none fits and the shelf is full: the smallest one makes room
 				size_t small = 0;
@@ -197,6 +66,7 @@ struct BlockPool {
 			}
 		}
 		out.cap = bytes + bytes / 8 + 65536;
+		out.device = device;
 		const hipError_t rc = pinned ? hipHostMalloc(&out.p, out.cap, hipHostMallocDefault) : hipMalloc(&out.p, out.cap);
 		if (rc != hipSuccess) { out.p = nullptr; out.cap = 0; }
 		return rc;
@@ -283,7 +153,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 #define ING(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) { hip_fail(e_, #call); goto done; } } while (0)
 	{
 		ING(hipSetDevice(device));
-		ING(pin_pool().take(len + 64, pin));
+		ING(pin_pool().take(len + 64, pin, device));
 		{   // the file, on the host's threads, straight into page-locked memory
 			std::atomic<int> bad{0};
 			char *buf = (char *)pin.p;
@@ -305,7 +175,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		}
 		lap("pread (page-locked)");
 		ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-		ING(dev_pool().take(len + 64 + 512, txt));
+		ING(dev_pool().take(len + 64 + 512, txt, device));
 		char *d_text = (char *)txt.p;
 		unsigned long long *d_cnt = (unsigned long long *)(d_text + ((len + 64 + 255) & ~(size_t)255));      // [n_nl][select's count][irregular]
 		ING(hipMemcpyAsync(d_text, pin.p, len + 64, hipMemcpyHostToDevice, st));
@@ -327,7 +197,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		(void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)2 * n + 1, rocprim::plus<uint32_t>(), st);
 		const size_t tmp_bytes = std::max(sel_tmp, std::max(sort_tmp, scan_tmp)) + 256;
 		ING(dev_pool().take(Carve::need({(size_t)(n_nl + 1) * 4, (size_t)n * sizeof(Fields), (size_t)n * 8, (size_t)n * 8, (size_t)n * 4, (size_t)n * 4,
-		                                 ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, tmp_bytes, 64}), work));
+		                                 ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, tmp_bytes, 64}), work, device));
 		Carve cw(work.p);
 		uint32_t *d_nl = cw.take<uint32_t>((size_t)n_nl + 1);
 		Fields *d_fields = cw.take<Fields>(n);
@@ -354,7 +224,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		if (irr) { rc = -1001; goto done; }
 		const size_t nb = totals[0], ni = totals[1];      // (each below the file's size: no 32-bit overflow)
 		// the bucket's arrays on the device, and their host copies (all but bases and qualities)
-		ING(dev_pool().take(Carve::need({nb + 8, nb + 8, ni + 8, ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, (size_t)n * 8}), keep));
+		ING(dev_pool().take(Carve::need({nb + 8, nb + 8, ni + 8, ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, (size_t)n * 8}), keep, device));
 		Carve ck(keep.p);
 		char *k_bases = ck.take<char>(nb + 8), *k_quals = ck.take<char>(nb + 8), *k_ids = ck.take<char>(ni + 8);
 		uint32_t *k_off = ck.take<uint32_t>((size_t)2 * n + 1), *k_id_off = ck.take<uint32_t>((size_t)n + 1);

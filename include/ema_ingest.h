@@ -54,7 +54,8 @@ typedef struct ema_bucket {
  * MAX_READ_LEN is 200, include/align.h:61; the engine takes up to 255).  *out is freed with ema_bucket_free(). */
 int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_len, ema_bucket **out);
 
-/* The same with the parsing on the device (csrc/ingest_dev.hip): the file is read into page-locked memory and uploaded as it is;
+/* The same -- read_special_fastq, reference src/align.c:759-806 -- with the parsing on the device (csrc/ingest_dev.hip): the file is read
+ * into page-locked memory and uploaded as it is;
  * line table, field scan with the reader's checks, stable radix sort by barcode, prefix sums and the gather of bases / qualities /
  * names into their sorted places are kernels.  The bucket that comes back is the one ema_bucket_read returns, except that bases and
  * quals stay on the device (bucket->dev; NULL on the host): ema_stream_sam hands them to the engine and to the SAM formatter there.

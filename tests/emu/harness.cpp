@@ -25,6 +25,7 @@ const char *ema_tuning_get(const char *key)
 #include "k_pair.hip"
 #include "k_final.hip"
 #include "k_sam.hip"
+#include "ingest_kernels.hpp"
 
 // per-read capacities of the emulated launches (the strides of the arrays tests/emu_lib.py allocates)
 #define EMU_INTV_CAP 512
@@ -289,6 +290,46 @@ long long emu_sam_format(const SamJob *job, char *text, long long cap)
 	return bad ? -7 : (long long)total;
 }
 int emu_sizeof_sam_job() { return (int)sizeof(SamJob); }
+
+// ingest_kernels.hpp: the bucket reader's kernels on host memory, with the driver's library passes (newline select, radix sort,
+// prefix sums: rocPRIM on the device) done by plain loops here.  Returns the kernels' irregularity flags (0: the bucket is in the
+// caller's arrays, *n_out pairs); bases / quals / ids must hold len bytes each, bc n_cap, off 2 n_cap + 1, id_off n_cap + 1 entries.
+int emu_ingest(const char *text, uint32_t len, int bc_len, uint32_t max_read_len, uint32_t n_cap, uint64_t *bc, uint32_t *off, uint32_t *id_off,
+               char *bases, char *quals, char *ids, uint32_t *n_out)
+{
+	unsigned long long n_nl64 = 0;
+	int irr = 0;
+	*n_out = 0;
+	if (!len) return 0;
+	std::vector<char> t(text, text + len);
+	t.resize((size_t)len + 64, 0);
+	hipLaunchKernelGGL(ema_k_ing_count, dim3((len + 4095u) / 4096u), dim3(256), 0, nullptr, t.data(), len, &n_nl64, &irr);
+	if (irr) return irr;
+	std::vector<uint32_t> nl;
+	for (uint32_t i = 0; i < len; ++i) if (t[i] == '\n') nl.push_back(i);
+	if (nl.size() != n_nl64) return -1;
+	const uint32_t n_nl = (uint32_t)nl.size(), n = n_nl + (t[len - 1] != '\n' ? 1u : 0u);
+	if (n > n_cap) return -2;
+	nl.push_back(0);
+	std::vector<Fields> fields(n);
+	std::vector<uint64_t> codes(n), codes_s(n);
+	std::vector<uint32_t> idx(n), order(n), rlen(2 * (size_t)n + 1), ilen((size_t)n + 1);
+	hipLaunchKernelGGL(ema_k_ing_parse, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, t.data(), len, nl.data(), n_nl, n, bc_len, max_read_len,
+	                   fields.data(), codes.data(), idx.data(), &irr);
+	if (irr) return irr;
+	order = idx;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] < codes[b]; });
+	for (uint32_t i = 0; i < n; ++i) codes_s[i] = codes[order[i]];
+	hipLaunchKernelGGL(ema_k_ing_lens, dim3(n / 256u + 1u), dim3(256), 0, nullptr, order.data(), fields.data(), n, rlen.data(), ilen.data());
+	uint32_t run = 0;
+	for (size_t r = 0; r <= 2 * (size_t)n; ++r) { off[r] = run; run += rlen[r]; }
+	run = 0;
+	for (size_t p = 0; p <= n; ++p) { id_off[p] = run; run += ilen[p]; }
+	hipLaunchKernelGGL(ema_k_ing_gather, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, t.data(), len, nl.data(), n_nl, order.data(), fields.data(), codes_s.data(), n,
+	                   bc_len, off, id_off, bases, quals, ids, bc);
+	*n_out = n;
+	return 0;
+}
 
 // the whole pipeline K1..K4 on host memory (n_reads even: pairs)
 // K4's set-aside path (k_final.hip: K4t / K4r) on host memory: lists, arena and counters; EMU_K4_HEAVY = regions a read must have left

@@ -298,12 +298,37 @@ struct PinPool {
 	std::vector<PinSet *> idle;
 	int refs = 1;          // the engine's + one per set handed out
 	bool closed = false;
+	int n_sets = 0;        // sets made so far (idle or handed out)
+	// Spare sets, page-locked at the sizes of the first batch fetched, so that the pool does not meet its first moment of FOUR or FIVE
+	// batches out at once -- a consumer a little late with ema_batch_free -- in the middle of a stream: page-locking half a gigabyte
+	// takes 100-200 ms, and bench.py saw it as one run in four coming out 5 % slow with one or two long gaps between steps (r05).
+	void prewarm(const PinSet &like, int target)
+	{
+		for (;;) {
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				if (closed || n_sets >= target) return;
+				++n_sets;
+			}
+			PinSet *s = new PinSet();
+			s->pool = this;
+			if (s->cand_off.reserve(like.cand_off.n) != hipSuccess || s->status.reserve(like.status.n) != hipSuccess || s->redone.reserve(like.redone.n) != hipSuccess ||
+			    s->cand.reserve(like.cand.n) != hipSuccess || s->cigar.reserve(like.cigar.n) != hipSuccess) {
+				s->release(); delete s;
+				std::lock_guard<std::mutex> lk(mu);
+				--n_sets;
+				return;      // (no spare then: the pool still works)
+			}
+			std::lock_guard<std::mutex> lk(mu);
+			idle.push_back(s);
+		}
+	}
 	PinSet *take()
 	{
 		std::lock_guard<std::mutex> lk(mu);
 		PinSet *s;
 		if (!idle.empty()) { s = idle.back(); idle.pop_back(); }
-		else { s = new PinSet(); s->pool = this; }
+		else { s = new PinSet(); s->pool = this; ++n_sets; }
 		++refs;
 		return s;
 	}
@@ -436,6 +461,7 @@ struct ema_engine {
 	int merged_cand_per_read = 6, merged_cig_per_read = 24;      // size of the merged set (tuning knobs merged_cand / merged_cigar: the fallback's test)
 	int n_merge_fallbacks = 0;
 	struct PinPool *pin_pool = nullptr;                  // page-locked landing buffers that ARE the batches handed out (below)
+	bool pin_prewarmed = false;
 	struct FetchPin { PinBuf<uint64_t> c_off, g_off; PinBuf<int> status; PinBuf<ema_cand_t> cand; PinBuf<uint32_t> cig; };
 	std::vector<FetchPin> fetch_pin;     // page-locked landing buffers of ema_engine_fetch_ticket, per slice + full tier
 	hipStream_t copy_stream = nullptr, h2d_stream = nullptr;   // device -> host / host -> device copies of the async path (never behind a kernel)
@@ -1434,6 +1460,7 @@ int ema_engine_fetch_ticket(ema_engine_t *e, int ticket, ema_batch_out **out)
 		ok = ok && hipStreamSynchronize(cs) == hipSuccess;
 		if (!ok) return fail("download of a pass's results failed", EMA_EDEVICE);
 		release.now();
+		if (!e->pin_prewarmed) { e->pin_prewarmed = true; e->pin_pool->prewarm(*ps, EMA_MAX_INFLIGHT + 2); }      // (once, behind the first pass fetched)
 		ema_batch_out *o = (ema_batch_out *)calloc(1, sizeof(ema_batch_out));
 		if (!o) return fail("out of host memory", EMA_EDEVICE);
 		o->n_pairs = t.n_pairs; o->n_redone = n_redo; o->n_cigar = (size_t)tot[1];

@@ -307,6 +307,19 @@ def sam_leg(args, eng, batches, workdir, world):
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
         by_stage = stream.host_cpu_seconds()
+        # ... and once more with -d (BASELINE configs[2]: "-d density optimisation on"): the reference draws the optimiser's moves from libc's
+        # rand(), so the barcode groups of a bucket run on ONE host thread, in order (include/ema_clouds.h) -- the cloud stage is then the bound
+        with_d = None
+        try:
+            from ema_amd import clouds as _clouds
+            _clouds.reseed(1500000000)
+            t0d = time.perf_counter()
+            _b, sd = stream.stream_sam(eng, paths * 2, fd, rg_id=b"rg1", continue_cloud_ids=True, density_opt=True)
+            dtd = time.perf_counter() - t0d
+            with_d = {"value": round(2 * n_files * per / dtd, 1), "unit": "pairs/s", "buckets": 2 * n_files, "bad_clouds": int(sum(x["bad_clouds"] for x in sd)),
+                      "what": "the same call with ema_cloud_opts.density_opt = 1 (`ema align -d`): one host thread per bucket in the cloud stage, as the reference's rand() order demands"}
+        except Exception as e:      # noqa: BLE001
+            log(f"[rank 0] bucket files -> SAM text with -d failed: {e}")
         os.close(fd)
         for path in paths:
             os.remove(path)
@@ -321,7 +334,7 @@ def sam_leg(args, eng, batches, workdir, world):
                                   "clouds_em_duplicates": round(sum(s["select_s"] for s in sst), 3), "formatter_and_write": round(sum(s["write_s"] for s in sst), 3)},
                 "host_cpu_seconds_per_million_pairs": round(cpu_s / tot * 1e6, 3), "host_cpus_busy": round(cpu_s / dt, 1),
                 "host_cpu_seconds_per_million_pairs_by_stage": {k: round(v / tot * 1e6, 3) for k, v in by_stage.items()},
-                "sam_lines": int(sum(s["lines"] for s in sst))}
+                "sam_lines": int(sum(s["lines"] for s in sst)), "with_density_optimiser": with_d}
     except Exception as e:      # an extra: never at the cost of the line
         log(f"[rank 0] bucket files -> SAM text leg failed: {e}")
         return None

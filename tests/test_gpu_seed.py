@@ -136,8 +136,7 @@ def test_seed_parity_one_control_pass_per_tick_and_parking(onepass, park, rounds
     _check("two_contigs", 300, 37, "lane", tuning, len1=250, len2=250, n_rate=0.01)
 
 
-@pytest.mark.parametrize("split", ["1", "0"])
-@pytest.mark.parametrize("k", ["", "0", "5", "11"])
+@pytest.mark.parametrize("k,split", [("", "1"), ("0", "1"), ("5", "1"), ("11", "1"), ("", "0"), ("0", "0")])      # (the old form: with and without the table)
 def test_seed_parity_pass_3_in_its_own_kernel_and_inside_k1(k, split, tuning):
     """Pass 3 (bwt_seed_strategy1, the LAST-like seeds) runs as a kernel of its own behind K1 (k_seed_p3.hip, the default) or inside
     K1's machine (tuning knob seed_split3=0, round 4's form): the same interval sets either way, with and without the k-mer table

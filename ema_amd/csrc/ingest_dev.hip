@@ -2,7 +2,8 @@
 // "parallel parse + (GPU) radix sort by barcode").
 //
 // read_special_fastq (reference src/align.c:759-806: count_lines, fgets + strcpy per line, qsort of the lines by
-// strncmp(.., BC_LEN), six copy_until_space calls) for a bucket of 10x-style barcodes (ACGT / acgt, at most 21 bases):
+// strncmp(.., BC_LEN), six copy_until_space calls) for a bucket of 10x-style barcodes (ACGT / acgt, at most 21 bases) or haplotag ones
+// (AxxCxxBxxDxx: the twelve bytes are the sort key as they are, 96 bits in two stable sorts):
 // the file goes into a page-locked buffer with pread() and up as it is; then, all on the device,
 //   1. newline positions (one count, one rocPRIM select) -> the line table;
 //   2. ema_k_ing_parse: one lane per line -- the six fields as copy_until_space finds them (the same scan as host_ingest.cpp's
@@ -15,7 +16,7 @@
 // The bucket that comes back has bc / off / id_off / ids / group_off on the host (the cloud stage's inputs) and bases / quals
 // ON THE DEVICE ONLY (bucket->dev): the engine stages them device-to-device (ema_engine_stage_async_dev) and the SAM formatter
 // (k_sam.hip) reads them where they are -- a read's 300 bytes never cross the host's caches again.
-// Anything irregular -- a line the checks refuse, a NUL or a line of 5000 bytes, haplotag or longer barcodes, a file of 4 GB -- goes to
+// Anything irregular -- a line the checks refuse, a NUL or a line of 5000 bytes, barcodes beyond 21 bases, a file of 4 GB -- goes to
 // the host reader (ema_bucket_read), which owns the error messages and the odd cases: the result is the host reader's either way.
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -128,7 +129,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 	g_dev_err.clear();
 	if (!path || bc_len < 1 || bc_len > 32 || max_read_len < 1 || max_read_len > 4096 || (is_haplotag && bc_len != 12))
 		return ema_bucket_read(path, bc_len, is_haplotag, max_read_len, out);      // (the host reader words the refusal)
-	if (is_haplotag || bc_len > 21) return ema_bucket_read(path, bc_len, is_haplotag, max_read_len, out);
+	if (!is_haplotag && bc_len > 21) return ema_bucket_read(path, bc_len, is_haplotag, max_read_len, out);      // (no platform has such barcodes)
 	EMA_CPU(EMA_CPU_READER);
 	const int fd = open(path, O_RDONLY);
 	struct stat sb;
@@ -193,24 +194,36 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		// scratch for the lines
 		size_t sel_tmp = 0, sort_tmp = 0, scan_tmp = 0;
 		(void)rocprim::select(nullptr, sel_tmp, rocprim::make_counting_iterator<uint32_t>(0), (uint32_t *)nullptr, (size_t *)nullptr, len, IsNewline{d_text}, st);
-		(void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, (unsigned)(3 * bc_len), st);
+		(void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, is_haplotag ? 64u : (unsigned)(3 * bc_len), st);
+		if (is_haplotag) {
+			size_t b32 = 0;
+			(void)rocprim::radix_sort_pairs(nullptr, b32, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u, st);
+			sort_tmp = std::max(sort_tmp, b32);
+		}
 		(void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)2 * n + 1, rocprim::plus<uint32_t>(), st);
 		const size_t tmp_bytes = std::max(sel_tmp, std::max(sort_tmp, scan_tmp)) + 256;
-		ING(dev_pool().take(Carve::need({(size_t)(n_nl + 1) * 4, (size_t)n * sizeof(Fields), (size_t)n * 8, (size_t)n * 8, (size_t)n * 4, (size_t)n * 4,
+		ING(dev_pool().take(Carve::need({(size_t)(n_nl + 1) * 4, (size_t)n * sizeof(Fields), (size_t)n * 8, (size_t)n * 8, (size_t)n * 4, (size_t)n * 4, (size_t)n * 8, (size_t)n * 4, (size_t)n * 4,
 		                                 ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, ((size_t)2 * n + 1) * 4, ((size_t)n + 1) * 4, tmp_bytes, 64}), work, device));
 		Carve cw(work.p);
 		uint32_t *d_nl = cw.take<uint32_t>((size_t)n_nl + 1);
 		Fields *d_fields = cw.take<Fields>(n);
 		uint64_t *d_codes = cw.take<uint64_t>(n), *d_codes_s = cw.take<uint64_t>(n);
 		uint32_t *d_idx = cw.take<uint32_t>(n), *d_order = cw.take<uint32_t>(n);
+		uint64_t *d_pick = cw.take<uint64_t>(n);      // haplotag: the high key words after the first sort
+		uint32_t *d_lo = cw.take<uint32_t>(n), *d_lo_s = cw.take<uint32_t>(n);
 		uint32_t *d_rlen = cw.take<uint32_t>((size_t)2 * n + 1), *d_ilen = cw.take<uint32_t>((size_t)n + 1);
 		uint32_t *d_off = cw.take<uint32_t>((size_t)2 * n + 1), *d_id_off = cw.take<uint32_t>((size_t)n + 1);
 		void *d_tmp = cw.take<char>(tmp_bytes);
 		size_t *d_sel_n = (size_t *)cw.take<char>(64);
 		if (n_nl) { size_t b = tmp_bytes; ING(rocprim::select(d_tmp, b, rocprim::make_counting_iterator<uint32_t>(0), d_nl, d_sel_n, len, IsNewline{d_text}, st)); }
-		hipLaunchKernelGGL(ema_k_ing_parse, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (uint32_t)len, d_nl, n_nl, n, bc_len, (uint32_t)max_read_len,
-		                   d_fields, d_codes, d_idx, d_irr);
-		{ size_t b = tmp_bytes; ING(rocprim::radix_sort_pairs(d_tmp, b, d_codes, d_codes_s, d_idx, d_order, (size_t)n, 0u, (unsigned)(3 * bc_len), st)); }
+		hipLaunchKernelGGL(ema_k_ing_parse, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (uint32_t)len, d_nl, n_nl, n, bc_len, is_haplotag, (uint32_t)max_read_len,
+		                   d_fields, d_codes, d_lo, d_idx, d_irr);
+		if (is_haplotag) {      // a 96-bit key: two stable sorts, the low word first
+			{ size_t b = tmp_bytes; ING(rocprim::radix_sort_pairs(d_tmp, b, d_lo, d_lo_s, d_idx, d_order, (size_t)n, 0u, 32u, st)); }
+			hipLaunchKernelGGL(ema_k_ing_pick, dim3((n + 255) / 256), dim3(256), 0, st, d_codes, d_order, n, d_pick);
+			{ size_t b = tmp_bytes; ING(rocprim::radix_sort_pairs(d_tmp, b, d_pick, d_codes_s, d_order, d_idx, (size_t)n, 0u, 64u, st)); }
+			std::swap(d_order, d_idx);      // (the final order is in what was d_idx)
+		} else { size_t b = tmp_bytes; ING(rocprim::radix_sort_pairs(d_tmp, b, d_codes, d_codes_s, d_idx, d_order, (size_t)n, 0u, (unsigned)(3 * bc_len), st)); }
 		hipLaunchKernelGGL(ema_k_ing_lens, dim3(n / 256 + 1), dim3(256), 0, st, d_order, d_fields, n, d_rlen, d_ilen);
 		{ size_t b = tmp_bytes; ING(rocprim::exclusive_scan(d_tmp, b, d_rlen, d_off, 0u, (size_t)2 * n + 1, rocprim::plus<uint32_t>(), st)); }
 		{ size_t b = tmp_bytes; ING(rocprim::exclusive_scan(d_tmp, b, d_ilen, d_id_off, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st)); }
@@ -231,7 +244,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 		uint64_t *k_bc = ck.take<uint64_t>(n);
 		ING(hipMemcpyAsync(k_off, d_off, ((size_t)2 * n + 1) * 4, hipMemcpyDeviceToDevice, st));
 		ING(hipMemcpyAsync(k_id_off, d_id_off, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, st));
-		hipLaunchKernelGGL(ema_k_ing_gather, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (uint32_t)len, d_nl, n_nl, d_order, d_fields, d_codes_s, n, bc_len,
+		hipLaunchKernelGGL(ema_k_ing_gather, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (uint32_t)len, d_nl, n_nl, d_order, d_fields, d_codes_s, n, bc_len, is_haplotag,
 		                   k_off, k_id_off, k_bases, k_quals, k_ids, k_bc);
 		ING(hipGetLastError());
 		o = (ema_bucket *)calloc(1, sizeof(ema_bucket));

@@ -73,7 +73,8 @@ struct IsNewline {
 
 __global__ void __launch_bounds__(256)
 ema_k_ing_parse(const char *__restrict__ text, uint32_t text_len, const uint32_t *__restrict__ nl, uint32_t n_nl, uint32_t n_lines, int bc_len,
-                uint32_t max_read_len, Fields *__restrict__ fields, uint64_t *__restrict__ codes, uint32_t *__restrict__ idx, int *__restrict__ irregular)
+                int is_haplotag, uint32_t max_read_len, Fields *__restrict__ fields, uint64_t *__restrict__ codes, uint32_t *__restrict__ codes_lo,
+                uint32_t *__restrict__ idx, int *__restrict__ irregular)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_lines) return;
@@ -89,7 +90,13 @@ ema_k_ing_parse(const char *__restrict__ text, uint32_t text_len, const uint32_t
 	bool bad = !six || fl[0] != (uint32_t)bc_len || fl[1] == 0 || fl[1] > kMaxId || fl[2] > max_read_len || fl[4] > max_read_len ||
 	           fl[3] != fl[2] || fl[5] != fl[4];
 	uint64_t code = 0;
-	if (!bad) {
+	uint32_t code_lo = 0;
+	if (!bad && is_haplotag) {
+		// AxxCxxBxxDxx (bc_len 12): the reference sorts the LINES by strncmp over these twelve bytes whatever they are -- the key is the
+		// bytes themselves, big-endian: eight in `code`, four in `code_lo` (two stable sorts, least significant first)
+		for (int j = 0; j < 8; ++j) code = code << 8 | (uint64_t)(unsigned char)s[j];
+		for (int j = 8; j < 12; ++j) code_lo = code_lo << 8 | (uint32_t)(unsigned char)s[j];
+	} else if (!bad) {
 		for (int j = 0; j < bc_len; ++j) {
 			const char ch = s[j];
 			int c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'a' ? 4 : ch == 'c' ? 5 : ch == 'g' ? 6 : ch == 't' ? 7 : -1;
@@ -97,13 +104,14 @@ ema_k_ing_parse(const char *__restrict__ text, uint32_t text_len, const uint32_t
 			code = code << 3 | (uint64_t)c;
 		}
 	}
-	if (bad) { atomicOr(irregular, 2); code = 0; }      // (the host reader takes the bucket; the line still gets its -- empty -- entries: the passes
+	if (bad) { atomicOr(irregular, 2); code = 0; code_lo = 0; }      // (the host reader takes the bucket; the line still gets its -- empty -- entries: the passes
 	else {                                               //  queued behind this one index by them before the flag is looked at)
 		f.id_b = (uint16_t)fb[1]; f.id_l = (uint16_t)fl[1];
 		f.r1_b = (uint16_t)fb[2]; f.r1_l = (uint16_t)fl[2]; f.q1_b = (uint16_t)fb[3];
 		f.r2_b = (uint16_t)fb[4]; f.r2_l = (uint16_t)fl[4]; f.q2_b = (uint16_t)fb[5];
 	}
 	fields[i] = f; codes[i] = code; idx[i] = i;
+	if (is_haplotag) codes_lo[i] = code_lo;
 }
 
 // lengths in sorted order, interleaved for one prefix sum each: rlen[2i], rlen[2i+1] (reads), ilen[i] (name); one zero past the end
@@ -117,6 +125,21 @@ ema_k_ing_lens(const uint32_t *__restrict__ order, const Fields *__restrict__ fi
 	rlen[2 * i] = f.r1_l; rlen[2 * i + 1] = f.r2_l; ilen[i] = f.id_l;
 }
 
+// the high key words in the order the first (low-word) sort left the lines in
+__global__ void __launch_bounds__(256)
+ema_k_ing_pick(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ order1, uint32_t n, uint64_t *__restrict__ out)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) out[i] = codes[order1[i]];
+}
+
+// encode_bc_haplotag (reference src/util.c:63-70): the four two-digit numbers, the reference's int arithmetic whatever the bytes are
+__device__ __forceinline__ uint64_t encode_haplotag(const char *s)
+{
+	const int a = 10 * (s[1] - '0') + (s[2] - '0'), c = 10 * (s[4] - '0') + (s[5] - '0'), b = 10 * (s[7] - '0') + (s[8] - '0'), d = 10 * (s[10] - '0') + (s[11] - '0');
+	return (uint64_t)(uint32_t)((uint32_t)a << 24 | (uint32_t)c << 16 | (uint32_t)b << 8 | (uint32_t)d);
+}
+
 __device__ __forceinline__ void copy_bytes(char *__restrict__ dst, const char *__restrict__ src, uint32_t n)
 {
 	uint32_t k = 0;
@@ -126,7 +149,8 @@ __device__ __forceinline__ void copy_bytes(char *__restrict__ dst, const char *_
 
 __global__ void __launch_bounds__(256)
 ema_k_ing_gather(const char *__restrict__ text, uint32_t text_len, const uint32_t *__restrict__ nl, uint32_t n_nl, const uint32_t *__restrict__ order,
-                 const Fields *__restrict__ fields, const uint64_t *__restrict__ codes_sorted, uint32_t n, int bc_len, const uint32_t *__restrict__ off,
+                 const Fields *__restrict__ fields, const uint64_t *__restrict__ codes_sorted, uint32_t n, int bc_len, int is_haplotag,
+                 const uint32_t *__restrict__ off,
                  const uint32_t *__restrict__ id_off, char *__restrict__ bases, char *__restrict__ quals, char *__restrict__ ids, uint64_t *__restrict__ bc)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -142,6 +166,7 @@ ema_k_ing_gather(const char *__restrict__ text, uint32_t text_len, const uint32_
 	copy_bytes(quals + off[2 * i + 1], s + f.q2_b, f.r2_l);
 	copy_bytes(ids + id_off[i], s + f.id_b, f.id_l);
 	// two bits a base, first base lowest (encode_bc_default, src/util.c:41-61): the low bits of the sort code's digits
+	if (is_haplotag) { bc[i] = encode_haplotag(s); return; }
 	const uint64_t code = codes_sorted[i];
 	uint64_t v = 0;
 	for (int t = 0; t < bc_len; ++t) v = v << 2 | ((code >> (3 * t)) & 3u);

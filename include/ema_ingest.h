@@ -59,7 +59,7 @@ int ema_bucket_read(const char *path, int bc_len, int is_haplotag, int max_read_
  * line table, field scan with the reader's checks, stable radix sort by barcode, prefix sums and the gather of bases / qualities /
  * names into their sorted places are kernels.  The bucket that comes back is the one ema_bucket_read returns, except that bases and
  * quals stay on the device (bucket->dev; NULL on the host): ema_stream_sam hands them to the engine and to the SAM formatter there.
- * Whatever the kernels do not take -- haplotag or longer-than-21 barcodes, a line the checks refuse, a NUL byte, 4 GB of text -- is
+ * 10x-style and haplotag barcodes.  Whatever the kernels do not take -- a line the checks refuse, a NUL byte, 4 GB of text -- is
  * read by ema_bucket_read instead (then bases / quals are host arrays and dev is NULL): same result, same error texts. */
 int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int max_read_len, int device, ema_bucket **out);
 /* bases / quals of a device-resident bucket copied to the caller's arrays (off[2 * n_pairs] bytes each); EMA_EARG if dev is NULL */

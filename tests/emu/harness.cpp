@@ -294,7 +294,7 @@ int emu_sizeof_sam_job() { return (int)sizeof(SamJob); }
 // ingest_kernels.hpp: the bucket reader's kernels on host memory, with the driver's library passes (newline select, radix sort,
 // prefix sums: rocPRIM on the device) done by plain loops here.  Returns the kernels' irregularity flags (0: the bucket is in the
 // caller's arrays, *n_out pairs); bases / quals / ids must hold len bytes each, bc n_cap, off 2 n_cap + 1, id_off n_cap + 1 entries.
-int emu_ingest(const char *text, uint32_t len, int bc_len, uint32_t max_read_len, uint32_t n_cap, uint64_t *bc, uint32_t *off, uint32_t *id_off,
+int emu_ingest(const char *text, uint32_t len, int bc_len, int is_haplotag, uint32_t max_read_len, uint32_t n_cap, uint64_t *bc, uint32_t *off, uint32_t *id_off,
                char *bases, char *quals, char *ids, uint32_t *n_out)
 {
 	unsigned long long n_nl64 = 0;
@@ -313,12 +313,12 @@ int emu_ingest(const char *text, uint32_t len, int bc_len, uint32_t max_read_len
 	nl.push_back(0);
 	std::vector<Fields> fields(n);
 	std::vector<uint64_t> codes(n), codes_s(n);
-	std::vector<uint32_t> idx(n), order(n), rlen(2 * (size_t)n + 1), ilen((size_t)n + 1);
-	hipLaunchKernelGGL(ema_k_ing_parse, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, t.data(), len, nl.data(), n_nl, n, bc_len, max_read_len,
-	                   fields.data(), codes.data(), idx.data(), &irr);
+	std::vector<uint32_t> idx(n), order(n), lo(n), rlen(2 * (size_t)n + 1), ilen((size_t)n + 1);
+	hipLaunchKernelGGL(ema_k_ing_parse, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, t.data(), len, nl.data(), n_nl, n, bc_len, is_haplotag, max_read_len,
+	                   fields.data(), codes.data(), lo.data(), idx.data(), &irr);
 	if (irr) return irr;
 	order = idx;
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] < codes[b]; });
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] != codes[b] ? codes[a] < codes[b] : (is_haplotag && lo[a] < lo[b]); });
 	for (uint32_t i = 0; i < n; ++i) codes_s[i] = codes[order[i]];
 	hipLaunchKernelGGL(ema_k_ing_lens, dim3(n / 256u + 1u), dim3(256), 0, nullptr, order.data(), fields.data(), n, rlen.data(), ilen.data());
 	uint32_t run = 0;
@@ -326,7 +326,7 @@ int emu_ingest(const char *text, uint32_t len, int bc_len, uint32_t max_read_len
 	run = 0;
 	for (size_t p = 0; p <= n; ++p) { id_off[p] = run; run += ilen[p]; }
 	hipLaunchKernelGGL(ema_k_ing_gather, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, t.data(), len, nl.data(), n_nl, order.data(), fields.data(), codes_s.data(), n,
-	                   bc_len, off, id_off, bases, quals, ids, bc);
+	                   bc_len, is_haplotag, off, id_off, bases, quals, ids, bc);
 	*n_out = n;
 	return 0;
 }

@@ -15,23 +15,23 @@ from ema_amd import ingest
 from test_ingest import make_bucket
 
 
-def emu_read(text, bc_len=16, max_read_len=255):
+def emu_read(text, bc_len=16, max_read_len=255, haplotag=False):
     L = emu_lib.lib()
     L.emu_ingest.restype = C.c_int
-    L.emu_ingest.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.POINTER(C.c_uint32)]
+    L.emu_ingest.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.POINTER(C.c_uint32)]
     cap = text.count(b"\n") + 2
     bc, off, id_off = np.zeros(cap, np.uint64), np.zeros(2 * cap + 1, np.uint32), np.zeros(cap + 1, np.uint32)
     bases, quals, ids = (np.zeros(len(text) + 8, np.uint8) for _ in range(3))
     n = C.c_uint32()
-    rc = L.emu_ingest(text, len(text), bc_len, max_read_len, cap, bc.ctypes.data, off.ctypes.data, id_off.ctypes.data, bases.ctypes.data,
+    rc = L.emu_ingest(text, len(text), bc_len, int(haplotag), max_read_len, cap, bc.ctypes.data, off.ctypes.data, id_off.ctypes.data, bases.ctypes.data,
                       quals.ctypes.data, ids.ctypes.data, C.byref(n))
     n = n.value
     return rc, dict(bc=bc[:n], off=off[:2 * n + 1], id_off=id_off[:n + 1], bases=bases[:off[2 * n]], quals=quals[:off[2 * n]], ids=ids[:id_off[n]])
 
 
-def same(text, bc_len=16):
-    want = ingest.parse_bucket(text, bc_len)
-    rc, got = emu_read(text, bc_len)
+def same(text, bc_len=16, haplotag=False):
+    want = ingest.parse_bucket(text, bc_len, haplotag)
+    rc, got = emu_read(text, bc_len, haplotag=haplotag)
     assert rc == 0
     for name, arr in got.items():
         assert np.array_equal(arr, getattr(want, name)), name
@@ -50,6 +50,8 @@ def test_interpreted_kernels_equal_the_host_reader():
     same(make_bucket(rng, 100, bc_len=20), 20)
     same(make_bucket(rng, 40, bc_len=3), 3)
     same(make_bucket(rng, 1))
+    same(make_bucket(rng, 150, bc_len=12, haplotag=True), 12, True)      # the twelve bytes as the key: two stable sorts on the device
+    same(make_bucket(random.Random(3), 60, bc_len=12, haplotag=True).replace(b"A0", b"Ax"), 12, True)      # ... whatever the bytes are (the reference's macros)
 
 
 @pytest.mark.parametrize("bad", [

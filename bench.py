@@ -308,7 +308,7 @@ def sam_leg(args, eng, batches, workdir, world):
         cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
         by_stage = stream.host_cpu_seconds()
         # ... and once more with -d (BASELINE configs[2]: "-d density optimisation on"): the reference draws the optimiser's moves from libc's
-        # rand(), so the barcode groups of a bucket run on ONE host thread, in order (include/ema_clouds.h) -- the cloud stage is then the bound
+        # rand(), so the barcode groups with a bad cloud run on ONE host thread, in order, after the others (include/ema_clouds.h)
         with_d = None
         try:
             from ema_amd import clouds as _clouds
@@ -317,7 +317,7 @@ def sam_leg(args, eng, batches, workdir, world):
             _b, sd = stream.stream_sam(eng, paths * 2, fd, rg_id=b"rg1", continue_cloud_ids=True, density_opt=True)
             dtd = time.perf_counter() - t0d
             with_d = {"value": round(2 * n_files * per / dtd, 1), "unit": "pairs/s", "buckets": 2 * n_files, "bad_clouds": int(sum(x["bad_clouds"] for x in sd)),
-                      "what": "the same call with ema_cloud_opts.density_opt = 1 (`ema align -d`): one host thread per bucket in the cloud stage, as the reference's rand() order demands"}
+                      "what": "the same call with ema_cloud_opts.density_opt = 1 (`ema align -d`): the groups with a bad cloud on one host thread in order (the reference's rand() order), the others on all"}
         except Exception as e:      # noqa: BLE001
             log(f"[rank 0] bucket files -> SAM text with -d failed: {e}")
         os.close(fd)

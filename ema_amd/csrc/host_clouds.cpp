@@ -345,13 +345,16 @@ void mark_optimal_alignments_in_cloud(Work &w, const Shared &S, const std::vecto
 	for (size_t i = 0; i < n_mmaps; i++) R(records[mmaps[i].idx + (size_t)mmaps[i].active]).active = 1;
 }
 
-// one barcode group: pairs [p0, p1), records [r0, r1) of ema_aln_out
-void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, uint64_t r1)
+// one barcode group: pairs [p0, p1), records [r0, r1) of ema_aln_out.  may_draw (-d only): this call may reach the density optimiser,
+// i.e. libc's rand(); a call that may not returns false at the group's first bad cloud, having written nothing (the caller runs
+// such groups afterwards, in group order, on one thread: groups without a bad cloud draw nothing, so the draws fall exactly as in
+// a one-thread run over all groups -- the reference's `-t 1`)
+bool do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, uint64_t r1, bool may_draw)
 {
 	const ema_bucket *bk = S.bk;
 	const size_t n = (size_t)(r1 - r0), n_pairs = p1 - p0;
 	S.n_sel[g] = 0; S.n_clouds[g] = 0; S.n_bad[g] = 0;
-	if (n == 0) return;
+	if (n == 0) return true;
 	// read names of the group (the identifier field without its first character, src/align.c:925-929), ranked in strcmp order
 	w.names.resize(n_pairs);
 	for (size_t p = p0; p < p1; ++p) {
@@ -412,6 +415,7 @@ void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 			++cov;
 		}
 		if (collision) {      // two candidates of one read in this cloud: re-enter it by read name, every record forced in
+			if (S.o.density_opt && !may_draw) { S.n_bad[g] = 0; return false; }
 			w.clouds[(size_t)ci].bad = 1;
 			++S.n_bad[g];
 			w.split.assign(w.ord.begin() + (long)at, w.ord.begin() + (long)(at + cov));
@@ -527,6 +531,7 @@ void do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 		}
 	}
 	S.n_sel[g] = n_out;
+	return true;
 }
 
 int n_host_threads(int want)
@@ -583,6 +588,7 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 	S.n_sel.assign(n_groups + 1, 0); S.n_clouds.assign(n_groups + 1, 0); S.n_bad.assign(n_groups + 1, 0);
 	{   // barcode groups over the host's threads, a few at a time from a shared counter
 		std::atomic<size_t> next{0};
+		std::vector<uint8_t> deferred(S.o.density_opt ? n_groups : 0, 0);
 		auto run = [&] {
 			EMA_CPU(EMA_CPU_CLOUDS);
 			Work w;
@@ -591,13 +597,21 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 				if (g0 >= n_groups) break;
 				for (size_t g = g0; g < g0 + 8 && g < n_groups; ++g) {
 					const size_t p0 = bk->group_off[g], p1 = bk->group_off[g + 1];
-					do_group(w, S, g, p0, p1, a->pair_off[p0], a->pair_off[p1]);
+					if (!do_group(w, S, g, p0, p1, a->pair_off[p0], a->pair_off[p1], !S.o.density_opt)) deferred[g] = 1;
 				}
 			}
 		};
-		// -d draws from libc's rand(): one thread, groups in order, so that the draws fall as in a `-t 1` run of the reference
-		const int nt = S.o.density_opt ? 1 : (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 16 + 1);
+		const int nt = (int)std::min<size_t>((size_t)n_host_threads(S.o.n_threads), n_groups / 16 + 1);
 		EmaPool::get().run((size_t)nt, [&](size_t) { run(); });
+		// -d draws from libc's rand(): the groups that reach the optimiser (the ones with a bad cloud: few) run here, on one thread, in
+		// order, so that the draws fall as in a `-t 1` run of the reference.  (Until r05 every group of a -d run went this way.)
+		if (S.o.density_opt) {
+			Work w;
+			for (size_t g = 0; g < n_groups; ++g) if (deferred[g]) {
+				const size_t p0 = bk->group_off[g], p1 = bk->group_off[g + 1];
+				(void)do_group(w, S, g, p0, p1, a->pair_off[p0], a->pair_off[p1], true);
+			}
+		}
 	}
 	// assembly: cloud numbers of a single-threaded run, the selected records as formatter input, statistics -- on the host's threads
 	// as well (round 2 did this part on one: more than half of the stage's wall time, r03): the offsets of every group's records

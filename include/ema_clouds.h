@@ -42,8 +42,9 @@ typedef struct {
 	/* `ema align -d` (src/split.c:38-338, hook at src/align.c:396-397): in a cloud with a read-name collision, simulated annealing over
 	 * the multi-mapped reads' alignments against the platform's read-density model decides which alignments stay `active`.  The
 	 * reference draws its moves from libc's rand(), seeded ONCE per process from time(); this library draws from the same rand(), so the
-	 * result equals the reference's for the same seed (ema_clouds_reseed) and the same order of work -- with density_opt the barcode
-	 * groups therefore run on ONE thread, in order (the reference's own -d under -t N is not reproducible either: SURVEY 0.5-1) */
+	 * result equals the reference's for the same seed (ema_clouds_reseed) and the same order of work: the barcode groups that reach the
+	 * optimiser (the ones with a bad cloud) run on ONE thread, in group order, after the others -- which draw nothing and run on the
+	 * host's threads as without -d -- so the draws fall as in a `-t 1` run (the reference's own -d under -t N is not reproducible: SURVEY 0.5-1) */
 	int32_t density_opt;      /* -d */
 	int32_t n_density_probs;  /* tech->n_density_probs, tech->density_probs (src/techs.c:74-127): 4 x {0.6, 0.05, 0.2, 0.01} for 10x */
 	double density_probs[16];

@@ -179,6 +179,34 @@ def test_threaded_equals_single_thread(tmp_path):
     assert texts[0] == texts[1] and texts[0].count(b"\n") > 2500
 
 
+def test_density_optimiser_on_many_threads_draws_as_on_one(tmp_path):
+    """-d draws from libc's rand().  The groups that reach the optimiser (a bad cloud) run on one thread, in group order, AFTER the
+    others, which run on all threads: the text must be what one thread over all groups in order writes -- and what the oracle's -d
+    (oracle/clouds.c, pinned to the reference's golden SAM by tests/test_golden_sam.py) writes with the same seed."""
+    prefix, ctg, bucket = make_bucket(tmp_path, "exact_dups", 1600, 109, 30, sub_rate=0.004, dup_frac=0.0)
+    ordered = synth.Pairs(bucket.bases, bucket.off)
+    batch = batch_from_oracle(prefix, ordered)
+    rec, pair_off = E.append_alignments(batch, bucket.off)
+    names = [f"chr{i + 1}".encode() for i in range(len(ctg))]
+    texts, stats = [], []
+    for nt, d in ((1, 1), (7, 1), (7, 0)):
+        co = clouds.default_opts()
+        co.n_threads, co.density_opt = nt, d
+        clouds.reseed(4242)
+        sel = clouds.select(bucket, batch, rec, pair_off, names, co)
+        texts.append(sam.format_lines(sel.lines, sel.n_lines, sam.default_opts()))
+        stats.append(sel.stats)
+    assert stats[0]["groups"] > 40 and stats[0]["bad_clouds"] > 5
+    assert texts[0] == texts[1]
+    assert texts[0] != texts[2], "-d changed nothing: the test has no teeth"
+    O.clouds_density(True, seed=4242)
+    try:
+        arr, n, keep, rows, next_id = oracle_selection(bucket, batch, rec, pair_off, names)
+        assert texts[1] == oracle_text(arr, n, sam.default_opts())
+    finally:
+        O.clouds_density(False)
+
+
 def test_cloud_numbers_continue_across_buckets(tmp_path):
     prefix, ctg, bucket = make_bucket(tmp_path, "two_contigs", 200, 107, 40)
     ordered = synth.Pairs(bucket.bases, bucket.off)

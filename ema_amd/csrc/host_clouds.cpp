@@ -93,6 +93,8 @@ struct Work {
 	std::vector<int32_t> ent_of;      // (rank, mate) -> entry
 	std::vector<Name> names;
 	std::vector<int32_t> rank_of_pair;
+	std::vector<double> log_weight;      // EM: log of a cloud's weight, taken once per round
+	std::vector<uint8_t> have_log_weight;
 };
 
 struct Shared {
@@ -443,12 +445,19 @@ bool do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 	// EM (src/align.c:432-525)
 	const bool full_em = n_pairs >= 30;
 	std::vector<double> cw;
+	// (two savings that change no bit: a read with ONE candidate has gamma 1 whatever its score, cloud weight and mate say -- normalize_log_probs
+	// of one value -- so the round's arithmetic is skipped for it; and a cloud's log(weight), constant within a round, is taken once)
+	std::vector<double> &lw = w.log_weight;
+	std::vector<uint8_t> &have_lw = w.have_log_weight;
+	lw.resize(nc); have_lw.resize(nc);
 	for (int q = 0; q < kEmIters && full_em; q++) {
 		for (size_t i = 0; i < nc; i++) cl[i].exp_cov = 0.0;
+		std::fill(have_lw.begin(), have_lw.end(), (uint8_t)0);
 		for (size_t k = w.n_ents; k-- > 0;) {
 			Entry &e = w.ents[k];
 			const Entry *m = e.mate >= 0 ? &w.ents[(size_t)e.mate] : nullptr;
 			const size_t num = e.c.size();
+			if (num == 1) { e.c[0].gamma = 1.0; continue; }
 			if (S.o.many_clouds) {      // with many clouds the weights are normalised per read
 				cw.resize(num);
 				double tot = 0;
@@ -463,12 +472,19 @@ bool do_group(Work &w, Shared &S, size_t g, size_t p0, size_t p1, uint64_t r0, u
 						const Rec &rj = w.recs[(size_t)mc.rec];
 						if (rj.chrom == ri.chrom && rj.rev != ri.rev && mc.cloud == e.c[i].cloud && mc.gamma != 0.0) {
 							const double penalty = ri.rev ? mate_dist_penalty(ri.pos, rj.pos) : mate_dist_penalty(rj.pos, ri.pos);
-							const double mate_score = penalty + std::log(mc.gamma);
+							const double mate_score = penalty + (mc.gamma == 1.0 ? 0.0 : std::log(mc.gamma));      // (log(1.0) is +0.0: the mate with one candidate)
 							if (mate_score > best_mate_score) best_mate_score = mate_score;
 						}
 					}
 				}
-				e.c[i].gamma = ri.score + (S.o.many_clouds ? std::log(cw[i]) : std::log(cl[(size_t)e.c[i].cloud].weight)) + best_mate_score;
+				double log_w;
+				if (S.o.many_clouds) log_w = std::log(cw[i]);
+				else {
+					const size_t ci = (size_t)e.c[i].cloud;
+					if (!have_lw[ci]) { lw[ci] = std::log(cl[ci].weight); have_lw[ci] = 1; }
+					log_w = lw[ci];
+				}
+				e.c[i].gamma = ri.score + log_w + best_mate_score;
 			}
 			normalize_log_probs(e.c);
 		}

@@ -200,25 +200,26 @@ __device__ __forceinline__ int ema_wave_sum(int v) { return __builtin_amdgcn_rea
 // semantics; reference path: src/bwabridge.c:236 -> mem_align1_core -> bwt_extend), `pos` in the with-sentinel row
 // space.  The lane fetches the 32-byte block with two 16-byte loads and does the popcounts itself, so a wavefront
 // keeps 64 independent searches in flight and needs no cross-lane traffic.
-__device__ __forceinline__ void ema_lane_occ4(const DevIndex &ix, uint64_t pos, uint64_t cnt[4])
+//
+// [r6] The block's 64 symbols are two BIT PLANES (dev_types.h): word 0 = the symbols' low bits, word 1 = their high bits, symbol t at
+// bit t of both.  Counting the symbols 0..r is one mask and three population counts -- low bits, high bits, both -- from which the
+// four counts follow by subtraction: with the symbols as 2-bit codes side by side (rounds 1-5) the same query took a 64-bit mask
+// per word and nine masked population counts, ~95 vector instructions per block against ~20.
+__device__ __forceinline__ void ema_occ_planes(uint64_t lo, uint64_t hi, int r, unsigned &pl, unsigned &ph, unsigned &p3)
 {
-	const uint64_t p = pos - (pos >= ix.primary ? 1 : 0);   // '$' is not stored
-	const OccBlock *blk = ix.occ + (p >> 6);
-	const uint4 head = *reinterpret_cast<const uint4 *>(blk);
-	const ulong2 sym = *(reinterpret_cast<const ulong2 *>(blk) + 1);
+	const uint64_t m = (2ULL << r) - 1;      // positions 0..r (r = 63: 2 << 63 wraps to 0, minus one = all of them)
+	lo &= m; hi &= m;
+	pl = (unsigned)__popcll(lo); ph = (unsigned)__popcll(hi); p3 = (unsigned)__popcll(lo & hi);
+}
+// the arithmetic of ema_lane_occ4 on a block that is already in registers (head = the four counts, sym4 = the two planes):
+// p = the row with the sentinel taken out
+__device__ __forceinline__ void ema_occ4_decode(const DevIndex &ix, uint64_t p, const uint4 &head, const uint4 &sym4, uint64_t cnt[4])
+{
 	const int r = (int)(p & 63);
-	unsigned c1 = 0, c2 = 0, c3 = 0;
-	const uint64_t w[2] = {sym.x, sym.y};
-#pragma unroll
-	for (int j = 0; j < 2; ++j) {
-		int nvalid = r + 1 - (j << 5);
-		nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
-		const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
-		const uint64_t lo = w[j] & m55, hi = (w[j] >> 1) & m55;
-		c3 += __popcll(hi & lo); c2 += __popcll(hi & ~lo); c1 += __popcll(~hi & lo);
-	}
-	const unsigned c0 = (unsigned)(r + 1) - c1 - c2 - c3;
-	cnt[0] = (uint64_t)head.x + c0; cnt[1] = (uint64_t)head.y + c1; cnt[2] = (uint64_t)head.z + c2; cnt[3] = (uint64_t)head.w + c3;
+	unsigned pl, ph, p3;
+	ema_occ_planes((uint64_t)sym4.y << 32 | sym4.x, (uint64_t)sym4.w << 32 | sym4.z, r, pl, ph, p3);
+	cnt[0] = (uint64_t)head.x + ((unsigned)(r + 1) - pl - ph + p3); cnt[1] = (uint64_t)head.y + (pl - p3);
+	cnt[2] = (uint64_t)head.z + (ph - p3); cnt[3] = (uint64_t)head.w + p3;
 	if (ix.n_super > 1) {      // wave-uniform: only references beyond 2^31 BWT symbols have more than one superblock
 		const int sb = (int)(p >> EMA_OCC_SUPER_SHIFT);
 #pragma unroll
@@ -226,33 +227,17 @@ __device__ __forceinline__ void ema_lane_occ4(const DevIndex &ix, uint64_t pos, 
 			cnt[c] += sb == 0 ? 0 : sb == 1 ? ix.occ_super[0][c] : sb == 2 ? ix.occ_super[1][c] : ix.occ_super[2][c];
 	}
 }
-
-// the arithmetic of ema_lane_occ4 on a block that is already in registers (head = the four counts, sym = the 64 symbols):
-// p = the row with the sentinel taken out
-__device__ __forceinline__ void ema_occ4_decode(const DevIndex &ix, uint64_t p, const uint4 &head, const uint4 &sym4, uint64_t cnt[4])
+__device__ __forceinline__ void ema_lane_occ4(const DevIndex &ix, uint64_t pos, uint64_t cnt[4])
 {
-	const int r = (int)(p & 63);
-	unsigned c1 = 0, c2 = 0, c3 = 0;
-	const uint64_t w[2] = {(uint64_t)sym4.y << 32 | sym4.x, (uint64_t)sym4.w << 32 | sym4.z};
-#pragma unroll
-	for (int j = 0; j < 2; ++j) {
-		int nvalid = r + 1 - (j << 5);
-		nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
-		const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
-		const uint64_t lo = w[j] & m55, hi = (w[j] >> 1) & m55;
-		c3 += __popcll(hi & lo); c2 += __popcll(hi & ~lo); c1 += __popcll(~hi & lo);
-	}
-	const unsigned c0 = (unsigned)(r + 1) - c1 - c2 - c3;
-	cnt[0] = (uint64_t)head.x + c0; cnt[1] = (uint64_t)head.y + c1; cnt[2] = (uint64_t)head.z + c2; cnt[3] = (uint64_t)head.w + c3;
-	if (ix.n_super > 1) {
-		const int sb = (int)(p >> EMA_OCC_SUPER_SHIFT);
-#pragma unroll
-		for (int c = 0; c < 4; ++c)
-			cnt[c] += sb == 0 ? 0 : sb == 1 ? ix.occ_super[0][c] : sb == 2 ? ix.occ_super[1][c] : ix.occ_super[2][c];
-	}
+	const uint64_t p = pos - (pos >= ix.primary ? 1 : 0);   // '$' is not stored
+	const OccBlock *blk = ix.occ + (p >> 6);
+	const uint4 head = *reinterpret_cast<const uint4 *>(blk);
+	const uint4 sym = *(reinterpret_cast<const uint4 *>(blk) + 1);
+	ema_occ4_decode(ix, p, head, sym, cnt);
 }
 
-// bwt_extend for one symbol by one lane; arguments as in ema_group8_extend
+// bwt_extend for one symbol by one lane: x_nb = the coordinate the rank queries are made on (k for a backward extension, k' for a
+// forward one), x_b = the other, c = the symbol (complemented by the caller for a forward extension)
 __device__ __forceinline__ void ema_lane_extend(const DevIndex &ix, uint64_t x_nb, uint64_t x_b, uint64_t size, int c,
                                                 uint64_t &o_nb, uint64_t &o_b, uint64_t &o_size)
 {
@@ -268,15 +253,71 @@ __device__ __forceinline__ void ema_lane_extend(const DevIndex &ix, uint64_t x_n
 	o_nb = ix.L2[cc] + 1 + (cc == 3 ? tk[3] : cc == 2 ? tk[2] : cc == 1 ? tk[1] : tk[0]);
 }
 
-// k-mer interval table (dev_types.h): suffix-array interval of the string with 2-bit code `code` (first base in the high
-// bits) and length L <= ix.kmer_k
+// [r6] bwt_extend for ONE symbol from the two rank blocks in registers -- the lane machines' form (k_seed.hip, k_seed_bwd.hip,
+// k_seed_p3.hip), where a tick's instruction count is what the chip is short of.  bwt_extend derives all four symbols' intervals;
+// the caller keeps one: its size s[cc], the rows of the larger symbols before it (n_gt = s[cc + 1] + .. + s[3], what the untouched
+// coordinate advances by) and its start L2[cc] + 1 + occ(cc, k - 1).  So the sizes stay 32-bit DIFFERENCES of the two blocks'
+// counts (an interval that needs a rank query is far below 2^32 rows, and the superblock bases cancel unless the interval
+// straddles a superblock boundary: a branch no wavefront takes in practice), and the one 64-bit quantity, the start, takes
+// its base -- L2[cc] + 1 + the superblock's count -- from a 16-entry table in LDS (ema_rank_table_init) instead of two chains of selects.
+#define EMA_RANK_TABLE 16
+__device__ __forceinline__ void ema_rank_table_init(const DevIndex &ix, uint64_t *T)      // T: this WAVEFRONT's 16 words of LDS
+{
+	const int t = (int)(threadIdx.x & 63);
+#pragma unroll
+	for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			if (t == sb * 4 + c) T[t] = ix.L2[c] + 1 + (sb ? ix.occ_super[sb ? sb - 1 : 0][c] : 0);
+	ema_wave_sync();
+}
+__device__ __forceinline__ void ema_extend_blocks(const DevIndex &ix, const uint64_t *T, uint64_t qk, uint64_t ql, const uint4 &hk, const uint4 &sk,
+                                                  const uint4 &hl, const uint4 &sl, int cc, uint64_t &o_start, uint32_t &o_size, uint32_t &n_gt)
+{
+	const int rk = (int)(qk & 63), rl = (int)(ql & 63);
+	unsigned plk, phk, p3k, pll, phl, p3l;
+	ema_occ_planes((uint64_t)sk.y << 32 | sk.x, (uint64_t)sk.w << 32 | sk.z, rk, plk, phk, p3k);
+	ema_occ_planes((uint64_t)sl.y << 32 | sl.x, (uint64_t)sl.w << 32 | sl.z, rl, pll, phl, p3l);
+	const uint32_t d3 = p3l - p3k, dh = phl - phk, dl = pll - plk;
+	uint32_t s3 = hl.w - hk.w + d3, s2 = hl.z - hk.z + dh - d3, s1 = hl.y - hk.y + dl - d3, s0 = hl.x - hk.x + (uint32_t)(rl - rk) - dh - dl + d3;
+	int sbk = 0;
+	if (ix.n_super > 1) {      // wave-uniform
+		sbk = (int)(qk >> EMA_OCC_SUPER_SHIFT);
+		const int sbl = (int)(ql >> EMA_OCC_SUPER_SHIFT);
+		if (sbk != sbl) {      // the interval straddles a superblock boundary
+			s0 += (uint32_t)(T[sbl * 4 + 0] - T[sbk * 4 + 0]); s1 += (uint32_t)(T[sbl * 4 + 1] - T[sbk * 4 + 1]);
+			s2 += (uint32_t)(T[sbl * 4 + 2] - T[sbk * 4 + 2]); s3 += (uint32_t)(T[sbl * 4 + 3] - T[sbk * 4 + 3]);
+		}
+	}
+	// (selects on two shared conditions, spelt with masks: left to itself the compiler turns the four-way choices into branches,
+	// and a divergent branch costs a wavefront more than the three selects)
+	const uint32_t odd = 0u - (uint32_t)(cc & 1), top = 0u - (uint32_t)((cc >> 1) & 1);
+	auto sel4 = [&](uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) -> uint32_t {
+		const uint32_t a = (v0 & ~odd) | (v1 & odd), b = (v2 & ~odd) | (v3 & odd);
+		return (a & ~top) | (b & top);
+	};
+	const uint32_t ck = sel4(hk.x + ((uint32_t)(rk + 1) - plk - phk + p3k), hk.y + (plk - p3k), hk.z + (phk - p3k), hk.w + p3k);
+	o_size = sel4(s0, s1, s2, s3);
+	n_gt = sel4(s3 + s2 + s1, s3 + s2, s3, 0u);
+	o_start = T[sbk * 4 + cc] + ck;
+}
+
+// k-mer interval table (dev_types.h): where level L begins, in entries.  (4^L - 1) / 3 is the bit pattern 0101..01 with L ones, so
+// the offsets (4^L - 4) / 3 and (4^L - 4^(EMA_KMER_WIDE + 1)) / 3 are a mask and a subtraction (written as a division the compiler
+// emits a 64-bit multiply-high sequence per look-up, in every tick of the lane machines).  L <= EMA_KMER_MAX = 15: 32 bits hold them.
+__device__ __forceinline__ uint32_t ema_kmer_base_wide(int L) { return (0x55555555u & ((1u << (2 * L)) - 1u)) - 1u; }
+__device__ __forceinline__ uint32_t ema_kmer_base_narrow(int L)
+{
+	return (0x55555555u & ((1u << (2 * L)) - 1u)) - (0x55555555u & ((1u << (2 * (EMA_KMER_WIDE + 1))) - 1u));
+}
+// suffix-array interval of the string with 2-bit code `code` (first base in the high bits) and length L <= ix.kmer_k
 __device__ __forceinline__ void ema_kmer_lookup(const DevIndex &ix, int L, uint32_t code, uint64_t &x0, uint64_t &x2)
 {
 	if (L <= EMA_KMER_WIDE) {
-		const ulong2 e = reinterpret_cast<const ulong2 *>(ix.kmer_wide)[(((size_t)1 << (2 * L)) - 4) / 3 + code];
+		const ulong2 e = reinterpret_cast<const ulong2 *>(ix.kmer_wide)[(size_t)ema_kmer_base_wide(L) + code];
 		x0 = e.x; x2 = e.y;
 	} else {
-		const uint64_t e = ix.kmer_narrow[(((size_t)1 << (2 * L)) - ((size_t)1 << (2 * (EMA_KMER_WIDE + 1)))) / 3 + code];
+		const uint64_t e = ix.kmer_narrow[(size_t)ema_kmer_base_narrow(L) + code];
 		x0 = e & 0xFFFFFFFFFFULL; x2 = e >> 40;
 	}
 }

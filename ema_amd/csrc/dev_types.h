@@ -1,13 +1,7 @@
 // ema_amd/csrc/dev_types.h -- plain structs shared by the host side and the HIP kernels.
 //
 // HBM layout of the index (one replica per GPU):
-//   occ     : 64-byte blocks, one per 128 BWT symbols.  A block is four 16-byte
-//             slots {u64 count_c, u64 bases_c}: count_c = occurrences of symbol c
-//             before the block, bases_c = symbols 32c..32c+31 of the block, 2 bits
-//             each, symbol t of the slot at bits 2t..2t+1.  Four adjacent lanes
-//             read one block with a single 16-byte load each (global_load_dwordx4)
-//             and between them hold all four counters -- one coalesced 64-byte
-//             transaction per occ4 query.
+//   occ     : 32-byte blocks, one per 64 BWT symbols (OccBlock below): four counts + the symbols as two bit planes.
 //   sa      : the whole suffix array (seq_len+1 rows, 4 or 8 bytes each): locating
 //             an occurrence is one load.
 //   pac     : forward strand, bwa's byte layout (4 bases/byte, first base in the
@@ -20,8 +14,9 @@
 
 // FM-index rank structure in HBM: one 32-byte block per 64 BWT symbols -- the number of A/C/G/T before the block
 // (relative to the block's superblock of 2^31 symbols, whose absolute counts ride in DevIndex) and the 64 symbols
-// themselves, 2 bit each (symbol t of the block at bits 2(t%32) of bases[t/32]).  One occ4 query = one block = two
-// 16-byte loads by the querying lane.
+// themselves as two bit planes: bit t of bases[0] = the low bit of symbol t's 2-bit code, bit t of bases[1] = its high
+// bit ([r6]; rounds 1-5 kept the codes side by side, which cost the rank query a mask and three masked population counts
+// per 32 symbols -- dev_common.hpp, ema_occ_planes).  One occ4 query = one block = two 16-byte loads by the querying lane.
 struct OccBlock { uint32_t cnt[4]; uint64_t bases[2]; };
 #ifndef EMA_OCC_SUPER_SHIFT
 #define EMA_OCC_SUPER_SHIFT 31      // (a test build of the host interpreter lowers it to exercise several superblocks on a small reference)

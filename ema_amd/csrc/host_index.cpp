@@ -72,9 +72,9 @@ void host_expand_sa(HostIndex &ix)
 		const uint64_t p = k - (k > ix.primary ? 1 : 0);
 		const OccBlock &b = ix.occ[p >> 6];
 		const int r = (int)(p & 63);
-		const unsigned c = (unsigned)(b.bases[r >> 5] >> ((r & 31) << 1)) & 3u;
-		uint64_t cnt = b.cnt[c];
-		for (int t = 0; t <= r; ++t) cnt += ((b.bases[t >> 5] >> ((t & 31) << 1)) & 3u) == c;
+		const unsigned c = (unsigned)((b.bases[0] >> r) & 1u) | (unsigned)((b.bases[1] >> r) & 1u) << 1;      // two bit planes (dev_types.h)
+		const uint64_t m = (2ULL << r) - 1, lo = c & 1 ? b.bases[0] : ~b.bases[0], hi = c & 2 ? b.bases[1] : ~b.bases[1];
+		uint64_t cnt = b.cnt[c] + (uint64_t)__builtin_popcountll(lo & hi & m);
 		const uint64_t sb = p >> EMA_OCC_SUPER_SHIFT;
 		if (sb > 0) cnt += ix.occ_super[sb - 1][c];
 		return ix.L2[c] + cnt;
@@ -147,7 +147,7 @@ std::string host_index_load(const std::string &prefix, HostIndex &ix, bool with_
 						if (pos >= ix.seq_len) break;
 						const int tt = half * 64 + t2;
 						const unsigned sym = w[b * 16 + 8 + (tt >> 4)] >> ((~tt & 15) << 1) & 3;
-						o.bases[t2 >> 5] |= (uint64_t)sym << ((t2 & 31) << 1);
+						o.bases[0] |= (uint64_t)(sym & 1) << t2; o.bases[1] |= (uint64_t)(sym >> 1) << t2;      // two bit planes (dev_types.h)
 						++running[sym];
 					}
 				}

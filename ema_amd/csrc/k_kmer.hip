@@ -86,18 +86,10 @@ ema_k_sa_expand(DevIndex ix, const uint64_t *__restrict__ sampled, int shift, vo
 			const uint4 head = *reinterpret_cast<const uint4 *>(blk);
 			const ulong2 sym = *(reinterpret_cast<const ulong2 *>(blk) + 1);
 			const int q = (int)(p & 63);
-			const unsigned c = (unsigned)((q < 32 ? sym.x : sym.y) >> ((q & 31) << 1)) & 3u;
-			// positions 0..q of the block holding symbol c: the two bit planes matched against c, cut after position q
-			const uint64_t w[2] = {sym.x, sym.y};
-			unsigned cnt = 0;
-#pragma unroll
-			for (int j = 0; j < 2; ++j) {
-				int nvalid = q + 1 - (j << 5);
-				nvalid = nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid);
-				const uint64_t m55 = nvalid == 32 ? 0x5555555555555555ULL : (((1ULL << (2 * nvalid)) - 1) & 0x5555555555555555ULL);
-				const uint64_t lo = (c & 1 ? w[j] : ~w[j]) & m55, hi = ((c & 2 ? w[j] : ~w[j]) >> 1) & m55;
-				cnt += (unsigned)__popcll(lo & hi);
-			}
+			// the symbol at position q and how many of positions 0..q hold it: the two bit planes matched against it
+			const unsigned c = (unsigned)((sym.x >> q) & 1u) | (unsigned)((sym.y >> q) & 1u) << 1;
+			const uint64_t m = (2ULL << q) - 1;
+			const unsigned cnt = (unsigned)__popcll((c & 1 ? sym.x : ~sym.x) & (c & 2 ? sym.y : ~sym.y) & m);
 			uint64_t total = (uint64_t)(c == 0 ? head.x : c == 1 ? head.y : c == 2 ? head.z : head.w) + cnt;
 			if (ix.n_super > 1) {
 				const int sb = (int)(p >> EMA_OCC_SUPER_SHIFT);

@@ -39,8 +39,11 @@ ema_k_seed_p3(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, cons
 {
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
 	__shared__ uint32_t lds_n[4][8 * 64];       // N mask, 8 words per lane
+	__shared__ uint64_t lds_rt[4][EMA_RANK_TABLE];      // ema_extend_blocks' bases, one copy per wavefront
 	const int lane = (int)(threadIdx.x & 63), wib = ema_uni((int)(threadIdx.x >> 6));
 	const uint32_t *qw = lds_q[wib] + lane, *nm = lds_n[wib] + lane;
+	const uint64_t *rt = lds_rt[wib];
+	ema_rank_table_init(ix, lds_rt[wib]);
 	const int n_tasks = ema_work_count(n_reads, n_pairs_dev, 2);
 	const int kk = ix.kmer_k;
 	const int jump = kk > 0 ? (kk < opt.min_seed_len ? kk : opt.min_seed_len) : 0;
@@ -151,11 +154,11 @@ ema_k_seed_p3(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, cons
 				const int L = (int)req_len;
 				const uint32_t rcode = want_rc ? ema_kmer_revcomp(req_code, kk) : req_code;
 				if (L <= EMA_KMER_WIDE) {
-					const size_t base = (((size_t)1 << (2 * L)) - 4) / 3;
+					const size_t base = ema_kmer_base_wide(L);
 					p0 = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + req_code));
 					p2 = reinterpret_cast<const uint4 *>(ix.kmer_wide + 2 * (base + rcode));
 				} else {
-					const size_t base = (((size_t)1 << (2 * L)) - ((size_t)1 << (2 * (EMA_KMER_WIDE + 1)))) / 3;
+					const size_t base = ema_kmer_base_narrow(L);
 					p0 = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + req_code);
 					p2 = reinterpret_cast<const uint4 *>(ix.kmer_narrow + base + rcode);
 				}
@@ -172,17 +175,9 @@ ema_k_seed_p3(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, cons
 				else { r0 = ea & 0xFFFFFFFFFFULL; r2 = ea >> 40; r1 = want_rc ? (eb & 0xFFFFFFFFFFULL) : 0; }
 				r_code = req_code;
 			} else {
-				uint64_t tk[4], tl[4];
-				ema_occ4_decode(ix, qk, a0, a1, tk);
-				ema_occ4_decode(ix, ql, b0, b1, tl);
-				const uint64_t s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
-				const uint64_t b3 = x_b + ((x_nb <= ix.primary && x_nb + sz - 1 >= ix.primary) ? 1 : 0);
-				const uint64_t b2 = b3 + s3, b1_ = b2 + s2, b0_ = b1_ + s1;
-				const int cc = req_c & 3;
-				const uint64_t o_b = cc == 3 ? b3 : cc == 2 ? b2 : cc == 1 ? b1_ : b0_;
-				const uint64_t o_size = cc == 3 ? s3 : cc == 2 ? s2 : cc == 1 ? s1 : s0;
-				const uint64_t o_nb = ix.L2[cc] + 1 + (cc == 3 ? tk[3] : cc == 2 ? tk[2] : cc == 1 ? tk[1] : tk[0]);
-				r0 = o_b; r1 = o_nb; r2 = o_size;
+				uint64_t o_nb; uint32_t o_size, n_gt;
+				ema_extend_blocks(ix, rt, qk, ql, a0, a1, b0, b1, req_c & 3, o_nb, o_size, n_gt);
+				r0 = x_b + ((x_nb <= ix.primary && x_nb + sz - 1 >= ix.primary) ? 1 : 0) + n_gt; r1 = o_nb; r2 = o_size;
 				r_code = 0;
 			}
 			has_req = 0;

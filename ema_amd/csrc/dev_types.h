@@ -73,6 +73,8 @@ struct DevOpts {
 	// bit 2 = one control pass per tick ("one pass per tick")
 	// bit 3 = pass 3 (the LAST-like seeds, bwt_seed_strategy1) runs as a kernel of its own behind K1 (k_seed_p3.hip); K1 then ends a
 	//         read after pass 2 and leaves the extends it has used in seed_ext[read] (the lean budget runs on across the passes)
+	// bit 4 = [r6] the backward phases of bwt_smem1 run as tasks of a machine of their own (k_seed_bwd.hip): K1 ends a search after
+	//         its forward phase and leaves a SeedTask; needs bit 3 and the table mode
 	int seed_flags;
 	int32_t *seed_ext;
 };
@@ -92,6 +94,26 @@ struct Intv { uint64_t x0, x1, x2, info; };
 #define EMA_SEED_BUDGET_LEAN 4096
 #define EMA_SEED_BUDGET_LANE 2048      // ... when the reads over it are seeded by K1w in place (engine.hip, run_seed) instead of going to the full tier
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
+
+// [r6] K1 -> K1b (k_seed_bwd.hip): the backward phase of one bwt_smem1 search as a task.  The forward phase left its intervals
+// (bwa's `curr` vector before the swap: one per change of the interval's size, shortest match first) in a pool; the task names them,
+// carries the last one -- the longest match, the first entry of the first backward row -- so that the first extend is posted
+// without a look-up, and says where the row walk begins.  list: index of the first entry the backward phase uses (entries the
+// window test ruled out come before it); geom = entries | sm_x << 16 | c_end << 24 (sm_x: the position the search started at, the
+// first row extends with the base at sm_x - 1; c_end: where the longest match ends).  n_ext: the read's extends when the task
+// was left (the lean budget runs on from there).
+struct SeedTask { uint64_t c0, c2; uint32_t c_code; int32_t read; uint32_t list; int32_t min_intv; int32_t n_ext; uint32_t geom; uint32_t pad[2]; };
+// what a K1 launch of the split form needs beside its own arguments
+struct SeedSplit {
+	SeedTask *tasks;                   // [0, cap_heavy): tasks with at least heavy_min entries (K1b takes them first), [cap_heavy, cap_heavy + cap_light): the others
+	int *n_task;                       // [2]: tasks left in either part (may exceed the caps: the surplus was not written, its reads are flagged)
+	int cap_heavy, cap_light, heavy_min;
+	Intv *pool;                        // forward lists, handed out to the lanes in chunks of EMA_SEED_CHUNK entries
+	unsigned long long *pool_used;
+	unsigned long long pool_cap;       // entries
+	int phase;                         // 1: pass 1 of every read (fresh reads); 2: pass 2 (the reads come with their pass-1 intervals)
+};
+#define EMA_SEED_CHUNK 256       // = EMA_LIST_CAP: a fresh chunk holds any forward list
 
 // bwa's mem_seed_t plus the link to the next seed of the same chain
 struct SeedRec { int64_t rbeg; int32_t qbeg, len; int32_t next, pad; };

@@ -208,6 +208,7 @@ inline void __threadfence_block() {}
 inline void __threadfence() {}
 template <typename T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> inline T atomicSub(T *p, T v) { T o = *p; *p = o - v; return o; }
 template <typename T> inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 using std::min;

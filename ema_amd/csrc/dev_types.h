@@ -112,6 +112,8 @@ struct SeedSplit {
 	unsigned long long *pool_used;
 	unsigned long long pool_cap;       // entries
 	int phase;                         // 1: pass 1 of every read (fresh reads); 2: pass 2 (the reads come with their pass-1 intervals)
+	unsigned long long *prof;          // tuning knob seed_split_prof=1 (else null): [0] tasks, [1] their ticks, [2] K1b wave-ticks, [3] busy lane-ticks, [4] longest task,
+	                                   // [5] longest wave, [8 + b] tasks / [16 + b] ticks by first-row entries (<= 2, 4, 8, .. 128, more); K1 split form: [24] wave-ticks, [25] busy lane-ticks, [26] longest wave
 };
 #define EMA_SEED_CHUNK 256       // = EMA_LIST_CAP: a fresh chunk holds any forward list
 

@@ -240,6 +240,7 @@ struct Slice {
 	DevBuf<SeedTask> d_stasks;                    // [r6] K1 -> K1b (k_seed_bwd.hip): backward phases as tasks, heavy part then light part (dev_types.h, SeedSplit),
 	DevBuf<Intv> d_spool;                         //      the forward lists they start from,
 	DevBuf<int> d_sctr;                           //      [0..1] tasks left in either part, [2] K1b's queue, [4..5] pool entries handed out (u64), [6] the pass-2 launch's queue
+	DevBuf<unsigned long long> d_sprof;           //      tuning knob seed_split_prof=1: SeedSplit::prof, printed when the engine closes
 	SeedSplit split = SeedSplit();
 	DevBuf<ExtTask> d_xtasks;                     // K2x: seed tasks of this pass, their results by record and chain, the flags that say which were computed,
 	DevBuf<ExtRes> d_xres;                        //      and [0] the task count, [1..3] the claim counters of the three launches (k_ext_lane.hip)
@@ -274,7 +275,7 @@ struct Slice {
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_long.release(); d_order.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
-		d_xtasks.release(); d_xres.release(); d_xvalid.release(); d_xctr.release(); d_sext.release(); d_stasks.release(); d_spool.release(); d_sctr.release();
+		d_xtasks.release(); d_xres.release(); d_xvalid.release(); d_xctr.release(); d_sext.release(); d_stasks.release(); d_spool.release(); d_sctr.release(); d_sprof.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -542,6 +543,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 		HIPCHK(e, s.d_sctr.alloc(16));
 		sp.tasks = s.d_stasks.p; sp.pool = s.d_spool.p; sp.n_task = s.d_sctr.p; sp.pool_used = (unsigned long long *)(s.d_sctr.p + 4);
 		s.dopts.seed_flags |= 16;
+		if (ema_tuning_get("seed_split_prof")) { HIPCHK(e, s.d_sprof.alloc(32)); HIPCHK(e, hipMemset(s.d_sprof.p, 0, 256)); sp.prof = s.d_sprof.p; }
 	}
 	if (e->ext_lane) {
 		HIPCHK(e, s.d_xtasks.alloc(n_reads * 3 + 1024)); HIPCHK(e, s.d_xres.alloc(n_reads * EMA_HAND_SEEDS + 8));
@@ -761,9 +763,10 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	e->pair_blocks = e->n_cu * ema_pair_blocks_per_cu();
 	e->final_blocks = e->n_cu * ema_final_blocks_per_cu();
 	e->lane_blocks = e->n_cu * ema_align_simple_blocks_per_cu();
-	{   // EMA_GRID="k2a,k2b,k3,k4": resident blocks per CU of those kernels, at most what the occupancy calculation allows (0 = leave)
+	{   // grid=k2a:k2b:k3:k4 -- resident blocks per CU of those kernels, at most what the occupancy calculation allows (0 = leave).
+		// (':' between the values: ',' separates the knobs of a tuning string -- ADVICE r05)
 		int v[4] = {0, 0, 0, 0};
-		if (const char *g = ema_tuning_get("grid")) sscanf(g, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+		if (const char *g = ema_tuning_get("grid")) sscanf(g, "%d:%d:%d:%d", &v[0], &v[1], &v[2], &v[3]);
 		int *blk[4] = {&e->lane_blocks, &e->align_blocks, &e->pair_blocks, &e->final_blocks};
 		for (int k = 0; k < 4; ++k) if (v[k] > 0 && v[k] * e->n_cu < *blk[k]) *blk[k] = v[k] * e->n_cu;
 	}
@@ -772,7 +775,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = ema_tuning_get("seed_long_wave")) e->long_wave = atoi(v) != 0;
 	if (const char *v = ema_tuning_get("seed_order")) {
 		int m4 = 0, ns = 0;
-		const int got = sscanf(v, "%d,%d", &m4, &ns);
+		const int got = sscanf(v, "%d:%d", &m4, &ns);      // seed_order=mult4:samples
 		e->seed_order = got >= 1 && m4 != 0;
 		if (got >= 1 && m4 > 1) e->order_mult4 = m4;      // ("1" = on with the defaults)
 		if (got >= 2 && ns >= 1) e->order_samples = std::min(16, ns);
@@ -869,6 +872,17 @@ void ema_engine_close(ema_engine_t *e)
 	if (e->shadow) { ema_engine_close(e->shadow); e->shadow = nullptr; }
 	(void)hipSetDevice(e->device);
 	(void)hipDeviceSynchronize();
+	for (size_t k = 0; k < e->sl.size(); ++k) if (e->sl[k].d_sprof.p) {      // tuning knob seed_split_prof=1 (dev_types.h, SeedSplit::prof)
+		unsigned long long h[32];
+		if (hipMemcpy(h, e->sl[k].d_sprof.p, 256, hipMemcpyDeviceToHost) != hipSuccess) continue;
+		fprintf(stderr, "K1 split, slice %zu: K1b tasks %llu, ticks %llu (%.1f per task, longest %llu), wave-ticks %llu (%.1f lanes busy, longest wave %llu); K1 forward: wave-ticks %llu (%.1f lanes busy, longest wave %llu)\n",
+		        k, h[0], h[1], h[0] ? (double)h[1] / h[0] : 0.0, h[4], h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[5], h[24], h[24] ? (double)h[25] / h[24] : 0.0, h[26]);
+		fprintf(stderr, "   tasks by first-row entries (<= 2, 4, 8, 16, 32, 64, 128, more): count");
+		for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", h[8 + b]);
+		fprintf(stderr, "; ticks");
+		for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", h[16 + b]);
+		fprintf(stderr, "\n");
+	}
 	if (e->d_xprof) { (void)hipFree(e->d_xprof); e->d_xprof = nullptr; }
 	if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
 	if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
@@ -932,6 +946,13 @@ int ema_engine_index_info(const ema_engine_t *e, int32_t info[4])
 	info[0] = e->dix.n_super; info[1] = EMA_OCC_SUPER_SHIFT; info[2] = e->dix.sa_width; info[3] = e->dix.kmer_k;
 	return EMA_OK;
 }
+int ema_engine_debug_grids(const ema_engine_t *e, int32_t grids[6])
+{
+	if (!e || !grids || e->n_cu <= 0) return EMA_EARG;
+	const int b[6] = {e->seed_blocks, e->lane_blocks, e->align_blocks, e->pair_blocks, e->final_blocks, e->n_cu * e->seed_bwd_blocks};
+	for (int k = 0; k < 6; ++k) grids[k] = b[k] / e->n_cu;
+	return EMA_OK;
+}
 size_t ema_engine_batch_capacity(const ema_engine_t *e) { return e ? e->cap_pairs : 0; }
 int ema_engine_max_read_len(void) { return EMA_MAX_READ; }
 size_t ema_engine_full_tier_capacity(const ema_engine_t *e) { return e ? e->full.cap_pairs : 0; }
@@ -990,7 +1011,7 @@ static int stage_slot_impl(ema_engine_t *e, int slot, const char *bases, const u
 // stage_async for buckets whose reads are already on this device (ema_bucket_read_device, ingest_dev.hip): the buckets are laid end to
 // end in the slot with device-to-device copies and a rebase of their offsets; the conversion to nt4 + packed form follows as usual.
 // The caller has checked the read lengths against EMA_MAX_READ on its host copy of the offsets.
-extern "C" void ema_launch_rebase_off(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t add, hipStream_t stream);
+extern "C" void ema_launch_rebase_off(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t add, uint32_t max_len, int *too_long, hipStream_t stream);
 int ema_engine_stage_async_dev(ema_engine_t *e, int slot, const ema_bucket *const *buckets, size_t n_buckets)
 {
 	if (!e || (!buckets && n_buckets)) return EMA_EARG;
@@ -1010,18 +1031,29 @@ int ema_engine_stage_async_dev(ema_engine_t *e, int slot, const ema_bucket *cons
 		if (rc != EMA_OK) return rc;
 	}
 	ema_engine::InputSet &in = e->in[slot];
+	if (n_bases > in.d_bases.n) { e->err = "ema_engine_stage_async_dev: more bases than the input slot holds (reads longer than EMA_MAX_READ)"; return EMA_ELIMIT; }
 	if (!e->h2d_stream) HIPCHK(e, hipStreamCreate(&e->h2d_stream));
 	if (e->slot_free[slot]) HIPCHK(e, hipEventSynchronize(e->slot_free[slot]));      // the last run queued on this slot has read it
 	hipStream_t st = e->h2d_stream;
 	const size_t n_reads = 2 * n_pairs;
 	size_t at_r = 0, at_b = 0;
+	// (the read lengths are checked HERE, on the device-resident offsets, whoever the caller is: ema_bucket_read_device accepts reads of up
+	// to 4,096 bases, the packed reads behind ema_k_stage_reads hold EMA_MAX_READ -- ADVICE r05.  The flag lives in the slack behind the packed reads.)
+	int *const d_flag = reinterpret_cast<int *>(in.d_qpack.p + in.d_qpack.n + 1);      // (a word of the slack every DevBuf is allocated with)
+	HIPCHK(e, hipMemsetAsync(d_flag, 0, 4, st));
 	HIPCHK(e, hipMemsetAsync(in.d_off.p, 0, 4, st));
 	for (size_t k = 0; k < n_buckets; ++k) {
 		const ema_bucket_dev *d = ema_bucket_dev_view(buckets[k]);
 		if (!d->n_pairs) continue;
 		HIPCHK(e, hipMemcpyAsync(in.d_bases.p + at_b, d->bases, d->n_bases, hipMemcpyDeviceToDevice, st));
-		ema_launch_rebase_off(in.d_off.p + at_r + 1, d->off + 1, (uint32_t)(2 * d->n_pairs), (uint32_t)at_b, st);
+		ema_launch_rebase_off(in.d_off.p + at_r + 1, d->off + 1, (uint32_t)(2 * d->n_pairs), (uint32_t)at_b, EMA_MAX_READ, d_flag, st);
 		at_r += 2 * d->n_pairs; at_b += d->n_bases;
+	}
+	{
+		int too_long = 0;
+		HIPCHK(e, hipMemcpyAsync(&too_long, d_flag, 4, hipMemcpyDeviceToHost, st));
+		HIPCHK(e, hipStreamSynchronize(st));
+		if (too_long) { in.staged = false; e->err = "read longer than EMA_MAX_READ"; return EMA_ELIMIT; }
 	}
 	HIPCHK(e, hipMemsetAsync(in.d_qpack.p + n_reads * 24, 0, 8 * 4, st));
 	ema_launch_stage_reads(in.d_off.p, (int)n_reads, in.d_bases.p, in.d_qpack.p, st);

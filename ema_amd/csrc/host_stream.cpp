@@ -159,8 +159,9 @@ int host_resident(ema_bucket *bk)
 	if (!bk->dev || bk->bases) return EMA_OK;
 	const size_t nb = bk->off[2 * bk->n_pairs];
 	bk->bases = (char *)malloc(nb + 1); bk->quals = (char *)malloc(nb + 1);
-	if (!bk->bases || !bk->quals) return EMA_EIO;
-	return ema_bucket_dev_fetch(bk, bk->bases, bk->quals);
+	int rc = bk->bases && bk->quals ? ema_bucket_dev_fetch(bk, bk->bases, bk->quals) : EMA_EIO;
+	if (rc != EMA_OK) { free(bk->bases); free(bk->quals); bk->bases = bk->quals = nullptr; }      // (never leave an unfilled copy behind: the next call would take it for the reads)
+	return rc;
 }
 
 void reader(Stream &S, size_t first, size_t step)      // buckets first, first + step, ...
@@ -263,7 +264,17 @@ void stager(Stream &S, AsyncState &A)
 		size_t n_dev = 0, n_used = 0;
 		for (size_t j = 0; j < ps.len; ++j) { const Item &x = S.items[k + j]; if (x.rc == EMA_OK && x.n_pairs) { ++n_used; n_dev += x.bk && x.bk->dev && !x.bk->bases; } }
 		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap && n_dev && n_dev < n_used)
-			for (size_t j = 0; j < ps.len; ++j) { Item &x = S.items[k + j]; if (x.bk && x.bk->dev && host_resident(x.bk) == EMA_OK) x.bases = x.bk->bases; }
+			for (size_t j = 0; j < ps.len; ++j) {
+				Item &x = S.items[k + j];
+				if (!(x.bk && x.bk->dev)) continue;
+				const int hr = host_resident(x.bk);
+				if (hr == EMA_OK) x.bases = x.bk->bases;
+				else {      // the whole pass fails, as it does when the reader's own fetch fails (no copy to lay end to end)
+					for (size_t j2 = 0; j2 < ps.len; ++j2) { S.items[k + j2].rc = hr; S.items[k + j2].err = "cannot fetch a device-resident bucket's reads back to the host"; }
+					ok = -1;
+					break;
+				}
+			}
 		if (it.rc == EMA_OK && it.slot < 0 && it.n_pairs <= S.cap && n_dev && n_dev == n_used) {
 			std::vector<const ema_bucket *> bks;
 			size_t np = 0;

@@ -53,6 +53,7 @@ struct BlockPool {
 	explicit BlockPool(bool pin) : pinned(pin) {}
 	hipError_t take(size_t bytes, Block &out, int device)
 	{
+		Block evicted;      // (freed AFTER the lock is dropped: hipFree waits for the whole device, and the SAM writer's ema_bucket_dev_release waits for this mutex -- ADVICE r05)
 		{
 			std::lock_guard<std::mutex> lk(mu);
 			int best = -1;
@@ -62,10 +63,11 @@ struct BlockPool {
 			if (idle.size() >= 6) {      // none fits and the shelf is full: the smallest one makes room
 				size_t small = 0;
 				for (size_t k = 1; k < idle.size(); ++k) if (idle[k].cap < idle[small].cap) small = k;
-				if (pinned) (void)hipHostFree(idle[small].p); else (void)hipFree(idle[small].p);
+				evicted = idle[small];
 				idle.erase(idle.begin() + (long)small);
 			}
 		}
+		if (evicted.p) { if (pinned) (void)hipHostFree(evicted.p); else (void)hipFree(evicted.p); }
 		out.cap = bytes + bytes / 8 + 65536;
 		out.device = device;
 		const hipError_t rc = pinned ? hipHostMalloc(&out.p, out.cap, hipHostMallocDefault) : hipMalloc(&out.p, out.cap);
@@ -279,7 +281,9 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 done:
 #undef ING
 	close(fd);
-	if (st) (void)hipStreamDestroy(st);
+	// (on a failure path copies and kernels may still be queued on st: the blocks go back to pools other readers take from, and the
+	// targets of the device-to-host copies are about to leave scope -- wait for the stream first)
+	if (st) { if (rc != 0) (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	pin_pool().give(pin); dev_pool().give(txt); dev_pool().give(work); dev_pool().give(keep);
 	if (rc == 0) { *out = o; return 0; }
 	if (o) { free(o->bc); free(o->off); free(o->id_off); free(o->ids); free(o->group_off); free(o); }

@@ -203,15 +203,20 @@ extern "C" void ema_launch_stage_reads(const uint32_t *off, int n_reads, uint8_t
 	hipLaunchKernelGGL(ema_k_stage_reads, dim3((unsigned)(((size_t)n_reads * 8 + 255) / 256)), dim3(256), 0, stream, off, n_reads, bases, qpack);
 }
 
-// offsets of one bucket laid behind others in a shared input slot (ema_engine_stage_async_dev): dst[r] = src[r] + add
+// offsets of one bucket laid behind others in a shared input slot (ema_engine_stage_async_dev): dst[r] = src[r] + add, where src[r] is
+// the END of the bucket's read r (src points at its off[1]).  *too_long is set when a read is longer than max_len or the offsets
+// run backwards: the kernels behind (ema_k_stage_reads, K1's packed reads) hold EMA_MAX_READ bases per read and nothing more
 __global__ void __launch_bounds__(256)
-ema_k_rebase_off(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t n, uint32_t add)
+ema_k_rebase_off(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t n, uint32_t add, uint32_t max_len, int *__restrict__ too_long)
 {
 	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-	if (r < n) dst[r] = src[r] + add;
+	if (r >= n) return;
+	const uint32_t end = src[r], beg = src[(int)r - 1];
+	if (end < beg || end - beg > max_len) *too_long = 1;
+	dst[r] = end + add;
 }
-extern "C" void ema_launch_rebase_off(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t add, hipStream_t stream)
+extern "C" void ema_launch_rebase_off(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t add, uint32_t max_len, int *too_long, hipStream_t stream)
 {
 	if (!n) return;
-	hipLaunchKernelGGL(ema_k_rebase_off, dim3((n + 255u) / 256u), dim3(256), 0, stream, dst, src, n, add);
+	hipLaunchKernelGGL(ema_k_rebase_off, dim3((n + 255u) / 256u), dim3(256), 0, stream, dst, src, n, add, max_len, too_long);
 }

@@ -601,6 +601,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			}
 			break;
 		}
+		if (SPLIT && sp.prof) { ++n_tick; n_active += __popcll(__ballot(has_req != 0)); }
 		if (prof) {
 			++n_tick; n_active += __popcll(__ballot(has_req != 0));
 			n_kind[0] += __ballot(has_req == 1) != 0; n_kind[1] += __ballot(has_req == 2) != 0; n_kind[2] += __ballot(has_req >= 3) != 0;
@@ -711,6 +712,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			has_req = 0;
 		}
 	}
+	if (SPLIT && sp.prof && lane == 0) { atomicAdd(sp.prof + 24, n_tick); atomicAdd(sp.prof + 25, n_active); atomicMax(sp.prof + 26, n_tick); }
 	if (prof) {
 		atomicAdd(prof + 30, n_pass_lane);
 		atomicAdd(prof + 32, n_by_pass[0]); atomicAdd(prof + 33, n_by_pass[1]); atomicAdd(prof + 34, n_by_pass[2]); atomicAdd(prof + 35, n_by_pass[3]);

@@ -33,7 +33,7 @@ namespace { enum { B_IDLE = 0, B_ROW, B_RES, B_N }; }
 __global__ void __launch_bounds__(256, EMA_SEED_BWD_WPS)
 ema_k_seed_bwd(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const int *__restrict__ map, const SeedTask *__restrict__ tasks,
                const int *__restrict__ n_task, int cap_heavy, int cap_light, const Intv *__restrict__ pool, Intv *__restrict__ intv,
-               int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists, int *__restrict__ counter)
+               int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists, int *__restrict__ counter, unsigned long long *prof)
 {
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
 	__shared__ uint32_t lds_n[4][8 * 64];       // N mask, 8 words per lane
@@ -57,6 +57,8 @@ ema_k_seed_bwd(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, con
 	Intv ent; ent.x0 = ent.x1 = ent.x2 = ent.info = 0;
 	size_t out_base = 0;
 	bool exhausted = false;
+	unsigned long long n_tick = 0, n_busy = 0;      // (prof)
+	int n_first = 0;
 	for (;;) {
 		// ---- phase A: one pass of the control program (registers and LDS; the task fetch and an interval's slot wait for memory)
 		if (!has_req && !exhausted) {
@@ -101,6 +103,11 @@ ema_k_seed_bwd(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, con
 				if (read >= 0) {
 					if (n_ext) atomicAdd(opt.seed_ext + read, n_ext);
 					if (st) atomicOr(status + read, st);
+					if (prof) {
+						const int b = n_first <= 2 ? 0 : n_first <= 4 ? 1 : n_first <= 8 ? 2 : n_first <= 16 ? 3 : n_first <= 32 ? 4 : n_first <= 64 ? 5 : n_first <= 128 ? 6 : 7;
+						atomicAdd(prof, 1ULL); atomicAdd(prof + 1, (unsigned long long)n_ext); atomicMax(prof + 4, (unsigned long long)n_ext);
+						atomicAdd(prof + 8 + b, 1ULL); atomicAdd(prof + 16 + b, (unsigned long long)n_ext);
+					}
 					read = -1;
 				}
 				const int t = atomicAdd(counter, 1);
@@ -111,7 +118,7 @@ ema_k_seed_bwd(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, con
 					c0 = (uint64_t)t0.y << 32 | t0.x; c2 = (uint64_t)t0.w << 32 | t0.z;
 					c_code = t1.x; read = (int)t1.y; fl = pool + t1.z; min_intv = (int)t1.w;
 					n_ext0 = (int)t2.x; n_prev = (int)(t2.y & 0xffff); i = (int)((t2.y >> 16) & 0xff) - 1; c_end = t2.y >> 24;
-					n_ext = 0; st = 0; n_curr = 0; rev = 1; j = 0; n_mem_call = 0; last_mem_start = 0;
+					n_ext = 0; st = 0; n_curr = 0; rev = 1; j = 0; n_mem_call = 0; last_mem_start = 0; n_first = n_prev;
 					out_base = (size_t)read * opt.intv_cap;
 					const int in_read = ema_in_read(map, read);
 					const uint4 *pw = reinterpret_cast<const uint4 *>(qpack + (size_t)in_read * 24);
@@ -139,7 +146,9 @@ ema_k_seed_bwd(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, con
 				}
 			}
 		}
-		if (!__ballot(!exhausted)) break;
+		const unsigned long long busy = __ballot(!exhausted);
+		if (!busy) break;
+		if (prof) { ++n_tick; n_busy += (unsigned long long)__popcll(__ballot(has_req != 0)); }
 		// ---- phase B: the tick's loads, issued together
 		if (has_req) {
 			if (j + 1 < n_prev) {
@@ -175,13 +184,14 @@ ema_k_seed_bwd(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, con
 			has_req = 0;
 		}
 	}
+	if (prof && lane == 0) { atomicAdd(prof + 2, n_tick); atomicAdd(prof + 3, n_busy); atomicMax(prof + 5, n_tick); }
 }
 
 extern "C" void ema_launch_seed_bwd(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const int *map, const SeedSplit *sp, Intv *intv,
                                     int *n_intv, int *status, Intv *lists, int *counter, int n_blocks, hipStream_t stream)
 {
 	hipLaunchKernelGGL(ema_k_seed_bwd, dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, qpack, map, sp->tasks, sp->n_task, sp->cap_heavy, sp->cap_light,
-	                   sp->pool, intv, n_intv, status, lists, counter);
+	                   sp->pool, intv, n_intv, status, lists, counter, sp->prof);
 }
 // resident 256-thread blocks per CU (sizes the grid and the list slabs)
 extern "C" int ema_seed_bwd_blocks_per_cu()

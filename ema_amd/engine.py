@@ -154,7 +154,7 @@ def set_tuning(**knobs):
         if v is None:
             _tuning.pop(k, None)
         else:
-            _tuning[k] = str(v)
+            _tuning[k] = str(v).replace(",", ":")      # ',' separates knobs in the library's string: a knob's own list ("grid", "seed_order") uses ':'
     L.ema_engine_set_tuning(",".join(f"{k}={v}" for k, v in _tuning.items()).encode() if _tuning else None)
 
 
@@ -405,6 +405,13 @@ class Engine:
         self._L.ema_engine_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         self._check(self._L.ema_engine_index_info(self._h, a), "index_info")
         return {"n_super": a[0], "super_shift": a[1], "sa_width": a[2], "kmer_k": a[3]}
+
+    def debug_grids(self):
+        """Blocks per compute unit of the kernels' launches (ema_engine_debug_grids)."""
+        a = (C.c_int32 * 6)()
+        self._L.ema_engine_debug_grids.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self._check(self._L.ema_engine_debug_grids(self._h, a), "debug_grids")
+        return dict(zip(("k1", "k2a", "k2b", "k3", "k4", "k1b"), (int(x) for x in a)))
 
     def debug_sa(self, first: int, n: int) -> np.ndarray:
         """Rows [first, first + n) of the suffix array in HBM (ema_engine_debug_sa)."""

@@ -81,3 +81,23 @@ def test_contig_lookups_equal_bwas(eng, layout):
     assert np.array_equal(got_pos, want_pos), np.flatnonzero(got_pos != want_pos)[:10]
     assert np.array_equal(got_intv, want_intv), np.flatnonzero(got_intv != want_intv)[:10]
     assert (want_intv >= 0).sum() > 0 and (len(lens) == 1 or (want_intv == -1).sum() > 0)
+
+
+def test_tuning_string_takes_lists_with_colons(tuning):
+    """`grid` and `seed_order` are lists inside a comma-separated tuning string (with commas inside the value only the
+    first number arrived).  The wrapper turns a legacy "a,b,c,d" into "a:b:c:d"; all four grids must follow."""
+    prefix, _ = small_ref("two_contigs")
+    e = Engine(prefix)
+    free = e.debug_grids()
+    e.close()
+    assert min(free[k] for k in ("k2a", "k2b", "k3", "k4")) >= 2, free
+    tuning(grid="1,1,1,1", seed_blocks_per_cu=1)
+    e = Engine(prefix)
+    held = e.debug_grids()
+    e.close()
+    assert [held[k] for k in ("k1", "k2a", "k2b", "k3", "k4")] == [1, 1, 1, 1, 1], held
+    tuning(grid="0:1:0:1")
+    e = Engine(prefix)
+    mixed = e.debug_grids()
+    e.close()
+    assert (mixed["k2a"], mixed["k2b"], mixed["k3"], mixed["k4"]) == (free["k2a"], 1, free["k3"], 1), mixed

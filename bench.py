@@ -279,14 +279,18 @@ def pmc_table(name):
 
 
 def sam_leg(args, eng, batches, workdir, world):
-    """SURVEY 8(d)'s end-to-end figure beside the hot path's: bucket FILES -> SAM text through one ema_stream_sam call (reader,
-    engine, append stage, clouds / EM / duplicates, formatter) to /dev/null, on buckets of `preproc`'s size cut from the bench
-    batches.  Runs last: it stages its own input over the resident batches.  N = 1 only."""
+    """SURVEY 8(d)'s end-to-end figure beside the hot path's, on BASELINE configs[2]'s shape: 500 barcode buckets streamed through ONE
+    ema_stream_sam call (reader, engine, append stage, clouds / EM / duplicates, formatter) to /dev/null, `-d` on -- every bucket its own
+    `ema align -s` process (cloud numbers from 0, its own stream of -d draws: ema_cloud_opts.seed_private) -- and the same call without -d.
+    The buckets are cut from the bench batches (50 distinct files of a tenth of a 512 Ki-pair half-batch each, taken ten times round:
+    26.2 M pairs per call at the default scale).  Runs last: it stages its own input over the resident batches.  N = 1 only."""
     if world != 1 or any(b.barcodes is None for b in batches[:2]):
         return None
-    from ema_amd import stream, synth
+    from ema_amd import shard, stream, synth
     try:
-        n_files, per, rep = 4, min(262144, args.pairs), 24      # 96 buckets: two dozen passes, so that the pipeline's fill and drain do not set the rate (r01-r05a: 48)
+        n_buckets = 500
+        per = max(256, min(52428, args.pairs // 20))      # 26.2 M pairs over 500 buckets at the default scale (configs[2]: 100 M reads in 500 buckets = 100,000 pairs each)
+        n_files = min(50, 5 * len(batches))
         t = time.time()
         paths = []
         for k in range(n_files):
@@ -296,45 +300,47 @@ def sam_leg(args, eng, batches, workdir, world):
             synth.write_special_fastq_fixed(path, src.subset(lo, lo + per))
             paths.append(path)
         t_write = time.time() - t
+        order = [paths[k % n_files] for k in range(n_buckets)]
+        tot = n_buckets * per
         fd = os.open("/dev/null", os.O_WRONLY)
-        stream.stream_sam(eng, paths[:1], fd, rg_id=b"rg1")      # warm-up: page cache, buffers
+        stream.stream_sam(eng, paths[:2], fd, rg_id=b"rg1")      # warm-up: page cache, buffers
         import resource
-        stream.host_cpu_seconds(reset=True)
-        ru0 = resource.getrusage(resource.RUSAGE_SELF)
-        t0 = time.perf_counter()
-        bst, sst = stream.stream_sam(eng, paths * rep, fd, rg_id=b"rg1", continue_cloud_ids=True)
-        dt = time.perf_counter() - t0
-        ru1 = resource.getrusage(resource.RUSAGE_SELF)
-        cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
-        by_stage = stream.host_cpu_seconds()
-        # ... and once more with -d (BASELINE configs[2]: "-d density optimisation on"): the reference draws the optimiser's moves from libc's
-        # rand(), so the barcode groups with a bad cloud run on ONE host thread, in order, after the others (include/ema_clouds.h)
-        with_d = None
-        try:
-            from ema_amd import clouds as _clouds
-            _clouds.reseed(1500000000)
-            t0d = time.perf_counter()
-            _b, sd = stream.stream_sam(eng, paths * 2, fd, rg_id=b"rg1", continue_cloud_ids=True, density_opt=True)
-            dtd = time.perf_counter() - t0d
-            with_d = {"value": round(2 * n_files * per / dtd, 1), "unit": "pairs/s", "buckets": 2 * n_files, "bad_clouds": int(sum(x["bad_clouds"] for x in sd)),
-                      "what": "the same call with ema_cloud_opts.density_opt = 1 (`ema align -d`): the groups with a bad cloud on one host thread in order (the reference's rand() order), the others on all"}
-        except Exception as e:      # noqa: BLE001
-            log(f"[rank 0] bucket files -> SAM text with -d failed: {e}")
+
+        def one(density):
+            stream.host_cpu_seconds(reset=True)
+            ru0 = resource.getrusage(resource.RUSAGE_SELF)
+            t0 = time.perf_counter()
+            bst, sst = stream.stream_sam(eng, order, fd, rg_id=b"rg1", density_opt=density, density_seed=1500000000 if density else None)
+            dt = time.perf_counter() - t0
+            ru1 = resource.getrusage(resource.RUSAGE_SELF)
+            cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
+            by_stage = stream.host_cpu_seconds()
+            # the per-bucket records a rank would gather (ema_amd/shard.py: every field of ema_bucket_stats and ema_sam_stats), summed here
+            table = shard.gather_stats(np.array([shard.bucket_stats(b, q) for b, q in zip(bst, sst)], dtype=np.int64), n_buckets)
+            tsum = shard.stats_as_dict(table.sum(axis=0))
+            return {"value": round(tot / dt, 1), "unit": "pairs/s", "seconds": round(dt, 3), "density_optimiser": bool(density),
+                    "stage_seconds": {"reader": round(sum(x["read_s"] for x in bst), 3), "append": round(sum(x["append_s"] for x in bst), 3),
+                                      "clouds_em_duplicates": round(sum(x["select_s"] for x in sst), 3), "formatter_and_write": round(sum(x["write_s"] for x in sst), 3)},
+                    "host_cpu_seconds_per_million_pairs": round(cpu_s / tot * 1e6, 3), "host_cpus_busy": round(cpu_s / dt, 1),
+                    "host_cpu_seconds_per_million_pairs_by_stage": {k: round(v / tot * 1e6, 3) for k, v in by_stage.items()},
+                    "bucket_records": {"buckets": int(table.shape[0]), "fields_per_bucket": int(table.shape[1]),
+                                       "totals": {k: tsum[k] for k in ("pairs", "records", "redone_pairs", "sam_lines", "sam_mapped", "sam_proper", "sam_duplicates",
+                                                                        "sam_with_xa", "sam_clouds", "sam_bad_clouds", "sam_mapq_hist")}}}
+        plain = one(False)
+        with_d = one(True)
         os.close(fd)
         for path in paths:
             os.remove(path)
-        tot = n_files * rep * per
-        log(f"[rank 0] bucket files -> SAM text: {tot / dt:.0f} pairs/s ({n_files * rep} buckets of {per} pairs in {dt:.2f}s; files written in {t_write:.1f}s)")
-        return {"value": round(tot / dt, 1), "unit": "pairs/s", "buckets": n_files * rep, "pairs_per_bucket": per,
-                "what": "bucket files (preproc's one-pair-per-line form, page cache) -> SAM text on /dev/null through ONE ema_stream_sam call: reader "
-                        "(r05: parse, sort by barcode and gather on the device; the reads stay in HBM), staging, K1-K4, fetch, append stage, clouds / "
-                        "EM / duplicate marking on the host's threads, formatter (r05: on the device, from 52-byte records of the cloud stage); small "
-                        "buckets share passes; host stages on the CPUs the box grants",
-                "stage_seconds": {"reader": round(sum(s["read_s"] for s in bst), 3), "append": round(sum(s["append_s"] for s in bst), 3),
-                                  "clouds_em_duplicates": round(sum(s["select_s"] for s in sst), 3), "formatter_and_write": round(sum(s["write_s"] for s in sst), 3)},
-                "host_cpu_seconds_per_million_pairs": round(cpu_s / tot * 1e6, 3), "host_cpus_busy": round(cpu_s / dt, 1),
-                "host_cpu_seconds_per_million_pairs_by_stage": {k: round(v / tot * 1e6, 3) for k, v in by_stage.items()},
-                "sam_lines": int(sum(s["lines"] for s in sst)), "with_density_optimiser": with_d}
+        log(f"[rank 0] bucket files -> SAM text, {n_buckets} buckets of {per} pairs: {with_d['value']:.0f} pairs/s with -d, {plain['value']:.0f} without (files written in {t_write:.1f}s)")
+        out = dict(with_d)
+        out.update({"buckets": n_buckets, "pairs_per_bucket": per, "distinct_bucket_files": n_files,
+                    "what": "BASELINE configs[2]'s shape: 500 bucket files (preproc's one-pair-per-line form, page cache) -> SAM text on /dev/null through ONE "
+                            "ema_stream_sam call with -d on: reader (parse, sort by barcode and gather on the device; the reads stay in HBM), staging, K1-K4, fetch, "
+                            "append stage, clouds / EM / duplicate marking / density optimiser on the host's threads (r06: every bucket its own reference "
+                            "process -- cloud numbers from 0, its own glibc random_r stream seeded seed + k -- so up to three buckets are in the cloud stage at a time), "
+                            "formatter on the device; small buckets share passes; host stages on the CPUs the box grants",
+                    "without_density_optimiser": plain})
+        return out
     except Exception as e:      # an extra: never at the cost of the line
         log(f"[rank 0] bucket files -> SAM text leg failed: {e}")
         return None
@@ -681,7 +687,7 @@ def main(argv=None):
     n_slices = eng.n_streams
 
     from ema_amd import shard
-    local_stats = np.array([[s[f] for f in shard.STAT_FIELDS] for s in st_timed], dtype=np.int64).sum(axis=0)[None, :]
+    local_stats = np.array([shard.bucket_stats(s) for s in st_timed], dtype=np.int64).sum(axis=0)[None, :]      # (the whole record of shard.STAT_FIELDS; its SAM part is the SAM leg's)
     # the "trivial RCCL gather of per-bucket statistics" of the north star: one record per rank, O(100 B) over xGMI
     gathered = shard.gather_stats(local_stats, world, device=(tdev if use_dist and tdev == "cuda" else None))
 

@@ -14,7 +14,7 @@ from . import sam as _sam
 
 class CloudOpts(C.Structure):
     _fields_ = [("dist_thresh", C.c_uint32), ("many_clouds", C.c_int32), ("n_threads", C.c_int32), ("first_cloud_id", C.c_int32),
-                ("density_opt", C.c_int32), ("n_density_probs", C.c_int32), ("density_probs", C.c_double * 16), ("emit", C.c_int32), ("pad_", C.c_int32)]
+                ("density_opt", C.c_int32), ("n_density_probs", C.c_int32), ("density_probs", C.c_double * 16), ("emit", C.c_int32), ("seed_private", C.c_int32), ("seed", C.c_uint32), ("pad_", C.c_int32)]
 
 
 class SamStats(C.Structure):

@@ -108,6 +108,18 @@ struct Shared {
 	std::vector<uint8_t> flags;              // bit 0 duplicate, bit 1 cloud bad
 	std::vector<Sel> sel;                    // per group, from the group's first record index on
 	std::vector<uint32_t> n_sel, n_clouds, n_bad;      // per group
+	// -d with ema_cloud_opts.seed_private: this call's own stream of draws (glibc's rand() is random() on a 128-byte state; random_r
+	// on a state of that size seeded by initstate_r is the same generator, minus the lock).  Drawn from on one thread, in group order.
+	mutable struct random_data rng;
+	mutable char rng_state[128];
+	bool rng_private = false;
+	int draw() const
+	{
+		if (!rng_private) return rand();
+		int32_t v = 0;
+		(void)random_r(&rng, &v);
+		return (int)v;
+	}
 };
 
 int sam_dict_add(Work &w, const Shared &S, int32_t k, int32_t v, bool force)      // src/samdict.c:79-148
@@ -214,7 +226,7 @@ void mark_optimal_alignments_in_cloud(Work &w, const Shared &S, const std::vecto
 {
 	const int kMaxNoMove = 500, kBinSize = 1000, kMaxBins = 1000000 / 1000, kScoreScale = 20, kSplitExtraDepth = 5, kIters = 50000;
 	const size_t kBuf = 50000;
-	if (!g_rand_seeded.load()) std::call_once(g_rand_once, [] { if (!g_rand_seeded.load()) { srand((unsigned)time(nullptr)); g_rand_seeded.store(true); } });
+	if (!S.rng_private && !g_rand_seeded.load()) std::call_once(g_rand_once, [] { if (!g_rand_seeded.load()) { srand((unsigned)time(nullptr)); g_rand_seeded.store(true); } });
 	size_t n_records = sorted.size();
 	if (n_records >= kBuf || n_records <= 5) return;
 	auto R = [&](int32_t i) -> Rec & { return w.recs[(size_t)i]; };
@@ -280,9 +292,9 @@ void mark_optimal_alignments_in_cloud(Work &w, const Shared &S, const std::vecto
 	int no_move_count = 0;
 	for (size_t k = 0; k < (size_t)kIters; k++) {
 		const double t = std::pow(10.0, 0.0 - ((0.0 - (-12.0)) * k) / kIters);
-		const size_t r = (size_t)rand() % n_mmaps;
+		const size_t r = (size_t)S.draw() % n_mmaps;
 		const size_t r_old = (size_t)mmaps[r].active;
-		size_t r_new = (size_t)(rand() % (mmaps[r].n - 1));
+		size_t r_new = (size_t)(S.draw() % (mmaps[r].n - 1));
 		if (r_new >= r_old) ++r_new;
 		const Rec *active_mate = nullptr;
 		size_t mate_r = 0;
@@ -329,7 +341,7 @@ void mark_optimal_alignments_in_cloud(Work &w, const Shared &S, const std::vecto
 		}
 		score_prob_change += (rec_new->score - rec_old->score) / kScoreScale;
 		const double prob_change = density_prob_change + score_prob_change;
-		if (force_move || prob_change > 0 || std::exp(prob_change / t) >= ((double)rand()) / RAND_MAX) {
+		if (force_move || prob_change > 0 || std::exp(prob_change / t) >= ((double)S.draw()) / RAND_MAX) {
 			log_config_prob += prob_change;
 			mmaps[r].active = (int)r_new;
 			bins[old_bin] -= 1;
@@ -563,7 +575,7 @@ void ema_cloud_opts_default(ema_cloud_opts *o)
 {
 	if (!o) return;
 	o->dist_thresh = 50000; o->many_clouds = 0; o->n_threads = 0; o->first_cloud_id = 0;
-	o->density_opt = 0; o->n_density_probs = 4; o->emit = 0; o->pad_ = 0;
+	o->density_opt = 0; o->n_density_probs = 4; o->emit = 0; o->seed_private = 0; o->seed = 0; o->pad_ = 0;
 	for (double &p : o->density_probs) p = 0;
 	o->density_probs[0] = 0.6; o->density_probs[1] = 0.05; o->density_probs[2] = 0.2; o->density_probs[3] = 0.01;      // src/techs.c: every platform but cpt
 }
@@ -594,6 +606,11 @@ int ema_clouds_select(const ema_bucket *bk, const ema_batch_out *b, const ema_al
 	Shared S;
 	S.bk = bk; S.b = b; S.a = a;
 	if (opts) S.o = *opts; else ema_cloud_opts_default(&S.o);
+	if (S.o.density_opt && S.o.seed_private) {
+		memset(&S.rng, 0, sizeof(S.rng));
+		if (initstate_r(S.o.seed, S.rng_state, sizeof(S.rng_state), &S.rng) != 0) return EMA_EARG;
+		S.rng_private = true;
+	}
 	const size_t n_rec = a->n, n_groups = bk->n_groups;
 	for (size_t i = 0; i < n_rec; ++i) {
 		const ema_cand_t &c = b->cand[a->rec[i].cand];

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -582,12 +583,16 @@ int ema_stream_batches(ema_engine_t *e, const char *const *bases, const uint32_t
 
 namespace {
 // ema_stream_sam's sink hands every bucket to a three-stage host pipeline of its own, so that the engine thread goes straight back to
-// fetching the next pass: clouds / EM / duplicates on a cloud thread (one bucket at a time, in order: the cloud counter of an -x run
-// runs on from bucket to bucket; barcode groups on the host's threads inside), then the formatter + write on a writer thread.  The
-// lines point into the bucket, the batch and the selection, so the sink takes those over from the stream and the writer frees them.
-// (Round 2 ran the cloud stage inside the sink, on the engine thread: 78 of the ~130 ms a 262 K-pair bucket spent there.)
-struct CloudJob { size_t k; ema_bucket *bk; ema_batch_out *b; ema_aln_out *a; };
-struct WriteJob { size_t k; ema_clouds_out *sel; ema_bucket *bk; ema_batch_out *b; ema_aln_out *a; };
+// fetching the next pass: clouds / EM / duplicates on cloud threads (barcode groups on the host's threads inside), then the formatter +
+// write on a writer thread, in bucket order.  The lines point into the bucket, the batch and the selection, so the sink takes those over
+// from the stream and the writer frees them.  (Round 2 ran the cloud stage inside the sink, on the engine thread: 78 of the ~130 ms a
+// 262 K-pair bucket spent there.)
+// [r6] How many cloud threads: ONE when the cloud counter runs on from bucket to bucket (`-x`: bucket k + 1 starts where bucket k
+// ended) or when -d draws from the process's one rand() stream; otherwise -- every bucket its own `ema align -s` process, cloud
+// numbers from first_cloud_id, -d draws (if any) from the bucket's own stream, seed + bucket index -- up to three buckets at a time:
+// the part of -d that must run on one thread per bucket (the groups with a bad cloud, in order) then overlaps with other buckets'.
+struct CloudJob { size_t k, seq; ema_bucket *bk; ema_batch_out *b; ema_aln_out *a; };
+struct WriteJob { size_t k; ema_clouds_out *sel; ema_bucket *bk; ema_batch_out *b; ema_aln_out *a; bool skip; };
 struct SamSink {
 	ema_engine_t *e;
 	ema_sam_run_opts o;
@@ -600,9 +605,11 @@ struct SamSink {
 	ema_sam_dev_t *dev = nullptr;      // the formatter on the device (k_sam.hip); NULL: ema_sam_write on the host's threads
 	std::mutex mu;
 	std::condition_variable cv;
-	std::deque<CloudJob> cloud_jobs;
-	std::deque<WriteJob> jobs;
-	bool closing = false, clouds_done = false;
+	std::deque<CloudJob> cloud_jobs;           // waiting for a cloud thread, in bucket order
+	std::map<size_t, WriteJob> jobs;           // through the cloud stage, by sequence number: the writer takes next_write
+	size_t n_seq = 0, next_write = 0, in_clouds = 0;
+	int n_clouders = 1, clouders_left = 0;
+	bool closing = false;
 	int write_rc = EMA_OK, cloud_rc = EMA_OK;
 };
 
@@ -620,14 +627,14 @@ void sam_writer(SamSink &S)
 		WriteJob j;
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
-			S.cv.wait(lk, [&] { return S.clouds_done || !S.jobs.empty(); });
-			if (S.jobs.empty()) return;
-			j = S.jobs.front();
+			S.cv.wait(lk, [&] { return S.jobs.count(S.next_write) || (S.clouders_left == 0 && S.jobs.empty()); });
+			if (!S.jobs.count(S.next_write)) return;
+			j = S.jobs[S.next_write];
 		}
 		size_t n_bytes = 0;
 		const double t0 = now_s();
 		int rc = EMA_OK;
-		if (S.write_rc == EMA_OK) {
+		if (S.write_rc == EMA_OK && !j.skip) {
 			if (S.dev) {
 				const ema_clouds_out *sl = j.sel;
 				rc = ema_sam_dev_write(S.dev, S.fd, j.bk, j.b->cigar ? j.b->cigar + sl->cigar_lo : nullptr, sl->cigar_lo, sl->cigar_hi, sl->descs, sl->n_descs,
@@ -635,12 +642,13 @@ void sam_writer(SamSink &S)
 				if (rc == EMA_EIO && *ema_sam_dev_last_error()) { std::lock_guard<std::mutex> lk(S.mu); if (S.err.empty()) S.err = std::string("SAM formatter on the device: ") + ema_sam_dev_last_error(); }
 			} else rc = ema_sam_write(S.fd, j.sel->lines, j.sel->n_lines, &S.o.sam, &n_bytes);
 		}
-		if (S.sstats) S.sstats[j.k].write_s = now_s() - t0;
+		if (S.sstats && !j.skip) S.sstats[j.k].write_s = now_s() - t0;
 		free_job(j.sel, j.bk, j.b, j.a);
 		{
 			std::lock_guard<std::mutex> lk(S.mu);
 			if (rc != EMA_OK && S.write_rc == EMA_OK) S.write_rc = rc;
-			S.jobs.pop_front();
+			S.jobs.erase(S.next_write);
+			++S.next_write;
 		}
 		S.cv.notify_all();
 	}
@@ -654,34 +662,32 @@ void sam_clouds(SamSink &S)
 		{
 			std::unique_lock<std::mutex> lk(S.mu);
 			S.cv.wait(lk, [&] { return S.closing || !S.cloud_jobs.empty(); });
-			if (S.cloud_jobs.empty()) { S.clouds_done = true; lk.unlock(); S.cv.notify_all(); return; }
+			if (S.cloud_jobs.empty()) { --S.clouders_left; lk.unlock(); S.cv.notify_all(); return; }
 			c = S.cloud_jobs.front();
+			S.cloud_jobs.pop_front();
+			++S.in_clouds;
 			failed = S.cloud_rc != EMA_OK || S.write_rc != EMA_OK;      // read under the lock the writer stores write_rc under
 		}
+		S.cv.notify_all();
 		ema_clouds_out *sel = nullptr;
 		int rc = failed ? EMA_ESTATE : EMA_OK;      // after a failure: drain, freeing what arrives
 		if (rc == EMA_OK) {
 			ema_cloud_opts co = S.o.clouds;
-			if (S.o.continue_cloud_ids) co.first_cloud_id = S.next_cloud_id;
+			if (S.o.continue_cloud_ids) co.first_cloud_id = S.next_cloud_id;      // (one cloud thread then: nobody else touches it)
+			else if (co.density_opt && co.seed_private) co.seed += (uint32_t)c.k;  // the bucket's own stream
 			co.emit = S.dev ? 1 : 0;      // the compact records for the device's formatter, or the lines for the host's
 			rc = ema_clouds_select(c.bk, c.b, c.a, S.names.data(), (int32_t)S.names.size(), &co, &sel);
 			if (rc == EMA_OK) {
-				S.next_cloud_id = sel->next_cloud_id;
+				if (S.o.continue_cloud_ids) S.next_cloud_id = sel->next_cloud_id;
 				if (S.sstats) S.sstats[c.k] = sel->stats;
 			}
 		}
 		std::unique_lock<std::mutex> lk(S.mu);
-		if (rc != EMA_OK) {
-			if (S.cloud_rc == EMA_OK && S.write_rc == EMA_OK) { S.cloud_rc = rc; S.err = "ema_clouds_select failed"; }
-			S.cloud_jobs.pop_front();
-			lk.unlock();
-			free_job(sel, c.bk, c.b, c.a);
-			S.cv.notify_all();
-			continue;
-		}
-		S.cv.wait(lk, [&] { return S.jobs.size() < 2; });      // at most two buckets' worth of objects wait for the writer
-		S.jobs.push_back(WriteJob{c.k, sel, c.bk, c.b, c.a});
-		S.cloud_jobs.pop_front();
+		if (rc != EMA_OK && !failed && S.cloud_rc == EMA_OK && S.write_rc == EMA_OK) { S.cloud_rc = rc; S.err = "ema_clouds_select failed"; }
+		// at most two buckets' worth of objects wait for the writer beside the one it needs next
+		S.cv.wait(lk, [&] { return c.seq == S.next_write || S.jobs.size() < 2; });
+		S.jobs[c.seq] = WriteJob{c.k, sel, c.bk, c.b, c.a, rc != EMA_OK};
+		--S.in_clouds;
 		lk.unlock();
 		S.cv.notify_all();
 	}
@@ -691,10 +697,10 @@ int sam_sink(void *user, size_t k, const ema_bucket *bk, const ema_batch_out *b,
 {
 	SamSink &S = *(SamSink *)user;
 	std::unique_lock<std::mutex> lk(S.mu);
-	S.cv.wait(lk, [&] { return S.cloud_jobs.size() < 2; });      // at most two buckets wait for the cloud stage
+	S.cv.wait(lk, [&] { return S.cloud_jobs.size() < 2; });      // at most two buckets wait for a cloud thread
 	if (S.cloud_rc != EMA_OK) return S.cloud_rc;
 	if (S.write_rc != EMA_OK) { S.err = "ema_sam_write failed"; return S.write_rc; }
-	S.cloud_jobs.push_back(CloudJob{k, const_cast<ema_bucket *>(bk), const_cast<ema_batch_out *>(b), const_cast<ema_aln_out *>(a)});
+	S.cloud_jobs.push_back(CloudJob{k, S.n_seq++, const_cast<ema_bucket *>(bk), const_cast<ema_batch_out *>(b), const_cast<ema_aln_out *>(a)});
 	lk.unlock();
 	S.cv.notify_all();
 	S.stream->sink_kept = true;      // the pipeline frees them
@@ -766,15 +772,22 @@ int ema_stream_sam(ema_engine_t *e, const char *const *paths, size_t n, const em
 			T.device = ema_engine_device(e);
 		}
 	}
+	{   // cloud threads (see SamSink): buckets are independent of each other unless the cloud counter or the rand() stream runs through them
+		const bool chained = S.o.continue_cloud_ids != 0 || (S.o.clouds.density_opt && !S.o.clouds.seed_private);
+		const char *v = ema_tuning_get("sam_cloud_threads");
+		S.n_clouders = chained ? 1 : v ? std::max(1, std::min(8, atoi(v))) : 3;
+		S.clouders_left = S.n_clouders;
+	}
 	std::thread writer(sam_writer, std::ref(S));
-	std::thread clouder(sam_clouds, std::ref(S));
+	std::vector<std::thread> clouders;
+	for (int t = 0; t < S.n_clouders; ++t) clouders.emplace_back(sam_clouds, std::ref(S));
 	int rc = run_stream(e, T, sam_sink, &S, bstats);
 	{
 		std::lock_guard<std::mutex> lk(S.mu);
 		S.closing = true;
 	}
 	S.cv.notify_all();
-	clouder.join();
+	for (auto &t : clouders) t.join();
 	writer.join();
 	if (S.dev) ema_sam_dev_close(S.dev);
 	if (rc == EMA_OK && S.cloud_rc != EMA_OK) rc = S.cloud_rc;

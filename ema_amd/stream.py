@@ -188,9 +188,12 @@ def platform_opts(name: str) -> dict:
 
 def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None, is_haplotag: bool = False, bc_len: int = 16,
                continue_cloud_ids: bool = False, n_engines: int = 0, bx_index: bytes | None = None, density_opt: bool = False,
-               fastq_mates: list | None = None, platform: str | None = None):
+               fastq_mates: list | None = None, platform: str | None = None, density_seed: int | None = None):
     """ema_stream_sam: bucket files -> SAM text on fd.  Returns (per-bucket stream stats, per-bucket SAM stats).
-    platform: `-p <name>` (ema_sam_run_opts_platform; is_haplotag / bc_len are then the platform's)."""
+    platform: `-p <name>` (ema_sam_run_opts_platform; is_haplotag / bc_len are then the platform's).
+    density_seed (with density_opt, without continue_cloud_ids): every bucket draws -d's moves from a stream of its own, bucket k's
+    seeded with density_seed + k (ema_cloud_opts.seed_private: the bucket as its own `ema align -s` process); None: the process's one
+    rand() stream (ema_amd.clouds.reseed), buckets one after the other."""
     from . import clouds as _clouds
     from . import sam as _sam
     if not SamRunOpts.__dict__.get("_fields_"):
@@ -213,6 +216,8 @@ def stream_sam(eng: "_engine.Engine", paths, fd: int, rg_id: bytes | None = None
         o.sam.bx_index = bx_index
     o.continue_cloud_ids = int(continue_cloud_ids)
     o.clouds.density_opt = int(density_opt)
+    if density_seed is not None:
+        o.clouds.seed_private, o.clouds.seed = 1, int(density_seed) & 0xffffffff
     keep2 = None
     if fastq_mates is not None:      # `ema align -1 [-2]`: paths are FASTQ files; fastq_mates[k] = the mate-2 file of paths[k] or None (interleaved)
         o.stream.fastq_input = 1

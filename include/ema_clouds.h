@@ -50,9 +50,16 @@ typedef struct {
 	double density_probs[16];
 	int32_t emit;             /* what ema_clouds_out carries: 0 lines / recs / alts / idents (ema_sam_write's input); 1 the compact form only
 	                           * (descs / xas / sel_at: ema_sam_dev_write's input -- no per-record structs, no copies of the names); 2 both */
+	/* -d, where the draws come from.  0: the process's libc rand() stream (ema_clouds_reseed), shared by every call -- ONE reference process
+	 * over everything this process prints, the `-x` run.  1: this call draws from a stream of its own, seeded with `seed` exactly as
+	 * srand(seed) seeds rand() (glibc's random_r on a 128-byte state is the generator behind rand()) -- the bucket as its own
+	 * `ema align -s bucket` process, which is how the reference runs buckets in parallel (README.md:127-130; every process seeds once, from
+	 * time(), at its first bad cloud: src/split.c:54-59).  Calls with streams of their own may run concurrently. */
+	int32_t seed_private;
+	uint32_t seed;
 	int32_t pad_;
 } ema_cloud_opts;
-void ema_cloud_opts_default(ema_cloud_opts *o);   /* 50000, 0, 0, 0; no -d, the 10x density model */
+void ema_cloud_opts_default(ema_cloud_opts *o);   /* 50000, 0, 0, 0; no -d, the 10x density model, the process's rand() stream */
 /* srand(seed) for -d, as the reference's first bad cloud does with time(NULL) (src/split.c:54-59); without a call the library seeds
  * from the clock at its first use, like the reference */
 void ema_clouds_reseed(unsigned seed);

@@ -199,6 +199,30 @@ def test_density_optimiser_on_many_threads_draws_as_on_one(tmp_path):
     assert stats[0]["groups"] > 40 and stats[0]["bad_clouds"] > 5
     assert texts[0] == texts[1]
     assert texts[0] != texts[2], "-d changed nothing: the test has no teeth"
+    # [r6] a stream of draws of the call's own (ema_cloud_opts.seed_private: glibc's random_r on a 128-byte state) seeded with the same
+    # value is the same sequence as srand() / rand() -- whatever the process's stream was seeded with in between -- and a different
+    # seed moves differently; two calls with streams of their own do not disturb each other when they run at the same time
+    co = clouds.default_opts()
+    co.n_threads, co.density_opt, co.seed_private, co.seed = 7, 1, 1, 4242
+    clouds.reseed(7)
+    sel = clouds.select(bucket, batch, rec, pair_off, names, co)
+    assert sam.format_lines(sel.lines, sel.n_lines, sam.default_opts()) == texts[0]
+    co.seed = 4243
+    sel = clouds.select(bucket, batch, rec, pair_off, names, co)
+    assert sam.format_lines(sel.lines, sel.n_lines, sam.default_opts()) != texts[0]
+    import threading
+    got = {}
+    def one(seed):
+        c2 = clouds.default_opts()
+        c2.n_threads, c2.density_opt, c2.seed_private, c2.seed = 3, 1, 1, seed
+        sl = clouds.select(bucket, batch, rec, pair_off, names, c2)
+        got[seed] = sam.format_lines(sl.lines, sl.n_lines, sam.default_opts())
+    th = [threading.Thread(target=one, args=(sd,)) for sd in (4242, 4242 + 1, 4242 + 2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got[4242] == texts[0] and got[4243] != texts[0]
     O.clouds_density(True, seed=4242)
     try:
         arr, n, keep, rows, next_id = oracle_selection(bucket, batch, rec, pair_off, names)

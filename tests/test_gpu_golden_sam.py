@@ -24,6 +24,27 @@ REF_GPU = os.path.join(os.environ.get("EMA_REF_OUT") or os.path.join(os.environ.
 RUN_REF_BINARY = os.environ.get("EMA_RUN_REF_BINARY") == "1" and os.path.exists(REF_GPU)
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if Run(c).density_opt and not Run(c).x_mode and len(Run(c).paths) == 1], ids=lambda c: c["name"])
+def test_a_bucket_with_its_own_stream_of_draws_equals_the_reference_process(case, tmp_path):
+    """`-d` with ema_cloud_opts.seed_private: the bucket draws from a glibc random_r stream of its own, seeded with the
+    value the reference process's time() gave -- the same SAM text as the reference's srand() / rand(), byte for byte, without
+    touching the process's rand() (which is seeded with something else here to prove it)."""
+    from ema_amd import clouds
+    run = Run(case)
+    prefix, contigs = reference(case["ref"])
+    eng = E.Engine(prefix)
+    out = str(tmp_path / "out.sam")
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    head = run.header(contigs)
+    assert os.write(fd, head) == len(head)
+    clouds.reseed(12345)
+    stream.stream_sam(eng, run.paths, fd, rg_id=run.rg_id, platform=run.platform, bx_index=run.bx_index, density_opt=True, density_seed=run.density_seed,
+                      fastq_mates=[run.fastq_mate] if run.fastq else None)
+    os.close(fd)
+    eng.close()
+    assert open(out, "rb").read() == run.expected
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_stream_sam_equals_the_reference_host_code(case, tmp_path):
     run = Run(case)

@@ -184,8 +184,12 @@ def test_raw_fastq_through_count_and_preproc_to_sam(tmp_path):
     _check(tmp_path, prefix, ctg, paths, st["pairs_written"], False, True)
 
 
-def test_hundred_buckets_streamed_with_the_density_optimiser(tmp_path):
-    """BASELINE configs[2]'s shape: a hundred-odd barcode buckets through ONE ema_stream_sam call with `-d` on
+@pytest.mark.parametrize("draws", ["one_stream_for_the_run", "a_stream_per_bucket"])
+def test_hundred_buckets_streamed_with_the_density_optimiser(tmp_path, draws):
+    """[r6] draws: the process's one rand() stream through all buckets in order (one cloud thread), or every bucket its own stream seeded
+    seed + k (ema_cloud_opts.seed_private: each bucket an `ema align -s` process of its own; three cloud threads) -- the oracle chain
+    reseeds per bucket then.
+    BASELINE configs[2]'s shape: a hundred-odd barcode buckets through ONE ema_stream_sam call with `-d` on
     (ema_cloud_opts.density_opt; rand() seeded once, as the reference's first bad cloud does), the SAM text against the all-oracle
     chain -- oracle/ingest.c, the oracle's candidates and append stage, oracle/clouds.c WITH its restatement of src/split.c (pinned
     to the reference's own -d output by tests/test_golden_sam.py), oracle/sam.c -- byte for byte, bucket after bucket.  A reference
@@ -205,8 +209,9 @@ def test_hundred_buckets_streamed_with_the_density_optimiser(tmp_path):
     eng = E.Engine(prefix)
     out = str(tmp_path / "out.sam")
     fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    clouds.reseed(seed)
-    bst, sst = stream.stream_sam(eng, paths, fd, rg_id=b"rg1", density_opt=True)
+    per_bucket = draws == "a_stream_per_bucket"
+    clouds.reseed(seed if not per_bucket else 99)
+    bst, sst = stream.stream_sam(eng, paths, fd, rg_id=b"rg1", density_opt=True, density_seed=seed if per_bucket else None)
     os.close(fd)
     eng.close()
     got = open(out, "rb").read()
@@ -216,7 +221,11 @@ def test_hundred_buckets_streamed_with_the_density_optimiser(tmp_path):
     for on in (True, False):
         O.clouds_density(on, seed=seed if on else None)
         try:
-            texts[on] = [oracle_sam(prefix, path, names, so)[0] for path in paths]
+            texts[on] = []
+            for k, path in enumerate(paths):
+                if on and per_bucket:
+                    O.clouds_density(True, seed=seed + k)
+                texts[on].append(oracle_sam(prefix, path, names, so)[0])
         finally:
             O.clouds_density(False)
     want = b"".join(texts[True])

@@ -21,7 +21,7 @@ from ema_amd import shard
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(minutes=5))
 n = 5
-local = np.array([[1000 + b, 3 * b, 2 * b, b, 0, 1, 7] for b in range(n)], dtype=np.int64)
+local = np.array([[1000 * (f + 1) + b for f in range(len(shard.STAT_FIELDS))] for b in range(n)], dtype=np.int64)
 table = shard.gather_stats(local, n, device="cuda")
 t = torch.ones(4, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
 print(json.dumps({"backend": dist.get_backend(), "table": table.tolist(), "allreduce": t.tolist()}))
@@ -42,5 +42,6 @@ def test_rccl_all_gather_of_bucket_statistics_at_world_size_1():
     import json
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["backend"] == "nccl"
-    assert d["table"] == [[1000 + b, 3 * b, 2 * b, b, 0, 1, 7] for b in range(5)]
+    from ema_amd import shard
+    assert d["table"] == [[1000 * (f + 1) + b for f in range(len(shard.STAT_FIELDS))] for b in range(5)]      # every field of the record, bucket by bucket
     assert d["allreduce"] == [1.0] * 4

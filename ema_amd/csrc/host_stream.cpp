@@ -19,6 +19,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/stat.h>
 #include "ema_stream.h"
 #include "host_cpuacct.h"
 #include "host_pool.h"
@@ -485,7 +486,16 @@ int run_stream(ema_engine_t *e, Stream &S, ema_stream_sink sink, void *user, ema
 	AsyncState A;
 	// (two device readers taking turns were measured, r05p: 5.9-6.1 M pairs/s files -> SAM against 6.3 M with one -- the stream is bound
 	// by the GPU's passes, and two readers only contend for the copy engines)
-	const size_t n_readers = 1;
+	// [r6] ... with buckets of 262 K pairs.  With BASELINE configs[2]'s 50-100 K-pair buckets a bucket's fixed costs -- four waits for small
+	// kernels on a busy device -- are most of its 10 ms and ONE reader delivers 5.3 M pairs/s, the stream's bound: two readers there
+	// (500 buckets of 52 K pairs, files -> SAM: 5.0-5.4 -> 6.4-6.5 M pairs/s; three: the same; profiles/r06_sam_leg_ab.txt).  By the
+	// first file's size; tuning knob stream_readers overrides.
+	size_t n_readers = 1;
+	if (S.paths && !S.items.empty() && S.dev_reader) {
+		struct stat sb;
+		if (stat(S.paths[0], &sb) == 0 && sb.st_size < (off_t)48 << 20) n_readers = 2;
+	}
+	if (const char *v = ema_tuning_get("stream_readers")) n_readers = (size_t)std::max(1, std::min(4, atoi(v)));
 	if (S.paths) for (size_t t = 0; t < n_readers; ++t) th.emplace_back(reader, std::ref(S), t, n_readers);
 	if (S.n_eng == 2) {
 		for (int w = 0; w < S.n_eng; ++w) th.emplace_back(worker, std::ref(S), w);

@@ -177,7 +177,7 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 			memset(buf + len, 0, 64);
 		}
 		lap("pread (page-locked)");
-		ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));      // (a queue of the highest priority for these small kernels: measured, no effect -- profiles/r06_sam_leg_ab.txt)
 		ING(dev_pool().take(len + 64 + 512, txt, device));
 		char *d_text = (char *)txt.p;
 		unsigned long long *d_cnt = (unsigned long long *)(d_text + ((len + 64 + 255) & ~(size_t)255));      // [n_nl][select's count][irregular]

@@ -44,7 +44,7 @@ VALU_PEAK_GINST = 256 * 4 * 0.5 * 2.4
 CHR20_LEN = 64_444_167
 ENGINE_KNOBS = ("EMA_SEED_ROUNDS", "EMA_SEED_PARK", "EMA_SEED_BLOCKS_PER_CU", "EMA_FULL_SEED_LANE", "EMA_LANE_ALIGN", "EMA_FULL_OWN_STREAM",
                 "EMA_KMER_K", "EMA_HEAVY_CHAINS", "EMA_SEED_TAIL", "EMA_SEED_LONG_WAVE", "EMA_LEAN_SEED_EXTENDS", "EMA_GRID", "EMA_LEAN_INTERVALS",
-                "EMA_LEAN_REGIONS", "EMA_DEVICE_MERGE", "EMA_TUNING", "EMA_EXT_LANE")      # (ema_amd/engine.py hands the EMA_<KNOB> ones to ema_engine_set_tuning)
+                "EMA_LEAN_REGIONS", "EMA_DEVICE_MERGE", "EMA_TUNING")      # (ema_amd/engine.py hands the EMA_<KNOB> ones to ema_engine_set_tuning)
 
 
 def log(*a):

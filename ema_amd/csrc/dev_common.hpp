@@ -253,7 +253,7 @@ __device__ __forceinline__ void ema_lane_extend(const DevIndex &ix, uint64_t x_n
 	o_nb = ix.L2[cc] + 1 + (cc == 3 ? tk[3] : cc == 2 ? tk[2] : cc == 1 ? tk[1] : tk[0]);
 }
 
-// [r6] bwt_extend for ONE symbol from the two rank blocks in registers -- the lane machines' form (k_seed.hip, k_seed_bwd.hip,
+// [r6] bwt_extend for ONE symbol from the two rank blocks in registers -- the lane machines' form (k_seed.hip,
 // k_seed_p3.hip), where a tick's instruction count is what the chip is short of.  bwt_extend derives all four symbols' intervals;
 // the caller keeps one: its size s[cc], the rows of the larger symbols before it (n_gt = s[cc + 1] + .. + s[3], what the untouched
 // coordinate advances by) and its start L2[cc] + 1 + occ(cc, k - 1).  So the sizes stay 32-bit DIFFERENCES of the two blocks'

@@ -73,8 +73,6 @@ struct DevOpts {
 	// bit 2 = one control pass per tick ("one pass per tick")
 	// bit 3 = pass 3 (the LAST-like seeds, bwt_seed_strategy1) runs as a kernel of its own behind K1 (k_seed_p3.hip); K1 then ends a
 	//         read after pass 2 and leaves the extends it has used in seed_ext[read] (the lean budget runs on across the passes)
-	// bit 4 = [r6] the backward phases of bwt_smem1 run as tasks of a machine of their own (k_seed_bwd.hip): K1 ends a search after
-	//         its forward phase and leaves a SeedTask; needs bit 3 and the table mode
 	int seed_flags;
 	int32_t *seed_ext;
 };
@@ -94,28 +92,6 @@ struct Intv { uint64_t x0, x1, x2, info; };
 #define EMA_SEED_BUDGET_LEAN 4096
 #define EMA_SEED_BUDGET_LANE 2048      // ... when the reads over it are seeded by K1w in place (engine.hip, run_seed) instead of going to the full tier
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
-
-// [r6] K1 -> K1b (k_seed_bwd.hip): the backward phase of one bwt_smem1 search as a task.  The forward phase left its intervals
-// (bwa's `curr` vector before the swap: one per change of the interval's size, shortest match first) in a pool; the task names them,
-// carries the last one -- the longest match, the first entry of the first backward row -- so that the first extend is posted
-// without a look-up, and says where the row walk begins.  list: index of the first entry the backward phase uses (entries the
-// window test ruled out come before it); geom = entries | sm_x << 16 | c_end << 24 (sm_x: the position the search started at, the
-// first row extends with the base at sm_x - 1; c_end: where the longest match ends).  n_ext: the read's extends when the task
-// was left (the lean budget runs on from there).
-struct SeedTask { uint64_t c0, c2; uint32_t c_code; int32_t read; uint32_t list; int32_t min_intv; int32_t n_ext; uint32_t geom; uint32_t pad[2]; };
-// what a K1 launch of the split form needs beside its own arguments
-struct SeedSplit {
-	SeedTask *tasks;                   // [0, cap_heavy): tasks with at least heavy_min entries (K1b takes them first), [cap_heavy, cap_heavy + cap_light): the others
-	int *n_task;                       // [2]: tasks left in either part (may exceed the caps: the surplus was not written, its reads are flagged)
-	int cap_heavy, cap_light, heavy_min;
-	Intv *pool;                        // forward lists, handed out to the lanes in chunks of EMA_SEED_CHUNK entries
-	unsigned long long *pool_used;
-	unsigned long long pool_cap;       // entries
-	int phase;                         // 1: pass 1 of every read (fresh reads); 2: pass 2 (the reads come with their pass-1 intervals)
-	unsigned long long *prof;          // tuning knob seed_split_prof=1 (else null): [0] tasks, [1] their ticks, [2] K1b wave-ticks, [3] busy lane-ticks, [4] longest task,
-	                                   // [5] longest wave, [8 + b] tasks / [16 + b] ticks by first-row entries (<= 2, 4, 8, .. 128, more); K1 split form: [24] wave-ticks, [25] busy lane-ticks, [26] longest wave
-};
-#define EMA_SEED_CHUNK 256       // = EMA_LIST_CAP: a fresh chunk holds any forward list
 
 // bwa's mem_seed_t plus the link to the next seed of the same chain
 struct SeedRec { int64_t rbeg; int32_t qbeg, len; int32_t next, pad; };
@@ -142,13 +118,6 @@ struct ChainRec {
 struct HandHdr { int32_t read, n_chn, n_seed, l_query; uint32_t base_off; int32_t chain_from, n_av, pad; };
 #define EMA_HAND_BYTES (sizeof(HandHdr) + (size_t)EMA_HAND_SEEDS * (8 + sizeof(ChainRec) + sizeof(SeedRec)) + (size_t)EMA_HAND_REGS * sizeof(DevReg))
 
-// K2x (k_ext_lane.hip): the extension of a chain's first seed as a task of its own, one LANE per task.  A task names the seed, the
-// chain's window [rmax0, rmax1) as mem_chain2aln computes it, the read (its nt4 bytes at q_off of the batch's bases), and the slot
-// of its result: the region's ends and scores as mem_chain2aln derives them from ksw_extend2's two calls.  valid[slot] says whether
-// the result was computed (a task may be given up: band doubling, a window that does not fit); the consumer then runs the DP itself.
-struct ExtTask { int64_t rbeg, rmax0, rmax1; uint32_t q_off; int32_t l_query, qbeg, len, res, pad; };
-struct ExtRes { int64_t rb, re; int32_t qb, qe, score, truesc; };
-
 // Chain-rich reads (hundreds of chains, nearly every one of them extended: a read from a young repeat family) are a long
 // serial job for the one wavefront that owns them -- two extension DPs per chain, one after the other -- and they set the
 // length of a K2b launch once the work queue is empty.  K2b therefore sets such a read aside after the chain filter: its
@@ -167,10 +136,6 @@ struct HeavyCtl {
 	int *n_reads, *n_tasks;
 	int reads_cap, tasks_cap;
 	int min_chains;                    // a read with at least this many chains to extend is set aside
-	// K2x (k_ext_lane.hip) for K2a's hand-overs (mode 3): slot [record * EMA_HAND_SEEDS + chain in filtered order] holds the region of
-	// the chain's first seed when xvalid says so.  Null: every extension is run by the wave-per-read kernel.
-	const ExtRes *xres;
-	const uint8_t *xvalid;
 };
 struct HeavyHdr {                      // head of a record; the arrays follow at the offsets given (bytes from the record's start)
 	int32_t read, n_chn, n_chain, n_seed, status, n_ext;

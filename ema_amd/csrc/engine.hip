@@ -80,7 +80,7 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
                                 int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, const int *order, int n_blocks,
-                                hipStream_t stream, unsigned long long *prof, const SeedSplit *split);
+                                hipStream_t stream, unsigned long long *prof);
 extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack, const uint32_t *off, int n_reads, int *order, int *cnt, int n_samples,
                                       int mult4, hipStream_t stream);
 extern "C" size_t ema_seed_park_bytes();
@@ -110,18 +110,8 @@ extern "C" void ema_k4_prof_read(unsigned long long *out);
 extern "C" void ema_launch_seed_p3(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads, const int *n_pairs_dev,
                                    const int *map, Intv *intv, int *n_intv, int *status, const int32_t *ext, int *counter, int *long_list, int *n_long,
                                    int long_cap, int n_blocks, hipStream_t stream);
-extern "C" int ema_seed_splits_backward(const DevIndex *ix, const DevOpts *opt, const unsigned long long *prof);
-extern "C" void ema_launch_seed_bwd(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const int *map, const SeedSplit *sp, Intv *intv,
-                                    int *n_intv, int *status, Intv *lists, int *counter, int n_blocks, hipStream_t stream);
-extern "C" int ema_seed_bwd_blocks_per_cu();
 extern "C" int ema_seed_splits_pass3(const DevOpts *opt, const unsigned long long *prof);
 extern "C" size_t ema_align_lane_wave_bytes();
-// K2x (k_ext_lane.hip): the first seed of every chain K2a hands over, extended one lane per seed
-extern "C" void ema_launch_ext_plan_hand(const DevIndex *ix, const DevOpts *opt, const uint8_t *hand, const int *n_hand, int max_records, ExtTask *tasks, int *n_tasks,
-                                         int tasks_cap, uint8_t *valid, hipStream_t stream);
-extern "C" void ema_launch_ext_lane(const DevIndex *ix, const DevOpts *opt, const uint8_t *bases, const ExtTask *tasks, const int *n_tasks, int tasks_cap,
-                                    ExtRes *res, uint8_t *valid, int *counters, int n_cu, hipStream_t stream, unsigned long long *prof);
-extern "C" int ema_ext_lane_supported(const DevOpts *opt);
 extern "C" int ema_align_simple_blocks_per_cu();
 extern "C" void ema_launch_align_simple(const DevIndex *ix, const DevOpts *opt, const uint32_t *qpack, const uint32_t *off, int n_reads,
                                         const int *n_pairs_dev, const int *map, const Intv *intv, const int *n_intv, DevReg *regs,
@@ -237,15 +227,6 @@ struct Slice {
 	DevBuf<uint8_t> d_heavy;                      // chain-rich reads set aside by K2b: records (dev_types.h, HeavyCtl)
 	DevBuf<unsigned long long> d_heavy_reads, d_heavy_tasks;
 	DevBuf<int32_t> d_sext;                       // K1 -> K1c: the extends a read's passes 1 and 2 used (k_seed_p3.hip)
-	DevBuf<SeedTask> d_stasks;                    // [r6] K1 -> K1b (k_seed_bwd.hip): backward phases as tasks, heavy part then light part (dev_types.h, SeedSplit),
-	DevBuf<Intv> d_spool;                         //      the forward lists they start from,
-	DevBuf<int> d_sctr;                           //      [0..1] tasks left in either part, [2] K1b's queue, [4..5] pool entries handed out (u64), [6] the pass-2 launch's queue
-	DevBuf<unsigned long long> d_sprof;           //      tuning knob seed_split_prof=1: SeedSplit::prof, printed when the engine closes
-	SeedSplit split = SeedSplit();
-	DevBuf<ExtTask> d_xtasks;                     // K2x: seed tasks of this pass, their results by record and chain, the flags that say which were computed,
-	DevBuf<ExtRes> d_xres;                        //      and [0] the task count, [1..3] the claim counters of the three launches (k_ext_lane.hip)
-	DevBuf<uint8_t> d_xvalid;
-	DevBuf<int> d_xctr;
 	DevBuf<uint8_t> d_slabs, d_park[2], d_hand;   // d_hand: K2a -> K2b records (EMA_HAND_BYTES per read)   // d_park: K1's parked machines, ping-pong between the launches of a series
 	DevBuf<DevAln> d_alns;
 	DevBuf<uint32_t> d_cigars, d_cigar_out;
@@ -275,7 +256,7 @@ struct Slice {
 	{
 		d_intv.release(); d_lists.release(); d_n_intv.release();
 		d_status.release(); d_long.release(); d_order.release(); d_n_regs.release(); d_counters.release(); d_cig_n.release(); d_kdone.release(); d_todo.release(); d_regs.release(); d_slabs.release(); d_park[0].release(); d_park[1].release(); d_hand.release();
-		d_xtasks.release(); d_xres.release(); d_xvalid.release(); d_xctr.release(); d_sext.release(); d_stasks.release(); d_spool.release(); d_sctr.release(); d_sprof.release();
+		d_sext.release();
 		d_heavy.release(); d_heavy_reads.release(); d_heavy_tasks.release();
 		d_alns.release(); d_cigars.release(); d_cigar_out.release(); d_cand_off.release(); d_cig_off.release(); d_cand.release();
 		for (auto &o : out) o.release();
@@ -433,10 +414,6 @@ struct ema_engine {
 	bool lane_align = true;              // EMA_LANE_ALIGN=0: every read through the wave-per-read K2b
 	int seed_p3_blocks = 4;              // K1c's grid: 256-thread blocks per CU (tuning knob seed_p3_blocks_per_cu)
 	bool seed_split3 = true;             // tuning knob seed_split3=0: pass 3 inside K1's machine (round 4); 1: its own kernel behind K1 (k_seed_p3.hip)
-	bool seed_split = false;             // [r6] tuning knob seed_split=1: backward phases as tasks of K1b (k_seed_bwd.hip); 0: inside K1's machine (round 5)
-	int seed_bwd_blocks = 4, seed_heavy_min = 24;      // K1b's grid (blocks per CU, knob seed_bwd_blocks_per_cu); forward lists this long go first (knob seed_heavy_min)
-	bool ext_lane = false;               // tuning knob ext_lane=1: K2x (k_ext_lane.hip), the first seed of every handed-over chain extended one lane per seed.  Parity-green and OFF: measured slower (profiles/r05_k2x_profile.txt, DESIGN section 3 [r5])
-	unsigned long long *d_xprof = nullptr;      // tuning knob ext_lane_prof=1: K2x's counters (24 words)
 	bool small_one_slice = true;         // EMA_SMALL_ONE_SLICE=0: asynchronous passes always cut a batch into all slices
 	int heavy_attempts = 8;              // K3b sets a pair with at least this many candidate rescue anchors aside for K3t / K3r (0: never)
 	int heavy_regions = 8;               // K4b sets a read with at least this many regions left aside for K4t / K4r (0: never)
@@ -502,7 +479,7 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_intv.alloc(n_reads * (size_t)s.dopts.intv_cap));
 	HIPCHK(e, s.d_n_intv.alloc(n_reads));
 	HIPCHK(e, s.d_status.alloc(n_reads));
-	HIPCHK(e, s.d_lists.alloc(std::max((size_t)e->seed_blocks * 2, (size_t)e->n_cu * e->seed_bwd_blocks) * 256 * EMA_LIST_CAP));      // K1: lists F and B per lane; K1b: list B
+	HIPCHK(e, s.d_lists.alloc((size_t)e->seed_blocks * 256 * 2 * EMA_LIST_CAP));
 	HIPCHK(e, s.d_regs.alloc(n_reads * (size_t)s.dopts.reg_cap));
 	HIPCHK(e, s.d_n_regs.alloc(n_reads));
 	if (&s != &e->full && e->seed_order) HIPCHK(e, s.d_order.alloc(n_reads));
@@ -532,23 +509,6 @@ static int slice_alloc(ema_engine *e, Slice &s, hipStream_t shared_stream)
 	HIPCHK(e, s.d_kdone.alloc(n_reads));
 	HIPCHK(e, s.d_hand.alloc(n_reads * EMA_HAND_BYTES));
 	if (e->seed_split3) { HIPCHK(e, s.d_sext.alloc(n_reads + 1)); s.dopts.seed_ext = s.d_sext.p; s.dopts.seed_flags |= 8; }
-	if (e->seed_split3 && e->seed_split && &s != &e->full && e->dix.kmer_k > 0) {
-		// K1b's tasks and the forward lists behind them.  Measured on the benchmark mix: 1.25 tasks and 21 list entries per read and pass;
-		// a read whose task or list finds no room goes to the full-capacity tier (EMA_ST_LIST_OVERFLOW)
-		SeedSplit &sp = s.split;
-		sp.cap_heavy = (int)n_reads; sp.cap_light = (int)(8 * n_reads); sp.heavy_min = e->seed_heavy_min;
-		HIPCHK(e, s.d_stasks.alloc((size_t)sp.cap_heavy + sp.cap_light));
-		sp.pool_cap = 48 * n_reads + (size_t)e->seed_blocks * 256 * EMA_SEED_CHUNK;      // (every lane's first chunk + what the tasks keep)
-		HIPCHK(e, s.d_spool.alloc(sp.pool_cap));
-		HIPCHK(e, s.d_sctr.alloc(16));
-		sp.tasks = s.d_stasks.p; sp.pool = s.d_spool.p; sp.n_task = s.d_sctr.p; sp.pool_used = (unsigned long long *)(s.d_sctr.p + 4);
-		s.dopts.seed_flags |= 16;
-		if (ema_tuning_get("seed_split_prof")) { HIPCHK(e, s.d_sprof.alloc(32)); HIPCHK(e, hipMemset(s.d_sprof.p, 0, 256)); sp.prof = s.d_sprof.p; }
-	}
-	if (e->ext_lane) {
-		HIPCHK(e, s.d_xtasks.alloc(n_reads * 3 + 1024)); HIPCHK(e, s.d_xres.alloc(n_reads * EMA_HAND_SEEDS + 8));
-		HIPCHK(e, s.d_xvalid.alloc(n_reads * EMA_HAND_SEEDS + 64)); HIPCHK(e, s.d_xctr.alloc(8));
-	}
 	HIPCHK(e, s.d_todo.alloc(n_reads));
 	HIPCHK(e, s.d_cand_off.alloc(n_reads + 1));
 	HIPCHK(e, s.d_cig_off.alloc(n_reads + 1));
@@ -785,14 +745,7 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	if (const char *v = ema_tuning_get("merged_cigar")) e->merged_cig_per_read = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("lane_align")) e->lane_align = atoi(v) != 0;
 	if (const char *v = ema_tuning_get("seed_split3")) e->seed_split3 = atoi(v) != 0;
-	if (const char *v = ema_tuning_get("seed_split")) e->seed_split = atoi(v) != 0;
-	if (const char *v = ema_tuning_get("seed_heavy_min")) e->seed_heavy_min = std::max(1, atoi(v));
-	e->seed_bwd_blocks = std::min(e->seed_bwd_blocks, ema_seed_bwd_blocks_per_cu());
-	if (const char *v = ema_tuning_get("seed_bwd_blocks_per_cu")) e->seed_bwd_blocks = std::max(1, std::min(ema_seed_bwd_blocks_per_cu(), atoi(v)));
 	if (const char *v = ema_tuning_get("seed_p3_blocks_per_cu")) e->seed_p3_blocks = std::max(1, std::min(6, atoi(v)));
-	if (const char *v = ema_tuning_get("ext_lane")) e->ext_lane = atoi(v) != 0;
-	if (!e->lane_align) e->ext_lane = false;
-	if (const char *v = ema_tuning_get("ext_lane_prof")) if (atoi(v) != 0 && !e->d_xprof) { HIPCHK(e, hipMalloc(&e->d_xprof, 24 * 8)); HIPCHK(e, hipMemset(e->d_xprof, 0, 24 * 8)); }
 	if (const char *v = ema_tuning_get("heavy_chains")) e->heavy_chains = std::max(0, atoi(v));
 	if (const char *v = ema_tuning_get("heavy_attempts")) e->heavy_attempts = std::max(0, atoi(v));      // (the parity tests lower these two so that every
 	if (const char *v = ema_tuning_get("heavy_regions")) e->heavy_regions = std::max(0, atoi(v));        //  pair / read takes the set-aside route)
@@ -851,39 +804,12 @@ static int engine_open(const char *index_prefix, const ema_engine *share, int de
 	return EMA_OK;
 }
 
-// K2x's counters (tuning knob ext_lane_prof=1), summed over every launch since the engine opened or the last call: per class of
-// task (longer query < 64, < 128, < 256 bases) eight words -- wavefront lifetimes in shader clocks, wavefronts, row-steps,
-// lane-rows (lanes busy in a row-step), DP cells, tasks finished, DP sides run, unused
-int ema_engine_debug_xprof(ema_engine_t *e, uint64_t out[24])
-{
-	if (!e || !out) return EMA_EARG;
-	memset(out, 0, 24 * 8);
-	if (!e->d_xprof) return EMA_OK;
-	HIPCHK(e, hipSetDevice(e->device));
-	HIPCHK(e, hipDeviceSynchronize());
-	HIPCHK(e, hipMemcpy(out, e->d_xprof, 24 * 8, hipMemcpyDeviceToHost));
-	HIPCHK(e, hipMemset(e->d_xprof, 0, 24 * 8));
-	return EMA_OK;
-}
-
 void ema_engine_close(ema_engine_t *e)
 {
 	if (!e) return;
 	if (e->shadow) { ema_engine_close(e->shadow); e->shadow = nullptr; }
 	(void)hipSetDevice(e->device);
 	(void)hipDeviceSynchronize();
-	for (size_t k = 0; k < e->sl.size(); ++k) if (e->sl[k].d_sprof.p) {      // tuning knob seed_split_prof=1 (dev_types.h, SeedSplit::prof)
-		unsigned long long h[32];
-		if (hipMemcpy(h, e->sl[k].d_sprof.p, 256, hipMemcpyDeviceToHost) != hipSuccess) continue;
-		fprintf(stderr, "K1 split, slice %zu: K1b tasks %llu, ticks %llu (%.1f per task, longest %llu), wave-ticks %llu (%.1f lanes busy, longest wave %llu); K1 forward: wave-ticks %llu (%.1f lanes busy, longest wave %llu)\n",
-		        k, h[0], h[1], h[0] ? (double)h[1] / h[0] : 0.0, h[4], h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[5], h[24], h[24] ? (double)h[25] / h[24] : 0.0, h[26]);
-		fprintf(stderr, "   tasks by first-row entries (<= 2, 4, 8, 16, 32, 64, 128, more): count");
-		for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", h[8 + b]);
-		fprintf(stderr, "; ticks");
-		for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", h[16 + b]);
-		fprintf(stderr, "\n");
-	}
-	if (e->d_xprof) { (void)hipFree(e->d_xprof); e->d_xprof = nullptr; }
 	if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
 	if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
 	for (auto &ev : e->slot_free) if (ev) (void)hipEventDestroy(ev);
@@ -946,11 +872,11 @@ int ema_engine_index_info(const ema_engine_t *e, int32_t info[4])
 	info[0] = e->dix.n_super; info[1] = EMA_OCC_SUPER_SHIFT; info[2] = e->dix.sa_width; info[3] = e->dix.kmer_k;
 	return EMA_OK;
 }
-int ema_engine_debug_grids(const ema_engine_t *e, int32_t grids[6])
+int ema_engine_debug_grids(const ema_engine_t *e, int32_t grids[5])
 {
 	if (!e || !grids || e->n_cu <= 0) return EMA_EARG;
-	const int b[6] = {e->seed_blocks, e->lane_blocks, e->align_blocks, e->pair_blocks, e->final_blocks, e->n_cu * e->seed_bwd_blocks};
-	for (int k = 0; k < 6; ++k) grids[k] = b[k] / e->n_cu;
+	const int b[5] = {e->seed_blocks, e->lane_blocks, e->align_blocks, e->pair_blocks, e->final_blocks};
+	for (int k = 0; k < 5; ++k) grids[k] = b[k] / e->n_cu;
 	return EMA_OK;
 }
 size_t ema_engine_batch_capacity(const ema_engine_t *e) { return e ? e->cap_pairs : 0; }
@@ -1139,22 +1065,6 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 		ema_launch_seed_order(&e->dix, w.qpack, w.off, 2 * w.n_pairs, s.d_order.p, s.d_counters.p + 5, e->order_samples, e->order_mult4, s.stream);
 		HIPCHK(e, hipGetLastError());
 	}
-	if (&s != &e->full && s.d_stasks.p && ema_seed_splits_backward(&e->dix, &s.dopts, e->d_prof.p)) {
-		// [r6] the split series: pass 1 of every read (forward phases; window tests, anchors), its backward phases as K1b's tasks, pass 2
-		// from pass 1's SMEMs, its tasks, then K1c's pass 3 below -- which also lists the reads over the budget for K1w (nobody did before it)
-		for (int phase = 1; phase <= 2; ++phase) {
-			HIPCHK(e, hipMemsetAsync(s.d_sctr.p, 0, 16 * 4, s.stream));
-			s.split.phase = phase;
-			ema_launch_seed(&e->dix, &s.dopts, w.qpack, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_status.p,
-			                s.d_lists.p, phase == 1 ? s.d_counters.p + 3 : s.d_sctr.p + 6, nullptr, s.d_counters.p + 16, nullptr, s.d_counters.p + 17,
-			                0, nullptr, s.d_counters.p + 18, 0, ordered ? s.d_order.p : nullptr, e->seed_blocks, s.stream, nullptr, &s.split);
-			HIPCHK(e, hipGetLastError());
-			ema_launch_seed_bwd(&e->dix, &s.dopts, w.qpack, w.map, &s.split, s.d_intv.p, s.d_n_intv.p, s.d_status.p, s.d_lists.p, s.d_sctr.p + 2,
-			                    e->n_cu * e->seed_bwd_blocks, s.stream);
-			HIPCHK(e, hipGetLastError());
-		}
-		watchdog(e, s, "ema_k_seed (split)");
-	} else {
 	// a series of launches: fresh reads first, then the machines the retiring waves of the previous launch parked
 	const int rounds = e->seed_rounds;
 	for (int r = 0; r < rounds; ++r) {
@@ -1165,11 +1075,10 @@ static int run_seed(ema_engine *e, Slice &s, const Work &w)
 		                s.d_lists.p, r == 0 ? s.d_counters.p + 3 : s.d_counters.p + 8 + r, r == 0 ? nullptr : s.d_park[in].p,
 		                s.d_counters.p + 16 + in, last ? nullptr : s.d_park[out].p, s.d_counters.p + 16 + out,
 		                last ? 0 : e->seed_park_max, s.d_long.p, s.d_counters.p + 18, (int)(s.d_long.p ? e->long_cap : 0), ordered ? s.d_order.p : nullptr,
-		                e->seed_blocks, s.stream, e->d_prof.p, nullptr);
+		                e->seed_blocks, s.stream, e->d_prof.p);
 		HIPCHK(e, hipGetLastError());
 	}
 	watchdog(e, s, "ema_k_seed");
-	}
 	if (ema_seed_splits_pass3(&s.dopts, e->d_prof.p)) {
 		// K1c: pass 3 of every read K1 finished, as a three-state machine of its own (k_seed_p3.hip) -- before K1w takes the reads over
 		// the lean budget, which it seeds from scratch, all three passes
@@ -1205,24 +1114,12 @@ static int run_align(ema_engine *e, Slice &s, const Work &w)
 	const bool heavy = s.d_heavy.p != nullptr;
 	hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr;
 	hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30;
-	hv.xres = nullptr; hv.xvalid = nullptr;
-	if (e->lane_align && e->ext_lane && s.d_xres.p && ema_ext_lane_supported(&s.dopts)) {
-		// K2x: one task per chain of every record K2a handed over -- the chain's first seed, extended one lane per seed -- so that
-		// mode 3 below finds the regions ready and runs a wave DP only where no task was computed (k_ext_lane.hip)
-		HIPCHK(e, hipMemsetAsync(s.d_xctr.p, 0, 8 * 4, s.stream));
-		ema_launch_ext_plan_hand(&e->dix, &s.dopts, s.d_hand.p, s.d_counters.p + 24, (int)(2 * w.n_pairs), s.d_xtasks.p, s.d_xctr.p, (int)s.d_xtasks.n, s.d_xvalid.p, s.stream);
-		HIPCHK(e, hipGetLastError());
-		ema_launch_ext_lane(&e->dix, &s.dopts, e->cur_bases, s.d_xtasks.p, s.d_xctr.p, (int)s.d_xtasks.n, s.d_xres.p, s.d_xvalid.p, s.d_xctr.p + 1, e->n_cu, s.stream, e->d_xprof);
-		HIPCHK(e, hipGetLastError());
-		hv.xres = s.d_xres.p; hv.xvalid = s.d_xvalid.p;
-	}
 	if (e->lane_align) {      // (mode 3 reads K2a's dense records: their number is counter 24)
 		ema_launch_align(&e->dix, &s.dopts, e->cur_bases, w.off, 2 * w.n_pairs, w.n_dev, w.map, s.d_intv.p, s.d_n_intv.p, s.d_regs.p,
 		                 s.d_n_regs.p, s.d_status.p, nullptr, s.d_counters.p + 24, s.d_hand.p, s.d_slabs.p, s.d_counters.p + 22,
 		                 e->align_blocks, s.stream, s.dbg, e->d_prof.p, &hv, 3);
 		HIPCHK(e, hipGetLastError());
 	}
-	hv.xres = nullptr; hv.xvalid = nullptr;
 	if (heavy) {
 		hv.arena = s.d_heavy.p; hv.arena_bytes = s.d_heavy.n; hv.arena_used = reinterpret_cast<unsigned long long *>(s.d_counters.p + 30);
 		hv.reads = s.d_heavy_reads.p; hv.tasks = s.d_heavy_tasks.p; hv.n_reads = s.d_counters.p + 26; hv.n_tasks = s.d_counters.p + 27;
@@ -1771,9 +1668,8 @@ int ema_engine_set_opts(ema_engine_t *e, const ema_engine_opts *o)
 		dst = d; dst.intv_cap = ic; dst.reg_cap = rc; dst.cig_cap = cc; dst.seed_budget = sb;
 		dst.seed_ext = ext; if (ext) dst.seed_flags |= 8;
 	};
-	auto keep_split = [&](Slice &sl) { if (sl.d_stasks.p) sl.dopts.seed_flags |= 16; };
 	keep_caps(e->dopts);
-	for (auto &s : e->sl) { keep_caps(s.dopts); keep_split(s); }
+	for (auto &s : e->sl) keep_caps(s.dopts);
 	keep_caps(e->full.dopts);
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_FULL, &e->full.dopts, sizeof(DevOpts), hipMemcpyHostToDevice));
 	HIPCHK(e, hipMemcpy(e->d_k1w_args.p + K1W_OPTS_LEAN, &e->sl[0].dopts, sizeof(DevOpts), hipMemcpyHostToDevice));

@@ -1109,12 +1109,9 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				ema_clamp_window(ix, rmax0, c.f_rbeg, rmax1);
 			}
 			if (rmax1 - rmax0 > EMA_RSEQ_CAP) { cb.status |= EMA_ST_RSEQ_OVERFLOW; continue; }
-			// MODE 3 with K2x's results (k_ext_lane.hip): the first seed's region usually comes from the table and nothing else of the
-			// chain is extended, so the window is fetched only when a DP does run here -- as in K2d
-			const bool lazy_win = MODE == 3 && hv.xres != nullptr;
-			bool have_win = MODE != 2 && !lazy_win;      // K2d fetches the window only if it has to run a DP itself
+			bool have_win = MODE != 2;      // K2d fetches the window only if it has to run a DP itself
 			if (MODE == 3) {
-				if (!lazy_win && ci_sorted >= win_end) {
+				if (ci_sorted >= win_end) {
 					// The windows of this chain and of the next ones, as many as fit the buffer (at most four, each of at most 63 words +
 					// the odd bases: a longer one travels alone), in ONE round trip: every lane takes a word of each.
 					const int b = ci_sorted;
@@ -1152,7 +1149,7 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 					}
 					ema_wave_sync();
 				}
-				if (!lazy_win) rs = rseq + ema_uni((int)sl.kept[ci_sorted]);
+				rs = rseq + ema_uni((int)sl.kept[ci_sorted]);
 				// ks_introsort_64 on (score << 32 | index): keys are distinct, so the result is THE sorted order
 				ema_wave_sync();
 				if (cn > 1 && cn <= EMA_WAVE) ema_rank_sort_distinct(sl.srt, cn);      // (distinct keys: dev_sort.hpp)
@@ -1224,21 +1221,8 @@ ema_k_align_t(DevIndex ix, DevOpts opt, const uint8_t *__restrict__ bases, const
 				DevReg a;
 				if (MODE == 2 && ema_uni((int)hv_valid[hv_base + (cn - 1 - k)]) != 0) {
 					a = ema_uni(hv_res[hv_base + (cn - 1 - k)]);      // K2c extended this seed
-				} else if (MODE == 3 && lazy_win && k == cn - 1 && ema_uni((int)hv.xvalid[(size_t)rec_i * EMA_HAND_SEEDS + ci_sorted]) != 0) {
-					// K2x extended this seed (the chain's first in processing order): the region's ends and scores as the two ksw_extend2
-					// calls give them; the band was not doubled (a task that would have had to is left to the code below)
-					const ExtRes xr = hv.xres[(size_t)rec_i * EMA_HAND_SEEDS + ci_sorted];
-					a.rb = ema_uni(xr.rb); a.re = ema_uni(xr.re); a.qb = ema_uni(xr.qb); a.qe = ema_uni(xr.qe); a.score = ema_uni(xr.score); a.truesc = ema_uni(xr.truesc);
-					a.sub = a.csub = a.secondary = a.n_comp = a.is_alt = 0; a.rid = c.rid;
-					int cov = 0;
-					for (int t = lane; t < cn; t += EMA_WAVE) {
-						const SeedRec u = sl.cs[t];
-						if (u.qbeg >= a.qb && u.qbeg + u.len <= a.qe && u.rbeg >= a.rb && u.rbeg + u.len <= a.re) cov += u.len;
-					}
-					a.seedcov = ema_wave_sum(cov);
-					a.w = opt.w; a.seedlen0 = s.len; a.frac_rep = frac_rep;
 				} else {
-				if ((MODE == 2 || lazy_win) && !have_win) { ema_wave_fetch(ix, rmax0, rmax1, rseq); ema_wave_sync(); have_win = true; rs = rseq; }
+				if (MODE == 2 && !have_win) { ema_wave_fetch(ix, rmax0, rmax1, rseq); ema_wave_sync(); have_win = true; rs = rseq; }
 				a.sub = a.csub = a.secondary = a.n_comp = a.is_alt = 0; a.seedcov = 0;
 				int aw0 = opt.w, aw1 = opt.w;
 				a.score = a.truesc = -1;
@@ -1364,7 +1348,7 @@ extern "C" void ema_launch_align(const DevIndex *ix, const DevOpts *opt, const u
 {
 	HeavyCtl hv;
 	if (heavy) hv = *heavy;
-	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; hv.xres = nullptr; hv.xvalid = nullptr; }
+	else { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = nullptr; hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
 #define EMA_ALIGN_LAUNCH(...) hipLaunchKernelGGL((ema_k_align_t<__VA_ARGS__>), dim3(n_blocks), dim3(256), 0, stream, *ix, *opt, bases, off, n_reads, n_pairs_dev, map, intv, n_intv, regs, \
 	                   n_regs, status, todo, n_todo, hand, slabs, counter, dbg, prof, hv)
 	const int level = ema_align_light_prof ? 2 : prof != nullptr ? 1 : 0;

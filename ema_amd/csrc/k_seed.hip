@@ -153,21 +153,14 @@ __device__ __forceinline__ uint32_t seed_rev_bits(uint32_t v)
 #endif
 // P3: pass 3 (bwt_seed_strategy1) is part of this machine.  [r5] The product runs it as a kernel of its own (k_seed_p3.hip: a forward-only
 // machine of three states whose tick costs a fifth of this one's) and launches the <.., false> build, which carries none of its states.
-// SPLIT [r6]: the backward phases are k_seed_bwd.hip's.  This machine ends a search after its forward phase (and what decides about
-// the backward phase without running it: the window test, the anchors) and leaves a SeedTask; it carries none of the backward states
-// and no list B.  One launch runs pass 1 of every read (SeedSplit::phase 1), K1b works through its tasks, a second launch runs pass 2
-// -- whose searches start from pass 1's SMEMs, all of them in the read's list by then -- and K1b follows again; pass 3 is K1c's.  The
-// forward lists go to a pool the lanes take chunks of (a list must outlive the launch, so the lane's slab will not do): a search
-// whose forward phase leaves no task gives its room back, one that does moves the lane's cursor on.  No parking in this form: what
-// a read costs here is bounded by its length, and a task's cost is K1b's to balance.
-template <bool PROF, bool P3, bool SPLIT>      // PROF: the diagnostic build (tick statistics); the product build carries none of its registers
+template <bool PROF, bool P3>      // PROF: the diagnostic build (tick statistics); the product build carries none of its registers
 __global__ void __launch_bounds__(256, PROF ? 1 : EMA_SEED_WPS)
 ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const uint32_t *__restrict__ off, int n_reads,
            const int *__restrict__ n_pairs_dev, const int *__restrict__ map, Intv *__restrict__ intv,
            int *__restrict__ n_intv, int *__restrict__ status, Intv *__restrict__ lists,
            int *__restrict__ counter, const SeedPark *__restrict__ park_in, const int *__restrict__ n_park_in,
            SeedPark *__restrict__ park_out, int *__restrict__ n_park_out, int park_max, int *__restrict__ long_list,
-           int *__restrict__ n_long, int long_cap, const int *__restrict__ order, unsigned long long *prof_arg, SeedSplit sp)
+           int *__restrict__ n_long, int long_cap, const int *__restrict__ order, unsigned long long *prof_arg)
 {
 	unsigned long long *const prof = PROF ? prof_arg : nullptr;
 	__shared__ uint32_t lds_q[4][16 * 64];      // 2-bit read codes, 16 words per lane, lane-interleaved
@@ -208,8 +201,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 	const bool anchors = wtest && tails && (opt.seed_flags & 2);
 	const bool one_pass = (opt.seed_flags & 4) != 0;
 	uint32_t c_code = 0, f_code = 0, r_code = 0, req_code = 0, req_len = 0;      // 2-bit codes of the strings behind c, f, r
-	Intv *fl = nullptr;      // (SPLIT) where this search's forward list goes, and how many entries of the lane's chunk are left from there
-	int fl_room = 0;
 
 	auto q = [&](int p_) -> int {
 		const int code = (qw[(p_ >> 4) << 6] >> ((p_ & 15) << 1)) & 3;
@@ -252,7 +243,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				aft = true;
 				break;
 			case PC_BWD_RES:      // backward loop body for row entry c at query position i
-				if (SPLIT) break;
 				if (r2 < (uint64_t)min_intv) {
 					if (n_curr == 0 && (n_mem_call == 0 || i + 1 < last_mem_start)) {
 						++n_mem_call; last_mem_start = i + 1;
@@ -276,7 +266,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				break;
 			case PC_BWD_N:        // start of the read or an ambiguous base: every entry of the row dies; only the first can be
 			                      // emitted (the others fail `start < last emitted start`), and the search is over
-				if (SPLIT) break;
 				if (n_curr == 0 && (n_mem_call == 0 || i + 1 < last_mem_start)) {
 					++n_mem_call; last_mem_start = i + 1;
 					if ((int)c_end - (i + 1) >= opt.min_seed_len) { ev = 2; v0 = c0; v1 = c1; v2 = c2; v_start = (uint32_t)(i + 1); v_end = c_end; }
@@ -346,7 +335,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				Intv e; e.x0 = v0; e.x1 = v1; e.x2 = v2;
 				Intv *dst = nullptr;
 				if (ev != 2) {
-					if (n_curr >= (SPLIT ? fl_room : EMA_LIST_CAP)) st |= EMA_ST_LIST_OVERFLOW;
+					if (n_curr >= EMA_LIST_CAP) st |= EMA_ST_LIST_OVERFLOW;
 					else {
 						e.info = v_end;
 						if (ev == 3 && n_curr < EMA_SEED_LDS_LIST) {
@@ -354,7 +343,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 							w.x = (uint32_t)v0; w.y = ((uint32_t)(v0 >> 32) & 0xff) | (v_end & 0xff) << 8 | (uint32_t)(v1 & 0xffff) << 16;
 							w.z = (uint32_t)v2; w.w = ((uint32_t)(v2 >> 32) & 0xff) | (uint32_t)(v1 >> 16) << 8;
 							bl[n_curr << 6] = w;
-						} else dst = SPLIT ? fl + n_curr : wl + ((size_t)((ev == 3 ? EMA_LIST_CAP : 0) + n_curr) << 6);
+						} else dst = wl + ((size_t)((ev == 3 ? EMA_LIST_CAP : 0) + n_curr) << 6);
 						if (n_curr == 0) { f0 = v0; f1 = v1; f2 = v2; f_end = v_end; f_code = (uint32_t)v1; }
 						++n_curr;
 					}
@@ -380,32 +369,14 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 						n_skip = __popcll(last_curr_size & (d < 64 ? (1ULL << d) - 1 : ~0ULL));
 						if (n_skip >= n_curr) n_skip = n_curr - 1;
 					}
-					if (SPLIT) {      // the backward phase is a task of K1b's: the list from entry n_skip on, its last entry (= c) carried along
-						const int n_ent = n_curr - n_skip, heavy = n_ent >= sp.heavy_min ? 1 : 0;
-						if (!(st & EMA_ST_LIST_OVERFLOW)) {
-							const int slot = atomicAdd(sp.n_task + (heavy ? 0 : 1), 1);
-							if (slot >= (heavy ? sp.cap_heavy : sp.cap_light)) st |= EMA_ST_LIST_OVERFLOW;
-							else {
-								uint4 *tp = reinterpret_cast<uint4 *>(sp.tasks + (heavy ? 0 : sp.cap_heavy) + slot);
-								uint4 t0, t1, t2;
-								t0.x = (uint32_t)c0; t0.y = (uint32_t)(c0 >> 32); t0.z = (uint32_t)c2; t0.w = (uint32_t)(c2 >> 32);
-								t1.x = c_code; t1.y = (uint32_t)read; t1.z = (uint32_t)(fl - sp.pool) + (uint32_t)n_skip; t1.w = (uint32_t)min_intv;
-								t2.x = (uint32_t)n_ext; t2.y = (uint32_t)n_ent | (uint32_t)sm_x << 16 | c_end << 24; t2.z = t2.w = 0;
-								tp[0] = t0; tp[1] = t1; tp[2] = t2;
-							}
-						}
-						fl += n_curr; fl_room -= n_curr; n_curr = 0;
-						pc = pass == 1 ? PC_P1_NEXT : PC_P2_NEXT;
-					} else {
-						if (pass == 1) k2 = n_skip;      // (k2 is pass 2's cursor: idle in pass 1)
-						n_prev = n_curr - n_skip; n_curr = 0; rev = 1;
-						i = sm_x - 1; j = 0;
-						pc = PC_BWD;
-					}
+					if (pass == 1) k2 = n_skip;      // (k2 is pass 2's cursor: idle in pass 1)
+					n_prev = n_curr - n_skip; n_curr = 0; rev = 1;
+					i = sm_x - 1; j = 0;
+					pc = PC_BWD;
 				}
 			}
 			// (4) row entry done: next entry (already in c), next row, or end of the search
-			if (!SPLIT && nxt && ++j == n_prev) {
+			if (nxt && ++j == n_prev) {
 				if (n_curr == 0) pc = pass == 1 ? PC_P1_NEXT : PC_P2_NEXT;
 				else {
 					n_prev = n_curr; n_curr = 0; rev = 0; j = 0; --i;
@@ -416,8 +387,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			switch (pc) {
 			case PC_DONE:
 				if (read >= 0) {
-					if (!SPLIT || sp.phase == 1) n_intv[read] = n_out;      // (pass 2 of the split form reports nothing itself: its SMEMs are its tasks')
-					status[read] = st;
+					n_intv[read] = n_out; status[read] = st;
 					if (!P3 && opt.seed_ext) opt.seed_ext[read] = n_ext;      // pass 3 follows in its own kernel: the budget runs on
 					if ((st & EMA_ST_LONG) && long_list) {      // over the extend budget: on the list K1w (one wavefront per read) works through next
 						const int at = atomicAdd(n_long, 1);
@@ -460,12 +430,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				out_base = (size_t)read * opt.intv_cap;
 				if (park_in) break;
 				st = 0; n_out = 0; pass = 1; x = 0; n_curr = 0; n_ext = 0;
-				if (SPLIT && sp.phase == 2) {      // pass 2: the read comes with pass 1's intervals, flags and extends
-					st = status[read]; n_out = old_n = n_intv[read]; n_ext = opt.seed_ext[read]; pass = 2; k2 = 0;
-					if (!st && n_ext > opt.seed_budget) st = EMA_ST_LONG;      // (its tasks' extends are in the count only now)
-					if (!st && len >= opt.min_seed_len) pc = PC_P2_NEXT;
-					break;
-				}
 				if (len >= opt.min_seed_len) pc = PC_P1_NEXT;      // mem_chain: no seeds for a read shorter than min_seed_len
 				break;
 			case PC_WT_NEXT: {    // window test: the next window [i - wlen, i) over sm_x that is not condemned yet
@@ -492,7 +456,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			}
 			case PC_P1_NEXT:      // pass 1: SMEMs from left to right
 				while (x < len && q(x) > 3) ++x;
-				if (x >= len) { if (SPLIT && sp.phase == 1) pc = PC_DONE; else { pass = 2; old_n = n_out; k2 = 0; pc = PC_P2_NEXT; } }
+				if (x >= len) { pass = 2; old_n = n_out; k2 = 0; pc = PC_P2_NEXT; }
 				else { sm_x = x; min_intv = 1; start = true; }
 				break;
 			case PC_P3_NEXT:      // pass 3: LAST-like seeds
@@ -538,11 +502,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 				if (prune) n_prev = prune;
 				last_curr_size = 0;      // (forward phase: which prefix lengths are on list F, bit c_end - sm_x; a backward row's own use comes later)
 				pc = PC_FWD;
-				if (SPLIT && fl_room < len - sm_x + 1) {      // (a forward phase pushes at most one interval per base: a fresh chunk when the rest of this one may not do)
-					const unsigned long long at = atomicAdd(sp.pool_used, (unsigned long long)EMA_SEED_CHUNK);
-					if (at + EMA_SEED_CHUNK > sp.pool_cap) { fl = nullptr; fl_room = 0; st |= EMA_ST_LIST_OVERFLOW; pc = PC_DONE; }      // the full-capacity tier redoes the pair
-					else { fl = sp.pool + at; fl_room = EMA_SEED_CHUNK; }
-				}
 			}
 			// (7) the one place that looks up the next base and posts the extend
 			if (pc == PC_WT) {      // window test: one more base to the left (the window holds no ambiguous base)
@@ -551,13 +510,13 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			}
 			else if (pc == PC_TXT) { has_req = 4; pc = PC_TXT_RES; }
 			else if (pc == PC_AB) { has_req = 5; pc = PC_AB_RES; }
-			else if (pc == PC_FWD || (!SPLIT && pc == PC_BWD) || (P3 && pc == PC_S3)) {
+			else if (pc == PC_FWD || pc == PC_BWD || (P3 && pc == PC_S3)) {
 				const int b = (i >= 0 && i < len) ? q(i) : 4;
 				if (b < 4 && ++n_ext > opt.seed_budget) { st |= EMA_ST_LONG; pc = PC_DONE; }      // too long for this tier
 				else if (b < 4 && tails && pc == PC_FWD && c2 == 1 && i - sm_x > kk) { has_req = 3; pc = PC_TSA_RES; }      // a tail begins
 				else if (b < 4) {
 					has_req = 1;
-					if (!SPLIT && pc == PC_BWD) {
+					if (pc == PC_BWD) {
 						req_c = b;
 						if (j + 1 < n_prev) {      // the row's next entry comes from the slab: list F walked from its end, or list B beyond its LDS part
 							if (rev) { ld_at = (size_t)(n_prev - 2 - j + (pass == 1 ? k2 : 0)) << 6; ld_kind = 1; }      // (+ the entries left out at the list's start)
@@ -573,7 +532,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 					}
 					pc += 1;
 				} else if (pc == PC_FWD) pc = PC_FWD_STOP;
-				else if (!SPLIT && pc == PC_BWD) pc = PC_BWD_N;
+				else if (pc == PC_BWD) pc = PC_BWD_N;
 				else { x = i + 1; pc = PC_P3_NEXT; }
 			}
 		}
@@ -601,7 +560,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			}
 			break;
 		}
-		if (SPLIT && sp.prof) { ++n_tick; n_active += __popcll(__ballot(has_req != 0)); }
 		if (prof) {
 			++n_tick; n_active += __popcll(__ballot(has_req != 0));
 			n_kind[0] += __ballot(has_req == 1) != 0; n_kind[1] += __ballot(has_req == 2) != 0; n_kind[2] += __ballot(has_req >= 3) != 0;
@@ -621,7 +579,7 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			//   table look-up (has_req 2): the entry of the result string (its interval) and, when a forward extension reaches
 			//   the table's last level, the entry of its reverse complement (the reverse-strand coordinate the next rank query
 			//   needs) -- read as 32 bytes each like the blocks (the entries are 16 or 8 bytes; the tables are padded).
-			const bool tab = has_req == 2, back = (!SPLIT && pc == PC_BWD_RES) || pc == PC_WT_RES;
+			const bool tab = has_req == 2, back = pc == PC_BWD_RES || pc == PC_WT_RES;
 			const bool wt = pc == PC_WT_RES;      // (the window test keeps its interval apart, in f1 / f2: pass 1 still needs c)
 			const uint64_t x_nb = wt ? f1 : back ? c0 : c1, x_b = back ? c1 : c0, sz = wt ? f2 : c2;
 			const uint64_t pk = x_nb - 1, pl = x_nb - 1 + sz;                    // rows whose occ4 the extend needs
@@ -712,7 +670,6 @@ ema_k_seed_t(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, const
 			has_req = 0;
 		}
 	}
-	if (SPLIT && sp.prof && lane == 0) { atomicAdd(sp.prof + 24, n_tick); atomicAdd(sp.prof + 25, n_active); atomicMax(sp.prof + 26, n_tick); }
 	if (prof) {
 		atomicAdd(prof + 30, n_pass_lane);
 		atomicAdd(prof + 32, n_by_pass[0]); atomicAdd(prof + 33, n_by_pass[1]); atomicAdd(prof + 34, n_by_pass[2]); atomicAdd(prof + 35, n_by_pass[3]);
@@ -734,29 +691,21 @@ extern "C" void ema_launch_seed(const DevIndex *ix, const DevOpts *opt, const ui
                                 int n_reads, const int *n_pairs_dev, const int *map, Intv *intv, int *n_intv, int *status,
                                 Intv *lists, int *counter, const void *park_in, const int *n_park_in, void *park_out,
                                 int *n_park_out, int park_max, int *long_list, int *n_long, int long_cap, const int *order, int n_blocks,
-                                hipStream_t stream, unsigned long long *prof, const SeedSplit *split)
+                                hipStream_t stream, unsigned long long *prof)
 {
 	// (seed_flags bit 3 with a seed_ext array: pass 3 is k_seed_p3.hip's; the diagnostic build keeps it, and its statistics, in one machine)
 	const bool split3 = (opt->seed_flags & 8) && opt->seed_ext != nullptr && !prof;
 	DevOpts o = *opt;
 	if (!split3) o.seed_ext = nullptr;
-	SeedSplit sp = SeedSplit();
-	if (split && split3) sp = *split;
 #define EMA_SEED_ARGS *ix, o, qpack, off, n_reads, n_pairs_dev, map, intv, n_intv, status, lists, counter, (const SeedPark *)park_in, n_park_in, \
-	(SeedPark *)park_out, n_park_out, park_max, long_list, n_long, long_cap, order, prof, sp
-	if (prof) hipLaunchKernelGGL((ema_k_seed_t<true, true, false>), dim3(n_blocks), dim3(256), 0, stream, EMA_SEED_ARGS);
-	else if (split && split3) hipLaunchKernelGGL((ema_k_seed_t<false, false, true>), dim3(n_blocks), dim3(256), 0, stream, EMA_SEED_ARGS);      // (no parking: park_max 0, one launch)
-	else if (split3) hipLaunchKernelGGL((ema_k_seed_t<false, false, false>), dim3(n_blocks), dim3(256), 0, stream, EMA_SEED_ARGS);
-	else hipLaunchKernelGGL((ema_k_seed_t<false, true, false>), dim3(n_blocks), dim3(256), 0, stream, EMA_SEED_ARGS);
+	(SeedPark *)park_out, n_park_out, park_max, long_list, n_long, long_cap, order, prof
+	if (prof) hipLaunchKernelGGL((ema_k_seed_t<true, true>), dim3(n_blocks), dim3(256), 0, stream, EMA_SEED_ARGS);
+	else if (split3) hipLaunchKernelGGL((ema_k_seed_t<false, false>), dim3(n_blocks), dim3(256), 0, stream, EMA_SEED_ARGS);
+	else hipLaunchKernelGGL((ema_k_seed_t<false, true>), dim3(n_blocks), dim3(256), 0, stream, EMA_SEED_ARGS);
 #undef EMA_SEED_ARGS
 }
 // does this launch of the series leave pass 3 to k_seed_p3.hip?  (the engine asks, so that both decide alike)
 extern "C" int ema_seed_splits_pass3(const DevOpts *opt, const unsigned long long *prof) { return (opt->seed_flags & 8) && opt->seed_ext != nullptr && !prof; }
-// ... and the backward phases to k_seed_bwd.hip?  (table mode, pass 3 split off, and mem_collect_intv runs pass 3 at all: K1c closes the series)
-extern "C" int ema_seed_splits_backward(const DevIndex *ix, const DevOpts *opt, const unsigned long long *prof)
-{
-	return ema_seed_splits_pass3(opt, prof) && (opt->seed_flags & 16) && ix->kmer_k > 0 && opt->max_mem_intv > 0;
-}
 
 // The order in which K1 takes a slice's reads: the ones expected to be LONG first.  A launch series is as long as its bulk plus
 // the tail of the last long reads -- a read from a repeat family needs 2,000-4,000 dependent ticks, and one that comes up when the
@@ -808,6 +757,6 @@ extern "C" void ema_launch_seed_order(const DevIndex *ix, const uint32_t *qpack,
 extern "C" int ema_seed_blocks_per_cu()
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_seed_t<false, true, false>, 256, 0) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ema_k_seed_t<false, true>, 256, 0) != hipSuccess || n < 1) n = 1;
 	return n > 8 ? 8 : n;
 }

@@ -47,9 +47,6 @@ ema_k_seed_p3(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, cons
 	const int n_tasks = ema_work_count(n_reads, n_pairs_dev, 2);
 	const int kk = ix.kmer_k;
 	const int jump = kk > 0 ? (kk < opt.min_seed_len ? kk : opt.min_seed_len) : 0;
-	// [r6] behind the split form of K1 (k_seed.hip, SPLIT; k_seed_bwd.hip) nobody has listed the reads over the budget yet -- a task may
-	// have flagged one after its K1 lane had left it -- and a read's count is complete only now: this kernel does both
-	const bool closes = (opt.seed_flags & 16) != 0 && kk > 0;
 	auto q = [&](int p_) -> int {
 		const int code = (qw[(p_ >> 4) << 6] >> ((p_ & 15) << 1)) & 3;
 		return ((nm[(p_ >> 5) << 6] >> (p_ & 31)) & 1) ? 4 : code;
@@ -91,14 +88,7 @@ ema_k_seed_p3(DevIndex ix, DevOpts opt, const uint32_t *__restrict__ qpack, cons
 				read = atomicAdd(counter, 1);
 				if (read >= n_tasks) { read = -1; exhausted = true; break; }
 				st = status[read];
-				if (closes && !st && ext[read] > opt.seed_budget) status[read] = st = EMA_ST_LONG;
-				if (st) {      // given up by K1 (budget, capacity): the full-capacity tier redoes the pair
-					if (closes && (st & EMA_ST_LONG) && long_list) {
-						const int at = atomicAdd(n_long, 1);
-						if (at < long_cap) long_list[at] = read;
-					}
-					read = -1; continue;
-				}
+				if (st) { read = -1; continue; }      // given up by K1 (budget, capacity): the full-capacity tier redoes the pair
 				const int in_read = ema_in_read(map, read);
 				len = (int)(off[in_read + 1] - off[in_read]);
 				const uint4 *pw = reinterpret_cast<const uint4 *>(qpack + (size_t)in_read * 24);

@@ -137,7 +137,7 @@ LEGACY_KNOB_VARS = ("EMA_KMER_K", "EMA_SEED_TAIL", "EMA_SEED_WTEST", "EMA_SEED_A
                     "EMA_SEED_BLOCKS_PER_CU", "EMA_SEED_ORDER", "EMA_SEED_LONG_WAVE", "EMA_FULL_SEED_LANE", "EMA_FULL_OWN_STREAM", "EMA_GRID",
                     "EMA_DEVICE_MERGE", "EMA_LANE_ALIGN", "EMA_HEAVY_CHAINS", "EMA_HEAVY_ATTEMPTS", "EMA_HEAVY_REGIONS", "EMA_SMALL_ONE_SLICE",
                     "EMA_LEAN_INTERVALS", "EMA_LEAN_REGIONS", "EMA_PHASE_PROFILE", "EMA_WATCHDOG_S", "EMA_WATCHDOG_NOMARK", "EMA_DP_TIMING",
-                    "EMA_ALIGN_PIPELINE", "EMA_VERBOSE", "EMA_EXT_LANE")
+                    "EMA_ALIGN_PIPELINE", "EMA_VERBOSE")
 
 
 _tuning = {}
@@ -408,10 +408,10 @@ class Engine:
 
     def debug_grids(self):
         """Blocks per compute unit of the kernels' launches (ema_engine_debug_grids)."""
-        a = (C.c_int32 * 6)()
+        a = (C.c_int32 * 5)()
         self._L.ema_engine_debug_grids.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         self._check(self._L.ema_engine_debug_grids(self._h, a), "debug_grids")
-        return dict(zip(("k1", "k2a", "k2b", "k3", "k4", "k1b"), (int(x) for x in a)))
+        return dict(zip(("k1", "k2a", "k2b", "k3", "k4"), (int(x) for x in a)))
 
     def debug_sa(self, first: int, n: int) -> np.ndarray:
         """Rows [first, first + n) of the suffix array in HBM (ema_engine_debug_sa)."""

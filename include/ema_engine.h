@@ -87,11 +87,10 @@ int64_t ema_engine_l_pac(const ema_engine_t *e);
 /* layout of the index in HBM: info[0] = rank superblocks, info[1] = log2 symbols per superblock, info[2] = bytes per
  * suffix-array row (4, or 8 beyond 2^32 rows), info[3] = k of the k-mer interval table (0 = none) */
 int ema_engine_index_info(const ema_engine_t *e, int32_t info[4]);
-/* development: the launch grids this engine settled on, in 256-thread blocks per compute unit -- grids[0..5] = K1 (lane-per-read
- * seeding), K2a, K2b, K3b, K4b, K1b (the seeding's backward phases as tasks).  What the tuning string's `grid=k2a:k2b:k3:k4`,
- * `seed_blocks_per_cu` and `seed_bwd_blocks_per_cu` knobs came to; no counterpart in the reference (its parallelism is OpenMP threads,
- * src/align.c:261). */
-int ema_engine_debug_grids(const ema_engine_t *e, int32_t grids[6]);
+/* development: the launch grids this engine settled on, in 256-thread blocks per compute unit -- grids[0..4] = K1 (lane-per-read
+ * seeding), K2a, K2b, K3b, K4b.  What the tuning string's `grid=k2a:k2b:k3:k4` and `seed_blocks_per_cu` knobs came to; no counterpart
+ * in the reference (its parallelism is OpenMP threads, src/align.c:261). */
+int ema_engine_debug_grids(const ema_engine_t *e, int32_t grids[5]);
 
 /* One candidate = one element of the reference's results.a (mem_alnreg_t, read through
  * interpret_align, src/bwabridge.c:313-339, and mem_approx_mapq_se_insist, src/align.c:959-984)
@@ -220,10 +219,6 @@ int ema_engine_debug_final(ema_engine_t *e, const char *read, int l_read, const 
  * {read, intervals or -1, seed occurrences, chains, seeds, regions before dedup, extension DPs, shader clocks / 16};
  * this returns and resets the log (n records of 8 ints; caller frees). */
 int ema_engine_debug_readlog(ema_engine_t *e, int32_t **log, size_t *n);
-/* Profiling aid: the counters of the lane-per-seed extension kernel (k_ext_lane.hip) when the engine was opened with the tuning knob
- * ext_lane_prof=1: three classes of task (longer query < 64, < 128, < 256 bases) x eight words -- wavefront lifetimes in shader clocks,
- * wavefronts, row-steps, lane-rows, DP cells, tasks finished, DP sides run, unused.  Summed since the previous call. */
-int ema_engine_debug_xprof(ema_engine_t *e, uint64_t out[24]);
 
 /* Region de-duplication in isolation (bwa's mem_sort_dedup_patch as mem_matesw calls it, i.e. without patching),
  * one task per wavefront: task t owns regs[t*cap .. t*cap + n_in[t]) (records laid out as in ema_engine_debug_regions);

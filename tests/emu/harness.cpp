@@ -17,12 +17,10 @@ const char *ema_tuning_get(const char *key)
 #include "k_kmer.hip"
 #include "k_seed.hip"
 #include "k_seed_p3.hip"
-#include "k_seed_bwd.hip"
 #include "k_seed_wave.hip"
 #include "k_dp_test.hip"
 #include "k_align.hip"
 #include "k_align_lane.hip"
-#include "k_ext_lane.hip"
 #include "k_pair.hip"
 #include "k_final.hip"
 #include "k_sam.hip"
@@ -98,26 +96,10 @@ static void emu_run_align(const DevIndex &di, const DevOpts &d, const uint8_t *b
 		hv.n_reads = &hn[0]; hv.n_tasks = &hn[1]; hv.reads_cap = (int)hreads.size(); hv.tasks_cap = (int)htasks.size(); hv.min_chains = heavy_chains;
 	}
 	if (heavy_chains <= 0) { hv.arena = nullptr; hv.arena_bytes = 0; hv.arena_used = nullptr; hv.reads = hv.tasks = nullptr; hv.n_reads = hv.n_tasks = nullptr; hv.reads_cap = hv.tasks_cap = 0; hv.min_chains = 1 << 30; }
-	hv.xres = nullptr; hv.xvalid = nullptr;
 	int c3 = 0;
-	// K2x: the first seed of every chain K2a handed over, one lane per seed (k_ext_lane.hip); EMU_EXT_LANE=0: all extensions by the wave kernel
-	const char *vx = getenv("EMU_EXT_LANE");
-	std::vector<ExtTask> xtasks((size_t)n_reads * 4 + 64);
-	std::vector<ExtRes> xres((size_t)n_reads * EMA_HAND_SEEDS + 1);
-	std::vector<uint8_t> xvalid((size_t)n_reads * EMA_HAND_SEEDS + 8, 0);
-	if (lane && (!vx || atoi(vx) != 0) && ema_ext_lane_supported(&d)) {
-		int xn = 0, xc[4] = {0, 0, 0, 0};
-		ema_launch_ext_plan_hand(&di, &d, hand.data(), &n_hand, n_hand, xtasks.data(), &xn, (int)xtasks.size(), xvalid.data(), nullptr);
-		ema_launch_ext_lane(&di, &d, bases, xtasks.data(), &xn, (int)xtasks.size(), xres.data(), xvalid.data(), xc, 1, nullptr, nullptr);
-		size_t nv = 0;
-		for (size_t i = 0; i < (size_t)n_hand * EMA_HAND_SEEDS; ++i) nv += xvalid[i];
-		fprintf(stderr, "emu K2x: %d seed tasks planned for %d records, %zu results computed\n", xn, n_hand, nv);
-		hv.xres = xres.data(); hv.xvalid = xvalid.data();
-	}
 	if (lane)      // K2a's hand-overs on their own build
 		ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, nullptr, &n_hand, hand.data(), slabs,
 		                 &c3, n_blocks, nullptr, nullptr, nullptr, &hv, 3);
-	hv.xres = nullptr; hv.xvalid = nullptr;
 	ema_launch_align(&di, &d, bases, off, n_reads, n_dev, map, intv, n_intv, regs, n_regs, status, lane ? todo.data() : nullptr, &n_todo, hand.data(), slabs,
 	                 &c1, n_blocks, nullptr, nullptr, nullptr, &hv, 0);
 	if (heavy_chains > 0) {
@@ -184,31 +166,7 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 		ema_launch_seed_order(&di, qp.data(), off, n_reads, emu_order.data(), cnt, 6, 16, nullptr);
 		fprintf(stderr, "emu_seed order: %d reads expected long first, %d after them\n", cnt[0], cnt[1]);
 	}
-	const char *spl = getenv("EMU_SEED_SPLIT");
-	if (!(spl && atoi(spl) == 0)) d.seed_flags |= 16;
-	if (ema_seed_splits_backward(&di, &d, nullptr)) {
-		// the engine's split series (engine.hip, run_seed): pass 1, its backward phases as K1b's tasks, pass 2, its tasks, pass 3.
-		// EMU_SEED_CHUNKS: chunks of the forward-list pool (default: plenty; small values exercise the overflow flag); EMU_SEED_HEAVY_MIN
-		const int nb = n_blocks < 0 ? -n_blocks : n_blocks;
-		SeedSplit sp = SeedSplit();
-		sp.cap_heavy = n_reads + 1; sp.cap_light = (getenv("EMU_SEED_TASKS") ? atoi(getenv("EMU_SEED_TASKS")) : 32) * n_reads + 1; sp.heavy_min = getenv("EMU_SEED_HEAVY_MIN") ? atoi(getenv("EMU_SEED_HEAVY_MIN")) : 24;
-		std::vector<SeedTask> tasks((size_t)sp.cap_heavy + sp.cap_light);
-		sp.pool_cap = (size_t)(getenv("EMU_SEED_CHUNKS") ? atoi(getenv("EMU_SEED_CHUNKS")) : nb * 256 + 64 + n_reads) * EMA_SEED_CHUNK;
-		std::vector<Intv> pool(sp.pool_cap);
-		lists.assign((size_t)nb * 256 * EMA_LIST_CAP, Intv());
-		int n_task[2]; unsigned long long used;
-		sp.tasks = tasks.data(); sp.pool = pool.data(); sp.n_task = n_task; sp.pool_used = &used;
-		for (int phase = 1; phase <= 2; ++phase) {
-			n_task[0] = n_task[1] = 0; used = 0;
-			int ctr = 0, bctr = 0;
-			sp.phase = phase;
-			ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, lists.data(), &ctr, nullptr, nullptr, nullptr, nullptr,
-			                0, nullptr, nullptr, 0, emu_order.empty() ? nullptr : emu_order.data(), nb, nullptr, nullptr, &sp);
-			fprintf(stderr, "emu_seed split phase %d: %d + %d tasks, %llu list entries handed out\n", phase, n_task[0], n_task[1], used);
-			ema_launch_seed_bwd(&di, &d, qp.data(), nullptr, &sp, (Intv *)intv, n_intv, status, lists.data(), &bctr, nb, nullptr);
-		}
-		emu_seed_p3(di, d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, nb);
-	} else {   // the engine's series of launches: fresh reads, then the machines parked by retiring waves (n_blocks < 0: no parking)
+	{   // the engine's series of launches: fresh reads, then the machines parked by retiring waves (n_blocks < 0: no parking)
 		const int nb = n_blocks < 0 ? -n_blocks : n_blocks, park_max = n_blocks < 0 ? 0 : 40, rounds = n_blocks < 0 ? 1 : 4;
 		lists.assign((size_t)nb * 256 * 2 * EMA_LIST_CAP, Intv());
 		std::vector<uint8_t> park[2];
@@ -220,7 +178,7 @@ int emu_seed(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, ui
 			if (r >= 2) n_park[out] = 0;
 			ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, lists.data(), &ctr[r],
 			                r == 0 ? nullptr : park[in].data(), &n_park[in], last ? nullptr : park[out].data(), &n_park[out],
-			                last ? 0 : park_max, nullptr, nullptr, 0, emu_order.empty() ? nullptr : emu_order.data(), nb, nullptr, nullptr, nullptr);
+			                last ? 0 : park_max, nullptr, nullptr, 0, emu_order.empty() ? nullptr : emu_order.data(), nb, nullptr, nullptr);
 			fprintf(stderr, "emu_seed round %d: parked %d\n", r, last ? 0 : n_park[out]);
 		}
 		emu_seed_p3(di, d, qp.data(), off, n_reads, nullptr, nullptr, (Intv *)intv, n_intv, status, nb);
@@ -287,7 +245,7 @@ int emu_align(void *h, const uint8_t *bases, const uint32_t *off, int n_reads, v
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
 	emu_seed_p3(di, d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, 1);
 	std::vector<uint8_t> slabs((size_t)n_blocks * 4 * ema_align_slab_bytes());
 	int counter = 0;
@@ -391,7 +349,7 @@ int emu_pipeline(void *h, const uint8_t *bases, const uint32_t *off, int n_reads
 	for (int i = 0; i < n_reads; ++i) status[i] = 0;
 	int seed_counter = 0;
 	std::vector<uint32_t> qp = pack_reads(bases, off, n_reads);
-	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, lists.data(), &seed_counter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
 	emu_seed_p3(di, d, qp.data(), off, n_reads, nullptr, nullptr, intv.data(), n_intv.data(), status, 1);
 	size_t slab = ema_align_slab_bytes();
 	if (ema_pair_slab_bytes() > slab) slab = ema_pair_slab_bytes();
@@ -441,7 +399,7 @@ static void run_tier(const DevIndex &di, const DevOpts &d, const ema_engine_opts
 	if (ema_final_slab_bytes() > slab) slab = ema_final_slab_bytes();
 	std::vector<uint8_t> slabs((size_t)4 * slab);
 	int counter[4] = {0, 0, 0, 0};
-	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr);
+	ema_launch_seed(&di, &d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), lists.data(), &counter[3], nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr);
 	emu_seed_p3(di, d, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.status.data(), 1);
 	emu_run_align(di, d, bases, qp, off, 2 * n_pairs, n_dev, map, t.intv.data(), t.n_intv.data(), t.regs.data(), t.n_regs.data(), t.status.data(),
 	              slabs.data(), 1);

@@ -91,7 +91,7 @@ def test_tuning_string_takes_lists_with_colons(tuning):
     free = e.debug_grids()
     e.close()
     assert min(free[k] for k in ("k2a", "k2b", "k3", "k4")) >= 2, free
-    tuning(grid="1,1,1,1", seed_blocks_per_cu=1)
+    tuning(grid="1,1,1,1", seed_blocks_per_cu=1)      # (the wrapper turns the commas of a list into colons)
     e = Engine(prefix)
     held = e.debug_grids()
     e.close()

@@ -410,15 +410,12 @@ def test_chr20_scale_reference_50k_pairs_against_the_oracle():
         eng.close()
 
 
-def test_lane_per_seed_extension_route(tuning):
-    """K2x (k_ext_lane.hip; tuning knob ext_lane=1: off by default, measured slower than the wave DP in round 5): the first seed of every
-    chain K2a hands over extended ONE LANE PER SEED -- ksw_extend2 cell by cell with the H/E row in LDS, left then right, the
-    known-outcome shortcuts, the exact early exit -- and mode 3 of K2b taking the regions from the result table (wave DP only where no
-    result was computed).  Same candidates as the oracle: clean and noisy reads (indels: gapped paths, z-drop, dead extensions in
-    repeats), 250 bp reads (the widest class), ambiguous bases, other scorings (asymmetric gaps; mismatches cheaper than a gap, so the
-    shortcuts do not apply), a narrow band (w = 4: max_off >= 3/4 w gives the task up to the band-doubling wave route), and tiny lean
-    capacities (the full-capacity tier runs the same route)."""
-    tuning(ext_lane=1)
+def test_extension_under_other_scorings_and_a_narrow_band():
+    """The extension DPs of K2 away from the defaults (the cases round 5 wrote for its lane-per-seed executor, K2x, which measured
+    slower than the wave DP and is gone -- DESIGN 3; they hold the wave route to the same bar): clean and noisy reads (indels: gapped
+    paths, z-drop, dead extensions in repeats), 250 bp reads, ambiguous bases, other scorings (asymmetric gaps; mismatches cheaper than a
+    gap, so the known-outcome shortcuts do not apply), a narrow band (w = 4: max_off >= 3/4 w doubles the band), and tiny lean
+    capacities (the full-capacity tier runs the same route).  Same candidates as the oracle."""
     _check("two_contigs", 900, 141, sub_rate=0.03, indel_rate=0.004)
     _check("repeats", 700, 142, sub_rate=0.02, indel_rate=0.002, chimeric=0.05)
     _check("repeats", 300, 143, len1=250, len2=250, sub_rate=0.015, indel_rate=0.003)

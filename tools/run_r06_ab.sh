@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev aid: the seeding tests, then bench.py (20 steps, kernels + delivery only) over a set of tuning strings on ONE GPU box, so that the numbers compare.
-#   gpurun --timeout 2400 -- 'bash tools/run_r06_ab.sh tag [--tests "tests/test_gpu_seed.py ..."] "" seed_split=0 seed_split=1,seed_bwd_blocks_per_cu=3 ...'   ("" = no tuning)
+#   gpurun --timeout 2400 -- 'bash tools/run_r06_ab.sh tag [--tests "tests/test_gpu_seed.py ..."] "" seed_blocks_per_cu=3 seed_park=32 ...'   ("" = no tuning)
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag

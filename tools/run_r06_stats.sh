@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev aid: rocprofv3 kernel statistics of bench.py (3 steps, kernels + delivery only) under a tuning string.
-#   gpurun --timeout 900 -- 'bash tools/run_r06_stats.sh tag "seed_split=1" ["seed_split=1,seed_bwd_blocks_per_cu=2" ...]'
+#   gpurun --timeout 900 -- 'bash tools/run_r06_stats.sh tag "" ["seed_blocks_per_cu=3" ...]'
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag

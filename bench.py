@@ -739,7 +739,7 @@ def main(argv=None):
         knobs = [k for k in ENGINE_KNOBS if k in os.environ]
         default_run = (args.pairs == 1048576 and n_slices == 3 and args.lean_seed_extends == 0 and not knobs)
         traffic, traffic_source, traffic_stale = None, None, None
-        pmc_name = next((n for n in ({0.0: ("r04_pmc_chr20.csv", "r03_pmc_chr20.csv"), 3100.0: ("r05_pmc_grch38scale.csv", "r04_pmc_grch38scale.csv", "r03_pmc_grch38scale.csv")}
+        pmc_name = next((n for n in ({0.0: ("r04_pmc_chr20.csv", "r03_pmc_chr20.csv"), 3100.0: ("r06_pmc_grch38scale.csv", "r05_pmc_grch38scale.csv", "r04_pmc_grch38scale.csv", "r03_pmc_grch38scale.csv")}
                                      .get(float(args.genome_mbp), ())) if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         tab = pmc_table(pmc_name) if (pmc_name and default_run) else None
         if tab:      # do the stored counters describe THESE kernels?  (tools/kernel_hash.py beside the table; none stored = unknown = stale)

@@ -488,14 +488,16 @@ int run_stream(ema_engine_t *e, Stream &S, ema_stream_sink sink, void *user, ema
 	// by the GPU's passes, and two readers only contend for the copy engines)
 	// [r6] ... with buckets of 262 K pairs.  With BASELINE configs[2]'s 50-100 K-pair buckets a bucket's fixed costs -- four waits for small
 	// kernels on a busy device -- are most of its 10 ms and ONE reader delivers 5.3 M pairs/s, the stream's bound: two readers there
-	// (500 buckets of 52 K pairs, files -> SAM: 5.0-5.4 -> 6.4-6.5 M pairs/s; three: the same; profiles/r06_sam_leg_ab.txt).  By the
-	// first file's size; tuning knob stream_readers overrides.
+	// (500 buckets of 52 K pairs, files -> SAM: 5.0-5.4 -> 6.4-6.5 M pairs/s; three: the same) -- PROVIDED their kernels go to the device's
+	// highest-priority queue (ingest_dev.hip): on ordinary queues two readers contend and gain nothing (profiles/r06_sam_leg_ab.txt).
+	// By the first file's size; tuning knob stream_readers overrides.
 	size_t n_readers = 1;
 	if (S.paths && !S.items.empty() && S.dev_reader) {
 		struct stat sb;
 		if (stat(S.paths[0], &sb) == 0 && sb.st_size < (off_t)48 << 20) n_readers = 2;
 	}
 	if (const char *v = ema_tuning_get("stream_readers")) n_readers = (size_t)std::max(1, std::min(4, atoi(v)));
+	if (S.trace) fprintf(stderr, "[stream] %zu reader thread(s), device reader %d\n", S.paths ? n_readers : (size_t)0, (int)S.dev_reader);
 	if (S.paths) for (size_t t = 0; t < n_readers; ++t) th.emplace_back(reader, std::ref(S), t, n_readers);
 	if (S.n_eng == 2) {
 		for (int w = 0; w < S.n_eng; ++w) th.emplace_back(worker, std::ref(S), w);

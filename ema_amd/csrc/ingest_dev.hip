@@ -177,7 +177,15 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 			memset(buf + len, 0, 64);
 		}
 		lap("pread (page-locked)");
-		ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));      // (a queue of the highest priority for these small kernels: measured, no effect -- profiles/r06_sam_leg_ab.txt)
+		{   // [r6] the reader's kernels are small and the host waits for four of them per bucket (counts, sizes): on the queue of highest
+			// priority they are dispatched ahead of the engine's long launches instead of behind them.  No effect with one reader; what
+			// lets TWO readers overlap (profiles/r06_sam_leg_ab.txt).  Tuning knob ingest_priority=0: a queue like any other
+			const char *v = ema_tuning_get("ingest_priority");
+			int least = 0, greatest = 0;
+			if (!(v && atoi(v) == 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+				ING(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+			else ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		}
 		ING(dev_pool().take(len + 64 + 512, txt, device));
 		char *d_text = (char *)txt.p;
 		unsigned long long *d_cnt = (unsigned long long *)(d_text + ((len + 64 + 255) & ~(size_t)255));      // [n_nl][select's count][irregular]

@@ -39,8 +39,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
-# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD-32 ("v_fma_f32 (wave64) 2 cyc"), 2.4 GHz
-VALU_PEAK_GINST = 256 * 4 * 0.5 * 2.4
+# VALU issue peak, MEASURED (tools/valu_issue_microbench.hip, profiles/r06_valu_issue_microbench.txt): full-rate 32-bit integer instructions
+# (v_add_u32, v_and_b32) from >= 2 wavefronts per SIMD issue at one per 2.2-2.4 clocks per SIMD: 1,073 G wave-instructions/s chip-wide at
+# 8 waves per SIMD (the guide's one-per-2-cycles figure would be 1,229 G at 2.4 GHz); ONE wavefront alone issues one per ~5 clocks, and
+# v_bcnt_u32_b32 / v_lshlrev_b64 are half rate (593 G).  K2's stream is mostly full-rate 32-bit integer work.
+VALU_PEAK_GINST = 1073.0
 CHR20_LEN = 64_444_167
 ENGINE_KNOBS = ("EMA_SEED_ROUNDS", "EMA_SEED_PARK", "EMA_SEED_BLOCKS_PER_CU", "EMA_FULL_SEED_LANE", "EMA_LANE_ALIGN", "EMA_FULL_OWN_STREAM",
                 "EMA_KMER_K", "EMA_HEAVY_CHAINS", "EMA_SEED_TAIL", "EMA_SEED_LONG_WAVE", "EMA_LEAN_SEED_EXTENDS", "EMA_GRID", "EMA_LEAN_INTERVALS",
@@ -787,7 +790,7 @@ def main(argv=None):
                             "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 5),
                             "insts_per_launch": int(per_launch), "kernel_ms": round(ms, 3),
                             "source": f"profiles/{pmc_name}: SQ_INSTS_VALU per launch (stored PMC pass) / this run's isolated K2 time; peak = "
-                                      f"256 CUs x 4 SIMDs x 1 wave64 VALU instruction per 2 cycles x 2.4 GHz"}
+                                      f"the measured chip-wide rate of full-rate 32-bit integer VALU instructions at 8 waves per SIMD (tools/valu_issue_microbench.hip, profiles/r06_valu_issue_microbench.txt; half-rate instructions -- v_bcnt, 64-bit shifts -- peak at 593 G)"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (contract)
             import resource

@@ -89,7 +89,7 @@ struct Intv { uint64_t x0, x1, x2, info; };
 #define EMA_INTV_LEAN 96      // lean tier (engine.hip).  [r4] 96 / 96 / 192: at the GRCh38 scale 0.5 % of pairs had a read over 48 intervals and 0.2 % one
 #define EMA_REG_LEAN 96       // over 48 regions (tools/gpu_capdist.py); with 96 both are under 0.04 %, and the full tier's pass is a quarter shorter
 #define EMA_CIG_LEAN 192
-#define EMA_SEED_BUDGET_LEAN 4096
+#define EMA_SEED_BUDGET_LEAN 6144      // [r6] 4,096 until K1's rank decode got cheaper: 135.1-135.3 ms per step against 136.7-137.1 (5,120: 135.9; 7,168: 135.2; 8,192: 135.7-137.7; profiles/r06_ab.txt)
 #define EMA_SEED_BUDGET_LANE 2048      // ... when the reads over it are seeded by K1w in place (engine.hip, run_seed) instead of going to the full tier
 #define EMA_MAX_READ 255      // longest read the engine accepts (reference MAX_READ_LEN is 200, include/align.h:61)
 

@@ -53,7 +53,7 @@ typedef struct {
 	int full_tier_pairs;        /* pairs per batch the full-capacity tier can redo (0 = default: batch/16 within 4096..65536) */
 	int lean_intervals, lean_regions, lean_cigar_ops;   /* per-read capacities of the lean tier (0 = defaults 48, 48, 192) */
 	int mapq_coef_len, mapq_coef_fac;   /* bwa's mapQ_coef_len = 50 and mapQ_coef_fac = (int)log(50) = 3, read by the mapq formula (reference src/align.c:969-973) */
-	int lean_seed_extends;      /* lean tier: FM-index extends one read's seeding may take (0 = default 4096, < 0 = no limit) */
+	int lean_seed_extends;      /* lean tier: FM-index extends one read's seeding may take (0 = default 6144, < 0 = no limit) */
 } ema_engine_opts;
 
 void ema_engine_opts_default(ema_engine_opts *o);

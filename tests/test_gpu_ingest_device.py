@@ -74,3 +74,40 @@ def test_what_the_kernels_do_not_take_goes_to_the_host_reader(tmp_path):
     with pytest.raises(ingest.BucketError) as e:
         ingest.read_bucket_device(str(tmp_path / "nope.fq"))
     assert e.value.code == ingest.EMA_EIO
+
+
+def test_staging_a_device_bucket_checks_the_read_lengths_on_the_device(tmp_path):
+    """ema_bucket_read_device accepts reads of up to 4,096 bases, the packed reads behind ema_k_stage_reads hold
+    EMA_MAX_READ (255).  ema_engine_stage_async_dev is a public entry point: whoever calls it, a device-resident bucket with a longer
+    read must be refused (EMA_ELIMIT, nothing staged) by a check on the device-resident offsets -- not by a comment about the caller."""
+    import ctypes as C
+    from common import small_ref
+    from ema_amd.engine import Engine
+    L = ingest._lib()
+    L.ema_bucket_read_device.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(ingest._Bucket))]
+    L.ema_engine_stage_async_dev.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(ingest._Bucket)), C.c_size_t]
+    L.ema_engine_strerror.restype = C.c_char_p
+    L.ema_engine_strerror.argtypes = [C.c_void_p]
+    prefix, _ = small_ref("two_contigs")
+    eng = Engine(prefix)
+    try:
+        for long_read, want in ((0, 0), (300, -4)):      # -4 = EMA_ELIMIT
+            rng = random.Random(21)
+            lines = []
+            for i in range(40):
+                l1 = long_read if (long_read and i == 17) else 100
+                r1 = "".join(rng.choice("ACGT") for _ in range(l1))
+                r2 = "".join(rng.choice("ACGT") for _ in range(120))
+                lines.append("ACGTACGTACGTAC%s s%d %s %s %s %s\n" % ("GT" if i % 2 else "CA", i, r1, "F" * l1, r2, "F" * 120))
+            p = str(tmp_path / ("b%d.fq" % long_read))
+            open(p, "w").write("".join(lines))
+            bk = C.POINTER(ingest._Bucket)()
+            assert L.ema_bucket_read_device(p.encode(), 16, 0, 4096, 0, C.byref(bk)) == 0 and bk.contents.dev
+            arr = (C.POINTER(ingest._Bucket) * 1)(bk)
+            rc = L.ema_engine_stage_async_dev(eng._h, 1, arr, 1)
+            assert rc == want, (rc, L.ema_engine_strerror(eng._h))
+            if want:
+                assert b"EMA_MAX_READ" in L.ema_engine_strerror(eng._h)
+            L.ema_bucket_free(bk)
+    finally:
+        eng.close()

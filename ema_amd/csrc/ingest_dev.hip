@@ -39,6 +39,7 @@
 #include "host_pool.h"
 #include "ingest_kernels.hpp"
 #include <chrono>
+#include <time.h>
 
 const char *ema_tuning_get(const char *key);      // engine.hip
 
@@ -142,11 +143,14 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 	const size_t len = (size_t)sb.st_size;
 	const bool prof = ema_tuning_get("ingest_prof") != nullptr;      // phase times on stderr (tools/ingest_rate.py --device)
 	auto t_last = std::chrono::steady_clock::now();
-	auto lap = [&](const char *what) {
+	auto cpu_now = [] { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6; };
+	double c_last = prof ? cpu_now() : 0.0;
+	auto lap = [&](const char *what) {      // wall milliseconds of the phase, and the CPU milliseconds THIS thread spent in it (the pool's threads not counted)
 		if (!prof) return;
 		const auto t = std::chrono::steady_clock::now();
-		fprintf(stderr, "[ingest_dev] %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
-		t_last = t;
+		const double c = cpu_now();
+		fprintf(stderr, "[ingest_dev] %-22s %7.2f ms wall %7.2f ms cpu\n", what, std::chrono::duration<double, std::milli>(t - t_last).count(), c - c_last);
+		t_last = t; c_last = c;
 	};
 	Block pin, txt, work, keep;
 	ema_bucket *o = nullptr;

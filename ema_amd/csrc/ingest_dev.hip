@@ -186,9 +186,9 @@ int ema_bucket_read_device(const char *path, int bc_len, int is_haplotag, int ma
 			// lets TWO readers overlap (profiles/r06_sam_leg_ab.txt).  Tuning knob ingest_priority=0: a queue like any other
 			const char *v = ema_tuning_get("ingest_priority");
 			int least = 0, greatest = 0;
-			if (!(v && atoi(v) == 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-				ING(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
-			else ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+			if (!(v && atoi(v) == 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+			    hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) { st = nullptr; (void)hipGetLastError(); }      // (no such queue: an ordinary one)
+			if (!st) ING(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 		}
 		ING(dev_pool().take(len + 64 + 512, txt, device));
 		char *d_text = (char *)txt.p;
